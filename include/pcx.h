@@ -1,0 +1,180 @@
+/*
+ * pcx.h -- C ABI of libpcx_hip.so: the MI355X (gfx950) device path behind the
+ * PothosComms streaming-DSP blocks.
+ *
+ * The reference has no FFI: each block is a C++ class whose work() runs the
+ * arithmetic inline.  This header is the boundary a Pothos
+ * plugin TU (pothos_plugin/) calls from inside
+ * work()/setters instead of those loops.  One entry point per reference
+ * loop / setter it replaces, cited as <file>:<line> of the reference tree.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ types, no exceptions; every call
+ *     returns PCX_OK (0) or a negative pcx_status and records a message
+ *     retrievable with pcx_last_error() (thread-local).
+ *   - scalar types are pcx_scalar codes; a complex stream is interleaved
+ *     (re, im) pairs of that scalar -- the memory layout of std::complex<T>.
+ *   - "elements" are stream elements (one complex pair = one element).
+ *   - *_dev variants take DEVICE pointers and a hipStream_t (as void*) and
+ *     only enqueue work; the plain variants take HOST pointers (the
+ *     BufferChunk memory of a Pothos port), stage through a device workspace
+ *     owned by the handle and return after the result is in `out`.
+ *   - handles are not thread-safe; one handle per block instance, exactly as
+ *     Pothos serialises work() and setters on one actor.
+ *   - there is NO CPU fallback: a type/size the device path does not implement
+ *     returns PCX_ERR_UNSUPPORTED.
+ */
+#ifndef PCX_H
+#define PCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCX_API __attribute__((visibility("default")))
+
+typedef enum pcx_scalar {
+    PCX_F64 = 0, PCX_F32 = 1, PCX_I64 = 2, PCX_I32 = 3, PCX_I16 = 4, PCX_I8 = 5
+} pcx_scalar;
+
+typedef enum pcx_status {
+    PCX_OK = 0,
+    PCX_ERR_ARG = -1,          /* Pothos::InvalidArgumentException territory */
+    PCX_ERR_UNSUPPORTED = -2,  /* valid in the reference, not implemented on device */
+    PCX_ERR_HIP = -3,          /* a HIP runtime call failed */
+    PCX_ERR_STATE = -4         /* call sequence error (e.g. process before taps upload) */
+} pcx_status;
+
+PCX_API const char *pcx_last_error(void);
+PCX_API const char *pcx_version(void);
+
+/* ---- device plumbing (for hosts without their own HIP runtime binding) ---- */
+PCX_API int pcx_device_count(int *count);
+PCX_API int pcx_set_device(int ordinal);
+PCX_API int pcx_dev_alloc(void **dptr, size_t bytes);
+PCX_API int pcx_dev_free(void *dptr);
+PCX_API int pcx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+PCX_API int pcx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+PCX_API int pcx_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+PCX_API int pcx_stream_sync(void *stream);
+/* synthetic stream generator on the device: the same splitmix64 counter hash as
+ * the oracle's orc_fill_uniform_f32 (uniform [-1,1), bit-identical values) */
+PCX_API int pcx_fill_uniform_f32_dev(float *dst_dev, size_t n_scalars, uint64_t seed, uint64_t offset, void *stream);
+
+/* ===================================================================== *
+ *  /comms/fir_filter      filter/FIRFilter.cpp
+ * ===================================================================== */
+typedef struct pcx_fir pcx_fir;
+
+typedef enum pcx_fir_algo {
+    PCX_FIR_AUTO = 0,    /* OLS_FFT when it applies and pays, else DIRECT */
+    PCX_FIR_DIRECT = 1,  /* time-domain LDS-tiled dot product (FMA) */
+    PCX_FIR_OLS_FFT = 2, /* frequency-domain overlap-save on the Stockham kernel */
+    PCX_FIR_EXACT = 3    /* time-domain, reference accumulation order, no FMA:
+                            bit-identical to FIRFilter.cpp:295-300 for float types */
+} pcx_fir_algo;
+
+/* FIRFilterFactory(dtype, tapsType), FIRFilter.cpp:369-384.
+ * complex_taps = 1 is tapsType "COMPLEX" (complex element types only). */
+PCX_API int pcx_fir_create(int scalar, int is_complex, int complex_taps, pcx_fir **out);
+PCX_API int pcx_fir_destroy(pcx_fir *h);
+/* setTaps, FIRFilter.cpp:138-144 + updateInternals :327-354.  `taps` holds ntaps
+ * doubles (REAL) or ntaps (re,im) double pairs (COMPLEX).  ntaps == 0 -> PCX_ERR_ARG. */
+PCX_API int pcx_fir_set_taps(pcx_fir *h, const double *taps, size_t ntaps);
+/* setDecimation / setInterpolation, FIRFilter.cpp:151-168.  0 -> PCX_ERR_ARG. */
+PCX_API int pcx_fir_set_decimation(pcx_fir *h, size_t decim);
+PCX_API int pcx_fir_set_interpolation(pcx_fir *h, size_t interp);
+PCX_API int pcx_fir_set_algo(pcx_fir *h, int algo);
+/* K = ceil(ntaps/L) (FIRFilter.cpp:335) and _inputRequire = M+K-1 (:353) */
+PCX_API int pcx_fir_get_geometry(const pcx_fir *h, size_t *K, size_t *input_require);
+/* which algorithm the last process call ran (pcx_fir_algo) */
+PCX_API int pcx_fir_last_algo(const pcx_fir *h);
+/*
+ * The filter loop, FIRFilter.cpp:278-308.  `in` points at the front of the input
+ * buffer: in_elems elements of which the first K-1 are history (the reference's
+ * `x = in + (K-1)`, :281).  out_cap = room in the output buffer, in elements.
+ *   N         = min((in_elems-(K-1))/M, out_cap/L)*M          (:278)
+ *   *consumed = N                                              (:307)
+ *   *produced = (N/M)*L                                        (:308)
+ * Burst flush (:263-272) is the caller's job: it passes the zero-padded buffer.
+ */
+PCX_API int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size_t out_cap,
+                            size_t *consumed, size_t *produced);
+PCX_API int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                size_t *consumed, size_t *produced, void *stream);
+
+/* ===================================================================== *
+ *  /comms/fft             fft/FFT.cpp, fft/FFTAux.h, fft/kissfft.hh, fft/kiss_fft.c
+ * ===================================================================== */
+typedef struct pcx_fft pcx_fft;
+/* FFTFactory(dtype, numBins, inverse), FFT.cpp:83-93: scalar in {F64, F32, I16}
+ * (always complex).  Forward = exp(-j..), inverse = exp(+j..), float paths
+ * unscaled (kissfft.hh:81-161), int16 path scaled by 1/radix per stage
+ * (kiss_fft.c:61, _kiss_fft_guts.h:73-78). */
+PCX_API int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out);
+PCX_API int pcx_fft_destroy(pcx_fft *h);
+/* FFTAux::transform over `nframes` back-to-back frames (FFT::work does one,
+ * FFT.cpp:66-71; a device caller batches whole frames per call). */
+PCX_API int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes);
+PCX_API int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream);
+
+/* ===================================================================== *
+ *  /comms/freq_demod      demod/FreqDemod.cpp
+ * ===================================================================== */
+typedef struct pcx_freqdemod pcx_freqdemod;
+/* FreqDemodFactory(dtype), FreqDemod.cpp:80-93: complex<scalar> in, scalar out */
+PCX_API int pcx_freqdemod_create(int scalar, pcx_freqdemod **out);
+PCX_API int pcx_freqdemod_destroy(pcx_freqdemod *h);
+/* activate(): _prev = 0, FreqDemod.cpp:44-47 */
+PCX_API int pcx_freqdemod_reset(pcx_freqdemod *h);
+/* the loop FreqDemod.cpp:60-67: out[i] = angle(in[i]*prev); prev = conj(in[i]);
+ * prev is carried across calls inside the handle (device side) */
+PCX_API int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n);
+PCX_API int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_dev, size_t n, void *stream);
+
+/* ===================================================================== *
+ *  /comms/rotate, /comms/scale, /comms/abs, /comms/conjugate   (math/)
+ *  Stateless maps; n counts stream elements times dtype.dimension().
+ * ===================================================================== */
+/* arrayRotate, Rotate.cpp:15-23.  (phasor_re, phasor_im) is std::polar(1.0, phase)
+ * BEFORE floatToQ (Rotate.cpp:74); pass (0,0) for a block whose setPhase was never
+ * called (value-initialised _phasor).  Complex element types only (:143-157). */
+PCX_API int pcx_rotate(int scalar, double phasor_re, double phasor_im, const void *in, void *out, size_t n);
+PCX_API int pcx_rotate_dev(int scalar, double phasor_re, double phasor_im, const void *in_dev, void *out_dev, size_t n, void *stream);
+/* arrayScale, Scale.cpp:15-23 with factorScaled = floatToQ(factor) (:70-74); real factor */
+PCX_API int pcx_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n);
+PCX_API int pcx_scale_dev(int scalar, int is_complex, double factor, const void *in_dev, void *out_dev, size_t n, void *stream);
+/* Abs.cpp:40-43 via getAbs, FxptHelpers.hpp:36-49; out is the real scalar type */
+PCX_API int pcx_abs(int scalar, int is_complex, const void *in, void *out, size_t n);
+PCX_API int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *out_dev, size_t n, void *stream);
+/* Conjugate.cpp:36-39; complex element types only */
+PCX_API int pcx_conj(int scalar, const void *in, void *out, size_t n);
+PCX_API int pcx_conj_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream);
+
+/* ===================================================================== *
+ *  Fused FM-demod chain  Rotate -> FIR -> FreqDemod in one kernel
+ *  (BASELINE.json configs[4]); equals the three blocks above connected in a
+ *  topology: Rotate.cpp:15-23 -> FIRFilter.cpp:286-302 (M=L=1) -> FreqDemod.cpp:60-67
+ *  complex_float32 in, float32 out.
+ * ===================================================================== */
+typedef struct pcx_fmchain pcx_fmchain;
+PCX_API int pcx_fmchain_create(pcx_fmchain **out);
+PCX_API int pcx_fmchain_destroy(pcx_fmchain *h);
+PCX_API int pcx_fmchain_set_phase(pcx_fmchain *h, double phase);
+/* REAL (complex_taps=0) or COMPLEX taps, as pcx_fir_set_taps */
+PCX_API int pcx_fmchain_set_taps(pcx_fmchain *h, const double *taps, size_t ntaps, int complex_taps);
+PCX_API int pcx_fmchain_reset(pcx_fmchain *h);
+/* in_elems input samples with K-1 history in front -> in_elems-(K-1) demodulated
+ * outputs; FreqDemod's prev is carried in the handle */
+PCX_API int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *out, size_t out_cap,
+                                size_t *consumed, size_t *produced);
+PCX_API int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                    size_t *consumed, size_t *produced, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCX_H */

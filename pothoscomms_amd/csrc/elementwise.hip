@@ -1,0 +1,411 @@
+// elementwise.hip -- HBM-bound maps for /comms/{rotate,scale,abs,conjugate,freq_demod}
+//
+// One grid-stride kernel template: each lane moves 16-byte vectors (the coalescing
+// sweet spot on gfx950: 1 KiB per wave-instruction), UNROLL vectors in flight per
+// lane, <= 2048 blocks of 256 threads.  No LDS, no MFMA: these ops have no reuse
+// and ~1 flop/byte, so the only roof is HBM.
+//
+// This TU is compiled with -ffp-contract=off: the reference computes
+// (a*c - b*d, a*d + b*c) with every product and sum rounded separately
+// (std::complex operator* on baseline x86-64), and keeping the same unfused
+// sequence makes Rotate/Scale/Conjugate/Abs(float) BIT-IDENTICAL to it.
+#include "pcx_internal.hpp"
+
+#include <type_traits>
+
+namespace pcx {
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+
+// IN_PER / OUT_PER scalars per stream item; ITEMS items per lane-vector
+template <typename In, typename Out, int IN_PER, int OUT_PER, int ITEMS, typename Op>
+__global__ __launch_bounds__(kBlock) void map_kernel(const In *__restrict__ in, Out *__restrict__ out, size_t nitems, Op op)
+{
+    using VIn = Vec<In, IN_PER * ITEMS>;
+    using VOut = Vec<Out, OUT_PER * ITEMS>;
+    const size_t nvec = nitems / ITEMS;
+    const size_t chunk = (size_t)kBlock * kUnroll;
+    const size_t nchunks = nvec / chunk;
+    const VIn *vin = reinterpret_cast<const VIn *>(in);
+    VOut *vout = reinterpret_cast<VOut *>(out);
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t base = c * chunk + threadIdx.x;
+        VIn a[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) a[u] = vin[base + (size_t)u * kBlock];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            VOut b;
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) op(&a[u].v[k * IN_PER], &b.v[k * OUT_PER]);
+            vout[base + (size_t)u * kBlock] = b;
+        }
+    }
+    // remaining whole vectors, then the scalar tail
+    const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x, gstride = (size_t)gridDim.x * kBlock;
+    for (size_t i = nchunks * chunk + gtid; i < nvec; i += gstride) {
+        VIn a = vin[i];
+        VOut b;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) op(&a.v[k * IN_PER], &b.v[k * OUT_PER]);
+        vout[i] = b;
+    }
+    for (size_t i = nvec * ITEMS + gtid; i < nitems; i += gstride) op(in + i * IN_PER, out + i * OUT_PER);
+}
+
+template <typename In, typename Out, int IN_PER, int OUT_PER, typename Op>
+static int launch_map(const void *in, void *out, size_t nitems, Op op, hipStream_t st)
+{
+    if (nitems == 0) return PCX_OK;
+    constexpr int item_bytes = (int)sizeof(In) * IN_PER;
+    constexpr int ITEMS = item_bytes >= 16 ? 1 : 16 / item_bytes;
+    const In *pin = static_cast<const In *>(in);
+    Out *pout = static_cast<Out *>(out);
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) % (sizeof(In) * IN_PER * ITEMS) == 0) &&
+                         (reinterpret_cast<uintptr_t>(out) % (sizeof(Out) * OUT_PER * ITEMS) == 0);
+    if (aligned && ITEMS > 1) {
+        const unsigned grid = stream_grid(nitems / ITEMS / kUnroll + 1, kBlock);
+        hipLaunchKernelGGL((map_kernel<In, Out, IN_PER, OUT_PER, ITEMS, Op>), dim3(grid), dim3(kBlock), 0, st, pin, pout, nitems, op);
+    } else {
+        const unsigned grid = stream_grid(nitems / kUnroll + 1, kBlock);
+        hipLaunchKernelGGL((map_kernel<In, Out, IN_PER, OUT_PER, 1, Op>), dim3(grid), dim3(kBlock), 0, st, pin, pout, nitems, op);
+    }
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+// ---- Q-format integer helpers (device): exact ring arithmetic modulo 2^bits(Q) ----
+template <typename Q>
+struct QCompute {
+    using type = typename std::conditional<(sizeof(Q) < 4), uint32_t, typename std::make_unsigned<Q>::type>::type;
+};
+template <typename S, typename Q>
+__device__ inline S from_q_dev(typename QCompute<Q>::type v)
+{
+    const Q q = (Q)v;                       // wrap to the Q width
+    return (S)(q >> (4 * sizeof(Q)));       // fromQ: arithmetic >> half the Q bits, then truncate
+}
+
+// ---- Rotate  (math/Rotate.cpp:15-23) ----
+template <typename T>
+struct RotateF {
+    T pr, pi;
+    __device__ void operator()(const T *x, T *y) const
+    {
+        const T ac = pr * x[0], bd = pi * x[1], ad = pr * x[1], bc = pi * x[0];
+        y[0] = ac - bd;
+        y[1] = ad + bc;
+    }
+};
+template <typename S, typename Q>
+struct RotateI {
+    using C = typename QCompute<Q>::type;
+    C pr, pi;
+    __device__ void operator()(const S *x, S *y) const
+    {
+        const C c = (C)(Q)x[0], d = (C)(Q)x[1];
+        y[0] = from_q_dev<S, Q>(pr * c - pi * d);
+        y[1] = from_q_dev<S, Q>(pr * d + pi * c);
+    }
+};
+int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n, hipStream_t st)
+{
+    switch (scalar) {
+    case PCX_F32: return launch_map<float, float, 2, 2>(in, out, n, RotateF<float>{(float)pr, (float)pi}, st);
+    case PCX_F64: return launch_map<double, double, 2, 2>(in, out, n, RotateF<double>{pr, pi}, st);
+    case PCX_I64: return launch_map<int64_t, int64_t, 2, 2>(in, out, n, RotateI<int64_t, int64_t>{(uint64_t)float_to_q(pr, 64), (uint64_t)float_to_q(pi, 64)}, st);
+    case PCX_I32: return launch_map<int32_t, int32_t, 2, 2>(in, out, n, RotateI<int32_t, int64_t>{(uint64_t)float_to_q(pr, 64), (uint64_t)float_to_q(pi, 64)}, st);
+    case PCX_I16: return launch_map<int16_t, int16_t, 2, 2>(in, out, n, RotateI<int16_t, int32_t>{(uint32_t)float_to_q(pr, 32), (uint32_t)float_to_q(pi, 32)}, st);
+    case PCX_I8: return launch_map<int8_t, int8_t, 2, 2>(in, out, n, RotateI<int8_t, int16_t>{(uint32_t)float_to_q(pr, 16), (uint32_t)float_to_q(pi, 16)}, st);
+    }
+    set_error("rotate: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+
+// ---- Scale  (math/Scale.cpp:15-23); real factor => componentwise on scalars ----
+template <typename T>
+struct ScaleF {
+    T f;
+    __device__ void operator()(const T *x, T *y) const { y[0] = x[0] * f; }
+};
+template <typename S, typename Q>
+struct ScaleI {
+    using C = typename QCompute<Q>::type;
+    C f;
+    __device__ void operator()(const S *x, S *y) const { y[0] = from_q_dev<S, Q>(f * (C)(Q)x[0]); }
+};
+int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st)
+{
+    const size_t ns = n * (is_complex ? 2 : 1);
+    switch (scalar) {
+    case PCX_F32: return launch_map<float, float, 1, 1>(in, out, ns, ScaleF<float>{(float)factor}, st);
+    case PCX_F64: return launch_map<double, double, 1, 1>(in, out, ns, ScaleF<double>{factor}, st);
+    case PCX_I64: return launch_map<int64_t, int64_t, 1, 1>(in, out, ns, ScaleI<int64_t, int64_t>{(uint64_t)float_to_q(factor, 64)}, st);
+    case PCX_I32: return launch_map<int32_t, int32_t, 1, 1>(in, out, ns, ScaleI<int32_t, int64_t>{(uint64_t)float_to_q(factor, 64)}, st);
+    case PCX_I16: return launch_map<int16_t, int16_t, 1, 1>(in, out, ns, ScaleI<int16_t, int32_t>{(uint32_t)float_to_q(factor, 32)}, st);
+    case PCX_I8: return launch_map<int8_t, int8_t, 1, 1>(in, out, ns, ScaleI<int8_t, int16_t>{(uint32_t)float_to_q(factor, 16)}, st);
+    }
+    set_error("scale: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+
+// ---- Conjugate  (math/Conjugate.cpp:36-39) ----
+template <typename T>
+struct ConjOp {
+    __device__ void operator()(const T *x, T *y) const
+    {
+        y[0] = x[0];
+        if constexpr (std::is_floating_point<T>::value) y[1] = -x[1];
+        else y[1] = (T)((typename std::make_unsigned<T>::type)0 - (typename std::make_unsigned<T>::type)x[1]);
+    }
+};
+int launch_conj(int scalar, const void *in, void *out, size_t n, hipStream_t st)
+{
+    switch (scalar) {
+    case PCX_F32: return launch_map<float, float, 2, 2>(in, out, n, ConjOp<float>{}, st);
+    case PCX_F64: return launch_map<double, double, 2, 2>(in, out, n, ConjOp<double>{}, st);
+    case PCX_I64: return launch_map<int64_t, int64_t, 2, 2>(in, out, n, ConjOp<int64_t>{}, st);
+    case PCX_I32: return launch_map<int32_t, int32_t, 2, 2>(in, out, n, ConjOp<int32_t>{}, st);
+    case PCX_I16: return launch_map<int16_t, int16_t, 2, 2>(in, out, n, ConjOp<int16_t>{}, st);
+    case PCX_I8: return launch_map<int8_t, int8_t, 2, 2>(in, out, n, ConjOp<int8_t>{}, st);
+    }
+    set_error("conjugate: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+
+// ---- Abs  (math/Abs.cpp:40-43, FxptHelpers.hpp:36-49) ----
+struct AbsRealF32 { __device__ void operator()(const float *x, float *y) const { y[0] = fabsf(x[0]); } };
+struct AbsRealF64 { __device__ void operator()(const double *x, double *y) const { y[0] = fabs(x[0]); } };
+// std::abs(std::complex<float>) = hypotf.  glibc 2.35's hypotf is
+// (float)sqrt((double)x*x + (double)y*y) with inf/nan special cases; fp64 sqrt on
+// the device is correctly rounded, so this reproduces it bit for bit.
+struct AbsCplxF32 {
+    __device__ void operator()(const float *x, float *y) const
+    {
+        const float a = x[0], b = x[1];
+        if (isinf(a) || isinf(b)) { y[0] = INFINITY; return; }
+        const double da = (double)a, db = (double)b;
+        y[0] = (float)sqrt(da * da + db * db);
+    }
+};
+struct AbsCplxF64 { __device__ void operator()(const double *x, double *y) const { y[0] = hypot(x[0], x[1]); } };
+template <typename S>
+struct AbsRealI {
+    __device__ void operator()(const S *x, S *y) const
+    {
+        using U = typename std::make_unsigned<S>::type;
+        const S v = x[0];
+        y[0] = v < 0 ? (S)((U)0 - (U)v) : v;
+    }
+};
+// complex integer: mag2 in the promoted type (int for int8/int16/int32 products,
+// int64 for int64), OutType(std::sqrt(float(mag2))); float->int as cvttss2si
+template <typename S>
+struct AbsCplxI {
+    __device__ void operator()(const S *x, S *y) const
+    {
+        using P = typename std::conditional<(sizeof(S) == 8), int64_t, int32_t>::type;
+        using UP = typename std::make_unsigned<P>::type;
+        const UP re = (UP)(P)x[0], im = (UP)(P)x[1];
+        const P mag2 = (P)(re * re + im * im);
+        const float r = sqrtf((float)mag2);
+        P o;
+        if (r != r) o = (sizeof(S) == 8) ? (P)INT64_MIN : (P)INT32_MIN;
+        else o = (P)r;
+        y[0] = (S)o;
+    }
+};
+int launch_abs(int scalar, int is_complex, const void *in, void *out, size_t n, hipStream_t st)
+{
+    if (!is_complex) {
+        switch (scalar) {
+        case PCX_F32: return launch_map<float, float, 1, 1>(in, out, n, AbsRealF32{}, st);
+        case PCX_F64: return launch_map<double, double, 1, 1>(in, out, n, AbsRealF64{}, st);
+        case PCX_I64: return launch_map<int64_t, int64_t, 1, 1>(in, out, n, AbsRealI<int64_t>{}, st);
+        case PCX_I32: return launch_map<int32_t, int32_t, 1, 1>(in, out, n, AbsRealI<int32_t>{}, st);
+        case PCX_I16: return launch_map<int16_t, int16_t, 1, 1>(in, out, n, AbsRealI<int16_t>{}, st);
+        case PCX_I8: return launch_map<int8_t, int8_t, 1, 1>(in, out, n, AbsRealI<int8_t>{}, st);
+        }
+    } else {
+        switch (scalar) {
+        case PCX_F32: return launch_map<float, float, 2, 1>(in, out, n, AbsCplxF32{}, st);
+        case PCX_F64: return launch_map<double, double, 2, 1>(in, out, n, AbsCplxF64{}, st);
+        case PCX_I64: return launch_map<int64_t, int64_t, 2, 1>(in, out, n, AbsCplxI<int64_t>{}, st);
+        case PCX_I32: return launch_map<int32_t, int32_t, 2, 1>(in, out, n, AbsCplxI<int32_t>{}, st);
+        case PCX_I16: return launch_map<int16_t, int16_t, 2, 1>(in, out, n, AbsCplxI<int16_t>{}, st);
+        case PCX_I8: return launch_map<int8_t, int8_t, 2, 1>(in, out, n, AbsCplxI<int8_t>{}, st);
+        }
+    }
+    set_error("abs: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+
+// ---- fxpt_atan2 on the device (functions/fxpt_atan2.cpp:36-138), integer-exact ----
+__device__ inline int16_t d_s16_nabs(int16_t j)
+{
+    const int16_t negSign = (int16_t)~(j >> 15);
+    return (int16_t)((j ^ negSign) - negSign);
+}
+__device__ inline int16_t d_q15_mul(int16_t j, int16_t k)
+{
+    const int32_t im = j * (int32_t)k;
+    return (int16_t)((im + ((im & 0x7FFF) == 0x4000 ? 0 : 0x4000)) >> 15);
+}
+__device__ inline int16_t d_q15_div(int16_t numer, int16_t denom)
+{
+    return (int16_t)(((int32_t)((uint32_t)(int32_t)numer << 15)) / denom);
+}
+__device__ inline uint16_t d_fxpt_atan2(int16_t y, int16_t x)
+{
+    // q15_from_double(0.273/pi) = 2847, q15_from_double(0.25 + 0.273/pi) = 11039
+    if (x == y) return y > 0 ? 8192 : (y < 0 ? 40960 : 0);
+    const int16_t nabs_y = d_s16_nabs(y), nabs_x = d_s16_nabs(x);
+    if (nabs_x < nabs_y) {
+        const int16_t q = d_q15_div(y, x);
+        const int16_t corr = d_q15_mul(2847, d_s16_nabs(q));
+        const int16_t un = d_q15_mul((int16_t)(11039 + corr), q);
+        return x > 0 ? (uint16_t)un : (uint16_t)(32768 + un);
+    } else {
+        const int16_t q = d_q15_div(x, y);
+        const int16_t corr = d_q15_mul(2847, d_s16_nabs(q));
+        const int16_t un = d_q15_mul((int16_t)(11039 + corr), q);
+        return y > 0 ? (uint16_t)(16384 - un) : (uint16_t)(49152 - un);
+    }
+}
+
+// ---- FreqDemod  (demod/FreqDemod.cpp:60-67) ----
+// out[i] = angle(in[i] * _prev), _prev = conj(in[i-1]); for i = 0 _prev comes from
+// *prev_in (carried from the previous call; zero after activate()); *prev_out gets the
+// new _prev.  prev_in/prev_out are distinct device slots (ping-pong), so no lane of this
+// launch can observe the update.  Each lane handles ITEMS consecutive
+// samples from one 16-byte load plus one extra neighbour load (an L1/L2 hit).
+// (a,b) = in[i], (c,d) = _prev = conj(in[i-1]) (value-initialised zero after activate)
+template <typename T>
+__device__ inline T demod_one(T a, T b, T c, T d);
+template <>
+__device__ inline float demod_one<float>(float a, float b, float c, float d)
+{
+    // in_i * _prev, unfused: re = a*c - b*d, im = a*d + b*c
+    const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    return atan2f(ad + bc, ac - bd);
+}
+template <>
+__device__ inline double demod_one<double>(double a, double b, double c, double d)
+{
+    const double ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    return atan2(ad + bc, ac - bd);
+}
+template <typename T>
+__device__ inline T conj_im(T d)
+{
+    if constexpr (std::is_floating_point<T>::value) return -d;
+    else return (T)((typename std::make_unsigned<T>::type)0 - (typename std::make_unsigned<T>::type)d);
+}
+template <typename S>
+__device__ inline S demod_one_int(S a, S b, S c, S d)
+{
+    // complex<intN> product wraps modulo 2^N; getAngle truncates both parts to int16
+    using U = typename std::conditional<(sizeof(S) == 8), uint64_t, uint32_t>::type;
+    const U ua = (U)a, ub = (U)b, uc = (U)c, ud = (U)d;
+    const S re = (S)(ua * uc - ub * ud), im = (S)(ua * ud + ub * uc);
+    return (S)d_fxpt_atan2((int16_t)im, (int16_t)re);
+}
+template <>
+__device__ inline int64_t demod_one<int64_t>(int64_t a, int64_t b, int64_t c, int64_t d) { return demod_one_int(a, b, c, d); }
+template <>
+__device__ inline int32_t demod_one<int32_t>(int32_t a, int32_t b, int32_t c, int32_t d) { return demod_one_int(a, b, c, d); }
+template <>
+__device__ inline int16_t demod_one<int16_t>(int16_t a, int16_t b, int16_t c, int16_t d) { return demod_one_int(a, b, c, d); }
+template <>
+__device__ inline int8_t demod_one<int8_t>(int8_t a, int8_t b, int8_t c, int8_t d) { return demod_one_int(a, b, c, d); }
+
+template <typename T, int ITEMS>
+__global__ __launch_bounds__(kBlock) void freqdemod_kernel(const T *__restrict__ in, T *__restrict__ out, size_t n,
+                                                           const T *__restrict__ prev_in, T *__restrict__ prev_out)
+{
+    using VIn = Vec<T, 2 * ITEMS>;
+    using VOut = Vec<T, ITEMS>;
+    const size_t nvec = n / ITEMS;
+    const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x, gstride = (size_t)gridDim.x * kBlock;
+    for (size_t i = gtid; i < nvec; i += gstride) {
+        const VIn a = reinterpret_cast<const VIn *>(in)[i];
+        T c, d;
+        if (i == 0) { c = prev_in[0]; d = prev_in[1]; }
+        else { c = in[2 * (i * ITEMS - 1)]; d = conj_im<T>(in[2 * (i * ITEMS - 1) + 1]); }
+        VOut o;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            o.v[k] = demod_one<T>(a.v[2 * k], a.v[2 * k + 1], c, d);
+            c = a.v[2 * k]; d = conj_im<T>(a.v[2 * k + 1]);
+        }
+        reinterpret_cast<VOut *>(out)[i] = o;
+    }
+    for (size_t i = nvec * ITEMS + gtid; i < n; i += gstride) {
+        T c, d;
+        if (i == 0) { c = prev_in[0]; d = prev_in[1]; }
+        else { c = in[2 * (i - 1)]; d = conj_im<T>(in[2 * (i - 1) + 1]); }
+        out[i] = demod_one<T>(in[2 * i], in[2 * i + 1], c, d);
+    }
+    if (gtid == 0 && n > 0) { prev_out[0] = in[2 * (n - 1)]; prev_out[1] = conj_im<T>(in[2 * (n - 1) + 1]); }
+}
+template <typename T>
+static int launch_freqdemod_t(const void *in, void *out, size_t n, const void *prev_in, void *prev_out, hipStream_t st)
+{
+    if (n == 0) return PCX_OK;
+    constexpr int ITEMS = (2 * sizeof(T) >= 16) ? 1 : (int)(16 / (2 * sizeof(T)));
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % (sizeof(T) * ITEMS) == 0);
+    if (aligned && ITEMS > 1) {
+        const unsigned grid = stream_grid(n / ITEMS + 1, kBlock);
+        hipLaunchKernelGGL((freqdemod_kernel<T, ITEMS>), dim3(grid), dim3(kBlock), 0, st, (const T *)in, (T *)out, n, (const T *)prev_in, (T *)prev_out);
+    } else {
+        const unsigned grid = stream_grid(n, kBlock);
+        hipLaunchKernelGGL((freqdemod_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T *)in, (T *)out, n, (const T *)prev_in, (T *)prev_out);
+    }
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+int launch_freqdemod(int scalar, const void *in, void *out, size_t n, const void *prev_in, void *prev_out, hipStream_t st)
+{
+    switch (scalar) {
+    case PCX_F32: return launch_freqdemod_t<float>(in, out, n, prev_in, prev_out, st);
+    case PCX_F64: return launch_freqdemod_t<double>(in, out, n, prev_in, prev_out, st);
+    case PCX_I64: return launch_freqdemod_t<int64_t>(in, out, n, prev_in, prev_out, st);
+    case PCX_I32: return launch_freqdemod_t<int32_t>(in, out, n, prev_in, prev_out, st);
+    case PCX_I16: return launch_freqdemod_t<int16_t>(in, out, n, prev_in, prev_out, st);
+    case PCX_I8: return launch_freqdemod_t<int8_t>(in, out, n, prev_in, prev_out, st);
+    }
+    set_error("freq_demod: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+
+// ---- synthetic stream generator (same hash as oracle orc_fill_uniform_f32) ----
+__device__ inline uint64_t d_splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void fill_uniform_kernel(float *dst, size_t n, uint64_t seed, uint64_t offset)
+{
+    const size_t gstride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += gstride) {
+        const uint64_t h = d_splitmix64(seed * 0x100000001B3ull + offset + i);
+        dst[i] = (float)((int32_t)(h >> 40) - (1 << 23)) * (1.0f / (float)(1 << 23));
+    }
+}
+int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t offset, hipStream_t st)
+{
+    if (n == 0) return PCX_OK;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, dst, n, seed, offset);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+}  // namespace pcx

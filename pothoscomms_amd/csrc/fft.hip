@@ -1,0 +1,302 @@
+// fft.hip -- /comms/fft on the device.
+//
+//   fft4096_kernel     complex_float32, numBins = 4096: radix-16 x 3 Stockham, one frame
+//                      per workgroup, registers + one padded LDS image (fft4096.hpp).
+//                      HBM-bound: 64 KiB of traffic per 245,760 flop frame.
+//   fft_pow2_kernel    complex_float32 / complex_float64, numBins = 2^k: Stockham
+//                      radix-4 passes (+ one radix-2 pass when k is odd), ping-pong LDS.
+//   fft_q15_kernel     complex_int16: the reference's fixed-point kiss_fft
+//                      (fft/kiss_fft.c, -DFIXED_POINT=16) restated pass by pass so every
+//                      rounding (sround, C_FIXDIV by the radix) matches bit for bit.
+//
+// Replaces kissfft<T>::transform (fft/kissfft.hh:81-161) and kiss_fft (fft/kiss_fft.c:237-302)
+// called from FFT::work (fft/FFT.cpp:61-72).
+#include "fft4096.hpp"
+#include "pcx_internal.hpp"
+
+namespace pcx {
+
+// --------------------------------------------------------------------------------- //
+// 4096-point complex_float32
+// --------------------------------------------------------------------------------- //
+template <bool INV>
+__global__ __launch_bounds__(256) void fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                      size_t nframes, fft4k::Tables tb)
+{
+    using namespace fft4k;
+    __shared__ float2 lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const float2 *x = in + f * N;
+        float2 *y = out + f * N;
+        float2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = x[j + 256 * r];
+        pass1<INV>(v, lds, j);
+        pass2<INV>(v, lds, j, tb);
+        pass3<INV>(v, lds, j, tb);
+#pragma unroll
+        for (int q = 0; q < 16; q++) y[j + 256 * bin_of(q)] = v[q];
+    }
+}
+
+int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, hipStream_t st)
+{
+    if (nframes == 0) return PCX_OK;
+    fft4k::Tables tb;
+    tb.tw2 = static_cast<const float2 *>(tw4096);
+    tb.tw3 = tb.tw2 + 256;
+    // one frame per workgroup; 4 workgroups per CU fit (34.8 KB LDS each), so cap the
+    // grid at 256 CUs x 8 and let workgroups walk frames with a grid stride
+    const unsigned grid = (unsigned)(nframes < 2048 ? nframes : 2048);
+    if (inverse)
+        hipLaunchKernelGGL(fft4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tb);
+    else
+        hipLaunchKernelGGL(fft4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tb);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+// --------------------------------------------------------------------------------- //
+// generic power-of-two Stockham (radix 4, final radix 2 when log2 N is odd)
+// --------------------------------------------------------------------------------- //
+template <typename T>
+struct C2 {
+    T x, y;
+};
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T>
+__device__ __forceinline__ C2<T> c_add(C2<T> a, C2<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T>
+__device__ __forceinline__ C2<T> c_sub(C2<T> a, C2<T> b) { return {a.x - b.x, a.y - b.y}; }
+// a * w (forward table entry) or a * conj(w)
+template <typename T, bool INV>
+__device__ __forceinline__ C2<T> c_mul_tw(C2<T> a, C2<T> w)
+{
+    if (INV) return {t_fma(a.x, w.x, a.y * w.y), t_fma(a.y, w.x, -a.x * w.y)};
+    return {t_fma(a.x, w.x, -a.y * w.y), t_fma(a.y, w.x, a.x * w.y)};
+}
+template <typename T, bool INV>
+__device__ __forceinline__ C2<T> c_mul_unit(C2<T> a)
+{
+    return INV ? C2<T>{-a.y, a.x} : C2<T>{a.y, -a.x};
+}
+
+// tw[i] = exp(-j 2 pi i / N), i < N (device, precision T)
+template <typename T, bool INV>
+__global__ __launch_bounds__(256) void fft_pow2_kernel(const C2<T> *__restrict__ in, C2<T> *__restrict__ out, int N,
+                                                       int log2n, size_t nframes, const C2<T> *__restrict__ tw)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C2<T> *bufA = reinterpret_cast<C2<T> *>(smem_raw);
+    C2<T> *bufB = bufA + N;
+    const int nt = blockDim.x;
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const C2<T> *src = in + f * (size_t)N;
+        C2<T> *dst_final = out + f * (size_t)N;
+        C2<T> *ping = bufA, *pong = bufB;
+        int Ns = 1, s = 0;
+        const int n4 = log2n / 2;  // radix-4 passes
+        const bool odd = (log2n & 1) != 0;
+        const int npass = n4 + (odd ? 1 : 0);
+        __syncthreads();  // previous frame's readers done
+        for (int p = 0; p < npass; p++, s++) {
+            const bool last = (p == npass - 1);
+            const bool radix2 = odd && last;
+            const C2<T> *rd = (p == 0) ? src : ping;
+            C2<T> *wr = last ? dst_final : pong;
+            if (!radix2) {
+                const int q = N >> 2;  // butterflies this pass
+                const int tstep = N / (Ns * 4);
+                for (int j = threadIdx.x; j < q; j += nt) {
+                    const int k = j & (Ns - 1);
+                    C2<T> a0 = rd[j], a1 = rd[j + q], a2 = rd[j + 2 * q], a3 = rd[j + 3 * q];
+                    if (Ns > 1) {
+                        a1 = c_mul_tw<T, INV>(a1, tw[k * tstep]);
+                        a2 = c_mul_tw<T, INV>(a2, tw[2 * k * tstep]);
+                        a3 = c_mul_tw<T, INV>(a3, tw[3 * k * tstep]);
+                    }
+                    const C2<T> t0 = c_add(a0, a2), t1 = c_sub(a0, a2), t2 = c_add(a1, a3), t3 = c_mul_unit<T, INV>(c_sub(a1, a3));
+                    const int j0 = ((j - k) << 2) + k;
+                    wr[j0] = c_add(t0, t2);
+                    wr[j0 + Ns] = c_add(t1, t3);
+                    wr[j0 + 2 * Ns] = c_sub(t0, t2);
+                    wr[j0 + 3 * Ns] = c_sub(t1, t3);
+                }
+                Ns <<= 2;
+            } else {
+                const int q = N >> 1;
+                const int tstep = N / (Ns * 2);
+                for (int j = threadIdx.x; j < q; j += nt) {
+                    const int k = j & (Ns - 1);
+                    C2<T> a0 = rd[j], a1 = rd[j + q];
+                    if (Ns > 1) a1 = c_mul_tw<T, INV>(a1, tw[k * tstep]);
+                    const int j0 = ((j - k) << 1) + k;
+                    wr[j0] = c_add(a0, a1);
+                    wr[j0 + Ns] = c_sub(a0, a1);
+                }
+                Ns <<= 1;
+            }
+            if (!last) {
+                __syncthreads();
+                C2<T> *t = ping; ping = pong; pong = t;
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_fft_pow2_t(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, hipStream_t st)
+{
+    if (nframes == 0) return PCX_OK;
+    int log2n = 0;
+    while (((size_t)1 << log2n) < nbins) log2n++;
+    if (((size_t)1 << log2n) != nbins || nbins < 2) { set_error("fft: %zu is not a power of two >= 2", nbins); return PCX_ERR_UNSUPPORTED; }
+    const size_t lds = 2 * nbins * sizeof(C2<T>);
+    if (lds > 160 * 1024) { set_error("fft: numBins %zu exceeds the single-workgroup LDS plan", nbins); return PCX_ERR_UNSUPPORTED; }
+    unsigned threads = (unsigned)(nbins / 4);
+    if (threads < 64) threads = 64;
+    if (threads > 256) threads = 256;
+    const unsigned grid = (unsigned)(nframes < 4096 ? nframes : 4096);
+    auto k = inverse ? fft_pow2_kernel<T, true> : fft_pow2_kernel<T, false>;
+    if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, (const C2<T> *)in, (C2<T> *)out, (int)nbins, log2n, nframes, (const C2<T> *)tw);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+int launch_fft_pow2_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, hipStream_t st)
+{
+    return launch_fft_pow2_t<float>(in, out, nbins, nframes, inverse, tw, st);
+}
+int launch_fft_pow2_cf64(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, hipStream_t st)
+{
+    return launch_fft_pow2_t<double>(in, out, nbins, nframes, inverse, tw, st);
+}
+
+// --------------------------------------------------------------------------------- //
+// complex_int16: kiss_fft -DFIXED_POINT=16, bit-exact
+// --------------------------------------------------------------------------------- //
+struct K16 {
+    int16_t r, i;
+};
+#define Q15_SROUND(x) ((int16_t)(((x) + (1 << 14)) >> 15))
+__device__ __forceinline__ K16 k16_mul(K16 a, K16 b)  // C_MUL, _kiss_fft_guts.h:69-71
+{
+    K16 m;
+    m.r = Q15_SROUND((int32_t)a.r * b.r - (int32_t)a.i * b.i);
+    m.i = Q15_SROUND((int32_t)a.r * b.i + (int32_t)a.i * b.r);
+    return m;
+}
+__device__ __forceinline__ K16 k16_fixdiv(K16 c, int mult)  // C_FIXDIV: mult = 32767/radix
+{
+    K16 m;
+    m.r = Q15_SROUND((int32_t)c.r * mult);
+    m.i = Q15_SROUND((int32_t)c.i * mult);
+    return m;
+}
+__device__ __forceinline__ K16 k16_add(K16 a, K16 b) { return {(int16_t)(a.r + b.r), (int16_t)(a.i + b.i)}; }
+__device__ __forceinline__ K16 k16_sub(K16 a, K16 b) { return {(int16_t)(a.r - b.r), (int16_t)(a.i - b.i)}; }
+
+constexpr int kMaxStages = 16;
+struct Q15Plan {
+    int nstages;
+    int radix[kMaxStages];  // top (stage 0) .. bottom, as kf_factor emits them (kiss_fft.c:309-328)
+};
+
+// kf_work's recursion (kiss_fft.c:237-302) unrolled: a digit-reversing gather (the
+// m==1 leaves, :276-280) followed by the butterfly passes bottom-up.  Butterflies of
+// one pass are independent, so running them in parallel leaves every rounding as is.
+__global__ __launch_bounds__(256) void fft_q15_kernel(const K16 *__restrict__ in, K16 *__restrict__ out, int N,
+                                                      size_t nframes, const K16 *__restrict__ tw, Q15Plan plan, int inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    K16 *buf = reinterpret_cast<K16 *>(smem_raw);
+    const int nt = blockDim.x;
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const K16 *src = in + f * (size_t)N;
+        __syncthreads();
+        // leaf gather: output position pos = sum_s q_s * m_s  <-  input index sum_s q_s * fstride_s
+        for (int pos = threadIdx.x; pos < N; pos += nt) {
+            int rem = pos, m = N, fstride = 1, idx = 0;
+            for (int s = 0; s < plan.nstages; s++) {
+                const int p = plan.radix[s];
+                m /= p;
+                const int q = rem / m;
+                rem -= q * m;
+                idx += q * fstride;
+                fstride *= p;
+            }
+            buf[pos] = src[idx];
+        }
+        __syncthreads();
+        // butterfly passes, bottom (m = 1) to top (m = N/p0)
+        int m = 1;
+        for (int s = plan.nstages - 1; s >= 0; s--) {
+            const int p = plan.radix[s];
+            const int fstride = N / (p * m);
+            const int nb = N / p;  // butterflies this pass
+            for (int b = threadIdx.x; b < nb; b += nt) {
+                const int k = b % m, g = b / m;
+                K16 *F = buf + g * (p * m) + k;
+                if (p == 4) {  // kf_bfly4, kiss_fft.c:44-90
+                    K16 f0 = k16_fixdiv(F[0], 8191), f1 = k16_fixdiv(F[m], 8191), f2 = k16_fixdiv(F[2 * m], 8191), f3 = k16_fixdiv(F[3 * m], 8191);
+                    const K16 s0 = k16_mul(f1, tw[k * fstride]);
+                    const K16 s1 = k16_mul(f2, tw[k * fstride * 2]);
+                    const K16 s2 = k16_mul(f3, tw[k * fstride * 3]);
+                    const K16 s5 = k16_sub(f0, s1);
+                    f0 = k16_add(f0, s1);
+                    const K16 s3 = k16_add(s0, s2);
+                    const K16 s4 = k16_sub(s0, s2);
+                    F[2 * m] = k16_sub(f0, s3);
+                    F[0] = k16_add(f0, s3);
+                    if (inverse) {
+                        F[m] = {(int16_t)(s5.r - s4.i), (int16_t)(s5.i + s4.r)};
+                        F[3 * m] = {(int16_t)(s5.r + s4.i), (int16_t)(s5.i - s4.r)};
+                    } else {
+                        F[m] = {(int16_t)(s5.r + s4.i), (int16_t)(s5.i - s4.r)};
+                        F[3 * m] = {(int16_t)(s5.r - s4.i), (int16_t)(s5.i + s4.r)};
+                    }
+                } else {  // p == 2: kf_bfly2, kiss_fft.c:21-42
+                    const K16 f0 = k16_fixdiv(F[0], 16383), f1 = k16_fixdiv(F[m], 16383);
+                    const K16 t = k16_mul(f1, tw[k * fstride]);
+                    F[m] = k16_sub(f0, t);
+                    F[0] = k16_add(f0, t);
+                }
+            }
+            __syncthreads();
+            m *= p;
+        }
+        K16 *dst = out + f * (size_t)N;
+        for (int i = threadIdx.x; i < N; i += nt) dst[i] = buf[i];
+    }
+}
+
+int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
+                   const int *radix_host, int nstages, hipStream_t st)
+{
+    if (nframes == 0) return PCX_OK;
+    if (nstages > kMaxStages) { set_error("fft(int16): too many stages"); return PCX_ERR_UNSUPPORTED; }
+    Q15Plan plan;
+    plan.nstages = nstages;
+    for (int s = 0; s < nstages; s++) {
+        if (radix_host[s] != 4 && radix_host[s] != 2) {
+            set_error("fft(int16): radix-%d stage (numBins %zu) is not implemented on the device", radix_host[s], nbins);
+            return PCX_ERR_UNSUPPORTED;
+        }
+        plan.radix[s] = radix_host[s];
+    }
+    const size_t lds = nbins * sizeof(K16);
+    if (lds > 160 * 1024) { set_error("fft(int16): numBins %zu exceeds LDS", nbins); return PCX_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_q15_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    unsigned threads = (unsigned)(nbins / 4);
+    if (threads < 64) threads = 64;
+    if (threads > 256) threads = 256;
+    const unsigned grid = (unsigned)(nframes < 4096 ? nframes : 4096);
+    hipLaunchKernelGGL(fft_q15_kernel, dim3(grid), dim3(threads), lds, st, (const K16 *)in, (K16 *)out, (int)nbins, nframes,
+                       (const K16 *)tw, plan, inverse ? 1 : 0);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+}  // namespace pcx

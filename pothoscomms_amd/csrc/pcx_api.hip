@@ -1,0 +1,691 @@
+// pcx_api.hip -- the extern "C" boundary of libpcx_hip.so (include/pcx.h).
+// Host-side only: handle bookkeeping, coefficient tables, algorithm choice, staging
+// of host buffers.  All arithmetic on stream data happens in the HIP kernels.
+#include <algorithm>
+#include <complex>
+#include <new>
+#include <string>
+
+#include "pcx_internal.hpp"
+
+namespace pcx {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int64_t float_to_q(double x, int qbits)
+{
+    const double v = std::ldexp(x, qbits / 2);
+    if (qbits == 64) {
+        if (!(v >= -9223372036854775808.0 && v < 9223372036854775808.0)) return INT64_MIN;
+        return (int64_t)v;
+    }
+    if (qbits == 32) {
+        if (!(v >= -2147483648.0 && v < 2147483648.0)) return INT32_MIN;
+        return (int32_t)v;
+    }
+    if (!(v >= -2147483648.0 && v < 2147483648.0)) return 0;
+    return (int16_t)(uint16_t)(uint32_t)(int32_t)v;
+}
+
+int DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap) return PCX_OK;
+    release();
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    PCX_HIP(hipMalloc(&p, want));
+    cap = want;
+    return PCX_OK;
+}
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+// upload a host vector into a DevBuf (control plane: synchronous)
+template <typename T>
+static int upload(DevBuf &b, const std::vector<T> &v)
+{
+    PCX_TRY(b.ensure(v.size() * sizeof(T)));
+    PCX_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PCX_OK;
+}
+
+// tables of the radix-16 x3 4096-point transform (fft4096.hpp):
+//   [0, 256)        tw2[r*16 + kk]  = exp(-j 2 pi kk r / 256)
+//   [256, 256+4096) tw3[r*256 + j]  = exp(-j 2 pi j r / 4096)
+static std::vector<float> make_tw4096()
+{
+    std::vector<float> t(2 * (256 + 4096));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int r = 0; r < 16; r++)
+        for (int kk = 0; kk < 16; kk++) {
+            const double a = -two_pi * (double)(kk * r) / 256.0;
+            t[2 * (r * 16 + kk)] = (float)std::cos(a);
+            t[2 * (r * 16 + kk) + 1] = (float)std::sin(a);
+        }
+    for (int r = 0; r < 16; r++)
+        for (int j = 0; j < 256; j++) {
+            const double a = -two_pi * (double)(j * r) / 4096.0;
+            t[2 * (256 + r * 256 + j)] = (float)std::cos(a);
+            t[2 * (256 + r * 256 + j) + 1] = (float)std::sin(a);
+        }
+    return t;
+}
+
+}  // namespace pcx
+
+using namespace pcx;
+
+#define PCX_CHECK_ARG(cond, ...)        \
+    do {                                \
+        if (!(cond)) {                  \
+            set_error(__VA_ARGS__);     \
+            return PCX_ERR_ARG;         \
+        }                               \
+    } while (0)
+
+// every function below is declared extern "C" in pcx.h and keeps that linkage
+
+const char *pcx_last_error(void) { return g_err.c_str(); }
+const char *pcx_version(void) { return "pothoscomms_amd 0.1 (gfx950)"; }
+
+int pcx_device_count(int *count)
+{
+    PCX_CHECK_ARG(count, "null count");
+    PCX_HIP(hipGetDeviceCount(count));
+    return PCX_OK;
+}
+int pcx_set_device(int ordinal) { PCX_HIP(hipSetDevice(ordinal)); return PCX_OK; }
+int pcx_dev_alloc(void **dptr, size_t bytes)
+{
+    PCX_CHECK_ARG(dptr, "null dptr");
+    PCX_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return PCX_OK;
+}
+int pcx_dev_free(void *dptr) { PCX_HIP(hipFree(dptr)); return PCX_OK; }
+int pcx_memcpy_h2d(void *d, const void *s, size_t n, void *st) { PCX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st))); return PCX_OK; }
+int pcx_memcpy_d2h(void *d, const void *s, size_t n, void *st) { PCX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, as_stream(st))); return PCX_OK; }
+int pcx_memcpy_d2d(void *d, const void *s, size_t n, void *st) { PCX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, as_stream(st))); return PCX_OK; }
+int pcx_stream_sync(void *st) { PCX_HIP(hipStreamSynchronize(as_stream(st))); return PCX_OK; }
+int pcx_fill_uniform_f32_dev(float *dst, size_t n, uint64_t seed, uint64_t offset, void *st)
+{
+    return launch_fill_uniform_f32(dst, n, seed, offset, as_stream(st));
+}
+
+/* ===================================================================== *
+ *  FIR
+ * ===================================================================== */
+struct pcx_fir {
+    int scalar = PCX_F32, cplx = 1, ctaps = 1;
+    std::vector<double> taps;  // ntaps * (ctaps ? 2 : 1)
+    size_t ntaps = 1, M = 1, L = 1, K = 1, inputRequire = 1;
+    int algo = PCX_FIR_AUTO, last_algo = 0;
+    bool dirty = true;
+    DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096, wsIn, wsOut;
+    size_t Kp = 8;
+    bool have_ols = false;
+};
+
+// FIRFilter::updateInternals, FIRFilter.cpp:327-354 (host mirror; tables uploaded lazily)
+static void fir_update_internals(pcx_fir *h)
+{
+    h->K = h->ntaps / h->L + ((h->ntaps % h->L) == 0 ? 0 : 1);
+    h->inputRequire = h->M + (h->K - 1);
+    h->dirty = true;
+}
+
+template <typename TT>
+static int fir_upload_rows(pcx_fir *h, bool integer)
+{
+    const size_t L = h->L, K = h->K, w = h->ctaps ? 2 : 1;
+    std::vector<uint32_t> rowLen(L, 0);
+    std::vector<TT> rows(L * K * w, TT(0));
+    const int qb = q_bits(h->scalar);
+    for (size_t j = 0; j < L; j++) {
+        size_t len = 0;
+        for (size_t k = 0; k < K; k++) {
+            const size_t i = j + k * L;
+            if (i >= h->ntaps) continue;
+            for (size_t c = 0; c < w; c++) {
+                const double t = h->taps[i * w + c];
+                rows[(j * K + len) * w + c] = integer ? (TT)float_to_q(t, qb) : (TT)t;  // floatToQ<QTapsType>, :348
+            }
+            len++;
+        }
+        rowLen[j] = (uint32_t)len;
+    }
+    PCX_TRY(upload(h->rowLen, rowLen));
+    PCX_TRY(upload(h->rowTaps, rows));
+    return PCX_OK;
+}
+
+static bool fir_fast_applicable(const pcx_fir *h) { return h->scalar == PCX_F32 && h->cplx && h->M == 1 && h->L == 1; }
+
+static int fir_sync_tables(pcx_fir *h)
+{
+    if (!h->dirty) return PCX_OK;
+    switch (h->scalar) {
+    case PCX_F32: PCX_TRY(fir_upload_rows<float>(h, false)); break;
+    case PCX_F64: PCX_TRY(fir_upload_rows<double>(h, false)); break;
+    case PCX_I64: case PCX_I32: PCX_TRY(fir_upload_rows<int64_t>(h, true)); break;
+    case PCX_I16: PCX_TRY(fir_upload_rows<int32_t>(h, true)); break;
+    case PCX_I8: PCX_TRY(fir_upload_rows<int16_t>(h, true)); break;
+    }
+    h->have_ols = false;
+    if (fir_fast_applicable(h)) {
+        const size_t K = h->K;
+        // reversed, zero-padded complex taps for the LDS-tiled direct kernel
+        h->Kp = (K + 7) / 8 * 8;
+        std::vector<float> rev(2 * h->Kp, 0.f);
+        for (size_t m = 0; m < K; m++) {
+            const size_t k = K - 1 - m;
+            rev[2 * m] = (float)(h->ctaps ? h->taps[2 * k] : h->taps[k]);
+            rev[2 * m + 1] = h->ctaps ? (float)h->taps[2 * k + 1] : 0.f;
+        }
+        PCX_TRY(upload(h->tapsRev, rev));
+        if (K <= 2049) {
+            // H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096, taps first narrowed to
+            // float (floatToQ<QTapsType>, FIRFilter.cpp:348), DFT accumulated in double
+            std::vector<double> cs(2 * 4096);
+            const double two_pi = 6.283185307179586476925286766559;
+            for (int i = 0; i < 4096; i++) { cs[2 * i] = std::cos(two_pi * i / 4096.0); cs[2 * i + 1] = -std::sin(two_pi * i / 4096.0); }
+            std::vector<float> H(2 * 4096);
+            for (size_t b = 0; b < 4096; b++) {
+                double sr = 0, si = 0;
+                for (size_t k = 0; k < K; k++) {
+                    const double hr = (double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]);
+                    const double hi = h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0;
+                    const size_t e = (b * k) & 4095;
+                    sr += hr * cs[2 * e] - hi * cs[2 * e + 1];
+                    si += hr * cs[2 * e + 1] + hi * cs[2 * e];
+                }
+                H[2 * b] = (float)(sr / 4096.0);
+                H[2 * b + 1] = (float)(si / 4096.0);
+            }
+            PCX_TRY(upload(h->Hspec, H));
+            PCX_TRY(upload(h->tw4096, make_tw4096()));
+            h->have_ols = true;
+        }
+    }
+    h->dirty = false;
+    return PCX_OK;
+}
+
+int pcx_fir_create(int scalar, int is_complex, int complex_taps, pcx_fir **out)
+{
+    PCX_CHECK_ARG(out, "null out");
+    // FIRFilterFactory's if-chain, FIRFilter.cpp:371-383
+    PCX_CHECK_ARG(valid_scalar(scalar), "FIRFilterFactory: unsupported types (scalar %d)", scalar);
+    PCX_CHECK_ARG(!(complex_taps && !is_complex), "FIRFilterFactory: unsupported types (COMPLEX taps on a real stream)");
+    pcx_fir *h = new (std::nothrow) pcx_fir();
+    if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
+    h->scalar = scalar; h->cplx = is_complex ? 1 : 0; h->ctaps = complex_taps ? 1 : 0;
+    h->taps.assign(h->ctaps ? 2 : 1, 0.0);
+    h->taps[0] = 1.0;  // ctor: setTaps({1}), FIRFilter.cpp:125
+    h->ntaps = 1;
+    fir_update_internals(h);
+    *out = h;
+    return PCX_OK;
+}
+int pcx_fir_destroy(pcx_fir *h) { delete h; return PCX_OK; }
+int pcx_fir_set_taps(pcx_fir *h, const double *taps, size_t ntaps)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(ntaps > 0 && taps, "FIRFilter::setTaps(): taps cannot be empty");
+    h->taps.assign(taps, taps + ntaps * (h->ctaps ? 2 : 1));
+    h->ntaps = ntaps;
+    fir_update_internals(h);
+    return PCX_OK;
+}
+int pcx_fir_set_decimation(pcx_fir *h, size_t decim)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(decim != 0, "FIRFilter::setDecimation(): decimation cannot be 0");
+    h->M = decim;
+    fir_update_internals(h);
+    return PCX_OK;
+}
+int pcx_fir_set_interpolation(pcx_fir *h, size_t interp)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(interp != 0, "FIRFilter::setInterpolation(): interpolation cannot be 0");
+    h->L = interp;
+    fir_update_internals(h);
+    return PCX_OK;
+}
+int pcx_fir_set_algo(pcx_fir *h, int algo)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(algo >= PCX_FIR_AUTO && algo <= PCX_FIR_EXACT, "unknown FIR algorithm %d", algo);
+    h->algo = algo;
+    return PCX_OK;
+}
+int pcx_fir_get_geometry(const pcx_fir *h, size_t *K, size_t *input_require)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    if (K) *K = h->K;
+    if (input_require) *input_require = h->inputRequire;
+    return PCX_OK;
+}
+int pcx_fir_last_algo(const pcx_fir *h) { return h ? h->last_algo : PCX_ERR_ARG; }
+
+static size_t fir_elem_bytes(const pcx_fir *h) { return (size_t)scalar_bytes(h->scalar) * (h->cplx ? 2 : 1); }
+
+// N of FIRFilter.cpp:278
+static size_t fir_iterations(const pcx_fir *h, size_t in_elems, size_t out_cap)
+{
+    if (in_elems < h->K - 1) return 0;
+    const size_t a = (in_elems - (h->K - 1)) / h->M, b = out_cap / h->L;
+    return std::min(a, b) * h->M;
+}
+
+int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                        size_t *consumed, size_t *produced, void *stream)
+{
+    PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    *consumed = 0; *produced = 0;
+    const size_t N = fir_iterations(h, in_elems, out_cap);
+    if (N == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    PCX_TRY(fir_sync_tables(h));
+    const size_t n_out = (N / h->M) * h->L;
+    hipStream_t st = as_stream(stream);
+    int algo = h->algo;
+    const bool fast = fir_fast_applicable(h);
+    if (algo == PCX_FIR_AUTO) {
+        // frequency domain pays from a few dozen taps up (direct form turns FMA-bound
+        // near K ~ 40); below that the LDS-tiled direct kernel is HBM-bound too
+        if (fast && h->have_ols && h->K >= 24) algo = PCX_FIR_OLS_FFT;
+        else if (fast) algo = PCX_FIR_DIRECT;
+        else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
+    }
+    if (algo == PCX_FIR_OLS_FFT && !(fast && h->have_ols)) {
+        set_error("fir: OLS_FFT needs complex_float32, M=L=1, K<=2049");
+        return PCX_ERR_UNSUPPORTED;
+    }
+    int rc;
+    // only the samples the N iterations touch: N + K-1
+    const size_t used_in = N + h->K - 1;
+    if (algo == PCX_FIR_OLS_FFT) {
+        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_DIRECT && fast) {
+        rc = launch_fir_cf32_direct(in_dev, used_in, out_dev, n_out, h->tapsRev.p, h->K, h->Kp, st);
+    } else {
+        FirGeom g{h->L, h->M, h->K, static_cast<const uint32_t *>(h->rowLen.p), h->rowTaps.p};
+        rc = launch_fir_generic(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, g, in_dev, out_dev, n_out, st);
+    }
+    if (rc != PCX_OK) return rc;
+    h->last_algo = algo;
+    *consumed = N;
+    *produced = n_out;
+    return PCX_OK;
+}
+
+int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
+{
+    PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    *consumed = 0; *produced = 0;
+    const size_t N = fir_iterations(h, in_elems, out_cap);
+    if (N == 0) return PCX_OK;
+    PCX_CHECK_ARG(in && out, "null buffer");
+    const size_t esz = fir_elem_bytes(h), used_in = N + h->K - 1, n_out = (N / h->M) * h->L;
+    PCX_TRY(h->wsIn.ensure(used_in * esz));
+    PCX_TRY(h->wsOut.ensure(n_out * esz));
+    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, used_in * esz, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(pcx_fir_process_dev(h, h->wsIn.p, used_in, h->wsOut.p, n_out, consumed, produced, nullptr));
+    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, *produced * esz, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
+
+/* ===================================================================== *
+ *  FFT
+ * ===================================================================== */
+struct pcx_fft {
+    int scalar = PCX_F32;
+    size_t nbins = 0;
+    int inverse = 0;
+    bool is4096 = false;
+    DevBuf tw, wsIn, wsOut;
+    std::vector<int> radix;  // int16 path: kf_factor order
+};
+
+int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
+{
+    PCX_CHECK_ARG(out, "null out");
+    // FFTFactory, FFT.cpp:83-93: complex<double>, complex<float>, complex<int16> only
+    PCX_CHECK_ARG(scalar == PCX_F64 || scalar == PCX_F32 || scalar == PCX_I16, "FFTFactory: unsupported type (scalar %d)", scalar);
+    PCX_CHECK_ARG(num_bins >= 1, "FFT: numBins must be >= 1");
+    if ((num_bins & (num_bins - 1)) != 0) {
+        set_error("FFT: numBins=%zu: only power-of-two sizes are implemented on the device", num_bins);
+        return PCX_ERR_UNSUPPORTED;
+    }
+    pcx_fft *h = new (std::nothrow) pcx_fft();
+    if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
+    h->scalar = scalar; h->nbins = num_bins; h->inverse = inverse ? 1 : 0;
+    const double two_pi = 6.283185307179586476925286766559;
+    int rc = PCX_OK;
+    if (scalar == PCX_F32 && num_bins == 4096) {
+        h->is4096 = true;
+        rc = upload(h->tw, make_tw4096());
+    } else if (scalar == PCX_F32) {
+        std::vector<float> t(2 * num_bins);
+        for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(-std::sin(two_pi * i / num_bins)); }
+        rc = upload(h->tw, t);
+    } else if (scalar == PCX_F64) {
+        std::vector<double> t(2 * num_bins);
+        for (size_t i = 0; i < num_bins; i++) { t[2 * i] = std::cos(two_pi * i / num_bins); t[2 * i + 1] = -std::sin(two_pi * i / num_bins); }
+        rc = upload(h->tw, t);
+    } else {
+        // kiss_fft_alloc, kiss_fft.c:339-368: Q15 twiddles floor(.5 + 32767*cos/sin(phase))
+        std::vector<int16_t> t(2 * num_bins);
+        for (size_t i = 0; i < num_bins; i++) {
+            const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+            double phase = -2 * pi * (double)i / (double)num_bins;
+            if (h->inverse) phase *= -1;
+            t[2 * i] = (int16_t)std::floor(.5 + 32767 * std::cos(phase));
+            t[2 * i + 1] = (int16_t)std::floor(.5 + 32767 * std::sin(phase));
+        }
+        rc = upload(h->tw, t);
+        // kf_factor, kiss_fft.c:309-328
+        int n = (int)num_bins, p = 4;
+        const double floor_sqrt = std::floor(std::sqrt((double)n));
+        do {
+            while (n % p) {
+                switch (p) { case 4: p = 2; break; case 2: p = 3; break; default: p += 2; break; }
+                if (p > floor_sqrt) p = n;
+            }
+            n /= p;
+            h->radix.push_back(p);
+        } while (n > 1);
+    }
+    if (rc != PCX_OK) { delete h; return rc; }
+    *out = h;
+    return PCX_OK;
+}
+int pcx_fft_destroy(pcx_fft *h) { delete h; return PCX_OK; }
+
+int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    if (nframes == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    hipStream_t st = as_stream(stream);
+    if (h->nbins == 1) {  // DFT of one point is the identity (kissfft leaf copy, kissfft.hh:94-98)
+        PCX_HIP(hipMemcpyAsync(out_dev, in_dev, nframes * 2 * (size_t)scalar_bytes(h->scalar), hipMemcpyDeviceToDevice, st));
+        return PCX_OK;
+    }
+    if (h->is4096) return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, st);
+    if (h->scalar == PCX_F32) return launch_fft_pow2_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
+    if (h->scalar == PCX_F64) return launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
+    return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
+}
+int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    if (nframes == 0) return PCX_OK;
+    PCX_CHECK_ARG(in && out, "null buffer");
+    const size_t bytes = nframes * h->nbins * 2 * (size_t)scalar_bytes(h->scalar);
+    PCX_TRY(h->wsIn.ensure(bytes));
+    PCX_TRY(h->wsOut.ensure(bytes));
+    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, bytes, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(pcx_fft_transform_dev(h, h->wsIn.p, h->wsOut.p, nframes, nullptr));
+    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, bytes, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
+
+/* ===================================================================== *
+ *  FreqDemod
+ * ===================================================================== */
+struct pcx_freqdemod {
+    int scalar = PCX_F32;
+    DevBuf prev;  // two complex slots (ping-pong), holds _prev = conj(last input)
+    int cur = 0;
+    DevBuf wsIn, wsOut;
+};
+int pcx_freqdemod_create(int scalar, pcx_freqdemod **out)
+{
+    PCX_CHECK_ARG(out, "null out");
+    PCX_CHECK_ARG(valid_scalar(scalar), "FreqDemodFactory: unsupported types (scalar %d)", scalar);
+    pcx_freqdemod *h = new (std::nothrow) pcx_freqdemod();
+    if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
+    h->scalar = scalar;
+    int rc = h->prev.ensure(64);
+    if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
+    if (rc != PCX_OK) { delete h; return rc; }
+    *out = h;
+    return PCX_OK;
+}
+int pcx_freqdemod_destroy(pcx_freqdemod *h) { delete h; return PCX_OK; }
+int pcx_freqdemod_reset(pcx_freqdemod *h)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_HIP(hipMemset(h->prev.p, 0, 64));  // _prev = 0, FreqDemod.cpp:46
+    h->cur = 0;
+    return PCX_OK;
+}
+int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    char *base = static_cast<char *>(h->prev.p);
+    const void *pin = base + 32 * h->cur;
+    void *pout = base + 32 * (h->cur ^ 1);
+    PCX_TRY(launch_freqdemod(h->scalar, in_dev, out_dev, n, pin, pout, as_stream(stream)));
+    h->cur ^= 1;
+    return PCX_OK;
+}
+int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in && out, "null buffer");
+    const size_t sb = (size_t)scalar_bytes(h->scalar);
+    PCX_TRY(h->wsIn.ensure(n * 2 * sb));
+    PCX_TRY(h->wsOut.ensure(n * sb));
+    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, n * 2 * sb, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(pcx_freqdemod_process_dev(h, h->wsIn.p, h->wsOut.p, n, nullptr));
+    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, n * sb, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
+
+/* ===================================================================== *
+ *  stateless maps
+ * ===================================================================== */
+// host-buffer wrapper: stage in, run, stage out (one temporary device allocation pair
+// per thread, grown on demand)
+struct MapWs {
+    DevBuf in, out;
+};
+static thread_local MapWs g_mapws;
+
+template <typename F>
+static int run_host_map(const void *in, void *out, size_t in_bytes, size_t out_bytes, F &&launch)
+{
+    if (in_bytes == 0) return PCX_OK;
+    PCX_CHECK_ARG(in && out, "null buffer");
+    PCX_TRY(g_mapws.in.ensure(in_bytes));
+    PCX_TRY(g_mapws.out.ensure(out_bytes));
+    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, in, in_bytes, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(launch(g_mapws.in.p, g_mapws.out.p));
+    PCX_HIP(hipMemcpyAsync(out, g_mapws.out.p, out_bytes, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
+
+int pcx_rotate_dev(int scalar, double pr, double pi, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "rotateFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    return launch_rotate(scalar, pr, pi, in_dev, out_dev, n, as_stream(stream));
+}
+int pcx_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "rotateFactory: unsupported type (scalar %d)", scalar);
+    const size_t b = n * 2 * (size_t)scalar_bytes(scalar);
+    return run_host_map(in, out, b, b, [&](void *di, void *dout) { return launch_rotate(scalar, pr, pi, di, dout, n, nullptr); });
+}
+int pcx_scale_dev(int scalar, int is_complex, double factor, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    return launch_scale(scalar, is_complex, factor, in_dev, out_dev, n, as_stream(stream));
+}
+int pcx_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
+    const size_t b = n * (is_complex ? 2 : 1) * (size_t)scalar_bytes(scalar);
+    return run_host_map(in, out, b, b, [&](void *di, void *dout) { return launch_scale(scalar, is_complex, factor, di, dout, n, nullptr); });
+}
+int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "absFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    return launch_abs(scalar, is_complex, in_dev, out_dev, n, as_stream(stream));
+}
+int pcx_abs(int scalar, int is_complex, const void *in, void *out, size_t n)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "absFactory: unsupported type (scalar %d)", scalar);
+    const size_t sb = (size_t)scalar_bytes(scalar);
+    return run_host_map(in, out, n * (is_complex ? 2 : 1) * sb, n * sb,
+                        [&](void *di, void *dout) { return launch_abs(scalar, is_complex, di, dout, n, nullptr); });
+}
+int pcx_conj_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "conjugateFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    return launch_conj(scalar, in_dev, out_dev, n, as_stream(stream));
+}
+int pcx_conj(int scalar, const void *in, void *out, size_t n)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "conjugateFactory: unsupported type (scalar %d)", scalar);
+    const size_t b = n * 2 * (size_t)scalar_bytes(scalar);
+    return run_host_map(in, out, b, b, [&](void *di, void *dout) { return launch_conj(scalar, di, dout, n, nullptr); });
+}
+
+/* ===================================================================== *
+ *  fused Rotate -> FIR -> FreqDemod
+ * ===================================================================== */
+struct pcx_fmchain {
+    double phase = 0.0;
+    bool phase_set = false;  // Rotate before setPhase: zero phasor (Rotate.cpp:60-62)
+    std::vector<double> taps;
+    size_t ntaps = 1;
+    int ctaps = 0;
+    bool dirty = true;
+    size_t K = 1, Kp = 8;
+    DevBuf tapsRev, prev, wsIn, wsOut;
+    int cur = 0;
+};
+int pcx_fmchain_create(pcx_fmchain **out)
+{
+    PCX_CHECK_ARG(out, "null out");
+    pcx_fmchain *h = new (std::nothrow) pcx_fmchain();
+    if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
+    h->taps.assign(1, 1.0);
+    int rc = h->prev.ensure(64);
+    if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
+    if (rc != PCX_OK) { delete h; return rc; }
+    *out = h;
+    return PCX_OK;
+}
+int pcx_fmchain_destroy(pcx_fmchain *h) { delete h; return PCX_OK; }
+int pcx_fmchain_set_phase(pcx_fmchain *h, double phase)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    h->phase = phase; h->phase_set = true; h->dirty = true;
+    return PCX_OK;
+}
+int pcx_fmchain_set_taps(pcx_fmchain *h, const double *taps, size_t ntaps, int complex_taps)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(ntaps > 0 && taps, "FIRFilter::setTaps(): taps cannot be empty");
+    h->taps.assign(taps, taps + ntaps * (complex_taps ? 2 : 1));
+    h->ntaps = ntaps; h->ctaps = complex_taps ? 1 : 0; h->dirty = true;
+    return PCX_OK;
+}
+int pcx_fmchain_reset(pcx_fmchain *h)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_HIP(hipMemset(h->prev.p, 0, 64));
+    h->cur = 0;
+    return PCX_OK;
+}
+static int fmchain_sync(pcx_fmchain *h)
+{
+    if (!h->dirty) return PCX_OK;
+    const size_t K = h->ntaps;
+    h->K = K;
+    h->Kp = (K + 7) / 8 * 8;
+    // Rotate's phasor folded into the taps: FIR(p*x) = (p*h) (*) x.  p is first narrowed
+    // to float as floatToQ<complex<float>> does (Rotate.cpp:74), h as FIRFilter.cpp:348.
+    const std::complex<double> p = h->phase_set ? std::complex<double>((double)(float)std::cos(h->phase), (double)(float)std::sin(h->phase))
+                                                : std::complex<double>(0.0, 0.0);
+    std::vector<float> rev(2 * h->Kp, 0.f);
+    for (size_t m = 0; m < K; m++) {
+        const size_t k = K - 1 - m;
+        const std::complex<double> t = h->ctaps ? std::complex<double>((double)(float)h->taps[2 * k], (double)(float)h->taps[2 * k + 1])
+                                                : std::complex<double>((double)(float)h->taps[k], 0.0);
+        const std::complex<double> g = p * t;
+        rev[2 * m] = (float)g.real();
+        rev[2 * m + 1] = (float)g.imag();
+    }
+    PCX_TRY(upload(h->tapsRev, rev));
+    h->dirty = false;
+    return PCX_OK;
+}
+int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                            size_t *consumed, size_t *produced, void *stream)
+{
+    PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    *consumed = 0; *produced = 0;
+    PCX_TRY(fmchain_sync(h));
+    if (in_elems < h->K) return PCX_OK;
+    const size_t N = std::min(in_elems - (h->K - 1), out_cap);
+    if (N == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    char *base = static_cast<char *>(h->prev.p);
+    PCX_TRY(launch_fmchain_cf32(in_dev, N + h->K - 1, out_dev, N, h->tapsRev.p, h->K, h->Kp, base + 32 * h->cur,
+                                base + 32 * (h->cur ^ 1), as_stream(stream)));
+    h->cur ^= 1;
+    *consumed = N; *produced = N;
+    return PCX_OK;
+}
+int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
+{
+    PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    *consumed = 0; *produced = 0;
+    PCX_TRY(fmchain_sync(h));
+    if (in_elems < h->K) return PCX_OK;
+    const size_t N = std::min(in_elems - (h->K - 1), out_cap);
+    if (N == 0) return PCX_OK;
+    PCX_CHECK_ARG(in && out, "null buffer");
+    const size_t used = N + h->K - 1;
+    PCX_TRY(h->wsIn.ensure(used * 8));
+    PCX_TRY(h->wsOut.ensure(N * 4));
+    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, used * 8, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(pcx_fmchain_process_dev(h, h->wsIn.p, used, h->wsOut.p, N, consumed, produced, nullptr));
+    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, N * 4, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
+

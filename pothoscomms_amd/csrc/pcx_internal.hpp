@@ -1,0 +1,124 @@
+// pcx_internal.hpp -- shared host-side helpers of libpcx_hip.so (not installed)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "pcx.h"
+
+namespace pcx {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define PCX_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            ::pcx::set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return PCX_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define PCX_TRY(expr)              \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != PCX_OK) return rc__; \
+    } while (0)
+
+#define PCX_LAUNCH_CHECK() PCX_HIP(hipGetLastError())
+
+inline int scalar_bytes(int s)
+{
+    switch (s) {
+    case PCX_F64: case PCX_I64: return 8;
+    case PCX_F32: case PCX_I32: return 4;
+    case PCX_I16: return 2;
+    case PCX_I8: return 1;
+    }
+    return 0;
+}
+inline bool valid_scalar(int s) { return s >= PCX_F64 && s <= PCX_I8; }
+inline bool is_float_scalar(int s) { return s == PCX_F64 || s == PCX_F32; }
+// Q (accumulator) width for an integer element type: FIRFilter.cpp:377-382,
+// Rotate.cpp:151-154, Scale.cpp:150-153
+inline int q_bits(int s)
+{
+    switch (s) {
+    case PCX_I64: case PCX_I32: return 64;
+    case PCX_I16: return 32;
+    case PCX_I8: return 16;
+    }
+    return 0;
+}
+// Pothos::Util::floatToQ<T>(x) for integer T: T(std::ldexp(x, 4*sizeof(T)))
+int64_t float_to_q(double x, int qbits);
+
+// growable device workspace owned by a handle
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// grid size for an HBM-bound grid-stride kernel: enough blocks to fill 256 CUs x 8
+inline unsigned stream_grid(size_t work_items, unsigned block)
+{
+    size_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256u * 8u) g = 256u * 8u;
+    return (unsigned)g;
+}
+
+// ---- kernel launchers implemented in the .hip files ----
+int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n, hipStream_t st);
+int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st);
+int launch_abs(int scalar, int is_complex, const void *in, void *out, size_t n, hipStream_t st);
+int launch_conj(int scalar, const void *in, void *out, size_t n, hipStream_t st);
+// out[i] = angle(in[i]*_prev); _prev(i=0) := *prev_in (already conjugated); *prev_out := conj(in[n-1])
+int launch_freqdemod(int scalar, const void *in, void *out, size_t n, const void *prev_in, void *prev_out, hipStream_t st);
+int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t offset, hipStream_t st);
+
+// FIR: generic polyphase kernel (all types; EXACT = reference order, unfused)
+struct FirGeom {
+    size_t L, M, K;
+    const uint32_t *rowLen;  // device, L entries
+    const void *rowTaps;     // device, L*K entries of the tap type (Q precision), row-major
+};
+int launch_fir_generic(int scalar, int is_complex, int complex_taps, bool exact, const FirGeom &g, const void *in,
+                       void *out, size_t n_out, hipStream_t st);
+// FIR: fast LDS-tiled direct form, complex_float32, M=L=1.  taps_rev: device array of
+// Kp (K rounded up to 8) cf32 taps in reversed order g[m] = h[K-1-m], zero padded
+int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_out, const void *taps_rev, size_t K,
+                           size_t Kp, hipStream_t st);
+// FIR: frequency-domain overlap-save, complex_float32, M=L=1, K <= 2049.
+// Hspec: device array of 4096 cf32 = FFT_4096(h)/4096 in natural bin order.
+int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
+                            const void *tw4096, hipStream_t st);
+
+// FFT
+int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, hipStream_t st);
+int launch_fft_pow2_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
+                         hipStream_t st);
+int launch_fft_pow2_cf64(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
+                         hipStream_t st);
+// kiss_fft Q15 (bit-exact): nbins = product of radix 4/2 stages; tw = int16 pairs
+int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
+                   const int *radix_host, int nstages, hipStream_t st);
+
+// fused Rotate -> FIR -> FreqDemod
+int launch_fmchain_cf32(const void *in, size_t in_elems, void *out, size_t n_out, const void *taps_rev, size_t K,
+                        size_t Kp, const void *prev_in, void *prev_out, hipStream_t st);
+
+}  // namespace pcx

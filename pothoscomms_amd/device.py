@@ -1,0 +1,293 @@
+"""Thin Python handles over the C ABI (include/pcx.h) -- plumbing for tests, bench.py
+and the multi-GPU stream driver.  Host arrays are numpy, device arrays are torch CUDA
+(ROCm) tensors used purely as device memory; every call goes through libpcx_hip.so.
+
+Stream layout: a complex stream of scalar type T is an array of shape (n, 2) of T
+(interleaved re, im = std::complex<T>); numpy complex64/complex128 are accepted and
+viewed that way.  Real streams are 1-D arrays of T.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import F64, F32, I64, I32, I16, I8  # noqa: F401  (re-exported)
+
+NP_SCALAR = {F64: np.float64, F32: np.float32, I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8}
+SCALAR_OF_NP = {np.dtype(v): k for k, v in NP_SCALAR.items()}
+
+# Pothos DType names (DType::toString) -> (scalar code, is_complex)
+DTYPE_NAMES = {}
+for _code, _nm in ((F64, "float64"), (F32, "float32"), (I64, "int64"), (I32, "int32"), (I16, "int16"), (I8, "int8")):
+    DTYPE_NAMES[_nm] = (_code, False)
+    DTYPE_NAMES["complex_" + _nm] = (_code, True)
+DTYPE_NAMES["complex64"] = (F32, True)    # Pothos accepts numpy-style aliases
+DTYPE_NAMES["complex128"] = (F64, True)
+DTYPE_NAMES["float"] = (F32, False)
+DTYPE_NAMES["double"] = (F64, False)
+
+
+def parse_dtype(dtype):
+    """'complex_float32' / np.dtype / (scalar, is_complex) -> (scalar code, is_complex)."""
+    if isinstance(dtype, tuple):
+        return dtype
+    if isinstance(dtype, str):
+        if dtype not in DTYPE_NAMES:
+            raise _lib.InvalidArgument(_lib.ERR_ARG, "unknown dtype %r" % dtype)
+        return DTYPE_NAMES[dtype]
+    dt = np.dtype(dtype)
+    if dt == np.complex64:
+        return (F32, True)
+    if dt == np.complex128:
+        return (F64, True)
+    return (SCALAR_OF_NP[dt], False)
+
+
+def as_pairs(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.complex64:
+        return a.view(np.float32).reshape(-1, 2)
+    if a.dtype == np.complex128:
+        return a.view(np.float64).reshape(-1, 2)
+    return a
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _dev_ptr(t):
+    if not t.is_cuda:
+        raise ValueError("device variant needs a CUDA/ROCm tensor")
+    if not t.is_contiguous():
+        raise ValueError("device buffers must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream=None):
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            getattr(_lib.load(), self._destroy)(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FirFilter(_Handle):
+    """pcx_fir_*: the loop of filter/FIRFilter.cpp:278-308 behind FIRFilterFactory's type matrix."""
+    _destroy = "pcx_fir_destroy"
+
+    def __init__(self, dtype="complex_float32", taps_type="COMPLEX"):
+        super().__init__()
+        self.scalar, self.is_complex = parse_dtype(dtype)
+        if taps_type not in ("REAL", "COMPLEX"):
+            raise _lib.InvalidArgument(_lib.ERR_ARG, "FIRFilterFactory: unsupported types")
+        self.complex_taps = taps_type == "COMPLEX"
+        _lib.check(_lib.load().pcx_fir_create(self.scalar, int(self.is_complex), int(self.complex_taps), C.byref(self._h)))
+
+    def set_taps(self, taps):
+        t = np.asarray(taps)
+        if self.complex_taps:
+            t = np.ascontiguousarray(t.astype(np.complex128)).view(np.float64)
+            n = t.size // 2
+        else:
+            t = np.ascontiguousarray(np.real(t).astype(np.float64))
+            n = t.size
+        _lib.check(_lib.load().pcx_fir_set_taps(self._h, _np_ptr(t), n))
+
+    def set_decimation(self, m):
+        _lib.check(_lib.load().pcx_fir_set_decimation(self._h, m))
+
+    def set_interpolation(self, l):
+        _lib.check(_lib.load().pcx_fir_set_interpolation(self._h, l))
+
+    def set_algo(self, algo):
+        _lib.check(_lib.load().pcx_fir_set_algo(self._h, algo))
+
+    @property
+    def last_algo(self):
+        return _lib.load().pcx_fir_last_algo(self._h)
+
+    def geometry(self):
+        k, r = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().pcx_fir_get_geometry(self._h, C.byref(k), C.byref(r)))
+        return k.value, r.value
+
+    @property
+    def K(self):
+        return self.geometry()[0]
+
+    def process(self, inbuf, out_cap):
+        """Host buffers.  Returns (out[:produced], consumed, produced)."""
+        x = as_pairs(inbuf)
+        n_in = x.shape[0]
+        shape = (out_cap, 2) if self.is_complex else (out_cap,)
+        y = np.zeros(shape, dtype=NP_SCALAR[self.scalar])
+        c, p = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().pcx_fir_process(self._h, _np_ptr(x), n_in, _np_ptr(y), out_cap, C.byref(c), C.byref(p)))
+        return y[:p.value], c.value, p.value
+
+    def process_dev(self, x, y, in_elems=None, out_cap=None, stream=None):
+        """Device tensors (x: in_elems elements incl. K-1 history).  Returns (consumed, produced)."""
+        w = 2 if self.is_complex else 1
+        if in_elems is None:
+            in_elems = x.numel() // w
+        if out_cap is None:
+            out_cap = y.numel() // w
+        c, p = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().pcx_fir_process_dev(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap,
+                                                   C.byref(c), C.byref(p), _stream_ptr(stream)))
+        return c.value, p.value
+
+
+class Fft(_Handle):
+    """pcx_fft_*: FFTAux::transform (fft/FFTAux.h) over whole frames."""
+    _destroy = "pcx_fft_destroy"
+
+    def __init__(self, dtype, num_bins, inverse=False):
+        super().__init__()
+        self.scalar, cplx = parse_dtype(dtype)
+        if not cplx:
+            raise _lib.InvalidArgument(_lib.ERR_ARG, "FFTFactory: unsupported type")
+        self.num_bins = int(num_bins)
+        _lib.check(_lib.load().pcx_fft_create(self.scalar, self.num_bins, int(bool(inverse)), C.byref(self._h)))
+
+    def transform(self, x, nframes=None):
+        xp = as_pairs(x)
+        nf = xp.shape[0] // self.num_bins if nframes is None else nframes
+        y = np.zeros_like(xp[:nf * self.num_bins])
+        _lib.check(_lib.load().pcx_fft_transform(self._h, _np_ptr(xp), _np_ptr(y), nf))
+        return y
+
+    def transform_dev(self, x, y, nframes, stream=None):
+        _lib.check(_lib.load().pcx_fft_transform_dev(self._h, _dev_ptr(x), _dev_ptr(y), nframes, _stream_ptr(stream)))
+
+
+class FreqDemod(_Handle):
+    """pcx_freqdemod_*: demod/FreqDemod.cpp:44-71 with _prev carried on the device."""
+    _destroy = "pcx_freqdemod_destroy"
+
+    def __init__(self, dtype="complex_float32"):
+        super().__init__()
+        self.scalar, cplx = parse_dtype(dtype)
+        if not cplx:
+            raise _lib.InvalidArgument(_lib.ERR_ARG, "FreqDemodFactory: unsupported types")
+        _lib.check(_lib.load().pcx_freqdemod_create(self.scalar, C.byref(self._h)))
+
+    def reset(self):
+        _lib.check(_lib.load().pcx_freqdemod_reset(self._h))
+
+    def process(self, x):
+        xp = as_pairs(x)
+        y = np.zeros(xp.shape[0], dtype=NP_SCALAR[self.scalar])
+        _lib.check(_lib.load().pcx_freqdemod_process(self._h, _np_ptr(xp), _np_ptr(y), xp.shape[0]))
+        return y
+
+    def process_dev(self, x, y, n, stream=None):
+        _lib.check(_lib.load().pcx_freqdemod_process_dev(self._h, _dev_ptr(x), _dev_ptr(y), n, _stream_ptr(stream)))
+
+
+class FmChain(_Handle):
+    """pcx_fmchain_*: Rotate -> FIR -> FreqDemod in one kernel (complex_float32 -> float32)."""
+    _destroy = "pcx_fmchain_destroy"
+
+    def __init__(self):
+        super().__init__()
+        _lib.check(_lib.load().pcx_fmchain_create(C.byref(self._h)))
+
+    def set_phase(self, phase):
+        _lib.check(_lib.load().pcx_fmchain_set_phase(self._h, float(phase)))
+
+    def set_taps(self, taps, complex_taps=None):
+        t = np.asarray(taps)
+        if complex_taps is None:
+            complex_taps = np.iscomplexobj(t)
+        if complex_taps:
+            t = np.ascontiguousarray(t.astype(np.complex128)).view(np.float64)
+            n = t.size // 2
+        else:
+            t = np.ascontiguousarray(np.real(t).astype(np.float64))
+            n = t.size
+        _lib.check(_lib.load().pcx_fmchain_set_taps(self._h, _np_ptr(t), n, int(bool(complex_taps))))
+
+    def reset(self):
+        _lib.check(_lib.load().pcx_fmchain_reset(self._h))
+
+    def process(self, x, out_cap):
+        xp = as_pairs(x)
+        y = np.zeros(out_cap, dtype=np.float32)
+        c, p = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().pcx_fmchain_process(self._h, _np_ptr(xp), xp.shape[0], _np_ptr(y), out_cap, C.byref(c), C.byref(p)))
+        return y[:p.value], c.value, p.value
+
+    def process_dev(self, x, y, in_elems, out_cap, stream=None):
+        c, p = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().pcx_fmchain_process_dev(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap,
+                                                       C.byref(c), C.byref(p), _stream_ptr(stream)))
+        return c.value, p.value
+
+
+# ---- stateless maps ------------------------------------------------------------------
+def _map(host_fn, dev_fn, scalar_args, x, out_shape_fn, n, out=None, stream=None):
+    L = _lib.load()
+    if _is_torch(x):
+        _lib.check(getattr(L, dev_fn)(*scalar_args, _dev_ptr(x), _dev_ptr(out), n, _stream_ptr(stream)))
+        return out
+    y = np.zeros(out_shape_fn(x), dtype=x.dtype) if out is None else out
+    _lib.check(getattr(L, host_fn)(*scalar_args, _np_ptr(x), _np_ptr(y), n))
+    return y
+
+
+def rotate(x, phase, scalar=None, out=None, n=None, stream=None):
+    """arrayRotate (math/Rotate.cpp:15-23).  phase=None: block whose setPhase was never called."""
+    pr, pi = (0.0, 0.0) if phase is None else (float(np.cos(phase)), float(np.sin(phase)))
+    if not _is_torch(x):
+        x = as_pairs(x)
+        scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
+    return _map("pcx_rotate", "pcx_rotate_dev", (scalar, pr, pi), x, lambda a: a.shape, n, out, stream)
+
+
+def scale(x, factor, is_complex, scalar=None, out=None, n=None, stream=None):
+    if not _is_torch(x):
+        x = as_pairs(x)
+        scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
+    return _map("pcx_scale", "pcx_scale_dev", (scalar, int(is_complex), float(factor)), x, lambda a: a.shape, n, out, stream)
+
+
+def abs_(x, is_complex, scalar=None, out=None, n=None, stream=None):
+    if not _is_torch(x):
+        x = as_pairs(x)
+        scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
+    return _map("pcx_abs", "pcx_abs_dev", (scalar, int(is_complex)), x, lambda a: (a.shape[0],), n, out, stream)
+
+
+def conj(x, scalar=None, out=None, n=None, stream=None):
+    if not _is_torch(x):
+        x = as_pairs(x)
+        scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
+    return _map("pcx_conj", "pcx_conj_dev", (scalar,), x, lambda a: a.shape, n, out, stream)
+
+
+def fill_uniform_f32_dev(t, seed, offset=0, stream=None):
+    """Fill a float32 CUDA tensor with the deterministic synthetic stream (uniform [-1,1))."""
+    _lib.check(_lib.load().pcx_fill_uniform_f32_dev(_dev_ptr(t), t.numel(), seed, offset, _stream_ptr(stream)))
+    return t

@@ -1,0 +1,329 @@
+"""GPU parity: the HIP path, called through the C ABI (include/pcx.h), against the CPU oracle
+on the same seeded inputs.  Bars (north_star): bit-exact for integer work and for the float
+maps whose arithmetic order is preserved (Rotate/Scale/Conjugate/Abs/EXACT FIR); 1e-5 of
+max|ref| for the float kernels that reorder/fuse arithmetic (FIR direct/OLS, FFT); 1e-5*pi
+angular for FreqDemod (libm vs device atan2).
+"""
+import numpy as np
+import pytest
+
+from tests.util import NAMES, SCALARS, TOL, ang_err, nerr, rand_stream
+
+pytestmark = pytest.mark.gpu
+
+
+# --------------------------------------------------------------------------- #
+# element-wise blocks
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("scalar", SCALARS, ids=lambda s: NAMES[s])
+@pytest.mark.parametrize("n", [0, 1, 13, 1000, 65537])
+def test_conjugate(oracle, dev, scalar, n):
+    rng = np.random.default_rng(n + scalar)
+    x = rand_stream(rng, scalar, n, True)
+    assert np.array_equal(dev.conj(x), oracle.conj(x))
+
+
+@pytest.mark.parametrize("scalar", SCALARS, ids=lambda s: NAMES[s])
+@pytest.mark.parametrize("phase", [None, 0.0, 0.7, np.pi / 2, np.pi, 3 * np.pi / 2, -2.5])
+def test_rotate(oracle, dev, scalar, phase):
+    rng = np.random.default_rng(7 + scalar)
+    for n in (1, 13, 4099):
+        x = rand_stream(rng, scalar, n, True)
+        assert np.array_equal(dev.rotate(x, phase), oracle.rotate(x, phase)), (n, phase)
+
+
+@pytest.mark.parametrize("scalar", SCALARS, ids=lambda s: NAMES[s])
+@pytest.mark.parametrize("is_complex", [False, True])
+@pytest.mark.parametrize("factor", [-1.0, -0.5, 0.0, 0.5, 1.0, 3.14159, 1e-3])
+def test_scale(oracle, dev, scalar, is_complex, factor):
+    rng = np.random.default_rng(11 + scalar)
+    for n in (1, 13, 4099):
+        x = rand_stream(rng, scalar, n, is_complex)
+        assert np.array_equal(dev.scale(x, factor, is_complex), oracle.scale(x, factor, is_complex))
+
+
+@pytest.mark.parametrize("scalar", SCALARS, ids=lambda s: NAMES[s])
+@pytest.mark.parametrize("is_complex", [False, True])
+def test_abs(oracle, dev, scalar, is_complex):
+    rng = np.random.default_rng(13 + scalar)
+    for n in (1, 100, 70001):
+        x = rand_stream(rng, scalar, n, is_complex)
+        got, ref = dev.abs_(x, is_complex), oracle.abs_(x, is_complex)
+        if scalar == oracle.F64 and is_complex:
+            assert nerr(got, ref) <= 1e-15 * 4     # device hypot vs glibc hypot: <= 2 ulp
+        else:
+            assert np.array_equal(got, ref)         # float32 magnitude is bit-exact (fp64 sqrt path)
+
+
+def test_abs_cf32_special_values(oracle, dev):
+    x = np.array([[1e-30, 1e-30], [3e38, 3e38], [1e-45, 0], [0, 0], [-0.0, 0.0], [np.inf, 1], [np.inf, np.nan],
+                  [3, 4], [-5, 12]], np.float32)
+    got, ref = dev.abs_(x, True), oracle.abs_(x, True)
+    assert np.array_equal(got, ref, equal_nan=True)
+
+
+@pytest.mark.parametrize("scalar", SCALARS, ids=lambda s: NAMES[s])
+def test_freqdemod(oracle, dev, scalar):
+    rng = np.random.default_rng(17 + scalar)
+    n = 50001
+    if scalar in (oracle.F64, oracle.F32):
+        # FM-like signal with non-vanishing envelope so atan2 is well conditioned
+        ph = np.cumsum(rng.uniform(-1.5, 1.5, n))
+        x = np.stack([np.cos(ph), np.sin(ph)], 1) * rng.uniform(0.5, 1.5, (n, 1))
+        x = x.astype(oracle.NP_SCALAR[scalar])
+    else:
+        x = rand_stream(rng, scalar, n, True)
+    # several work() calls of ragged sizes: _prev must carry across calls
+    ref_blk, gpu_blk = oracle.FreqDemod(scalar), dev.FreqDemod((scalar, True))
+    cuts = [0, 1, 2, 7, 4096, 4097, 30000, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ref, got = ref_blk.work(x[a:b]), gpu_blk.process(x[a:b])
+        if scalar in (oracle.F64, oracle.F32):
+            assert ang_err(got, ref) <= TOL, (a, b)
+        else:
+            assert np.array_equal(got, ref), (a, b)
+    # activate() resets _prev
+    ref_blk.activate(); gpu_blk.reset()
+    ref, got = ref_blk.work(x[:100]), gpu_blk.process(x[:100])
+    if scalar in (oracle.F64, oracle.F32):
+        assert ang_err(got, ref) <= TOL
+    else:
+        assert np.array_equal(got, ref)
+
+
+def test_freqdemod_first_sample_quadrants(oracle, dev):
+    """_prev = 0 at activate: the first output is arg(+-0 +-0j), whose value depends on signs."""
+    for re, im in [(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, 1), (-1, -1), (1, -1)]:
+        x = np.array([[re, im], [0.3, 0.4]], np.float32)
+        ref, got = oracle.FreqDemod(oracle.F32).work(x), dev.FreqDemod("complex_float32").process(x)
+        assert ang_err(got, ref) <= TOL, (re, im, got, ref)
+
+
+# --------------------------------------------------------------------------- #
+# FIR
+# --------------------------------------------------------------------------- #
+def _taps(rng, n, cplx):
+    t = rng.normal(size=n) / np.sqrt(n)
+    return t + 1j * rng.normal(size=n) / np.sqrt(n) if cplx else t
+
+
+@pytest.mark.parametrize("scalar", SCALARS, ids=lambda s: NAMES[s])
+@pytest.mark.parametrize("kind", ["real-REAL", "complex-REAL", "complex-COMPLEX"])
+@pytest.mark.parametrize("L,M", [(1, 1), (1, 3), (3, 1), (3, 2), (2, 3)])
+def test_fir_all_types_polyphase(oracle, dev, scalar, kind, L, M):
+    """Every combination FIRFilterFactory accepts (FIRFilter.cpp:369-384) with rational resampling."""
+    is_complex, ctaps = kind != "real-REAL", kind == "complex-COMPLEX"
+    rng = np.random.default_rng(1000 * scalar + 10 * L + M)
+    ntaps = 21
+    taps = _taps(rng, ntaps, ctaps) * (0.5 if scalar in (oracle.F64, oracle.F32) else 0.9)
+    x = rand_stream(rng, scalar, 4096, is_complex)
+    ref_blk = oracle.Fir(scalar, is_complex, ctaps)
+    gpu_blk = dev.FirFilter((scalar, is_complex), "COMPLEX" if ctaps else "REAL")
+    for b in (ref_blk, gpu_blk):
+        b.set_taps(taps); b.set_decimation(M); b.set_interpolation(L)
+    ref_blk.activate()
+    out_cap = 3 * 4096
+    ref, rc, rp, _ = ref_blk.work(x, out_cap)
+    floats = scalar in (oracle.F64, oracle.F32)
+    gpu_blk.set_algo(dev._lib.FIR_EXACT)
+    got, gc, gp = gpu_blk.process(x, out_cap)
+    assert (gc, gp) == (rc, rp)
+    assert np.array_equal(got, ref)            # bit-exact: integer ring arithmetic / unfused float order
+    if floats:
+        gpu_blk.set_algo(dev._lib.FIR_DIRECT)  # same order with FMA
+        got, gc, gp = gpu_blk.process(x, out_cap)
+        assert (gc, gp) == (rc, rp)
+        assert nerr(got, ref) <= (TOL if scalar == oracle.F32 else 1e-13)
+
+
+def test_fir_anchors(oracle, dev):
+    """SURVEY appendix A anchors: K=63 on 4096 -> 4034/4034; L=3, M=2, 21 taps -> 2730/4095."""
+    rng = np.random.default_rng(5)
+    x = rand_stream(rng, oracle.F32, 4096, True)
+    f = dev.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(_taps(rng, 63, True))
+    _, c, p = f.process(x, 1 << 20)
+    assert (c, p) == (4034, 4034)
+    f = dev.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(_taps(rng, 61, True)); f.set_interpolation(3); f.set_decimation(2)
+    assert f.K == 21
+    _, c, p = f.process(x, 4096)      # the probe's output buffer held 4096 elements
+    assert (c, p) == (2730, 4095)
+
+
+@pytest.mark.parametrize("algo", ["DIRECT", "OLS_FFT", "AUTO"])
+@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 9, 63, 64, 127, 255, 256, 257, 1000, 2049])
+def test_fir_cf32_fast_paths(oracle, dev, algo, ntaps):
+    """LDS-tiled direct kernel and frequency-domain overlap-save kernel vs the oracle."""
+    if algo == "DIRECT" and ntaps > 2049:
+        pytest.skip("direct tile plan")
+    rng = np.random.default_rng(ntaps)
+    n = 3 * 4096 + 777 + ntaps
+    x = rand_stream(rng, oracle.F32, n, True)
+    taps = _taps(rng, ntaps, True)
+    ref_blk = oracle.Fir(oracle.F32, True, True); ref_blk.set_taps(taps); ref_blk.activate()
+    ref, rc, rp, _ = ref_blk.work(x, n)
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(taps)
+    f.set_algo(getattr(dev._lib, "FIR_" + algo))
+    got, gc, gp = f.process(x, n)
+    assert (gc, gp) == (rc, rp) == (n - ntaps + 1, n - ntaps + 1)
+    assert nerr(got, ref) <= TOL, f.last_algo
+
+
+def test_fir_cf32_real_taps_fast(oracle, dev):
+    rng = np.random.default_rng(3)
+    x = rand_stream(rng, oracle.F32, 20000, True)
+    taps = _taps(rng, 127, False)
+    ref_blk = oracle.Fir(oracle.F32, True, False); ref_blk.set_taps(taps); ref_blk.activate()
+    ref, rc, rp, _ = ref_blk.work(x, 20000)
+    for algo in ("FIR_DIRECT", "FIR_OLS_FFT"):
+        f = dev.FirFilter("complex_float32", "REAL"); f.set_taps(taps); f.set_algo(getattr(dev._lib, algo))
+        got, gc, gp = f.process(x, 20000)
+        assert (gc, gp) == (rc, rp)
+        assert nerr(got, ref) <= TOL
+
+
+def test_fir_streaming_equivalence(oracle, dev):
+    """Repeated work() calls with the K-1 tail left un-consumed == one big call (FIRFilter.cpp:305-308)."""
+    rng = np.random.default_rng(9)
+    ntaps, n = 255, 40000
+    x = rand_stream(rng, oracle.F32, n, True)
+    taps = _taps(rng, ntaps, True)
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(taps)
+    whole, _, _ = f.process(x, n)
+    pos, outs = 0, []
+    for avail in (300, 5000, 254, 255, 256, 12345, n):
+        chunk = x[pos:min(n, pos + avail)]
+        y, c, p = f.process(chunk, 1 << 20)
+        outs.append(y); pos += c
+    y, c, p = f.process(x[pos:], 1 << 20)
+    outs.append(y); pos += c
+    got = np.concatenate(outs)
+    assert got.shape == whole.shape
+    assert nerr(got, whole) <= 2e-6   # block boundaries differ between calls (OLS), arithmetic does not
+
+
+def test_fir_output_capacity_limits_consumption(oracle, dev):
+    rng = np.random.default_rng(10)
+    x = rand_stream(rng, oracle.F32, 5000, True)
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(_taps(rng, 31, True)); f.set_decimation(4)
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(np.ones(31)); ref.set_decimation(4); ref.activate()
+    for cap in (0, 1, 7, 100, 10000):
+        _, rc, rp, _ = ref.work(x, cap)
+        _, gc, gp = f.process(x, cap)
+        assert (gc, gp) == (rc, rp)
+
+
+def test_fir_errors(dev):
+    with pytest.raises(ValueError):
+        dev.FirFilter("float32", "COMPLEX")           # FIRFilterFactory: unsupported types
+    f = dev.FirFilter("complex_float32", "COMPLEX")
+    with pytest.raises(ValueError):
+        f.set_taps([])                                 # "taps cannot be empty"
+    with pytest.raises(ValueError):
+        f.set_decimation(0)
+    with pytest.raises(ValueError):
+        f.set_interpolation(0)
+    # default taps {1.0}: pass-through (ctor setTaps, FIRFilter.cpp:125)
+    x = np.arange(20, dtype=np.float32).reshape(10, 2)
+    y, c, p = f.process(x, 100)
+    assert (c, p) == (10, 10) and np.array_equal(y, x)
+
+
+# --------------------------------------------------------------------------- #
+# FFT
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("nbins", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_fft_cf32(oracle, dev, nbins, inverse):
+    rng = np.random.default_rng(nbins)
+    nframes = 5 if nbins >= 1024 else 37
+    x = rand_stream(rng, oracle.F32, nbins * nframes, True)
+    ref = oracle.fft(x, nbins, inverse)
+    got = dev.Fft("complex_float32", nbins, inverse).transform(x)
+    assert nerr(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("nbins", [2, 8, 64, 1024, 4096])
+def test_fft_cf64(oracle, dev, nbins, inverse):
+    rng = np.random.default_rng(nbins + 1)
+    x = rand_stream(rng, oracle.F64, nbins * 3, True)
+    ref = oracle.fft(x, nbins, inverse)
+    got = dev.Fft("complex_float64", nbins, inverse).transform(x)
+    assert nerr(got, ref) <= 1e-13
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("nbins", [2, 4, 8, 16, 32, 128, 1024, 2048, 4096, 16384])
+def test_fft_int16_bit_exact(oracle, dev, nbins, inverse):
+    """kiss_fft -DFIXED_POINT=16: every Q15 rounding reproduced (scaled by 1/N overall)."""
+    rng = np.random.default_rng(nbins + 2)
+    x = rand_stream(rng, oracle.I16, nbins * 3, True)
+    ref = oracle.fft(x, nbins, inverse)
+    got = dev.Fft("complex_int16", nbins, inverse).transform(x)
+    assert np.array_equal(got, ref)
+
+
+def test_fft_kat_reference_vectors(dev):
+    """fft/TestFFT.cpp:14-29 (float) and :95-105,131-132 (int16, result/N)."""
+    x = np.array([[0.4, 0.6], [-0.7, 0.6], [-0.2, 0.8], [0.9, 0.2]], np.float32)
+    want = np.array([[0.4, 2.2], [1.0, 1.4], [0.0, 0.6], [0.2, -1.8]], np.float32)
+    got = dev.Fft("complex_float32", 4, False).transform(x)
+    assert np.max(np.abs(got - want)) < 0.01
+    back = dev.Fft("complex_float32", 4, True).transform(want)
+    assert np.max(np.abs(back - 4 * x)) < 0.01
+    xi = (x * 1000).astype(np.int16)
+    goti = dev.Fft("complex_int16", 4, False).transform(xi)
+    assert np.array_equal(goti, np.array([[100, 550], [250, 350], [0, 150], [50, -450]], np.int16))
+
+
+def test_fft_many_frames_4096(oracle, dev):
+    """more frames than the launch has workgroups: exercises the grid-stride frame loop"""
+    rng = np.random.default_rng(4)
+    nframes = 2048 + 300
+    x = rand_stream(rng, oracle.F32, 4096 * nframes, True)
+    got = dev.Fft("complex_float32", 4096, False).transform(x)
+    # spot-check frames across the whole range against the oracle
+    for f in (0, 1, 2047, 2048, 2049, nframes - 1):
+        ref = oracle.fft(x[f * 4096:(f + 1) * 4096], 4096, False)
+        assert nerr(got[f * 4096:(f + 1) * 4096], ref) <= TOL
+    # round trip: ifft(fft(x)) = N x
+    back = dev.Fft("complex_float32", 4096, True).transform(got)
+    assert nerr(back / 4096.0, x) <= TOL
+
+
+def test_fft_errors(dev):
+    with pytest.raises(ValueError):
+        dev.Fft("complex_int32", 64)       # FFTFactory: unsupported type
+    with pytest.raises(NotImplementedError):
+        dev.Fft("complex_float32", 1000)   # valid in the reference, no device kernel: fails loudly
+
+
+# --------------------------------------------------------------------------- #
+# fused Rotate -> FIR -> FreqDemod
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("ntaps,ctaps", [(127, False), (63, True), (1, False)])
+def test_fm_chain(oracle, dev, ntaps, ctaps):
+    from pothoscomms_amd import taps as tp
+    rng = np.random.default_rng(ntaps)
+    n = 3 * 2047 + 500 + ntaps
+    x = tp.fm_test_signal(n)
+    taps = tp.lowpass(ntaps, 0.1) if not ctaps else tp.complex_bandpass(ntaps, 0.1, 0.03)
+    phase = 0.7
+    # the three reference blocks back to back (oracle)
+    xr = oracle.rotate(x, phase)
+    fir = oracle.Fir(oracle.F32, True, ctaps); fir.set_taps(taps); fir.activate()
+    y, _, _, _ = fir.work(xr, n)
+    ref = oracle.FreqDemod(oracle.F32).work(y)
+    ch = dev.FmChain(); ch.set_phase(phase); ch.set_taps(taps, ctaps)
+    got, c, p = ch.process(x, n)
+    assert (c, p) == (n - ntaps + 1, n - ntaps + 1)
+    assert ang_err(got, ref) <= TOL
+    # split into two calls: carried state
+    ch.reset()
+    cut = 4000
+    g1, c1, _ = ch.process(x[:cut], n)
+    g2, _, _ = ch.process(x[c1:], n)
+    assert ang_err(np.concatenate([g1, g2]), ref) <= TOL
+    del rng

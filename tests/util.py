@@ -1,0 +1,37 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from oracle import oracle as o
+
+SCALARS = [o.F64, o.F32, o.I64, o.I32, o.I16, o.I8]
+NAMES = {o.F64: "float64", o.F32: "float32", o.I64: "int64", o.I32: "int32", o.I16: "int16", o.I8: "int8"}
+TOL = 1e-5  # north_star: within 1e-5 relative for float32, normalised by max|ref|
+
+
+def rand_stream(rng, scalar, n, is_complex, amp=None):
+    """Random stream of `n` elements as (n,2) pairs or (n,) reals of the scalar type."""
+    dt = o.NP_SCALAR[scalar]
+    shape = (n, 2) if is_complex else (n,)
+    if np.issubdtype(dt, np.floating):
+        return rng.uniform(-1, 1, shape).astype(dt)
+    info = np.iinfo(dt)
+    if amp is None:
+        return rng.integers(info.min, info.max + 1, shape, dtype=dt)
+    return rng.integers(-amp, amp + 1, shape).astype(dt)
+
+
+def nerr(got, ref):
+    """max|got-ref| / max|ref| per buffer."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    if ref.size == 0:
+        return 0.0
+    den = np.max(np.abs(ref))
+    return float(np.max(np.abs(got - ref)) / (den if den > 0 else 1.0))
+
+
+def ang_err(got, ref):
+    """max |wrap_pi(got-ref)| / pi (FreqDemod metric: +pi and -pi are the same angle)."""
+    d = np.asarray(got, np.float64) - np.asarray(ref, np.float64)
+    d = (d + np.pi) % (2 * np.pi) - np.pi
+    return float(np.max(np.abs(d)) / np.pi) if d.size else 0.0

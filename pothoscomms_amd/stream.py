@@ -1,0 +1,71 @@
+"""Overlap-save sharding of ONE sample stream across the GPUs of a node.
+
+The reference has no multi-device story (a Pothos block runs on one scheduler thread); the
+FIR loop (filter/FIRFilter.cpp:286-302) makes output n depend on inputs n .. n+K-1 only, so a
+stream of G*C samples splits into G contiguous shards of C samples, shard g needing the LAST
+K-1 samples of shard g-1 as its front halo -- exactly the history the reference keeps in its
+circular input buffer between work() calls (FIRFilter.cpp:305-307).  Rank 0 keeps its own
+K-1 history.  One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on
+ROCm), one grouped send/recv of (K-1)*elem bytes per shard boundary per pass (2,032 B for 255
+taps) and no other data-path collective.
+
+Buffer layout on every rank: one contiguous tensor [halo | C samples] -- the halo sits directly
+in front of the shard so the kernel sees the same "history at the front" buffer as a single-GPU
+call (pcx_fir_process_dev), and the received bytes land in place (no staging copy).
+"""
+import torch
+import torch.distributed as dist
+
+
+class HaloRing:
+    """Neighbour exchange of the tap-length halo (rank r -> r+1), in place.
+
+    Works on any backend/device (the CPU tests run it over gloo): it only moves the last
+    `halo` elements of each rank's buffer into the first `halo` elements of the next rank's.
+    """
+
+    def __init__(self, halo, group=None):
+        self.halo = int(halo)
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def exchange(self, buf):
+        """buf: [halo + C, ...] contiguous.  Returns after the halo is usable on the current stream."""
+        if self.world == 1 or self.halo == 0:
+            return
+        ops = []
+        if self.rank + 1 < self.world:
+            ops.append(dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], self.rank + 1, self.group))
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.irecv, buf[:self.halo], self.rank - 1, self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+class ShardedFir:
+    """A 255-tap-style complex_float32 FIR over one shard of a node-wide stream (M = L = 1)."""
+
+    def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None):
+        from . import device as dv   # the HIP path; raises if libpcx_hip.so is missing
+        self.fir = dv.FirFilter("complex_float32", taps_type)
+        self.fir.set_taps(taps)
+        if algo is not None:
+            self.fir.set_algo(algo)
+        self.K = self.fir.K
+        self.C = int(shard_len)
+        self.ring = HaloRing(self.K - 1, group)
+        self.buf = torch.zeros((self.K - 1 + self.C, 2), dtype=torch.float32, device=device)
+        self.out = torch.empty((self.C, 2), dtype=torch.float32, device=device)
+
+    @property
+    def shard(self):
+        """The C samples this rank owns (a view behind the halo)."""
+        return self.buf[self.K - 1:]
+
+    def step(self):
+        """One pass: halo from the left neighbour, then filter the shard -> C outputs."""
+        self.ring.exchange(self.buf)
+        c, p = self.fir.process_dev(self.buf, self.out, self.K - 1 + self.C, self.C)
+        assert c == self.C and p == self.C, (c, p)
+        return self.out

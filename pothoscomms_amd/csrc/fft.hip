@@ -21,38 +21,45 @@ namespace pcx {
 // --------------------------------------------------------------------------------- //
 template <bool INV>
 __global__ __launch_bounds__(256) void fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                      size_t nframes, fft4k::Tables tb)
+                                                      size_t nframes, const float2 *__restrict__ twtab)
 {
     using namespace fft4k;
-    __shared__ float2 lds[LDS_ELEMS];
+    __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
-    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
-        const float2 *x = in + f * N;
-        float2 *y = out + f * N;
-        float2 v[16];
+    Twiddles tw;
+    load_twiddles(tw, twtab, j);  // once per workgroup; the frame loop issues no table loads
+    size_t f = blockIdx.x;
+    if (f >= nframes) return;
+    cf nx[16];                    // register prefetch of the next frame
+    load_frame<false>(nx, make_rsrc(in + f * N, N * 8), j);
+    for (; f < nframes; f += gridDim.x) {
+        cf v[16];
+        // inverse = conj(FFT(conj(x))) on the forward passes (one set of twiddle registers)
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = x[j + 256 * r];
-        pass1<INV>(v, lds, j);
-        pass2<INV>(v, lds, j, tb);
-        pass3<INV>(v, lds, j, tb);
+        for (int r = 0; r < 16; r++) v[r] = INV ? cf{nx[r].x, -nx[r].y} : nx[r];
+        const size_t fn = f + gridDim.x;
+        if (fn < nframes) load_frame<false>(nx, make_rsrc(in + fn * N, N * 8), j);
+        pass1(v, lds, j, tw);
+        pass2(v, lds, j, tw);
+        pass3(v, lds, j, tw);
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + f * N, N * 8);
 #pragma unroll
-        for (int q = 0; q < 16; q++) y[j + 256 * bin_of(q)] = v[q];
+        for (int q = 0; q < 16; q++)
+            store_cf(ws, (unsigned)(j + 256 * bin_of(q)) * 8u, INV ? cf{v[q].x, -v[q].y} : v[q]);
     }
 }
 
 int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, hipStream_t st)
 {
     if (nframes == 0) return PCX_OK;
-    fft4k::Tables tb;
-    tb.tw2 = static_cast<const float2 *>(tw4096);
-    tb.tw3 = tb.tw2 + 256;
-    // one frame per workgroup; 4 workgroups per CU fit (34.8 KB LDS each), so cap the
-    // grid at 256 CUs x 8 and let workgroups walk frames with a grid stride
-    const unsigned grid = (unsigned)(nframes < 2048 ? nframes : 2048);
+    const float2 *tab = static_cast<const float2 *>(tw4096);
+    // persistent workgroups: LDS (34.8 KB) admits 4 per CU; each walks frames with a grid
+    // stride, keeping its twiddles in registers and the next frame in flight
+    const unsigned grid = (unsigned)(nframes < 1024 ? nframes : 1024);
     if (inverse)
-        hipLaunchKernelGGL(fft4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tb);
+        hipLaunchKernelGGL(fft4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab);
     else
-        hipLaunchKernelGGL(fft4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tb);
+        hipLaunchKernelGGL(fft4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

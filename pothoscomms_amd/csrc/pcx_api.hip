@@ -62,24 +62,23 @@ static int upload(DevBuf &b, const std::vector<T> &v)
     return PCX_OK;
 }
 
-// tables of the radix-16 x3 4096-point transform (fft4096.hpp):
-//   [0, 256)        tw2[r*16 + kk]  = exp(-j 2 pi kk r / 256)
-//   [256, 256+4096) tw3[r*256 + j]  = exp(-j 2 pi j r / 4096)
+// per-lane twiddle table of the radix-16 x3 4096-point transform (fft4096.hpp):
+//   p = 0..5 <-> powers {1,2,3,4,8,12}
+//   tab[(p    ) * 256 + j] = exp(-j 2 pi (j & 15) * pow[p] / 256)     pass 2
+//   tab[(6 + p) * 256 + j] = exp(-j 2 pi  j       * pow[p] / 4096)    pass 3
 static std::vector<float> make_tw4096()
 {
-    std::vector<float> t(2 * (256 + 4096));
+    std::vector<float> t(2 * 12 * 256);
     const double two_pi = 6.283185307179586476925286766559;
-    for (int r = 0; r < 16; r++)
-        for (int kk = 0; kk < 16; kk++) {
-            const double a = -two_pi * (double)(kk * r) / 256.0;
-            t[2 * (r * 16 + kk)] = (float)std::cos(a);
-            t[2 * (r * 16 + kk) + 1] = (float)std::sin(a);
-        }
-    for (int r = 0; r < 16; r++)
+    const int pw[6] = {1, 2, 3, 4, 8, 12};
+    for (int p = 0; p < 6; p++)
         for (int j = 0; j < 256; j++) {
-            const double a = -two_pi * (double)(j * r) / 4096.0;
-            t[2 * (256 + r * 256 + j)] = (float)std::cos(a);
-            t[2 * (256 + r * 256 + j) + 1] = (float)std::sin(a);
+            const double a2 = -two_pi * (double)((j & 15) * pw[p]) / 256.0;
+            t[2 * (p * 256 + j)] = (float)std::cos(a2);
+            t[2 * (p * 256 + j) + 1] = (float)std::sin(a2);
+            const double a3 = -two_pi * (double)(j * pw[p]) / 4096.0;
+            t[2 * ((6 + p) * 256 + j)] = (float)std::cos(a3);
+            t[2 * ((6 + p) * 256 + j) + 1] = (float)std::sin(a3);
         }
     return t;
 }

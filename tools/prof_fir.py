@@ -1,0 +1,26 @@
+"""Minimal driver for rocprofv3: runs the headline FIR workload a few times (no CPU leg)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pothoscomms_amd import _lib, device, taps as tp
+from pothoscomms_amd.stream import ShardedFir
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "fir255"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda", 0)
+C = 64 * 1024 * 1024
+if wl in ("fir255", "direct255"):
+    sf = ShardedFir(tp.c1_taps(), C, dev, "COMPLEX", _lib.FIR_OLS_FFT if wl == "fir255" else _lib.FIR_DIRECT)
+    device.fill_uniform_f32_dev(sf.buf, seed=2, offset=0)
+    for _ in range(n):
+        sf.step()
+elif wl == "fft4096":
+    nframes = 65536
+    x = torch.empty((nframes * 4096, 2), dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    device.fill_uniform_f32_dev(x, seed=3)
+    fft = device.Fft("complex_float32", 4096, False)
+    for _ in range(n):
+        fft.transform_dev(x, y, nframes)
+torch.cuda.synchronize()
+print("done", wl)

@@ -1,0 +1,133 @@
+// ubench.hip -- access-pattern and issue-rate microbenchmarks used to size the kernels
+// (DESIGN.md cites the numbers).  Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ __launch_bounds__(256) void copy16(const float4* __restrict__ in, float4* __restrict__ out, size_t n)
+{
+    size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
+        float4 a = in[i], b = in[i + 256], c = in[i + 512], d = in[i + 768];
+        out[i] = a; out[i + 256] = b; out[i + 512] = c; out[i + 768] = d;
+    }
+}
+// frame-structured copy: one 4096 x float2 frame per workgroup pass, lane j touches j + 256 r (8 B per lane)
+template <int WAVES_HINT>
+__global__ __launch_bounds__(256) void frame_copy8(const float2* __restrict__ in, float2* __restrict__ out, size_t nframes)
+{
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const float2* x = in + f * 4096; float2* y = out + f * 4096;
+        float2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = x[threadIdx.x + 256 * r];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[threadIdx.x + 256 * r] = v[r];
+    }
+}
+// same frame, 16 B per lane: 128 lanes per frame, 2 frames per 256-lane workgroup
+__global__ __launch_bounds__(256) void frame_copy16(const float4* __restrict__ in, float4* __restrict__ out, size_t nframes)
+{
+    const int t = threadIdx.x & 127, h = threadIdx.x >> 7;
+    for (size_t f = 2 * (size_t)blockIdx.x + h; f < nframes; f += 2 * (size_t)gridDim.x) {
+        const float4* x = in + f * 2048; float4* y = out + f * 2048;
+        float4 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = x[t + 128 * r];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[t + 128 * r] = v[r];
+    }
+}
+// frame copy through LDS with barriers (2 exchanges) to mimic the FFT's phase structure
+__global__ __launch_bounds__(256) void frame_copy8_lds(const float2* __restrict__ in, float2* __restrict__ out, size_t nframes)
+{
+    __shared__ float2 lds[4096 + 256];
+    const int j = threadIdx.x;
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const float2* x = in + f * 4096; float2* y = out + f * 4096;
+        float2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = x[j + 256 * r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[17 * j + r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = lds[j + (j >> 4) + 272 * r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds[(j >> 4) * 272 + (j & 15) + 17 * r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = lds[j + (j >> 4) + 272 * r];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[j + 256 * r] = v[r];
+    }
+}
+// VALU issue rate: dependent-free FMA chains
+template <bool PK>
+__global__ __launch_bounds__(256) void fma_rate(float* out, int iters)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a[16];
+    for (int i = 0; i < 16; i++) a[i] = f2{(float)threadIdx.x + i, 1.0f};
+    f2 m = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (PK) a[i] = __builtin_elementwise_fma(a[i], m, c);
+            else { a[i].x = __builtin_fmaf(a[i].x, m.x, c.x); a[i].y = __builtin_fmaf(a[i].y, m.y, c.y); }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 16; i++) s += a[i].x + a[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <typename F>
+static float time_ms(F launch, int reps)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; i++) launch();
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / reps;
+}
+
+int main()
+{
+    const size_t nframes = 32768;            // 1 GiB in + 1 GiB out
+    const size_t bytes = nframes * 4096 * 8;
+    void *in, *out;
+    CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes));
+    CK(hipMemset(in, 1, bytes));
+    const double gb = 2.0 * bytes / 1e9;
+    for (int grid : {1024, 2048, 4096}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, 0, (const float4*)in, (float4*)out, bytes / 16); }, 10);
+        printf("copy16          grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+    }
+    for (int grid : {1024, 2048, 4096, 32768}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(frame_copy8<0>, dim3(grid), dim3(256), 0, 0, (const float2*)in, (float2*)out, nframes); }, 10);
+        printf("frame_copy8     grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+    }
+    for (int grid : {512, 1024, 2048, 16384}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(frame_copy16, dim3(grid), dim3(256), 0, 0, (const float4*)in, (float4*)out, nframes); }, 10);
+        printf("frame_copy16    grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+    }
+    for (int grid : {1024, 2048, 32768}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(frame_copy8_lds, dim3(grid), dim3(256), 0, 0, (const float2*)in, (float2*)out, nframes); }, 10);
+        printf("frame_copy8_lds grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+    }
+    {
+        const int iters = 4096, grid = 256 * 8;
+        float ms = time_ms([&] { hipLaunchKernelGGL(fma_rate<false>, dim3(grid), dim3(256), 0, 0, (float*)out, iters); }, 5);
+        double fl = (double)grid * 256 * iters * 16 * 2 * 2;
+        printf("v_fma_f32    : %.3f ms  %.1f TFLOP/s\n", ms, fl / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(fma_rate<true>, dim3(grid), dim3(256), 0, 0, (float*)out, iters); }, 5);
+        printf("v_pk_fma_f32 : %.3f ms  %.1f TFLOP/s\n", ms, fl / ms / 1e9);
+    }
+    return 0;
+}

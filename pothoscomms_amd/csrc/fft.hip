@@ -20,28 +20,31 @@ namespace pcx {
 // 4096-point complex_float32
 // --------------------------------------------------------------------------------- //
 template <bool INV>
-__global__ __launch_bounds__(256) void fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+__global__ __launch_bounds__(256, 4) void fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                       size_t nframes, const float2 *__restrict__ twtab)
 {
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
-    Twiddles tw;
-    load_twiddles(tw, twtab, j);  // once per workgroup; the frame loop issues no table loads
     size_t f = blockIdx.x;
     if (f >= nframes) return;
+    // once per workgroup: pass-3 twiddles into registers, pass-2 table into LDS (its first
+    // reader sits behind two barriers); the frame loop issues no table loads
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
     cf nx[16];                    // register prefetch of the next frame
     load_frame<false>(nx, make_rsrc(in + f * N, N * 8), j);
     for (; f < nframes; f += gridDim.x) {
         cf v[16];
-        // inverse = conj(FFT(conj(x))) on the forward passes (one set of twiddle registers)
+        // inverse = conj(FFT(conj(x))) on the forward passes (one set of twiddles)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = INV ? cf{nx[r].x, -nx[r].y} : nx[r];
         const size_t fn = f + gridDim.x;
         if (fn < nframes) load_frame<false>(nx, make_rsrc(in + fn * N, N * 8), j);
-        pass1(v, lds, j, tw);
-        pass2(v, lds, j, tw);
-        pass3(v, lds, j, tw);
+        pass1(v, lds, j);
+        pass2(v, lds, j);
+        pass3(v, lds, j, tw3);
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + f * N, N * 8);
 #pragma unroll
         for (int q = 0; q < 16; q++)

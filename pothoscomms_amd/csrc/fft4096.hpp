@@ -16,16 +16,24 @@
 // element per 16 (pad(i) = i + i/16) so pass-1/2 scatter writes (16-lane groups) and the
 // stride-1 gathers are bank-conflict free.
 //
-// Twiddles.  A lane's pass-2/pass-3 twiddles are powers w^r (r = 0..15) of ONE base that
-// depends only on the lane (w = W256^(j&15), resp. W4096^j) -- not on the frame.  Writing
-// r = 4 n1 + n2, w^r = (w^4)^n1 * w^n2: the factor (w^4)^n1 is applied to the inputs, the
-// factor w^n2 after the inner DFT4 (it is common to the four inputs of that DFT4).  So a
-// lane needs only w, w^2, w^3, w^4, w^8, w^12 per pass: 12 values, loaded ONCE per kernel
-// from a [12][256] table (host-generated in double precision, rounded once -- more accurate
-// than kissfft's float-evaluated table, kissfft.hh:21-26) and kept in registers while the
-// persistent workgroup walks its frames.  No table traffic inside the frame loop means the
-// only vector-memory operations in flight are the stream itself, so a register prefetch of
-// the next frame is never stuck behind a table load in the in-order vmcnt queue.
+// Twiddles.  The radix-16 butterfly is two layers of DFT4 (n = 4 n1 + n2, k = k1 + 4 k2).
+// A lane's external twiddle w^n (w = W256^(j&15) in pass 2, W4096^j in pass 3) factors as
+// (w^4)^n1 * w^n2: the first factor goes on the inputs of the inner DFT4 (3 distinct
+// values), the second merges with the butterfly's own W16^(n2 k1) into ONE per-lane factor
+//   c[n2][k1] = w^n2 * W16^(n2 k1)           (12 values)
+// applied between the layers -- 24 complex multiplies per pass, the count of a plain
+// radix-4 FFT, and no separate constant-twiddle step.  All 15 values depend only on the
+// lane, never on the frame, so the persistent workgroup keeps the pass-3 set in registers
+// (30 VGPRs) and the pass-2 set (a function of j & 15 only: 15 x 16 entries) in 1.9 KB of
+// LDS.  Nothing but the sample stream is fetched from global memory inside the frame loop,
+// so a register prefetch of the next frame never queues behind a table load in the
+// in-order vmcnt counter.  Tables are generated on the host in double precision and
+// rounded once (more accurate than kissfft's float-evaluated table, kissfft.hh:21-26).
+//
+// Arithmetic is packed (v_pk_*_f32 on (re, im) register pairs).  The complex multiply and
+// the +-i rotations are written as asm with op_sel / neg modifiers: hipcc otherwise
+// materialises swizzled and negated copies of the lane-constant twiddles in extra
+// registers (it spilled) and spends a v_xor + v_mov per rotation.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -33,114 +41,146 @@ namespace pcx {
 namespace fft4k {
 
 constexpr int N = 4096;
-constexpr int T = 256;                 // lanes per frame
-constexpr int LDS_ELEMS = N + N / 16;  // padded float2 count (34,816 bytes)
-constexpr int TW_TABLE_ELEMS = 12 * 256;
+constexpr int T = 256;                    // lanes per frame
+constexpr int LDS_DATA = N + N / 16;      // padded cf count of the frame image (34,816 B)
+constexpr int LDS_TW2 = 15 * 16;          // pass-2 twiddle table (1,920 B)
+constexpr int LDS_ELEMS = LDS_DATA + LDS_TW2;
+constexpr int TW_TABLE_ELEMS = 15 * 16 + 15 * 256;   // device table: pass-2 block, then pass-3 block
 
-// complex values are native 2-vectors so every complex add/sub is ONE v_pk_add_f32
-typedef float cf __attribute__((ext_vector_type(2)));
+typedef float cf __attribute__((ext_vector_type(2)));   // complex: one v_pk_add_f32 per add
 
-// a * w.  Two packed instructions on the (re, im) register PAIRS as they stand: the
-// operand swizzles (a.yx, w.yy, w.xx) and the sign ride on VOP3P op_sel / neg modifiers.
-// Written as asm because hipcc otherwise materialises the splat / negated twiddle vectors
-// in extra registers and hoists them out of the frame loop (12 lane-constant twiddles
-// became ~60 live VGPRs and spilled).
-__device__ __forceinline__ cf cmul(cf a, cf w)
+// (a, b) <- (a * wa, b * wb): 4 packed instructions, two independent chains interleaved
+__device__ __forceinline__ void cmul2(cf &a, cf &b, cf wa, cf wb)
 {
-    cf t, r;
-    // t = (-a.y * w.y, a.x * w.y)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    // r = (a.x * w.x + t.x, a.y * w.x + t.y)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;
+    cf ra, rb;
+    asm("v_pk_mul_f32 %0, %2, %4 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]\n\t"   // (-a.y w.y, a.x w.y)
+        "v_pk_mul_f32 %1, %3, %5 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"        // (a.x w.x, a.y w.x) + t
+        "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+        : "=&v"(ra), "=&v"(rb)
+        : "v"(a), "v"(b), "v"(wa), "v"(wb));
+    a = ra;
+    b = rb;
 }
-// conj(a * h) = (a.x h.x - a.y h.y, -(a.y h.x + a.x h.y))
-__device__ __forceinline__ cf cmul_conj(cf a, cf h)
+// (a, b) <- (conj(a * ha), conj(b * hb))
+__device__ __forceinline__ void cmul2_conj(cf &a, cf &b, cf ha, cf hb)
 {
-    cf t, r;
-    // t = (-a.y * h.y, -a.x * h.y)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(h));
-    // r = (a.x * h.x + t.x, -a.y * h.x + t.y)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(h), "v"(t));
-    return r;
+    cf ra, rb;
+    asm("v_pk_mul_f32 %0, %2, %4 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"   // (-a.y h.y, -a.x h.y)
+        "v_pk_mul_f32 %1, %3, %5 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]\n\t"      // (a.x h.x, -a.y h.x) + t
+        "v_pk_fma_f32 %1, %3, %5, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+        : "=&v"(ra), "=&v"(rb)
+        : "v"(a), "v"(b), "v"(ha), "v"(hb));
+    a = ra;
+    b = rb;
 }
-// multiply by -i: (x, y) -> (y, -x)
-__device__ __forceinline__ cf mul_mi(cf a) { return cf{a.y, -a.x}; }
+// a + (-i) d = (a.x + d.y, a.y - d.x)   and   a - (-i) d = (a.x - d.y, a.y + d.x)
+__device__ __forceinline__ void addsub_mi(cf &p, cf &m, cf a, cf d)
+{
+    asm("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=&v"(p), "=&v"(m)
+        : "v"(a), "v"(d));
+}
 // a * exp(-i*theta), (c, s) = (cos theta, sin theta) compile-time constants
 __device__ __forceinline__ cf cmul_cs(cf a, float c, float s)
 {
     return cf{__builtin_fmaf(a.x, c, a.y * s), __builtin_fmaf(a.y, c, -a.x * s)};
 }
 
+// forward DFT4 in place
 __device__ __forceinline__ void fft4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
-    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;
-    a1 = t1 + t3;
     a2 = t0 - t2;
-    a3 = t1 - t3;
+    addsub_mi(a1, a3, t1, d);
+}
+// forward DFT4 of (a0, a1, -i*a2, a3): the W16^4 = -i twiddle of the untwiddled butterfly
+__device__ __forceinline__ void fft4_mi2(cf &a0, cf &a1, cf &a2, cf &a3)
+{
+    cf t0, t1;
+    addsub_mi(t0, t1, a0, a2);
+    const cf t2 = a1 + a3, d = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    addsub_mi(a1, a3, t1, d);
 }
 
-// per-lane twiddle powers of one pass: w[0..2] = w, w^2, w^3;  w[3..5] = w^4, w^8, w^12
+// the 15 lane-constant factors of one twiddled pass
 struct LaneTw {
-    cf w[6];
+    cf a[3];    // (w^4)^n1, n1 = 1..3
+    cf c[12];   // c[(n2-1)*4 + k1] = w^n2 * W16^(n2 k1), n2 = 1..3, k1 = 0..3
 };
 
-// Forward 16-point DFT in registers of x[n] * w^n (TW) or x[n] (no external twiddle).
-// Input x[n] at v[n]; output X[k] at v[4*(k & 3) + (k >> 2)].  The inverse transform is
-// taken as conj(FFT(conj(x))) by the callers, so only the forward butterfly exists.
-template <bool TW>
-__device__ __forceinline__ void fft16(cf (&v)[16], const LaneTw &tw)
+// inner layer: DFT4 over n1 for each n2: x[4 n1 + n2] -> y[n2][k1] at v[4 k1 + n2]
+__device__ __forceinline__ void fft16_inner(cf (&v)[16])
+{
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) fft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+}
+// outer layer: DFT4 over n2 for each k1 -> X[k1 + 4 k2] at v[4 k1 + k2]
+__device__ __forceinline__ void fft16_outer(cf (&v)[16])
+{
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) fft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+// 16-point forward DFT of x[n] (no external twiddle).  Output X[k] at v[4*(k&3) + (k>>2)].
+__device__ __forceinline__ void fft16_plain(cf (&v)[16])
 {
     constexpr float C1 = 0.92387953251128673848f;  // cos(pi/8)
     constexpr float S1 = 0.38268343236508978178f;  // sin(pi/8)
     constexpr float R2 = 0.70710678118654752440f;  // cos(pi/4)
-    if (TW) {  // (w^4)^n1 on input n = 4 n1 + n2
-#pragma unroll
-        for (int n1 = 1; n1 < 4; n1++)
-#pragma unroll
-            for (int n2 = 0; n2 < 4; n2++) v[4 * n1 + n2] = cmul(v[4 * n1 + n2], tw.w[2 + n1]);
-    }
-    // inner DFT4 over n1 for each n2: x[4 n1 + n2] -> y[n2][k1] stored at v[4 k1 + n2]
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) fft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
-    if (TW) {  // w^n2, common to the inner DFT4 of column n2
-#pragma unroll
-        for (int n2 = 1; n2 < 4; n2++)
-#pragma unroll
-            for (int k1 = 0; k1 < 4; k1++) v[4 * k1 + n2] = cmul(v[4 * k1 + n2], tw.w[n2 - 1]);
-    }
-    // y[n2][k1] *= W16^(n2 k1)
+    fft16_inner(v);
+    // y[n2][k1] *= W16^(n2 k1); e = n2 k1 = 4 (k1 = 2, n2 = 2) rides inside fft4_mi2
     v[4 * 1 + 1] = cmul_cs(v[4 * 1 + 1], C1, S1);    // e = 1
     v[4 * 1 + 2] = cmul_cs(v[4 * 1 + 2], R2, R2);    // e = 2
     v[4 * 1 + 3] = cmul_cs(v[4 * 1 + 3], S1, C1);    // e = 3
     v[4 * 2 + 1] = cmul_cs(v[4 * 2 + 1], R2, R2);    // e = 2
-    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);             // e = 4
     v[4 * 2 + 3] = cmul_cs(v[4 * 2 + 3], -R2, R2);   // e = 6
     v[4 * 3 + 1] = cmul_cs(v[4 * 3 + 1], S1, C1);    // e = 3
     v[4 * 3 + 2] = cmul_cs(v[4 * 3 + 2], -R2, R2);   // e = 6
     v[4 * 3 + 3] = cmul_cs(v[4 * 3 + 3], -C1, -S1);  // e = 9
-    // outer DFT4 over n2 for each k1: -> X[k1 + 4 k2] at v[4 k1 + k2]
+    fft4(v[0], v[1], v[2], v[3]);
+    fft4(v[4], v[5], v[6], v[7]);
+    fft4_mi2(v[8], v[9], v[10], v[11]);
+    fft4(v[12], v[13], v[14], v[15]);
+}
+// 16-point forward DFT of x[n] * w^n with the lane's factors in `tw`
+__device__ __forceinline__ void fft16_tw(cf (&v)[16], const LaneTw &tw)
+{
 #pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) fft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    for (int n1 = 1; n1 < 4; n1++) {
+        cmul2(v[4 * n1 + 0], v[4 * n1 + 1], tw.a[n1 - 1], tw.a[n1 - 1]);
+        cmul2(v[4 * n1 + 2], v[4 * n1 + 3], tw.a[n1 - 1], tw.a[n1 - 1]);
+    }
+    fft16_inner(v);
+#pragma unroll
+    for (int n2 = 1; n2 < 4; n2++) {
+        cmul2(v[4 * 0 + n2], v[4 * 1 + n2], tw.c[(n2 - 1) * 4 + 0], tw.c[(n2 - 1) * 4 + 1]);
+        cmul2(v[4 * 2 + n2], v[4 * 3 + n2], tw.c[(n2 - 1) * 4 + 2], tw.c[(n2 - 1) * 4 + 3]);
+    }
+    fft16_outer(v);
 }
 // register index q holds output bin k = bin_of(q)
 __device__ __forceinline__ constexpr int bin_of(int q) { return (q >> 2) + 4 * (q & 3); }
 
-// table layout (device global memory, forward sign), p = 0..5 <-> powers {1,2,3,4,8,12}:
-//   tab[(p    ) * 256 + j] = exp(-j 2 pi (j & 15) * pow[p] / 256)     pass 2
-//   tab[(6 + p) * 256 + j] = exp(-j 2 pi  j       * pow[p] / 4096)    pass 3
-struct Twiddles {
-    LaneTw p2, p3;
-};
-__device__ __forceinline__ void load_twiddles(Twiddles &t, const float2 *__restrict__ tab, int j)
+// device table (forward sign), p = 0..14: p < 3 -> (w^4)^(p+1); p = 3 + (n2-1)*4 + k1 -> c[n2][k1]
+//   tab[p * 16 + kk]              w = exp(-j 2 pi kk / 256)     pass 2   (240 entries)
+//   tab[240 + p * 256 + j]        w = exp(-j 2 pi j / 4096)     pass 3   (3840 entries)
+__device__ __forceinline__ void load_pass3_twiddles(LaneTw &t, const float2 *__restrict__ tab, int j)
 {
-    const cf *tb = reinterpret_cast<const cf *>(tab);
+    const cf *tb = reinterpret_cast<const cf *>(tab) + LDS_TW2;
 #pragma unroll
-    for (int p = 0; p < 6; p++) {
-        t.p2.w[p] = tb[p * 256 + j];
-        t.p3.w[p] = tb[(6 + p) * 256 + j];
-    }
+    for (int p = 0; p < 3; p++) t.a[p] = tb[p * 256 + j];
+#pragma unroll
+    for (int p = 0; p < 12; p++) t.c[p] = tb[(3 + p) * 256 + j];
+}
+// copy the pass-2 table into this workgroup's LDS (call once, before the first pass 2)
+__device__ __forceinline__ void stage_pass2_twiddles(cf *lds, const float2 *__restrict__ tab, int j)
+{
+    if (j < LDS_TW2) lds[LDS_DATA + j] = reinterpret_cast<const cf *>(tab)[j];
 }
 
 // ---- stream access through buffer descriptors (SRSRC) ----
@@ -182,33 +222,39 @@ __device__ __forceinline__ void store_cf(__amdgpu_buffer_rsrc_t rs, unsigned vof
 }
 
 // pass 1: v[r] = x[j + 256 r] on entry; leaves the pass-1 result in LDS
-__device__ __forceinline__ void pass1(cf (&v)[16], cf *lds, int j, const Twiddles &t)
+__device__ __forceinline__ void pass1(cf (&v)[16], cf *lds, int j)
 {
-    fft16<false>(v, t.p2);
+    fft16_plain(v);
     __syncthreads();  // previous readers of this LDS image are done
 #pragma unroll
     for (int q = 0; q < 16; q++) lds[17 * j + bin_of(q)] = v[q];  // pad(16 j + k) = 17 j + k
 }
-__device__ __forceinline__ void pass2(cf (&v)[16], cf *lds, int j, const Twiddles &t)
+__device__ __forceinline__ void pass2(cf (&v)[16], cf *lds, int j)
 {
     __syncthreads();
     const int rb = j + (j >> 4);  // pad(j + 256 r) = rb + 272 r
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
-    fft16<true>(v, t.p2);
+    LaneTw tw;                    // this lane's pass-2 factors: 16 distinct rows, broadcast reads
+    const cf *t2 = lds + LDS_DATA + (j & 15);
+#pragma unroll
+    for (int p = 0; p < 3; p++) tw.a[p] = t2[p * 16];
+#pragma unroll
+    for (int p = 0; p < 12; p++) tw.c[p] = t2[(3 + p) * 16];
+    fft16_tw(v, tw);
     __syncthreads();
     const int wb = (j >> 4) * 272 + (j & 15);  // pad((j>>4)*256 + kk + 16 k) = wb + 17 k
 #pragma unroll
     for (int q = 0; q < 16; q++) lds[wb + 17 * bin_of(q)] = v[q];
 }
 // pass 3: on exit v[q] = X[j + 256 * bin_of(q)]
-__device__ __forceinline__ void pass3(cf (&v)[16], const cf *lds, int j, const Twiddles &t)
+__device__ __forceinline__ void pass3(cf (&v)[16], const cf *lds, int j, const LaneTw &tw3)
 {
     __syncthreads();
     const int rb = j + (j >> 4);
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
-    fft16<true>(v, t.p3);
+    fft16_tw(v, tw3);
 }
 
 }  // namespace fft4k

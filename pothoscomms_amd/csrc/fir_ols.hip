@@ -19,53 +19,61 @@
 
 namespace pcx {
 
-// TAIL=false: every block this launch touches is full (all 4096 inputs inside the buffer,
-// all S outputs wanted).  TAIL=true is the ragged last block: same code, the buffer
-// descriptors' range check zero-fills the missing inputs and drops the surplus outputs.
-template <bool TAIL>
+// One launch covers the whole call.  Full blocks take the fast load path; the ragged last
+// block (fewer than 4096 inputs left / fewer than S outputs wanted) takes the range-checked
+// load path -- a wave-uniform choice per block.  Stores always go through the descriptor's
+// range check, which drops both the K-1 aliased samples and anything past n_out.
 __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Km1,
-                                                                  const float2 *__restrict__ twtab, size_t b0, size_t nblocks)
+                                                                  const float2 *__restrict__ twtab, size_t nfull, size_t nblocks)
 {
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - Km1);
-    size_t b = b0 + blockIdx.x;
+    size_t b = blockIdx.x;
     if (b >= nblocks) return;
-    // loop invariants of the persistent workgroup, in registers: the lane's twiddles and its
-    // 16 bins of H.  Nothing but the stream itself is loaded inside the loop.
-    Twiddles tw;
-    load_twiddles(tw, twtab, j);
+    // loop invariants of the persistent workgroup: the lane's pass-3 twiddles and its 16 bins
+    // of H in registers, the pass-2 twiddle table in LDS.  Nothing but the stream itself is
+    // loaded from global memory inside the loop.
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
     cf H[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
-    auto in_rsrc = [&](size_t blk) {
+    auto fetch = [&](cf (&dst)[16], size_t blk) {
         const size_t left = in_elems - blk * S;   // samples from the block start to the end of the buffer
-        return make_rsrc(in + blk * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8));
+        if (blk < nfull) load_frame<false>(dst, make_rsrc(in + blk * S, N * 8), j);
+        else load_frame<true>(dst, make_rsrc(in + blk * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8)), j);
     };
     cf nx[16];
-    load_frame<TAIL>(nx, in_rsrc(b), j);
+    fetch(nx, b);
     for (; b < nblocks; b += gridDim.x) {
         cf v[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = nx[r];
         const size_t bn = b + gridDim.x;
-        if (bn < nblocks) load_frame<TAIL>(nx, in_rsrc(bn), j);  // in flight during this block's math
-        pass1(v, lds, j, tw);
-        pass2(v, lds, j, tw);
-        pass3(v, lds, j, tw);
+        if (bn < nblocks) fetch(nx, bn);   // in flight during this block's math
+        pass1(v, lds, j);
+        pass2(v, lds, j);
+        pass3(v, lds, j, tw3);
         // spectrum times H, re-ordered into natural register order for the next pass 1.
         // The inverse transform runs on the FORWARD passes: IFFT(z) = conj(FFT(conj(z))), so
-        // one set of twiddles serves both directions (conjugated copies would double the
-        // loop-invariant registers).  u = conj(v * H); the final conj rides on the store.
+        // one set of twiddles serves both directions.  u = conj(v * H); the final conj rides
+        // on the store.
         cf u[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) u[bin_of(q)] = cmul_conj(v[q], H[bin_of(q)]);
-        pass1(u, lds, j, tw);
-        pass2(u, lds, j, tw);
-        pass3(u, lds, j, tw);
+        for (int q = 0; q < 16; q += 2) {
+            const int k0 = bin_of(q), k1 = bin_of(q + 1);
+            u[k0] = v[q];
+            u[k1] = v[q + 1];
+            cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
+        }
+        pass1(u, lds, j);
+        pass2(u, lds, j);
+        pass3(u, lds, j, tw3);
         // time sample i of the block is output b*S + i - (K-1).  For i < K-1 (circularly
         // aliased) the unsigned byte offset wraps far beyond num_records and the store is
         // dropped by the range check, as are outputs past n_out in the last block.
@@ -91,17 +99,10 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     size_t nfull = n_out / S;
     while (nfull > 0 && (nfull - 1) * S + 4096 > in_elems) nfull--;
     const size_t nblocks = (n_out + S - 1) / S;
-    if (nfull > 0) {
-        const unsigned grid = (unsigned)(nfull < 768 ? nfull : 768);   // 3 persistent workgroups per CU
-        hipLaunchKernelGGL(fir_cf32_ols4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems,
-                           (float2 *)out, n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, (size_t)0, nfull);
-        PCX_LAUNCH_CHECK();
-    }
-    if (nblocks > nfull) {
-        hipLaunchKernelGGL(fir_cf32_ols4096_kernel<true>, dim3((unsigned)(nblocks - nfull)), dim3(256), 0, st, (const float2 *)in,
-                           in_elems, (float2 *)out, n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
-        PCX_LAUNCH_CHECK();
-    }
+    const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);   // 3 persistent workgroups per CU
+    hipLaunchKernelGGL(fir_cf32_ols4096_kernel, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                       n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
+    PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
 

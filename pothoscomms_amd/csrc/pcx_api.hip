@@ -62,24 +62,31 @@ static int upload(DevBuf &b, const std::vector<T> &v)
     return PCX_OK;
 }
 
-// per-lane twiddle table of the radix-16 x3 4096-point transform (fft4096.hpp):
-//   p = 0..5 <-> powers {1,2,3,4,8,12}
-//   tab[(p    ) * 256 + j] = exp(-j 2 pi (j & 15) * pow[p] / 256)     pass 2
-//   tab[(6 + p) * 256 + j] = exp(-j 2 pi  j       * pow[p] / 4096)    pass 3
+// lane-constant twiddle table of the radix-16 x3 4096-point transform (fft4096.hpp):
+//   p = 0..14:  p < 3 -> (w^4)^(p+1);   p = 3 + (n2-1)*4 + k1 -> w^n2 * W16^(n2 k1)
+//   tab[p * 16 + kk]        with w = exp(-j 2 pi kk / 256)    (pass 2, 240 entries)
+//   tab[240 + p * 256 + j]  with w = exp(-j 2 pi j / 4096)    (pass 3, 3840 entries)
 static std::vector<float> make_tw4096()
 {
-    std::vector<float> t(2 * 12 * 256);
+    std::vector<float> t(2 * (15 * 16 + 15 * 256));
     const double two_pi = 6.283185307179586476925286766559;
-    const int pw[6] = {1, 2, 3, 4, 8, 12};
-    for (int p = 0; p < 6; p++)
-        for (int j = 0; j < 256; j++) {
-            const double a2 = -two_pi * (double)((j & 15) * pw[p]) / 256.0;
-            t[2 * (p * 256 + j)] = (float)std::cos(a2);
-            t[2 * (p * 256 + j) + 1] = (float)std::sin(a2);
-            const double a3 = -two_pi * (double)(j * pw[p]) / 4096.0;
-            t[2 * ((6 + p) * 256 + j)] = (float)std::cos(a3);
-            t[2 * ((6 + p) * 256 + j) + 1] = (float)std::sin(a3);
+    auto angle = [&](int p, double base /* turns per unit of w */) {
+        if (p < 3) return base * 4.0 * (p + 1);
+        const int n2 = (p - 3) / 4 + 1, k1 = (p - 3) % 4;
+        return base * n2 + (double)(n2 * k1) / 16.0;
+    };
+    for (int p = 0; p < 15; p++) {
+        for (int kk = 0; kk < 16; kk++) {
+            const double a = -two_pi * angle(p, (double)kk / 256.0);
+            t[2 * (p * 16 + kk)] = (float)std::cos(a);
+            t[2 * (p * 16 + kk) + 1] = (float)std::sin(a);
         }
+        for (int j = 0; j < 256; j++) {
+            const double a = -two_pi * angle(p, (double)j / 4096.0);
+            t[2 * (240 + p * 256 + j)] = (float)std::cos(a);
+            t[2 * (240 + p * 256 + j) + 1] = (float)std::sin(a);
+        }
+    }
     return t;
 }
 

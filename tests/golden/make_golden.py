@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden.npz -- the committed golden vectors for the hot path.
+
+Run in the BUILD container only (needs /root/reference through oracle/_ref):
+    make -C oracle all _ref && python tests/golden/make_golden.py
+
+Two kinds of vectors, all plain data (inputs + expected outputs):
+
+ 1. The known-answer vectors the reference's OWN tests hold for this path, transcribed as
+    data with the expectation formula each test states:
+      fft/TestFFT.cpp:14-29,64-80      4-point float KAT (+ inverse = input*N)
+      fft/TestFFT.cpp:95-105,131-132   int16 KAT (forward = result/N), :155-156 inverse
+      math/TestRotate.cpp:28-32,50-53  13 points (10i, -20i), phase in {0, pi/2, pi, 3pi/2}
+      math/TestScale.cpp:28-31,49-52   13 points 10i, factor in {-1,-.5,0,.5,1}
+      math/TestAbs.cpp:28-31,63-66     100 values i-50 (complex: re-typed as 50 pairs)
+      math/TestConjugate.cpp:30-34     150 pairs (the test uses unseeded rand()%100; a
+                                       seeded stand-in of the same range is stored)
+      math/TestAngle.cpp:30-35,53-65   13 points mag*polar(1, i*pi/5) (pins getAngle, which
+                                       FreqDemod shares)
+ 2. Outputs of the compiled reference (oracle/_ref: kissfft.hh, kiss_fft.c -DFIXED_POINT=16,
+    fxpt_atan2.cpp, FxptHelpers.hpp built from /root/reference where they lie) on seeded
+    random inputs -- these pin the oracle bit-for-bit on the GPU box, where the reference
+    sources do not exist.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as o  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz")
+INT_TYPES = {"int8": np.int8, "int16": np.int16, "int32": np.int32, "int64": np.int64}
+ALL_TYPES = dict(INT_TYPES, float32=np.float32, float64=np.float64)
+
+
+def main():
+    assert o.ref() is not None, "oracle/_ref is not built (needs /root/reference)"
+    g = {}
+    rng = np.random.default_rng(20240101)
+
+    # ---- 1. reference test vectors ------------------------------------------------
+    kat_in = np.array([[0.4, 0.6], [-0.7, 0.6], [-0.2, 0.8], [0.9, 0.2]])
+    kat_out = np.array([[0.4, 2.2], [1.0, 1.4], [0.0, 0.6], [0.2, -1.8]])   # numpy.fft.fft of kat_in
+    g["fft_kat_in"], g["fft_kat_out"] = kat_in, kat_out
+
+    i13 = np.arange(13, dtype=np.float64)
+    for name, dt in ALL_TYPES.items():
+        # TestRotate: pIn[i] = (Type(10*i), Type(-20*i)) -- integer types wrap like the C++ cast
+        xin = np.stack([10 * i13, -20 * i13], 1).astype(np.int64).astype(dt)
+        g["rotate_in_" + name] = xin
+        for pi_, phase in enumerate([0.0, np.pi / 2, np.pi, 3 * np.pi / 2]):
+            z = (xin[:, 0].astype(np.float64) + 1j * xin[:, 1].astype(np.float64)) * np.exp(1j * phase)
+            # expected = std::complex<Type>(input * polar(1, phase)): C++ double->integer casts truncate
+            exp = np.stack([z.real, z.imag], 1)
+            exp = np.trunc(exp) if name.startswith("int") else exp
+            g["rotate_exp_%s_%d" % (name, pi_)] = exp   # float64, compared with tolerance 1 (TestRotate.cpp:53)
+        sin = (10 * i13).astype(np.int64).astype(dt)
+        g["scale_in_" + name] = sin
+        for fi, factor in enumerate([-1.0, -0.5, 0.0, 0.5, 1.0]):
+            e = sin.astype(np.float64) * factor
+            g["scale_exp_%s_%d" % (name, fi)] = np.trunc(e) if name.startswith("int") else e
+        # TestAbs: T(i) - T(50); expected = getAbs (the compiled reference)
+        av = (np.arange(100) - 50).astype(dt)
+        g["abs_in_" + name] = av
+        g["abs_real_exp_" + name] = o.ref_abs(av, False)
+        g["abs_cplx_exp_" + name] = o.ref_abs(av.reshape(50, 2), True)
+        # TestAngle inputs (complex<Type>(mag*polar(1, angle))); expected std::arg of the typed input
+        ang = i13 * (np.pi / 5)
+        z = (i13 * 1000) * np.exp(1j * ang)
+        zin = np.stack([z.real, z.imag], 1)
+        zin = np.trunc(zin).astype(np.int64).astype(dt) if name.startswith("int") else zin.astype(dt)
+        g["angle_in_" + name] = zin
+        g["angle_ref_" + name] = o.ref_angle(zin)      # what getAngle returns (compiled reference)
+    g["conj_in"] = rng.integers(0, 100, (150, 2)).astype(np.float32)
+
+    # ---- 2. compiled-reference outputs on seeded inputs ----------------------------
+    for n in (2, 3, 4, 5, 8, 9, 15, 16, 20, 64, 100, 210, 256, 1024, 4096):
+        for inv in (0, 1):
+            nf = 2 if n < 256 else 1
+            x32 = rng.uniform(-1, 1, (nf * n, 2)).astype(np.float32)
+            x64 = rng.uniform(-1, 1, (nf * n, 2))
+            x16 = rng.integers(-32768, 32768, (nf * n, 2)).astype(np.int16)
+            g["fft_f32_in_%d_%d" % (n, inv)] = x32
+            g["fft_f32_out_%d_%d" % (n, inv)] = o.ref_fft(x32, n, bool(inv))
+            if n <= 256:
+                g["fft_f64_in_%d_%d" % (n, inv)] = x64
+                g["fft_f64_out_%d_%d" % (n, inv)] = o.ref_fft(x64, n, bool(inv))
+            g["fft_i16_in_%d_%d" % (n, inv)] = x16
+            g["fft_i16_out_%d_%d" % (n, inv)] = o.ref_fft(x16, n, bool(inv))
+    yx = rng.integers(-32768, 32768, (2048, 2)).astype(np.int16)
+    yx[:64] = rng.integers(-3, 4, (64, 2))
+    yx[64:72] = [[0, 0], [1, 1], [-1, -1], [-32768, -32768], [32767, 32767], [-32768, 32767], [0, -32768], [-32768, 0]]
+    R = o.ref()
+    g["atan2_in"] = yx
+    g["atan2_out"] = np.array([R.ref_fxpt_atan2(int(y), int(x)) for y, x in yx], dtype=np.uint16)
+    for name, dt in ALL_TYPES.items():
+        if name.startswith("int"):
+            info = np.iinfo(dt)
+            z = rng.integers(info.min, info.max + 1, (512, 2), dtype=dt)
+            z[:64] = rng.integers(-100, 100, (64, 2))
+        else:
+            z = (rng.normal(size=(512, 2)) * np.exp(rng.uniform(-20, 20, (512, 1)))).astype(dt)
+        g["rand_in_" + name] = z
+        g["rand_angle_" + name] = o.ref_angle(z)
+        g["rand_abs_cplx_" + name] = o.ref_abs(z, True)
+        g["rand_abs_real_" + name] = o.ref_abs(np.ascontiguousarray(z[:, 0]), False)
+
+    np.savez_compressed(OUT, **g)
+    print("wrote %s: %d arrays, %d bytes" % (OUT, len(g), os.path.getsize(OUT)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+/*
+ * pcx_blocks.h -- runner ABI of libpcx_blocks.so: drives the MI355X-backed /comms blocks
+ * (pothoscomms_amd/csrc/blocks/comms_blocks.cpp) the way the Pothos scheduler would, for hosts
+ * without PothosCore (the test-suite, language bindings).  Inside a real Pothos install the
+ * blocks are loaded as a plugin module instead and this ABI is not used.
+ *
+ * One call = one scheduler action on one block: make (BlockRegistry::make), call a registered
+ * setter/getter by name (Proxy call), activate(), one work() on planted port buffers followed
+ * by propagateLabels().  Buffers are HOST memory, exactly like Pothos BufferChunks.
+ */
+#ifndef PCX_BLOCKS_H
+#define PCX_BLOCKS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCXB_API __attribute__((visibility("default")))
+
+typedef struct pcxb_block pcxb_block;
+
+/* Label::data payload kinds */
+enum { PCXB_NONE = 0, PCXB_SIZE = 1, PCXB_DOUBLE = 2, PCXB_STRING = 3 };
+typedef struct pcxb_label {
+    char id[32];       /* Label::id */
+    uint64_t index;    /* Label::index */
+    uint64_t width;    /* Label::width */
+    int kind;          /* which of the fields below holds Label::data */
+    uint64_t uval;
+    double dval;
+    char sval[32];
+} pcxb_label;
+
+PCXB_API const char *pcxb_last_error(void);
+/* registry: 1 if a factory is registered under `path` (e.g. "/comms/fir_filter") */
+PCXB_API int pcxb_registry_has(const char *path);
+PCXB_API size_t pcxb_registry_count(void);
+PCXB_API const char *pcxb_registry_path(size_t i);
+
+/* BlockRegistry::make(path, dtype, ...).  dtype is a Pothos DType name ("complex_float32"),
+ * dimension its vector dimension.  The remaining factory arguments by block:
+ *   fir_filter: sarg = tapsType ("REAL"/"COMPLEX");  fft: num_bins, inverse;  others: none */
+PCXB_API int pcxb_make(const char *path, const char *dtype, size_t dimension, const char *sarg, size_t num_bins,
+                       int inverse, pcxb_block **out);
+PCXB_API int pcxb_destroy(pcxb_block *b);
+
+/* registered calls (registerCall names): one argument of the given kind, or a getter */
+PCXB_API int pcxb_call_double(pcxb_block *b, const char *name, double v);
+PCXB_API int pcxb_call_size(pcxb_block *b, const char *name, size_t v);
+PCXB_API int pcxb_call_bool(pcxb_block *b, const char *name, int v);
+PCXB_API int pcxb_call_string(pcxb_block *b, const char *name, const char *v);
+PCXB_API int pcxb_call_taps(pcxb_block *b, const char *name, const double *taps, size_t n, int is_complex);
+PCXB_API int pcxb_get_double(pcxb_block *b, const char *name, double *out);
+PCXB_API int pcxb_get_size(pcxb_block *b, const char *name, size_t *out);
+PCXB_API int pcxb_get_bool(pcxb_block *b, const char *name, int *out);
+PCXB_API int pcxb_get_string(pcxb_block *b, const char *name, char *out, size_t cap);
+PCXB_API int pcxb_get_taps(pcxb_block *b, const char *name, double *out, size_t cap_doubles, size_t *n, int is_complex);
+
+PCXB_API int pcxb_activate(pcxb_block *b);
+/* port 0 types and the buffer managers the block requests */
+PCXB_API int pcxb_port_dtype(pcxb_block *b, int is_output, char *name, size_t cap, size_t *dimension, size_t *bytes);
+PCXB_API int pcxb_buffer_manager(pcxb_block *b, int is_output, char *name, size_t cap, size_t *buffer_size);
+/* the reserve a block asked for at construction time (FFT: numBins); SIZE_MAX = none */
+PCXB_API int pcxb_initial_reserve(pcxb_block *b, size_t *reserve);
+
+/*
+ * One work() call: plant `in` (in_elems elements, labels attached) and `out` (room for
+ * out_elems), set workInfo().minElements = min(in_elems, out_elems), call work(), then
+ * propagateLabels() on the labels inside the consumed region.
+ *   *reserve = value passed to setReserve during this call, SIZE_MAX if it was not called
+ *   posted labels (at most cap) are copied to `posted`, *nposted = their number
+ */
+PCXB_API int pcxb_work(pcxb_block *b, const void *in, size_t in_elems, const pcxb_label *labels, size_t nlabels,
+                       void *out, size_t out_elems, size_t *consumed, size_t *produced, size_t *reserve,
+                       pcxb_label *posted, size_t cap, size_t *nposted);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCX_BLOCKS_H */

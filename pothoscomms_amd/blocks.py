@@ -1,0 +1,227 @@
+"""Python face of the host-side block layer (libpcx_blocks.so, include/pcx_blocks.h).
+
+`make(path, dtype, ...)` is BlockRegistry::make for the MI355X-backed /comms blocks; the
+returned Block exposes the registered calls by name (`call("setTaps", taps)`), `activate()`
+and `work(inbuf, out_elems, labels)` -- one scheduler work() on host buffers, returning what
+the block consumed / produced / reserved and the labels it posted.  Used by the tests to show
+the blocks behave like the reference blocks; inside Pothos the same C++ blocks load as a
+plugin module and this wrapper is not involved.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .device import NP_SCALAR, as_pairs, parse_dtype
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BLOCKS_LIB_PATH = os.path.join(_HERE, "libpcx_blocks.so")
+NONE, SIZE, DOUBLE, STRING = 0, 1, 2, 3
+_SIZE_MAX = C.c_size_t(-1).value
+
+
+class PcxbLabel(C.Structure):
+    _fields_ = [("id", C.c_char * 32), ("index", C.c_uint64), ("width", C.c_uint64), ("kind", C.c_int),
+                ("uval", C.c_uint64), ("dval", C.c_double), ("sval", C.c_char * 32)]
+
+
+_blib = None
+
+
+def load():
+    global _blib
+    if _blib is not None:
+        return _blib
+    _lib.load()    # one HIP runtime per process, libpcx_hip.so first
+    if not os.path.exists(BLOCKS_LIB_PATH):
+        raise ImportError("%s is missing: build with make -C pothoscomms_amd/csrc" % BLOCKS_LIB_PATH)
+    L = C.CDLL(BLOCKS_LIB_PATH)
+    vp, sz, i, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
+    L.pcxb_last_error.restype = cp
+    L.pcxb_registry_has.argtypes = [cp]
+    L.pcxb_registry_count.restype = sz
+    L.pcxb_registry_path.restype = cp
+    L.pcxb_registry_path.argtypes = [sz]
+    L.pcxb_make.argtypes = [cp, cp, sz, cp, sz, i, C.POINTER(vp)]
+    L.pcxb_destroy.argtypes = [vp]
+    L.pcxb_call_double.argtypes = [vp, cp, C.c_double]
+    L.pcxb_call_size.argtypes = [vp, cp, sz]
+    L.pcxb_call_bool.argtypes = [vp, cp, i]
+    L.pcxb_call_string.argtypes = [vp, cp, cp]
+    L.pcxb_call_taps.argtypes = [vp, cp, vp, sz, i]
+    L.pcxb_get_double.argtypes = [vp, cp, C.POINTER(C.c_double)]
+    L.pcxb_get_size.argtypes = [vp, cp, C.POINTER(sz)]
+    L.pcxb_get_bool.argtypes = [vp, cp, C.POINTER(i)]
+    L.pcxb_get_string.argtypes = [vp, cp, cp, sz]
+    L.pcxb_get_taps.argtypes = [vp, cp, vp, sz, C.POINTER(sz), i]
+    L.pcxb_activate.argtypes = [vp]
+    L.pcxb_port_dtype.argtypes = [vp, i, cp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.pcxb_buffer_manager.argtypes = [vp, i, cp, sz, C.POINTER(sz)]
+    L.pcxb_initial_reserve.argtypes = [vp, C.POINTER(sz)]
+    L.pcxb_work.argtypes = [vp, vp, sz, C.POINTER(PcxbLabel), sz, vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
+                            C.POINTER(PcxbLabel), sz, C.POINTER(sz)]
+    _blib = L
+    return L
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = load().pcxb_last_error().decode("utf-8", "replace")
+    if rc == _lib.ERR_ARG:
+        raise _lib.InvalidArgument(rc, msg)
+    if rc == _lib.ERR_UNSUPPORTED:
+        raise _lib.Unsupported(rc, msg)
+    raise _lib.PcxError(rc, msg)
+
+
+def registry_paths():
+    L = load()
+    return sorted(L.pcxb_registry_path(i).decode() for i in range(L.pcxb_registry_count()))
+
+
+class Label:
+    """(id, index, width, data) -- data is None, an int (size_t), a float or a str."""
+
+    def __init__(self, id, index, data=None, width=1):
+        self.id, self.index, self.data, self.width = id, int(index), data, int(width)
+
+    def __repr__(self):
+        return "Label(%r, index=%d, data=%r, width=%d)" % (self.id, self.index, self.data, self.width)
+
+    def __eq__(self, o):
+        return (self.id, self.index, self.data, self.width) == (o.id, o.index, o.data, o.width)
+
+    def _to_c(self, c):
+        c.id = self.id.encode()
+        c.index, c.width = self.index, self.width
+        if self.data is None:
+            c.kind = NONE
+        elif isinstance(self.data, bool) or isinstance(self.data, (int, np.integer)):
+            c.kind, c.uval = SIZE, int(self.data)
+        elif isinstance(self.data, float):
+            c.kind, c.dval = DOUBLE, self.data
+        else:
+            c.kind, c.sval = STRING, str(self.data).encode()
+
+    @staticmethod
+    def _from_c(c):
+        data = None
+        if c.kind == SIZE:
+            data = int(c.uval)
+        elif c.kind == DOUBLE:
+            data = float(c.dval)
+        elif c.kind == STRING:
+            data = c.sval.decode()
+        return Label(c.id.decode(), c.index, data, c.width)
+
+
+class Block:
+    def __init__(self, path, dtype, *args, dimension=1):
+        L = load()
+        self.path = path
+        self.dtype = dtype
+        sarg, nbins, inverse = None, 0, 0
+        if path.endswith("fir_filter"):
+            sarg = (args[0] if args else "").encode()
+        elif path == "/comms/fft":
+            nbins, inverse = int(args[0]), int(bool(args[1])) if len(args) > 1 else 0
+        self._h = C.c_void_p()
+        _check(L.pcxb_make(path.encode(), dtype.encode(), dimension, sarg, nbins, inverse, C.byref(self._h)))
+        self.in_dtype, self.in_dim, _ = self._port(0)
+        self.out_dtype, self.out_dim, _ = self._port(1)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().pcxb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _port(self, is_output):
+        name = C.create_string_buffer(64)
+        dim, nbytes = C.c_size_t(), C.c_size_t()
+        _check(load().pcxb_port_dtype(self._h, is_output, name, 64, C.byref(dim), C.byref(nbytes)))
+        return name.value.decode(), dim.value, nbytes.value
+
+    # ---- registered calls ----
+    def call(self, name, *args):
+        L, n = load(), name.encode()
+        if name == "setTaps":
+            t = np.asarray(args[0])
+            cplx = np.iscomplexobj(t)
+            flat = np.ascontiguousarray(t.astype(np.complex128)).view(np.float64) if cplx else np.ascontiguousarray(t.astype(np.float64))
+            return _check(L.pcxb_call_taps(self._h, n, flat.ctypes.data_as(C.c_void_p), t.size, int(cplx)))
+        if name == "getTaps":
+            cplx = bool(args[0]) if args else False
+            buf = np.zeros(1 << 16, np.float64)
+            cnt = C.c_size_t()
+            _check(L.pcxb_get_taps(self._h, n, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(cnt), int(cplx)))
+            return buf[:2 * cnt.value].view(np.complex128).copy() if cplx else buf[:cnt.value].copy()
+        if not args:   # getter
+            if name in ("getDecimation", "getInterpolation"):
+                v = C.c_size_t()
+                _check(L.pcxb_get_size(self._h, n, C.byref(v)))
+                return v.value
+            if name in ("getWaitTaps",):
+                v = C.c_int()
+                _check(L.pcxb_get_bool(self._h, n, C.byref(v)))
+                return bool(v.value)
+            if name in ("getPhase", "getFactor"):
+                v = C.c_double()
+                _check(L.pcxb_get_double(self._h, n, C.byref(v)))
+                return v.value
+            s = C.create_string_buffer(128)
+            _check(L.pcxb_get_string(self._h, n, s, 128))
+            return s.value.decode()
+        a = args[0]
+        if isinstance(a, bool):
+            return _check(L.pcxb_call_bool(self._h, n, int(a)))
+        if isinstance(a, (int, np.integer)):
+            return _check(L.pcxb_call_size(self._h, n, int(a)))
+        if isinstance(a, float):
+            return _check(L.pcxb_call_double(self._h, n, a))
+        return _check(L.pcxb_call_string(self._h, n, str(a).encode()))
+
+    def activate(self):
+        _check(load().pcxb_activate(self._h))
+
+    def buffer_manager(self, is_output):
+        name = C.create_string_buffer(64)
+        sz = C.c_size_t()
+        _check(load().pcxb_buffer_manager(self._h, int(is_output), name, 64, C.byref(sz)))
+        return name.value.decode(), sz.value
+
+    def initial_reserve(self):
+        r = C.c_size_t()
+        load().pcxb_initial_reserve(self._h, C.byref(r))
+        return None if r.value == _SIZE_MAX else r.value
+
+    def work(self, inbuf, out_elems, labels=()):
+        """One work() call.  Returns (out[:produced], consumed, produced, reserve, posted_labels)."""
+        x = as_pairs(inbuf)
+        scalar, cplx = parse_dtype(self.out_dtype)
+        shape = [out_elems * self.out_dim] + ([2] if cplx else [])
+        y = np.zeros(shape, dtype=NP_SCALAR[scalar])
+        in_elems = x.shape[0] // self.in_dim
+        labs = (PcxbLabel * max(1, len(labels)))()
+        for i, l in enumerate(labels):
+            l._to_c(labs[i])
+        posted = (PcxbLabel * 64)()
+        c, p, r, npost = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(load().pcxb_work(self._h, x.ctypes.data_as(C.c_void_p), in_elems, labs, len(labels),
+                                y.ctypes.data_as(C.c_void_p), out_elems, C.byref(c), C.byref(p), C.byref(r),
+                                posted, 64, C.byref(npost)))
+        reserve = None if r.value == _SIZE_MAX else r.value
+        return (y[:p.value * self.out_dim], c.value, p.value, reserve,
+                [Label._from_c(posted[i]) for i in range(min(npost.value, 64))])
+
+
+def make(path, dtype, *args, dimension=1):
+    """BlockRegistry::make(path, dtype, *args)."""
+    return Block(path, dtype, *args, dimension=dimension)

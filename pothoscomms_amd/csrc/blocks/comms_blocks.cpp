@@ -1,0 +1,545 @@
+// comms_blocks.cpp -- the MI355X-backed /comms blocks: same registry paths, factory
+// arguments, setters/getters, port types, buffer-manager requests, label behaviour and
+// consume/produce accounting as the reference blocks; the arithmetic runs in libpcx_hip.so
+// through the C ABI (include/pcx.h).
+//
+//   /comms/fir_filter (+ /blocks/fir_filter)   filter/FIRFilter.cpp:98-389
+//   /comms/fft                                 fft/FFT.cpp:39-95
+//   /comms/freq_demod                          demod/FreqDemod.cpp:33-95
+//   /comms/rotate                              math/Rotate.cpp:47-160
+//   /comms/scale                               math/Scale.cpp:46-160
+//   /comms/abs                                 math/Abs.cpp:66-125
+//   /comms/conjugate                           math/Conjugate.cpp:61-119
+//
+// The reference instantiates one C++ template per element type; here a block carries a
+// pcx_scalar code instead and the type dispatch happens behind the ABI, so one class per
+// block serves the whole factory matrix.  There is no CPU path: a (type, size) the device
+// library does not implement surfaces as an exception from the factory or from work().
+//
+// Built against pcx_framework.hpp: PothosCore when -DPCX_WITH_POTHOS, the bundled runtime
+// otherwise (tests, runner ABI).
+#include <cmath>
+#include <complex>
+#include <string>
+#include <vector>
+
+#include "pcx.h"
+#include "pcx_framework.hpp"
+
+using pcxfw::Block;
+using pcxfw::BufferChunk;
+using pcxfw::DType;
+using pcxfw::InvalidArgumentException;
+using pcxfw::Label;
+
+namespace {
+
+// DType element name -> (pcx_scalar, complex?)
+bool parseElemType(const DType &dt, int &scalar, bool &cplx)
+{
+    std::string n = DType::fromDType(dt, 1).name();
+    cplx = n.compare(0, 8, "complex_") == 0;
+    if (cplx) n = n.substr(8);
+    if (n == "float64") scalar = PCX_F64;
+    else if (n == "float32") scalar = PCX_F32;
+    else if (n == "int64") scalar = PCX_I64;
+    else if (n == "int32") scalar = PCX_I32;
+    else if (n == "int16") scalar = PCX_I16;
+    else if (n == "int8") scalar = PCX_I8;
+    else return false;
+    return true;
+}
+DType realOf(const DType &dt)
+{
+    std::string n = DType::fromDType(dt, 1).name();
+    if (n.compare(0, 8, "complex_") == 0) n = n.substr(8);
+    return DType(n, dt.dimension());
+}
+// ABI status -> the exception type the reference would throw at that point
+void check(int rc, const std::string &where)
+{
+    if (rc == PCX_OK) return;
+    const std::string msg = pcx_last_error();
+    if (rc == PCX_ERR_ARG) throw InvalidArgumentException(where, msg);
+    throw pcxfw::Exception(where, msg);
+}
+
+/***********************************************************************
+ * /comms/fir_filter
+ **********************************************************************/
+class FIRFilter : public Block {
+public:
+    FIRFilter(const DType &dtype, int scalar, bool cplx, bool complexTaps)
+        : _complexTaps(complexTaps), _elemBytes(dtype.size()), M(1), L(1), K(1), _inputRequire(1),
+          _waitTapsMode(false), _waitTapsArmed(false), _eobSampsLeft(0), _dtype(dtype), _h(nullptr)
+    {
+        check(pcx_fir_create(scalar, cplx ? 1 : 0, complexTaps ? 1 : 0, &_h), "FIRFilterFactory(" + dtype.toString() + ")");
+        this->setupInput(0, dtype);
+        this->setupOutput(0, dtype);
+        if (complexTaps) {
+            this->registerCall(this, "setTaps", &FIRFilter::setTapsComplex);
+            this->registerCall(this, "getTaps", &FIRFilter::getTapsComplex);
+        } else {
+            this->registerCall(this, "setTaps", &FIRFilter::setTapsReal);
+            this->registerCall(this, "getTaps", &FIRFilter::getTapsReal);
+        }
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setDecimation));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getDecimation));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setInterpolation));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getInterpolation));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setWaitTaps));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getWaitTaps));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setFrameStartId));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getFrameStartId));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setFrameEndId));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getFrameEndId));
+        // initial update: a single unit tap (reference ctor)
+        _taps.assign(1, std::complex<double>(1.0, 0.0));
+        this->pushTaps();
+    }
+    ~FIRFilter() { pcx_fir_destroy(_h); }
+
+    void setTapsReal(const std::vector<double> &taps)
+    {
+        if (taps.empty()) throw InvalidArgumentException("FIRFilter::setTaps()", "taps cannot be empty");
+        _taps.assign(taps.begin(), taps.end());
+        _waitTapsArmed = false;  // got taps
+        this->pushTaps();
+    }
+    void setTapsComplex(const std::vector<std::complex<double>> &taps)
+    {
+        if (taps.empty()) throw InvalidArgumentException("FIRFilter::setTaps()", "taps cannot be empty");
+        _taps = taps;
+        _waitTapsArmed = false;
+        this->pushTaps();
+    }
+    std::vector<double> getTapsReal() const
+    {
+        std::vector<double> t(_taps.size());
+        for (size_t i = 0; i < t.size(); i++) t[i] = _taps[i].real();
+        return t;
+    }
+    std::vector<std::complex<double>> getTapsComplex() const { return _taps; }
+
+    void setDecimation(const size_t decim)
+    {
+        if (decim == 0) throw InvalidArgumentException("FIRFilter::setDecimation()", "decimation cannot be 0");
+        M = decim;
+        check(pcx_fir_set_decimation(_h, decim), "FIRFilter::setDecimation()");
+        this->refreshGeometry();
+    }
+    size_t getDecimation() const { return M; }
+    void setInterpolation(const size_t interp)
+    {
+        if (interp == 0) throw InvalidArgumentException("FIRFilter::setInterpolation()", "interpolation cannot be 0");
+        L = interp;
+        check(pcx_fir_set_interpolation(_h, interp), "FIRFilter::setInterpolation()");
+        this->refreshGeometry();
+    }
+    size_t getInterpolation() const { return L; }
+    void setWaitTaps(const bool waitTaps) { _waitTapsMode = waitTaps; }
+    bool getWaitTaps() const { return _waitTapsMode; }
+    void setFrameStartId(std::string id) { _frameStartId = id; }
+    std::string getFrameStartId() const { return _frameStartId; }
+    void setFrameEndId(std::string id) { _frameEndId = id; }
+    std::string getFrameEndId() const { return _frameEndId; }
+
+    // the sliding window needs its K-1 history contiguous in front of new samples
+    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &)
+    {
+        return pcxfw::BufferManager::make("circular");
+    }
+
+    void activate()
+    {
+        _waitTapsArmed = _waitTapsMode;
+        _eobSampsLeft = 0;
+    }
+
+    void work()
+    {
+        if (_waitTapsArmed) return;
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        size_t avail = inPort->elements();
+        if (avail == 0) return;
+
+        // burst bookkeeping: where does the current frame end?
+        if (_eobSampsLeft == 0) {
+            for (const auto &label : inPort->labels()) {
+                if (!_frameStartId.empty() && label.id == _frameStartId && label.data.canConvert(typeid(size_t))) {
+                    _eobSampsLeft = label.index + label.data.template convert<size_t>() * label.width;
+                    break;
+                }
+                if (!_frameEndId.empty() && label.id == _frameEndId) {
+                    _eobSampsLeft = label.index + label.width;
+                    break;
+                }
+            }
+        }
+        if (_eobSampsLeft != 0) {
+            if (_eobSampsLeft > avail) { inPort->setReserve(_eobSampsLeft); return; }  // wait for the whole frame
+            avail = _eobSampsLeft;
+        } else if (avail < _inputRequire) {
+            inPort->setReserve(_inputRequire);
+            return;
+        }
+        inPort->setReserve(0);
+
+        // device call on [history | samples]; a burst tail shorter than M+K-1 is flushed with K-1 zeros
+        const void *src = inPort->buffer().template as<const void *>();
+        size_t srcElems = avail;
+        if (_eobSampsLeft != 0 && _eobSampsLeft < _inputRequire) {
+            _flush.assign((_eobSampsLeft + K - 1) * _elemBytes, 0);
+            std::memcpy(_flush.data(), src, _eobSampsLeft * _elemBytes);
+            src = _flush.data();
+            srcElems = _eobSampsLeft + K - 1;
+        }
+        size_t consumed = 0, produced = 0;
+        check(pcx_fir_process(_h, src, srcElems, outPort->buffer().template as<void *>(), outPort->elements(), &consumed, &produced),
+              "FIRFilter::work()");
+
+        // K-1 elements stay in the input buffer as filter history
+        if (_eobSampsLeft != 0) _eobSampsLeft -= consumed;
+        inPort->consume(consumed);
+        outPort->produce(produced);
+    }
+
+    void propagateLabels(const pcxfw::InputPort *port)
+    {
+        auto outputPort = this->output(0);
+        for (const auto &label : port->labels()) {
+            auto newLabel = label.toAdjusted(L, M);
+            if (label.id == "rxRate" && label.data.type() == typeid(double)) {
+                newLabel.data = pcxfw::Object((double(label.data) * L) / M);
+            }
+            outputPort->postLabel(newLabel);
+        }
+    }
+
+private:
+    void pushTaps()
+    {
+        std::vector<double> flat;
+        if (_complexTaps) {
+            flat.resize(2 * _taps.size());
+            for (size_t i = 0; i < _taps.size(); i++) { flat[2 * i] = _taps[i].real(); flat[2 * i + 1] = _taps[i].imag(); }
+        } else {
+            flat.resize(_taps.size());
+            for (size_t i = 0; i < _taps.size(); i++) flat[i] = _taps[i].real();
+        }
+        check(pcx_fir_set_taps(_h, flat.data(), _taps.size()), "FIRFilter::setTaps()");
+        this->refreshGeometry();
+    }
+    void refreshGeometry() { check(pcx_fir_get_geometry(_h, &K, &_inputRequire), "FIRFilter::updateInternals()"); }
+
+    std::vector<std::complex<double>> _taps;
+    bool _complexTaps;
+    size_t _elemBytes;
+    size_t M, L, K, _inputRequire;
+    bool _waitTapsMode, _waitTapsArmed;
+    std::string _frameStartId, _frameEndId;
+    size_t _eobSampsLeft;
+    DType _dtype;
+    pcx_fir *_h;
+    std::vector<char> _flush;
+};
+
+Block *FIRFilterFactory(const DType &dtype, const std::string &tapsType)
+{
+    int scalar;
+    bool cplx;
+    const bool known = parseElemType(dtype, scalar, cplx);
+    const bool real = tapsType == "REAL", complexTaps = tapsType == "COMPLEX";
+    if (known && dtype.dimension() == 1 && (real || (complexTaps && cplx))) return new FIRFilter(dtype, scalar, cplx, complexTaps);
+    throw InvalidArgumentException("FIRFilterFactory(" + dtype.toString() + ")", "unsupported types");
+}
+pcxfw::BlockRegistry registerFIRFilter("/comms/fir_filter", &FIRFilterFactory);
+pcxfw::BlockRegistry registerFIRFilterOldPath("/blocks/fir_filter", &FIRFilterFactory);
+
+/***********************************************************************
+ * /comms/fft
+ **********************************************************************/
+class FFT : public Block {
+public:
+    // a device launch per 4096-sample frame would be launch-bound: the block asks for output
+    // slabs of several frames and transforms every whole frame present in one call.  Totals
+    // (consume == produce == frames * numBins) are those of the reference's one-frame calls.
+    static constexpr size_t kFramesPerSlab = 64;
+
+    FFT(const DType &dtype, int scalar, const size_t numBins, const bool inverse)
+        : _numBins(numBins), _inverse(inverse), _elemBytes(dtype.size()), _h(nullptr)
+    {
+        check(pcx_fft_create(scalar, numBins, inverse ? 1 : 0, &_h), "FFTFactory(" + dtype.toString() + ")");
+        this->setupInput(0, dtype);
+        this->setupOutput(0, dtype);
+        this->input(0)->setReserve(_numBins);
+    }
+    ~FFT() { pcx_fft_destroy(_h); }
+
+    pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &)
+    {
+        pcxfw::BufferManagerArgs args;
+        args.bufferSize = _numBins * _elemBytes * kFramesPerSlab;
+        return pcxfw::BufferManager::make("generic", args);
+    }
+
+    void work()
+    {
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        const size_t frames = std::min(inPort->elements(), outPort->elements()) / _numBins;
+        if (frames == 0) return;
+        check(pcx_fft_transform(_h, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), frames),
+              "FFT::work()");
+        inPort->consume(frames * _numBins);
+        outPort->produce(frames * _numBins);
+    }
+
+private:
+    const size_t _numBins;
+    const bool _inverse;
+    const size_t _elemBytes;
+    pcx_fft *_h;
+};
+
+Block *FFTFactory(const DType &dtype, const size_t numBins, const bool inverse)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx) && cplx && dtype.dimension() == 1 &&
+        (scalar == PCX_F64 || scalar == PCX_F32 || scalar == PCX_I16))
+        return new FFT(dtype, scalar, numBins, inverse);
+    throw InvalidArgumentException("FFTFactory(" + dtype.toString() + ")", "unsupported type");
+}
+pcxfw::BlockRegistry registerFFT("/comms/fft", &FFTFactory);
+
+/***********************************************************************
+ * /comms/freq_demod
+ **********************************************************************/
+class FreqDemod : public Block {
+public:
+    FreqDemod(const DType &dtype, int scalar) : _h(nullptr)
+    {
+        check(pcx_freqdemod_create(scalar, &_h), "FreqDemodFactory(" + dtype.toString() + ")");
+        this->setupInput(0, dtype);
+        this->setupOutput(0, realOf(dtype));
+    }
+    ~FreqDemod() { pcx_freqdemod_destroy(_h); }
+    void activate() { check(pcx_freqdemod_reset(_h), "FreqDemod::activate()"); }  // _prev = 0
+    void work()
+    {
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        const size_t N = this->workInfo().minElements;
+        if (N == 0) return;
+        check(pcx_freqdemod_process(_h, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
+              "FreqDemod::work()");
+        inPort->consume(N);
+        outPort->produce(N);
+    }
+
+private:
+    pcx_freqdemod *_h;
+};
+Block *FreqDemodFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx) && cplx && dtype.dimension() == 1) return new FreqDemod(dtype, scalar);
+    throw InvalidArgumentException("FreqDemodFactory(" + dtype.toString() + ")", "unsupported types");
+}
+pcxfw::BlockRegistry registerFreqDemod("/comms/freq_demod", &FreqDemodFactory);
+
+/***********************************************************************
+ * shared by Rotate and Scale: a coefficient that an upstream label may replace mid-stream
+ **********************************************************************/
+template <typename Derived>
+class LabelDrivenMap : public Block {
+protected:
+    // returns the number of elements to process this call, after applying a label that
+    // sits at the front and cutting the call short before the next matching label
+    size_t scanLabels(size_t elems)
+    {
+        if (_labelId.empty()) return elems;
+        for (const auto &label : this->input(0)->labels()) {
+            if (label.index >= elems) break;  // labels past the input bounds are not ours yet
+            if (label.id != _labelId) continue;
+            if (label.index == 0) static_cast<Derived *>(this)->applyLabel(label.data.template convert<double>());
+            else { elems = label.index; break; }  // that label will be at index 0 next call
+        }
+        return elems;
+    }
+    std::string _labelId;
+};
+
+/***********************************************************************
+ * /comms/rotate
+ **********************************************************************/
+class Rotate : public LabelDrivenMap<Rotate> {
+public:
+    Rotate(const DType &dtype, int scalar) : _scalar(scalar), _phase(0.0), _pr(0.0), _pi(0.0)
+    {
+        this->registerCall(this, PCX_FCN_TUPLE(Rotate, setPhase));
+        this->registerCall(this, PCX_FCN_TUPLE(Rotate, getPhase));
+        this->registerCall(this, PCX_FCN_TUPLE(Rotate, setLabelId));
+        this->registerCall(this, PCX_FCN_TUPLE(Rotate, getLabelId));
+        this->setupInput(0, dtype);
+        this->setupOutput(0, dtype);
+        // NB: like the reference, the phasor stays zero until setPhase() is called
+    }
+    void setPhase(const double phase)
+    {
+        _phase = phase;
+        const std::complex<double> p = std::polar(1.0, phase);
+        _pr = p.real();
+        _pi = p.imag();
+    }
+    double getPhase() const { return _phase; }
+    void setLabelId(const std::string &id) { _labelId = id; }
+    std::string getLabelId() const { return _labelId; }
+    void applyLabel(double v) { this->setPhase(v); }
+    void work()
+    {
+        auto elems = this->workInfo().minElements;
+        if (elems == 0) return;
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        elems = this->scanLabels(elems);
+        const size_t N = elems * inPort->dtype().dimension();
+        check(pcx_rotate(_scalar, _pr, _pi, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
+              "Rotate::work()");
+        inPort->consume(elems);
+        outPort->produce(elems);
+    }
+
+private:
+    int _scalar;
+    double _phase, _pr, _pi;
+};
+Block *rotateFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx) && cplx) return new Rotate(dtype, scalar);
+    throw InvalidArgumentException("rotateFactory(" + dtype.toString() + ")", "unsupported type");
+}
+pcxfw::BlockRegistry registerRotate("/comms/rotate", &rotateFactory);
+
+/***********************************************************************
+ * /comms/scale
+ **********************************************************************/
+class Scale : public LabelDrivenMap<Scale> {
+public:
+    Scale(const DType &dtype, int scalar, bool cplx) : _scalar(scalar), _cplx(cplx), _factor(0.0)
+    {
+        this->registerCall(this, PCX_FCN_TUPLE(Scale, setFactor));
+        this->registerCall(this, PCX_FCN_TUPLE(Scale, getFactor));
+        this->registerCall(this, PCX_FCN_TUPLE(Scale, setLabelId));
+        this->registerCall(this, PCX_FCN_TUPLE(Scale, getLabelId));
+        this->setupInput(0, dtype);
+        this->setupOutput(0, dtype);
+    }
+    void setFactor(const double factor) { _factor = factor; }
+    double getFactor() const { return _factor; }
+    void setLabelId(const std::string &id) { _labelId = id; }
+    std::string getLabelId() const { return _labelId; }
+    void applyLabel(double v) { this->setFactor(v); }
+    void work()
+    {
+        auto elems = this->workInfo().minElements;
+        if (elems == 0) return;
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        elems = this->scanLabels(elems);
+        const size_t N = elems * inPort->dtype().dimension();
+        check(pcx_scale(_scalar, _cplx ? 1 : 0, _factor, inPort->buffer().template as<const void *>(),
+                        outPort->buffer().template as<void *>(), N),
+              "Scale::work()");
+        inPort->consume(elems);
+        outPort->produce(elems);
+    }
+
+private:
+    int _scalar;
+    bool _cplx;
+    double _factor;
+};
+Block *scaleFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx)) return new Scale(dtype, scalar, cplx);
+    throw InvalidArgumentException("scaleFactory(" + dtype.toString() + ")", "unsupported type");
+}
+pcxfw::BlockRegistry registerScale("/comms/scale", &scaleFactory);
+
+/***********************************************************************
+ * /comms/abs, /comms/conjugate
+ **********************************************************************/
+class Abs : public Block {
+public:
+    Abs(const DType &dtype, int scalar, bool cplx) : _scalar(scalar), _cplx(cplx)
+    {
+        this->setupInput(0, dtype);
+        this->setupOutput(0, realOf(dtype));
+    }
+    void work()
+    {
+        const auto elems = this->workInfo().minElements;
+        if (elems == 0) return;
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        const size_t N = elems * inPort->dtype().dimension();
+        check(pcx_abs(_scalar, _cplx ? 1 : 0, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
+              "Abs::work()");
+        inPort->consume(elems);
+        outPort->produce(elems);
+    }
+
+private:
+    int _scalar;
+    bool _cplx;
+};
+Block *absFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx)) return new Abs(dtype, scalar, cplx);
+    throw InvalidArgumentException("absFactory(" + dtype.toString() + ")", "unsupported type");
+}
+pcxfw::BlockRegistry registerAbs("/comms/abs", &absFactory);
+
+class Conjugate : public Block {
+public:
+    Conjugate(const DType &dtype, int scalar) : _scalar(scalar)
+    {
+        this->setupInput(0, dtype);
+        this->setupOutput(0, dtype);
+    }
+    void work()
+    {
+        const auto elems = this->workInfo().minElements;
+        if (elems == 0) return;
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        const size_t N = elems * inPort->dtype().dimension();
+        check(pcx_conj(_scalar, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
+              "Conjugate::work()");
+        inPort->consume(elems);
+        outPort->produce(elems);
+    }
+
+private:
+    int _scalar;
+};
+Block *conjugateFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx) && cplx) return new Conjugate(dtype, scalar);
+    throw InvalidArgumentException("conjugateFactory(" + dtype.toString() + ")", "unsupported type");
+}
+pcxfw::BlockRegistry registerConjugate("/comms/conjugate", &conjugateFactory);
+
+}  // namespace

@@ -1,0 +1,184 @@
+// runner.cpp -- extern "C" driver over the bundled block runtime (include/pcx_blocks.h).
+// Plays the part of the Pothos scheduler for one block at a time: plants port buffers and
+// labels, sets workInfo, calls work() and propagateLabels(), reports consume/produce/reserve.
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+
+#include "pcx.h"
+#include "pcx_blocks.h"
+#include "pcx_framework.hpp"
+
+#ifdef PCX_WITH_POTHOS
+#error "the runner drives the bundled runtime; inside Pothos the framework does this"
+#endif
+
+using namespace pcxfw;
+
+struct pcxb_block {
+    std::unique_ptr<Block> blk;
+    size_t initialReserve = std::numeric_limits<size_t>::max();
+};
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guarded(F &&f)
+{
+    try {
+        f();
+        return PCX_OK;
+    } catch (const InvalidArgumentException &e) {
+        g_err = e.what();
+        return PCX_ERR_ARG;
+    } catch (const BlockCallNotFound &e) {
+        g_err = e.what();
+        return PCX_ERR_STATE;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        // device-side failures carry the ABI's own message; map "unsupported" back
+        return g_err.find("not implemented") != std::string::npos || g_err.find("only power-of-two") != std::string::npos
+                   ? PCX_ERR_UNSUPPORTED
+                   : PCX_ERR_HIP;
+    }
+}
+
+static Label toLabel(const pcxb_label &l)
+{
+    Object data;
+    if (l.kind == PCXB_SIZE) data = Object((unsigned long)l.uval);
+    else if (l.kind == PCXB_DOUBLE) data = Object(l.dval);
+    else if (l.kind == PCXB_STRING) data = Object(std::string(l.sval));
+    return Label(l.id, data, (size_t)l.index, (size_t)l.width);
+}
+static void fromLabel(const Label &l, pcxb_label &o)
+{
+    std::memset(&o, 0, sizeof(o));
+    std::snprintf(o.id, sizeof(o.id), "%s", l.id.c_str());
+    o.index = l.index;
+    o.width = l.width;
+    if (l.data.type() == typeid(double) || l.data.type() == typeid(float)) { o.kind = PCXB_DOUBLE; o.dval = l.data.convert<double>(); }
+    else if (l.data.isNumber()) { o.kind = PCXB_SIZE; o.uval = l.data.convert<unsigned long>(); }
+    else if (l.data.type() == typeid(std::string)) { o.kind = PCXB_STRING; std::snprintf(o.sval, sizeof(o.sval), "%s", l.data.convert<std::string>().c_str()); }
+}
+
+extern "C" {
+
+const char *pcxb_last_error(void) { return g_err.c_str(); }
+int pcxb_registry_has(const char *path) { return BlockRegistry::doesBlockExist(path) ? 1 : 0; }
+size_t pcxb_registry_count(void) { return BlockRegistry::paths().size(); }
+const char *pcxb_registry_path(size_t i)
+{
+    static thread_local std::string s;
+    const auto p = BlockRegistry::paths();
+    if (i >= p.size()) return "";
+    s = p[i];
+    return s.c_str();
+}
+
+int pcxb_make(const char *path, const char *dtype, size_t dimension, const char *sarg, size_t num_bins, int inverse, pcxb_block **out)
+{
+    return guarded([&] {
+        const std::string p(path);
+        const DType dt(std::string(dtype), dimension ? dimension : 1);
+        std::vector<Object> args{Object(dt)};
+        if (p == "/comms/fir_filter" || p == "/blocks/fir_filter") args.push_back(Object(std::string(sarg ? sarg : "")));
+        else if (p == "/comms/fft") { args.push_back(Object((unsigned long)num_bins)); args.push_back(Object(inverse != 0)); }
+        std::unique_ptr<pcxb_block> b(new pcxb_block());
+        b->blk.reset(BlockRegistry::make(p, args));
+        if (b->blk->input(0)->_reserveSet) b->initialReserve = b->blk->input(0)->_reserve;
+        *out = b.release();
+    });
+}
+int pcxb_destroy(pcxb_block *b) { delete b; return PCX_OK; }
+
+int pcxb_call_double(pcxb_block *b, const char *name, double v) { return guarded([&] { b->blk->call(name, {Object(v)}); }); }
+int pcxb_call_size(pcxb_block *b, const char *name, size_t v) { return guarded([&] { b->blk->call(name, {Object((unsigned long)v)}); }); }
+int pcxb_call_bool(pcxb_block *b, const char *name, int v) { return guarded([&] { b->blk->call(name, {Object(v != 0)}); }); }
+int pcxb_call_string(pcxb_block *b, const char *name, const char *v) { return guarded([&] { b->blk->call(name, {Object(std::string(v))}); }); }
+int pcxb_call_taps(pcxb_block *b, const char *name, const double *taps, size_t n, int is_complex)
+{
+    return guarded([&] {
+        if (is_complex) {
+            std::vector<std::complex<double>> t(n);
+            for (size_t i = 0; i < n; i++) t[i] = std::complex<double>(taps[2 * i], taps[2 * i + 1]);
+            b->blk->call(name, {Object(t)});
+        } else {
+            b->blk->call(name, {Object(std::vector<double>(taps, taps + n))});
+        }
+    });
+}
+int pcxb_get_double(pcxb_block *b, const char *name, double *out) { return guarded([&] { *out = b->blk->call(name).convert<double>(); }); }
+int pcxb_get_size(pcxb_block *b, const char *name, size_t *out) { return guarded([&] { *out = b->blk->call(name).convert<unsigned long>(); }); }
+int pcxb_get_bool(pcxb_block *b, const char *name, int *out) { return guarded([&] { *out = b->blk->call(name).convert<bool>() ? 1 : 0; }); }
+int pcxb_get_string(pcxb_block *b, const char *name, char *out, size_t cap)
+{
+    return guarded([&] { std::snprintf(out, cap, "%s", b->blk->call(name).convert<std::string>().c_str()); });
+}
+int pcxb_get_taps(pcxb_block *b, const char *name, double *out, size_t cap_doubles, size_t *n, int is_complex)
+{
+    return guarded([&] {
+        const auto t = b->blk->call(name).convert<std::vector<std::complex<double>>>();
+        *n = t.size();
+        for (size_t i = 0; i < t.size(); i++) {
+            if (is_complex) { if (2 * i + 1 < cap_doubles) { out[2 * i] = t[i].real(); out[2 * i + 1] = t[i].imag(); } }
+            else if (i < cap_doubles) out[i] = t[i].real();
+        }
+    });
+}
+
+int pcxb_activate(pcxb_block *b) { return guarded([&] { b->blk->activate(); }); }
+
+int pcxb_port_dtype(pcxb_block *b, int is_output, char *name, size_t cap, size_t *dimension, size_t *bytes)
+{
+    return guarded([&] {
+        const DType &dt = is_output ? b->blk->output(0)->dtype() : b->blk->input(0)->dtype();
+        std::snprintf(name, cap, "%s", dt.name().c_str());
+        if (dimension) *dimension = dt.dimension();
+        if (bytes) *bytes = dt.size();
+    });
+}
+int pcxb_buffer_manager(pcxb_block *b, int is_output, char *name, size_t cap, size_t *buffer_size)
+{
+    return guarded([&] {
+        auto m = is_output ? b->blk->getOutputBufferManager("", "") : b->blk->getInputBufferManager("", "");
+        std::snprintf(name, cap, "%s", m ? m->name.c_str() : "");
+        if (buffer_size) *buffer_size = m ? m->args.bufferSize : 0;
+    });
+}
+int pcxb_initial_reserve(pcxb_block *b, size_t *reserve) { *reserve = b->initialReserve; return PCX_OK; }
+
+int pcxb_work(pcxb_block *b, const void *in, size_t in_elems, const pcxb_label *labels, size_t nlabels, void *out,
+              size_t out_elems, size_t *consumed, size_t *produced, size_t *reserve, pcxb_label *posted, size_t cap,
+              size_t *nposted)
+{
+    return guarded([&] {
+        InputPort *ip = b->blk->input(0);
+        OutputPort *op = b->blk->output(0);
+        ip->_buffer = BufferChunk::view(const_cast<void *>(in), in_elems * ip->dtype().size(), ip->dtype());
+        op->_buffer = BufferChunk::view(out, out_elems * op->dtype().size(), op->dtype());
+        ip->_labels.clear();
+        for (size_t i = 0; i < nlabels; i++) ip->_labels.push_back(toLabel(labels[i]));
+        ip->_consumed = 0; ip->_reserveSet = false; ip->_reserve = 0;
+        op->_produced = 0; op->_posted.clear();
+        WorkInfo &wi = b->blk->workInfoMutable();
+        wi.minInElements = in_elems; wi.minOutElements = out_elems;
+        wi.minElements = in_elems < out_elems ? in_elems : out_elems;
+        b->blk->work();
+        *consumed = ip->_consumed;
+        *produced = op->_produced;
+        *reserve = ip->_reserveSet ? ip->_reserve : std::numeric_limits<size_t>::max();
+        // the framework forwards the labels that fell inside the consumed region [ext]
+        std::vector<Label> inside;
+        for (const auto &l : ip->_labels) if (l.index < ip->_consumed) inside.push_back(l);
+        ip->_labels.swap(inside);
+        if (!ip->_labels.empty()) b->blk->propagateLabels(ip);
+        size_t n = 0;
+        for (const auto &l : op->_posted) { if (n < cap && posted) fromLabel(l, posted[n]); n++; }
+        if (nposted) *nposted = n;
+    });
+}
+
+}  // extern "C"

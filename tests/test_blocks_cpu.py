@@ -1,0 +1,128 @@
+"""CPU suite: the host-side block layer (libpcx_blocks.so) -- registry paths, factory type
+matrices, registered calls, buffer managers and every work() path that returns before any
+device call.  Mirrors what the reference tests set up through BlockRegistry::make + call()."""
+import numpy as np
+import pytest
+
+from pothoscomms_amd import blocks as B
+
+ALL = ["float64", "float32", "int64", "int32", "int16", "int8"]
+
+
+def test_registry_paths_match_the_reference():
+    """FIRFilter.cpp:385-389, FFT.cpp:94-95, FreqDemod.cpp:94-95, Rotate.cpp:159-160, Scale.cpp:159-160,
+    Abs.cpp:124-125, Conjugate.cpp:118-119"""
+    assert B.registry_paths() == sorted(["/blocks/fir_filter", "/comms/abs", "/comms/conjugate", "/comms/fft",
+                                         "/comms/fir_filter", "/comms/freq_demod", "/comms/rotate", "/comms/scale"])
+    with pytest.raises(ValueError):
+        B.make("/comms/does_not_exist", "float32")
+
+
+@pytest.mark.parametrize("t", ALL)
+def test_fir_factory_matrix(t):
+    """FIRFilterFactory: REAL on real and complex streams, COMPLEX on complex streams only"""
+    for dtype, taps_type, ok in [(t, "REAL", True), ("complex_" + t, "REAL", True), ("complex_" + t, "COMPLEX", True),
+                                 (t, "COMPLEX", False), ("complex_" + t, "BOTH", False)]:
+        if ok:
+            blk = B.make("/comms/fir_filter", dtype, taps_type)
+            assert (blk.in_dtype, blk.out_dtype) == (dtype, dtype)
+            assert blk.buffer_manager(False)[0] == "circular"          # FIRFilter.cpp:196-199
+        else:
+            with pytest.raises(ValueError, match="unsupported types"):
+                B.make("/comms/fir_filter", dtype, taps_type)
+    with pytest.raises(ValueError):
+        B.make("/comms/fir_filter", "uint8", "REAL")
+    assert B.make("/blocks/fir_filter", "complex_float32", "COMPLEX").in_dtype == "complex_float32"
+
+
+def test_fir_registered_calls_round_trip():
+    blk = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    assert np.array_equal(blk.call("getTaps", True), [1.0 + 0j])      # ctor: setTaps({1})
+    taps = np.array([1 + 2j, 3 - 4j, 0.5j])
+    blk.call("setTaps", taps)
+    assert np.array_equal(blk.call("getTaps", True), taps)
+    blk.call("setDecimation", 3); blk.call("setInterpolation", 2)
+    assert (blk.call("getDecimation"), blk.call("getInterpolation")) == (3, 2)
+    blk.call("setWaitTaps", True)
+    assert blk.call("getWaitTaps") is True
+    blk.call("setFrameStartId", "START"); blk.call("setFrameEndId", "END")
+    assert (blk.call("getFrameStartId"), blk.call("getFrameEndId")) == ("START", "END")
+    with pytest.raises(ValueError, match="taps cannot be empty"):
+        blk.call("setTaps", np.array([], dtype=np.complex128))
+    with pytest.raises(ValueError, match="decimation cannot be 0"):
+        blk.call("setDecimation", 0)
+    with pytest.raises(ValueError, match="interpolation cannot be 0"):
+        blk.call("setInterpolation", 0)
+    with pytest.raises(B._lib.PcxError):
+        blk.call("noSuchCall", 1)
+    real = B.make("/comms/fir_filter", "float32", "REAL")
+    real.call("setTaps", np.array([0.25, 0.5]))
+    assert np.array_equal(real.call("getTaps"), [0.25, 0.5])
+
+
+def test_fir_work_paths_without_device_work():
+    """work() returns early: waiting for taps (:209), no input (:213), not enough input (:251-255),
+    burst not complete (:243-247)."""
+    blk = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    blk.call("setTaps", np.ones(10, np.complex128)); blk.call("setDecimation", 4)
+    blk.activate()
+    x = np.zeros((12, 2), np.float32)
+    _, c, p, r, _ = blk.work(x, 100)
+    assert (c, p, r) == (0, 0, 13)                    # M + K - 1
+    _, c, p, r, _ = blk.work(x[:0], 100)
+    assert (c, p, r) == (0, 0, None)
+    blk.call("setWaitTaps", True); blk.activate()
+    _, c, p, r, _ = blk.work(np.zeros((100, 2), np.float32), 100)
+    assert (c, p, r) == (0, 0, None)                  # armed until setTaps arrives
+    blk = B.make("/comms/fir_filter", "float32", "REAL")
+    blk.call("setTaps", np.ones(4)); blk.call("setFrameStartId", "S"); blk.activate()
+    _, c, p, r, _ = blk.work(np.ones(20, np.float32), 100, [B.Label("S", 5, 100)])
+    assert (c, p, r) == (0, 0, 105)                   # whole frame not here yet
+
+
+@pytest.mark.parametrize("t,ok", [("float64", True), ("float32", True), ("int16", True), ("int32", False), ("int8", False), ("int64", False)])
+def test_fft_factory_matrix(t, ok):
+    """FFTFactory: complex<double>, complex<float>, complex<int16>"""
+    if not ok:
+        with pytest.raises(ValueError, match="unsupported type"):
+            B.make("/comms/fft", "complex_" + t, 64, False)
+        return
+    with pytest.raises(ValueError):
+        B.make("/comms/fft", t, 64, False)            # real stream
+
+
+def test_fft_rejects_unimplemented_sizes_loudly():
+    with pytest.raises((NotImplementedError, B._lib.PcxError)):
+        B.make("/comms/fft", "complex_float32", 1000, False)
+
+
+@pytest.mark.parametrize("path,real_ok,out_real", [("/comms/freq_demod", False, True), ("/comms/rotate", False, False),
+                                                   ("/comms/scale", True, False), ("/comms/abs", True, True),
+                                                   ("/comms/conjugate", False, False)])
+@pytest.mark.parametrize("t", ALL)
+def test_map_block_factories(path, real_ok, out_real, t):
+    if path == "/comms/freq_demod":
+        pytest.skip("construction allocates the carried-state slot on the device (GPU suite)")
+    blk = B.make(path, "complex_" + t)
+    assert blk.in_dtype == "complex_" + t
+    assert blk.out_dtype == (t if out_real else "complex_" + t)
+    if real_ok:
+        assert B.make(path, t).out_dtype == t
+    else:
+        with pytest.raises(ValueError, match="unsupported type"):
+            B.make(path, t)
+    # vector dimension is carried on the ports (Rotate.cpp:126: N = elems * dimension)
+    assert B.make(path, "complex_" + t, dimension=4).in_dim == 4
+
+
+def test_rotate_scale_registered_calls():
+    r = B.make("/comms/rotate", "complex_float32")
+    assert r.call("getPhase") == 0.0
+    r.call("setPhase", 1.25); r.call("setLabelId", "ph")
+    assert (r.call("getPhase"), r.call("getLabelId")) == (1.25, "ph")
+    s = B.make("/comms/scale", "float32")
+    s.call("setFactor", -0.5); s.call("setLabelId", "gain")
+    assert (s.call("getFactor"), s.call("getLabelId")) == (-0.5, "gain")
+    # nothing to do: minElements == 0 returns before any device call
+    _, c, p, _, _ = s.work(np.zeros(0, np.float32), 10)
+    assert (c, p) == (0, 0)

@@ -1,0 +1,154 @@
+"""GPU suite: the /comms blocks driven work() by work() like a Pothos topology would, against the
+oracle's restatement of the reference work() functions on the same buffers and labels."""
+import numpy as np
+import pytest
+
+from pothoscomms_amd import blocks as B
+from tests.util import TOL, ang_err, nerr, rand_stream
+
+pytestmark = pytest.mark.gpu
+NAME = {0: "float64", 1: "float32", 2: "int64", 3: "int32", 4: "int16", 5: "int8"}
+
+
+def _stream_through(blk, ref, x, chunk_sizes, out_cap, labels_at=()):
+    """Feed x in pieces the way a circular buffer would: un-consumed input stays at the front."""
+    pos, avail_end = 0, 0
+    outs, routs = [], []
+    sizes = list(chunk_sizes)
+    while pos < len(x) and sizes:
+        avail_end = min(len(x), avail_end + sizes.pop(0))
+        win = x[pos:avail_end]
+        labs = [B.Label(i, idx - pos, d) for (i, idx, d) in labels_at if pos <= idx < avail_end]
+        rlabs = [(("S" if i == "S" else "E"), idx - pos, 1, d) for (i, idx, d) in labels_at if pos <= idx < avail_end]
+        y, c, p, r, _ = blk.work(win, out_cap, labs)
+        ry, rc, rp, rr = ref.work(win, out_cap, rlabs)
+        assert (c, p, r) == (rc, rp, rr), (pos, avail_end)
+        outs.append(y); routs.append(ry)
+        pos += c
+    return np.concatenate(outs), np.concatenate(routs)
+
+
+@pytest.mark.parametrize("scalar", [1, 0, 4])
+@pytest.mark.parametrize("L,M", [(1, 1), (3, 2)])
+def test_fir_block_streams_like_the_reference(oracle, scalar, L, M):
+    rng = np.random.default_rng(scalar * 7 + L)
+    taps = (rng.normal(size=63) + 1j * rng.normal(size=63)) / 8
+    x = rand_stream(rng, scalar, 20000, True, amp=1000)
+    blk = B.make("/comms/fir_filter", "complex_" + NAME[scalar], "COMPLEX")
+    ref = oracle.Fir(scalar, True, True)
+    blk.call("setTaps", taps); ref.set_taps(taps)
+    blk.call("setInterpolation", L); ref.set_interpolation(L)
+    blk.call("setDecimation", M); ref.set_decimation(M)
+    blk.activate(); ref.activate()
+    got, want = _stream_through(blk, ref, x, [10, 50, 3, 5000, 1, 7000, 100000], 6000)
+    assert got.shape == want.shape and got.shape[0] > 0
+    if scalar == 4:
+        assert np.array_equal(got, want)
+    else:
+        assert nerr(got, want) <= (TOL if scalar == 1 else 1e-12)
+
+
+def test_fir_block_burst_mode(oracle):
+    """frame start label -> exactly B outputs per burst, tail flushed with zeros (FIRFilter.cpp:218-272)"""
+    rng = np.random.default_rng(4)
+    taps = rng.normal(size=31) / 4
+    B_len = 1000
+    x = rand_stream(rng, oracle.F32, 3000, True)
+    blk = B.make("/comms/fir_filter", "complex_float32", "REAL")
+    ref = oracle.Fir(oracle.F32, True, False)
+    for b in (blk, ref):
+        (b.call("setTaps", taps) if b is blk else b.set_taps(taps))
+    blk.call("setFrameStartId", "S"); ref.set_frame_ids(True, False)
+    blk.activate(); ref.activate()
+    got, want = _stream_through(blk, ref, x, [400, 400, 400, 400, 400, 400, 400, 400], 100000,
+                                labels_at=[("S", 100, B_len)])
+    assert nerr(got, want) <= TOL
+    # 100 samples before the burst stream normally (K-1 stay behind), then the burst gives B_len outputs
+    assert got.shape[0] >= B_len
+
+
+def test_fir_block_propagates_labels(oracle):
+    """propagateLabels: index/width scaled by L/M, rxRate rescaled (FIRFilter.cpp:311-323)"""
+    blk = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    blk.call("setInterpolation", 3); blk.call("setDecimation", 2); blk.activate()
+    x = np.zeros((4096, 2), np.float32)
+    labs = [B.Label("rxRate", 100, 1e6), B.Label("other", 200, 7, width=4), B.Label("late", 4000, "x")]
+    _, c, p, _, posted = blk.work(x, 1 << 20, labs)
+    assert c == 4096 and p == 6144
+    assert posted == [B.Label("rxRate", 150, 1.5e6), B.Label("other", 300, 7, width=6), B.Label("late", 6000, "x")]
+
+
+def test_fft_block(oracle):
+    rng = np.random.default_rng(5)
+    blk = B.make("/comms/fft", "complex_float32", 256, False)
+    assert blk.initial_reserve() == 256                      # FFT.cpp:50
+    name, size = blk.buffer_manager(True)
+    assert name == "generic" and size % (256 * 8) == 0       # FFT.cpp:54-59 (several frames per slab)
+    x = rand_stream(rng, oracle.F32, 256 * 5 + 100, True)
+    y, c, p, _, _ = blk.work(x, 256 * 3)                     # room for 3 frames only
+    assert (c, p) == (768, 768)
+    assert nerr(y, oracle.fft(x[:768], 256)) <= TOL
+    y, c, p, _, _ = blk.work(x[:200], 256 * 3)               # less than a frame: nothing happens
+    assert (c, p) == (0, 0)
+    inv = B.make("/comms/fft", "complex_int16", 64, True)
+    xi = rand_stream(rng, oracle.I16, 128, True)
+    y, c, p, _, _ = inv.work(xi, 128)
+    assert (c, p) == (128, 128) and np.array_equal(y, oracle.fft(xi, 64, True))
+
+
+@pytest.mark.parametrize("scalar", [1, 4])
+def test_rotate_block_label_driven_phase(oracle, scalar):
+    """Rotate.cpp:105-123: a label at the front sets the phase; one further in ends this call"""
+    rng = np.random.default_rng(6)
+    x = rand_stream(rng, scalar, 1000, True, amp=1000)
+    blk = B.make("/comms/rotate", "complex_" + NAME[scalar])
+    y, c, p, _, _ = blk.work(x, 1000)
+    assert (c, p) == (1000, 1000) and not np.any(y)          # phasor never set -> zeros (Rotate.cpp:60-62)
+    blk.call("setPhase", 0.3); blk.call("setLabelId", "ph")
+    labs = [B.Label("ph", 400, 1.1), B.Label("noise", 10, 5.0), B.Label("ph", 700, -2.0)]
+    y, c, p, _, _ = blk.work(x, 1000, labs)
+    assert (c, p) == (400, 400) and np.array_equal(y, oracle.rotate(x[:400], 0.3))
+    labs = [B.Label("ph", 0, 1.1), B.Label("ph", 300, -2.0)]
+    y, c, p, _, _ = blk.work(x[400:], 1000, labs)
+    assert (c, p) == (300, 300) and np.array_equal(y, oracle.rotate(x[400:700], 1.1))
+    assert blk.call("getPhase") == 1.1
+    y, c, p, _, _ = blk.work(x[700:], 1000, [B.Label("ph", 0, -2.0)])
+    assert (c, p) == (300, 300) and np.array_equal(y, oracle.rotate(x[700:], -2.0))
+
+
+def test_scale_block_label_and_dimension(oracle):
+    rng = np.random.default_rng(7)
+    x = rand_stream(rng, oracle.F32, 1200, False)
+    blk = B.make("/comms/scale", "float32", dimension=4)     # 300 elements of dimension 4
+    blk.call("setFactor", 2.0); blk.call("setLabelId", "g")
+    y, c, p, _, _ = blk.work(x, 300, [B.Label("g", 100, 0.5)])
+    assert (c, p) == (100, 100) and np.array_equal(y, oracle.scale(x[:400], 2.0, False))
+    y, c, p, _, _ = blk.work(x[400:], 300, [B.Label("g", 0, 0.5)])
+    assert (c, p) == (200, 200) and np.array_equal(y, oracle.scale(x[400:], 0.5, False))
+
+
+@pytest.mark.parametrize("scalar", [1, 0, 3, 5])
+def test_abs_conjugate_freqdemod_blocks(oracle, scalar):
+    rng = np.random.default_rng(8 + scalar)
+    x = rand_stream(rng, scalar, 5000, True, amp=100)
+    y, c, p, _, _ = B.make("/comms/abs", "complex_" + NAME[scalar]).work(x, 4000)
+    assert (c, p) == (4000, 4000)
+    if scalar == 0:
+        assert nerr(y, oracle.abs_(x[:4000], True)) < 1e-15 * 4
+    else:
+        assert np.array_equal(y, oracle.abs_(x[:4000], True))
+    y, c, p, _, _ = B.make("/comms/conjugate", "complex_" + NAME[scalar]).work(x, 6000)
+    assert (c, p) == (5000, 5000) and np.array_equal(y, oracle.conj(x))
+    fd = B.make("/comms/freq_demod", "complex_" + NAME[scalar]); fd.activate()
+    assert fd.out_dtype == NAME[scalar]
+    ref = oracle.FreqDemod(scalar)
+    for a, b in ((0, 1), (1, 2500), (2500, 5000)):
+        y, c, p, _, _ = fd.work(x[a:b], 10000)
+        want = ref.work(x[a:b])
+        assert (c, p) == (b - a, b - a)
+        if scalar in (0, 1):
+            assert ang_err(y, want) <= TOL
+        else:
+            assert np.array_equal(y, want)
+    fd.activate(); ref.activate()
+    assert ang_err(fd.work(x[:10], 10)[0].astype(np.float64), ref.work(x[:10]).astype(np.float64)) <= TOL or scalar > 1

@@ -195,16 +195,18 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP events on the launch stream (torch's current stream is the stream every pcx_*_dev call gets)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream (torch's current stream is the stream every pcx_*_dev call
+    # gets): ONE pair around the K timed steps, so no event packet sits between two launches
+    # (a pair per step costs ~12 us of gap per step on this stack); avg launch = span / K.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(args.steps):
-        ev[k][0].record()
         step()
-        ev[k][1].record()
+    ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = [ev0.elapsed_time(ev1) / args.steps]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

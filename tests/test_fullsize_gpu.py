@@ -1,0 +1,113 @@
+"""GPU suite at BASELINE.json's full sizes (device-resident, through the *_dev entry points).
+The oracle cannot filter 64 Mi samples in seconds, so these check size-independent properties
+plus oracle parity on windows (first / last 64 Ki outputs and block seams)."""
+import numpy as np
+import pytest
+
+from tests.util import TOL, nerr
+
+pytestmark = pytest.mark.gpu
+C1 = 64 * 1024 * 1024
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch, torch.device("cuda", 0)
+
+
+def test_fir255_64Mi_windows_and_cross_check(oracle, dev, torch_dev):
+    """configs[1]: 255 taps, 64 Mi samples.  OLS vs oracle on windows; OLS vs direct everywhere."""
+    torch, d = torch_dev
+    from pothoscomms_amd import _lib, taps as tp
+    h = tp.c1_taps()
+    K = len(h)
+    x = torch.empty((C1 + K - 1, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(x, seed=2, offset=0)
+    y_ols = torch.empty((C1, 2), dtype=torch.float32, device=d)
+    y_dir = torch.empty((C1, 2), dtype=torch.float32, device=d)
+    for algo, y in ((_lib.FIR_OLS_FFT, y_ols), (_lib.FIR_DIRECT, y_dir)):
+        f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h); f.set_algo(algo)
+        c, p = f.process_dev(x, y)
+        assert (c, p) == (C1, C1)
+    torch.cuda.synchronize()
+    # the two kernels (frequency domain / time domain) agree over the WHOLE stream
+    scale = float(y_dir.abs().max())
+    assert float((y_ols - y_dir).abs().max()) / scale <= TOL
+    # oracle on windows: start, end, and around overlap-save block seams (S = 4096 - 254)
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h); ref.activate()
+    S = 4096 - (K - 1)
+    for start in (0, S - 300, 1000 * S - 300, C1 - 65536):
+        n = 65536 if start in (0, C1 - 65536) else 600
+        win = x[start:start + n + K - 1].cpu().numpy()
+        want, _, p, _ = ref.work(win, n)
+        assert p == n
+        assert nerr(y_ols[start:start + n].cpu().numpy(), want) <= TOL, start
+    # the device stream equals the oracle's generator bit for bit (same counter hash)
+    assert np.array_equal(x[:1000].cpu().numpy().ravel(), oracle.fill_uniform_f32(2000, 2, 0))
+
+
+def test_fir_linearity_and_impulse_full_size(dev, torch_dev):
+    """FIR(a x1 + x2) = a FIR(x1) + FIR(x2); an impulse returns the taps."""
+    torch, d = torch_dev
+    from pothoscomms_amd import taps as tp
+    h = tp.c1_taps()
+    K, n = len(h), 8 * 1024 * 1024
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h)
+    x1 = torch.empty((n + K - 1, 2), dtype=torch.float32, device=d); dev.fill_uniform_f32_dev(x1, seed=11)
+    x2 = torch.empty_like(x1); dev.fill_uniform_f32_dev(x2, seed=12)
+    y1, y2, y3 = (torch.empty((n, 2), dtype=torch.float32, device=d) for _ in range(3))
+    f.process_dev(x1, y1); f.process_dev(x2, y2)
+    f.process_dev(0.5 * x1 + x2, y3)
+    assert float((y3 - (0.5 * y1 + y2)).abs().max()) / float(y3.abs().max()) <= TOL
+    imp = torch.zeros((n + K - 1, 2), dtype=torch.float32, device=d)
+    pos = 5 * 3842 + 17
+    imp[K - 1 + pos, 0] = 1.0
+    f.process_dev(imp, y1)
+    got = y1[pos:pos + K].cpu().numpy()
+    want = np.stack([h.real, h.imag], 1).astype(np.float32)
+    assert np.max(np.abs(got - want)) <= 1e-6
+    assert float(y1[:pos].abs().max()) <= 1e-6 and float(y1[pos + K:].abs().max()) <= 1e-6
+
+
+def test_fft4096_65536_frames_roundtrip_and_parseval(oracle, dev, torch_dev):
+    """configs[2]: 65,536 frames of 4096.  ifft(fft(x)) = N x, Parseval per frame, oracle on 3 frames."""
+    torch, d = torch_dev
+    nframes = 65536
+    x = torch.empty((nframes * 4096, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(x, seed=3)
+    X = torch.empty_like(x); xb = torch.empty_like(x)
+    dev.Fft("complex_float32", 4096, False).transform_dev(x, X, nframes)
+    dev.Fft("complex_float32", 4096, True).transform_dev(X, xb, nframes)
+    torch.cuda.synchronize()
+    assert float((xb / 4096.0 - x).abs().max()) <= 5e-6
+    e_t = (x.double() ** 2).view(nframes, -1).sum(1)
+    e_f = (X.double() ** 2).view(nframes, -1).sum(1) / 4096.0
+    assert float(((e_t - e_f).abs() / e_t).max()) <= 1e-5
+    for fr in (0, 31337, nframes - 1):
+        want = oracle.fft(x[fr * 4096:(fr + 1) * 4096].cpu().numpy(), 4096)
+        assert nerr(X[fr * 4096:(fr + 1) * 4096].cpu().numpy(), want) <= TOL
+
+
+def test_fm_chain_full_size_against_separate_blocks(dev, torch_dev):
+    """configs[4]: the fused kernel equals Rotate -> FIR -> FreqDemod run as three device calls."""
+    torch, d = torch_dev
+    from pothoscomms_amd import _lib, taps as tp
+    n, h, phase = 16 * 1024 * 1024, tp.c4_taps(), tp.C4_PHASE
+    K = len(h)
+    xs = tp.fm_test_signal(1 << 20)                      # 1 Mi samples of the FM test signal, tiled on the device
+    x = torch.from_numpy(xs.view(np.float32).reshape(-1, 2)).to(d).repeat(17, 1)[:n + K - 1].contiguous()
+    fused = torch.empty(n, dtype=torch.float32, device=d)
+    ch = dev.FmChain(); ch.set_phase(phase); ch.set_taps(h, False)
+    assert ch.process_dev(x, fused, n + K - 1, n) == (n, n)
+    xr = torch.empty_like(x)
+    dev.rotate(x, phase, scalar=dev.F32, out=xr, n=n + K - 1)
+    f = dev.FirFilter("complex_float32", "REAL"); f.set_taps(h); f.set_algo(_lib.FIR_DIRECT)
+    y = torch.empty((n, 2), dtype=torch.float32, device=d)
+    f.process_dev(xr, y)
+    sep = torch.empty(n, dtype=torch.float32, device=d)
+    dev.FreqDemod("complex_float32").process_dev(y, sep, n)
+    torch.cuda.synchronize()
+    dd = (fused.double() - sep.double() + np.pi) % (2 * np.pi) - np.pi
+    assert float(dd.abs().max()) / np.pi <= TOL

@@ -167,11 +167,11 @@ def main():
         device.fill_uniform_f32_dev(x, seed=5, offset=0)
         units = n
         roof_bytes = 12.0 * n
-        kernel_name = "fmchain_cf32_kernel"
+        kernel_name = "fmchain_cf32_ols4096_kernel"
 
         def step():
             ch.process_dev(x, y, n + 126, n)
-        desc = {"workload": "fused Rotate->FIR(127 real taps)->FreqDemod, complex_float32 -> float32, %d samples" % n}
+        desc = {"workload": "fused Rotate->FIR(127 real taps)->FreqDemod in one frequency-domain kernel, complex_float32 -> float32, %d samples" % n}
         metric = "Msamples/s fused FM-demod chain"
     else:
         n = C

@@ -167,6 +167,9 @@ PCX_API int pcx_fmchain_set_phase(pcx_fmchain *h, double phase);
 /* REAL (complex_taps=0) or COMPLEX taps, as pcx_fir_set_taps */
 PCX_API int pcx_fmchain_set_taps(pcx_fmchain *h, const double *taps, size_t ntaps, int complex_taps);
 PCX_API int pcx_fmchain_reset(pcx_fmchain *h);
+/* PCX_FIR_AUTO (default), PCX_FIR_DIRECT (LDS-tiled time domain) or PCX_FIR_OLS_FFT (K <= 2048) */
+PCX_API int pcx_fmchain_set_algo(pcx_fmchain *h, int algo);
+PCX_API int pcx_fmchain_last_algo(const pcx_fmchain *h);
 /* in_elems input samples with K-1 history in front -> in_elems-(K-1) demodulated
  * outputs; FreqDemod's prev is carried in the handle */
 PCX_API int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *out, size_t out_cap,

@@ -80,6 +80,8 @@ SIGNATURES = {
     "pcx_fmchain_set_phase": (_i, [_vp, _d]),
     "pcx_fmchain_set_taps": (_i, [_vp, _vp, _sz, _i]),
     "pcx_fmchain_reset": (_i, [_vp]),
+    "pcx_fmchain_set_algo": (_i, [_vp, _i]),
+    "pcx_fmchain_last_algo": (_i, [_vp]),
     "pcx_fmchain_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz]),
     "pcx_fmchain_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp]),
 }

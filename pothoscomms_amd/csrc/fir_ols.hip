@@ -106,4 +106,118 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     return PCX_OK;
 }
 
+// --------------------------------------------------------------------------------- //
+// Fused Rotate -> FIR -> FreqDemod in the frequency domain (BASELINE configs[4]).
+//
+// Same block pipeline as above with H' = phasor * H (Rotate folded into the spectrum: FIR
+// is linear), then FreqDemod (demod/FreqDemod.cpp:60-67) on the time samples before anything
+// is stored:  d[m] = arg(y[m] * conj(y[m-1])).  Blocks overlap by K (not K-1) input samples so
+// that every y[m-1] a block needs is one of its own valid outputs: block b reads
+// xh[b*S - 1 + i], i = 0..4095, S = 4096 - K; time index i >= K-1 is FIR output m = b*S + i - K
+// and i >= K yields d[m].  y[-1] (block 0, i = K-1) is the state carried from the previous
+// call (*prev_in = conj(y_last), zero after reset); conj(y[n_out-1]) goes to *prev_out.
+// The lane's neighbour sample y[m-1] lives in lane j-1, so the block's time samples make one
+// extra trip through the LDS image.  12 algorithmic bytes per sample (8 in, 4 out).
+// --------------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256, 3) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
+                                                                      float *__restrict__ out, size_t n_out,
+                                                                      const float2 *__restrict__ Hspec, int K,
+                                                                      const float2 *__restrict__ twtab, size_t nblocks,
+                                                                      const float2 *__restrict__ prev_in,
+                                                                      float2 *__restrict__ prev_out)
+{
+    using namespace fft4k;
+    __shared__ cf lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    const size_t S = (size_t)(N - K);
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    cf H[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    // element i of block blk is xh[blk*S - 1 + i].  Blocks >= 1 put the descriptor at
+    // xh[blk*S - 1]; block 0 has no xh[-1], so its descriptor sits at xh[0] and the byte offset
+    // (i-1)*8 of i = 0 wraps past num_records and reads 0 (that sample only feeds y[-1], which
+    // is replaced by the carried state).  Offsets go through voffset: range-checked.
+    auto fetch = [&](cf (&dst)[16], size_t blk) {
+        const int shift = blk == 0 ? 1 : 0;
+        const size_t first = blk * S - (size_t)(1 - shift);          // xh index of the descriptor base
+        const size_t left = in_elems - first;
+        const size_t want = (size_t)(N - shift);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 8));
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * r - shift) * 8, 0, 0);
+            dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+        }
+    };
+    cf nx[16];
+    fetch(nx, b);
+    for (; b < nblocks; b += gridDim.x) {
+        cf v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = nx[r];
+        const size_t bn = b + gridDim.x;
+        if (bn < nblocks) fetch(nx, bn);
+        pass1(v, lds, j);
+        pass2(v, lds, j);
+        pass3(v, lds, j, tw3);
+        cf u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const int k0 = bin_of(q), k1 = bin_of(q + 1);
+            u[k0] = v[q];
+            u[k1] = v[q + 1];
+            cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
+        }
+        pass1(u, lds, j);
+        pass2(u, lds, j);
+        pass3(u, lds, j, tw3);
+        // u[q] = conj(y) at time index i = j + 256*bin_of(q).  Neighbour exchange through LDS.
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = j + 256 * bin_of(q);
+            // block 0: the slot of y[-1] (time index K-1) takes the carried conj(y[-1]) instead
+            lds[i] = (b == 0 && i == K - 1) ? cf{prev_in[0].x, prev_in[0].y} : u[q];
+        }
+        __syncthreads();
+        const size_t room = n_out - b * S;
+        const size_t cnt = room < S ? room : S;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)(cnt * 4));
+        const unsigned vbase = (unsigned)(j - K) * 4u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = 256 * bin_of(q);
+            if (row + 255 < K) continue;                      // no valid output in this row: uniform skip
+            const int i = row + j;
+            const cf a = u[q];
+            const cf p = lds[i > 0 ? i - 1 : 0];              // conj(y[m-1])
+            // y[m] * conj(y[m-1]) = conj(a) * p
+            const float re = a.x * p.x + a.y * p.y, im = a.x * p.y - a.y * p.x;
+            const float d = atan2f(im, re);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)row * 4u), 0, 0);
+            if (i >= K && (size_t)(i - K) == cnt - 1 && b == nblocks - 1) prev_out[0] = make_float2(a.x, a.y);
+        }
+    }
+}
+
+int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
+                                const void *tw4096, const void *prev_in, void *prev_out, hipStream_t st)
+{
+    if (n_out == 0) return PCX_OK;
+    if (K < 1 || K > 2048) { set_error("fm chain ols: K=%zu outside 1..2048", K); return PCX_ERR_UNSUPPORTED; }
+    const size_t S = 4096 - K;
+    const size_t nblocks = (n_out + S - 1) / S;
+    const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);
+    hipLaunchKernelGGL(fmchain_cf32_ols4096_kernel, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float *)out,
+                       n_out, (const float2 *)Hspec, (int)K, (const float2 *)tw4096, nblocks, (const float2 *)prev_in,
+                       (float2 *)prev_out);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 }  // namespace pcx

@@ -90,6 +90,27 @@ static std::vector<float> make_tw4096()
     return t;
 }
 
+// H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096 (the 1/N of the inverse transform folded
+// in), accumulated in double, rounded once to float; natural bin order
+static std::vector<float> make_hspec4096(const std::vector<std::complex<double>> &h)
+{
+    std::vector<double> cs(2 * 4096);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int i = 0; i < 4096; i++) { cs[2 * i] = std::cos(two_pi * i / 4096.0); cs[2 * i + 1] = -std::sin(two_pi * i / 4096.0); }
+    std::vector<float> H(2 * 4096);
+    for (size_t b = 0; b < 4096; b++) {
+        double sr = 0, si = 0;
+        for (size_t k = 0; k < h.size(); k++) {
+            const size_t e = (b * k) & 4095;
+            sr += h[k].real() * cs[2 * e] - h[k].imag() * cs[2 * e + 1];
+            si += h[k].real() * cs[2 * e + 1] + h[k].imag() * cs[2 * e];
+        }
+        H[2 * b] = (float)(sr / 4096.0);
+        H[2 * b + 1] = (float)(si / 4096.0);
+    }
+    return H;
+}
+
 }  // namespace pcx
 
 using namespace pcx;
@@ -202,24 +223,11 @@ static int fir_sync_tables(pcx_fir *h)
         }
         PCX_TRY(upload(h->tapsRev, rev));
         if (K <= 2049) {
-            // H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096, taps first narrowed to
-            // float (floatToQ<QTapsType>, FIRFilter.cpp:348), DFT accumulated in double
-            std::vector<double> cs(2 * 4096);
-            const double two_pi = 6.283185307179586476925286766559;
-            for (int i = 0; i < 4096; i++) { cs[2 * i] = std::cos(two_pi * i / 4096.0); cs[2 * i + 1] = -std::sin(two_pi * i / 4096.0); }
-            std::vector<float> H(2 * 4096);
-            for (size_t b = 0; b < 4096; b++) {
-                double sr = 0, si = 0;
-                for (size_t k = 0; k < K; k++) {
-                    const double hr = (double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]);
-                    const double hi = h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0;
-                    const size_t e = (b * k) & 4095;
-                    sr += hr * cs[2 * e] - hi * cs[2 * e + 1];
-                    si += hr * cs[2 * e + 1] + hi * cs[2 * e];
-                }
-                H[2 * b] = (float)(sr / 4096.0);
-                H[2 * b + 1] = (float)(si / 4096.0);
-            }
+            std::vector<std::complex<double>> hq(K);
+            for (size_t k = 0; k < K; k++)   // floatToQ<QTapsType>: narrowed to float first (FIRFilter.cpp:348)
+                hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]),
+                                             h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
+            const std::vector<float> H = make_hspec4096(hq);
             PCX_TRY(upload(h->Hspec, H));
             PCX_TRY(upload(h->tw4096, make_tw4096()));
             h->have_ols = true;
@@ -599,8 +607,10 @@ struct pcx_fmchain {
     int ctaps = 0;
     bool dirty = true;
     size_t K = 1, Kp = 8;
-    DevBuf tapsRev, prev, wsIn, wsOut;
+    DevBuf tapsRev, Hspec, tw4096, prev, wsIn, wsOut;
     int cur = 0;
+    int algo = PCX_FIR_AUTO, last_algo = 0;
+    bool have_ols = false;
 };
 int pcx_fmchain_create(pcx_fmchain **out)
 {
@@ -656,9 +666,25 @@ static int fmchain_sync(pcx_fmchain *h)
         rev[2 * m + 1] = (float)g.imag();
     }
     PCX_TRY(upload(h->tapsRev, rev));
+    h->have_ols = false;
+    if (K <= 2048) {   // frequency-domain variant: H' = FFT(p * h) / 4096
+        std::vector<std::complex<double>> g(K);
+        for (size_t m = 0; m < K; m++) g[K - 1 - m] = std::complex<double>((double)rev[2 * m], (double)rev[2 * m + 1]);
+        PCX_TRY(upload(h->Hspec, make_hspec4096(g)));
+        PCX_TRY(upload(h->tw4096, make_tw4096()));
+        h->have_ols = true;
+    }
     h->dirty = false;
     return PCX_OK;
 }
+int pcx_fmchain_set_algo(pcx_fmchain *h, int algo)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(algo == PCX_FIR_AUTO || algo == PCX_FIR_DIRECT || algo == PCX_FIR_OLS_FFT, "fm chain: algorithm %d not available", algo);
+    h->algo = algo;
+    return PCX_OK;
+}
+int pcx_fmchain_last_algo(const pcx_fmchain *h) { return h ? h->last_algo : PCX_ERR_ARG; }
 int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                             size_t *consumed, size_t *produced, void *stream)
 {
@@ -670,8 +696,17 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     if (N == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     char *base = static_cast<char *>(h->prev.p);
-    PCX_TRY(launch_fmchain_cf32(in_dev, N + h->K - 1, out_dev, N, h->tapsRev.p, h->K, h->Kp, base + 32 * h->cur,
-                                base + 32 * (h->cur ^ 1), as_stream(stream)));
+    int algo = h->algo;
+    if (algo == PCX_FIR_AUTO) algo = (h->have_ols && h->K >= 24) ? PCX_FIR_OLS_FFT : PCX_FIR_DIRECT;
+    if (algo == PCX_FIR_OLS_FFT) {
+        if (!h->have_ols) { set_error("fm chain: OLS_FFT needs K <= 2048"); return PCX_ERR_UNSUPPORTED; }
+        PCX_TRY(launch_fmchain_cf32_ols4096(in_dev, N + h->K - 1, out_dev, N, h->Hspec.p, h->K, h->tw4096.p, base + 32 * h->cur,
+                                            base + 32 * (h->cur ^ 1), as_stream(stream)));
+    } else {
+        PCX_TRY(launch_fmchain_cf32(in_dev, N + h->K - 1, out_dev, N, h->tapsRev.p, h->K, h->Kp, base + 32 * h->cur,
+                                    base + 32 * (h->cur ^ 1), as_stream(stream)));
+    }
+    h->last_algo = algo;
     h->cur ^= 1;
     *consumed = N; *produced = N;
     return PCX_OK;

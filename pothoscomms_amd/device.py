@@ -232,6 +232,13 @@ class FmChain(_Handle):
     def reset(self):
         _lib.check(_lib.load().pcx_fmchain_reset(self._h))
 
+    def set_algo(self, algo):
+        _lib.check(_lib.load().pcx_fmchain_set_algo(self._h, algo))
+
+    @property
+    def last_algo(self):
+        return _lib.load().pcx_fmchain_last_algo(self._h)
+
     def process(self, x, out_cap):
         xp = as_pairs(x)
         y = np.zeros(out_cap, dtype=np.float32)

@@ -303,11 +303,12 @@ def test_fft_errors(dev):
 # --------------------------------------------------------------------------- #
 # fused Rotate -> FIR -> FreqDemod
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("ntaps,ctaps", [(127, False), (63, True), (1, False)])
-def test_fm_chain(oracle, dev, ntaps, ctaps):
+@pytest.mark.parametrize("algo", ["DIRECT", "OLS_FFT"])
+@pytest.mark.parametrize("ntaps,ctaps", [(127, False), (63, True), (1, False), (2048, False)])
+def test_fm_chain(oracle, dev, ntaps, ctaps, algo):
     from pothoscomms_amd import taps as tp
     rng = np.random.default_rng(ntaps)
-    n = 3 * 2047 + 500 + ntaps
+    n = 3 * 2047 + 500 + ntaps + (9000 if ntaps > 1000 else 0)
     x = tp.fm_test_signal(n)
     taps = tp.lowpass(ntaps, 0.1) if not ctaps else tp.complex_bandpass(ntaps, 0.1, 0.03)
     phase = 0.7
@@ -317,8 +318,10 @@ def test_fm_chain(oracle, dev, ntaps, ctaps):
     y, _, _, _ = fir.work(xr, n)
     ref = oracle.FreqDemod(oracle.F32).work(y)
     ch = dev.FmChain(); ch.set_phase(phase); ch.set_taps(taps, ctaps)
+    ch.set_algo(getattr(dev._lib, "FIR_" + algo))
     got, c, p = ch.process(x, n)
     assert (c, p) == (n - ntaps + 1, n - ntaps + 1)
+    assert ch.last_algo == getattr(dev._lib, "FIR_" + algo)
     assert ang_err(got, ref) <= TOL
     # split into two calls: carried state
     ch.reset()

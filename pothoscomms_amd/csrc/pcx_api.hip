@@ -371,9 +371,9 @@ struct pcx_fft {
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
-    bool is4096 = false;
+    enum Kind { IDENTITY, R16_4096, POW2, Q15_POW2, MIXED } kind = MIXED;
     DevBuf tw, wsIn, wsOut;
-    std::vector<int> radix;  // int16 path: kf_factor order
+    std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
 };
 
 int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
@@ -382,28 +382,53 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     // FFTFactory, FFT.cpp:83-93: complex<double>, complex<float>, complex<int16> only
     PCX_CHECK_ARG(scalar == PCX_F64 || scalar == PCX_F32 || scalar == PCX_I16, "FFTFactory: unsupported type (scalar %d)", scalar);
     PCX_CHECK_ARG(num_bins >= 1, "FFT: numBins must be >= 1");
-    if ((num_bins & (num_bins - 1)) != 0) {
-        set_error("FFT: numBins=%zu: only power-of-two sizes are implemented on the device", num_bins);
+    const size_t esz = 2 * (size_t)scalar_bytes(scalar);
+    const bool pow2 = (num_bins & (num_bins - 1)) == 0;
+    // single-workgroup LDS plans: the frame (x2 for ping-pong) must fit 160 KB
+    if (num_bins > 1 && !(scalar == PCX_F32 && num_bins == 4096) && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
+        set_error("FFT: numBins=%zu (%s) does not fit the single-workgroup LDS plan; not implemented on the device", num_bins,
+                  scalar == PCX_F64 ? "complex_float64" : scalar == PCX_F32 ? "complex_float32" : "complex_int16");
         return PCX_ERR_UNSUPPORTED;
     }
     pcx_fft *h = new (std::nothrow) pcx_fft();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->scalar = scalar; h->nbins = num_bins; h->inverse = inverse ? 1 : 0;
+    {   // kf_factor: 4s, then 2s, then 3, 5, 7, ... (kiss_fft.c:309-328)
+        int n = (int)num_bins, p = 4;
+        const double floor_sqrt = std::floor(std::sqrt((double)n));
+        if (n > 1) do {
+            while (n % p) {
+                switch (p) { case 4: p = 2; break; case 2: p = 3; break; default: p += 2; break; }
+                if (p > floor_sqrt) p = n;
+            }
+            n /= p;
+            h->radix.push_back(p);
+        } while (n > 1);
+    }
     const double two_pi = 6.283185307179586476925286766559;
     int rc = PCX_OK;
-    if (scalar == PCX_F32 && num_bins == 4096) {
-        h->is4096 = true;
+    if (num_bins == 1) {
+        h->kind = pcx_fft::IDENTITY;
+    } else if (scalar == PCX_F32 && num_bins == 4096) {
+        h->kind = pcx_fft::R16_4096;
         rc = upload(h->tw, make_tw4096());
-    } else if (scalar == PCX_F32) {
-        std::vector<float> t(2 * num_bins);
-        for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(-std::sin(two_pi * i / num_bins)); }
-        rc = upload(h->tw, t);
-    } else if (scalar == PCX_F64) {
-        std::vector<double> t(2 * num_bins);
-        for (size_t i = 0; i < num_bins; i++) { t[2 * i] = std::cos(two_pi * i / num_bins); t[2 * i + 1] = -std::sin(two_pi * i / num_bins); }
-        rc = upload(h->tw, t);
+    } else if (scalar != PCX_I16) {
+        // forward table exp(-j 2 pi i / N); the power-of-two kernels conjugate it for the inverse,
+        // the mixed-radix kernel gets the direction baked in like kissfft's fill_twiddles (kissfft.hh:21-26)
+        h->kind = pow2 ? pcx_fft::POW2 : pcx_fft::MIXED;
+        const double sgn = (!pow2 && h->inverse) ? 1.0 : -1.0;
+        if (scalar == PCX_F32) {
+            std::vector<float> t(2 * num_bins);
+            for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(sgn * std::sin(two_pi * i / num_bins)); }
+            rc = upload(h->tw, t);
+        } else {
+            std::vector<double> t(2 * num_bins);
+            for (size_t i = 0; i < num_bins; i++) { t[2 * i] = std::cos(two_pi * i / num_bins); t[2 * i + 1] = sgn * std::sin(two_pi * i / num_bins); }
+            rc = upload(h->tw, t);
+        }
     } else {
         // kiss_fft_alloc, kiss_fft.c:339-368: Q15 twiddles floor(.5 + 32767*cos/sin(phase))
+        h->kind = pow2 ? pcx_fft::Q15_POW2 : pcx_fft::MIXED;
         std::vector<int16_t> t(2 * num_bins);
         for (size_t i = 0; i < num_bins; i++) {
             const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
@@ -413,17 +438,6 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
             t[2 * i + 1] = (int16_t)std::floor(.5 + 32767 * std::sin(phase));
         }
         rc = upload(h->tw, t);
-        // kf_factor, kiss_fft.c:309-328
-        int n = (int)num_bins, p = 4;
-        const double floor_sqrt = std::floor(std::sqrt((double)n));
-        do {
-            while (n % p) {
-                switch (p) { case 4: p = 2; break; case 2: p = 3; break; default: p += 2; break; }
-                if (p > floor_sqrt) p = n;
-            }
-            n /= p;
-            h->radix.push_back(p);
-        } while (n > 1);
     }
     if (rc != PCX_OK) { delete h; return rc; }
     *out = h;
@@ -437,14 +451,20 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
     if (nframes == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     hipStream_t st = as_stream(stream);
-    if (h->nbins == 1) {  // DFT of one point is the identity (kissfft leaf copy, kissfft.hh:94-98)
+    switch (h->kind) {
+    case pcx_fft::IDENTITY:  // DFT of one point is the identity (kissfft leaf copy, kissfft.hh:94-98)
         PCX_HIP(hipMemcpyAsync(out_dev, in_dev, nframes * 2 * (size_t)scalar_bytes(h->scalar), hipMemcpyDeviceToDevice, st));
         return PCX_OK;
+    case pcx_fft::R16_4096: return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, st);
+    case pcx_fft::POW2:
+        return h->scalar == PCX_F32 ? launch_fft_pow2_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st)
+                                    : launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
+    case pcx_fft::Q15_POW2:
+        return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
+    case pcx_fft::MIXED:
+        return launch_fft_mixed(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
     }
-    if (h->is4096) return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, st);
-    if (h->scalar == PCX_F32) return launch_fft_pow2_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
-    if (h->scalar == PCX_F64) return launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
-    return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
+    return PCX_ERR_STATE;
 }
 int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
 {

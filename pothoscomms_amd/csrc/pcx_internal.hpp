@@ -117,6 +117,10 @@ int launch_fft_pow2_cf64(const void *in, void *out, size_t nbins, size_t nframes
 int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
                    const int *radix_host, int nstages, hipStream_t st);
 
+// any numBins: kissfft's mixed-radix plan (radix 2/3/4/5 + generic), f32 / f64 / Q15 (bit-exact)
+int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
+                     const int *radix_host, int nstages, hipStream_t st);
+
 // fused Rotate -> FIR -> FreqDemod, frequency domain (Hspec already carries the phasor)
 int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                                 const void *tw4096, const void *prev_in, void *prev_out, hipStream_t st);

@@ -93,7 +93,7 @@ def test_fft_factory_matrix(t, ok):
 
 def test_fft_rejects_unimplemented_sizes_loudly():
     with pytest.raises((NotImplementedError, B._lib.PcxError)):
-        B.make("/comms/fft", "complex_float32", 1000, False)
+        B.make("/comms/fft", "complex_float32", 1 << 20, False)
 
 
 @pytest.mark.parametrize("path,real_ok,out_real", [("/comms/freq_demod", False, True), ("/comms/rotate", False, False),

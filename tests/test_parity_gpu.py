@@ -297,7 +297,7 @@ def test_fft_errors(dev):
     with pytest.raises(ValueError):
         dev.Fft("complex_int32", 64)       # FFTFactory: unsupported type
     with pytest.raises(NotImplementedError):
-        dev.Fft("complex_float32", 1000)   # valid in the reference, no device kernel: fails loudly
+        dev.Fft("complex_float32", 1 << 20)   # valid in the reference, beyond the single-workgroup LDS plan: fails loudly
 
 
 # --------------------------------------------------------------------------- #
@@ -330,3 +330,29 @@ def test_fm_chain(oracle, dev, ntaps, ctaps, algo):
     g2, _, _ = ch.process(x[c1:], n)
     assert ang_err(np.concatenate([g1, g2]), ref) <= TOL
     del rng
+
+
+# --------------------------------------------------------------------------- #
+# FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
+# --------------------------------------------------------------------------- #
+MIXED_SIZES = [3, 5, 6, 7, 9, 10, 12, 15, 20, 25, 27, 30, 49, 60, 100, 121, 210, 360, 1000, 1009, 1920, 6000]
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("nbins", MIXED_SIZES)
+def test_fft_mixed_radix_float(oracle, dev, nbins, inverse):
+    rng = np.random.default_rng(nbins)
+    x = rand_stream(rng, oracle.F32, nbins * 3, True)
+    assert nerr(dev.Fft("complex_float32", nbins, inverse).transform(x), oracle.fft(x, nbins, inverse)) <= TOL
+    if nbins <= 1000:
+        xd = rand_stream(rng, oracle.F64, nbins * 2, True)
+        assert nerr(dev.Fft("complex_float64", nbins, inverse).transform(xd), oracle.fft(xd, nbins, inverse)) <= 1e-13
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("nbins", MIXED_SIZES)
+def test_fft_mixed_radix_int16_bit_exact(oracle, dev, nbins, inverse):
+    """radix 3 / 5 / generic butterflies of kiss_fft.c in Q15: every rounding reproduced"""
+    rng = np.random.default_rng(nbins + 5)
+    x = rand_stream(rng, oracle.I16, nbins * 3, True)
+    assert np.array_equal(dev.Fft("complex_int16", nbins, inverse).transform(x), oracle.fft(x, nbins, inverse))

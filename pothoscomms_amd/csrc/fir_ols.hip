@@ -15,6 +15,8 @@
 //   store time samples i >= K-1 (the first K-1 are circularly aliased) to y[b*S + i-(K-1)]
 // HBM traffic per block: 32 KiB read + 8*S bytes written; LDS: one padded 34 KiB image.
 #include "fft4096.hpp"
+#include <cstdlib>
+
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -23,7 +25,10 @@ namespace pcx {
 // block (fewer than 4096 inputs left / fewer than S outputs wanted) takes the range-checked
 // load path -- a wave-uniform choice per block.  Stores always go through the descriptor's
 // range check, which drops both the K-1 aliased samples and anything past n_out.
-__global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
+// PREFETCH: keep the next block's 16 samples per lane in flight in registers (168 VGPRs, 3
+// workgroups per CU) or load at the top of each block (128 VGPRs, 4 workgroups per CU).
+template <bool PREFETCH>
+__global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Km1,
                                                                   const float2 *__restrict__ twtab, size_t nfull, size_t nblocks)
@@ -49,13 +54,17 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_kernel(const float2 *
         else load_frame<true>(dst, make_rsrc(in + blk * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8)), j);
     };
     cf nx[16];
-    fetch(nx, b);
+    if (PREFETCH) fetch(nx, b);
     for (; b < nblocks; b += gridDim.x) {
         cf v[16];
+        if (PREFETCH) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = nx[r];
-        const size_t bn = b + gridDim.x;
-        if (bn < nblocks) fetch(nx, bn);   // in flight during this block's math
+            for (int r = 0; r < 16; r++) v[r] = nx[r];
+            const size_t bn = b + gridDim.x;
+            if (bn < nblocks) fetch(nx, bn);   // in flight during this block's math
+        } else {
+            fetch(v, b);
+        }
         pass1(v, lds, j);
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
@@ -99,9 +108,19 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     size_t nfull = n_out / S;
     while (nfull > 0 && (nfull - 1) * S + 4096 > in_elems) nfull--;
     const size_t nblocks = (n_out + S - 1) / S;
-    const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);   // 3 persistent workgroups per CU
-    hipLaunchKernelGGL(fir_cf32_ols4096_kernel, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
-                       n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
+    // measured (64 Mi samples, K = 255, 200 launches): 4 workgroups/CU without prefetch 0.234 ms,
+    // 3 workgroups/CU with register prefetch 0.238 ms -- occupancy hides the load latency as well
+    // as the prefetch does, with 40 fewer VGPRs.  PCX_OLS_VARIANT=0 selects the prefetch form.
+    static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 1) {   // 4 persistent workgroups per CU, no register prefetch
+        const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+        hipLaunchKernelGGL(fir_cf32_ols4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                           n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
+    } else {              // 3 persistent workgroups per CU, next block prefetched in registers
+        const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);
+        hipLaunchKernelGGL(fir_cf32_ols4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                           n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
+    }
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -119,7 +138,7 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 // The lane's neighbour sample y[m-1] lives in lane j-1, so the block's time samples make one
 // extra trip through the LDS image.  12 algorithmic bytes per sample (8 in, 4 out).
 // --------------------------------------------------------------------------------- //
-__global__ __launch_bounds__(256, 3) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
+__global__ __launch_bounds__(256, 2) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                       float *__restrict__ out, size_t n_out,
                                                                       const float2 *__restrict__ Hspec, int K,
                                                                       const float2 *__restrict__ twtab, size_t nblocks,

@@ -154,6 +154,11 @@ PCX_API int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *ou
 PCX_API int pcx_conj(int scalar, const void *in, void *out, size_t n);
 PCX_API int pcx_conj_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream);
 
+/* /comms/angle (SURVEY 8f "next"): math/Angle.cpp:23-26 via getAngle, FxptHelpers.hpp:14-29;
+ * complex element types only, out is the real scalar type */
+PCX_API int pcx_angle(int scalar, const void *in, void *out, size_t n);
+PCX_API int pcx_angle_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream);
+
 /* ===================================================================== *
  *  Fused FM-demod chain  Rotate -> FIR -> FreqDemod in one kernel
  *  (BASELINE.json configs[4]); equals the three blocks above connected in a

@@ -75,6 +75,8 @@ SIGNATURES = {
     "pcx_abs_dev": (_i, [_i, _i, _vp, _vp, _sz, _vp]),
     "pcx_conj": (_i, [_i, _vp, _vp, _sz]),
     "pcx_conj_dev": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "pcx_angle": (_i, [_i, _vp, _vp, _sz]),
+    "pcx_angle_dev": (_i, [_i, _vp, _vp, _sz, _vp]),
     "pcx_fmchain_create": (_i, [C.POINTER(_vp)]),
     "pcx_fmchain_destroy": (_i, [_vp]),
     "pcx_fmchain_set_phase": (_i, [_vp, _d]),

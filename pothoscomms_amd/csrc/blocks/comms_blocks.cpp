@@ -10,6 +10,7 @@
 //   /comms/scale                               math/Scale.cpp:46-160
 //   /comms/abs                                 math/Abs.cpp:66-125
 //   /comms/conjugate                           math/Conjugate.cpp:61-119
+//   /comms/angle  (SURVEY 8f "next")           math/Angle.cpp:50-110
 //
 // The reference instantiates one C++ template per element type; here a block carries a
 // pcx_scalar code instead and the type dispatch happens behind the ABI, so one class per
@@ -509,6 +510,39 @@ Block *absFactory(const DType &dtype)
     throw InvalidArgumentException("absFactory(" + dtype.toString() + ")", "unsupported type");
 }
 pcxfw::BlockRegistry registerAbs("/comms/abs", &absFactory);
+
+// /comms/angle (math/Angle.cpp:50-110): the first "next" sibling, shares getAngle with FreqDemod
+class Angle : public Block {
+public:
+    Angle(const DType &dtype, int scalar) : _scalar(scalar)
+    {
+        this->setupInput(0, dtype);
+        this->setupOutput(0, realOf(dtype));
+    }
+    void work()
+    {
+        const auto elems = this->workInfo().minElements;
+        if (elems == 0) return;
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        const size_t N = elems * inPort->dtype().dimension();
+        check(pcx_angle(_scalar, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
+              "Angle::work()");
+        inPort->consume(elems);
+        outPort->produce(elems);
+    }
+
+private:
+    int _scalar;
+};
+Block *angleFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx) && cplx) return new Angle(dtype, scalar);
+    throw InvalidArgumentException("angleFactory(" + dtype.toString() + ")", "unsupported type");
+}
+pcxfw::BlockRegistry registerAngle("/comms/angle", &angleFactory);
 
 class Conjugate : public Block {
 public:

@@ -279,6 +279,31 @@ __device__ inline uint16_t d_fxpt_atan2(int16_t y, int16_t x)
     }
 }
 
+// ---- Angle  (math/Angle.cpp:23-26 via getAngle, FxptHelpers.hpp:14-29) ----
+// the arithmetic FreqDemod shares; /comms/angle is the first "next" sibling block
+template <typename T>
+struct AngleOp {
+    __device__ void operator()(const T *x, T *y) const
+    {
+        if constexpr (std::is_same<T, float>::value) y[0] = atan2f(x[1], x[0]);
+        else if constexpr (std::is_same<T, double>::value) y[0] = atan2(x[1], x[0]);
+        else y[0] = (T)d_fxpt_atan2((int16_t)x[1], (int16_t)x[0]);
+    }
+};
+int launch_angle(int scalar, const void *in, void *out, size_t n, hipStream_t st)
+{
+    switch (scalar) {
+    case PCX_F32: return launch_map<float, float, 2, 1>(in, out, n, AngleOp<float>{}, st);
+    case PCX_F64: return launch_map<double, double, 2, 1>(in, out, n, AngleOp<double>{}, st);
+    case PCX_I64: return launch_map<int64_t, int64_t, 2, 1>(in, out, n, AngleOp<int64_t>{}, st);
+    case PCX_I32: return launch_map<int32_t, int32_t, 2, 1>(in, out, n, AngleOp<int32_t>{}, st);
+    case PCX_I16: return launch_map<int16_t, int16_t, 2, 1>(in, out, n, AngleOp<int16_t>{}, st);
+    case PCX_I8: return launch_map<int8_t, int8_t, 2, 1>(in, out, n, AngleOp<int8_t>{}, st);
+    }
+    set_error("angle: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+
 // ---- FreqDemod  (demod/FreqDemod.cpp:60-67) ----
 // out[i] = angle(in[i] * _prev), _prev = conj(in[i-1]); for i = 0 _prev comes from
 // *prev_in (carried from the previous call; zero after activate()); *prev_out gets the

@@ -616,6 +616,20 @@ int pcx_conj(int scalar, const void *in, void *out, size_t n)
     return run_host_map(in, out, b, b, [&](void *di, void *dout) { return launch_conj(scalar, di, dout, n, nullptr); });
 }
 
+int pcx_angle_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "angleFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    return launch_angle(scalar, in_dev, out_dev, n, as_stream(stream));
+}
+int pcx_angle(int scalar, const void *in, void *out, size_t n)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "angleFactory: unsupported type (scalar %d)", scalar);
+    const size_t sb = (size_t)scalar_bytes(scalar);
+    return run_host_map(in, out, n * 2 * sb, n * sb, [&](void *di, void *dout) { return launch_angle(scalar, di, dout, n, nullptr); });
+}
+
 /* ===================================================================== *
  *  fused Rotate -> FIR -> FreqDemod
  * ===================================================================== */

@@ -86,6 +86,7 @@ int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, s
 int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st);
 int launch_abs(int scalar, int is_complex, const void *in, void *out, size_t n, hipStream_t st);
 int launch_conj(int scalar, const void *in, void *out, size_t n, hipStream_t st);
+int launch_angle(int scalar, const void *in, void *out, size_t n, hipStream_t st);
 // out[i] = angle(in[i]*_prev); _prev(i=0) := *prev_in (already conjugated); *prev_out := conj(in[n-1])
 int launch_freqdemod(int scalar, const void *in, void *out, size_t n, const void *prev_in, void *prev_out, hipStream_t st);
 int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t offset, hipStream_t st);

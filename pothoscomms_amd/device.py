@@ -294,6 +294,14 @@ def conj(x, scalar=None, out=None, n=None, stream=None):
     return _map("pcx_conj", "pcx_conj_dev", (scalar,), x, lambda a: a.shape, n, out, stream)
 
 
+def angle(x, scalar=None, out=None, n=None, stream=None):
+    """getAngle per element (math/Angle.cpp): complex in, real out."""
+    if not _is_torch(x):
+        x = as_pairs(x)
+        scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
+    return _map("pcx_angle", "pcx_angle_dev", (scalar,), x, lambda a: (a.shape[0],), n, out, stream)
+
+
 def fill_uniform_f32_dev(t, seed, offset=0, stream=None):
     """Fill a float32 CUDA tensor with the deterministic synthetic stream (uniform [-1,1))."""
     _lib.check(_lib.load().pcx_fill_uniform_f32_dev(_dev_ptr(t), t.numel(), seed, offset, _stream_ptr(stream)))

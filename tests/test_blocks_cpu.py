@@ -12,7 +12,7 @@ ALL = ["float64", "float32", "int64", "int32", "int16", "int8"]
 def test_registry_paths_match_the_reference():
     """FIRFilter.cpp:385-389, FFT.cpp:94-95, FreqDemod.cpp:94-95, Rotate.cpp:159-160, Scale.cpp:159-160,
     Abs.cpp:124-125, Conjugate.cpp:118-119"""
-    assert B.registry_paths() == sorted(["/blocks/fir_filter", "/comms/abs", "/comms/conjugate", "/comms/fft",
+    assert B.registry_paths() == sorted(["/blocks/fir_filter", "/comms/abs", "/comms/angle", "/comms/conjugate", "/comms/fft",
                                          "/comms/fir_filter", "/comms/freq_demod", "/comms/rotate", "/comms/scale"])
     with pytest.raises(ValueError):
         B.make("/comms/does_not_exist", "float32")
@@ -98,7 +98,7 @@ def test_fft_rejects_unimplemented_sizes_loudly():
 
 @pytest.mark.parametrize("path,real_ok,out_real", [("/comms/freq_demod", False, True), ("/comms/rotate", False, False),
                                                    ("/comms/scale", True, False), ("/comms/abs", True, True),
-                                                   ("/comms/conjugate", False, False)])
+                                                   ("/comms/conjugate", False, False), ("/comms/angle", False, True)])
 @pytest.mark.parametrize("t", ALL)
 def test_map_block_factories(path, real_ok, out_real, t):
     if path == "/comms/freq_demod":

@@ -356,3 +356,27 @@ def test_fft_mixed_radix_int16_bit_exact(oracle, dev, nbins, inverse):
     rng = np.random.default_rng(nbins + 5)
     x = rand_stream(rng, oracle.I16, nbins * 3, True)
     assert np.array_equal(dev.Fft("complex_int16", nbins, inverse).transform(x), oracle.fft(x, nbins, inverse))
+
+
+# --------------------------------------------------------------------------- #
+# /comms/angle (first "next" sibling: shares getAngle with FreqDemod; math/TestAngle.cpp)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("scalar", SCALARS, ids=lambda s: NAMES[s])
+def test_angle(oracle, dev, scalar):
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+    rng = np.random.default_rng(scalar + 40)
+    x = rand_stream(rng, scalar, 30001, True)
+    got, ref = dev.angle(x), oracle.angle(x)
+    if scalar in (oracle.F64, oracle.F32):
+        assert ang_err(got, ref) <= TOL
+    else:
+        assert np.array_equal(got, ref)
+    # the reference test's own 13 points and the compiled reference's outputs on them
+    zin = gold["angle_in_" + NAMES[scalar]]
+    g = dev.angle(zin)
+    if scalar in (oracle.F64, oracle.F32):
+        assert np.max(np.abs(g - np.arctan2(zin[:, 1].astype(np.float64), zin[:, 0]))) <= np.pi / 500   # TestAngle.cpp:57
+        assert ang_err(g, gold["angle_ref_" + NAMES[scalar]]) <= TOL
+    else:
+        assert np.array_equal(g, gold["angle_ref_" + NAMES[scalar]])

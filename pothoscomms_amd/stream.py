@@ -12,6 +12,11 @@ taps) and no other data-path collective.
 Buffer layout on every rank: one contiguous tensor [halo | C samples] -- the halo sits directly
 in front of the shard so the kernel sees the same "history at the front" buffer as a single-GPU
 call (pcx_fir_process_dev), and the received bytes land in place (no staging copy).
+
+Latency hiding: a 2 KB message is pure latency (tens of microseconds against a ~0.25 ms pass).
+Only the first `head` outputs of a shard read the halo, so a pass (a) posts the exchange,
+(b) filters everything behind the head while the message is in flight, (c) waits, (d) filters
+the head.  The wait then costs nothing unless the link is slower than the body of the pass.
 """
 import torch
 import torch.distributed as dist
@@ -30,21 +35,34 @@ class HaloRing:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
-    def exchange(self, buf):
-        """buf: [halo + C, ...] contiguous.  Returns after the halo is usable on the current stream."""
+    def start(self, buf):
+        """Post the exchange; returns the requests to pass to finish()."""
         if self.world == 1 or self.halo == 0:
-            return
+            return []
         ops = []
         if self.rank + 1 < self.world:
             ops.append(dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], self.rank + 1, self.group))
         if self.rank > 0:
             ops.append(dist.P2POp(dist.irecv, buf[:self.halo], self.rank - 1, self.group))
-        for w in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops)
+
+    @staticmethod
+    def finish(reqs):
+        """Make the current stream (or the host, on CPU backends) wait for the halo."""
+        for w in reqs:
             w.wait()
+
+    def exchange(self, buf):
+        """buf: [halo + C, ...] contiguous.  Returns after the halo is usable on the current stream."""
+        self.finish(self.start(buf))
 
 
 class ShardedFir:
     """A 255-tap-style complex_float32 FIR over one shard of a node-wide stream (M = L = 1)."""
+
+    # outputs computed after the halo has arrived: one overlap-save block's worth is the
+    # minimum (outputs 0 .. 4096-K); rounding up to 4096 keeps the split independent of K
+    HEAD = 4096
 
     def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None):
         from . import device as dv   # the HIP path; raises if libpcx_hip.so is missing
@@ -57,15 +75,26 @@ class ShardedFir:
         self.ring = HaloRing(self.K - 1, group)
         self.buf = torch.zeros((self.K - 1 + self.C, 2), dtype=torch.float32, device=device)
         self.out = torch.empty((self.C, 2), dtype=torch.float32, device=device)
+        self.head = min(self.HEAD, self.C)
 
     @property
     def shard(self):
         """The C samples this rank owns (a view behind the halo)."""
         return self.buf[self.K - 1:]
 
+    def _run(self, first_out, n_out):
+        # outputs [first_out, first_out + n_out) read buf[first_out : first_out + n_out + K - 1]
+        c, p = self.fir.process_dev(self.buf[first_out:], self.out[first_out:], n_out + self.K - 1, n_out)
+        assert c == n_out and p == n_out, (c, p, n_out)
+
     def step(self):
-        """One pass: halo from the left neighbour, then filter the shard -> C outputs."""
-        self.ring.exchange(self.buf)
-        c, p = self.fir.process_dev(self.buf, self.out, self.K - 1 + self.C, self.C)
-        assert c == self.C and p == self.C, (c, p)
+        """One pass: halo from the left neighbour overlapped with the body, then the head -> C outputs."""
+        if self.ring.world == 1:
+            self._run(0, self.C)
+            return self.out
+        reqs = self.ring.start(self.buf)
+        if self.C > self.head:
+            self._run(self.head, self.C - self.head)      # does not touch the halo
+        self.ring.finish(reqs)
+        self._run(0, self.head)
         return self.out

@@ -111,3 +111,22 @@ def test_fm_chain_full_size_against_separate_blocks(dev, torch_dev):
     torch.cuda.synchronize()
     dd = (fused.double() - sep.double() + np.pi) % (2 * np.pi) - np.pi
     assert float(dd.abs().max()) / np.pi <= TOL
+
+
+def test_sharded_step_split_equals_single_call(dev, torch_dev):
+    """The N>1 pass (body while the halo is in flight, then the head) gives the same outputs as
+    one call -- exercised on one GPU by making the ring believe it has a neighbour."""
+    torch, d = torch_dev
+    from pothoscomms_amd import taps as tp
+    from pothoscomms_amd.stream import ShardedFir
+    C = 1 << 20
+    sf = ShardedFir(tp.c1_taps(), C, d)
+    dev.fill_uniform_f32_dev(sf.buf, seed=9)
+    whole = sf.step().clone()
+    sf.ring.world = 2                       # take the multi-rank path; rank 0 has nothing to receive
+    sf.ring.rank = 0
+    sf.ring.start = lambda buf: []
+    sf.out.zero_()
+    split = sf.step()
+    torch.cuda.synchronize()
+    assert float((split - whole).abs().max()) / float(whole.abs().max()) <= 2e-6

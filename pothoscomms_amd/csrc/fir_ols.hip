@@ -27,7 +27,11 @@ namespace pcx {
 // range check, which drops both the K-1 aliased samples and anything past n_out.
 // PREFETCH: keep the next block's 16 samples per lane in flight in registers (168 VGPRs, 3
 // workgroups per CU) or load at the top of each block (128 VGPRs, 4 workgroups per CU).
-template <bool PREFETCH>
+// LAUX / SAUX: cache-policy bits of the stream loads / stores.  Measured at K = 255: plain loads
+// 0.232 ms, non-temporal loads 0.252 ms per 64 Mi samples -- consecutive blocks re-read K-1
+// samples, and those hits are lost when the first touch bypasses L2 -- so the FIR keeps plain
+// loads (the frame-disjoint FFT kernel gains 3 % from nt).
+template <bool PREFETCH, int LAUX = 0, int SAUX = 0>
 __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Km1,
@@ -50,8 +54,8 @@ __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel
     for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
     auto fetch = [&](cf (&dst)[16], size_t blk) {
         const size_t left = in_elems - blk * S;   // samples from the block start to the end of the buffer
-        if (blk < nfull) load_frame<false>(dst, make_rsrc(in + blk * S, N * 8), j);
-        else load_frame<true>(dst, make_rsrc(in + blk * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8)), j);
+        if (blk < nfull) load_frame<false, LAUX>(dst, make_rsrc(in + blk * S, N * 8), j);
+        else load_frame<true, LAUX>(dst, make_rsrc(in + blk * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8)), j);
     };
     cf nx[16];
     if (PREFETCH) fetch(nx, b);
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel
         for (int q = 0; q < 16; q++) {
             const int row = 256 * bin_of(q);
             if (row + 255 < Km1) continue;                    // whole row aliased: uniform skip
-            store_cf(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
+            store_cf<SAUX>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
     }
 }
@@ -112,7 +116,12 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     // 3 workgroups/CU with register prefetch 0.238 ms -- occupancy hides the load latency as well
     // as the prefetch does, with 40 fewer VGPRs.  PCX_OLS_VARIANT=0 selects the prefetch form.
     static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : 1; }();
-    if (variant == 1) {   // 4 persistent workgroups per CU, no register prefetch
+    if (variant >= 2) {   // A/B: cache-policy variants of the 4-workgroup form (2: nt loads, 3: nt loads + nt stores)
+        const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+        auto k = variant == 2 ? fir_cf32_ols4096_kernel<false, 2, 0> : fir_cf32_ols4096_kernel<false, 2, 2>;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                           n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
+    } else if (variant == 1) {   // 4 persistent workgroups per CU, no register prefetch
         const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
         hipLaunchKernelGGL(fir_cf32_ols4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
                            n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);

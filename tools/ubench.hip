@@ -13,6 +13,40 @@ __global__ __launch_bounds__(256) void copy16(const float4* __restrict__ in, flo
         out[i] = a; out[i + 256] = b; out[i + 512] = c; out[i + 768] = d;
     }
 }
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void copy16u(const f4* __restrict__ in, f4* __restrict__ out, size_t n)
+{
+    size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < n; i += stride) {
+        f4 a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = NT ? __builtin_nontemporal_load(&in[i + 256 * u]) : in[i + 256 * u];
+#pragma unroll
+        for (int u = 0; u < U; u++) { if (NT) __builtin_nontemporal_store(a[u], &out[i + 256 * u]); else out[i + 256 * u] = a[u]; }
+    }
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void read16(const f4* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    size_t stride = (size_t)gridDim.x * 256 * 4;
+    float s = 0;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { f4 a = NT ? __builtin_nontemporal_load(&in[i + 256 * u]) : in[i + 256 * u]; s += a.x + a.y + a.z + a.w; }
+    }
+    if (s == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void write16(f4* __restrict__ out, size_t n)
+{
+    size_t stride = (size_t)gridDim.x * 256 * 4;
+    const f4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { if (NT) __builtin_nontemporal_store(v, &out[i + 256 * u]); else out[i + 256 * u] = v; }
+    }
+}
 // frame-structured copy: one 4096 x float2 frame per workgroup pass, lane j touches j + 256 r (8 B per lane)
 template <int WAVES_HINT>
 __global__ __launch_bounds__(256) void frame_copy8(const float2* __restrict__ in, float2* __restrict__ out, size_t nframes)
@@ -108,6 +142,22 @@ int main()
     for (int grid : {1024, 2048, 4096}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, 0, (const float4*)in, (float4*)out, bytes / 16); }, 10);
         printf("copy16          grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+    }
+    for (int grid : {2048, 8192}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL((copy16u<false, 8>), dim3(grid), dim3(256), 0, 0, (const f4*)in, (f4*)out, bytes / 16); }, 10);
+        printf("copy16 x8       grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL((copy16u<true, 4>), dim3(grid), dim3(256), 0, 0, (const f4*)in, (f4*)out, bytes / 16); }, 10);
+        printf("copy16 nt x4    grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL((copy16u<true, 8>), dim3(grid), dim3(256), 0, 0, (const f4*)in, (f4*)out, bytes / 16); }, 10);
+        printf("copy16 nt x8    grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL(read16<false>, dim3(grid), dim3(256), 0, 0, (const f4*)in, (float*)out, bytes / 16); }, 10);
+        printf("read16          grid %5d: %.3f ms  %.0f GB/s (read only)\n", grid, ms, gb / 2 / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL(read16<true>, dim3(grid), dim3(256), 0, 0, (const f4*)in, (float*)out, bytes / 16); }, 10);
+        printf("read16 nt       grid %5d: %.3f ms  %.0f GB/s (read only)\n", grid, ms, gb / 2 / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL(write16<false>, dim3(grid), dim3(256), 0, 0, (f4*)out, bytes / 16); }, 10);
+        printf("write16         grid %5d: %.3f ms  %.0f GB/s (write only)\n", grid, ms, gb / 2 / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL(write16<true>, dim3(grid), dim3(256), 0, 0, (f4*)out, bytes / 16); }, 10);
+        printf("write16 nt      grid %5d: %.3f ms  %.0f GB/s (write only)\n", grid, ms, gb / 2 / ms * 1e3);
     }
     for (int grid : {1024, 2048, 4096, 32768}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(frame_copy8<0>, dim3(grid), dim3(256), 0, 0, (const float2*)in, (float2*)out, nframes); }, 10);

@@ -31,7 +31,7 @@ namespace pcx {
 // 0.232 ms, non-temporal loads 0.252 ms per 64 Mi samples -- consecutive blocks re-read K-1
 // samples, and those hits are lost when the first touch bypasses L2 -- so the FIR keeps plain
 // loads (the frame-disjoint FFT kernel gains 3 % from nt).
-template <bool PREFETCH, int LAUX = 0, int SAUX = 0>
+template <bool PREFETCH, int LAUX = 0, int SAUX = 0, bool CHUNKED = false>
 __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Km1,
@@ -41,8 +41,19 @@ __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - Km1);
-    size_t b = blockIdx.x;
-    if (b >= nblocks) return;
+    // CHUNKED: each persistent workgroup walks a CONTIGUOUS run of blocks (balanced partition)
+    // instead of a grid stride, so the K-1 samples block b+1 shares with block b were fetched
+    // by the same CU a moment ago (L2/L1 hit instead of a second trip to the memory side).
+    size_t b, bend, bstep;
+    if (CHUNKED) {
+        const size_t q = nblocks / gridDim.x, rem = nblocks % gridDim.x, w = blockIdx.x;
+        b = w * q + (w < rem ? w : rem);
+        bend = b + q + (w < rem ? 1 : 0);
+        bstep = 1;
+    } else {
+        b = blockIdx.x; bend = nblocks; bstep = gridDim.x;
+    }
+    if (b >= bend) return;
     // loop invariants of the persistent workgroup: the lane's pass-3 twiddles and its 16 bins
     // of H in registers, the pass-2 twiddle table in LDS.  Nothing but the stream itself is
     // loaded from global memory inside the loop.
@@ -59,13 +70,13 @@ __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel
     };
     cf nx[16];
     if (PREFETCH) fetch(nx, b);
-    for (; b < nblocks; b += gridDim.x) {
+    for (; b < bend; b += bstep) {
         cf v[16];
         if (PREFETCH) {
 #pragma unroll
             for (int r = 0; r < 16; r++) v[r] = nx[r];
-            const size_t bn = b + gridDim.x;
-            if (bn < nblocks) fetch(nx, bn);   // in flight during this block's math
+            const size_t bn = b + bstep;
+            if (bn < bend) fetch(nx, bn);   // in flight during this block's math
         } else {
             fetch(v, b);
         }
@@ -116,7 +127,11 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     // 3 workgroups/CU with register prefetch 0.238 ms -- occupancy hides the load latency as well
     // as the prefetch does, with 40 fewer VGPRs.  PCX_OLS_VARIANT=0 selects the prefetch form.
     static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : 1; }();
-    if (variant >= 2) {   // A/B: cache-policy variants of the 4-workgroup form (2: nt loads, 3: nt loads + nt stores)
+    if (variant == 4) {   // A/B: contiguous block runs per workgroup
+        const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+        hipLaunchKernelGGL((fir_cf32_ols4096_kernel<false, 0, 0, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems,
+                           (float2 *)out, n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
+    } else if (variant >= 2) {   // A/B: cache-policy variants of the 4-workgroup form (2: nt loads, 3: nt loads + nt stores)
         const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
         auto k = variant == 2 ? fir_cf32_ols4096_kernel<false, 2, 0> : fir_cf32_ols4096_kernel<false, 2, 2>;
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,

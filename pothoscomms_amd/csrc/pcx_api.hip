@@ -319,9 +319,10 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
     int algo = h->algo;
     const bool fast = fir_fast_applicable(h);
     if (algo == PCX_FIR_AUTO) {
-        // frequency domain pays from a few dozen taps up (direct form turns FMA-bound
-        // near K ~ 40); below that the LDS-tiled direct kernel is HBM-bound too
-        if (fast && h->have_ols && h->K >= 24) algo = PCX_FIR_OLS_FFT;
+        // measured sweep (tools/sweep_fir.py, 16 Mi samples): the frequency-domain kernel runs at
+        // 285-325 Gsamples/s for every K <= 1023 (197 at K = 2049) while the time-domain tile
+        // peaks at 240-256 and falls as 1/K beyond K ~ 48 -- so it is the choice whenever it applies
+        if (fast && h->have_ols) algo = PCX_FIR_OLS_FFT;
         else if (fast) algo = PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
@@ -731,7 +732,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     char *base = static_cast<char *>(h->prev.p);
     int algo = h->algo;
-    if (algo == PCX_FIR_AUTO) algo = (h->have_ols && h->K >= 24) ? PCX_FIR_OLS_FFT : PCX_FIR_DIRECT;
+    if (algo == PCX_FIR_AUTO) algo = h->have_ols ? PCX_FIR_OLS_FFT : PCX_FIR_DIRECT;
     if (algo == PCX_FIR_OLS_FFT) {
         if (!h->have_ols) { set_error("fm chain: OLS_FFT needs K <= 2048"); return PCX_ERR_UNSUPPORTED; }
         PCX_TRY(launch_fmchain_cf32_ols4096(in_dev, N + h->K - 1, out_dev, N, h->Hspec.p, h->K, h->tw4096.p, base + 32 * h->cur,

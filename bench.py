@@ -61,8 +61,12 @@ def cpu_baseline_fir(taps, seed, nsamples):
     assert p == nsamples
     # all host cores: static chunking with K-1 overlap (not reference behaviour, reported beside)
     import threading
-    ncores = os.cpu_count() or 1
-    per = nsamples // 4
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 64))        # bounded: the leg must stay within a few tens of seconds
+    per = nsamples // 8
     outs = [np.zeros((per, 2), np.float32) for _ in range(ncores)]
     L = o.lib()
 

@@ -150,6 +150,94 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 }
 
 // --------------------------------------------------------------------------------- //
+// Rational resampling (interpolation L, decimation M) on the same block pipeline.
+//
+// FIRFilter.cpp:286-302 walks the flat index f = n*L + j (input n, polyphase row j) and emits
+// an output whenever (f+1) % M == 0, computed with row j's taps h_j[k] = taps[j + k*L].  Here
+// one launch handles one row j: it filters the input with H_j at full rate in the frequency
+// domain and stores only the samples the decimator keeps, y_j[n] -> out[(f+1)/M - 1].
+// Cost: L passes over the input whatever M is -- against the generic kernel's K MACs per
+// output read from global memory.  The division by M is a multiply by a host-computed
+// reciprocal (x < M + 4096*L < 2^23, M < 2^17: exact).
+// --------------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const float2 *__restrict__ in, size_t in_elems,
+                                                                       float2 *__restrict__ out, size_t n_iter,
+                                                                       const float2 *__restrict__ Hspec, int Km1,
+                                                                       const float2 *__restrict__ twtab, size_t nblocks,
+                                                                       unsigned L, unsigned M, unsigned jrow, unsigned long long magic)
+{
+    using namespace fft4k;
+    __shared__ cf lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    const size_t S = (size_t)(N - Km1);
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    cf H[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    for (; b < nblocks; b += gridDim.x) {
+        cf v[16];
+        {
+            const size_t left = in_elems - b * S;
+            load_frame<true, 0>(v, make_rsrc(in + b * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8)), j);
+        }
+        pass1(v, lds, j);
+        pass2(v, lds, j);
+        pass3(v, lds, j, tw3);
+        cf u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const int k0 = bin_of(q), k1 = bin_of(q + 1);
+            u[k0] = v[q];
+            u[k1] = v[q + 1];
+            cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
+        }
+        pass1(u, lds, j);
+        pass2(u, lds, j);
+        pass3(u, lds, j, tw3);
+        // input index of time sample i is n = b*S + i - (K-1); flat index f = n*L + jrow
+        const unsigned long long B0 = (unsigned long long)(b * S) * L + jrow + 1;   // f+1 at i' = i-(K-1) = 0 (wave-uniform)
+        const unsigned long long q0 = B0 / M;
+        const unsigned r0 = (unsigned)(B0 - q0 * M);
+        const size_t n_left = n_iter - b * S;                                       // inputs of this call from the block start
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = 256 * bin_of(q);
+            if (row + 255 < Km1) continue;
+            const int ip = row + j - Km1;
+            if (ip < 0 || (size_t)ip >= n_left) continue;
+            const unsigned x = r0 + (unsigned)ip * L;
+            const unsigned qq = (unsigned)(((unsigned long long)x * magic) >> 40);   // x / M
+            if (x - qq * M == 0) out[q0 + qq - 1] = make_float2(u[q].x, -u[q].y);
+        }
+    }
+}
+
+int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec_rows, size_t K,
+                                 size_t L, size_t M, const void *tw4096, hipStream_t st)
+{
+    if (n_iter == 0) return PCX_OK;
+    if (K < 1 || K > 2049 || M >= (1u << 17) || 4096 * L + M >= (1u << 23)) {
+        set_error("fir ols (polyphase): K=%zu L=%zu M=%zu outside the kernel's range", K, L, M);
+        return PCX_ERR_UNSUPPORTED;
+    }
+    const size_t S = 4096 - (K - 1);
+    const size_t nblocks = (n_iter + S - 1) / S;
+    const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+    const unsigned long long magic = ((1ull << 40) + M - 1) / M;   // ceil(2^40 / M)
+    for (size_t jrow = 0; jrow < L; jrow++) {
+        hipLaunchKernelGGL(fir_cf32_ols4096_poly_kernel, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                           n_iter, (const float2 *)Hspec_rows + jrow * 4096, (int)(K - 1), (const float2 *)tw4096, nblocks,
+                           (unsigned)L, (unsigned)M, (unsigned)jrow, magic);
+        PCX_LAUNCH_CHECK();
+    }
+    return PCX_OK;
+}
+
+// --------------------------------------------------------------------------------- //
 // Fused Rotate -> FIR -> FreqDemod in the frequency domain (BASELINE configs[4]).
 //
 // Same block pipeline as above with H' = phasor * H (Rotate folded into the spectrum: FIR

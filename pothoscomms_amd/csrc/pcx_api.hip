@@ -163,6 +163,8 @@ struct pcx_fir {
     DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096, wsIn, wsOut;
     size_t Kp = 8;
     bool have_ols = false;
+    bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
+    DevBuf HspecRows;
 };
 
 // FIRFilter::updateInternals, FIRFilter.cpp:327-354 (host mirror; tables uploaded lazily)
@@ -232,6 +234,25 @@ static int fir_sync_tables(pcx_fir *h)
             PCX_TRY(upload(h->tw4096, make_tw4096()));
             h->have_ols = true;
         }
+    }
+    h->have_poly = false;
+    if (h->scalar == PCX_F32 && h->cplx && (h->L > 1 || h->M > 1) && h->K <= 2049 && h->L <= 64 && h->M < (1u << 17)) {
+        // one spectrum per polyphase row: h_j[k] = taps[j + k*L] (FIRFilter.cpp:341-350)
+        std::vector<float> rows(h->L * 2 * 4096);
+        for (size_t j = 0; j < h->L; j++) {
+            std::vector<std::complex<double>> hq;
+            for (size_t k = 0; k < h->K; k++) {
+                const size_t i = j + k * h->L;
+                if (i >= h->ntaps) continue;
+                hq.push_back(std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * i] : h->taps[i]),
+                                                  h->ctaps ? (double)(float)h->taps[2 * i + 1] : 0.0));
+            }
+            const std::vector<float> H = make_hspec4096(hq);
+            std::copy(H.begin(), H.end(), rows.begin() + j * 2 * 4096);
+        }
+        PCX_TRY(upload(h->HspecRows, rows));
+        PCX_TRY(upload(h->tw4096, make_tw4096()));
+        h->have_poly = true;
     }
     h->dirty = false;
     return PCX_OK;
@@ -322,18 +343,23 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // measured sweep (tools/sweep_fir.py, 16 Mi samples): the frequency-domain kernel runs at
         // 285-325 Gsamples/s for every K <= 1023 (197 at K = 2049) while the time-domain tile
         // peaks at 240-256 and falls as 1/K beyond K ~ 48 -- so it is the choice whenever it applies
-        if (fast && h->have_ols) algo = PCX_FIR_OLS_FFT;
+        // K == 1 (the block's default unit tap) stays on the time-domain tile: a pass-through
+        // filter must return its input bit for bit, as the reference does
+        if (fast && h->K == 1) algo = PCX_FIR_DIRECT;
+        else if ((fast && h->have_ols) || h->have_poly) algo = PCX_FIR_OLS_FFT;
         else if (fast) algo = PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
-    if (algo == PCX_FIR_OLS_FFT && !(fast && h->have_ols)) {
-        set_error("fir: OLS_FFT needs complex_float32, M=L=1, K<=2049");
+    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly)) {
+        set_error("fir: OLS_FFT needs complex_float32 and K<=2049 (L<=64 rows)");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
-    if (algo == PCX_FIR_OLS_FFT) {
+    if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
+        rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT) {
         rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
     } else if (algo == PCX_FIR_DIRECT && fast) {
         rc = launch_fir_cf32_direct(in_dev, used_in, out_dev, n_out, h->tapsRev.p, h->K, h->Kp, st);

@@ -380,3 +380,26 @@ def test_angle(oracle, dev, scalar):
         assert ang_err(g, gold["angle_ref_" + NAMES[scalar]]) <= TOL
     else:
         assert np.array_equal(g, gold["angle_ref_" + NAMES[scalar]])
+
+
+@pytest.mark.parametrize("ctaps", [True, False])
+@pytest.mark.parametrize("L,M,ntaps", [(1, 2, 255), (1, 4, 64), (1, 10, 1000), (3, 1, 100), (3, 2, 61), (2, 3, 255),
+                                       (5, 7, 333), (4, 4, 16), (1, 4096, 31), (8, 1, 2049 * 8)])
+def test_fir_cf32_frequency_domain_resampling(oracle, dev, L, M, ntaps, ctaps):
+    """interpolation / decimation on the overlap-save kernel (one launch per polyphase row) vs the oracle"""
+    rng = np.random.default_rng(L * 100 + M + ntaps)
+    n = 3 * 4096 + 1234 + (-(-ntaps // L))
+    x = rand_stream(rng, oracle.F32, n, True)
+    taps = _taps(rng, ntaps, ctaps)
+    ref_blk = oracle.Fir(oracle.F32, True, ctaps)
+    f = dev.FirFilter("complex_float32", "COMPLEX" if ctaps else "REAL")
+    for b in (ref_blk, f):
+        b.set_taps(taps); b.set_interpolation(L); b.set_decimation(M)
+    ref_blk.activate()
+    for cap in (n * L, 1000):
+        ref, rc, rp, _ = ref_blk.work(x, cap)
+        got, gc, gp = f.process(x, cap)
+        assert f.last_algo == dev._lib.FIR_OLS_FFT
+        assert (gc, gp) == (rc, rp)
+        if rp:
+            assert nerr(got, ref) <= TOL

@@ -58,7 +58,7 @@ int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse,
     const float2 *tab = static_cast<const float2 *>(tw4096);
     // persistent workgroups: LDS (34.8 KB) admits 4 per CU; each walks frames with a grid
     // stride, keeping its twiddles in registers and the next frame in flight
-    const unsigned grid = (unsigned)(nframes < 1024 ? nframes : 1024);
+    const unsigned grid = persistent_grid(nframes, 1024);
     if (inverse)
         hipLaunchKernelGGL(fft4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab);
     else

@@ -128,20 +128,20 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     // as the prefetch does, with 40 fewer VGPRs.  PCX_OLS_VARIANT=0 selects the prefetch form.
     static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : 1; }();
     if (variant == 4) {   // A/B: contiguous block runs per workgroup
-        const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+        const unsigned grid = persistent_grid(nblocks, 1024);
         hipLaunchKernelGGL((fir_cf32_ols4096_kernel<false, 0, 0, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems,
                            (float2 *)out, n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
     } else if (variant >= 2) {   // A/B: cache-policy variants of the 4-workgroup form (2: nt loads, 3: nt loads + nt stores)
-        const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+        const unsigned grid = persistent_grid(nblocks, 1024);
         auto k = variant == 2 ? fir_cf32_ols4096_kernel<false, 2, 0> : fir_cf32_ols4096_kernel<false, 2, 2>;
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
                            n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
     } else if (variant == 1) {   // 4 persistent workgroups per CU, no register prefetch
-        const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+        const unsigned grid = persistent_grid(nblocks, 1024);
         hipLaunchKernelGGL(fir_cf32_ols4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
                            n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
     } else {              // 3 persistent workgroups per CU, next block prefetched in registers
-        const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);
+        const unsigned grid = persistent_grid(nblocks, 768);
         hipLaunchKernelGGL(fir_cf32_ols4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
                            n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
     }
@@ -226,7 +226,7 @@ int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, siz
     }
     const size_t S = 4096 - (K - 1);
     const size_t nblocks = (n_iter + S - 1) / S;
-    const unsigned grid = (unsigned)(nblocks < 1024 ? nblocks : 1024);
+    const unsigned grid = persistent_grid(nblocks, 1024);
     const unsigned long long magic = ((1ull << 40) + M - 1) / M;   // ceil(2^40 / M)
     for (size_t jrow = 0; jrow < L; jrow++) {
         hipLaunchKernelGGL(fir_cf32_ols4096_poly_kernel, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
@@ -343,7 +343,7 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
     if (K < 1 || K > 2048) { set_error("fm chain ols: K=%zu outside 1..2048", K); return PCX_ERR_UNSUPPORTED; }
     const size_t S = 4096 - K;
     const size_t nblocks = (n_out + S - 1) / S;
-    const unsigned grid = (unsigned)(nblocks < 768 ? nblocks : 768);
+    const unsigned grid = persistent_grid(nblocks, 768);
     hipLaunchKernelGGL(fmchain_cf32_ols4096_kernel, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float *)out,
                        n_out, (const float2 *)Hspec, (int)K, (const float2 *)tw4096, nblocks, (const float2 *)prev_in,
                        (float2 *)prev_out);

@@ -90,6 +90,41 @@ static std::vector<float> make_tw4096()
     return t;
 }
 
+// lane-constant table of the radix-16 family (fft_r16.hip): [15][16] pass Ns=16, [15][256] pass
+// Ns=256 (numBins >= 4096), then the final radix-R pass: entry (t*(R-1) + r-1, l) = W_N^((l + t*LPF) r)
+static std::vector<float> make_tw_r16(int log2n)
+{
+    const int N = 1 << log2n, LPF = N / 16, A = log2n / 4, R = 1 << (log2n % 4);
+    std::vector<float> t(2 * fft_r16_table_elems(log2n));
+    const double two_pi = 6.283185307179586476925286766559;
+    auto put = [&](size_t idx, double turns) {
+        t[2 * idx] = (float)std::cos(-two_pi * turns);
+        t[2 * idx + 1] = (float)std::sin(-two_pi * turns);
+    };
+    auto angle15 = [](int p, double base) {
+        if (p < 3) return base * 4.0 * (p + 1);
+        const int n2 = (p - 3) / 4 + 1, k1 = (p - 3) % 4;
+        return base * n2 + (double)(n2 * k1) / 16.0;
+    };
+    size_t off = 0;
+    for (int p = 0; p < 15; p++)
+        for (int kk = 0; kk < 16; kk++) put(off + p * 16 + kk, angle15(p, (double)kk / 256.0));
+    off += 15 * 16;
+    if (A >= 3) {
+        for (int p = 0; p < 15; p++)
+            for (int j = 0; j < 256; j++) put(off + p * 256 + j, angle15(p, (double)j / 4096.0));
+        off += 15 * 256;
+    }
+    if (R > 1) {
+        const int G = 16 / R;
+        for (int tt = 0; tt < G; tt++)
+            for (int r = 1; r < R; r++)
+                for (int l = 0; l < LPF; l++)
+                    put(off + (size_t)(tt * (R - 1) + (r - 1)) * LPF + l, (double)(((long long)(l + tt * LPF) * r) % N) / (double)N);
+    }
+    return t;
+}
+
 // H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096 (the 1/N of the inverse transform folded
 // in), accumulated in double, rounded once to float; natural bin order
 static std::vector<float> make_hspec4096(const std::vector<std::complex<double>> &h)
@@ -398,7 +433,8 @@ struct pcx_fft {
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
-    enum Kind { IDENTITY, R16_4096, POW2, Q15_POW2, MIXED } kind = MIXED;
+    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED } kind = MIXED;
+    int log2n = 0;
     DevBuf tw, wsIn, wsOut;
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
 };
@@ -412,7 +448,8 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     const size_t esz = 2 * (size_t)scalar_bytes(scalar);
     const bool pow2 = (num_bins & (num_bins - 1)) == 0;
     // single-workgroup LDS plans: the frame (x2 for ping-pong) must fit 160 KB
-    if (num_bins > 1 && !(scalar == PCX_F32 && num_bins == 4096) && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
+    const bool r16 = scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384;
+    if (num_bins > 1 && !r16 && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
         set_error("FFT: numBins=%zu (%s) does not fit the single-workgroup LDS plan; not implemented on the device", num_bins,
                   scalar == PCX_F64 ? "complex_float64" : scalar == PCX_F32 ? "complex_float32" : "complex_int16");
         return PCX_ERR_UNSUPPORTED;
@@ -439,6 +476,10 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     } else if (scalar == PCX_F32 && num_bins == 4096) {
         h->kind = pcx_fft::R16_4096;
         rc = upload(h->tw, make_tw4096());
+    } else if (scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384) {
+        h->kind = pcx_fft::R16;
+        while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
+        rc = upload(h->tw, make_tw_r16(h->log2n));
     } else if (scalar != PCX_I16) {
         // forward table exp(-j 2 pi i / N); the power-of-two kernels conjugate it for the inverse,
         // the mixed-radix kernel gets the direction baked in like kissfft's fill_twiddles (kissfft.hh:21-26)
@@ -483,6 +524,7 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         PCX_HIP(hipMemcpyAsync(out_dev, in_dev, nframes * 2 * (size_t)scalar_bytes(h->scalar), hipMemcpyDeviceToDevice, st));
         return PCX_OK;
     case pcx_fft::R16_4096: return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, st);
+    case pcx_fft::R16: return launch_fft_r16_cf32(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st);
     case pcx_fft::POW2:
         return h->scalar == PCX_F32 ? launch_fft_pow2_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st)
                                     : launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);

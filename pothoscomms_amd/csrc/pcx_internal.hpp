@@ -81,6 +81,17 @@ inline unsigned stream_grid(size_t work_items, unsigned block)
     return (unsigned)g;
 }
 
+// grid of a persistent-workgroup kernel that walks `units` work items with a grid stride:
+// at most `slots` workgroups (CUs x resident workgroups per CU), sized so that every
+// workgroup gets the same number of rounds -- with units/slots = 17.06 a grid of `slots`
+// would run an 18th round at 6 % occupancy (a 5 % tail on the headline FIR launch).
+inline unsigned persistent_grid(size_t units, unsigned slots)
+{
+    if (units <= slots) return (unsigned)(units ? units : 1);
+    const size_t rounds = (units + slots - 1) / slots;
+    return (unsigned)((units + rounds - 1) / rounds);
+}
+
 // ---- kernel launchers implemented in the .hip files ----
 int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n, hipStream_t st);
 int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st);
@@ -122,6 +133,10 @@ int launch_fft_pow2_cf64(const void *in, void *out, size_t nbins, size_t nframes
 // kiss_fft Q15 (bit-exact): nbins = product of radix 4/2 stages; tw = int16 pairs
 int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
                    const int *radix_host, int nstages, hipStream_t st);
+
+// complex_float32, numBins = 2^log2n in 16..16384 (except 4096): register-resident radix-16 family
+size_t fft_r16_table_elems(int log2n);
+int launch_fft_r16_cf32(const void *in, void *out, int log2n, size_t nframes, bool inverse, const void *tw, hipStream_t st);
 
 // any numBins: kissfft's mixed-radix plan (radix 2/3/4/5 + generic), f32 / f64 / Q15 (bit-exact)
 int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,

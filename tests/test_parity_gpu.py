@@ -234,7 +234,7 @@ def test_fir_errors(dev):
 # FFT
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("inverse", [False, True])
-@pytest.mark.parametrize("nbins", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("nbins", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_fft_cf32(oracle, dev, nbins, inverse):
     rng = np.random.default_rng(nbins)
     nframes = 5 if nbins >= 1024 else 37

@@ -150,6 +150,88 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 }
 
 // --------------------------------------------------------------------------------- //
+// REAL float32 streams with REAL taps (FIRFilterFactory's first row, FIRFilter.cpp:374): two
+// overlap-save blocks share one complex transform.  With real taps the filter acts on the
+// real and imaginary parts independently, so z = xA + i*xB (xA, xB = blocks 2p and 2p+1 of the
+// real stream) gives Re(h*z) = h*xA and Im(h*z) = h*xB: same pipeline, half the transforms
+// per sample.  Loads/stores are 4 bytes per lane (two rows per complex element).
+// --------------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__restrict__ in, size_t in_elems,
+                                                                 float *__restrict__ out, size_t n_out,
+                                                                 const float2 *__restrict__ Hspec, int Km1,
+                                                                 const float2 *__restrict__ twtab, size_t nblocks)
+{
+    using namespace fft4k;
+    __shared__ cf lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    const size_t S = (size_t)(N - Km1);
+    const size_t npairs = (nblocks + 1) / 2;
+    size_t p = blockIdx.x;
+    if (p >= npairs) return;
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    cf H[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    for (; p < npairs; p += gridDim.x) {
+        const size_t bA = 2 * p, bB = 2 * p + 1;
+        const size_t leftA = in_elems - bA * S;
+        const size_t leftB = bB < nblocks ? in_elems - bB * S : 0;
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(in + bA * S, (unsigned)((leftA < (size_t)N ? leftA : (size_t)N) * 4));
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(in + (bB < nblocks ? bB * S : 0), (unsigned)((leftB < (size_t)N ? leftB : (size_t)N) * 4));
+        cf v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(ra, (j + 256 * r) * 4, 0, 0);
+            const unsigned b = __builtin_amdgcn_raw_buffer_load_b32(rb, (j + 256 * r) * 4, 0, 0);
+            v[r] = cf{__uint_as_float(a), __uint_as_float(b)};
+        }
+        pass1(v, lds, j);
+        pass2(v, lds, j);
+        pass3(v, lds, j, tw3);
+        cf u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const int k0 = bin_of(q), k1 = bin_of(q + 1);
+            u[k0] = v[q];
+            u[k1] = v[q + 1];
+            cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
+        }
+        pass1(u, lds, j);
+        pass2(u, lds, j);
+        pass3(u, lds, j, tw3);
+        // y = conj(u): real part -> block A's outputs, -imag part -> block B's
+        const size_t roomA = n_out - bA * S;
+        const size_t roomB = bB < nblocks ? n_out - bB * S : 0;
+        const __amdgpu_buffer_rsrc_t wa = make_rsrc(out + bA * S, (unsigned)((roomA < S ? roomA : S) * 4));
+        const __amdgpu_buffer_rsrc_t wb = make_rsrc(out + (bB < nblocks ? bB * S : 0), (unsigned)((roomB < S ? roomB : S) * 4));
+        const unsigned vbase = (unsigned)(j - Km1) * 4u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = 256 * bin_of(q);
+            if (row + 255 < Km1) continue;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[q].x), wa, (int)(vbase + (unsigned)row * 4u), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-u[q].y), wb, (int)(vbase + (unsigned)row * 4u), 0, 0);
+        }
+    }
+}
+
+int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
+                           const void *tw4096, hipStream_t st)
+{
+    if (n_out == 0) return PCX_OK;
+    if (K < 1 || K > 2049) { set_error("fir ols (real): K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
+    const size_t S = 4096 - (K - 1);
+    const size_t nblocks = (n_out + S - 1) / S;
+    const unsigned grid = persistent_grid((nblocks + 1) / 2, 1024);
+    hipLaunchKernelGGL(fir_f32_ols4096_kernel, dim3(grid), dim3(256), 0, st, (const float *)in, in_elems, (float *)out, n_out,
+                       (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nblocks);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+// --------------------------------------------------------------------------------- //
 // Rational resampling (interpolation L, decimation M) on the same block pipeline.
 //
 // FIRFilter.cpp:286-302 walks the flat index f = n*L + j (input n, polyphase row j) and emits

@@ -199,6 +199,7 @@ struct pcx_fir {
     size_t Kp = 8;
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
+    bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
     DevBuf HspecRows;
 };
 
@@ -269,6 +270,14 @@ static int fir_sync_tables(pcx_fir *h)
             PCX_TRY(upload(h->tw4096, make_tw4096()));
             h->have_ols = true;
         }
+    }
+    h->have_real_ols = false;
+    if (h->scalar == PCX_F32 && !h->cplx && h->M == 1 && h->L == 1 && h->K <= 2049) {
+        std::vector<std::complex<double>> hq(h->K);
+        for (size_t k = 0; k < h->K; k++) hq[k] = std::complex<double>((double)(float)h->taps[k], 0.0);
+        PCX_TRY(upload(h->Hspec, make_hspec4096(hq)));
+        PCX_TRY(upload(h->tw4096, make_tw4096()));
+        h->have_real_ols = true;
     }
     h->have_poly = false;
     if (h->scalar == PCX_F32 && h->cplx && (h->L > 1 || h->M > 1) && h->K <= 2049 && h->L <= 64 && h->M < (1u << 17)) {
@@ -381,18 +390,20 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // K == 1 (the block's default unit tap) stays on the time-domain tile: a pass-through
         // filter must return its input bit for bit, as the reference does
         if (fast && h->K == 1) algo = PCX_FIR_DIRECT;
-        else if ((fast && h->have_ols) || h->have_poly) algo = PCX_FIR_OLS_FFT;
+        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1)) algo = PCX_FIR_OLS_FFT;
         else if (fast) algo = PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
-    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly)) {
+    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols)) {
         set_error("fir: OLS_FFT needs complex_float32 and K<=2049 (L<=64 rows)");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
-    if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
+    if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
+        rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {
         rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);

@@ -119,6 +119,9 @@ int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                             const void *tw4096, hipStream_t st);
 
+// real float32 stream, real taps, M=L=1: two real blocks per complex transform
+int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
+                           const void *tw4096, hipStream_t st);
 // same pipeline with interpolation L / decimation M: one launch per polyphase row;
 // Hspec_rows: L spectra of 4096 cf32 (row j = FFT(taps[j + k*L]) / 4096); n_iter = inputs consumed
 int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec_rows, size_t K,

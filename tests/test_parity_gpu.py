@@ -403,3 +403,19 @@ def test_fir_cf32_frequency_domain_resampling(oracle, dev, L, M, ntaps, ctaps):
         assert (gc, gp) == (rc, rp)
         if rp:
             assert nerr(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("ntaps", [2, 31, 255, 1024, 2049])
+def test_fir_real_f32_frequency_domain(oracle, dev, ntaps):
+    """real float32 stream with REAL taps: two real blocks per complex transform"""
+    rng = np.random.default_rng(ntaps + 77)
+    for n in (ntaps + 5, 3842 * 2 + 100 + ntaps, 3842 * 5 + 7 + ntaps):
+        x = rand_stream(rng, oracle.F32, n, False)
+        taps = _taps(rng, ntaps, False)
+        ref_blk = oracle.Fir(oracle.F32, False, False); ref_blk.set_taps(taps); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n)
+        f = dev.FirFilter("float32", "REAL"); f.set_taps(taps)
+        got, gc, gp = f.process(x, n)
+        assert f.last_algo == dev._lib.FIR_OLS_FFT
+        assert (gc, gp) == (rc, rp) == (n - ntaps + 1, n - ntaps + 1)
+        assert nerr(got, ref) <= TOL

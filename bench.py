@@ -118,10 +118,18 @@ def main():
     from pothoscomms_amd.stream import ShardedFir
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # one rank per GPU on the node the driver gives us
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  PCX_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
+        # control flow on a single-GPU box (ranks then share cuda:0 and the halo goes through gloo).
+        backend = os.environ.get("PCX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     C = args.shard
     wl = args.workload

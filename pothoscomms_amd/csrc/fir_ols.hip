@@ -31,16 +31,25 @@ namespace pcx {
 // 0.232 ms, non-temporal loads 0.252 ms per 64 Mi samples -- consecutive blocks re-read K-1
 // samples, and those hits are lost when the first touch bypasses L2 -- so the FIR keeps plain
 // loads (the frame-disjoint FFT kernel gains 3 % from nt).
-template <bool PREFETCH, int LAUX = 0, int SAUX = 0, bool CHUNKED = false>
-__global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
+// DIAG (timing-only builds, wrong outputs): 1 = every block reads/writes block 0 (cache resident:
+// the compute floor), 2 = no transforms (load, store: the memory floor)
+// HGLOBAL: fetch the lane's 16 H bins from L2 in every block instead of holding them in 32 VGPRs
+// -- room for the register prefetch at 4 workgroups per CU.
+template <bool PREFETCH, int LAUX = 0, int SAUX = 0, bool CHUNKED = false, int DIAG = 0, bool HGLOBAL = false>
+__global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
-                                                                  const float2 *__restrict__ Hspec, int Km1,
-                                                                  const float2 *__restrict__ twtab, size_t nfull, size_t nblocks)
+                                                                  const float2 *__restrict__ Hspec, int Kov, int pad,
+                                                                  const float2 *__restrict__ twtab, size_t first_full,
+                                                                  size_t nfull, size_t nblocks)
 {
+    // Kov >= K-1 outputs are dropped at the head of every block and the block's input window starts
+    // `pad` = Kov-(K-1) samples before sample b*S: with Kov a multiple of 16 every row this kernel
+    // STORES starts on a 128-byte line (a K-1 = 254 overlap leaves each 512-byte row straddling
+    // lines: measured 11 % slower on the load+store floor).
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
-    const size_t S = (size_t)(N - Km1);
+    const size_t S = (size_t)(N - Kov);
     // CHUNKED: each persistent workgroup walks a CONTIGUOUS run of blocks (balanced partition)
     // instead of a grid stride, so the K-1 samples block b+1 shares with block b were fetched
     // by the same CU a moment ago (L2/L1 hit instead of a second trip to the memory side).
@@ -61,12 +70,28 @@ __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel
     load_pass3_twiddles(tw3, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
     cf H[16];
+    if (!HGLOBAL) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+        for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    }
     auto fetch = [&](cf (&dst)[16], size_t blk) {
-        const size_t left = in_elems - blk * S;   // samples from the block start to the end of the buffer
-        if (blk < nfull) load_frame<false, LAUX>(dst, make_rsrc(in + blk * S, N * 8), j);
-        else load_frame<true, LAUX>(dst, make_rsrc(in + blk * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8)), j);
+        if (DIAG == 1) blk = first_full;
+        if (blk >= first_full && blk < nfull) {
+            load_frame<false, LAUX>(dst, make_rsrc(in + blk * S - pad, N * 8), j);
+        } else {
+            // ragged: block 0 when pad > 0 (its window would start before the buffer: those samples
+            // only feed dropped outputs, read as 0 through the range check) and the tail block
+            const size_t shift = blk * S >= (size_t)pad ? 0 : (size_t)pad - blk * S;
+            const size_t first = blk * S + shift - pad;
+            const size_t left = in_elems > first ? in_elems - first : 0;
+            const size_t want = (size_t)N - shift;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 8));
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * r - (int)shift) * 8, 0, LAUX);
+                dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+            }
+        }
     };
     cf nx[16];
     if (PREFETCH) fetch(nx, b);
@@ -80,14 +105,22 @@ __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel
         } else {
             fetch(v, b);
         }
+        if (DIAG != 2) {
         pass1(v, lds, j);
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
+        }
         // spectrum times H, re-ordered into natural register order for the next pass 1.
         // The inverse transform runs on the FORWARD passes: IFFT(z) = conj(FFT(conj(z))), so
         // one set of twiddles serves both directions.  u = conj(v * H); the final conj rides
         // on the store.
         cf u[16];
+        if (HGLOBAL) {
+            const cf *Hp = reinterpret_cast<const cf *>(Hspec);
+            asm volatile("" : "+s"(Hp));   // loop-invariant loads must stay in the loop (L2 hits, not registers)
+#pragma unroll
+            for (int k = 0; k < 16; k++) H[k] = Hp[j + 256 * k];
+        }
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
             const int k0 = bin_of(q), k1 = bin_of(q + 1);
@@ -95,19 +128,22 @@ __global__ __launch_bounds__(256, PREFETCH ? 3 : 4) void fir_cf32_ols4096_kernel
             u[k1] = v[q + 1];
             cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
+        if (DIAG != 2) {
         pass1(u, lds, j);
         pass2(u, lds, j);
         pass3(u, lds, j, tw3);
+        }
         // time sample i of the block is output b*S + i - (K-1).  For i < K-1 (circularly
         // aliased) the unsigned byte offset wraps far beyond num_records and the store is
         // dropped by the range check, as are outputs past n_out in the last block.
-        const size_t room = n_out - b * S;
-        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)((room < S ? room : S) * 8));
-        const unsigned vbase = (unsigned)(j - Km1) * 8u;
+        const size_t bo = DIAG == 1 ? 0 : b;
+        const size_t room = n_out - bo * S;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + bo * S, (unsigned)((room < S ? room : S) * 8));
+        const unsigned vbase = (unsigned)(j - Kov) * 8u;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int row = 256 * bin_of(q);
-            if (row + 255 < Km1) continue;                    // whole row aliased: uniform skip
+            if (row + 255 < Kov) continue;                    // whole row dropped: uniform skip
             store_cf<SAUX>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
     }
@@ -118,33 +154,36 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols: K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
-    const size_t S = 4096 - (K - 1);
-    // full blocks: b*S + 4096 <= in_elems and (b+1)*S <= n_out
-    size_t nfull = n_out / S;
-    while (nfull > 0 && (nfull - 1) * S + 4096 > in_elems) nfull--;
-    const size_t nblocks = (n_out + S - 1) / S;
-    // measured (64 Mi samples, K = 255, 200 launches): 4 workgroups/CU without prefetch 0.234 ms,
-    // 3 workgroups/CU with register prefetch 0.238 ms -- occupancy hides the load latency as well
-    // as the prefetch does, with 40 fewer VGPRs.  PCX_OLS_VARIANT=0 selects the prefetch form.
+    // PCX_OLS_VARIANT (A/B and diagnostics): 1 default (4 workgroups/CU, no prefetch), 0 register
+    // prefetch (3/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs, 10/11 compute-only /
+    // memory-only timing builds.  PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
     static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : 1; }();
-    if (variant == 4) {   // A/B: contiguous block runs per workgroup
-        const unsigned grid = persistent_grid(nblocks, 1024);
-        hipLaunchKernelGGL((fir_cf32_ols4096_kernel<false, 0, 0, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems,
-                           (float2 *)out, n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
-    } else if (variant >= 2) {   // A/B: cache-policy variants of the 4-workgroup form (2: nt loads, 3: nt loads + nt stores)
-        const unsigned grid = persistent_grid(nblocks, 1024);
-        auto k = variant == 2 ? fir_cf32_ols4096_kernel<false, 2, 0> : fir_cf32_ols4096_kernel<false, 2, 2>;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
-                           n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
-    } else if (variant == 1) {   // 4 persistent workgroups per CU, no register prefetch
-        const unsigned grid = persistent_grid(nblocks, 1024);
-        hipLaunchKernelGGL(fir_cf32_ols4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
-                           n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
-    } else {              // 3 persistent workgroups per CU, next block prefetched in registers
-        const unsigned grid = persistent_grid(nblocks, 768);
-        hipLaunchKernelGGL(fir_cf32_ols4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
-                           n_out, (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nfull, nblocks);
+    static const int align = [] { const char *e = getenv("PCX_OLS_ALIGN"); return e ? atoi(e) : 1; }();
+    const size_t Km1 = K - 1;
+    const size_t Kov = align ? (Km1 + 15) / 16 * 16 : Km1;   // <= 2048
+    const size_t pad = Kov - Km1;
+    const size_t S = 4096 - Kov;
+    const size_t nblocks = (n_out + S - 1) / S;
+    // full blocks: window inside the buffer and all S outputs wanted
+    const size_t first_full = pad > 0 ? 1 : 0;
+    size_t nfull = n_out / S;
+    while (nfull > first_full && (nfull - 1) * S - pad + 4096 > in_elems) nfull--;
+    if (nfull < first_full) nfull = first_full;
+    const float2 *pi = (const float2 *)in, *ph = (const float2 *)Hspec, *pt = (const float2 *)tw4096;
+    float2 *po = (float2 *)out;
+    const unsigned g4 = persistent_grid(nblocks, 1024), g3 = persistent_grid(nblocks, 768);
+#define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks)
+    switch (variant) {
+    case 0: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true>), g3); break;
+    case 2: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 0>), g4); break;
+    case 3: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 2>), g4); break;
+    case 4: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, true>), g4); break;
+    case 5: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 0, 0, false, 0, true>), g4); break;
+    case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 1>), g4); break;
+    case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 2>), g4); break;
+    default: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false>), g4); break;
     }
+#undef PCX_OLS_LAUNCH
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

@@ -371,7 +371,7 @@ int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, siz
 // The lane's neighbour sample y[m-1] lives in lane j-1, so the block's time samples make one
 // extra trip through the LDS image.  12 algorithmic bytes per sample (8 in, 4 out).
 // --------------------------------------------------------------------------------- //
-__global__ __launch_bounds__(256, 2) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
+__global__ __launch_bounds__(256, 3) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                       float *__restrict__ out, size_t n_out,
                                                                       const float2 *__restrict__ Hspec, int K,
                                                                       const float2 *__restrict__ twtab, size_t nblocks,
@@ -406,14 +406,9 @@ __global__ __launch_bounds__(256, 2) void fmchain_cf32_ols4096_kernel(const floa
             dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
         }
     };
-    cf nx[16];
-    fetch(nx, b);
     for (; b < nblocks; b += gridDim.x) {
         cf v[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = nx[r];
-        const size_t bn = b + gridDim.x;
-        if (bn < nblocks) fetch(nx, bn);
+        fetch(v, b);
         pass1(v, lds, j);
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
@@ -450,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void fmchain_cf32_ols4096_kernel(const floa
             const cf p = lds[i > 0 ? i - 1 : 0];              // conj(y[m-1])
             // y[m] * conj(y[m-1]) = conj(a) * p
             const float re = a.x * p.x + a.y * p.y, im = a.x * p.y - a.y * p.x;
-            const float d = atan2f(im, re);
+            const float d = fast_atan2f(im, re);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)row * 4u), 0, 0);
             if (i >= K && (size_t)(i - K) == cnt - 1 && b == nblocks - 1) prev_out[0] = make_float2(a.x, a.y);
         }

@@ -60,6 +60,11 @@ PCX_API int pcx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, vo
 PCX_API int pcx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 PCX_API int pcx_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 PCX_API int pcx_stream_sync(void *stream);
+/* page-locked host memory for port buffers: a Pothos BufferManager that hands out slabs from
+ * pcx_host_alloc lets the plain (host-pointer) entry points copy at PCIe line rate instead of
+ * staging pageable memory */
+PCX_API int pcx_host_alloc(void **hptr, size_t bytes);
+PCX_API int pcx_host_free(void *hptr);
 /* synthetic stream generator on the device: the same splitmix64 counter hash as
  * the oracle's orc_fill_uniform_f32 (uniform [-1,1), bit-identical values) */
 PCX_API int pcx_fill_uniform_f32_dev(float *dst_dev, size_t n_scalars, uint64_t seed, uint64_t offset, void *stream);

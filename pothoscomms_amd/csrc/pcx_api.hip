@@ -180,6 +180,13 @@ int pcx_dev_free(void *dptr) { PCX_HIP(hipFree(dptr)); return PCX_OK; }
 int pcx_memcpy_h2d(void *d, const void *s, size_t n, void *st) { PCX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st))); return PCX_OK; }
 int pcx_memcpy_d2h(void *d, const void *s, size_t n, void *st) { PCX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, as_stream(st))); return PCX_OK; }
 int pcx_memcpy_d2d(void *d, const void *s, size_t n, void *st) { PCX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, as_stream(st))); return PCX_OK; }
+int pcx_host_alloc(void **hptr, size_t bytes)
+{
+    PCX_CHECK_ARG(hptr, "null hptr");
+    PCX_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return PCX_OK;
+}
+int pcx_host_free(void *hptr) { PCX_HIP(hipHostFree(hptr)); return PCX_OK; }
 int pcx_stream_sync(void *st) { PCX_HIP(hipStreamSynchronize(as_stream(st))); return PCX_OK; }
 int pcx_fill_uniform_f32_dev(float *dst, size_t n, uint64_t seed, uint64_t offset, void *st)
 {
@@ -430,6 +437,9 @@ int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size
     const size_t esz = fir_elem_bytes(h), used_in = N + h->K - 1, n_out = (N / h->M) * h->L;
     PCX_TRY(h->wsIn.ensure(used_in * esz));
     PCX_TRY(h->wsOut.ensure(n_out * esz));
+    // one H2D, the kernel, one D2H.  (A chunked three-stream pipeline was measured on page-locked
+    // buffers: 5.4 ms against 4.8 ms for this form at 16 Mi samples -- the two PCIe directions did
+    // not overlap on this platform -- so the simple form stays.)
     PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, used_in * esz, hipMemcpyHostToDevice, nullptr));
     PCX_TRY(pcx_fir_process_dev(h, h->wsIn.p, used_in, h->wsOut.p, n_out, consumed, produced, nullptr));
     PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, *produced * esz, hipMemcpyDeviceToHost, nullptr));

@@ -419,3 +419,19 @@ def test_fir_real_f32_frequency_domain(oracle, dev, ntaps):
         assert f.last_algo == dev._lib.FIR_OLS_FFT
         assert (gc, gp) == (rc, rp) == (n - ntaps + 1, n - ntaps + 1)
         assert nerr(got, ref) <= TOL
+
+
+def test_fir_host_path_large_buffer(oracle, dev):
+    """a multi-megasample host buffer through the staging path (seams of the device blocks checked)"""
+    rng = np.random.default_rng(123)
+    ntaps, n = 255, 7 * (1 << 20) + 12345
+    x = rand_stream(rng, oracle.F32, n + ntaps - 1, True)
+    taps = _taps(rng, ntaps, True)
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(taps)
+    got, c, p = f.process(x, n)
+    assert (c, p) == (n, n)
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(taps); ref.activate()
+    for start in (0, (1 << 21) - 300, 3 * (1 << 21) - 300, n - 5000):     # chunk seams and both ends
+        want, _, pp, _ = ref.work(x[start:start + 5000 + ntaps - 1], 5000)
+        m = min(5000, n - start)
+        assert nerr(got[start:start + m], want[:m]) <= TOL, start

@@ -435,3 +435,35 @@ def test_fir_host_path_large_buffer(oracle, dev):
         want, _, pp, _ = ref.work(x[start:start + 5000 + ntaps - 1], 5000)
         m = min(5000, n - start)
         assert nerr(got[start:start + m], want[:m]) <= TOL, start
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fir_randomised_configurations(oracle, dev, seed):
+    """random (type, taps kind, K, L, M, buffer sizes, output room) through AUTO vs the oracle's work()"""
+    rng = np.random.default_rng(1000 + seed)
+    scalar = [oracle.F32, oracle.F32, oracle.F32, oracle.F64, oracle.I16, oracle.I8, oracle.I32][seed % 7]
+    is_complex = bool(rng.integers(0, 4) > 0) or scalar != oracle.F32
+    ctaps = is_complex and bool(rng.integers(0, 2))
+    L, M = int(rng.integers(1, 5)), int(rng.integers(1, 6))
+    if seed % 3 == 0:
+        L = M = 1
+    ntaps = int(rng.integers(1, 700 if scalar == oracle.F32 else 80))
+    K = -(-ntaps // L)
+    n_in = int(rng.integers(K, K + 30000))
+    out_cap = int(rng.integers(1, 2 * n_in * L // M + 10))
+    taps = _taps(rng, ntaps, ctaps) * (1.0 if scalar in (oracle.F32, oracle.F64) else 0.9)
+    x = rand_stream(rng, scalar, n_in, is_complex, amp=1000 if scalar not in (oracle.I8,) else 100)
+    ref = oracle.Fir(scalar, is_complex, ctaps)
+    f = dev.FirFilter((scalar, is_complex), "COMPLEX" if ctaps else "REAL")
+    for b in (ref, f):
+        b.set_taps(taps); b.set_interpolation(L); b.set_decimation(M)
+    ref.activate()
+    want, rc, rp, _ = ref.work(x, out_cap)
+    got, gc, gp = f.process(x, out_cap)
+    assert (gc, gp) == (rc, rp), (scalar, is_complex, ctaps, L, M, ntaps, n_in, out_cap)
+    if rp == 0:
+        return
+    if scalar in (oracle.F32, oracle.F64):
+        assert nerr(got, want) <= (TOL if scalar == oracle.F32 else 1e-12)
+    else:
+        assert np.array_equal(got, want)

@@ -21,6 +21,11 @@
  *     owned by the handle and return after the result is in `out`.
  *   - handles are not thread-safe; one handle per block instance, exactly as
  *     Pothos serialises work() and setters on one actor.
+ *   - a handle is bound to ONE device: the device current (pcx_set_device) on
+ *     the calling thread at the handle's first device-touching call.  Later
+ *     calls from any thread run on that device and leave the caller's current
+ *     device unchanged, so a single Pothos process can place blocks on
+ *     different GPUs.
  *   - there is NO CPU fallback: a type/size the device path does not implement
  *     returns PCX_ERR_UNSUPPORTED.
  */

@@ -127,24 +127,25 @@ static std::vector<float> make_tw_r16(int log2n)
 
 // H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096 (the 1/N of the inverse transform folded
 // in), accumulated in double, rounded once to float; natural bin order
-static std::vector<float> make_hspec4096(const std::vector<std::complex<double>> &h)
+static std::vector<float> make_hspec(const std::vector<std::complex<double>> &h, size_t N)
 {
-    std::vector<double> cs(2 * 4096);
+    std::vector<double> cs(2 * N);
     const double two_pi = 6.283185307179586476925286766559;
-    for (int i = 0; i < 4096; i++) { cs[2 * i] = std::cos(two_pi * i / 4096.0); cs[2 * i + 1] = -std::sin(two_pi * i / 4096.0); }
-    std::vector<float> H(2 * 4096);
-    for (size_t b = 0; b < 4096; b++) {
+    for (size_t i = 0; i < N; i++) { cs[2 * i] = std::cos(two_pi * (double)i / (double)N); cs[2 * i + 1] = -std::sin(two_pi * (double)i / (double)N); }
+    std::vector<float> H(2 * N);
+    for (size_t b = 0; b < N; b++) {
         double sr = 0, si = 0;
         for (size_t k = 0; k < h.size(); k++) {
-            const size_t e = (b * k) & 4095;
+            const size_t e = (b * k) & (N - 1);
             sr += h[k].real() * cs[2 * e] - h[k].imag() * cs[2 * e + 1];
             si += h[k].real() * cs[2 * e + 1] + h[k].imag() * cs[2 * e];
         }
-        H[2 * b] = (float)(sr / 4096.0);
-        H[2 * b + 1] = (float)(si / 4096.0);
+        H[2 * b] = (float)(sr / (double)N);
+        H[2 * b + 1] = (float)(si / (double)N);
     }
     return H;
 }
+static std::vector<float> make_hspec4096(const std::vector<std::complex<double>> &h) { return make_hspec(h, 4096); }
 
 }  // namespace pcx
 
@@ -193,10 +194,25 @@ int pcx_fill_uniform_f32_dev(float *dst, size_t n, uint64_t seed, uint64_t offse
     return launch_fill_uniform_f32(dst, n, seed, offset, as_stream(st));
 }
 
+
+// A handle belongs to ONE device: the one current on the calling thread at the first call that
+// touches the device.  Later calls (any thread -- Pothos runs every block on its own) switch to
+// it for the duration of the call and restore the caller's device afterwards.
+struct DeviceScope {
+    int prev = -1; bool switched = false;
+    explicit DeviceScope(int &bound)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; return; }
+        if (bound < 0) { bound = prev; return; }
+        if (bound != prev) switched = (hipSetDevice(bound) == hipSuccess);
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
 /* ===================================================================== *
  *  FIR
  * ===================================================================== */
 struct pcx_fir {
+    int device = -1;
     int scalar = PCX_F32, cplx = 1, ctaps = 1;
     std::vector<double> taps;  // ntaps * (ctaps ? 2 : 1)
     size_t ntaps = 1, M = 1, L = 1, K = 1, inputRequire = 1;
@@ -208,7 +224,26 @@ struct pcx_fir {
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
     DevBuf HspecRows;
+    int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
 };
+
+// Overlap-save block size for K taps (complex_float32, M = L = 1): 0 = the dedicated 4096-sample
+// kernel (K <= 2049), else the log2 of a radix-16 family plan (fir_ols_r16.hip) for longer taps.
+// PCX_OLS_N=1024/2048/4096/8192/16384 forces a plan (A/B runs, tools/ab_ols.py).
+static int fir_ols_block_log2(size_t K)
+{
+    static const int forced = [] { const char *e = getenv("PCX_OLS_N"); return e ? atoi(e) : 0; }();
+    switch (forced) {
+    case 1024: return 10;
+    case 2048: return 11;
+    case 4096: return 12;
+    case 8192: return 13;
+    case 16384: return 14;
+    }
+    if (K <= 2049) return 0;
+    return K <= 4097 ? 13 : 14;
+}
+constexpr size_t kOlsMaxTaps = 8193;
 
 // FIRFilter::updateInternals, FIRFilter.cpp:327-354 (host mirror; tables uploaded lazily)
 static void fir_update_internals(pcx_fir *h)
@@ -267,14 +302,19 @@ static int fir_sync_tables(pcx_fir *h)
             rev[2 * m + 1] = h->ctaps ? (float)h->taps[2 * k + 1] : 0.f;
         }
         PCX_TRY(upload(h->tapsRev, rev));
-        if (K <= 2049) {
+        if (K <= kOlsMaxTaps) {
             std::vector<std::complex<double>> hq(K);
             for (size_t k = 0; k < K; k++)   // floatToQ<QTapsType>: narrowed to float first (FIRFilter.cpp:348)
                 hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]),
                                              h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
-            const std::vector<float> H = make_hspec4096(hq);
-            PCX_TRY(upload(h->Hspec, H));
-            PCX_TRY(upload(h->tw4096, make_tw4096()));
+            h->ols_log2n = fir_ols_block_log2(K);
+            if (h->ols_log2n == 0) {   // the dedicated 4096-sample kernel (fir_ols.hip)
+                PCX_TRY(upload(h->Hspec, make_hspec4096(hq)));
+                PCX_TRY(upload(h->tw4096, make_tw4096()));
+            } else {                   // radix-16 family plan (fir_ols_r16.hip)
+                PCX_TRY(upload(h->Hspec, make_hspec(hq, (size_t)1 << h->ols_log2n)));
+                PCX_TRY(upload(h->tw4096, make_tw_r16(h->ols_log2n)));
+            }
             h->have_ols = true;
         }
     }
@@ -381,6 +421,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
                         size_t *consumed, size_t *produced, void *stream)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    DeviceScope dev_scope(h->device);
     *consumed = 0; *produced = 0;
     const size_t N = fir_iterations(h, in_elems, out_cap);
     if (N == 0) return PCX_OK;
@@ -402,7 +443,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
     if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols)) {
-        set_error("fir: OLS_FFT needs complex_float32 and K<=2049 (L<=64 rows)");
+        set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows)");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
@@ -412,6 +453,8 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {
+        rc = launch_fir_cf32_ols_r16(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {
         rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
     } else if (algo == PCX_FIR_DIRECT && fast) {
@@ -430,6 +473,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
 int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    DeviceScope dev_scope(h->device);
     *consumed = 0; *produced = 0;
     const size_t N = fir_iterations(h, in_elems, out_cap);
     if (N == 0) return PCX_OK;
@@ -451,6 +495,7 @@ int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size
  *  FFT
  * ===================================================================== */
 struct pcx_fft {
+    int device = -1;
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
@@ -537,6 +582,7 @@ int pcx_fft_destroy(pcx_fft *h) { delete h; return PCX_OK; }
 int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream)
 {
     PCX_CHECK_ARG(h, "null handle");
+    DeviceScope dev_scope(h->device);
     if (nframes == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     hipStream_t st = as_stream(stream);
@@ -559,6 +605,7 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
 int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
 {
     PCX_CHECK_ARG(h, "null handle");
+    DeviceScope dev_scope(h->device);
     if (nframes == 0) return PCX_OK;
     PCX_CHECK_ARG(in && out, "null buffer");
     const size_t bytes = nframes * h->nbins * 2 * (size_t)scalar_bytes(h->scalar);
@@ -575,6 +622,7 @@ int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
  *  FreqDemod
  * ===================================================================== */
 struct pcx_freqdemod {
+    int device = -1;
     int scalar = PCX_F32;
     DevBuf prev;  // two complex slots (ping-pong), holds _prev = conj(last input)
     int cur = 0;
@@ -587,6 +635,7 @@ int pcx_freqdemod_create(int scalar, pcx_freqdemod **out)
     pcx_freqdemod *h = new (std::nothrow) pcx_freqdemod();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->scalar = scalar;
+    DeviceScope dev_scope(h->device);
     int rc = h->prev.ensure(64);
     if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
     if (rc != PCX_OK) { delete h; return rc; }
@@ -597,6 +646,7 @@ int pcx_freqdemod_destroy(pcx_freqdemod *h) { delete h; return PCX_OK; }
 int pcx_freqdemod_reset(pcx_freqdemod *h)
 {
     PCX_CHECK_ARG(h, "null handle");
+    DeviceScope dev_scope(h->device);
     PCX_HIP(hipMemset(h->prev.p, 0, 64));  // _prev = 0, FreqDemod.cpp:46
     h->cur = 0;
     return PCX_OK;
@@ -604,6 +654,7 @@ int pcx_freqdemod_reset(pcx_freqdemod *h)
 int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
     PCX_CHECK_ARG(h, "null handle");
+    DeviceScope dev_scope(h->device);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     char *base = static_cast<char *>(h->prev.p);
@@ -616,6 +667,7 @@ int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_de
 int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
 {
     PCX_CHECK_ARG(h, "null handle");
+    DeviceScope dev_scope(h->device);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in && out, "null buffer");
     const size_t sb = (size_t)scalar_bytes(h->scalar);
@@ -724,6 +776,7 @@ int pcx_angle(int scalar, const void *in, void *out, size_t n)
  *  fused Rotate -> FIR -> FreqDemod
  * ===================================================================== */
 struct pcx_fmchain {
+    int device = -1;
     double phase = 0.0;
     bool phase_set = false;  // Rotate before setPhase: zero phasor (Rotate.cpp:60-62)
     std::vector<double> taps;
@@ -742,6 +795,7 @@ int pcx_fmchain_create(pcx_fmchain **out)
     pcx_fmchain *h = new (std::nothrow) pcx_fmchain();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->taps.assign(1, 1.0);
+    DeviceScope dev_scope(h->device);
     int rc = h->prev.ensure(64);
     if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
     if (rc != PCX_OK) { delete h; return rc; }
@@ -766,6 +820,7 @@ int pcx_fmchain_set_taps(pcx_fmchain *h, const double *taps, size_t ntaps, int c
 int pcx_fmchain_reset(pcx_fmchain *h)
 {
     PCX_CHECK_ARG(h, "null handle");
+    DeviceScope dev_scope(h->device);
     PCX_HIP(hipMemset(h->prev.p, 0, 64));
     h->cur = 0;
     return PCX_OK;
@@ -813,6 +868,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
                             size_t *consumed, size_t *produced, void *stream)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    DeviceScope dev_scope(h->device);
     *consumed = 0; *produced = 0;
     PCX_TRY(fmchain_sync(h));
     if (in_elems < h->K) return PCX_OK;
@@ -838,6 +894,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
 int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    DeviceScope dev_scope(h->device);
     *consumed = 0; *produced = 0;
     PCX_TRY(fmchain_sync(h));
     if (in_elems < h->K) return PCX_OK;

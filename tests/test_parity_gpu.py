@@ -152,13 +152,13 @@ def test_fir_anchors(oracle, dev):
 
 
 @pytest.mark.parametrize("algo", ["DIRECT", "OLS_FFT", "AUTO"])
-@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 9, 63, 64, 127, 255, 256, 257, 1000, 2049])
+@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 9, 63, 64, 127, 255, 256, 257, 1000, 2049, 2050, 4097, 4098, 8193])
 def test_fir_cf32_fast_paths(oracle, dev, algo, ntaps):
     """LDS-tiled direct kernel and frequency-domain overlap-save kernel vs the oracle."""
     if algo == "DIRECT" and ntaps > 2049:
         pytest.skip("direct tile plan")
     rng = np.random.default_rng(ntaps)
-    n = 3 * 4096 + 777 + ntaps
+    n = 3 * 4096 + 777 + ntaps + (40000 if ntaps > 2049 else 0)   # several 8192/16384-sample blocks
     x = rand_stream(rng, oracle.F32, n, True)
     taps = _taps(rng, ntaps, True)
     ref_blk = oracle.Fir(oracle.F32, True, True); ref_blk.set_taps(taps); ref_blk.activate()
@@ -168,6 +168,8 @@ def test_fir_cf32_fast_paths(oracle, dev, algo, ntaps):
     got, gc, gp = f.process(x, n)
     assert (gc, gp) == (rc, rp) == (n - ntaps + 1, n - ntaps + 1)
     assert nerr(got, ref) <= TOL, f.last_algo
+    if algo == "AUTO" and ntaps > 1:
+        assert f.last_algo == dev._lib.FIR_OLS_FFT   # 4096-sample blocks to 2049 taps, 8192 / 16384 beyond
 
 
 def test_fir_cf32_real_taps_fast(oracle, dev):

@@ -1,0 +1,40 @@
+"""A/B of the overlap-save block size (PCX_OLS_N, read once per process): parity against the oracle on a
+short stream and the per-pass time at 64 Mi samples, for a few tap counts.  Run once per block size:
+    PCX_OLS_N=2048 python tools/ab_ols.py
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pothoscomms_amd import _lib, device, taps as tp
+from oracle import oracle
+
+d = torch.device("cuda", 0)
+N = os.environ.get("PCX_OLS_N", "dedicated-4096")
+Ks = [int(k) for k in os.environ.get("AB_KS", "16,64,127,255,511").split(",")]
+n = 64 * 1024 * 1024
+for K in Ks:
+    h = tp.complex_bandpass(K, 0.05, 0.05)
+    f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h); f.set_algo(_lib.FIR_OLS_FFT)
+    # parity on 100,003 outputs (ragged tail) against the reference loop restated in oracle/
+    m = 100003
+    xs = oracle.fill_uniform_f32(2 * (m + K - 1), 7).reshape(-1, 2)
+    o = oracle.Fir(oracle.F32, True, True); o.set_taps(h); o.activate()
+    want = o.work(xs, m)[0]
+    xd = torch.from_numpy(xs).to(d); yd = torch.empty((m, 2), dtype=torch.float32, device=d)
+    try:
+        f.process_dev(xd, yd)
+    except Exception as e:
+        print("N=%s K=%d: %s" % (N, K, e)); continue
+    got = yd.cpu().numpy()
+    err = float(np.abs(got - want).max() / np.abs(want).max())
+    x = torch.empty((n + K - 1, 2), dtype=torch.float32, device=d); device.fill_uniform_f32_dev(x, seed=1)
+    y = torch.empty((n, 2), dtype=torch.float32, device=d)
+    for _ in range(150): f.process_dev(x, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100): f.process_dev(x, y)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 100
+    print("N=%s K=%4d  err %.2e  %.4f ms  %.1f Gsamples/s" % (N, K, err, ms, n / ms / 1e6), flush=True)
+    del x, y

@@ -368,18 +368,24 @@ int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, siz
 // xh[b*S - 1 + i], i = 0..4095, S = 4096 - K; time index i >= K-1 is FIR output m = b*S + i - K
 // and i >= K yields d[m].  y[-1] (block 0, i = K-1) is the state carried from the previous
 // call (*prev_in = conj(y_last), zero after reset); conj(y[n_out-1]) goes to *prev_out.
-// The lane's neighbour sample y[m-1] lives in lane j-1, so the block's time samples make one
-// extra trip through the LDS image.  12 algorithmic bytes per sample (8 in, 4 out).
+// The lane's neighbour sample y[m-1] lives in lane j-1 of the same register: a wave-shift DPP move
+// fetches it, and only the 64 wave-boundary values cross through LDS.  12 algorithmic bytes per
+// sample (8 in, 4 out).  The overlap is rounded up to a multiple of 32 samples (aligned 1 KiB
+// output rows); 128 VGPRs, 4 workgroups per CU.
 // --------------------------------------------------------------------------------- //
-__global__ __launch_bounds__(256, 3) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
-                                                                      float *__restrict__ out, size_t n_out,
-                                                                      const float2 *__restrict__ Hspec, int K,
-                                                                      const float2 *__restrict__ twtab, size_t nblocks,
-                                                                      const float2 *__restrict__ prev_in,
-                                                                      float2 *__restrict__ prev_out)
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
+                                                                        float *__restrict__ out, size_t n_out,
+                                                                        const float2 *__restrict__ Hspec, int K, int pad,
+                                                                        const float2 *__restrict__ twtab, size_t nblocks,
+                                                                        const float2 *__restrict__ prev_in,
+                                                                        float2 *__restrict__ prev_out)
 {
+    // K here = the block overlap: taps + pad, a multiple of 32 so that every 1 KiB row of outputs
+    // this kernel stores starts on a 128-byte line (see fir_cf32_ols4096_kernel)
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
+    __shared__ cf bnd[64];   // last lane of each wave, per row: the demodulator's cross-wave neighbours
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - K);
     size_t b = blockIdx.x;
@@ -390,13 +396,17 @@ __global__ __launch_bounds__(256, 3) void fmchain_cf32_ols4096_kernel(const floa
     cf H[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
-    // element i of block blk is xh[blk*S - 1 + i].  Blocks >= 1 put the descriptor at
-    // xh[blk*S - 1]; block 0 has no xh[-1], so its descriptor sits at xh[0] and the byte offset
-    // (i-1)*8 of i = 0 wraps past num_records and reads 0 (that sample only feeds y[-1], which
-    // is replaced by the carried state).  Offsets go through voffset: range-checked.
+    // element i of block blk is xh[blk*S - 1 - pad + i].  Block 0 has no xh[-1-pad .. -1]: its
+    // descriptor sits at xh[0] and the byte offsets of those elements wrap past num_records and
+    // read 0 (they only feed dropped outputs and y[-1], which is replaced by the carried state).
     auto fetch = [&](cf (&dst)[16], size_t blk) {
-        const int shift = blk == 0 ? 1 : 0;
-        const size_t first = blk * S - (size_t)(1 - shift);          // xh index of the descriptor base
+        const size_t lead = (size_t)(1 + pad);
+        if (blk > 0 && blk * S - lead + N <= in_elems) {
+            load_frame<false, 0>(dst, make_rsrc(in + blk * S - lead, N * 8), j);
+            return;
+        }
+        const int shift = blk == 0 ? 1 + pad : 0;
+        const size_t first = blk * S - (lead - (size_t)shift);         // xh index of the descriptor base
         const size_t left = in_elems - first;
         const size_t want = (size_t)(N - shift);
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 8));
@@ -423,31 +433,49 @@ __global__ __launch_bounds__(256, 3) void fmchain_cf32_ols4096_kernel(const floa
         pass1(u, lds, j);
         pass2(u, lds, j);
         pass3(u, lds, j, tw3);
-        // u[q] = conj(y) at time index i = j + 256*bin_of(q).  Neighbour exchange through LDS.
-        __syncthreads();
+        // u[q] = conj(y) at time index i = j + 256*bin_of(q).  conj(y[i-1]) sits in lane j-1 of the
+        // same register: a wave-shift DPP move brings it over, and only the first lane of each wave
+        // needs the last lane of the wave before it (row k-1 for lane 0) -- 64 values through LDS
+        // instead of a fourth trip of the whole block image.
+        if (b == 0) {
+            // block 0: the slot of y[-1] (time index K-1, itself a dropped output) takes the carried state
+            const cf carried = cf{prev_in[0].x, prev_in[0].y};
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = j + 256 * bin_of(q);
-            // block 0: the slot of y[-1] (time index K-1) takes the carried conj(y[-1]) instead
-            lds[i] = (b == 0 && i == K - 1) ? cf{prev_in[0].x, prev_in[0].y} : u[q];
+            for (int q = 0; q < 16; q++)
+                if (j + 256 * bin_of(q) == K - 1) u[q] = carried;
+        }
+        if ((j & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) bnd[(j >> 6) * 16 + bin_of(q)] = u[q];
         }
         __syncthreads();
         const size_t room = n_out - b * S;
         const size_t cnt = room < S ? room : S;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)(cnt * 4));
         const unsigned vbase = (unsigned)(j - K) * 4u;
+        // lane 0 of wave w > 0 continues lane 63 of wave w-1 in the same row; lane 0 of wave 0 continues
+        // lane 255 of row k-1 (bnd[47 + k]; for k = 0 that is time index -1: never a valid output)
+        const cf *edge_row = bnd + ((j >> 6) > 0 ? ((j >> 6) - 1) * 16 : 47);
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int row = 256 * bin_of(q);
+            const int k = bin_of(q), row = 256 * k;
             if (row + 255 < K) continue;                      // no valid output in this row: uniform skip
-            const int i = row + j;
             const cf a = u[q];
-            const cf p = lds[i > 0 ? i - 1 : 0];              // conj(y[m-1])
+            const cf edge = edge_row[k];                      // wave-uniform address: broadcast read
+            cf p;                                             // conj(y[m-1])
+            p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge.x), __float_as_int(a.x), 0x138, 0xf, 0xf, false));
+            p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge.y), __float_as_int(a.y), 0x138, 0xf, 0xf, false));
             // y[m] * conj(y[m-1]) = conj(a) * p
             const float re = a.x * p.x + a.y * p.y, im = a.x * p.y - a.y * p.x;
             const float d = fast_atan2f(im, re);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)row * 4u), 0, 0);
-            if (i >= K && (size_t)(i - K) == cnt - 1 && b == nblocks - 1) prev_out[0] = make_float2(a.x, a.y);
+        }
+        if (b == nblocks - 1) {
+            // the stream's last output becomes the next call's carried state (kept conjugated)
+            const int i_last = K + (int)cnt - 1;
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                if (j + 256 * bin_of(q) == i_last) prev_out[0] = make_float2(u[q].x, u[q].y);
         }
     }
 }
@@ -457,12 +485,20 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2048) { set_error("fm chain ols: K=%zu outside 1..2048", K); return PCX_ERR_UNSUPPORTED; }
-    const size_t S = 4096 - K;
+    // PCX_FMCHAIN_OCC=3: 3 workgroups per CU (A/B); default 4
+    static const int occ = [] { const char *e = getenv("PCX_FMCHAIN_OCC"); return e ? atoi(e) : 4; }();
+    const size_t Kov = (K + 31) / 32 * 32, pad = Kov - K;    // <= 2048
+    const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
-    const unsigned grid = persistent_grid(nblocks, 768);
-    hipLaunchKernelGGL(fmchain_cf32_ols4096_kernel, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float *)out,
-                       n_out, (const float2 *)Hspec, (int)K, (const float2 *)tw4096, nblocks, (const float2 *)prev_in,
-                       (float2 *)prev_out);
+    if (occ == 3) {
+        hipLaunchKernelGGL(fmchain_cf32_ols4096_kernel<3>, dim3(persistent_grid(nblocks, 768)), dim3(256), 0, st, (const float2 *)in,
+                           in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks,
+                           (const float2 *)prev_in, (float2 *)prev_out);
+    } else {
+        hipLaunchKernelGGL(fmchain_cf32_ols4096_kernel<4>, dim3(persistent_grid(nblocks, 1024)), dim3(256), 0, st, (const float2 *)in,
+                           in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks,
+                           (const float2 *)prev_in, (float2 *)prev_out);
+    }
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

@@ -27,10 +27,11 @@ namespace pcx {
 // range check, which drops both the K-1 aliased samples and anything past n_out.
 // PREFETCH: keep the next block's 16 samples per lane in flight in registers (168 VGPRs, 3
 // workgroups per CU) or load at the top of each block (128 VGPRs, 4 workgroups per CU).
-// LAUX / SAUX: cache-policy bits of the stream loads / stores.  Measured at K = 255: plain loads
-// 0.232 ms, non-temporal loads 0.252 ms per 64 Mi samples -- consecutive blocks re-read K-1
-// samples, and those hits are lost when the first touch bypasses L2 -- so the FIR keeps plain
-// loads (the frame-disjoint FFT kernel gains 3 % from nt).
+// LAUX / SAUX: cache-policy bits of the stream loads / stores (LAUX >= 4: per-row policy, see fetch).
+// Measured at K = 255, one box, 64 Mi samples: plain 0.2269-0.2280 ms; nt on every load 0.2311 with
+// nt stores (consecutive blocks re-read the overlap, and those hits are lost when the first touch
+// bypasses L2); nt stores alone 0.2267-0.2277; nt stores + nt loads on the rows that only this block
+// reads 0.2204-0.2215 -- the default.
 // DIAG (timing-only builds, wrong outputs): 1 = every block reads/writes block 0 (cache resident:
 // the compute floor), 2 = no transforms (load, store: the memory floor)
 // HGLOBAL: fetch the lane's 16 H bins from L2 in every block instead of holding them in 32 VGPRs
@@ -77,7 +78,21 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
     auto fetch = [&](cf (&dst)[16], size_t blk) {
         if (DIAG == 1) blk = first_full;
         if (blk >= first_full && blk < nfull) {
-            load_frame<false, LAUX>(dst, make_rsrc(in + blk * S - pad, N * 8), j);
+            if (LAUX >= 4) {
+                // NOV = 1 << (LAUX-4) rows at either end of the window hold the (aligned) overlap with
+                // the neighbouring blocks: cached normally so the second reader hits in L2.  The rows
+                // between are touched by this block only: non-temporal.
+                constexpr int NOV = 1 << (LAUX >= 4 ? LAUX - 4 : 0);
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + blk * S - pad, N * 8);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const u32x2 t = (r < NOV || r >= 16 - NOV) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 0)
+                                                               : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 2);
+                    dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+                }
+            } else {
+                load_frame<false, LAUX>(dst, make_rsrc(in + blk * S - pad, N * 8), j);
+            }
         } else {
             // ragged: block 0 when pad > 0 (its window would start before the buffer: those samples
             // only feed dropped outputs, read as 0 through the range check) and the tail block
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 8));
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * r - (int)shift) * 8, 0, LAUX);
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * r - (int)shift) * 8, 0, LAUX >= 4 ? 0 : LAUX);
                 dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
             }
         }
@@ -154,10 +169,11 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols: K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
-    // PCX_OLS_VARIANT (A/B and diagnostics): 1 default (4 workgroups/CU, no prefetch), 0 register
-    // prefetch (3/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs, 10/11 compute-only /
-    // memory-only timing builds.  PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
-    static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : 1; }();
+    // PCX_OLS_VARIANT (A/B and diagnostics): unset = default policy below; 1 plain loads/stores, 0 register
+    // prefetch (3 workgroups/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs, 5 H from L2,
+    // 6 nt stores only, 7 nt interior loads only, 10/11 compute-only / memory-only timing builds.
+    // PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
+    static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : -1; }();
     static const int align = [] { const char *e = getenv("PCX_OLS_ALIGN"); return e ? atoi(e) : 1; }();
     const size_t Km1 = K - 1;
     const size_t Kov = align ? (Km1 + 15) / 16 * 16 : Km1;   // <= 2048
@@ -175,13 +191,22 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 #define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks)
     switch (variant) {
     case 0: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true>), g3); break;
+    case 1: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false>), g4); break;
     case 2: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 0>), g4); break;
     case 3: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 2>), g4); break;
     case 4: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, true>), g4); break;
     case 5: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 0, 0, false, 0, true>), g4); break;
+    case 6: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4); break;
+    case 7: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0>), g4); break;
     case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 1>), g4); break;
     case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 2>), g4); break;
-    default: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false>), g4); break;
+    default:
+        // non-temporal stores; non-temporal loads for the rows no other block reads
+        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), g4);
+        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2>), g4);
+        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2>), g4);
+        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4);
+        break;
     }
 #undef PCX_OLS_LAUNCH
     PCX_LAUNCH_CHECK();
@@ -373,7 +398,7 @@ int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, siz
 // sample (8 in, 4 out).  The overlap is rounded up to a multiple of 32 samples (aligned 1 KiB
 // output rows); 128 VGPRs, 4 workgroups per CU.
 // --------------------------------------------------------------------------------- //
-template <int OCC>
+template <int OCC, int NOV, int SAUX>
 __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                         float *__restrict__ out, size_t n_out,
                                                                         const float2 *__restrict__ Hspec, int K, int pad,
@@ -402,7 +427,15 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
     auto fetch = [&](cf (&dst)[16], size_t blk) {
         const size_t lead = (size_t)(1 + pad);
         if (blk > 0 && blk * S - lead + N <= in_elems) {
-            load_frame<false, 0>(dst, make_rsrc(in + blk * S - lead, N * 8), j);
+            // as in fir_cf32_ols4096_kernel: the NOV rows at either end are shared with the neighbouring
+            // blocks (cached normally), the rows between are read once (non-temporal)
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + blk * S - lead, N * 8);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32x2 t = (r < NOV || r >= 16 - NOV) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 0)
+                                                           : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 2);
+                dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+            }
             return;
         }
         const int shift = blk == 0 ? 1 + pad : 0;
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             // y[m] * conj(y[m-1]) = conj(a) * p
             const float re = a.x * p.x + a.y * p.y, im = a.x * p.y - a.y * p.x;
             const float d = fast_atan2f(im, re);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)row * 4u), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)row * 4u), 0, SAUX);
         }
         if (b == nblocks - 1) {
             // the stream's last output becomes the next call's carried state (kept conjugated)
@@ -485,20 +518,22 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2048) { set_error("fm chain ols: K=%zu outside 1..2048", K); return PCX_ERR_UNSUPPORTED; }
-    // PCX_FMCHAIN_OCC=3: 3 workgroups per CU (A/B); default 4
+    // PCX_FMCHAIN_OCC (A/B): 3 = 3 workgroups per CU, 5 = 4 per CU with plain loads/stores; default 4 + row policy
     static const int occ = [] { const char *e = getenv("PCX_FMCHAIN_OCC"); return e ? atoi(e) : 4; }();
     const size_t Kov = (K + 31) / 32 * 32, pad = Kov - K;    // <= 2048
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
-    if (occ == 3) {
-        hipLaunchKernelGGL(fmchain_cf32_ols4096_kernel<3>, dim3(persistent_grid(nblocks, 768)), dim3(256), 0, st, (const float2 *)in,
-                           in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks,
-                           (const float2 *)prev_in, (float2 *)prev_out);
-    } else {
-        hipLaunchKernelGGL(fmchain_cf32_ols4096_kernel<4>, dim3(persistent_grid(nblocks, 1024)), dim3(256), 0, st, (const float2 *)in,
-                           in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks,
-                           (const float2 *)prev_in, (float2 *)prev_out);
-    }
+#define PCX_FM_LAUNCH(OCC, NOV, SAUX, CAP)                                                                                   \
+    hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX>), dim3(persistent_grid(nblocks, CAP)), dim3(256), 0, st,   \
+                       (const float2 *)in, in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad,            \
+                       (const float2 *)tw4096, nblocks, (const float2 *)prev_in, (float2 *)prev_out)
+    if (occ == 3) PCX_FM_LAUNCH(3, 8, 0, 768);            // A/B: 3 workgroups per CU, plain loads and stores
+    else if (occ == 5) PCX_FM_LAUNCH(4, 8, 0, 1024);      // A/B: plain loads and stores
+    else if (Kov <= 256) PCX_FM_LAUNCH(4, 1, 2, 1024);
+    else if (Kov <= 512) PCX_FM_LAUNCH(4, 2, 2, 1024);
+    else if (Kov <= 1024) PCX_FM_LAUNCH(4, 4, 2, 1024);
+    else PCX_FM_LAUNCH(4, 8, 2, 1024);
+#undef PCX_FM_LAUNCH
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

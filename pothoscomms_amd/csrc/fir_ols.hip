@@ -220,15 +220,18 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 // real stream) gives Re(h*z) = h*xA and Im(h*z) = h*xB: same pipeline, half the transforms
 // per sample.  Loads/stores are 4 bytes per lane (two rows per complex element).
 // --------------------------------------------------------------------------------- //
+template <int NOV>
 __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__restrict__ in, size_t in_elems,
                                                                  float *__restrict__ out, size_t n_out,
-                                                                 const float2 *__restrict__ Hspec, int Km1,
+                                                                 const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                  const float2 *__restrict__ twtab, size_t nblocks)
 {
+    // Kov = K-1 rounded up to a multiple of 32 samples (128-byte aligned 1 KiB output rows), the
+    // window of block b starts `pad` = Kov-(K-1) samples before sample b*S (fir_cf32_ols4096_kernel)
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
-    const size_t S = (size_t)(N - Km1);
+    const size_t S = (size_t)(N - Kov);
     const size_t npairs = (nblocks + 1) / 2;
     size_t p = blockIdx.x;
     if (p >= npairs) return;
@@ -240,16 +243,42 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
     for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
     for (; p < npairs; p += gridDim.x) {
         const size_t bA = 2 * p, bB = 2 * p + 1;
-        const size_t leftA = in_elems - bA * S;
-        const size_t leftB = bB < nblocks ? in_elems - bB * S : 0;
-        const __amdgpu_buffer_rsrc_t ra = make_rsrc(in + bA * S, (unsigned)((leftA < (size_t)N ? leftA : (size_t)N) * 4));
-        const __amdgpu_buffer_rsrc_t rb = make_rsrc(in + (bB < nblocks ? bB * S : 0), (unsigned)((leftB < (size_t)N ? leftB : (size_t)N) * 4));
         cf v[16];
+        if (bA > 0 && bB * S - pad + N <= in_elems) {
+            // both windows inside the buffer.  The NOV rows at either end of a window are shared with
+            // the neighbouring blocks (cached normally); the rows between are read once (non-temporal)
+            const __amdgpu_buffer_rsrc_t ra = make_rsrc(in + bA * S - pad, N * 4);
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(in + bB * S - pad, N * 4);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(ra, (j + 256 * r) * 4, 0, 0);
-            const unsigned b = __builtin_amdgcn_raw_buffer_load_b32(rb, (j + 256 * r) * 4, 0, 0);
-            v[r] = cf{__uint_as_float(a), __uint_as_float(b)};
+            for (int r = 0; r < 16; r++) {
+                unsigned a, b;
+                if (r < NOV || r >= 16 - NOV) {
+                    a = __builtin_amdgcn_raw_buffer_load_b32(ra, j * 4, 1024 * r, 0);
+                    b = __builtin_amdgcn_raw_buffer_load_b32(rb, j * 4, 1024 * r, 0);
+                } else {
+                    a = __builtin_amdgcn_raw_buffer_load_b32(ra, j * 4, 1024 * r, 2);
+                    b = __builtin_amdgcn_raw_buffer_load_b32(rb, j * 4, 1024 * r, 2);
+                }
+                v[r] = cf{__uint_as_float(a), __uint_as_float(b)};
+            }
+        } else {
+            // ragged: block 0 (its window starts `pad` samples before the buffer: read as 0 through the
+            // range check, they only feed dropped outputs), the tail, a missing partner block
+            const size_t shiftA = bA * S >= (size_t)pad ? 0 : (size_t)pad - bA * S;
+            const size_t firstA = bA * S + shiftA - pad;
+            const size_t leftA = in_elems > firstA ? in_elems - firstA : 0;
+            const size_t wantA = (size_t)N - shiftA;
+            const bool haveB = bB < nblocks;
+            const size_t firstB = haveB ? bB * S - pad : 0;          // bB >= 1: S >= pad
+            const size_t leftB = haveB && in_elems > firstB ? in_elems - firstB : 0;
+            const __amdgpu_buffer_rsrc_t ra = make_rsrc(in + firstA, (unsigned)((leftA < wantA ? leftA : wantA) * 4));
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(in + firstB, (unsigned)((leftB < (size_t)N ? leftB : (size_t)N) * 4));
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(ra, (j + 256 * r - (int)shiftA) * 4, 0, 0);
+                const unsigned b = __builtin_amdgcn_raw_buffer_load_b32(rb, (j + 256 * r) * 4, 0, 0);
+                v[r] = cf{__uint_as_float(a), __uint_as_float(b)};
+            }
         }
         pass1(v, lds, j);
         pass2(v, lds, j);
@@ -270,13 +299,13 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
         const size_t roomB = bB < nblocks ? n_out - bB * S : 0;
         const __amdgpu_buffer_rsrc_t wa = make_rsrc(out + bA * S, (unsigned)((roomA < S ? roomA : S) * 4));
         const __amdgpu_buffer_rsrc_t wb = make_rsrc(out + (bB < nblocks ? bB * S : 0), (unsigned)((roomB < S ? roomB : S) * 4));
-        const unsigned vbase = (unsigned)(j - Km1) * 4u;
+        const unsigned vbase = (unsigned)(j - Kov) * 4u;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int row = 256 * bin_of(q);
-            if (row + 255 < Km1) continue;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[q].x), wa, (int)(vbase + (unsigned)row * 4u), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-u[q].y), wb, (int)(vbase + (unsigned)row * 4u), 0, 0);
+            if (row + 255 < Kov) continue;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[q].x), wa, (int)(vbase + (unsigned)row * 4u), 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-u[q].y), wb, (int)(vbase + (unsigned)row * 4u), 0, 2);
         }
     }
 }
@@ -286,11 +315,19 @@ int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols (real): K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
-    const size_t S = 4096 - (K - 1);
+    const size_t Km1 = K - 1;
+    const size_t Kov = (Km1 + 31) / 32 * 32, pad = Kov - Km1;     // <= 2048
+    const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
     const unsigned grid = persistent_grid((nblocks + 1) / 2, 1024);
-    hipLaunchKernelGGL(fir_f32_ols4096_kernel, dim3(grid), dim3(256), 0, st, (const float *)in, in_elems, (float *)out, n_out,
-                       (const float2 *)Hspec, (int)(K - 1), (const float2 *)tw4096, nblocks);
+#define PCX_REAL_LAUNCH(NOV)                                                                                                     \
+    hipLaunchKernelGGL(fir_f32_ols4096_kernel<NOV>, dim3(grid), dim3(256), 0, st, (const float *)in, in_elems, (float *)out, n_out, \
+                       (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks)
+    if (Kov <= 256) PCX_REAL_LAUNCH(1);
+    else if (Kov <= 512) PCX_REAL_LAUNCH(2);
+    else if (Kov <= 1024) PCX_REAL_LAUNCH(4);
+    else PCX_REAL_LAUNCH(8);
+#undef PCX_REAL_LAUNCH
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

@@ -12,23 +12,24 @@ d = torch.device("cuda", 0)
 N = os.environ.get("PCX_OLS_N", "dedicated-4096")
 Ks = [int(k) for k in os.environ.get("AB_KS", "16,64,127,255,511").split(",")]
 n = 64 * 1024 * 1024
+REAL = os.environ.get("AB_TYPE", "complex_float32") == "float32"     # real stream, real taps
 for K in Ks:
-    h = tp.complex_bandpass(K, 0.05, 0.05)
-    f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h); f.set_algo(_lib.FIR_OLS_FFT)
+    h = tp.lowpass(K, 0.1) if REAL else tp.complex_bandpass(K, 0.05, 0.05)
+    f = device.FirFilter("float32" if REAL else "complex_float32", "REAL" if REAL else "COMPLEX"); f.set_taps(h); f.set_algo(_lib.FIR_OLS_FFT)
     # parity on 100,003 outputs (ragged tail) against the reference loop restated in oracle/
     m = 100003
-    xs = oracle.fill_uniform_f32(2 * (m + K - 1), 7).reshape(-1, 2)
-    o = oracle.Fir(oracle.F32, True, True); o.set_taps(h); o.activate()
+    xs = oracle.fill_uniform_f32(m + K - 1, 7) if REAL else oracle.fill_uniform_f32(2 * (m + K - 1), 7).reshape(-1, 2)
+    o = oracle.Fir(oracle.F32, not REAL, not REAL); o.set_taps(h); o.activate()
     want = o.work(xs, m)[0]
-    xd = torch.from_numpy(xs).to(d); yd = torch.empty((m, 2), dtype=torch.float32, device=d)
+    xd = torch.from_numpy(xs).to(d); yd = torch.empty((m,) if REAL else (m, 2), dtype=torch.float32, device=d)
     try:
         f.process_dev(xd, yd)
     except Exception as e:
         print("N=%s K=%d: %s" % (N, K, e)); continue
     got = yd.cpu().numpy()
     err = float(np.abs(got - want).max() / np.abs(want).max())
-    x = torch.empty((n + K - 1, 2), dtype=torch.float32, device=d); device.fill_uniform_f32_dev(x, seed=1)
-    y = torch.empty((n, 2), dtype=torch.float32, device=d)
+    x = torch.empty((n + K - 1,) if REAL else (n + K - 1, 2), dtype=torch.float32, device=d); device.fill_uniform_f32_dev(x, seed=1)
+    y = torch.empty((n,) if REAL else (n, 2), dtype=torch.float32, device=d)
     for _ in range(150): f.process_dev(x, y)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -12,6 +12,8 @@
 // Replaces kissfft<T>::transform (fft/kissfft.hh:81-161) and kiss_fft (fft/kiss_fft.c:237-302)
 // called from FFT::work (fft/FFT.cpp:61-72).
 #include "fft4096.hpp"
+#include <cstdlib>
+
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -19,7 +21,7 @@ namespace pcx {
 // --------------------------------------------------------------------------------- //
 // 4096-point complex_float32
 // --------------------------------------------------------------------------------- //
-template <bool INV>
+template <bool INV, int SAUX>
 __global__ __launch_bounds__(256, 4) void fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                       size_t nframes, const float2 *__restrict__ twtab)
 {
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256, 4) void fft4096_kernel(const float2 *__restric
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + f * N, N * 8);
 #pragma unroll
         for (int q = 0; q < 16; q++)
-            store_cf(ws, (unsigned)(j + 256 * bin_of(q)) * 8u, INV ? cf{v[q].x, -v[q].y} : v[q]);
+            store_cf<SAUX>(ws, (unsigned)(j + 256 * bin_of(q)) * 8u, INV ? cf{v[q].x, -v[q].y} : v[q]);
     }
 }
 
@@ -59,10 +61,12 @@ int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse,
     // persistent workgroups: LDS (34.8 KB) admits 4 per CU; each walks frames with a grid
     // stride, keeping its twiddles in registers and the next frame in flight
     const unsigned grid = persistent_grid(nframes, 1024);
-    if (inverse)
-        hipLaunchKernelGGL(fft4096_kernel<true>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab);
-    else
-        hipLaunchKernelGGL(fft4096_kernel<false>, dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab);
+    // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
+    static const int saux = [] { const char *e = getenv("PCX_FFT_STORE_AUX"); return e ? atoi(e) : 2; }();
+#define PCX_FFT_LAUNCH(INV, SAUX) hipLaunchKernelGGL((fft4096_kernel<INV, SAUX>), dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab)
+    if (inverse) { if (saux == 2) PCX_FFT_LAUNCH(true, 2); else PCX_FFT_LAUNCH(true, 0); }
+    else { if (saux == 2) PCX_FFT_LAUNCH(false, 2); else PCX_FFT_LAUNCH(false, 0); }
+#undef PCX_FFT_LAUNCH
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

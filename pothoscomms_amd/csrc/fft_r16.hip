@@ -14,6 +14,7 @@
 // Same transform as kissfft<float> (fft/kissfft.hh:81-161): forward exp(-j..), inverse exp(+j..)
 // taken as conj(FFT(conj x)), unscaled.  Parity bar 1e-5 of max|X|.
 #include "fft4096.hpp"
+#include <cstdlib>
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -65,7 +66,7 @@ __device__ __forceinline__ void fft8(cf &a0, cf &a1, cf &a2, cf &a3, cf &a4, cf 
     a3 = e3 + w3; a7 = e3 - w3;
 }
 
-template <int LOG2N, bool INV>
+template <int LOG2N, bool INV, int SAUX>
 __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                        size_t nframes, const float2 *__restrict__ twtab)
 {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const flo
             // last radix-16 pass with Ns: out index = (l / Ns) * 16 Ns + (l % Ns) + k * Ns, and LPF = Ns there
             const cf r = INV ? cf{v[q].x, -v[q].y} : v[q];
             const u32x2 t = {__float_as_uint(r.x), __float_as_uint(r.y)};
-            __builtin_amdgcn_raw_buffer_store_b64(t, ws, (int)voff, k * LPF * 8, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(t, ws, (int)voff, k * LPF * 8, SAUX);
         }
     }
 }
@@ -184,7 +185,10 @@ int launch_r16(const void *in, void *out, size_t nframes, bool inverse, const vo
 {
     typedef Plan<LOG2N> P;
     const size_t lds = (size_t)P::LDS_FRAME * P::FPW * sizeof(cf);
-    auto k = inverse ? fft_r16_kernel<LOG2N, true> : fft_r16_kernel<LOG2N, false>;
+    // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
+    static const int saux = [] { const char *e = getenv("PCX_FFT_STORE_AUX"); return e ? atoi(e) : 2; }();
+    auto k = saux == 2 ? (inverse ? fft_r16_kernel<LOG2N, true, 2> : fft_r16_kernel<LOG2N, false, 2>)
+                       : (inverse ? fft_r16_kernel<LOG2N, true, 0> : fft_r16_kernel<LOG2N, false, 0>);
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const size_t ngroups = (nframes + P::FPW - 1) / P::FPW;
     unsigned per_cu = lds ? (unsigned)(160 * 1024 / lds) : 8;

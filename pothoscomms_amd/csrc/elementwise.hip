@@ -20,6 +20,35 @@ struct alignas(sizeof(T) * N) Vec {
     T v[N];
 };
 
+// The maps touch every byte exactly once: loads and stores carry the non-temporal hint (measured on
+// MI355X, tools/ubench.hip: copy 5.4 -> 5.8 TB/s with nt).  The builtins take scalar / ext-vector
+// types, so a Vec goes through a same-sized integer vector.
+template <int BYTES> struct RawVec;
+template <> struct RawVec<1> { typedef unsigned char type; };
+template <> struct RawVec<2> { typedef unsigned short type; };
+template <> struct RawVec<4> { typedef unsigned int type; };
+template <> struct RawVec<8> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
+template <> struct RawVec<16> { typedef unsigned int type __attribute__((ext_vector_type(4))); };
+template <typename V>
+__device__ __forceinline__ V nt_load(const V *p)
+{
+    static_assert(sizeof(V) <= 16, "vector wider than one 16-byte access");
+    typedef typename RawVec<sizeof(V)>::type R;
+    const R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
+    V v;
+    __builtin_memcpy(&v, &r, sizeof(V));
+    return v;
+}
+template <typename V>
+__device__ __forceinline__ void nt_store(V *p, const V &v)
+{
+    static_assert(sizeof(V) <= 16, "vector wider than one 16-byte access");
+    typedef typename RawVec<sizeof(V)>::type R;
+    R r;
+    __builtin_memcpy(&r, &v, sizeof(V));
+    __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
+}
+
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;
 
@@ -38,13 +67,13 @@ __global__ __launch_bounds__(kBlock) void map_kernel(const In *__restrict__ in, 
         const size_t base = c * chunk + threadIdx.x;
         VIn a[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; u++) a[u] = vin[base + (size_t)u * kBlock];
+        for (int u = 0; u < kUnroll; u++) a[u] = nt_load(&vin[base + (size_t)u * kBlock]);
 #pragma unroll
         for (int u = 0; u < kUnroll; u++) {
             VOut b;
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) op(&a[u].v[k * IN_PER], &b.v[k * OUT_PER]);
-            vout[base + (size_t)u * kBlock] = b;
+            nt_store(&vout[base + (size_t)u * kBlock], b);
         }
     }
     // remaining whole vectors, then the scalar tail
@@ -358,18 +387,42 @@ __global__ __launch_bounds__(kBlock) void freqdemod_kernel(const T *__restrict__
     using VOut = Vec<T, ITEMS>;
     const size_t nvec = n / ITEMS;
     const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x, gstride = (size_t)gridDim.x * kBlock;
-    for (size_t i = gtid; i < nvec; i += gstride) {
-        const VIn a = reinterpret_cast<const VIn *>(in)[i];
-        T c, d;
-        if (i == 0) { c = prev_in[0]; d = prev_in[1]; }
-        else { c = in[2 * (i * ITEMS - 1)]; d = conj_im<T>(in[2 * (i * ITEMS - 1) + 1]); }
+    const VIn *vin = reinterpret_cast<const VIn *>(in);
+    VOut *vout = reinterpret_cast<VOut *>(out);
+    // one vector: ITEMS outputs from ITEMS inputs and the sample before them (the previous lane's
+    // last element: a second, scalar-sized read of a line the wave fetches anyway)
+    auto one = [&](size_t i, const VIn &a, T c, T d) {
         VOut o;
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             o.v[k] = demod_one<T>(a.v[2 * k], a.v[2 * k + 1], c, d);
             c = a.v[2 * k]; d = conj_im<T>(a.v[2 * k + 1]);
         }
-        reinterpret_cast<VOut *>(out)[i] = o;
+        nt_store(&vout[i], o);
+    };
+    // kUnroll vectors per lane in flight, as in map_kernel
+    const size_t chunk = (size_t)kBlock * kUnroll;
+    const size_t nchunks = nvec / chunk;
+    for (size_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const size_t base = ch * chunk + threadIdx.x;
+        VIn a[kUnroll];
+        T c[kUnroll], d[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const size_t i = base + (size_t)u * kBlock;
+            a[u] = vin[i];
+            if (i == 0) { c[u] = prev_in[0]; d[u] = prev_in[1]; }
+            else { c[u] = in[2 * (i * ITEMS - 1)]; d[u] = conj_im<T>(in[2 * (i * ITEMS - 1) + 1]); }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) one(base + (size_t)u * kBlock, a[u], c[u], d[u]);
+    }
+    for (size_t i = nchunks * chunk + gtid; i < nvec; i += gstride) {
+        const VIn a = vin[i];
+        T c, d;
+        if (i == 0) { c = prev_in[0]; d = prev_in[1]; }
+        else { c = in[2 * (i * ITEMS - 1)]; d = conj_im<T>(in[2 * (i * ITEMS - 1) + 1]); }
+        one(i, a, c, d);
     }
     for (size_t i = nvec * ITEMS + gtid; i < n; i += gstride) {
         T c, d;
@@ -386,7 +439,7 @@ static int launch_freqdemod_t(const void *in, void *out, size_t n, const void *p
     constexpr int ITEMS = (2 * sizeof(T) >= 16) ? 1 : (int)(16 / (2 * sizeof(T)));
     const bool aligned = (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % (sizeof(T) * ITEMS) == 0);
     if (aligned && ITEMS > 1) {
-        const unsigned grid = stream_grid(n / ITEMS + 1, kBlock);
+        const unsigned grid = stream_grid(n / ITEMS / kUnroll + 1, kBlock);
         hipLaunchKernelGGL((freqdemod_kernel<T, ITEMS>), dim3(grid), dim3(kBlock), 0, st, (const T *)in, (T *)out, n, (const T *)prev_in, (T *)prev_out);
     } else {
         const unsigned grid = stream_grid(n, kBlock);

@@ -175,7 +175,10 @@ def main():
         ch = device.FmChain()
         ch.set_phase(tp.C4_PHASE)
         ch.set_taps(tp.c4_taps(), False)
-        x = torch.empty((n + 126, 2), dtype=torch.float32, device=dev)
+        # [lead | 126-sample history | n samples] with the samples (not the history) on a 128-byte line,
+        # the same placement ShardedFir uses
+        xa = torch.empty((2 + n + 126, 2), dtype=torch.float32, device=dev)
+        x = xa[2:]
         y = torch.empty((n,), dtype=torch.float32, device=dev)
         device.fill_uniform_f32_dev(x, seed=5, offset=0)
         units = n

@@ -171,7 +171,8 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     if (K < 1 || K > 2049) { set_error("fir ols: K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
     // PCX_OLS_VARIANT (A/B and diagnostics): unset = default policy below; 1 plain loads/stores, 0 register
     // prefetch (3 workgroups/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs, 5 H from L2,
-    // 6 nt stores only, 7 nt interior loads only, 10/11 compute-only / memory-only timing builds.
+    // 6 nt stores only, 7 nt interior loads only, 9 register prefetch + default cache policy,
+    // 10/11 compute-only / memory-only timing builds (plain accesses), 12/13 the same with the default policy.
     // PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
     static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : -1; }();
     static const int align = [] { const char *e = getenv("PCX_OLS_ALIGN"); return e ? atoi(e) : 1; }();
@@ -198,6 +199,9 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     case 5: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 0, 0, false, 0, true>), g4); break;
     case 6: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4); break;
     case 7: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0>), g4); break;
+    case 9: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 4, 2>), g3); break;
+    case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, false, 1>), g4); break;
+    case 13: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, false, 2>), g4); break;
     case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 1>), g4); break;
     case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 2>), g4); break;
     default:

@@ -11,7 +11,8 @@ taps) and no other data-path collective.
 
 Buffer layout on every rank: one contiguous tensor [halo | C samples] -- the halo sits directly
 in front of the shard so the kernel sees the same "history at the front" buffer as a single-GPU
-call (pcx_fir_process_dev), and the received bytes land in place (no staging copy).
+call (pcx_fir_process_dev), and the received bytes land in place (no staging copy).  The shard,
+not the halo, is placed on a 128-byte line (see ShardedFir.__init__).
 
 Latency hiding: a 2 KB message is pure latency (tens of microseconds against a ~0.25 ms pass).
 Only the first `head` outputs of a shard read the halo, so a pass (a) posts the exchange,
@@ -73,7 +74,13 @@ class ShardedFir:
         self.K = self.fir.K
         self.C = int(shard_len)
         self.ring = HaloRing(self.K - 1, group)
-        self.buf = torch.zeros((self.K - 1 + self.C, 2), dtype=torch.float32, device=device)
+        # layout in HBM: [lead | halo (K-1) | shard (C)] with the SHARD on a 128-byte line (the halo is
+        # right-aligned against it).  The overlap-save kernel rounds its block overlap up to 16 samples,
+        # so with this placement every 2 KiB row it loads AND every row it stores starts on a line
+        # (measured on MI355X: 0.2245 -> 0.2187 ms per 64 Mi samples against a line-aligned halo).
+        lead = (-(self.K - 1)) % 16
+        self._alloc = torch.zeros((lead + self.K - 1 + self.C, 2), dtype=torch.float32, device=device)
+        self.buf = self._alloc[lead:]
         self.out = torch.empty((self.C, 2), dtype=torch.float32, device=device)
         self.head = min(self.HEAD, self.C)
 

@@ -28,7 +28,11 @@ for K in Ks:
         print("N=%s K=%d: %s" % (N, K, e)); continue
     got = yd.cpu().numpy()
     err = float(np.abs(got - want).max() / np.abs(want).max())
-    x = torch.empty((n + K - 1,) if REAL else (n + K - 1, 2), dtype=torch.float32, device=d); device.fill_uniform_f32_dev(x, seed=1)
+    # AB_SHARD_ALIGN=1: place the stream so that the first sample AFTER the K-1 history (the shard) sits on a
+    # 128-byte line, instead of the history itself
+    lead = (-(K - 1)) % (32 if REAL else 16) if os.environ.get("AB_SHARD_ALIGN") else 0
+    xa = torch.empty((lead + n + K - 1,) if REAL else (lead + n + K - 1, 2), dtype=torch.float32, device=d); device.fill_uniform_f32_dev(xa, seed=1)
+    x = xa[lead:]
     y = torch.empty((n,) if REAL else (n, 2), dtype=torch.float32, device=d)
     for _ in range(150): f.process_dev(x, y)
     torch.cuda.synchronize()
@@ -38,4 +42,4 @@ for K in Ks:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 100
     print("N=%s K=%4d  err %.2e  %.4f ms  %.1f Gsamples/s" % (N, K, err, ms, n / ms / 1e6), flush=True)
-    del x, y
+    del x, xa, y

@@ -1,0 +1,46 @@
+"""Copy the judged rocprofv3 summaries from gpurun_out/<run> into profiles/<round> and rebuild
+profiles/traffic.json from the PMC summaries (tools/refresh_profiles.sh produces <run> on the GPU box).
+    python tools/collect_profiles.py gpurun_out/r01b profiles/r01
+"""
+import glob, json, os, re, shutil, sys
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+
+def newest(pattern):
+    fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return fs[-1] if fs else None
+
+for name in ("bench_default.json", "bench_other_workloads.jsonl"):
+    shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+f = newest(os.path.join(src, "bench_kt", "**", "*_kernel_stats.csv"))
+if f:
+    shutil.copy(f, os.path.join(dst, "bench_fir255_kernel_stats.csv"))
+traffic = {}
+for wl in ("fir255", "fft4096", "fmchain", "direct255"):
+    summ = os.path.join(src, wl, "summary.txt")
+    if not os.path.exists(summ):
+        continue
+    shutil.copy(summ, os.path.join(dst, wl + "_rocprofv3_summary.txt"))
+    f = newest(os.path.join(src, wl, "kt", "**", "*_kernel_stats.csv"))
+    if f:
+        shutil.copy(f, os.path.join(dst, wl + "_kernel_stats.csv"))
+    txt = open(summ).read()
+    fetch = re.search(r"FETCH_SIZE\s+([0-9.e+]+)", txt)
+    write = re.search(r"WRITE_SIZE\s+([0-9.e+]+)", txt)
+    if fetch and write:
+        fk, wk = float(fetch.group(1)), float(write.group(1))
+        traffic[wl] = {
+            "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
+            "FETCH_SIZE_KiB_raw": fk,
+            "WRITE_SIZE_KiB": wk,
+            "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams -> doubled "
+                          "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
+            "source": "%s/%s_rocprofv3_summary.txt (separate --pmc passes, mean of 3 launches)" % (dst, wl),
+        }
+old = {}
+tj = os.path.join(os.path.dirname(dst.rstrip("/")), "traffic.json")
+if os.path.exists(tj):
+    old = json.load(open(tj))
+old.update(traffic)
+json.dump(old, open(tj, "w"), indent=1)
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in old.items()}))

@@ -22,5 +22,12 @@ elif wl == "fft4096":
     fft = device.Fft("complex_float32", 4096, False)
     for _ in range(n):
         fft.transform_dev(x, y, nframes)
+elif wl == "fmchain":
+    ch = device.FmChain(); ch.set_phase(tp.C4_PHASE); ch.set_taps(tp.c4_taps(), False)
+    xa = torch.empty((2 + C + 126, 2), dtype=torch.float32, device=dev); x = xa[2:]
+    y = torch.empty((C,), dtype=torch.float32, device=dev)
+    device.fill_uniform_f32_dev(x, seed=5)
+    for _ in range(n):
+        ch.process_dev(x, y, C + 126, C)
 torch.cuda.synchronize()
 print("done", wl)

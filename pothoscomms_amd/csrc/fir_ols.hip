@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const flo
         cf v[16];
         {
             const size_t left = in_elems - b * S;
-            load_frame<true, 0>(v, make_rsrc(in + b * S, (unsigned)((left < (size_t)N ? left : (size_t)N) * 8)), j);
+            if (left >= (size_t)N) load_frame<false, 0>(v, make_rsrc(in + b * S, N * 8), j);   // row offsets in soffset
+            else load_frame<true, 0>(v, make_rsrc(in + b * S, (unsigned)(left * 8)), j);      // ragged tail: range-checked
         }
         pass1(v, lds, j);
         pass2(v, lds, j);
@@ -390,15 +391,18 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const flo
         const unsigned long long q0 = B0 / M;
         const unsigned r0 = (unsigned)(B0 - q0 * M);
         const size_t n_left = n_iter - b * S;                                       // inputs of this call from the block start
+        const unsigned nl = n_left < (size_t)N ? (unsigned)n_left : (unsigned)N;   // 32-bit bound for the lane tests
+        float2 *ob = out + q0 - 1;
+        asm volatile("" : "+s"(ob));   // keep ONE base pointer live instead of 16 hoisted row addresses
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int row = 256 * bin_of(q);
             if (row + 255 < Km1) continue;
-            const int ip = row + j - Km1;
-            if (ip < 0 || (size_t)ip >= n_left) continue;
-            const unsigned x = r0 + (unsigned)ip * L;
+            const unsigned ip = (unsigned)(row + j - Km1);      // negative wraps above nl
+            if (ip >= nl) continue;
+            const unsigned x = r0 + ip * L;
             const unsigned qq = (unsigned)(((unsigned long long)x * magic) >> 40);   // x / M
-            if (x - qq * M == 0) out[q0 + qq - 1] = make_float2(u[q].x, -u[q].y);
+            if (x - qq * M == 0) ob[qq] = make_float2(u[q].x, -u[q].y);
         }
     }
 }

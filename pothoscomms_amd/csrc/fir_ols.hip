@@ -36,7 +36,7 @@ namespace pcx {
 // the compute floor), 2 = no transforms (load, store: the memory floor)
 // HGLOBAL: fetch the lane's 16 H bins from L2 in every block instead of holding them in 32 VGPRs
 // -- room for the register prefetch at 4 workgroups per CU.
-template <bool PREFETCH, int LAUX = 0, int SAUX = 0, bool CHUNKED = false, int DIAG = 0, bool HGLOBAL = false>
+template <bool PREFETCH, int LAUX = 0, int SAUX = 0, int CHUNKED = 0, int DIAG = 0, bool HGLOBAL = false>
 __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Kov, int pad,
@@ -55,7 +55,16 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
     // instead of a grid stride, so the K-1 samples block b+1 shares with block b were fetched
     // by the same CU a moment ago (L2/L1 hit instead of a second trip to the memory side).
     size_t b, bend, bstep;
-    if (CHUNKED) {
+    if (CHUNKED == 2) {
+        // XCD-aware walk: workgroup w runs on XCD w % 8 (round-robin dispatch).  Each XCD takes one
+        // contiguous eighth of the blocks and its workgroups walk it side by side, so the window rows
+        // block b+1 shares with block b are fetched by the same XCD at about the same time (an L2
+        // hit instead of a second trip over the fabric: the per-XCD L2s do not see each other)
+        const size_t per = (nblocks + 7) / 8, x = blockIdx.x & 7;
+        b = x * per + (blockIdx.x >> 3);
+        bend = (x + 1) * per < nblocks ? (x + 1) * per : nblocks;
+        bstep = gridDim.x >> 3;
+    } else if (CHUNKED) {
         const size_t q = nblocks / gridDim.x, rem = nblocks % gridDim.x, w = blockIdx.x;
         b = w * q + (w < rem ? w : rem);
         bend = b + q + (w < rem ? 1 : 0);
@@ -172,7 +181,8 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     // PCX_OLS_VARIANT (A/B and diagnostics): unset = default policy below; 1 plain loads/stores, 0 register
     // prefetch (3 workgroups/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs, 5 H from L2,
     // 6 nt stores only, 7 nt interior loads only, 9 register prefetch + default cache policy,
-    // 10/11 compute-only / memory-only timing builds (plain accesses), 12/13 the same with the default policy.
+    // 10/11 compute-only / memory-only timing builds (plain accesses), 12/13 the same with the default policy,
+    // 14 XCD-aware block walk + default policy.
     // PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
     static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : -1; }();
     static const int align = [] { const char *e = getenv("PCX_OLS_ALIGN"); return e ? atoi(e) : 1; }();
@@ -189,21 +199,23 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     const float2 *pi = (const float2 *)in, *ph = (const float2 *)Hspec, *pt = (const float2 *)tw4096;
     float2 *po = (float2 *)out;
     const unsigned g4 = persistent_grid(nblocks, 1024), g3 = persistent_grid(nblocks, 768);
+    const unsigned gx = 8 * persistent_grid((nblocks + 7) / 8, 128);   // XCD-aware walk: equal rounds inside every XCD's eighth
 #define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks)
     switch (variant) {
     case 0: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true>), g3); break;
     case 1: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false>), g4); break;
     case 2: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 0>), g4); break;
     case 3: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 2>), g4); break;
-    case 4: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, true>), g4); break;
-    case 5: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 0, 0, false, 0, true>), g4); break;
+    case 4: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 1>), g4); break;
+    case 5: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 0, 0, 0, 0, true>), g4); break;
     case 6: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4); break;
     case 7: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0>), g4); break;
     case 9: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 4, 2>), g3); break;
-    case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, false, 1>), g4); break;
-    case 13: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, false, 2>), g4); break;
-    case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 1>), g4); break;
-    case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, false, 2>), g4); break;
+    case 14: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 2>), gx); break;
+    case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 1>), g4); break;
+    case 13: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 2>), g4); break;
+    case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 1>), g4); break;
+    case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 2>), g4); break;
     default:
         // non-temporal stores; non-temporal loads for the rows no other block reads
         if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), g4);

@@ -42,7 +42,9 @@ extern "C" {
 #define PCX_API __attribute__((visibility("default")))
 
 typedef enum pcx_scalar {
-    PCX_F64 = 0, PCX_F32 = 1, PCX_I64 = 2, PCX_I32 = 3, PCX_I16 = 4, PCX_I8 = 5
+    PCX_F64 = 0, PCX_F32 = 1, PCX_I64 = 2, PCX_I32 = 3, PCX_I16 = 4, PCX_I8 = 5,
+    /* unsigned element types: accepted by pcx_arith* only (arithmeticFactory, Arithmetic.cpp:284-296) */
+    PCX_U64 = 6, PCX_U32 = 7, PCX_U16 = 8, PCX_U8 = 9
 } pcx_scalar;
 
 typedef enum pcx_status {
@@ -168,6 +170,21 @@ PCX_API int pcx_conj_dev(int scalar, const void *in_dev, void *out_dev, size_t n
  * complex element types only, out is the real scalar type */
 PCX_API int pcx_angle(int scalar, const void *in, void *out, size_t n);
 PCX_API int pcx_angle_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream);
+
+/* /comms/arithmetic (SURVEY 8f "next"): math/Arithmetic.cpp:70-110, out[i] = in0[i] OP in1[i] with the
+ * C++ operator of the element type (real or std::complex of f64, f32, (u)int8..64).  The block's
+ * work() (:205-231) left-folds its N input ports: call once per extra port with in0 = out.  `out`
+ * may be exactly in0 or in1 (the reference forwards input 0's buffer, :157-158).  Integer x / 0
+ * traps in the reference; here it yields 0.  Unknown op or type: PCX_ERR_ARG ("unsupported args", :297). */
+typedef enum pcx_arith_op { PCX_ARITH_ADD = 0, PCX_ARITH_SUB = 1, PCX_ARITH_MUL = 2, PCX_ARITH_DIV = 3 } pcx_arith_op;
+PCX_API int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *in1, void *out, size_t n);
+PCX_API int pcx_arith_dev(int scalar, int is_complex, int op, const void *in0_dev, const void *in1_dev, void *out_dev, size_t n, void *stream);
+/* /comms/split_complex, /comms/combine_complex: utility/SplitComplex.cpp:10-18, utility/CombineComplex.cpp:10-17;
+ * scalar = the real type of the planes (f64, f32, int64..int8: splitComplexFactory :60-70) */
+PCX_API int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n);
+PCX_API int pcx_split_complex_dev(int scalar, const void *in_dev, void *re_dev, void *im_dev, size_t n, void *stream);
+PCX_API int pcx_combine_complex(int scalar, const void *re, const void *im, void *out, size_t n);
+PCX_API int pcx_combine_complex_dev(int scalar, const void *re_dev, const void *im_dev, void *out_dev, size_t n, void *stream);
 
 /* ===================================================================== *
  *  Fused FM-demod chain  Rotate -> FIR -> FreqDemod in one kernel

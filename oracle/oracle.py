@@ -14,8 +14,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # scalar type codes (same numbering as include/pcx.h)
-F64, F32, I64, I32, I16, I8 = range(6)
-NP_SCALAR = {F64: np.float64, F32: np.float32, I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8}
+F64, F32, I64, I32, I16, I8, U64, U32, U16, U8 = range(10)   # unsigned: /comms/arithmetic only
+NP_SCALAR = {F64: np.float64, F32: np.float32, I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8,
+             U64: np.uint64, U32: np.uint32, U16: np.uint16, U8: np.uint8}
+ADD, SUB, MUL, DIV = range(4)
 SCALAR_OF_NP = {np.dtype(v): k for k, v in NP_SCALAR.items()}
 
 
@@ -101,6 +103,9 @@ def _declare(L):
     L.orc_conj.argtypes = [C.c_int, vp, vp, sz]
     L.orc_angle.argtypes = [C.c_int, vp, vp, sz]
     L.orc_fill_uniform_f32.argtypes = [vp, sz, C.c_uint64, C.c_uint64]
+    L.orc_arith.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, sz]
+    L.orc_split_complex.argtypes = [C.c_int, vp, vp, vp, sz]
+    L.orc_combine_complex.argtypes = [C.c_int, vp, vp, vp, sz]
 
 
 # --------------------------------------------------------------------------- #
@@ -280,6 +285,42 @@ def angle(x):
     xp = as_pairs(x)
     y = np.zeros(xp.shape[0], dtype=xp.dtype)
     lib().orc_angle(scalar_code(xp), _ptr(xp), _ptr(y), xp.shape[0])
+    return y
+
+
+def arith(op, a, b, is_complex):
+    """out[i] = a[i] OP b[i] (math/Arithmetic.cpp:70-110); complex operands as (n, 2) arrays."""
+    ap, bp = as_pairs(a), as_pairs(b)
+    y = np.zeros_like(ap)
+    n = ap.shape[0]
+    if lib().orc_arith(scalar_code(ap), int(is_complex), op, _ptr(ap), _ptr(bp), _ptr(y), n) != 0:
+        raise ValueError("unsupported args")   # Arithmetic.cpp:297
+    return y
+
+
+def ref_arith(op, a, b, is_complex):
+    """The same expression evaluated by the C++ operators themselves (oracle/ref_driver.cpp)."""
+    ap, bp = as_pairs(a), as_pairs(b)
+    y = np.zeros_like(ap)
+    fn = ref().ref_std_arith
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    if fn(scalar_code(ap), int(is_complex), op, _ptr(ap), _ptr(bp), _ptr(y), ap.shape[0]) != 0:
+        raise ValueError("unsupported args")
+    return y
+
+
+def split_complex(x):
+    xp = as_pairs(x)
+    n = xp.shape[0]
+    re, im = np.zeros(n, dtype=xp.dtype), np.zeros(n, dtype=xp.dtype)
+    lib().orc_split_complex(scalar_code(xp), _ptr(xp), _ptr(re), _ptr(im), n)
+    return re, im
+
+
+def combine_complex(re, im):
+    re, im = np.ascontiguousarray(re), np.ascontiguousarray(im)
+    y = np.zeros((re.shape[0], 2), dtype=re.dtype)
+    lib().orc_combine_complex(scalar_code(re), _ptr(re), _ptr(im), _ptr(y), re.shape[0])
     return y
 
 

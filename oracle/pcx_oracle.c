@@ -41,15 +41,16 @@
 #define ORC_EXPORT __attribute__((visibility("default")))
 
 /* scalar type codes -- same numbering as include/pcx.h */
-enum { ORC_F64 = 0, ORC_F32 = 1, ORC_I64 = 2, ORC_I32 = 3, ORC_I16 = 4, ORC_I8 = 5 };
+enum { ORC_F64 = 0, ORC_F32 = 1, ORC_I64 = 2, ORC_I32 = 3, ORC_I16 = 4, ORC_I8 = 5,
+       ORC_U64 = 6, ORC_U32 = 7, ORC_U16 = 8, ORC_U8 = 9 };   /* unsigned: /comms/arithmetic only */
 
 static int scalar_bytes(int st)
 {
     switch (st) {
-    case ORC_F64: case ORC_I64: return 8;
-    case ORC_F32: case ORC_I32: return 4;
-    case ORC_I16: return 2;
-    case ORC_I8: return 1;
+    case ORC_F64: case ORC_I64: case ORC_U64: return 8;
+    case ORC_F32: case ORC_I32: case ORC_U32: return 4;
+    case ORC_I16: case ORC_U16: return 2;
+    case ORC_I8: case ORC_U8: return 1;
     }
     return 0;
 }
@@ -1009,6 +1010,168 @@ ORC_EXPORT int orc_conj(int st, const void *in, void *out, size_t n)
             store_int(out, 2 * i, st, load_int(in, 2 * i, st));
             store_int(out, 2 * i + 1, st, (int64_t)((uint64_t)0 - (uint64_t)load_int(in, 2 * i + 1, st)));
         }
+    }
+    return 0;
+}
+
+/* ===================================================================== *
+ *  /comms/arithmetic, /comms/split_complex, /comms/combine_complex  
+ *
+ *  Arithmetic::work (math/Arithmetic.cpp:205-231) left-folds the block's input ports through
+ *  one of four array functions (:70-110):  out[i] = in0[i] OP in1[i]  with the C++ operator of the
+ *  element type.  Types: float, double, (u)int8..64 and std::complex of each (:284-296).
+ *  What those operators are, on the reference's toolchain (libstdc++ <complex>, libgcc):
+ *    - integers narrower than int promote to int and narrow back on the store (wrap mod 2^bits);
+ *      32/64-bit signed overflow is undefined in C++ and wraps on every build of the reference;
+ *    - x / 0 traps (SIGFPE) in the reference and INT_MIN / -1 is undefined: this restatement
+ *      returns 0 resp. the wrapped quotient there, and the tests keep those inputs out of
+ *      parity claims;
+ *    - complex<float|double> * and / are the C99 operations (std::complex<T>::operator*= and /=
+ *      act on the __complex__ representation: libgcc __mulsc3/__divsc3/__muldc3/__divdc3), which
+ *      this file gets from the same libgcc_s.so.1 by using C99 _Complex arithmetic (Makefile:
+ *      -shared-libgcc).  Measured on this image (libgcc_s from GCC 12): complex<float> division is
+ *      evaluated in double -- den = c*c + d*d, ((a*c + b*d)/den, (b*c - a*d)/den), rounded once to
+ *      float; complex<double> division is Smith's ratio form; both multiplications are
+ *      (a*c - b*d, a*d + b*c) with separately rounded products for finite operands;
+ *    - complex<integer> uses libstdc++'s generic members: operator*= is
+ *        r = re*z.re - im*z.im;  im = re*z.im + im*z.re;  re = r          (each narrowed to T)
+ *      and operator/= is
+ *        r = re*z.re + im*z.im;  n = norm(z) = z.re*z.re + z.im*z.im      (r, n narrowed to T)
+ *        im = (im*z.re - re*z.im) / n;  re = r / n
+ *      -- note the asymmetry: the new imaginary part divides the un-narrowed promoted numerator.
+ *  Pinned by math/TestArithmeticBlocks.cpp:47-245 (closed-form vectors, all 20 types x 4 ops) through
+ *  tests/golden and, for the complex operators, against std::complex itself (oracle/ref_driver.cpp).
+ * ===================================================================== */
+enum { ORC_ADD = 0, ORC_SUB = 1, ORC_MUL = 2, ORC_DIV = 3 };
+
+/* T: element type; P: the type the operands are promoted to (int for the narrow types, the
+ * unsigned twin for 32/64-bit so that + - * wrap without undefined behaviour); D: the type the
+ * division is carried out in (T's own signedness after promotion) */
+#define ORC_ARITH_INT(NAME, T, P, D, DMIN)                                                          \
+    static inline D NAME##_div(D a, D b)                                                            \
+    {                                                                                               \
+        if (b == 0) return 0;               /* reference: SIGFPE */                                 \
+        if ((DMIN) != 0 && a == (D)(DMIN) && b == (D)-1) return a; /* reference: undefined */       \
+        return (D)(a / b);                                                                          \
+    }                                                                                               \
+    static void NAME##_real(int op, const T *a, const T *b, T *o, size_t n)                         \
+    {                                                                                               \
+        for (size_t i = 0; i < n; i++) {                                                            \
+            const P x = (P)a[i], y = (P)b[i];                                                       \
+            switch (op) {                                                                           \
+            case ORC_ADD: o[i] = (T)(P)(x + y); break;                                              \
+            case ORC_SUB: o[i] = (T)(P)(x - y); break;                                              \
+            case ORC_MUL: o[i] = (T)(P)(x * y); break;                                              \
+            default: o[i] = (T)NAME##_div((D)a[i], (D)b[i]); break;                                 \
+            }                                                                                       \
+        }                                                                                           \
+    }                                                                                               \
+    static void NAME##_cplx(int op, const T *a, const T *b, T *o, size_t n)                         \
+    {                                                                                               \
+        for (size_t i = 0; i < n; i++) {                                                            \
+            const P ar = (P)a[2 * i], ai = (P)a[2 * i + 1], br = (P)b[2 * i], bi = (P)b[2 * i + 1]; \
+            T re, im;                                                                               \
+            switch (op) {                                                                           \
+            case ORC_ADD: re = (T)(P)(ar + br); im = (T)(P)(ai + bi); break;                        \
+            case ORC_SUB: re = (T)(P)(ar - br); im = (T)(P)(ai - bi); break;                        \
+            case ORC_MUL: re = (T)(P)(ar * br - ai * bi); im = (T)(P)(ar * bi + ai * br); break;    \
+            default: {                                                                              \
+                const T r = (T)(P)(ar * br + ai * bi);                                              \
+                const T nn = (T)(P)(br * br + bi * bi);                                             \
+                /* numerator of the new imaginary part stays in the promoted type */                \
+                const P num = (P)(ai * br - ar * bi);                                               \
+                im = (T)NAME##_div((D)num, (D)nn);                                                  \
+                re = (T)NAME##_div((D)r, (D)nn);                                                    \
+            } break;                                                                                \
+            }                                                                                       \
+            o[2 * i] = re; o[2 * i + 1] = im;                                                       \
+        }                                                                                           \
+    }
+/* narrow types: operands promote to int, so P = D = int */
+ORC_ARITH_INT(ar_i8, int8_t, int, int, 0)
+ORC_ARITH_INT(ar_u8, uint8_t, int, int, 0)
+ORC_ARITH_INT(ar_i16, int16_t, int, int, 0)
+ORC_ARITH_INT(ar_u16, uint16_t, int, int, 0)
+/* 32/64-bit: + - * in the unsigned twin (wraps), division in the type itself */
+ORC_ARITH_INT(ar_i32, int32_t, uint32_t, int32_t, INT32_MIN)
+ORC_ARITH_INT(ar_u32, uint32_t, uint32_t, uint32_t, 0)
+ORC_ARITH_INT(ar_i64, int64_t, uint64_t, int64_t, INT64_MIN)
+ORC_ARITH_INT(ar_u64, uint64_t, uint64_t, uint64_t, 0)
+
+#define ORC_ARITH_FLT(NAME, T, CT)                                                                  \
+    static void NAME##_real(int op, const T *a, const T *b, T *o, size_t n)                         \
+    {                                                                                               \
+        for (size_t i = 0; i < n; i++) {                                                            \
+            switch (op) {                                                                           \
+            case ORC_ADD: o[i] = a[i] + b[i]; break;                                                \
+            case ORC_SUB: o[i] = a[i] - b[i]; break;                                                \
+            case ORC_MUL: o[i] = a[i] * b[i]; break;                                                \
+            default: o[i] = a[i] / b[i]; break;                                                     \
+            }                                                                                       \
+        }                                                                                           \
+    }                                                                                               \
+    static void NAME##_cplx(int op, const T *a, const T *b, T *o, size_t n)                         \
+    {                                                                                               \
+        for (size_t i = 0; i < n; i++) {                                                            \
+            CT x, y, z;                                                                             \
+            __real__ x = a[2 * i]; __imag__ x = a[2 * i + 1];                                       \
+            __real__ y = b[2 * i]; __imag__ y = b[2 * i + 1];                                       \
+            switch (op) {                                                                           \
+            case ORC_ADD: z = x + y; break;                                                         \
+            case ORC_SUB: z = x - y; break;                                                         \
+            case ORC_MUL: z = x * y; break;   /* __mulsc3 / __muldc3 */                             \
+            default: z = x / y; break;        /* __divsc3 / __divdc3 */                             \
+            }                                                                                       \
+            o[2 * i] = __real__ z; o[2 * i + 1] = __imag__ z;                                       \
+        }                                                                                           \
+    }
+ORC_ARITH_FLT(ar_f32, float, float _Complex)
+ORC_ARITH_FLT(ar_f64, double, double _Complex)
+
+/* out[i] = in0[i] OP in1[i]; n counts elements (complex elements when is_complex) */
+ORC_EXPORT int orc_arith(int st, int is_complex, int op, const void *in0, const void *in1, void *out, size_t n)
+{
+    if (op < ORC_ADD || op > ORC_DIV) return -1;
+#define ORC_ARITH_CASE(CODE, NAME, T)                                                          \
+    case CODE:                                                                                 \
+        if (is_complex) NAME##_cplx(op, (const T *)in0, (const T *)in1, (T *)out, n);          \
+        else NAME##_real(op, (const T *)in0, (const T *)in1, (T *)out, n);                     \
+        return 0;
+    switch (st) {
+        ORC_ARITH_CASE(ORC_F64, ar_f64, double)
+        ORC_ARITH_CASE(ORC_F32, ar_f32, float)
+        ORC_ARITH_CASE(ORC_I64, ar_i64, int64_t)
+        ORC_ARITH_CASE(ORC_I32, ar_i32, int32_t)
+        ORC_ARITH_CASE(ORC_I16, ar_i16, int16_t)
+        ORC_ARITH_CASE(ORC_I8, ar_i8, int8_t)
+        ORC_ARITH_CASE(ORC_U64, ar_u64, uint64_t)
+        ORC_ARITH_CASE(ORC_U32, ar_u32, uint32_t)
+        ORC_ARITH_CASE(ORC_U16, ar_u16, uint16_t)
+        ORC_ARITH_CASE(ORC_U8, ar_u8, uint8_t)
+    }
+#undef ORC_ARITH_CASE
+    return -1;
+}
+
+/* arraySplitComplex / arrayCombineComplex (utility/SplitComplex.cpp:10-18,
+ * utility/CombineComplex.cpp:10-17): pure data movement, any scalar width */
+ORC_EXPORT int orc_split_complex(int st, const void *in, void *re, void *im, size_t n)
+{
+    const size_t w = (size_t)scalar_bytes(st);
+    if (w == 0) return -1;
+    for (size_t i = 0; i < n; i++) {
+        memcpy((char *)re + i * w, (const char *)in + 2 * i * w, w);
+        memcpy((char *)im + i * w, (const char *)in + (2 * i + 1) * w, w);
+    }
+    return 0;
+}
+ORC_EXPORT int orc_combine_complex(int st, const void *re, const void *im, void *out, size_t n)
+{
+    const size_t w = (size_t)scalar_bytes(st);
+    if (w == 0) return -1;
+    for (size_t i = 0; i < n; i++) {
+        memcpy((char *)out + 2 * i * w, (const char *)re + i * w, w);
+        memcpy((char *)out + (2 * i + 1) * w, (const char *)im + i * w, w);
     }
     return 0;
 }

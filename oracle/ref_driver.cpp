@@ -84,3 +84,48 @@ REF_ABS(ref_abs_i64, int64_t)
 REF_ABS(ref_abs_i32, int32_t)
 REF_ABS(ref_abs_i16, int16_t)
 REF_ABS(ref_abs_i8, int8_t)
+
+// ---- /comms/arithmetic: the element operators themselves ----
+// math/Arithmetic.cpp:70-110 is `out[i] = in0[i] OP in1[i]` on `Type` = T or std::complex<T>; the file
+// needs <Pothos/Framework.hpp> and cannot be compiled here, but the operators it applies are the
+// toolchain's (C++ arithmetic conversions, libstdc++ <complex>, libgcc), and math/TestArithmeticBlocks.cpp
+// :146-151,201-206 computes its own expected complex outputs with the very same expressions.  These
+// exports evaluate those expressions so that oracle/pcx_oracle.c's C restatement of the operators can
+// be checked bit for bit and the golden vectors of the reference test generated.
+template <typename Type>
+static void std_arith(int op, const void *a, const void *b, void *o, size_t n)
+{
+    const Type *in0 = static_cast<const Type *>(a), *in1 = static_cast<const Type *>(b);
+    Type *out = static_cast<Type *>(o);
+    for (size_t i = 0; i < n; i++) {
+        switch (op) {
+        case 0: out[i] = in0[i] + in1[i]; break;
+        case 1: out[i] = in0[i] - in1[i]; break;
+        case 2: out[i] = in0[i] * in1[i]; break;
+        default: out[i] = in0[i] / in1[i]; break;   // the caller keeps zero divisors out
+        }
+    }
+}
+// st: include/pcx.h scalar codes (0 f64, 1 f32, 2..5 i64..i8, 6..9 u64..u8)
+REF_EXPORT int ref_std_arith(int st, int is_complex, int op, const void *in0, const void *in1, void *out, size_t n)
+{
+#define REF_ARITH_CASE(CODE, T)                                                       \
+    case CODE:                                                                        \
+        if (is_complex) std_arith<std::complex<T>>(op, in0, in1, out, n);             \
+        else std_arith<T>(op, in0, in1, out, n);                                      \
+        return 0;
+    switch (st) {
+        REF_ARITH_CASE(0, double)
+        REF_ARITH_CASE(1, float)
+        REF_ARITH_CASE(2, int64_t)
+        REF_ARITH_CASE(3, int32_t)
+        REF_ARITH_CASE(4, int16_t)
+        REF_ARITH_CASE(5, int8_t)
+        REF_ARITH_CASE(6, uint64_t)
+        REF_ARITH_CASE(7, uint32_t)
+        REF_ARITH_CASE(8, uint16_t)
+        REF_ARITH_CASE(9, uint8_t)
+    }
+#undef REF_ARITH_CASE
+    return -1;
+}

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcx_hip.so")
 
 # pcx_scalar
-F64, F32, I64, I32, I16, I8 = range(6)
+F64, F32, I64, I32, I16, I8, U64, U32, U16, U8 = range(10)   # unsigned: pcx_arith* only
+ARITH_ADD, ARITH_SUB, ARITH_MUL, ARITH_DIV = range(4)
 # pcx_status
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = 0, -1, -2, -3, -4
 # pcx_fir_algo
@@ -79,6 +80,12 @@ SIGNATURES = {
     "pcx_conj_dev": (_i, [_i, _vp, _vp, _sz, _vp]),
     "pcx_angle": (_i, [_i, _vp, _vp, _sz]),
     "pcx_angle_dev": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "pcx_arith": (_i, [_i, _i, _i, _vp, _vp, _vp, _sz]),
+    "pcx_arith_dev": (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "pcx_split_complex": (_i, [_i, _vp, _vp, _vp, _sz]),
+    "pcx_split_complex_dev": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+    "pcx_combine_complex": (_i, [_i, _vp, _vp, _vp, _sz]),
+    "pcx_combine_complex_dev": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
     "pcx_fmchain_create": (_i, [C.POINTER(_vp)]),
     "pcx_fmchain_destroy": (_i, [_vp]),
     "pcx_fmchain_set_phase": (_i, [_vp, _d]),

@@ -1,0 +1,334 @@
+// arith.hip -- /comms/arithmetic, /comms/split_complex, /comms/combine_complex:
+// two-stream element-wise kernels on the same 16-byte-vector, non-temporal, grid-stride scheme as
+// elementwise.hip.  HBM-bound: 3 streams of sizeof(element) each (24 B per cf32 element).
+//
+// Element operators = the C++ operators math/Arithmetic.cpp:70-110 applies (`out[i] = in0[i] OP in1[i]`),
+// restated for the device type by type -- see oracle/pcx_oracle.c (orc_arith) for the derivation and
+// the cross-check against std::complex:
+//   * integers narrower than int promote to int, 32/64-bit + - * wrap; results narrow on the store;
+//   * x / 0 (a trap in the reference) yields 0, INT_MIN / -1 (undefined there) yields INT_MIN;
+//   * complex<integer>: libstdc++'s generic operator*= / operator/= including the narrowing of r and
+//     norm(z) to T and the un-narrowed numerator of the new imaginary part;
+//   * complex<float> *: (ac - bd, ad + bc), every product and sum rounded (this TU is built with
+//     -ffp-contract=off); complex<float> /: evaluated in double, rounded once (libgcc_s __divsc3);
+//     complex<double> /: Smith's ratio form (__divdc3's path for operands in the normal range).
+// Float results are bit-identical to the reference for finite, normal-range operands; the parity bar
+// is 1e-5 relative.
+#include "pcx_internal.hpp"
+
+#include <type_traits>
+
+namespace pcx {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 2;   // two input streams: 2 x 2 x 16 B in flight per lane
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+template <int BYTES> struct RawVec;
+template <> struct RawVec<1> { typedef unsigned char type; };
+template <> struct RawVec<2> { typedef unsigned short type; };
+template <> struct RawVec<4> { typedef unsigned int type; };
+template <> struct RawVec<8> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
+template <> struct RawVec<16> { typedef unsigned int type __attribute__((ext_vector_type(4))); };
+template <typename V>
+__device__ __forceinline__ V nt_load(const V *p)
+{
+    typedef typename RawVec<sizeof(V)>::type R;
+    const R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
+    V v;
+    __builtin_memcpy(&v, &r, sizeof(V));
+    return v;
+}
+template <typename V>
+__device__ __forceinline__ void nt_store(V *p, const V &v)
+{
+    typedef typename RawVec<sizeof(V)>::type R;
+    R r;
+    __builtin_memcpy(&r, &v, sizeof(V));
+    __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
+}
+
+// ---- promoted / division types per element type (see the header comment) ----
+template <typename T> struct Prom {
+    typedef typename std::conditional<(sizeof(T) < 4), int, typename std::make_unsigned<T>::type>::type P;   // + - *
+    typedef typename std::conditional<(sizeof(T) < 4), int, T>::type D;                                      // /
+};
+template <typename D>
+__device__ __forceinline__ D int_div(D a, D b)
+{
+    if (b == 0) return 0;
+    if (std::is_signed<D>::value && sizeof(D) >= 4 && b == (D)-1) return (D)(0 - (typename std::make_unsigned<D>::type)a);   // wraps at MIN
+    return (D)(a / b);
+}
+
+template <typename T, int OP, bool FLT = std::is_floating_point<T>::value>
+struct RealOp;
+template <typename T, int OP>
+struct RealOp<T, OP, true> {
+    __device__ void operator()(const T *a, const T *b, T *o) const
+    {
+        o[0] = OP == PCX_ARITH_ADD ? a[0] + b[0] : OP == PCX_ARITH_SUB ? a[0] - b[0] : OP == PCX_ARITH_MUL ? a[0] * b[0] : a[0] / b[0];
+    }
+};
+template <typename T, int OP>
+struct RealOp<T, OP, false> {
+    __device__ void operator()(const T *a, const T *b, T *o) const
+    {
+        typedef typename Prom<T>::P P;
+        typedef typename Prom<T>::D D;
+        const P x = (P)a[0], y = (P)b[0];
+        if (OP == PCX_ARITH_ADD) o[0] = (T)(P)(x + y);
+        else if (OP == PCX_ARITH_SUB) o[0] = (T)(P)(x - y);
+        else if (OP == PCX_ARITH_MUL) o[0] = (T)(P)(x * y);
+        else o[0] = (T)int_div<D>((D)a[0], (D)b[0]);
+    }
+};
+
+template <typename T, int OP, bool FLT = std::is_floating_point<T>::value>
+struct CplxOp;
+// complex<integer>: libstdc++ generic members
+template <typename T, int OP>
+struct CplxOp<T, OP, false> {
+    __device__ void operator()(const T *a, const T *b, T *o) const
+    {
+        typedef typename Prom<T>::P P;
+        typedef typename Prom<T>::D D;
+        const P ar = (P)a[0], ai = (P)a[1], br = (P)b[0], bi = (P)b[1];
+        if (OP == PCX_ARITH_ADD) { o[0] = (T)(P)(ar + br); o[1] = (T)(P)(ai + bi); }
+        else if (OP == PCX_ARITH_SUB) { o[0] = (T)(P)(ar - br); o[1] = (T)(P)(ai - bi); }
+        else if (OP == PCX_ARITH_MUL) { o[0] = (T)(P)(ar * br - ai * bi); o[1] = (T)(P)(ar * bi + ai * br); }
+        else {
+            const T r = (T)(P)(ar * br + ai * bi);
+            const T nn = (T)(P)(br * br + bi * bi);
+            const P num = (P)(ai * br - ar * bi);     // stays in the promoted type
+            o[1] = (T)int_div<D>((D)num, (D)nn);
+            o[0] = (T)int_div<D>((D)r, (D)nn);
+        }
+    }
+};
+template <int OP>
+struct CplxOp<float, OP, true> {
+    __device__ void operator()(const float *a, const float *b, float *o) const
+    {
+        if (OP == PCX_ARITH_ADD) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; }
+        else if (OP == PCX_ARITH_SUB) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; }
+        else if (OP == PCX_ARITH_MUL) {
+            const float ac = a[0] * b[0], bd = a[1] * b[1], ad = a[0] * b[1], bc = a[1] * b[0];
+            o[0] = ac - bd; o[1] = ad + bc;
+        } else {
+            const double aa = a[0], bb = a[1], cc = b[0], dd = b[1];
+            const double den = (cc * cc) + (dd * dd);
+            o[0] = (float)(((aa * cc) + (bb * dd)) / den);
+            o[1] = (float)(((bb * cc) - (aa * dd)) / den);
+        }
+    }
+};
+template <int OP>
+struct CplxOp<double, OP, true> {
+    __device__ void operator()(const double *x, const double *y, double *o) const
+    {
+        const double a = x[0], b = x[1], c = y[0], d = y[1];
+        if (OP == PCX_ARITH_ADD) { o[0] = a + c; o[1] = b + d; }
+        else if (OP == PCX_ARITH_SUB) { o[0] = a - c; o[1] = b - d; }
+        else if (OP == PCX_ARITH_MUL) {
+            const double ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+            o[0] = ac - bd; o[1] = ad + bc;
+        } else if (fabs(c) < fabs(d)) {
+            const double ratio = c / d, den = (c * ratio) + d;
+            o[0] = ((a * ratio) + b) / den;
+            o[1] = ((b * ratio) - a) / den;
+        } else {
+            const double ratio = d / c, den = (d * ratio) + c;
+            o[0] = ((b * ratio) + a) / den;
+            o[1] = (b - (a * ratio)) / den;
+        }
+    }
+};
+
+// PER scalars per element, ITEMS elements per 16-byte lane vector
+template <typename T, int PER, int ITEMS, typename Op>
+__global__ __launch_bounds__(kBlock) void map2_kernel(const T *__restrict__ in0, const T *__restrict__ in1, T *out, size_t nitems, Op op)
+{
+    // `out` may alias in0 or in1 exactly (the reference forwards input 0's buffer to the output
+    // and folds further ports in place, Arithmetic.cpp:157-158,217-224): every lane reads its own
+    // elements before it writes them, no lane touches another's
+    using V = Vec<T, PER * ITEMS>;
+    const size_t nvec = nitems / ITEMS;
+    const size_t chunk = (size_t)kBlock * kUnroll;
+    const size_t nchunks = nvec / chunk;
+    const V *va = reinterpret_cast<const V *>(in0), *vb = reinterpret_cast<const V *>(in1);
+    V *vo = reinterpret_cast<V *>(out);
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t base = c * chunk + threadIdx.x;
+        V a[kUnroll], b[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            a[u] = nt_load(&va[base + (size_t)u * kBlock]);
+            b[u] = nt_load(&vb[base + (size_t)u * kBlock]);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            V o;
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) op(&a[u].v[k * PER], &b[u].v[k * PER], &o.v[k * PER]);
+            nt_store(&vo[base + (size_t)u * kBlock], o);
+        }
+    }
+    const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x, gstride = (size_t)gridDim.x * kBlock;
+    for (size_t i = nchunks * chunk + gtid; i < nvec; i += gstride) {
+        const V a = va[i], b = vb[i];
+        V o;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) op(&a.v[k * PER], &b.v[k * PER], &o.v[k * PER]);
+        vo[i] = o;
+    }
+    for (size_t i = nvec * ITEMS + gtid; i < nitems; i += gstride) {
+        T t[PER];
+        op(in0 + i * PER, in1 + i * PER, t);
+#pragma unroll
+        for (int k = 0; k < PER; k++) out[i * PER + k] = t[k];
+    }
+}
+
+template <typename T, int PER, typename Op>
+int launch_map2(const void *in0, const void *in1, void *out, size_t nitems, Op op, hipStream_t st)
+{
+    constexpr int item_bytes = (int)sizeof(T) * PER;
+    constexpr int ITEMS = item_bytes >= 16 ? 1 : 16 / item_bytes;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(in0) | reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(out);
+    const T *a = static_cast<const T *>(in0), *b = static_cast<const T *>(in1);
+    T *o = static_cast<T *>(out);
+    if (ITEMS > 1 && al % 16 == 0) {
+        const unsigned grid = stream_grid(nitems / ITEMS / kUnroll + 1, kBlock);
+        hipLaunchKernelGGL((map2_kernel<T, PER, ITEMS, Op>), dim3(grid), dim3(kBlock), 0, st, a, b, o, nitems, op);
+    } else {
+        const unsigned grid = stream_grid(nitems / kUnroll + 1, kBlock);
+        hipLaunchKernelGGL((map2_kernel<T, PER, 1, Op>), dim3(grid), dim3(kBlock), 0, st, a, b, o, nitems, op);
+    }
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+template <typename T>
+int launch_arith_t(int is_complex, int op, const void *a, const void *b, void *o, size_t n, hipStream_t st)
+{
+    if (is_complex) {
+        switch (op) {
+        case PCX_ARITH_ADD: return launch_map2<T, 2>(a, b, o, n, CplxOp<T, PCX_ARITH_ADD>{}, st);
+        case PCX_ARITH_SUB: return launch_map2<T, 2>(a, b, o, n, CplxOp<T, PCX_ARITH_SUB>{}, st);
+        case PCX_ARITH_MUL: return launch_map2<T, 2>(a, b, o, n, CplxOp<T, PCX_ARITH_MUL>{}, st);
+        default: return launch_map2<T, 2>(a, b, o, n, CplxOp<T, PCX_ARITH_DIV>{}, st);
+        }
+    }
+    switch (op) {
+    case PCX_ARITH_ADD: return launch_map2<T, 1>(a, b, o, n, RealOp<T, PCX_ARITH_ADD>{}, st);
+    case PCX_ARITH_SUB: return launch_map2<T, 1>(a, b, o, n, RealOp<T, PCX_ARITH_SUB>{}, st);
+    case PCX_ARITH_MUL: return launch_map2<T, 1>(a, b, o, n, RealOp<T, PCX_ARITH_MUL>{}, st);
+    default: return launch_map2<T, 1>(a, b, o, n, RealOp<T, PCX_ARITH_DIV>{}, st);
+    }
+}
+
+// ---- split / combine: W-byte scalars, ITEMS = 16 / W complex elements per lane: two 16-byte
+// vectors of interleaved input <-> one 16-byte vector per plane ----
+template <typename W, bool SPLIT>
+__global__ __launch_bounds__(kBlock) void planes_kernel(const W *inter_in, W *inter_out, const W *re_in, const W *im_in, W *re_out,
+                                                       W *im_out, size_t n, bool vec)
+{
+    constexpr int ITEMS = 16 / (int)sizeof(W);
+    using VP = Vec<W, ITEMS>;         // one plane vector
+    const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x, gstride = (size_t)gridDim.x * kBlock;
+    const size_t nvec = vec ? n / ITEMS : 0;
+    for (size_t i = gtid; i < nvec; i += gstride) {
+        if (SPLIT) {
+            const VP lo = nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i), hi = nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i + 1);
+            VP re, im;
+#pragma unroll
+            for (int k = 0; k < ITEMS / 2; k++) {
+                re.v[k] = lo.v[2 * k]; im.v[k] = lo.v[2 * k + 1];
+                re.v[ITEMS / 2 + k] = hi.v[2 * k]; im.v[ITEMS / 2 + k] = hi.v[2 * k + 1];
+            }
+            nt_store(reinterpret_cast<VP *>(re_out) + i, re);
+            nt_store(reinterpret_cast<VP *>(im_out) + i, im);
+        } else {
+            const VP re = nt_load(reinterpret_cast<const VP *>(re_in) + i), im = nt_load(reinterpret_cast<const VP *>(im_in) + i);
+            VP lo, hi;
+#pragma unroll
+            for (int k = 0; k < ITEMS / 2; k++) {
+                lo.v[2 * k] = re.v[k]; lo.v[2 * k + 1] = im.v[k];
+                hi.v[2 * k] = re.v[ITEMS / 2 + k]; hi.v[2 * k + 1] = im.v[ITEMS / 2 + k];
+            }
+            nt_store(reinterpret_cast<VP *>(inter_out) + 2 * i, lo);
+            nt_store(reinterpret_cast<VP *>(inter_out) + 2 * i + 1, hi);
+        }
+    }
+    for (size_t i = nvec * ITEMS + gtid; i < n; i += gstride) {
+        if (SPLIT) { re_out[i] = inter_in[2 * i]; im_out[i] = inter_in[2 * i + 1]; }
+        else { inter_out[2 * i] = re_in[i]; inter_out[2 * i + 1] = im_in[i]; }
+    }
+}
+template <typename W>
+int launch_planes(bool split, const void *inter_in, void *inter_out, const void *re_in, const void *im_in, void *re_out, void *im_out,
+                  size_t n, hipStream_t st)
+{
+    const uintptr_t al = reinterpret_cast<uintptr_t>(inter_in) | reinterpret_cast<uintptr_t>(inter_out) | reinterpret_cast<uintptr_t>(re_in) |
+                         reinterpret_cast<uintptr_t>(im_in) | reinterpret_cast<uintptr_t>(re_out) | reinterpret_cast<uintptr_t>(im_out);
+    const bool vec = al % 16 == 0;
+    const unsigned grid = stream_grid(vec ? n / (16 / sizeof(W)) + 1 : n, kBlock);
+    if (split)
+        hipLaunchKernelGGL((planes_kernel<W, true>), dim3(grid), dim3(kBlock), 0, st, (const W *)inter_in, (W *)nullptr, (const W *)nullptr,
+                           (const W *)nullptr, (W *)re_out, (W *)im_out, n, vec);
+    else
+        hipLaunchKernelGGL((planes_kernel<W, false>), dim3(grid), dim3(kBlock), 0, st, (const W *)nullptr, (W *)inter_out, (const W *)re_in,
+                           (const W *)im_in, (W *)nullptr, (W *)nullptr, n, vec);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+int launch_planes_w(int width, bool split, const void *ii, void *io, const void *ri, const void *mi, void *ro, void *mo, size_t n, hipStream_t st)
+{
+    switch (width) {
+    case 8: return launch_planes<uint64_t>(split, ii, io, ri, mi, ro, mo, n, st);
+    case 4: return launch_planes<uint32_t>(split, ii, io, ri, mi, ro, mo, n, st);
+    case 2: return launch_planes<uint16_t>(split, ii, io, ri, mi, ro, mo, n, st);
+    case 1: return launch_planes<uint8_t>(split, ii, io, ri, mi, ro, mo, n, st);
+    }
+    set_error("split/combine complex: unsupported scalar width %d", width);
+    return PCX_ERR_ARG;
+}
+
+}  // namespace
+
+int launch_arith(int scalar, int is_complex, int op, const void *in0, const void *in1, void *out, size_t n, hipStream_t st)
+{
+    if (n == 0) return PCX_OK;
+    switch (scalar) {
+    case PCX_F64: return launch_arith_t<double>(is_complex, op, in0, in1, out, n, st);
+    case PCX_F32: return launch_arith_t<float>(is_complex, op, in0, in1, out, n, st);
+    case PCX_I64: return launch_arith_t<int64_t>(is_complex, op, in0, in1, out, n, st);
+    case PCX_I32: return launch_arith_t<int32_t>(is_complex, op, in0, in1, out, n, st);
+    case PCX_I16: return launch_arith_t<int16_t>(is_complex, op, in0, in1, out, n, st);
+    case PCX_I8: return launch_arith_t<int8_t>(is_complex, op, in0, in1, out, n, st);
+    case PCX_U64: return launch_arith_t<uint64_t>(is_complex, op, in0, in1, out, n, st);
+    case PCX_U32: return launch_arith_t<uint32_t>(is_complex, op, in0, in1, out, n, st);
+    case PCX_U16: return launch_arith_t<uint16_t>(is_complex, op, in0, in1, out, n, st);
+    case PCX_U8: return launch_arith_t<uint8_t>(is_complex, op, in0, in1, out, n, st);
+    }
+    set_error("arithmetic: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+int launch_split_complex(int scalar, const void *in, void *re, void *im, size_t n, hipStream_t st)
+{
+    if (n == 0) return PCX_OK;
+    return launch_planes_w(scalar_bytes(scalar), true, in, nullptr, nullptr, nullptr, re, im, n, st);
+}
+int launch_combine_complex(int scalar, const void *re, const void *im, void *out, size_t n, hipStream_t st)
+{
+    if (n == 0) return PCX_OK;
+    return launch_planes_w(scalar_bytes(scalar), false, nullptr, out, re, im, nullptr, nullptr, n, st);
+}
+
+}  // namespace pcx

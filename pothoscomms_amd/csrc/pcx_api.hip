@@ -686,7 +686,7 @@ int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
 // host-buffer wrapper: stage in, run, stage out (one temporary device allocation pair
 // per thread, grown on demand)
 struct MapWs {
-    DevBuf in, out;
+    DevBuf in, out, in2, out2;
 };
 static thread_local MapWs g_mapws;
 
@@ -770,6 +770,77 @@ int pcx_angle(int scalar, const void *in, void *out, size_t n)
     PCX_CHECK_ARG(valid_scalar(scalar), "angleFactory: unsupported type (scalar %d)", scalar);
     const size_t sb = (size_t)scalar_bytes(scalar);
     return run_host_map(in, out, n * 2 * sb, n * sb, [&](void *di, void *dout) { return launch_angle(scalar, di, dout, n, nullptr); });
+}
+
+int pcx_arith_dev(int scalar, int is_complex, int op, const void *in0_dev, const void *in1_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_arith_scalar(scalar) && op >= PCX_ARITH_ADD && op <= PCX_ARITH_DIV,
+                  "arithmeticFactory: unsupported args (scalar %d, op %d)", scalar, op);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in0_dev && in1_dev && out_dev, "null buffer");
+    return launch_arith(scalar, is_complex, op, in0_dev, in1_dev, out_dev, n, as_stream(stream));
+}
+int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *in1, void *out, size_t n)
+{
+    PCX_CHECK_ARG(valid_arith_scalar(scalar) && op >= PCX_ARITH_ADD && op <= PCX_ARITH_DIV,
+                  "arithmeticFactory: unsupported args (scalar %d, op %d)", scalar, op);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in0 && in1 && out, "null buffer");
+    const size_t b = n * (is_complex ? 2 : 1) * (size_t)scalar_bytes(scalar);
+    PCX_TRY(g_mapws.in.ensure(b));
+    PCX_TRY(g_mapws.in2.ensure(b));
+    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, in0, b, hipMemcpyHostToDevice, nullptr));
+    PCX_HIP(hipMemcpyAsync(g_mapws.in2.p, in1, b, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(launch_arith(scalar, is_complex, op, g_mapws.in.p, g_mapws.in2.p, g_mapws.in.p, n, nullptr));   // in place on the staged copy
+    PCX_HIP(hipMemcpyAsync(out, g_mapws.in.p, b, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
+int pcx_split_complex_dev(int scalar, const void *in_dev, void *re_dev, void *im_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "splitComplexFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && re_dev && im_dev, "null buffer");
+    return launch_split_complex(scalar, in_dev, re_dev, im_dev, n, as_stream(stream));
+}
+int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "splitComplexFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in && re && im, "null buffer");
+    const size_t b = n * (size_t)scalar_bytes(scalar);
+    PCX_TRY(g_mapws.in.ensure(2 * b));
+    PCX_TRY(g_mapws.out.ensure(b));
+    PCX_TRY(g_mapws.out2.ensure(b));
+    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, in, 2 * b, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(launch_split_complex(scalar, g_mapws.in.p, g_mapws.out.p, g_mapws.out2.p, n, nullptr));
+    PCX_HIP(hipMemcpyAsync(re, g_mapws.out.p, b, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipMemcpyAsync(im, g_mapws.out2.p, b, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
+int pcx_combine_complex_dev(int scalar, const void *re_dev, const void *im_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "combineComplexFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(re_dev && im_dev && out_dev, "null buffer");
+    return launch_combine_complex(scalar, re_dev, im_dev, out_dev, n, as_stream(stream));
+}
+int pcx_combine_complex(int scalar, const void *re, const void *im, void *out, size_t n)
+{
+    PCX_CHECK_ARG(valid_scalar(scalar), "combineComplexFactory: unsupported type (scalar %d)", scalar);
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(re && im && out, "null buffer");
+    const size_t b = n * (size_t)scalar_bytes(scalar);
+    PCX_TRY(g_mapws.in.ensure(b));
+    PCX_TRY(g_mapws.in2.ensure(b));
+    PCX_TRY(g_mapws.out.ensure(2 * b));
+    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, re, b, hipMemcpyHostToDevice, nullptr));
+    PCX_HIP(hipMemcpyAsync(g_mapws.in2.p, im, b, hipMemcpyHostToDevice, nullptr));
+    PCX_TRY(launch_combine_complex(scalar, g_mapws.in.p, g_mapws.in2.p, g_mapws.out.p, n, nullptr));
+    PCX_HIP(hipMemcpyAsync(out, g_mapws.out.p, 2 * b, hipMemcpyDeviceToHost, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
 }
 
 /* ===================================================================== *

@@ -35,14 +35,15 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 inline int scalar_bytes(int s)
 {
     switch (s) {
-    case PCX_F64: case PCX_I64: return 8;
-    case PCX_F32: case PCX_I32: return 4;
-    case PCX_I16: return 2;
-    case PCX_I8: return 1;
+    case PCX_F64: case PCX_I64: case PCX_U64: return 8;
+    case PCX_F32: case PCX_I32: case PCX_U32: return 4;
+    case PCX_I16: case PCX_U16: return 2;
+    case PCX_I8: case PCX_U8: return 1;
     }
     return 0;
 }
 inline bool valid_scalar(int s) { return s >= PCX_F64 && s <= PCX_I8; }
+inline bool valid_arith_scalar(int s) { return s >= PCX_F64 && s <= PCX_U8; }   // + the unsigned types
 inline bool is_float_scalar(int s) { return s == PCX_F64 || s == PCX_F32; }
 // Q (accumulator) width for an integer element type: FIRFilter.cpp:377-382,
 // Rotate.cpp:151-154, Scale.cpp:150-153
@@ -98,6 +99,9 @@ int launch_scale(int scalar, int is_complex, double factor, const void *in, void
 int launch_abs(int scalar, int is_complex, const void *in, void *out, size_t n, hipStream_t st);
 int launch_conj(int scalar, const void *in, void *out, size_t n, hipStream_t st);
 int launch_angle(int scalar, const void *in, void *out, size_t n, hipStream_t st);
+int launch_arith(int scalar, int is_complex, int op, const void *in0, const void *in1, void *out, size_t n, hipStream_t st);
+int launch_split_complex(int scalar, const void *in, void *re, void *im, size_t n, hipStream_t st);
+int launch_combine_complex(int scalar, const void *re, const void *im, void *out, size_t n, hipStream_t st);
 // out[i] = angle(in[i]*_prev); _prev(i=0) := *prev_in (already conjugated); *prev_out := conj(in[n-1])
 int launch_freqdemod(int scalar, const void *in, void *out, size_t n, const void *prev_in, void *prev_out, hipStream_t st);
 int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t offset, hipStream_t st);

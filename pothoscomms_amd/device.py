@@ -11,14 +11,17 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import F64, F32, I64, I32, I16, I8  # noqa: F401  (re-exported)
+from ._lib import F64, F32, I64, I32, I16, I8, U64, U32, U16, U8  # noqa: F401  (re-exported)
 
-NP_SCALAR = {F64: np.float64, F32: np.float32, I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8}
+NP_SCALAR = {F64: np.float64, F32: np.float32, I64: np.int64, I32: np.int32, I16: np.int16, I8: np.int8,
+             U64: np.uint64, U32: np.uint32, U16: np.uint16, U8: np.uint8}   # unsigned: arithmetic only
+ARITH_OPS = {"ADD": _lib.ARITH_ADD, "SUB": _lib.ARITH_SUB, "MUL": _lib.ARITH_MUL, "DIV": _lib.ARITH_DIV}
 SCALAR_OF_NP = {np.dtype(v): k for k, v in NP_SCALAR.items()}
 
 # Pothos DType names (DType::toString) -> (scalar code, is_complex)
 DTYPE_NAMES = {}
-for _code, _nm in ((F64, "float64"), (F32, "float32"), (I64, "int64"), (I32, "int32"), (I16, "int16"), (I8, "int8")):
+for _code, _nm in ((F64, "float64"), (F32, "float32"), (I64, "int64"), (I32, "int32"), (I16, "int16"), (I8, "int8"),
+                   (U64, "uint64"), (U32, "uint32"), (U16, "uint16"), (U8, "uint8")):
     DTYPE_NAMES[_nm] = (_code, False)
     DTYPE_NAMES["complex_" + _nm] = (_code, True)
 DTYPE_NAMES["complex64"] = (F32, True)    # Pothos accepts numpy-style aliases
@@ -300,6 +303,47 @@ def angle(x, scalar=None, out=None, n=None, stream=None):
         x = as_pairs(x)
         scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
     return _map("pcx_angle", "pcx_angle_dev", (scalar,), x, lambda a: (a.shape[0],), n, out, stream)
+
+
+def arith(op, a, b, is_complex, scalar=None, out=None, n=None, stream=None):
+    """out[i] = a[i] OP b[i], OP in "ADD"/"SUB"/"MUL"/"DIV" (math/Arithmetic.cpp:70-110, factory :279-297).
+    torch operands: device buffers (out may be a or b); numpy: host path."""
+    L = _lib.load()
+    if op not in ARITH_OPS:
+        raise _lib.InvalidArgument(_lib.ERR_ARG, "arithmeticFactory: unsupported args (operation %r)" % (op,))
+    if _is_torch(a):
+        _lib.check(L.pcx_arith_dev(scalar, int(is_complex), ARITH_OPS[op], _dev_ptr(a), _dev_ptr(b), _dev_ptr(out), n, _stream_ptr(stream)))
+        return out
+    a, b = as_pairs(a), as_pairs(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("operands must match")
+    y = np.zeros_like(a) if out is None else out
+    _lib.check(L.pcx_arith(SCALAR_OF_NP[a.dtype], int(is_complex), ARITH_OPS[op], _np_ptr(a), _np_ptr(b), _np_ptr(y), a.shape[0]))
+    return y
+
+
+def split_complex(x, scalar=None, re=None, im=None, n=None, stream=None):
+    """arraySplitComplex (utility/SplitComplex.cpp:10-18): (n, 2) interleaved -> two planes."""
+    L = _lib.load()
+    if _is_torch(x):
+        _lib.check(L.pcx_split_complex_dev(scalar, _dev_ptr(x), _dev_ptr(re), _dev_ptr(im), n, _stream_ptr(stream)))
+        return re, im
+    x = as_pairs(x)
+    re, im = np.zeros(x.shape[0], dtype=x.dtype), np.zeros(x.shape[0], dtype=x.dtype)
+    _lib.check(L.pcx_split_complex(SCALAR_OF_NP[x.dtype], _np_ptr(x), _np_ptr(re), _np_ptr(im), x.shape[0]))
+    return re, im
+
+
+def combine_complex(re, im, scalar=None, out=None, n=None, stream=None):
+    """arrayCombineComplex (utility/CombineComplex.cpp:10-17)."""
+    L = _lib.load()
+    if _is_torch(re):
+        _lib.check(L.pcx_combine_complex_dev(scalar, _dev_ptr(re), _dev_ptr(im), _dev_ptr(out), n, _stream_ptr(stream)))
+        return out
+    re, im = np.ascontiguousarray(re), np.ascontiguousarray(im)
+    y = np.zeros((re.shape[0], 2), dtype=re.dtype)
+    _lib.check(L.pcx_combine_complex(SCALAR_OF_NP[re.dtype], _np_ptr(re), _np_ptr(im), _np_ptr(y), re.shape[0]))
+    return y
 
 
 def fill_uniform_f32_dev(t, seed, offset=0, stream=None):

@@ -17,6 +17,7 @@ Two kinds of vectors, all plain data (inputs + expected outputs):
                                        seeded stand-in of the same range is stored)
       math/TestAngle.cpp:30-35,53-65   13 points mag*polar(1, i*pi/5) (pins getAngle, which
                                        FreqDemod shares)
+      math/TestArithmeticBlocks.cpp:47-245  ADD/SUB/MUL/DIV vectors for all 20 element types
  2. Outputs of the compiled reference (oracle/_ref: kissfft.hh, kiss_fft.c -DFIXED_POINT=16,
     fxpt_atan2.cpp, FxptHelpers.hpp built from /root/reference where they lie) on seeded
     random inputs -- these pin the oracle bit-for-bit on the GPU box, where the reference
@@ -107,6 +108,65 @@ def main():
         g["rand_angle_" + name] = o.ref_angle(z)
         g["rand_abs_cplx_" + name] = o.ref_abs(z, True)
         g["rand_abs_real_" + name] = o.ref_abs(np.ascontiguousarray(z[:, 0]), False)
+
+    # ---- 3. /comms/arithmetic ---------------------------------------
+    # math/TestArithmeticBlocks.cpp:47-245: 100-element closed-form vectors for all 20 element types
+    # (the complex cases re-type the same bytes as 50 pairs, :80-91,116-127, and recompute MUL/DIV
+    # expectations with the std::complex operators, :146-151,201-206 -- here through ref_std_arith).
+    arith_types = dict(ALL_TYPES, uint8=np.uint8, uint16=np.uint16, uint32=np.uint32, uint64=np.uint64)
+    e = np.arange(100, dtype=np.int64)
+    for name, dt in arith_types.items():
+        signed = not name.startswith("uint")
+        sgn = -1 if signed else 1
+        cast = lambda v: np.asarray(v, dtype=np.int64).astype(dt)   # static_cast<T>(size_t expression)
+        ins = {
+            "ADD": [cast(e), cast(e // 2) * dt(sgn), cast(e // 4) * dt(sgn)],
+            "SUB": [cast(e), cast(e * 2) if signed else cast(e // 2)],
+            "MUL": [cast(e), cast((e % 2) + 1) * dt(sgn)],
+            "DIV": [cast(e), cast((e % 2) + 1) * dt(sgn)],
+        }
+        for opname, arrs in ins.items():
+            arrs = [np.ascontiguousarray(a.astype(dt)) for a in arrs]
+            for k, a in enumerate(arrs):
+                g["arith_%s_%s_in%d" % (opname, name, k)] = a
+            op = {"ADD": o.ADD, "SUB": o.SUB, "MUL": o.MUL, "DIV": o.DIV}[opname]
+            # real: the expectation formulas of the test, evaluated by the C++ operators (ref_std_arith)
+            acc = arrs[0]
+            for a in arrs[1:]:
+                acc = o.ref_arith(op, acc, a, False)
+            g["arith_%s_%s_exp" % (opname, name)] = acc
+            acc = arrs[0].reshape(50, 2)
+            for a in arrs[1:]:
+                acc = o.ref_arith(op, acc, a.reshape(50, 2), True)
+            g["arith_%s_c%s_exp" % (opname, name)] = acc
+    # closed forms the test states for the real ADD case (:66-73), as an independent check of the above
+    g["arith_ADD_formula_signed"] = e - e // 2 - e // 4
+    g["arith_ADD_formula_unsigned"] = e + e // 2 + e // 4
+    # std::complex / C++ operators on seeded random operands: pins oracle/pcx_oracle.c's restatement
+    # where libstdc++/libgcc_s are not at hand
+    rng3 = np.random.default_rng(20240303)
+    for name, dt in arith_types.items():
+        for cplx in (0, 1):
+            shape = (192, 2) if cplx else (192,)
+            if name.startswith("float"):
+                a = (rng3.standard_normal(shape) * 100).astype(dt)
+                b = (rng3.standard_normal(shape) * 10).astype(dt)
+                bd = b
+            else:
+                info = np.iinfo(dt)
+                a = rng3.integers(info.min, info.max, size=shape, dtype=dt, endpoint=True)
+                b = rng3.integers(info.min, info.max, size=shape, dtype=dt, endpoint=True)
+                # divisors: small and non-zero (x/0 traps, MIN/-1 is undefined in the reference)
+                small = rng3.integers(-9 if info.min < 0 else 1, 10, size=shape)
+                bd = np.where(small == 0, 3, small).astype(dt)
+            g["arith_rand_%s_%d_a" % (name, cplx)] = a
+            g["arith_rand_%s_%d_b" % (name, cplx)] = b
+            g["arith_rand_%s_%d_bd" % (name, cplx)] = bd
+            ad = a if name.startswith("float") else (a // 4).astype(dt)   # keeps MIN/-1 out of the quotients
+            g["arith_rand_%s_%d_ad" % (name, cplx)] = ad
+            for opname, op in (("ADD", o.ADD), ("SUB", o.SUB), ("MUL", o.MUL)):
+                g["arith_rand_%s_%d_%s" % (name, cplx, opname)] = o.ref_arith(op, a, b, bool(cplx))
+            g["arith_rand_%s_%d_DIV" % (name, cplx)] = o.ref_arith(o.DIV, ad, bd, bool(cplx))
 
     np.savez_compressed(OUT, **g)
     print("wrote %s: %d arrays, %d bytes" % (OUT, len(g), os.path.getsize(OUT)))

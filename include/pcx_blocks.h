@@ -42,7 +42,8 @@ PCXB_API const char *pcxb_registry_path(size_t i);
 
 /* BlockRegistry::make(path, dtype, ...).  dtype is a Pothos DType name ("complex_float32"),
  * dimension its vector dimension.  The remaining factory arguments by block:
- *   fir_filter: sarg = tapsType ("REAL"/"COMPLEX");  fft: num_bins, inverse;  others: none */
+ *   fir_filter: sarg = tapsType ("REAL"/"COMPLEX");  arithmetic: sarg = operation ("ADD"/"SUB"/"MUL"/"DIV");
+ *   fft: num_bins, inverse;  others: none */
 PCXB_API int pcxb_make(const char *path, const char *dtype, size_t dimension, const char *sarg, size_t num_bins,
                        int inverse, pcxb_block **out);
 PCXB_API int pcxb_destroy(pcxb_block *b);
@@ -53,6 +54,8 @@ PCXB_API int pcxb_call_size(pcxb_block *b, const char *name, size_t v);
 PCXB_API int pcxb_call_bool(pcxb_block *b, const char *name, int v);
 PCXB_API int pcxb_call_string(pcxb_block *b, const char *name, const char *v);
 PCXB_API int pcxb_call_taps(pcxb_block *b, const char *name, const double *taps, size_t n, int is_complex);
+PCXB_API int pcxb_call_sizes(pcxb_block *b, const char *name, const size_t *v, size_t n);   /* std::vector<size_t> (setPreload) */
+PCXB_API int pcxb_get_sizes(pcxb_block *b, const char *name, size_t *out, size_t cap, size_t *n);
 PCXB_API int pcxb_get_double(pcxb_block *b, const char *name, double *out);
 PCXB_API int pcxb_get_size(pcxb_block *b, const char *name, size_t *out);
 PCXB_API int pcxb_get_bool(pcxb_block *b, const char *name, int *out);
@@ -60,7 +63,7 @@ PCXB_API int pcxb_get_string(pcxb_block *b, const char *name, char *out, size_t 
 PCXB_API int pcxb_get_taps(pcxb_block *b, const char *name, double *out, size_t cap_doubles, size_t *n, int is_complex);
 
 PCXB_API int pcxb_activate(pcxb_block *b);
-/* port 0 types and the buffer managers the block requests */
+/* the first input / output port's type (indexed port 0, or the first named port) and the buffer managers the block requests */
 PCXB_API int pcxb_port_dtype(pcxb_block *b, int is_output, char *name, size_t cap, size_t *dimension, size_t *bytes);
 PCXB_API int pcxb_buffer_manager(pcxb_block *b, int is_output, char *name, size_t cap, size_t *buffer_size);
 /* the reserve a block asked for at construction time (FFT: numBins); SIZE_MAX = none */
@@ -76,6 +79,20 @@ PCXB_API int pcxb_initial_reserve(pcxb_block *b, size_t *reserve);
 PCXB_API int pcxb_work(pcxb_block *b, const void *in, size_t in_elems, const pcxb_label *labels, size_t nlabels,
                        void *out, size_t out_elems, size_t *consumed, size_t *produced, size_t *reserve,
                        pcxb_label *posted, size_t cap, size_t *nposted);
+
+/*
+ * Blocks with several ports (arithmetic: N indexed inputs; split_complex: outputs "re","im";
+ * combine_complex: inputs "re","im").  Ports are numbered indexed-first, then the named ones in
+ * the order the block declared them.  `preloaded` = elements queued on an input by activate()
+ * (Arithmetic's feedback preload): the host prepends that many zero elements to the port's stream.
+ */
+PCXB_API int pcxb_num_ports(pcxb_block *b, int is_output, size_t *count);
+PCXB_API int pcxb_port_info(pcxb_block *b, int is_output, size_t i, char *name, size_t name_cap, char *dtype, size_t dtype_cap,
+                            size_t *dimension, size_t *bytes, size_t *preloaded);
+/* one work() call on planted buffers for every port: workInfo().minElements = minimum over the
+ * indexed ports, minAllElements over all of them; no labels on this path */
+PCXB_API int pcxb_work_ports(pcxb_block *b, size_t nin, const void *const *ins, const size_t *in_elems, size_t nout,
+                             void *const *outs, const size_t *out_elems, size_t *consumed, size_t *produced);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,11 @@ def load():
     L.pcxb_port_dtype.argtypes = [vp, i, cp, sz, C.POINTER(sz), C.POINTER(sz)]
     L.pcxb_buffer_manager.argtypes = [vp, i, cp, sz, C.POINTER(sz)]
     L.pcxb_initial_reserve.argtypes = [vp, C.POINTER(sz)]
+    L.pcxb_call_sizes.argtypes = [vp, cp, C.POINTER(sz), sz]
+    L.pcxb_get_sizes.argtypes = [vp, cp, C.POINTER(sz), sz, C.POINTER(sz)]
+    L.pcxb_num_ports.argtypes = [vp, i, C.POINTER(sz)]
+    L.pcxb_port_info.argtypes = [vp, i, sz, cp, sz, cp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.pcxb_work_ports.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.pcxb_work.argtypes = [vp, vp, sz, C.POINTER(PcxbLabel), sz, vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
                             C.POINTER(PcxbLabel), sz, C.POINTER(sz)]
     _blib = L
@@ -123,8 +128,8 @@ class Block:
         self.path = path
         self.dtype = dtype
         sarg, nbins, inverse = None, 0, 0
-        if path.endswith("fir_filter"):
-            sarg = (args[0] if args else "").encode()
+        if path.endswith("fir_filter") or path.endswith("/arithmetic"):
+            sarg = (args[0] if args else "").encode()     # tapsType resp. operation
         elif path == "/comms/fft":
             nbins, inverse = int(args[0]), int(bool(args[1])) if len(args) > 1 else 0
         self._h = C.c_void_p()
@@ -163,8 +168,15 @@ class Block:
             cnt = C.c_size_t()
             _check(L.pcxb_get_taps(self._h, n, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(cnt), int(cplx)))
             return buf[:2 * cnt.value].view(np.complex128).copy() if cplx else buf[:cnt.value].copy()
+        if name == "setPreload":
+            v = (C.c_size_t * max(1, len(args[0])))(*[int(a) for a in args[0]])
+            return _check(L.pcxb_call_sizes(self._h, n, v, len(args[0])))
+        if name == "preload":
+            v, cnt = (C.c_size_t * 64)(), C.c_size_t()
+            _check(L.pcxb_get_sizes(self._h, n, v, 64, C.byref(cnt)))
+            return [int(v[k]) for k in range(cnt.value)]
         if not args:   # getter
-            if name in ("getDecimation", "getInterpolation"):
+            if name in ("getDecimation", "getInterpolation", "getNumInlineBuffers"):
                 v = C.c_size_t()
                 _check(L.pcxb_get_size(self._h, n, C.byref(v)))
                 return v.value
@@ -201,6 +213,43 @@ class Block:
         r = C.c_size_t()
         load().pcxb_initial_reserve(self._h, C.byref(r))
         return None if r.value == _SIZE_MAX else r.value
+
+    def ports(self, is_output):
+        """[(name, dtype name, dimension, bytes per element, preloaded elements)] -- indexed ports first."""
+        L = load()
+        cnt = C.c_size_t()
+        _check(L.pcxb_num_ports(self._h, int(is_output), C.byref(cnt)))
+        out = []
+        for k in range(cnt.value):
+            nm, dt = C.create_string_buffer(64), C.create_string_buffer(64)
+            dim, nb, pre = C.c_size_t(), C.c_size_t(), C.c_size_t()
+            _check(L.pcxb_port_info(self._h, int(is_output), k, nm, 64, dt, 64, C.byref(dim), C.byref(nb), C.byref(pre)))
+            out.append((nm.value.decode(), dt.value.decode(), dim.value, nb.value, pre.value))
+        return out
+
+    def work_ports(self, ins, out_elems, inline=False):
+        """One work() call with a buffer planted on every port (ins: one array per input port, out_elems:
+        room per output port).  inline=True plants input 0's buffer as output 0 (the buffer forwarding the
+        reference's setReadBeforeWrite enables).  Returns (outs trimmed to produced, consumed, produced)."""
+        L = load()
+        ip, op = self.ports(0), self.ports(1)
+        xs = [np.ascontiguousarray(as_pairs(x)) for x in ins]
+        if isinstance(out_elems, int):
+            out_elems = [out_elems] * len(op)
+        ys = []
+        for (nm, dt, dim, nb, _), ne in zip(op, out_elems):
+            scalar, cplx = parse_dtype(dt)
+            ys.append(np.zeros([ne * dim] + ([2] if cplx else []), dtype=NP_SCALAR[scalar]))
+        if inline:
+            ys[0] = xs[0]
+        in_ptrs = (C.c_void_p * len(xs))(*[x.ctypes.data for x in xs])
+        in_n = (C.c_size_t * len(xs))(*[x.shape[0] // p[2] for x, p in zip(xs, ip)])
+        out_ptrs = (C.c_void_p * len(ys))(*[y.ctypes.data for y in ys])
+        out_n = (C.c_size_t * len(ys))(*[int(n) for n in out_elems])
+        cons, prod = (C.c_size_t * len(xs))(), (C.c_size_t * len(ys))()
+        _check(L.pcxb_work_ports(self._h, len(xs), in_ptrs, in_n, len(ys), out_ptrs, out_n, cons, prod))
+        produced = [int(v) for v in prod]
+        return [y[:p * port[2]] for y, p, port in zip(ys, produced, op)], [int(v) for v in cons], produced
 
     def work(self, inbuf, out_elems, labels=()):
         """One work() call.  Returns (out[:produced], consumed, produced, reserve, posted_labels)."""

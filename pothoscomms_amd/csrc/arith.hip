@@ -152,7 +152,7 @@ struct CplxOp<double, OP, true> {
 
 // PER scalars per element, ITEMS elements per 16-byte lane vector
 template <typename T, int PER, int ITEMS, typename Op>
-__global__ __launch_bounds__(kBlock) void map2_kernel(const T *__restrict__ in0, const T *__restrict__ in1, T *out, size_t nitems, Op op)
+__global__ __launch_bounds__(kBlock) void map2_kernel(const T *in0, const T *in1, T *out, size_t nitems, Op op)
 {
     // `out` may alias in0 or in1 exactly (the reference forwards input 0's buffer to the output
     // and folds further ports in place, Arithmetic.cpp:157-158,217-224): every lane reads its own
@@ -243,28 +243,46 @@ __global__ __launch_bounds__(kBlock) void planes_kernel(const W *inter_in, W *in
     using VP = Vec<W, ITEMS>;         // one plane vector
     const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x, gstride = (size_t)gridDim.x * kBlock;
     const size_t nvec = vec ? n / ITEMS : 0;
-    for (size_t i = gtid; i < nvec; i += gstride) {
-        if (SPLIT) {
-            const VP lo = nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i), hi = nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i + 1);
-            VP re, im;
+    constexpr int U = 2;    // plane vectors per lane and iteration: 4 x 16 B in flight
+    const size_t chunk = (size_t)kBlock * U, nchunks = nvec / chunk;
+    auto split1 = [&](const VP &lo, const VP &hi, size_t i) {
+        VP re, im;
 #pragma unroll
-            for (int k = 0; k < ITEMS / 2; k++) {
-                re.v[k] = lo.v[2 * k]; im.v[k] = lo.v[2 * k + 1];
-                re.v[ITEMS / 2 + k] = hi.v[2 * k]; im.v[ITEMS / 2 + k] = hi.v[2 * k + 1];
-            }
-            nt_store(reinterpret_cast<VP *>(re_out) + i, re);
-            nt_store(reinterpret_cast<VP *>(im_out) + i, im);
-        } else {
-            const VP re = nt_load(reinterpret_cast<const VP *>(re_in) + i), im = nt_load(reinterpret_cast<const VP *>(im_in) + i);
-            VP lo, hi;
-#pragma unroll
-            for (int k = 0; k < ITEMS / 2; k++) {
-                lo.v[2 * k] = re.v[k]; lo.v[2 * k + 1] = im.v[k];
-                hi.v[2 * k] = re.v[ITEMS / 2 + k]; hi.v[2 * k + 1] = im.v[ITEMS / 2 + k];
-            }
-            nt_store(reinterpret_cast<VP *>(inter_out) + 2 * i, lo);
-            nt_store(reinterpret_cast<VP *>(inter_out) + 2 * i + 1, hi);
+        for (int k = 0; k < ITEMS / 2; k++) {
+            re.v[k] = lo.v[2 * k]; im.v[k] = lo.v[2 * k + 1];
+            re.v[ITEMS / 2 + k] = hi.v[2 * k]; im.v[ITEMS / 2 + k] = hi.v[2 * k + 1];
         }
+        nt_store(reinterpret_cast<VP *>(re_out) + i, re);
+        nt_store(reinterpret_cast<VP *>(im_out) + i, im);
+    };
+    auto combine1 = [&](const VP &re, const VP &im, size_t i) {
+        VP lo, hi;
+#pragma unroll
+        for (int k = 0; k < ITEMS / 2; k++) {
+            lo.v[2 * k] = re.v[k]; lo.v[2 * k + 1] = im.v[k];
+            hi.v[2 * k] = re.v[ITEMS / 2 + k]; hi.v[2 * k + 1] = im.v[ITEMS / 2 + k];
+        }
+        nt_store(reinterpret_cast<VP *>(inter_out) + 2 * i, lo);
+        nt_store(reinterpret_cast<VP *>(inter_out) + 2 * i + 1, hi);
+    };
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t base = c * chunk + threadIdx.x;
+        VP a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (SPLIT) { a[u] = nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i); b[u] = nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i + 1); }
+            else { a[u] = nt_load(reinterpret_cast<const VP *>(re_in) + i); b[u] = nt_load(reinterpret_cast<const VP *>(im_in) + i); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = base + (size_t)u * kBlock;
+            if (SPLIT) split1(a[u], b[u], i); else combine1(a[u], b[u], i);
+        }
+    }
+    for (size_t i = nchunks * chunk + gtid; i < nvec; i += gstride) {
+        if (SPLIT) split1(nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i), nt_load(reinterpret_cast<const VP *>(inter_in) + 2 * i + 1), i);
+        else combine1(nt_load(reinterpret_cast<const VP *>(re_in) + i), nt_load(reinterpret_cast<const VP *>(im_in) + i), i);
     }
     for (size_t i = nvec * ITEMS + gtid; i < n; i += gstride) {
         if (SPLIT) { re_out[i] = inter_in[2 * i]; im_out[i] = inter_in[2 * i + 1]; }
@@ -278,7 +296,7 @@ int launch_planes(bool split, const void *inter_in, void *inter_out, const void 
     const uintptr_t al = reinterpret_cast<uintptr_t>(inter_in) | reinterpret_cast<uintptr_t>(inter_out) | reinterpret_cast<uintptr_t>(re_in) |
                          reinterpret_cast<uintptr_t>(im_in) | reinterpret_cast<uintptr_t>(re_out) | reinterpret_cast<uintptr_t>(im_out);
     const bool vec = al % 16 == 0;
-    const unsigned grid = stream_grid(vec ? n / (16 / sizeof(W)) + 1 : n, kBlock);
+    const unsigned grid = stream_grid(vec ? n / (16 / sizeof(W)) / 2 + 1 : n, kBlock);
     if (split)
         hipLaunchKernelGGL((planes_kernel<W, true>), dim3(grid), dim3(kBlock), 0, st, (const W *)inter_in, (W *)nullptr, (const W *)nullptr,
                            (const W *)nullptr, (W *)re_out, (W *)im_out, n, vec);

@@ -11,6 +11,8 @@
 //   /comms/abs                                 math/Abs.cpp:66-125
 //   /comms/conjugate                           math/Conjugate.cpp:61-119
 //   /comms/angle  (SURVEY 8f "next")           math/Angle.cpp:50-110
+//   /comms/arithmetic (+ /blocks/arithmetic)   math/Arithmetic.cpp:150-305      (8f "next")
+//   /comms/split_complex, /comms/combine_complex   utility/{Split,Combine}Complex.cpp  (8f "next")
 //
 // The reference instantiates one C++ template per element type; here a block carries a
 // pcx_scalar code instead and the type dispatch happens behind the ABI, so one class per
@@ -19,8 +21,10 @@
 //
 // Built against pcx_framework.hpp: PothosCore when -DPCX_WITH_POTHOS, the bundled runtime
 // otherwise (tests, runner ABI).
+#include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -49,6 +53,23 @@ bool parseElemType(const DType &dt, int &scalar, bool &cplx)
     else if (n == "int8") scalar = PCX_I8;
     else return false;
     return true;
+}
+// the arithmetic factory also takes the unsigned types (Arithmetic.cpp:288-291)
+bool parseArithType(const DType &dt, int &scalar, bool &cplx)
+{
+    if (parseElemType(dt, scalar, cplx)) return true;
+    std::string n = DType::fromDType(dt, 1).name();
+    if (cplx) n = n.substr(8);
+    if (n == "uint64") scalar = PCX_U64;
+    else if (n == "uint32") scalar = PCX_U32;
+    else if (n == "uint16") scalar = PCX_U16;
+    else if (n == "uint8") scalar = PCX_U8;
+    else return false;
+    return true;
+}
+DType complexOf(const DType &dt)
+{
+    return DType("complex_" + DType::fromDType(dt, 1).name(), dt.dimension());
 }
 DType realOf(const DType &dt)
 {
@@ -575,5 +596,164 @@ Block *conjugateFactory(const DType &dtype)
     throw InvalidArgumentException("conjugateFactory(" + dtype.toString() + ")", "unsupported type");
 }
 pcxfw::BlockRegistry registerConjugate("/comms/conjugate", &conjugateFactory);
+
+/***********************************************************************
+ * /comms/arithmetic (+ /blocks/arithmetic)   math/Arithmetic.cpp:150-305   
+ **********************************************************************/
+class Arithmetic : public Block {
+public:
+    Arithmetic(const DType &dtype, int scalar, bool cplx, int op) : _scalar(scalar), _cplx(cplx), _op(op), _numInlineBuffers(0)
+    {
+        this->registerCall(this, PCX_FCN_TUPLE(Arithmetic, setNumInputs));
+        this->registerCall(this, PCX_FCN_TUPLE(Arithmetic, setPreload));
+        this->registerCall(this, PCX_FCN_TUPLE(Arithmetic, preload));
+        this->registerCall(this, PCX_FCN_TUPLE(Arithmetic, getNumInlineBuffers));
+        this->setupInput(0, dtype);
+        this->setupOutput(0, dtype, this->uid());   // unique domain because of inline buffer forwarding
+        this->output(0)->setReadBeforeWrite(this->input(0));
+    }
+    void setNumInputs(const size_t numInputs)
+    {
+        if (numInputs < 2) throw pcxfw::RangeException("Arithmetic::setNumInputs(" + std::to_string(numInputs) + ")", "require inputs >= 2");
+        for (size_t i = this->inputs().size(); i < numInputs; i++) this->setupInput(i, this->input(0)->dtype());
+    }
+    void setPreload(const std::vector<size_t> &preload)
+    {
+        this->setNumInputs(std::max<size_t>(2, preload.size()));
+        _preload = preload;
+    }
+    std::vector<size_t> preload() const { return _preload; }
+    void activate()
+    {
+        // feedback ports start with `preload` zero elements queued (Arithmetic.cpp:190-201)
+        for (size_t i = 0; i < _preload.size(); i++) {
+            const auto bytes = _preload[i] * this->input(i)->dtype().size();
+            if (bytes == 0) continue;
+            BufferChunk buffer(bytes);
+            std::memset(buffer.as<void *>(), 0, buffer.length);
+            this->input(i)->clear();
+            this->input(i)->pushBuffer(buffer);
+        }
+    }
+    void work()
+    {
+        const auto elems = this->workInfo().minElements;
+        if (elems == 0) return;
+        const std::vector<pcxfw::InputPort *> &inputs = this->inputs();
+        auto output = this->output(0);
+        void *out = output->buffer().template as<void *>();
+        const void *in0 = inputs[0]->buffer().template as<const void *>();
+        if (out == in0) _numInlineBuffers++;   // track buffer inlining
+        const size_t N = elems * output->dtype().dimension();
+        // left fold over the ports, the running result living in `out` (Arithmetic.cpp:217-224)
+        for (size_t i = 1; i < inputs.size(); i++) {
+            check(pcx_arith(_scalar, _cplx ? 1 : 0, _op, in0, inputs[i]->buffer().template as<const void *>(), out, N), "Arithmetic::work()");
+            in0 = out;
+            inputs[i]->consume(elems);
+        }
+        inputs[0]->consume(elems);
+        output->produce(elems);
+    }
+    void propagateLabels(const pcxfw::InputPort *port)
+    {
+        // a feedback port: do not propagate labels from it
+        if (_preload.size() > size_t(port->index()) && _preload[port->index()] > 0) return;
+        Block::propagateLabels(port);
+    }
+    size_t getNumInlineBuffers() const { return _numInlineBuffers; }
+
+private:
+    int _scalar;
+    bool _cplx;
+    int _op;
+    size_t _numInlineBuffers;
+    std::vector<size_t> _preload;
+};
+Block *arithmeticFactory(const DType &dtype, const std::string &operation)
+{
+    int scalar;
+    bool cplx;
+    const int op = operation == "ADD" ? PCX_ARITH_ADD : operation == "SUB" ? PCX_ARITH_SUB : operation == "MUL" ? PCX_ARITH_MUL
+                 : operation == "DIV" ? PCX_ARITH_DIV : -1;
+    if (op >= 0 && parseArithType(dtype, scalar, cplx)) return new Arithmetic(dtype, scalar, cplx, op);
+    throw InvalidArgumentException("arithmeticFactory(" + dtype.toString() + ", " + operation + ")", "unsupported args");
+}
+pcxfw::BlockRegistry registerArithmetic("/comms/arithmetic", &arithmeticFactory);
+pcxfw::BlockRegistry registerArithmeticOldPath("/blocks/arithmetic", &arithmeticFactory);
+
+/***********************************************************************
+ * /comms/split_complex, /comms/combine_complex   utility/SplitComplex.cpp:39-77, utility/CombineComplex.cpp:38-76
+ **********************************************************************/
+class SplitComplex : public Block {
+public:
+    SplitComplex(const DType &dtype, int scalar) : _scalar(scalar)
+    {
+        this->setupInput(0, complexOf(dtype));
+        _rePort = this->setupOutput("re", dtype);
+        _imPort = this->setupOutput("im", dtype);
+    }
+    void work()
+    {
+        const auto elems = this->workInfo().minAllElements;
+        if (elems == 0) return;
+        auto inPort = this->input(0);
+        const size_t N = elems * inPort->dtype().dimension();
+        check(pcx_split_complex(_scalar, inPort->buffer().template as<const void *>(), _rePort->buffer().template as<void *>(),
+                                _imPort->buffer().template as<void *>(), N),
+              "SplitComplex::work()");
+        inPort->consume(elems);
+        _rePort->produce(elems);
+        _imPort->produce(elems);
+    }
+
+private:
+    int _scalar;
+    pcxfw::OutputPort *_rePort;
+    pcxfw::OutputPort *_imPort;
+};
+class CombineComplex : public Block {
+public:
+    CombineComplex(const DType &dtype, int scalar) : _scalar(scalar)
+    {
+        _rePort = this->setupInput("re", dtype);
+        _imPort = this->setupInput("im", dtype);
+        this->setupOutput(0, complexOf(dtype));
+    }
+    void work()
+    {
+        const auto elems = this->workInfo().minAllElements;
+        if (elems == 0) return;
+        auto outPort = this->output(0);
+        const size_t N = elems * outPort->dtype().dimension();
+        check(pcx_combine_complex(_scalar, _rePort->buffer().template as<const void *>(), _imPort->buffer().template as<const void *>(),
+                                  outPort->buffer().template as<void *>(), N),
+              "CombineComplex::work()");
+        outPort->produce(elems);
+        _rePort->consume(elems);
+        _imPort->consume(elems);
+    }
+
+private:
+    int _scalar;
+    pcxfw::InputPort *_rePort;
+    pcxfw::InputPort *_imPort;
+};
+// both factories take the REAL element type (splitComplexFactory / combineComplexFactory :60-70)
+Block *splitComplexFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx) && !cplx) return new SplitComplex(dtype, scalar);
+    throw InvalidArgumentException("splitComplexFactory(" + dtype.toString() + ")", "unsupported type");
+}
+Block *combineComplexFactory(const DType &dtype)
+{
+    int scalar;
+    bool cplx;
+    if (parseElemType(dtype, scalar, cplx) && !cplx) return new CombineComplex(dtype, scalar);
+    throw InvalidArgumentException("combineComplexFactory(" + dtype.toString() + ")", "unsupported type");
+}
+pcxfw::BlockRegistry registerSplitComplex("/comms/split_complex", &splitComplexFactory);
+pcxfw::BlockRegistry registerCombineComplex("/comms/combine_complex", &combineComplexFactory);
 
 }  // namespace

@@ -45,6 +45,10 @@ class InvalidArgumentException : public Exception {
 public:
     using Exception::Exception;
 };
+class RangeException : public Exception {
+public:
+    RangeException(const std::string &where, const std::string &what) : Exception(where, what) {}
+};
 class BlockCallNotFound : public Exception {
 public:
     using Exception::Exception;
@@ -118,6 +122,7 @@ public:
     Object(const DType &d) : _t(&typeid(DType)), _i((long long)d.dimension()), _s(d.name()) {}
     Object(const std::vector<double> &v) : _t(&typeid(std::vector<double>)), _vd(v) {}
     Object(const std::vector<std::complex<double>> &v) : _t(&typeid(std::vector<std::complex<double>>)), _vc(v) {}
+    Object(const std::vector<size_t> &v) : _t(&typeid(std::vector<size_t>)), _vs(v) {}
 
     const std::type_info &type() const { return *_t; }
     bool isNumber() const
@@ -136,6 +141,7 @@ public:
         if (toNumber) return isNumber();
         if (to == typeid(DType)) return *_t == typeid(std::string);
         if (to == typeid(std::vector<std::complex<double>>)) return *_t == typeid(std::vector<double>);
+        if (to == typeid(std::vector<size_t>)) return *_t == typeid(std::vector<double>);
         return false;
     }
     template <typename T>
@@ -162,12 +168,18 @@ private:
         if (*_t == typeid(std::vector<double>)) return std::vector<std::complex<double>>(_vd.begin(), _vd.end());
         return _vc;
     }
+    std::vector<size_t> get(std::vector<size_t> *) const
+    {
+        if (*_t == typeid(std::vector<double>)) return std::vector<size_t>(_vd.begin(), _vd.end());
+        return _vs;
+    }
     const std::type_info *_t;
     double _d = 0;
     long long _i = 0;
     std::string _s;
     std::vector<double> _vd;
     std::vector<std::complex<double>> _vc;
+    std::vector<size_t> _vs;
 };
 
 // ---- BufferChunk: a view (optionally owning) of typed memory ----
@@ -183,6 +195,7 @@ public:
         address = reinterpret_cast<size_t>(_own.get());
     }
     BufferChunk(const std::type_info &t, size_t numElems) : BufferChunk(DType(t), numElems) {}
+    explicit BufferChunk(size_t numBytes) : BufferChunk(DType("uint8"), numBytes) {}
     static BufferChunk view(void *p, size_t bytes, const DType &dt)
     {
         BufferChunk b;
@@ -220,7 +233,8 @@ struct Label {
 };
 
 struct WorkInfo {
-    size_t minElements = 0, minInElements = 0, minOutElements = 0;
+    // minElements: over the indexed ports; minAllElements: indexed and named ports alike
+    size_t minElements = 0, minInElements = 0, minOutElements = 0, minAllElements = 0;
 };
 
 struct BufferManagerArgs {
@@ -251,12 +265,20 @@ public:
     void consume(size_t n) { _consumed += n; }
     void setReserve(size_t n) { _reserve = n; _reserveSet = true; }
     const DType &dtype() const { return _dtype; }
+    int index() const { return _index; }            // -1 for a named (non-indexed) port
+    const std::string &name() const { return _name; }
+    // feedback preload (Arithmetic::activate): drop what is queued, queue a caller-made buffer
+    void clear() { _pushed.clear(); }
+    void pushBuffer(const BufferChunk &b) { _pushed.push_back(b); }
     // runtime side
     BufferChunk _buffer;
     std::vector<Label> _labels;
     size_t _consumed = 0, _reserve = 0;
     bool _reserveSet = false;
     DType _dtype;
+    int _index = -1;
+    std::string _name;
+    std::vector<BufferChunk> _pushed;
 };
 class OutputPort {
 public:
@@ -265,10 +287,17 @@ public:
     void produce(size_t n) { _produced += n; }
     void postLabel(const Label &l) { _posted.push_back(l); }
     const DType &dtype() const { return _dtype; }
+    int index() const { return _index; }
+    const std::string &name() const { return _name; }
+    // buffer-inlining hint (Arithmetic ctor): the runner decides whether out aliases that input
+    void setReadBeforeWrite(InputPort *p) { _readBeforeWrite = p; }
     BufferChunk _buffer;
     size_t _produced = 0;
     std::vector<Label> _posted;
     DType _dtype;
+    int _index = -1;
+    std::string _name;
+    InputPort *_readBeforeWrite = nullptr;
 };
 
 // ---- registered calls: name -> type-erased member function ----
@@ -296,8 +325,10 @@ public:
     virtual void deactivate() {}
     virtual void propagateLabels(const InputPort *port)
     {
-        for (const auto &l : port->labels())
+        for (const auto &l : port->labels()) {
             for (auto &o : _outputs) o->postLabel(l);
+            for (auto &o : _namedOutputs) o->postLabel(l);
+        }
     }
     virtual BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return BufferManager::Sptr(); }
     virtual BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return BufferManager::Sptr(); }
@@ -307,17 +338,77 @@ public:
         if (_inputs.size() <= i) _inputs.resize(i + 1);
         _inputs[i].reset(new InputPort());
         _inputs[i]->_dtype = dt;
+        _inputs[i]->_index = (int)i;
+        _inputs[i]->_name = std::to_string(i);
         return _inputs[i].get();
     }
-    OutputPort *setupOutput(size_t i, const DType &dt = DType())
+    OutputPort *setupOutput(size_t i, const DType &dt = DType(), const std::string & /*domain*/ = "")
     {
         if (_outputs.size() <= i) _outputs.resize(i + 1);
         _outputs[i].reset(new OutputPort());
         _outputs[i]->_dtype = dt;
+        _outputs[i]->_index = (int)i;
+        _outputs[i]->_name = std::to_string(i);
         return _outputs[i].get();
+    }
+    // named ports (SplitComplex "re"/"im", CombineComplex): kept behind the indexed ones
+    InputPort *setupInput(const std::string &name, const DType &dt = DType())
+    {
+        _namedInputs.emplace_back(new InputPort());
+        _namedInputs.back()->_dtype = dt;
+        _namedInputs.back()->_name = name;
+        return _namedInputs.back().get();
+    }
+    OutputPort *setupOutput(const std::string &name, const DType &dt = DType(), const std::string & /*domain*/ = "")
+    {
+        _namedOutputs.emplace_back(new OutputPort());
+        _namedOutputs.back()->_dtype = dt;
+        _namedOutputs.back()->_name = name;
+        return _namedOutputs.back().get();
     }
     InputPort *input(size_t i) const { return _inputs.at(i).get(); }
     OutputPort *output(size_t i) const { return _outputs.at(i).get(); }
+    InputPort *input(const std::string &name) const
+    {
+        for (const auto &p : _namedInputs) if (p->name() == name) return p.get();
+        for (const auto &p : _inputs) if (p && p->name() == name) return p.get();
+        throw Exception("Block::input(" + name + ")", "no such port");
+    }
+    OutputPort *output(const std::string &name) const
+    {
+        for (const auto &p : _namedOutputs) if (p->name() == name) return p.get();
+        for (const auto &p : _outputs) if (p && p->name() == name) return p.get();
+        throw Exception("Block::output(" + name + ")", "no such port");
+    }
+    // the indexed ports, in index order (Pothos::Block::inputs())
+    const std::vector<InputPort *> &inputs()
+    {
+        _inputPtrs.clear();
+        for (const auto &p : _inputs) _inputPtrs.push_back(p.get());
+        return _inputPtrs;
+    }
+    const std::vector<OutputPort *> &outputs()
+    {
+        _outputPtrs.clear();
+        for (const auto &p : _outputs) _outputPtrs.push_back(p.get());
+        return _outputPtrs;
+    }
+    // every port, indexed first (runtime side)
+    std::vector<InputPort *> allInputs() const
+    {
+        std::vector<InputPort *> v;
+        for (const auto &p : _inputs) v.push_back(p.get());
+        for (const auto &p : _namedInputs) v.push_back(p.get());
+        return v;
+    }
+    std::vector<OutputPort *> allOutputs() const
+    {
+        std::vector<OutputPort *> v;
+        for (const auto &p : _outputs) v.push_back(p.get());
+        for (const auto &p : _namedOutputs) v.push_back(p.get());
+        return v;
+    }
+    std::string uid() const { return "pcx-" + std::to_string(reinterpret_cast<size_t>(this)); }
     const WorkInfo &workInfo() const { return _workInfo; }
     WorkInfo &workInfoMutable() { return _workInfo; }
 
@@ -343,8 +434,10 @@ public:
     bool hasCall(const std::string &name) const { return _calls.count(name) != 0; }
 
 private:
-    std::vector<std::unique_ptr<InputPort>> _inputs;
-    std::vector<std::unique_ptr<OutputPort>> _outputs;
+    std::vector<std::unique_ptr<InputPort>> _inputs, _namedInputs;
+    std::vector<std::unique_ptr<OutputPort>> _outputs, _namedOutputs;
+    std::vector<InputPort *> _inputPtrs;
+    std::vector<OutputPort *> _outputPtrs;
     WorkInfo _workInfo;
     std::map<std::string, std::function<Object(const std::vector<Object> &)>> _calls;
 };

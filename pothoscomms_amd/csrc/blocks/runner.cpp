@@ -84,11 +84,12 @@ int pcxb_make(const char *path, const char *dtype, size_t dimension, const char 
         const std::string p(path);
         const DType dt(std::string(dtype), dimension ? dimension : 1);
         std::vector<Object> args{Object(dt)};
-        if (p == "/comms/fir_filter" || p == "/blocks/fir_filter") args.push_back(Object(std::string(sarg ? sarg : "")));
+        if (p == "/comms/fir_filter" || p == "/blocks/fir_filter" || p == "/comms/arithmetic" || p == "/blocks/arithmetic")
+            args.push_back(Object(std::string(sarg ? sarg : "")));
         else if (p == "/comms/fft") { args.push_back(Object((unsigned long)num_bins)); args.push_back(Object(inverse != 0)); }
         std::unique_ptr<pcxb_block> b(new pcxb_block());
         b->blk.reset(BlockRegistry::make(p, args));
-        if (b->blk->input(0)->_reserveSet) b->initialReserve = b->blk->input(0)->_reserve;
+        if (!b->blk->inputs().empty() && b->blk->input(0)->_reserveSet) b->initialReserve = b->blk->input(0)->_reserve;
         *out = b.release();
     });
 }
@@ -108,6 +109,18 @@ int pcxb_call_taps(pcxb_block *b, const char *name, const double *taps, size_t n
         } else {
             b->blk->call(name, {Object(std::vector<double>(taps, taps + n))});
         }
+    });
+}
+int pcxb_call_sizes(pcxb_block *b, const char *name, const size_t *v, size_t n)
+{
+    return guarded([&] { b->blk->call(name, {Object(std::vector<size_t>(v, v + n))}); });
+}
+int pcxb_get_sizes(pcxb_block *b, const char *name, size_t *out, size_t cap, size_t *n)
+{
+    return guarded([&] {
+        const auto v = b->blk->call(name).convert<std::vector<size_t>>();
+        *n = v.size();
+        for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
     });
 }
 int pcxb_get_double(pcxb_block *b, const char *name, double *out) { return guarded([&] { *out = b->blk->call(name).convert<double>(); }); }
@@ -134,7 +147,7 @@ int pcxb_activate(pcxb_block *b) { return guarded([&] { b->blk->activate(); }); 
 int pcxb_port_dtype(pcxb_block *b, int is_output, char *name, size_t cap, size_t *dimension, size_t *bytes)
 {
     return guarded([&] {
-        const DType &dt = is_output ? b->blk->output(0)->dtype() : b->blk->input(0)->dtype();
+        const DType &dt = is_output ? b->blk->allOutputs().at(0)->dtype() : b->blk->allInputs().at(0)->dtype();   // first port, indexed or named
         std::snprintf(name, cap, "%s", dt.name().c_str());
         if (dimension) *dimension = dt.dimension();
         if (bytes) *bytes = dt.size();
@@ -178,6 +191,69 @@ int pcxb_work(pcxb_block *b, const void *in, size_t in_elems, const pcxb_label *
         size_t n = 0;
         for (const auto &l : op->_posted) { if (n < cap && posted) fromLabel(l, posted[n]); n++; }
         if (nposted) *nposted = n;
+    });
+}
+
+int pcxb_num_ports(pcxb_block *b, int is_output, size_t *count)
+{
+    return guarded([&] { *count = is_output ? b->blk->allOutputs().size() : b->blk->allInputs().size(); });
+}
+int pcxb_port_info(pcxb_block *b, int is_output, size_t i, char *name, size_t name_cap, char *dtype, size_t dtype_cap,
+                   size_t *dimension, size_t *bytes, size_t *preloaded)
+{
+    return guarded([&] {
+        DType dt;
+        std::string nm;
+        size_t pre = 0;
+        if (is_output) {
+            OutputPort *p = b->blk->allOutputs().at(i);
+            dt = p->dtype(); nm = p->name();
+        } else {
+            InputPort *p = b->blk->allInputs().at(i);
+            dt = p->dtype(); nm = p->name();
+            for (const auto &c : p->_pushed) pre += c.length / dt.size();
+        }
+        if (name) std::snprintf(name, name_cap, "%s", nm.c_str());
+        if (dtype) std::snprintf(dtype, dtype_cap, "%s", dt.name().c_str());
+        if (dimension) *dimension = dt.dimension();
+        if (bytes) *bytes = dt.size();
+        if (preloaded) *preloaded = pre;
+    });
+}
+int pcxb_work_ports(pcxb_block *b, size_t nin, const void *const *ins, const size_t *in_elems, size_t nout, void *const *outs,
+                    const size_t *out_elems, size_t *consumed, size_t *produced)
+{
+    return guarded([&] {
+        const auto ips = b->blk->allInputs();
+        const auto ops = b->blk->allOutputs();
+        if (ips.size() != nin || ops.size() != nout) throw pcxfw::Exception("pcxb_work_ports()", "port count mismatch");
+        const size_t none = std::numeric_limits<size_t>::max();
+        size_t minIn = none, minOut = none, minAll = none;
+        for (size_t i = 0; i < nin; i++) {
+            InputPort *ip = ips[i];
+            ip->_buffer = BufferChunk::view(const_cast<void *>(ins[i]), in_elems[i] * ip->dtype().size(), ip->dtype());
+            ip->_labels.clear();
+            ip->_consumed = 0; ip->_reserveSet = false; ip->_reserve = 0;
+            if (ip->index() >= 0) minIn = std::min(minIn, in_elems[i]);
+            minAll = std::min(minAll, in_elems[i]);
+        }
+        for (size_t i = 0; i < nout; i++) {
+            OutputPort *op = ops[i];
+            op->_buffer = BufferChunk::view(outs[i], out_elems[i] * op->dtype().size(), op->dtype());
+            op->_produced = 0; op->_posted.clear();
+            if (op->index() >= 0) minOut = std::min(minOut, out_elems[i]);
+            minAll = std::min(minAll, out_elems[i]);
+        }
+        WorkInfo &wi = b->blk->workInfoMutable();
+        wi.minInElements = minIn == none ? 0 : minIn;
+        wi.minOutElements = minOut == none ? 0 : minOut;
+        // minElements spans the indexed ports only; a side without indexed ports does not bound it
+        const size_t me = std::min(minIn, minOut);
+        wi.minElements = me == none ? 0 : me;
+        wi.minAllElements = minAll == none ? 0 : minAll;
+        b->blk->work();
+        for (size_t i = 0; i < nin; i++) consumed[i] = ips[i]->_consumed;
+        for (size_t i = 0; i < nout; i++) produced[i] = ops[i]->_produced;
     });
 }
 

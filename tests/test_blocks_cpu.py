@@ -13,7 +13,9 @@ def test_registry_paths_match_the_reference():
     """FIRFilter.cpp:385-389, FFT.cpp:94-95, FreqDemod.cpp:94-95, Rotate.cpp:159-160, Scale.cpp:159-160,
     Abs.cpp:124-125, Conjugate.cpp:118-119"""
     assert B.registry_paths() == sorted(["/blocks/fir_filter", "/comms/abs", "/comms/angle", "/comms/conjugate", "/comms/fft",
-                                         "/comms/fir_filter", "/comms/freq_demod", "/comms/rotate", "/comms/scale"])
+                                         "/comms/fir_filter", "/comms/freq_demod", "/comms/rotate", "/comms/scale",
+                                         # SURVEY 8f rank 3: Arithmetic.cpp:300-304, SplitComplex.cpp:72-73, CombineComplex.cpp:71-72
+                                         "/blocks/arithmetic", "/comms/arithmetic", "/comms/split_complex", "/comms/combine_complex"])
     with pytest.raises(ValueError):
         B.make("/comms/does_not_exist", "float32")
 
@@ -126,3 +128,64 @@ def test_rotate_scale_registered_calls():
     # nothing to do: minElements == 0 returns before any device call
     _, c, p, _, _ = s.work(np.zeros(0, np.float32), 10)
     assert (c, p) == (0, 0)
+
+
+# ---- /comms/arithmetic, /comms/split_complex, /comms/combine_complex (host logic) ------------
+ARITH_TYPES = ALL + ["uint64", "uint32", "uint16", "uint8"]
+
+
+@pytest.mark.parametrize("t", ARITH_TYPES)
+def test_arithmetic_factory_matrix(t):
+    """arithmeticFactory (Arithmetic.cpp:279-297): 10 scalar types x real/complex x ADD/SUB/MUL/DIV."""
+    for dtype in (t, "complex_" + t):
+        for op in ("ADD", "SUB", "MUL", "DIV"):
+            blk = B.make("/comms/arithmetic", dtype, op)
+            assert (blk.in_dtype, blk.out_dtype) == (dtype, dtype)
+            assert [p[0] for p in blk.ports(0)] == ["0"] and [p[0] for p in blk.ports(1)] == ["0"]
+        with pytest.raises(ValueError, match="unsupported args"):
+            B.make("/comms/arithmetic", dtype, "POW")
+    assert B.make("/blocks/arithmetic", "float32", "ADD").in_dtype == "float32"
+
+
+def test_arithmetic_ports_and_preload():
+    blk = B.make("/comms/arithmetic", "complex_float32", "ADD")
+    with pytest.raises(B._lib.PcxError, match="require inputs >= 2"):
+        blk.call("setNumInputs", 1)
+    blk.call("setNumInputs", 4)
+    assert [p[:2] for p in blk.ports(0)] == [(str(k), "complex_float32") for k in range(4)]
+    blk.call("setNumInputs", 2)                      # never removes ports (Arithmetic.cpp:174-180)
+    assert len(blk.ports(0)) == 4
+    fb = B.make("/comms/arithmetic", "int16", "ADD")
+    fb.call("setPreload", [0, 5])                    # feedback on port 1: five zero elements queued at activate()
+    assert fb.call("preload") == [0, 5] and len(fb.ports(0)) == 2
+    assert [p[4] for p in fb.ports(0)] == [0, 0]
+    fb.activate()
+    assert [p[4] for p in fb.ports(0)] == [0, 5]
+    fb.activate()                                    # clear() + pushBuffer(): not cumulative
+    assert [p[4] for p in fb.ports(0)] == [0, 5]
+    fb3 = B.make("/comms/arithmetic", "int16", "ADD")
+    fb3.call("setPreload", [1, 2, 3])                # setPreload grows the port list (:184-187)
+    assert len(fb3.ports(0)) == 3
+    # nothing to do: returns before touching the device, nothing consumed or produced
+    outs, cons, prod = fb.work_ports([np.zeros(0, np.int16), np.zeros(8, np.int16)], 8)
+    assert cons == [0, 0] and prod == [0]
+    assert fb.call("getNumInlineBuffers") == 0
+
+
+@pytest.mark.parametrize("t", ALL)
+def test_split_combine_factories(t):
+    """both factories take the REAL element type; ports are named (SplitComplex.cpp:42-46, CombineComplex.cpp:41-45)"""
+    sp = B.make("/comms/split_complex", t)
+    assert [p[:2] for p in sp.ports(0)] == [("0", "complex_" + t)]
+    assert [p[:2] for p in sp.ports(1)] == [("re", t), ("im", t)]
+    cb = B.make("/comms/combine_complex", t)
+    assert [p[:2] for p in cb.ports(0)] == [("re", t), ("im", t)]
+    assert [p[:2] for p in cb.ports(1)] == [("0", "complex_" + t)]
+    for path in ("/comms/split_complex", "/comms/combine_complex"):
+        with pytest.raises(ValueError, match="unsupported type"):
+            B.make(path, "complex_" + t)
+        with pytest.raises(ValueError):
+            B.make(path, "uint8")
+    # minAllElements = 0 -> no device call
+    outs, cons, prod = sp.work_ports([np.zeros((4, 2), np.dtype(t))], [4, 0])
+    assert cons == [0] and prod == [0, 0]

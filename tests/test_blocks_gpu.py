@@ -152,3 +152,65 @@ def test_abs_conjugate_freqdemod_blocks(oracle, scalar):
             assert np.array_equal(y, want)
     fd.activate(); ref.activate()
     assert ang_err(fd.work(x[:10], 10)[0].astype(np.float64), ref.work(x[:10]).astype(np.float64)) <= TOL or scalar > 1
+
+
+# ---- /comms/arithmetic, split_complex, combine_complex blocks ---------------------------------
+@pytest.mark.parametrize("dtype", ["complex_float32", "int16", "complex_int8", "uint32", "float64"])
+@pytest.mark.parametrize("op", ["ADD", "SUB", "MUL", "DIV"])
+def test_arithmetic_block_folds_ports(oracle, dtype, op):
+    """out = in0 OP in1 OP in2 (Arithmetic.cpp:217-224); every port consumes minElements."""
+    from pothoscomms_amd.device import parse_dtype, NP_SCALAR
+    scalar, cplx = parse_dtype(dtype)
+    dt = np.dtype(NP_SCALAR[scalar])
+    rng = np.random.default_rng(3)
+    shape = lambda n: (n, 2) if cplx else (n,)
+    def operand(n, divisor):
+        if dt.kind == "f":
+            return (rng.standard_normal(shape(n)) * 10 + (20 if divisor else 0)).astype(dt)
+        lo, hi = (1, 9) if dt.kind == "u" or not divisor else (-9, 9)
+        if divisor:
+            v = rng.integers(lo, hi, size=shape(n), endpoint=True)
+            return np.where(v == 0, 3, v).astype(dt)
+        info = np.iinfo(dt)
+        return (rng.integers(info.min, info.max, size=shape(n), dtype=dt, endpoint=True) // 4).astype(dt)
+    blk = B.make("/comms/arithmetic", dtype, op)
+    blk.call("setNumInputs", 3)
+    blk.activate()
+    ins = [operand(1000, False), operand(700, op == "DIV"), operand(900, op == "DIV")]
+    outs, cons, prod = blk.work_ports(ins, 800)
+    assert cons == [700, 700, 700] and prod == [700]
+    o = getattr(oracle, op)
+    ref = oracle.arith(o, oracle.arith(o, ins[0][:700], ins[1][:700], cplx), ins[2][:700], cplx)
+    assert np.array_equal(outs[0].view(np.uint8), ref.view(np.uint8))
+    assert blk.call("getNumInlineBuffers") == 0
+    # the framework may forward input 0's buffer as the output buffer (setReadBeforeWrite): same result in place
+    a0 = ins[0][:700].copy()
+    outs, cons, prod = blk.work_ports([a0, ins[1], ins[2]], 700, inline=True)
+    assert np.array_equal(outs[0].view(np.uint8), ref.view(np.uint8)) and blk.call("getNumInlineBuffers") == 1
+
+
+def test_arithmetic_block_vector_dimension(oracle):
+    blk = B.make("/comms/arithmetic", "float32", "MUL", dimension=4)
+    rng = np.random.default_rng(5)
+    a, b = rng.standard_normal(4 * 50).astype(np.float32), rng.standard_normal(4 * 60).astype(np.float32)
+    blk.call("setNumInputs", 2)
+    outs, cons, prod = blk.work_ports([a, b], 64)
+    assert cons == [50, 50] and prod == [50]
+    assert np.array_equal(outs[0], oracle.arith(oracle.MUL, a, b[:200], False))
+
+
+@pytest.mark.parametrize("t", ["float32", "int16", "float64", "int8"])
+def test_split_combine_blocks(oracle, t):
+    """utility/TestComplex.cpp:13-60: combine -> split returns both planes."""
+    dt = np.dtype(t)
+    rng = np.random.default_rng(6)
+    re, im = (rng.standard_normal(300) * 50).astype(dt), (rng.standard_normal(260) * 50).astype(dt)
+    cb = B.make("/comms/combine_complex", t)
+    outs, cons, prod = cb.work_ports([re, im], 280)
+    assert cons == [260, 260] and prod == [260]
+    z = outs[0]
+    assert np.array_equal(z, oracle.combine_complex(re[:260], im[:260]))
+    sp = B.make("/comms/split_complex", t)
+    outs, cons, prod = sp.work_ports([z], [300, 250])
+    assert cons == [250] and prod == [250, 250]
+    assert np.array_equal(outs[0], re[:250]) and np.array_equal(outs[1], im[:250])

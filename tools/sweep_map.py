@@ -17,6 +17,12 @@ cases = [
     ("angle", lambda: device.angle(x, scalar=device.F32, out=yr, n=n), 12),
     ("freq_demod", lambda: fd.process_dev(x, yr, n), 12),
 ]
+x2 = torch.empty((n, 2), dtype=torch.float32, device=d); device.fill_uniform_f32_dev(x2, seed=2); x2 += 2.0
+yr2 = torch.empty((n,), dtype=torch.float32, device=d)
+for op in ("ADD", "MUL", "DIV"):
+    cases.append(("arith " + op, (lambda op=op: device.arith(op, x, x2, True, scalar=device.F32, out=yc, n=n)), 24))
+cases.append(("split", lambda: device.split_complex(x, scalar=device.F32, re=yr, im=yr2, n=n), 16))
+cases.append(("combine", lambda: device.combine_complex(yr, yr2, scalar=device.F32, out=yc, n=n), 16))
 for name, fn, bytes_per in cases:
     for _ in range(100): fn()
     torch.cuda.synchronize()

@@ -198,7 +198,9 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     if (nfull < first_full) nfull = first_full;
     const float2 *pi = (const float2 *)in, *ph = (const float2 *)Hspec, *pt = (const float2 *)tw4096;
     float2 *po = (float2 *)out;
-    const unsigned g4 = persistent_grid(nblocks, 1024), g3 = persistent_grid(nblocks, 768);
+    // PCX_OLS_SLOTS (diagnostic): resident workgroups to use chip-wide (default 1024 = 4 per CU)
+    static const unsigned slots = [] { const char *e = getenv("PCX_OLS_SLOTS"); return e ? (unsigned)atoi(e) : 1024u; }();
+    const unsigned g4 = persistent_grid(nblocks, slots), g3 = persistent_grid(nblocks, 768);
     const unsigned gx = 8 * persistent_grid((nblocks + 7) / 8, 128);   // XCD-aware walk: equal rounds inside every XCD's eighth
 #define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks)
     switch (variant) {

@@ -221,43 +221,48 @@ struct Q15Plan {
 // kf_work's recursion (kiss_fft.c:237-302) unrolled: a digit-reversing gather (the
 // m==1 leaves, :276-280) followed by the butterfly passes bottom-up.  Butterflies of
 // one pass are independent, so running them in parallel leaves every rounding as is.
-__global__ __launch_bounds__(256) void fft_q15_kernel(const K16 *__restrict__ in, K16 *__restrict__ out, int N,
-                                                      size_t nframes, const K16 *__restrict__ tw, Q15Plan plan, int inverse)
+// Every radix is 2 or 4, so m and fstride are powers of two (shifts and masks, no division); the
+// gather order is a host-made table (`perm`, numBins entries) and the Q15 twiddles sit in LDS next
+// to the frame.  FPW frames share a workgroup when numBins is small.
+__global__ __launch_bounds__(256) void fft_q15_kernel(const K16 *__restrict__ in, K16 *__restrict__ out, int N, int log2N,
+                                                      size_t nframes, const K16 *__restrict__ tw, const unsigned short *__restrict__ perm,
+                                                      Q15Plan plan, int inverse, int fpw, int stage_tw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    K16 *buf = reinterpret_cast<K16 *>(smem_raw);
-    const int nt = blockDim.x;
-    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+    K16 *twstage = reinterpret_cast<K16 *>(smem_raw);      // N twiddles (when they fit beside the frames)
+    K16 *bufs = twstage + (stage_tw ? N : 0);              // fpw frames
+    const K16 *twl = stage_tw ? twstage : tw;
+    const int nt = blockDim.x / fpw;                       // lanes per frame
+    const int fl = threadIdx.x / nt, t = threadIdx.x % nt; // frame slot, lane within the frame
+    K16 *buf = bufs + (size_t)fl * N;
+    if (stage_tw)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) twstage[i] = tw[i];
+    const size_t ngroups = (nframes + fpw - 1) / fpw;
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const size_t f = g * fpw + fl;
+        const bool live = f < nframes;
         const K16 *src = in + f * (size_t)N;
         __syncthreads();
-        // leaf gather: output position pos = sum_s q_s * m_s  <-  input index sum_s q_s * fstride_s
-        for (int pos = threadIdx.x; pos < N; pos += nt) {
-            int rem = pos, m = N, fstride = 1, idx = 0;
-            for (int s = 0; s < plan.nstages; s++) {
-                const int p = plan.radix[s];
-                m /= p;
-                const int q = rem / m;
-                rem -= q * m;
-                idx += q * fstride;
-                fstride *= p;
-            }
-            buf[pos] = src[idx];
-        }
+        if (live)
+            for (int pos = t; pos < N; pos += nt) buf[pos] = src[perm[pos]];
         __syncthreads();
         // butterfly passes, bottom (m = 1) to top (m = N/p0)
-        int m = 1;
+        int lm = 0;   // log2(m)
         for (int s = plan.nstages - 1; s >= 0; s--) {
             const int p = plan.radix[s];
-            const int fstride = N / (p * m);
-            const int nb = N / p;  // butterflies this pass
-            for (int b = threadIdx.x; b < nb; b += nt) {
-                const int k = b % m, g = b / m;
-                K16 *F = buf + g * (p * m) + k;
+            const int lp = p == 4 ? 2 : 1;
+            const int m = 1 << lm;
+            const int lfs = log2N - lp - lm;   // log2(fstride), fstride = N / (p*m)
+            const int nb = N >> lp;            // butterflies this pass
+            if (live)
+            for (int b = t; b < nb; b += nt) {
+                const int k = b & (m - 1), gq = b >> lm;
+                K16 *F = buf + (gq << (lp + lm)) + k;
                 if (p == 4) {  // kf_bfly4, kiss_fft.c:44-90
                     K16 f0 = k16_fixdiv(F[0], 8191), f1 = k16_fixdiv(F[m], 8191), f2 = k16_fixdiv(F[2 * m], 8191), f3 = k16_fixdiv(F[3 * m], 8191);
-                    const K16 s0 = k16_mul(f1, tw[k * fstride]);
-                    const K16 s1 = k16_mul(f2, tw[k * fstride * 2]);
-                    const K16 s2 = k16_mul(f3, tw[k * fstride * 3]);
+                    const K16 s0 = k16_mul(f1, twl[k << lfs]);
+                    const K16 s1 = k16_mul(f2, twl[(k << lfs) * 2]);
+                    const K16 s2 = k16_mul(f3, twl[(k << lfs) * 3]);
                     const K16 s5 = k16_sub(f0, s1);
                     f0 = k16_add(f0, s1);
                     const K16 s3 = k16_add(s0, s2);
@@ -273,20 +278,22 @@ __global__ __launch_bounds__(256) void fft_q15_kernel(const K16 *__restrict__ in
                     }
                 } else {  // p == 2: kf_bfly2, kiss_fft.c:21-42
                     const K16 f0 = k16_fixdiv(F[0], 16383), f1 = k16_fixdiv(F[m], 16383);
-                    const K16 t = k16_mul(f1, tw[k * fstride]);
-                    F[m] = k16_sub(f0, t);
-                    F[0] = k16_add(f0, t);
+                    const K16 tt = k16_mul(f1, twl[k << lfs]);
+                    F[m] = k16_sub(f0, tt);
+                    F[0] = k16_add(f0, tt);
                 }
             }
             __syncthreads();
-            m *= p;
+            lm += lp;
         }
-        K16 *dst = out + f * (size_t)N;
-        for (int i = threadIdx.x; i < N; i += nt) dst[i] = buf[i];
+        if (live) {
+            K16 *dst = out + f * (size_t)N;
+            for (int i = t; i < N; i += nt) dst[i] = buf[i];
+        }
     }
 }
 
-int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
+int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *perm,
                    const int *radix_host, int nstages, hipStream_t st)
 {
     if (nframes == 0) return PCX_OK;
@@ -300,15 +307,25 @@ int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool
         }
         plan.radix[s] = radix_host[s];
     }
-    const size_t lds = nbins * sizeof(K16);
+    int log2n = 0;
+    while (((size_t)1 << log2n) < nbins) log2n++;
+    // lanes per frame: one per radix-4 butterfly, at least 16; frames per workgroup fill 256 lanes
+    unsigned lanes = (unsigned)(nbins / 4);
+    if (lanes < 16) lanes = 16;
+    if (lanes > 256) lanes = 256;
+    const unsigned fpw = 256 / lanes;
+    size_t lds = nbins * sizeof(K16) * (1 + fpw);            // twiddles + fpw frames
+    const int stage_tw = lds <= 160 * 1024;
+    if (!stage_tw) lds = nbins * sizeof(K16) * fpw;          // largest sizes: twiddles stay in L2
     if (lds > 160 * 1024) { set_error("fft(int16): numBins %zu exceeds LDS", nbins); return PCX_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fft_q15_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    unsigned threads = (unsigned)(nbins / 4);
-    if (threads < 64) threads = 64;
-    if (threads > 256) threads = 256;
-    const unsigned grid = (unsigned)(nframes < 4096 ? nframes : 4096);
-    hipLaunchKernelGGL(fft_q15_kernel, dim3(grid), dim3(threads), lds, st, (const K16 *)in, (K16 *)out, (int)nbins, nframes,
-                       (const K16 *)tw, plan, inverse ? 1 : 0);
+    const size_t ngroups = (nframes + fpw - 1) / fpw;
+    unsigned per_cu = (unsigned)(160 * 1024 / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
+    hipLaunchKernelGGL(fft_q15_kernel, dim3(grid), dim3(lanes * fpw), lds, st, (const K16 *)in, (K16 *)out, (int)nbins, log2n, nframes,
+                       (const K16 *)tw, (const unsigned short *)perm, plan, inverse ? 1 : 0, (int)fpw, stage_tw);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

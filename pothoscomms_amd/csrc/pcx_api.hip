@@ -501,7 +501,7 @@ struct pcx_fft {
     int inverse = 0;
     enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED } kind = MIXED;
     int log2n = 0;
-    DevBuf tw, wsIn, wsOut;
+    DevBuf tw, perm, wsIn, wsOut;
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
 };
 
@@ -572,6 +572,23 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
             t[2 * i + 1] = (int16_t)std::floor(.5 + 32767 * std::sin(phase));
         }
         rc = upload(h->tw, t);
+        if (rc == PCX_OK && pow2 && num_bins <= 65536) {
+            // the leaf gather of kf_work (kiss_fft.c:276-280): position sum q_s*m_s <- input index sum q_s*fstride_s
+            std::vector<uint16_t> perm(num_bins);
+            for (size_t pos = 0; pos < num_bins; pos++) {
+                size_t rem = pos, m = num_bins, fstride = 1, idx = 0;
+                for (size_t si = 0; si < h->radix.size(); si++) {
+                    const size_t p = (size_t)h->radix[si];
+                    m /= p;
+                    const size_t q = rem / m;
+                    rem -= q * m;
+                    idx += q * fstride;
+                    fstride *= p;
+                }
+                perm[pos] = (uint16_t)idx;
+            }
+            rc = upload(h->perm, perm);
+        }
     }
     if (rc != PCX_OK) { delete h; return rc; }
     *out = h;
@@ -596,7 +613,7 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         return h->scalar == PCX_F32 ? launch_fft_pow2_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st)
                                     : launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
     case pcx_fft::Q15_POW2:
-        return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
+        return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     case pcx_fft::MIXED:
         return launch_fft_mixed(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
     }

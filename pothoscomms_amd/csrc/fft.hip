@@ -293,6 +293,155 @@ __global__ __launch_bounds__(256) void fft_q15_kernel(const K16 *__restrict__ in
     }
 }
 
+// --------------------------------------------------------------------------------- //
+// complex_int16, numBins = 4^s (16 ... 16384): the same passes with TWO radix-4 stages fused per
+// trip through LDS.  A lane holds 16 elements of a frame in registers; for the pair of stages with
+// butterfly strides m and 4m (m = 16^p) those are positions G*16m + k + j*m, j = 0..15: stage m
+// runs its four butterflies on j = 4a + {0,1,2,3}, stage 4m on j = b + {0,4,8,12} -- every operand
+// of both stages is in the lane, and each butterfly is kf_bfly4 (kiss_fft.c:44-90) with its own
+// FIXDIV / sround sequence, so the result is the reference's bit for bit.  When log4(numBins) is
+// odd one single radix-4 pass follows (stride numBins/4, elements t + j*T).  The digit-reversing
+// leaf gather goes straight from global memory into the registers of the first pair, the last
+// pair's results are stored straight to global memory (lane-contiguous): 2 LDS round trips for
+// 4096 bins instead of 6 passes plus a gather.  LDS image padded i + i/16.
+// --------------------------------------------------------------------------------- //
+__device__ __forceinline__ void k16_bfly4(K16 &f0, K16 &f1, K16 &f2, K16 &f3, K16 w1, K16 w2, K16 w3, int inverse)
+{
+    f0 = k16_fixdiv(f0, 8191); f1 = k16_fixdiv(f1, 8191); f2 = k16_fixdiv(f2, 8191); f3 = k16_fixdiv(f3, 8191);
+    const K16 s0 = k16_mul(f1, w1);
+    const K16 s1 = k16_mul(f2, w2);
+    const K16 s2 = k16_mul(f3, w3);
+    const K16 s5 = k16_sub(f0, s1);
+    f0 = k16_add(f0, s1);
+    const K16 s3 = k16_add(s0, s2);
+    const K16 s4 = k16_sub(s0, s2);
+    f2 = k16_sub(f0, s3);
+    f0 = k16_add(f0, s3);
+    if (inverse) {
+        f1 = {(int16_t)(s5.r - s4.i), (int16_t)(s5.i + s4.r)};
+        f3 = {(int16_t)(s5.r + s4.i), (int16_t)(s5.i - s4.r)};
+    } else {
+        f1 = {(int16_t)(s5.r + s4.i), (int16_t)(s5.i - s4.r)};
+        f3 = {(int16_t)(s5.r - s4.i), (int16_t)(s5.i + s4.r)};
+    }
+}
+
+template <int LOG2N>
+struct Q15R16 {
+    static constexpr int N = 1 << LOG2N;
+    static constexpr int T = N / 16;                      // lanes per frame
+    static constexpr int THREADS = T < 256 ? 256 : T;
+    static constexpr int FPW = THREADS / T;               // frames per workgroup
+    static constexpr int NF = LOG2N / 4;                  // fused stage pairs
+    static constexpr bool TAIL = (LOG2N % 4) == 2;        // one more single radix-4 pass
+    static constexpr int IMG = N + N / 16;                // padded frame image (elements)
+    static constexpr size_t LDS = ((size_t)N + (size_t)FPW * IMG) * sizeof(K16);
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(Q15R16<LOG2N>::THREADS) void fft_q15_r16_kernel(const K16 *__restrict__ in, K16 *__restrict__ out, size_t nframes,
+                                                                           const K16 *__restrict__ tw, const unsigned short *__restrict__ perm,
+                                                                           int inverse)
+{
+    typedef Q15R16<LOG2N> P;
+    constexpr int N = P::N, T = P::T, FPW = P::FPW, NF = P::NF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    K16 *twl = reinterpret_cast<K16 *>(smem_raw);
+    const int fl = threadIdx.x / T, t = threadIdx.x % T;
+    K16 *img = twl + N + (size_t)fl * P::IMG;
+    for (int i = threadIdx.x; i < N; i += P::THREADS) twl[i] = tw[i];
+    // the lane's 16 leaf positions 16t .. 16t+15 and where they come from
+    unsigned short src_idx[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) src_idx[j] = perm[16 * t + j];
+    __syncthreads();
+    const size_t ngroups = (nframes + FPW - 1) / FPW;
+    for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const size_t f = g * FPW + fl;
+        const bool live = f < nframes;
+        const K16 *src = in + (live ? f : 0) * (size_t)N;
+        K16 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = src[src_idx[j]];
+#pragma unroll
+        for (int p = 0; p < NF; p++) {
+            const int lm = 4 * p, m = 1 << lm;
+            const int G = t >> lm, k = t & (m - 1);
+            if (p > 0) {
+                // hand-over: previous pair's positions -> this pair's positions (in place, padded image)
+                const int lmp = lm - 4, mp = 1 << lmp;
+                const int bp = ((t >> lmp) << (lmp + 4)) + (t & (mp - 1));
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 16; j++) { const int pos = bp + (j << lmp); img[pos + (pos >> 4)] = v[j]; }
+                __syncthreads();
+                const int b0 = (G << (lm + 4)) + k;
+#pragma unroll
+                for (int j = 0; j < 16; j++) { const int pos = b0 + (j << lm); v[j] = img[pos + (pos >> 4)]; }
+            }
+            // stage m: butterflies (g = 4G + a, k), twiddles tw[k * fstride * r], fstride = N / (4m)
+            {
+                const int ti = k << (LOG2N - lm - 2);
+                const K16 w1 = twl[ti], w2 = twl[2 * ti], w3 = twl[3 * ti];
+#pragma unroll
+                for (int a = 0; a < 4; a++) k16_bfly4(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], w1, w2, w3, inverse);
+            }
+            // stage 4m: butterflies (g = G, k + b*m), fstride = N / (16m)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int ti = (k + b * m) << (LOG2N - lm - 4);
+                k16_bfly4(v[b], v[b + 4], v[b + 8], v[b + 12], twl[ti], twl[2 * ti], twl[3 * ti], inverse);
+            }
+        }
+        if (P::TAIL) {
+            // last pair's positions -> t + j*T; butterflies k = t + b*T of the stride-N/4 stage (fstride 1)
+            constexpr int lmp = 4 * (NF - 1), mp = 1 << lmp;
+            const int bp = ((t >> lmp) << (lmp + 4)) + (t & (mp - 1));
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const int pos = bp + (j << lmp); img[pos + (pos >> 4)] = v[j]; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const int pos = t + j * T; v[j] = img[pos + (pos >> 4)]; }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int ti = t + b * T;
+                k16_bfly4(v[b], v[b + 4], v[b + 8], v[b + 12], twl[ti], twl[2 * ti], twl[3 * ti], inverse);
+            }
+        }
+        if (live) {
+            K16 *dst = out + f * (size_t)N;
+            if (P::TAIL) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) dst[t + j * T] = v[j];
+            } else {
+                constexpr int lm = 4 * (NF - 1);
+                const int b0 = ((t >> lm) << (lm + 4)) + (t & ((1 << lm) - 1));
+#pragma unroll
+                for (int j = 0; j < 16; j++) dst[b0 + (j << lm)] = v[j];
+            }
+        }
+    }
+}
+
+template <int LOG2N>
+static int launch_q15_r16(const void *in, void *out, size_t nframes, bool inverse, const void *tw, const void *perm, hipStream_t st)
+{
+    typedef Q15R16<LOG2N> P;
+    auto k = fft_q15_r16_kernel<LOG2N>;
+    if (P::LDS > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS));
+    const size_t ngroups = (nframes + P::FPW - 1) / P::FPW;
+    unsigned per_cu = (unsigned)(160 * 1024 / P::LDS);
+    const unsigned by_threads = 2048 / P::THREADS;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    hipLaunchKernelGGL(k, dim3(persistent_grid(ngroups, 256 * per_cu)), dim3(P::THREADS), P::LDS, st, (const K16 *)in, (K16 *)out, nframes,
+                       (const K16 *)tw, (const unsigned short *)perm, inverse ? 1 : 0);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *perm,
                    const int *radix_host, int nstages, hipStream_t st)
 {
@@ -309,6 +458,18 @@ int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool
     }
     int log2n = 0;
     while (((size_t)1 << log2n) < nbins) log2n++;
+    // pure radix-4 plans (numBins = 4^s) take the fused-pair kernel; PCX_FFT_Q15_PASSES=1 keeps the pass kernel (A/B)
+    static const int passes_only = [] { const char *e = getenv("PCX_FFT_Q15_PASSES"); return e ? atoi(e) : 0; }();
+    if (!passes_only) {
+        switch (log2n) {
+        case 4: return launch_q15_r16<4>(in, out, nframes, inverse, tw, perm, st);
+        case 6: return launch_q15_r16<6>(in, out, nframes, inverse, tw, perm, st);
+        case 8: return launch_q15_r16<8>(in, out, nframes, inverse, tw, perm, st);
+        case 10: return launch_q15_r16<10>(in, out, nframes, inverse, tw, perm, st);
+        case 12: return launch_q15_r16<12>(in, out, nframes, inverse, tw, perm, st);
+        case 14: return launch_q15_r16<14>(in, out, nframes, inverse, tw, perm, st);
+        }
+    }
     // lanes per frame: one per radix-4 butterfly, at least 16; frames per workgroup fill 256 lanes
     unsigned lanes = (unsigned)(nbins / 4);
     if (lanes < 16) lanes = 16;

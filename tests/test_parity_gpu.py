@@ -257,14 +257,23 @@ def test_fft_cf64(oracle, dev, nbins, inverse):
 
 
 @pytest.mark.parametrize("inverse", [False, True])
-@pytest.mark.parametrize("nbins", [2, 4, 8, 16, 32, 128, 1024, 2048, 4096, 16384])
+@pytest.mark.parametrize("nbins", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
 def test_fft_int16_bit_exact(oracle, dev, nbins, inverse):
-    """kiss_fft -DFIXED_POINT=16: every Q15 rounding reproduced (scaled by 1/N overall)."""
+    """kiss_fft -DFIXED_POINT=16: every Q15 rounding reproduced (scaled by 1/N overall).  4^s sizes run
+    the fused-pair kernel, 2*4^s sizes the pass kernel."""
     rng = np.random.default_rng(nbins + 2)
     x = rand_stream(rng, oracle.I16, nbins * 3, True)
     ref = oracle.fft(x, nbins, inverse)
     got = dev.Fft("complex_int16", nbins, inverse).transform(x)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("nbins,nframes", [(16, 1000), (64, 333), (256, 77), (32, 515), (1024, 9)])
+def test_fft_int16_many_frames(oracle, dev, nbins, nframes):
+    """frame counts that do not fill the last workgroup (several frames share one for short transforms)"""
+    rng = np.random.default_rng(nbins)
+    x = rand_stream(rng, oracle.I16, nbins * nframes, True)
+    assert np.array_equal(dev.Fft("complex_int16", nbins, False).transform(x), oracle.fft(x, nbins, False))
 
 
 def test_fft_kat_reference_vectors(dev):

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void fft_q15_kernel(const K16 *__restrict__ in
 }
 
 // --------------------------------------------------------------------------------- //
-// complex_int16, numBins = 4^s (16 ... 16384): the same passes with TWO radix-4 stages fused per
+// complex_int16, numBins = 16 ... 16384: the same passes with TWO radix-4 stages fused per
 // trip through LDS.  A lane holds 16 elements of a frame in registers; for the pair of stages with
 // butterfly strides m and 4m (m = 16^p) those are positions G*16m + k + j*m, j = 0..15: stage m
 // runs its four butterflies on j = 4a + {0,1,2,3}, stage 4m on j = b + {0,4,8,12} -- every operand
@@ -326,14 +326,23 @@ __device__ __forceinline__ void k16_bfly4(K16 &f0, K16 &f1, K16 &f2, K16 &f3, K1
     }
 }
 
+// Stage schedule for numBins = 2^LOG2N, 16 <= numBins <= 16384: kf_factor gives radix 4 as often as
+// possible and one radix-2 stage at the BOTTOM when LOG2N is odd (kiss_fft.c:309-328).  Pass 0 works
+// on the 16 consecutive leaf positions of a lane: two radix-4 stages (m = 1, 4), or -- LEAD2 -- the
+// radix-2 stage plus the m = 2 radix-4 stage (two groups of 8).  Every later pass pairs two radix-4
+// stages with strides m, 4m, m = 2^LM(p); an odd stage left over is the single TAIL pass.
 template <int LOG2N>
 struct Q15R16 {
     static constexpr int N = 1 << LOG2N;
     static constexpr int T = N / 16;                      // lanes per frame
     static constexpr int THREADS = T < 256 ? 256 : T;
     static constexpr int FPW = THREADS / T;               // frames per workgroup
-    static constexpr int NF = LOG2N / 4;                  // fused stage pairs
-    static constexpr bool TAIL = (LOG2N % 4) == 2;        // one more single radix-4 pass
+    static constexpr bool LEAD2 = (LOG2N % 2) == 1;
+    static constexpr int R4 = LOG2N / 2;                  // radix-4 stages
+    static constexpr int REST = R4 - (LEAD2 ? 1 : 2);     // radix-4 stages after pass 0
+    static constexpr int NF = 1 + REST / 2;               // passes that run in registers: pass 0 + pairs
+    static constexpr bool TAIL = (REST % 2) == 1;         // one more single radix-4 pass
+    static constexpr int LM(int p) { return p == 0 ? 0 : (LEAD2 ? 4 * p - 1 : 4 * p); }   // log2 stride of pass p
     static constexpr int IMG = N + N / 16;                // padded frame image (elements)
     static constexpr size_t LDS = ((size_t)N + (size_t)FPW * IMG) * sizeof(K16);
 };
@@ -355,6 +364,8 @@ __global__ __launch_bounds__(Q15R16<LOG2N>::THREADS) void fft_q15_r16_kernel(con
 #pragma unroll
     for (int j = 0; j < 16; j++) src_idx[j] = perm[16 * t + j];
     __syncthreads();
+    // positions of pass p: base(p) + (j << LM(p))
+    auto base_of = [&](int lm) { return ((t >> lm) << (lm + 4)) + (t & ((1 << lm) - 1)); };
     const size_t ngroups = (nframes + FPW - 1) / FPW;
     for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const size_t f = g * FPW + fl;
@@ -363,43 +374,68 @@ __global__ __launch_bounds__(Q15R16<LOG2N>::THREADS) void fft_q15_r16_kernel(con
         K16 v[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] = src[src_idx[j]];
+        // ---- pass 0 on the leaf positions ----
+        if (P::LEAD2) {
+            // kf_bfly2 (kiss_fft.c:21-42), m = 1, twiddle tw[0]
+            const K16 w0 = twl[0];
 #pragma unroll
-        for (int p = 0; p < NF; p++) {
-            const int lm = 4 * p, m = 1 << lm;
-            const int G = t >> lm, k = t & (m - 1);
-            if (p > 0) {
-                // hand-over: previous pair's positions -> this pair's positions (in place, padded image)
-                const int lmp = lm - 4, mp = 1 << lmp;
-                const int bp = ((t >> lmp) << (lmp + 4)) + (t & (mp - 1));
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < 16; j++) { const int pos = bp + (j << lmp); img[pos + (pos >> 4)] = v[j]; }
-                __syncthreads();
-                const int b0 = (G << (lm + 4)) + k;
-#pragma unroll
-                for (int j = 0; j < 16; j++) { const int pos = b0 + (j << lm); v[j] = img[pos + (pos >> 4)]; }
+            for (int i = 0; i < 8; i++) {
+                const K16 f0 = k16_fixdiv(v[2 * i], 16383), f1 = k16_fixdiv(v[2 * i + 1], 16383);
+                const K16 tt = k16_mul(f1, w0);
+                v[2 * i + 1] = k16_sub(f0, tt);
+                v[2 * i] = k16_add(f0, tt);
             }
-            // stage m: butterflies (g = 4G + a, k), twiddles tw[k * fstride * r], fstride = N / (4m)
-            {
+            // radix-4 stage m = 2: butterflies (g, k in {0,1}), fstride = N / 8
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int ti = k << (LOG2N - 3);
+                const K16 w1 = twl[ti], w2 = twl[2 * ti], w3 = twl[3 * ti];
+#pragma unroll
+                for (int h = 0; h < 2; h++) k16_bfly4(v[8 * h + k], v[8 * h + k + 2], v[8 * h + k + 4], v[8 * h + k + 6], w1, w2, w3, inverse);
+            }
+        } else {
+            {   // stage m = 1: twiddle index 0 for every butterfly (tw[0] = 32767: NOT an identity in Q15)
+                const K16 w0 = twl[0];
+#pragma unroll
+                for (int a = 0; a < 4; a++) k16_bfly4(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], w0, w0, w0, inverse);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {   // stage m = 4: k = b, fstride = N / 16
+                const int ti = b << (LOG2N - 4);
+                k16_bfly4(v[b], v[b + 4], v[b + 8], v[b + 12], twl[ti], twl[2 * ti], twl[3 * ti], inverse);
+            }
+        }
+        // ---- pairs of radix-4 stages, strides m and 4m ----
+#pragma unroll
+        for (int p = 1; p < NF; p++) {
+            const int lm = P::LM(p), m = 1 << lm, lmp = P::LM(p - 1);
+            const int k = t & (m - 1);
+            const int bp = base_of(lmp), b0 = base_of(lm);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const int pos = bp + (j << lmp); img[pos + (pos >> 4)] = v[j]; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const int pos = b0 + (j << lm); v[j] = img[pos + (pos >> 4)]; }
+            {   // stage m: butterflies (g = 4G + a, k), fstride = N / (4m)
                 const int ti = k << (LOG2N - lm - 2);
                 const K16 w1 = twl[ti], w2 = twl[2 * ti], w3 = twl[3 * ti];
 #pragma unroll
                 for (int a = 0; a < 4; a++) k16_bfly4(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], w1, w2, w3, inverse);
             }
-            // stage 4m: butterflies (g = G, k + b*m), fstride = N / (16m)
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < 4; b++) {   // stage 4m: butterflies (g = G, k + b*m), fstride = N / (16m)
                 const int ti = (k + b * m) << (LOG2N - lm - 4);
                 k16_bfly4(v[b], v[b + 4], v[b + 8], v[b + 12], twl[ti], twl[2 * ti], twl[3 * ti], inverse);
             }
         }
+        constexpr int lml = P::LM(NF - 1);   // stride of the last register pass
         if (P::TAIL) {
-            // last pair's positions -> t + j*T; butterflies k = t + b*T of the stride-N/4 stage (fstride 1)
-            constexpr int lmp = 4 * (NF - 1), mp = 1 << lmp;
-            const int bp = ((t >> lmp) << (lmp + 4)) + (t & (mp - 1));
+            // last pass's positions -> t + j*T; butterflies k = t + b*T of the stride-N/4 stage (fstride 1)
+            const int bp = base_of(lml);
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; j++) { const int pos = bp + (j << lmp); img[pos + (pos >> 4)] = v[j]; }
+            for (int j = 0; j < 16; j++) { const int pos = bp + (j << lml); img[pos + (pos >> 4)] = v[j]; }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 16; j++) { const int pos = t + j * T; v[j] = img[pos + (pos >> 4)]; }
@@ -415,10 +451,9 @@ __global__ __launch_bounds__(Q15R16<LOG2N>::THREADS) void fft_q15_r16_kernel(con
 #pragma unroll
                 for (int j = 0; j < 16; j++) dst[t + j * T] = v[j];
             } else {
-                constexpr int lm = 4 * (NF - 1);
-                const int b0 = ((t >> lm) << (lm + 4)) + (t & ((1 << lm) - 1));
+                const int b0 = base_of(lml);
 #pragma unroll
-                for (int j = 0; j < 16; j++) dst[b0 + (j << lm)] = v[j];
+                for (int j = 0; j < 16; j++) dst[b0 + (j << lml)] = v[j];
             }
         }
     }
@@ -458,15 +493,20 @@ int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool
     }
     int log2n = 0;
     while (((size_t)1 << log2n) < nbins) log2n++;
-    // pure radix-4 plans (numBins = 4^s) take the fused-pair kernel; PCX_FFT_Q15_PASSES=1 keeps the pass kernel (A/B)
+    // 16 <= numBins <= 16384 take the fused-pair kernel; PCX_FFT_Q15_PASSES=1 keeps the pass kernel (A/B)
     static const int passes_only = [] { const char *e = getenv("PCX_FFT_Q15_PASSES"); return e ? atoi(e) : 0; }();
     if (!passes_only) {
         switch (log2n) {
         case 4: return launch_q15_r16<4>(in, out, nframes, inverse, tw, perm, st);
+        case 5: return launch_q15_r16<5>(in, out, nframes, inverse, tw, perm, st);
         case 6: return launch_q15_r16<6>(in, out, nframes, inverse, tw, perm, st);
+        case 7: return launch_q15_r16<7>(in, out, nframes, inverse, tw, perm, st);
         case 8: return launch_q15_r16<8>(in, out, nframes, inverse, tw, perm, st);
+        case 9: return launch_q15_r16<9>(in, out, nframes, inverse, tw, perm, st);
         case 10: return launch_q15_r16<10>(in, out, nframes, inverse, tw, perm, st);
+        case 11: return launch_q15_r16<11>(in, out, nframes, inverse, tw, perm, st);
         case 12: return launch_q15_r16<12>(in, out, nframes, inverse, tw, perm, st);
+        case 13: return launch_q15_r16<13>(in, out, nframes, inverse, tw, perm, st);
         case 14: return launch_q15_r16<14>(in, out, nframes, inverse, tw, perm, st);
         }
     }

@@ -6,14 +6,17 @@
 // pinned at the FP32-FMA roof (~77 Gsamples/s); overlap-save costs ~134 flop per sample
 // whatever K (<= 2049), which puts the filter back under the HBM roof.
 //
-// One workgroup (256 lanes) per block of S = 4096-(K-1) outputs:
-//   load 4096 inputs (block b starts at xh[b*S]; consecutive blocks overlap by K-1)
+// One persistent workgroup (256 lanes, 4 resident per CU) walks blocks of S = 4096-Kov outputs,
+// Kov = K-1 rounded up to 16 samples (aligned rows, see the kernel):
+//   load 4096 inputs (block b starts at xh[b*S - pad]; consecutive blocks overlap by Kov)
 //   forward radix-16 x3 Stockham (fft4096.hpp)            -> lane j holds X[j + 256 k]
-//   multiply by H[j + 256 k] (coalesced, L2-resident)
+//   multiply by the lane's 16 bins of H (32 VGPRs, loaded once per workgroup)
 //   inverse radix-16 x3: its pass 1 wants x[j + 256 r], exactly what the lane holds,
 //   so the spectrum never leaves registers
-//   store time samples i >= K-1 (the first K-1 are circularly aliased) to y[b*S + i-(K-1)]
+//   store time samples i >= Kov (the first K-1 are circularly aliased) to y[b*S + i-Kov]
 // HBM traffic per block: 32 KiB read + 8*S bytes written; LDS: one padded 34 KiB image.
+// The kernel runs at the package power cap: what remains above the load+store
+// floor is clock, not scheduling.
 #include "fft4096.hpp"
 #include <cstdlib>
 

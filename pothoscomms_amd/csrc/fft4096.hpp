@@ -249,40 +249,52 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
     return __builtin_copysignf(r, y);
 }
 
+// PART (timing-only builds of the energy split, wrong outputs): 0 = the real pass, 1 = butterflies only
+// (no LDS exchange, no barriers), 2 = exchange only (no butterfly arithmetic)
 // pass 1: v[r] = x[j + 256 r] on entry; leaves the pass-1 result in LDS
+template <int PART = 0>
 __device__ __forceinline__ void pass1(cf (&v)[16], cf *lds, int j)
 {
-    fft16_plain(v);
+    if (PART != 2) fft16_plain(v);
+    if (PART == 1) return;
     __syncthreads();  // previous readers of this LDS image are done
 #pragma unroll
     for (int q = 0; q < 16; q++) lds[17 * j + bin_of(q)] = v[q];  // pad(16 j + k) = 17 j + k
 }
+template <int PART = 0>
 __device__ __forceinline__ void pass2(cf (&v)[16], cf *lds, int j)
 {
-    __syncthreads();
-    const int rb = j + (j >> 4);  // pad(j + 256 r) = rb + 272 r
+    if (PART != 1) {
+        __syncthreads();
+        const int rb = j + (j >> 4);  // pad(j + 256 r) = rb + 272 r
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
+        for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
+    }
     LaneTw tw;                    // this lane's pass-2 factors: 16 distinct rows, broadcast reads
     const cf *t2 = lds + LDS_DATA + (j & 15);
 #pragma unroll
     for (int p = 0; p < 3; p++) tw.a[p] = t2[p * 16];
 #pragma unroll
     for (int p = 0; p < 12; p++) tw.c[p] = t2[(3 + p) * 16];
-    fft16_tw(v, tw);
+    if (PART != 2) fft16_tw(v, tw);
+    else v[0] = v[0] + tw.a[0] + tw.c[0];   // keep the table reads alive
+    if (PART == 1) return;
     __syncthreads();
     const int wb = (j >> 4) * 272 + (j & 15);  // pad((j>>4)*256 + kk + 16 k) = wb + 17 k
 #pragma unroll
     for (int q = 0; q < 16; q++) lds[wb + 17 * bin_of(q)] = v[q];
 }
 // pass 3: on exit v[q] = X[j + 256 * bin_of(q)]
+template <int PART = 0>
 __device__ __forceinline__ void pass3(cf (&v)[16], const cf *lds, int j, const LaneTw &tw3)
 {
-    __syncthreads();
-    const int rb = j + (j >> 4);
+    if (PART != 1) {
+        __syncthreads();
+        const int rb = j + (j >> 4);
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
-    fft16_tw(v, tw3);
+        for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
+    }
+    if (PART != 2) fft16_tw(v, tw3);
 }
 
 }  // namespace fft4k

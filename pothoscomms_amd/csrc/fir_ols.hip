@@ -36,7 +36,8 @@ namespace pcx {
 // bypasses L2); nt stores alone 0.2267-0.2277; nt stores + nt loads on the rows that only this block
 // reads 0.2204-0.2215 -- the default.
 // DIAG (timing-only builds, wrong outputs): 1 = every block reads/writes block 0 (cache resident:
-// the compute floor), 2 = no transforms (load, store: the memory floor)
+// the compute floor), 2 = no transforms (load, store: the memory floor), 3 = real stream, butterflies
+// without the LDS exchanges, 4 = real stream, LDS exchanges without the butterflies (energy split)
 // HGLOBAL: fetch the lane's 16 H bins from L2 in every block instead of holding them in 32 VGPRs
 // -- room for the register prefetch at 4 workgroups per CU.
 template <bool PREFETCH, int LAUX = 0, int SAUX = 0, int CHUNKED = 0, int DIAG = 0, bool HGLOBAL = false>
@@ -132,10 +133,11 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         } else {
             fetch(v, b);
         }
+        constexpr int PART = DIAG == 3 ? 1 : DIAG == 4 ? 2 : 0;
         if (DIAG != 2) {
-        pass1(v, lds, j);
-        pass2(v, lds, j);
-        pass3(v, lds, j, tw3);
+        pass1<PART>(v, lds, j);
+        pass2<PART>(v, lds, j);
+        pass3<PART>(v, lds, j, tw3);
         }
         // spectrum times H, re-ordered into natural register order for the next pass 1.
         // The inverse transform runs on the FORWARD passes: IFFT(z) = conj(FFT(conj(z))), so
@@ -156,9 +158,9 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
             cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
         if (DIAG != 2) {
-        pass1(u, lds, j);
-        pass2(u, lds, j);
-        pass3(u, lds, j, tw3);
+        pass1<PART>(u, lds, j);
+        pass2<PART>(u, lds, j);
+        pass3<PART>(u, lds, j, tw3);
         }
         // time sample i of the block is output b*S + i - (K-1).  For i < K-1 (circularly
         // aliased) the unsigned byte offset wraps far beyond num_records and the store is
@@ -185,7 +187,7 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     // prefetch (3 workgroups/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs, 5 H from L2,
     // 6 nt stores only, 7 nt interior loads only, 9 register prefetch + default cache policy,
     // 10/11 compute-only / memory-only timing builds (plain accesses), 12/13 the same with the default policy,
-    // 14 XCD-aware block walk + default policy.
+    // 14 XCD-aware block walk + default policy, 15/16 butterflies-only / exchanges-only on the real stream.
     // PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
     static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : -1; }();
     static const int align = [] { const char *e = getenv("PCX_OLS_ALIGN"); return e ? atoi(e) : 1; }();
@@ -217,6 +219,8 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     case 7: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0>), g4); break;
     case 9: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 4, 2>), g3); break;
     case 14: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 2>), gx); break;
+    case 15: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 3>), g4); break;
+    case 16: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 4>), g4); break;
     case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 1>), g4); break;
     case 13: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 2>), g4); break;
     case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 1>), g4); break;

@@ -214,3 +214,47 @@ def test_split_combine_blocks(oracle, t):
     outs, cons, prod = sp.work_ports([z], [300, 250])
     assert cons == [250] and prod == [250, 250]
     assert np.array_equal(outs[0], re[:250]) and np.array_equal(outs[1], im[:250])
+
+
+# ---- filter/TestFIRFilter.cpp:10-80, restated on the runner ---------------------------------------
+@pytest.mark.parametrize("dtype", ["complex_float64", "complex_int16", "complex_float32"])
+def test_fir_filter_tone_rms_like_the_reference(oracle, dtype):
+    """A 30 kHz tone of amplitude 1000 at 1 MS/s through a 101-tap complex band-pass around it, for every
+    decimation/interpolation in 1..3: the output RMS must stay above 0.1 * amplitude (TestFIRFilter.cpp:62-80).
+    The reference gets its taps from /comms/fir_designer (spuce, absent here); the band edges are the
+    test's own (waveFreq -+ 0.1 * sampRate at the filter's rate), the prototype a Hann-windowed sinc."""
+    from pothoscomms_amd import taps as tp
+    from pothoscomms_amd.device import parse_dtype, NP_SCALAR
+    scalar, _ = parse_dtype(dtype)
+    amplitude, rate, freq, total = 1000.0, 1e6, 30e3, 4096
+    n = np.arange(total)
+    wave = amplitude * np.exp(2j * np.pi * freq / rate * n)
+    x = np.stack([wave.real, wave.imag], 1)
+    x = (np.trunc(x) if scalar >= 2 else x).astype(NP_SCALAR[scalar])
+    for decim in (1, 2, 3):
+        for interp in (1, 2, 3):
+            frate = rate * interp / decim                       # designer.setSampleRate((sampRate*interp)/decim)
+            h = tp.complex_bandpass(101, 0.1 * rate / frate, freq / frate)
+            if not (0.1 * rate / frate < 0.5 and abs(freq / frate) + 0.1 * rate / frate < 0.5):
+                h = tp.complex_bandpass(101, 0.2, freq / frate)  # band edge beyond Nyquist at this rate: clamp
+            blk = B.make("/comms/fir_filter", dtype, "COMPLEX")
+            blk.call("setDecimation", decim); blk.call("setInterpolation", interp)
+            blk.call("setWaitTaps", True)
+            blk.activate()
+            ref = oracle.Fir(scalar, True, True)
+            ref.set_decimation(decim); ref.set_interpolation(interp); ref.set_wait_taps(True); ref.activate()
+            cap = total * interp // decim + 8
+            # armed by activate(): nothing moves until the designer's tapsChanged reaches setTaps (FIRFilter.cpp:201-216)
+            assert blk.work(x, cap)[1:3] == (0, 0) and ref.work(x, cap)[1:3] == (0, 0)
+            blk.call("setTaps", h * interp)                      # unity pass-band gain after zero-stuffing
+            ref.set_taps(h * interp)
+            y, c, p, _, _ = blk.work(x, cap)
+            ry, rc, rp, _ = ref.work(x, cap)
+            assert (c, p) == (rc, rp) and p > 0
+            if scalar >= 2:
+                assert np.array_equal(y, ry)
+            else:
+                assert nerr(y, ry) <= TOL
+            z = y.astype(np.float64)
+            rms = np.sqrt(np.mean(z[:, 0] ** 2 + z[:, 1] ** 2))
+            assert rms > 0.1 * amplitude, (decim, interp, rms)

@@ -258,3 +258,43 @@ def test_fir_filter_tone_rms_like_the_reference(oracle, dtype):
             z = y.astype(np.float64)
             rms = np.sqrt(np.mean(z[:, 0] ** 2 + z[:, 1] ** 2))
             assert rms > 0.1 * amplitude, (decim, interp, rms)
+
+
+def test_arithmetic_feedback_like_the_reference():
+    """math/TestArithmeticBlocks.cpp:300-338: adder with its output fed back to input 1 (preload 1 zero)
+    accumulates a running sum.  The scheduler's part (queue per port, one element becomes available
+    on the feedback port per work()) is played here."""
+    adder = B.make("/comms/arithmetic", "int32", "ADD")
+    adder.call("setPreload", [0, 1])
+    adder.activate()
+    pre = [p[4] for p in adder.ports(0)]
+    assert pre == [0, 1]
+    q0 = list(range(10))                       # feeder: 0..9
+    q1 = [0] * pre[1]                          # feedback port: the preloaded zero
+    collected = []
+    while q0 and q1:
+        n = min(len(q0), len(q1))
+        outs, cons, prod = adder.work_ports([np.array(q0[:n], np.int32), np.array(q1[:n], np.int32)], n)
+        assert cons == [n, n] and prod == [n]
+        del q0[:n], q1[:n]
+        y = outs[0].tolist()
+        collected += y
+        q1 += y                                # adder:0 -> adder:1
+    last, want = 0, []
+    for i in range(10):
+        last = i + last
+        want.append(last)
+    assert collected == want
+
+
+def test_arithmetic_inline_buffer_like_the_reference():
+    """math/TestArithmeticBlocks.cpp:341-391: 4000 elements i and i+4000 added; the framework forwards
+    input 0's buffer as the output buffer and the block counts it."""
+    n = 4000
+    a = np.arange(n, dtype=np.int32)
+    b = (np.arange(n) + n).astype(np.int32)
+    adder = B.make("/comms/arithmetic", "int32", "ADD")
+    adder.call("setNumInputs", 2)
+    outs, cons, prod = adder.work_ports([a.copy(), b], n, inline=True)
+    assert prod == [n] and np.array_equal(outs[0], a + a + n)
+    assert adder.call("getNumInlineBuffers") > 0

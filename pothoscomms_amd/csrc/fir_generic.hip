@@ -90,6 +90,153 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const S *__restrict__ 
     }
 }
 
+// --------------------------------------------------------------------------------- //
+// M = L = 1 (no resampling), every type: R consecutive outputs per lane from a register sliding
+// window.  Output o needs x[o + K-1 - k] for tap k; a lane that owns outputs o0 .. o0+R-1 keeps
+// w[r] = x[o0 + r + K-1 - k] in registers, and stepping k by one shifts the window down by one
+// sample: one new element per lane and tap instead of one per lane, tap AND output.  The k loop is
+// unrolled by R so the shift is a static renaming; the R elements a group needs are loaded together
+// ahead of the arithmetic.  Taps are wave-uniform (scalar loads).  Accumulation order per output is
+// k = 0, 1, 2, ... exactly as FIRFilter.cpp:294-300, so the EXACT float mode stays bit-identical.
+// MAD24 (int16 / int8 elements): both factors fit 24 bits (16-bit samples; Q taps checked on the
+// host), so the products are v_mul_i32_i24 / v_mad_i32_i24 -- full rate where v_mul_lo_u32 runs at
+// a quarter -- and still exact modulo 2^32.
+// --------------------------------------------------------------------------------- //
+template <typename S, typename TT, bool FLT> struct SlideAcc { typedef S type; };
+template <typename S, typename TT> struct SlideAcc<S, TT, false> { typedef typename QComp<TT>::type type; };
+
+template <typename S, typename TT, bool CPLX, bool CTAPS, bool EXACT, bool MAD24, int R>
+__global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in, S *__restrict__ out, size_t n_out, size_t K,
+                                                        const TT *__restrict__ taps)
+{
+    constexpr bool FLT = std::is_floating_point<S>::value;
+    constexpr int EW = CPLX ? 2 : 1, TW = CTAPS ? 2 : 1;
+    using C = typename SlideAcc<S, TT, FLT>::type;   // accumulator: S for floats, the unsigned compute type of Q otherwise
+    const size_t gstride = (size_t)gridDim.x * blockDim.x * R;
+    const size_t last = n_out - 1;          // input index o + K-1-k <= last + K-1 always exists
+    for (size_t o0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * R; o0 < n_out; o0 += gstride) {
+        C ar[R], ai[R], wr[R], wi[R];
+        auto fetch = [&](size_t idx, C &re, C &im) {
+            // idx may run past the last sample the call owns for the lanes of the ragged tail: clamp (unused)
+            const size_t i = idx < last + K ? idx : last + K - 1;
+            if constexpr (FLT) { re = in[i * EW]; im = CPLX ? in[i * EW + 1] : S(0); }
+            else { re = (C)(TT)in[i * EW]; im = CPLX ? (C)(TT)in[i * EW + 1] : C(0); }
+        };
+#pragma unroll
+        for (int r = 0; r < R; r++) { ar[r] = 0; ai[r] = 0; fetch(o0 + r + K - 1, wr[r], wi[r]); }
+        for (size_t kb = 0; kb < K; kb += R) {
+            // the R elements that enter the window during this group: x[o0 + K-2-k], k = kb .. kb+R-1
+            C nr[R], ni[R];
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const size_t k = kb + u;
+                if (k + 1 < K) fetch(o0 + K - 2 - k, nr[u], ni[u]);
+                else { nr[u] = 0; ni[u] = 0; }
+            }
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const size_t k = kb + u;
+                if (k >= K) break;
+                const C a = FLT ? (C)taps[k * TW] : (C)taps[k * TW];
+                const C b = CTAPS ? (C)taps[k * TW + 1] : C(0);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int ph = (r - u + R) % R;     // logical w[r] lives in physical slot (r - u) mod R
+                    const C c = wr[ph], d = wi[ph];
+                    if constexpr (FLT) {
+                        if constexpr (!CPLX) {
+                            if constexpr (EXACT) { const S p = a * c; ar[r] = ar[r] + p; }
+                            else ar[r] = t_fma(a, c, ar[r]);
+                        } else if constexpr (!CTAPS) {
+                            if constexpr (EXACT) { const S pr = c * a, pi = d * a; ar[r] = ar[r] + pr; ai[r] = ai[r] + pi; }
+                            else { ar[r] = t_fma(c, a, ar[r]); ai[r] = t_fma(d, a, ai[r]); }
+                        } else {
+                            if constexpr (EXACT) {
+                                const S ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+                                const S pr = ac - bd, pi = ad + bc;
+                                ar[r] = ar[r] + pr; ai[r] = ai[r] + pi;
+                            } else {
+                                ar[r] = t_fma(a, c, ar[r]); ar[r] = t_fma(-b, d, ar[r]);
+                                ai[r] = t_fma(a, d, ai[r]); ai[r] = t_fma(b, c, ai[r]);
+                            }
+                        }
+                    } else if constexpr (MAD24) {
+                        const int ia = (int)a, ib = (int)b, ic = (int)c, id = (int)d;
+                        if constexpr (!CPLX) ar[r] += (C)__mul24(ia, ic);
+                        else if constexpr (!CTAPS) { ar[r] += (C)__mul24(ia, ic); ai[r] += (C)__mul24(ia, id); }
+                        else {
+                            ar[r] += (C)__mul24(ia, ic) - (C)__mul24(ib, id);
+                            ai[r] += (C)__mul24(ia, id) + (C)__mul24(ib, ic);
+                        }
+                    } else {
+                        if constexpr (!CPLX) ar[r] += a * c;
+                        else if constexpr (!CTAPS) { ar[r] += a * c; ai[r] += a * d; }
+                        else { ar[r] += a * c - b * d; ai[r] += a * d + b * c; }
+                    }
+                }
+                // slide: the oldest slot (logical w[R-1]) takes the element that becomes w[0]
+                const int slot = (R - 1 - u + R) % R;
+                wr[slot] = nr[u]; wi[slot] = ni[u];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const size_t o = o0 + r;
+            if (o >= n_out) break;
+            if constexpr (FLT) {
+                out[o * EW] = ar[r];
+                if constexpr (CPLX) out[o * EW + 1] = ai[r];
+            } else {
+                out[o * EW] = (S)(((TT)ar[r]) >> (4 * sizeof(TT)));
+                if constexpr (CPLX) out[o * EW + 1] = (S)(((TT)ai[r]) >> (4 * sizeof(TT)));
+            }
+        }
+    }
+}
+
+template <typename S, typename TT, bool EXACT, bool MAD24>
+static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g, const void *in, void *out, size_t n_out, hipStream_t st)
+{
+    if (n_out == 0) return PCX_OK;
+    constexpr int R = sizeof(S) >= 8 ? 4 : 8;
+    size_t gsz = (n_out + 256 * R - 1) / (256 * R);
+    if (gsz > (1u << 20)) gsz = 1u << 20;
+    const unsigned grid = (unsigned)gsz;
+    const S *pin = (const S *)in;
+    S *pout = (S *)out;
+    const TT *tp = (const TT *)g.rowTaps;
+#define PCX_FIR_LAUNCH(CP, CT) \
+    hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R>), dim3(grid), dim3(256), 0, st, pin, pout, n_out, g.K, tp)
+    if (!is_complex) PCX_FIR_LAUNCH(false, false);
+    else if (!complex_taps) PCX_FIR_LAUNCH(true, false);
+    else PCX_FIR_LAUNCH(true, true);
+#undef PCX_FIR_LAUNCH
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+// M = L = 1 entry: `taps24` = every Q tap fits 24 signed bits (int16 / int8 element types)
+int launch_fir_slide(int scalar, int is_complex, int complex_taps, bool exact, bool taps24, const FirGeom &g, const void *in,
+                     void *out, size_t n_out, hipStream_t st)
+{
+    switch (scalar) {
+    case PCX_F32:
+        return exact ? launch_fir_slide_t<float, float, true, false>(is_complex, complex_taps, g, in, out, n_out, st)
+                     : launch_fir_slide_t<float, float, false, false>(is_complex, complex_taps, g, in, out, n_out, st);
+    case PCX_F64:
+        return exact ? launch_fir_slide_t<double, double, true, false>(is_complex, complex_taps, g, in, out, n_out, st)
+                     : launch_fir_slide_t<double, double, false, false>(is_complex, complex_taps, g, in, out, n_out, st);
+    case PCX_I64: return launch_fir_slide_t<int64_t, int64_t, true, false>(is_complex, complex_taps, g, in, out, n_out, st);
+    case PCX_I32: return launch_fir_slide_t<int32_t, int64_t, true, false>(is_complex, complex_taps, g, in, out, n_out, st);
+    case PCX_I16:
+        return taps24 ? launch_fir_slide_t<int16_t, int32_t, true, true>(is_complex, complex_taps, g, in, out, n_out, st)
+                      : launch_fir_slide_t<int16_t, int32_t, true, false>(is_complex, complex_taps, g, in, out, n_out, st);
+    case PCX_I8: return launch_fir_slide_t<int8_t, int16_t, true, true>(is_complex, complex_taps, g, in, out, n_out, st);
+    }
+    set_error("fir: unsupported scalar type %d", scalar);
+    return PCX_ERR_ARG;
+}
+
 template <typename S, typename TT, bool EXACT>
 static int launch_fir_generic_t(int is_complex, int complex_taps, const FirGeom &g, const void *in, void *out, size_t n_out, hipStream_t st)
 {

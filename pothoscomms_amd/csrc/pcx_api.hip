@@ -225,6 +225,7 @@ struct pcx_fir {
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
     DevBuf HspecRows;
     int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
+    bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
 };
 
 // Overlap-save block size for K taps (complex_float32, M = L = 1): 0 = the dedicated 4096-sample
@@ -275,6 +276,10 @@ static int fir_upload_rows(pcx_fir *h, bool integer)
     }
     PCX_TRY(upload(h->rowLen, rowLen));
     PCX_TRY(upload(h->rowTaps, rows));
+    h->taps24 = integer;
+    if (integer)
+        for (const TT &t : rows)
+            if ((long long)t < -(1ll << 23) || (long long)t >= (1ll << 23)) { h->taps24 = false; break; }
     return PCX_OK;
 }
 
@@ -461,7 +466,12 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         rc = launch_fir_cf32_direct(in_dev, used_in, out_dev, n_out, h->tapsRev.p, h->K, h->Kp, st);
     } else {
         FirGeom g{h->L, h->M, h->K, static_cast<const uint32_t *>(h->rowLen.p), h->rowTaps.p};
-        rc = launch_fir_generic(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, g, in_dev, out_dev, n_out, st);
+        // PCX_FIR_SLIDE=0 keeps the one-output-per-lane kernel for M = L = 1 too (A/B)
+        static const int slide = [] { const char *e = getenv("PCX_FIR_SLIDE"); return e ? atoi(e) : 1; }();
+        if (slide && h->L == 1 && h->M == 1)
+            rc = launch_fir_slide(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, h->taps24, g, in_dev, out_dev, n_out, st);
+        else
+            rc = launch_fir_generic(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, g, in_dev, out_dev, n_out, st);
     }
     if (rc != PCX_OK) return rc;
     h->last_algo = algo;

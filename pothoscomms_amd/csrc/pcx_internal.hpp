@@ -114,6 +114,9 @@ struct FirGeom {
 };
 int launch_fir_generic(int scalar, int is_complex, int complex_taps, bool exact, const FirGeom &g, const void *in,
                        void *out, size_t n_out, hipStream_t st);
+// M = L = 1, every type: register sliding window (fir_generic.hip); taps24 = all Q taps fit 24 signed bits
+int launch_fir_slide(int scalar, int is_complex, int complex_taps, bool exact, bool taps24, const FirGeom &g, const void *in,
+                     void *out, size_t n_out, hipStream_t st);
 // FIR: fast LDS-tiled direct form, complex_float32, M=L=1.  taps_rev: device array of
 // Kp (K rounded up to 8) cf32 taps in reversed order g[m] = h[K-1-m], zero padded
 int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_out, const void *taps_rev, size_t K,

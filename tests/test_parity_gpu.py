@@ -478,3 +478,19 @@ def test_fir_randomised_configurations(oracle, dev, seed):
         assert nerr(got, want) <= (TOL if scalar == oracle.F32 else 1e-12)
     else:
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_fir_int16_tap_magnitude_paths(oracle, dev, big):
+    """int16 streams: Q16.16 taps below 128 in magnitude take the 24-bit multiply path, larger ones the
+    32-bit one; both wrap exactly like the oracle's ring arithmetic."""
+    rng = np.random.default_rng(77 + big)
+    n, K = 50001, 37
+    x = rand_stream(rng, oracle.I16, n, True)
+    taps = (rng.standard_normal(K) + 1j * rng.standard_normal(K)) * (300.0 if big else 0.4)
+    ref = oracle.Fir(oracle.I16, True, True); ref.set_taps(taps); ref.activate()
+    want, rc, rp, _ = ref.work(x, n)
+    f = dev.FirFilter("complex_int16", "COMPLEX"); f.set_taps(taps)
+    got, gc, gp = f.process(x, n)
+    assert (gc, gp) == (rc, rp)
+    assert np.array_equal(got, want)

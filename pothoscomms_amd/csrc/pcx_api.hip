@@ -509,11 +509,18 @@ struct pcx_fft {
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
-    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED } kind = MIXED;
+    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, FOURSTEP } kind = MIXED;
     int log2n = 0;
     DevBuf tw, perm, wsIn, wsOut;
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
+    // FOURSTEP (fft_large.hip): numBins = n1 * n2, both within the single-workgroup plans
+    size_t n1 = 0, n2 = 0;
+    pcx_fft *sub1 = nullptr, *sub2 = nullptr;
+    DevBuf ws1, ws2;
+    ~pcx_fft() { delete sub1; delete sub2; }
 };
+// longest power-of-two transform one workgroup handles
+static size_t fft_single_wg_limit(int scalar) { return scalar == PCX_F32 ? 16384 : 4096; }
 
 int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
 {
@@ -525,7 +532,10 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     const bool pow2 = (num_bins & (num_bins - 1)) == 0;
     // single-workgroup LDS plans: the frame (x2 for ping-pong) must fit 160 KB
     const bool r16 = scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384;
-    if (num_bins > 1 && !r16 && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
+    // float power-of-two sizes beyond one workgroup: four-step around the short kernels (fft_large.hip)
+    const size_t wg_limit = fft_single_wg_limit(scalar);
+    const bool four_step = scalar != PCX_I16 && pow2 && num_bins > wg_limit && num_bins <= wg_limit * wg_limit;
+    if (num_bins > 1 && !r16 && !four_step && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
         set_error("FFT: numBins=%zu (%s) does not fit the single-workgroup LDS plan; not implemented on the device", num_bins,
                   scalar == PCX_F64 ? "complex_float64" : scalar == PCX_F32 ? "complex_float32" : "complex_int16");
         return PCX_ERR_UNSUPPORTED;
@@ -549,6 +559,14 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     int rc = PCX_OK;
     if (num_bins == 1) {
         h->kind = pcx_fft::IDENTITY;
+    } else if (four_step) {
+        h->kind = pcx_fft::FOURSTEP;
+        int l2 = 0;
+        while (((size_t)1 << l2) < num_bins) l2++;
+        h->n1 = (size_t)1 << ((l2 + 1) / 2);
+        h->n2 = num_bins / h->n1;
+        rc = pcx_fft_create(scalar, h->n1, inverse, &h->sub1);
+        if (rc == PCX_OK) rc = pcx_fft_create(scalar, h->n2, inverse, &h->sub2);
     } else if (scalar == PCX_F32 && num_bins == 4096) {
         h->kind = pcx_fft::R16_4096;
         rc = upload(h->tw, make_tw4096());
@@ -624,6 +642,17 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
                                     : launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
     case pcx_fft::Q15_POW2:
         return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
+    case pcx_fft::FOURSTEP: {
+        const size_t bytes = nframes * h->nbins * 2 * (size_t)scalar_bytes(h->scalar);
+        PCX_TRY(h->ws1.ensure(bytes));
+        PCX_TRY(h->ws2.ensure(bytes));
+        // [F][n1][n2] -> [F][n2][n1]; n2*F transforms of n1; twiddle + back to [F][n1][n2]; n1*F transforms of n2; -> [F][n2][n1] = natural order
+        PCX_TRY(launch_transpose(h->scalar, in_dev, h->ws1.p, h->n1, h->n2, nframes, 0, st));
+        PCX_TRY(pcx_fft_transform_dev(h->sub1, h->ws1.p, h->ws2.p, nframes * h->n2, stream));
+        PCX_TRY(launch_transpose(h->scalar, h->ws2.p, h->ws1.p, h->n2, h->n1, nframes, h->inverse ? 2 : 1, st));
+        PCX_TRY(pcx_fft_transform_dev(h->sub2, h->ws1.p, h->ws2.p, nframes * h->n1, stream));
+        return launch_transpose(h->scalar, h->ws2.p, out_dev, h->n1, h->n2, nframes, 0, st);
+    }
     case pcx_fft::MIXED:
         return launch_fft_mixed(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
     }

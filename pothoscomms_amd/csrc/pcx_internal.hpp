@@ -137,6 +137,8 @@ int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, siz
                                  size_t L, size_t M, const void *tw4096, hipStream_t st);
 
 // FFT
+// batched complex transpose (+ four-step twiddle): out[b][c][r] = in[b][r][c] * {1, W_N^(rc), W_N^(-rc)}, N = rows*cols
+int launch_transpose(int scalar, const void *in, void *out, size_t rows, size_t cols, size_t batch, int mode, hipStream_t st);
 int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, hipStream_t st);
 int launch_fft_pow2_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
                          hipStream_t st);

@@ -308,7 +308,23 @@ def test_fft_errors(dev):
     with pytest.raises(ValueError):
         dev.Fft("complex_int32", 64)       # FFTFactory: unsupported type
     with pytest.raises(NotImplementedError):
-        dev.Fft("complex_float32", 1 << 20)   # valid in the reference, beyond the single-workgroup LDS plan: fails loudly
+        dev.Fft("complex_float32", 3 << 16)   # valid in the reference; not a power of two and beyond one workgroup's LDS: fails loudly
+    with pytest.raises(NotImplementedError):
+        dev.Fft("complex_int16", 1 << 16)     # the Q15 rounding order cannot be kept across a four-step split
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("dtype,nbins,nframes", [("complex_float32", 1 << 15, 3), ("complex_float32", 1 << 16, 2), ("complex_float32", 1 << 20, 1),
+                                                 ("complex_float64", 1 << 13, 3), ("complex_float64", 1 << 16, 1)])
+def test_fft_four_step_sizes(oracle, dev, dtype, nbins, nframes, inverse):
+    """Power-of-two transforms beyond one workgroup (four-step around the short kernels) against kissfft's
+    restatement; same 1e-5 bar (1e-13 for float64)."""
+    scalar = oracle.F32 if dtype.endswith("32") else oracle.F64
+    rng = np.random.default_rng(nbins % 1000 + inverse)
+    x = rand_stream(rng, scalar, nbins * nframes, True)
+    ref = oracle.fft(x, nbins, inverse)
+    got = dev.Fft(dtype, nbins, inverse).transform(x)
+    assert nerr(got, ref) <= (TOL if scalar == oracle.F32 else 1e-13)
 
 
 # --------------------------------------------------------------------------- #

@@ -302,7 +302,12 @@ public:
     pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &)
     {
         pcxfw::BufferManagerArgs args;
-        args.bufferSize = _numBins * _elemBytes * kFramesPerSlab;
+        // several frames per slab so one call amortises the PCIe round trip, but never less than one
+        // frame (the reference's own request, FFT.cpp:54-59) nor slabs beyond 16 MiB for long transforms
+        const size_t frame = _numBins * _elemBytes;
+        size_t frames = kFramesPerSlab;
+        while (frames > 1 && frame * frames > (16u << 20)) frames /= 2;
+        args.bufferSize = frame * frames;
         return pcxfw::BufferManager::make("generic", args);
     }
 

@@ -54,10 +54,11 @@ def _worker(rank, world, port, C, K, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K", [255, 2])
-def test_two_rank_overlap_save_sharding_has_no_seam(K):
+@pytest.mark.parametrize("K,world", [(255, 2), (2, 2), (255, 4)])
+def test_overlap_save_sharding_has_no_seam(K, world):
+    """world 2 as the contract asks; world 4 also exercises interior ranks, which both send and receive"""
     from oracle import oracle as o
-    world, C = 2, 5000
+    C = 5000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -15,6 +15,7 @@
 // Float results are bit-identical to the reference for finite, normal-range operands; the parity bar
 // is 1e-5 relative.
 #include "pcx_internal.hpp"
+#include "vec_io.hpp"
 
 #include <type_traits>
 
@@ -24,34 +25,6 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kUnroll = 2;   // two input streams: 2 x 2 x 16 B in flight per lane
-
-template <typename T, int N>
-struct alignas(sizeof(T) * N) Vec {
-    T v[N];
-};
-template <int BYTES> struct RawVec;
-template <> struct RawVec<1> { typedef unsigned char type; };
-template <> struct RawVec<2> { typedef unsigned short type; };
-template <> struct RawVec<4> { typedef unsigned int type; };
-template <> struct RawVec<8> { typedef unsigned int type __attribute__((ext_vector_type(2))); };
-template <> struct RawVec<16> { typedef unsigned int type __attribute__((ext_vector_type(4))); };
-template <typename V>
-__device__ __forceinline__ V nt_load(const V *p)
-{
-    typedef typename RawVec<sizeof(V)>::type R;
-    const R r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
-    V v;
-    __builtin_memcpy(&v, &r, sizeof(V));
-    return v;
-}
-template <typename V>
-__device__ __forceinline__ void nt_store(V *p, const V &v)
-{
-    typedef typename RawVec<sizeof(V)>::type R;
-    R r;
-    __builtin_memcpy(&r, &v, sizeof(V));
-    __builtin_nontemporal_store(r, reinterpret_cast<R *>(p));
-}
 
 // ---- promoted / division types per element type (see the header comment) ----
 template <typename T> struct Prom {

@@ -42,32 +42,6 @@ struct OlsPlan {
     static constexpr bool NATURAL = R > 1;                // register q holds bin q*LPF + l (else bin_of(q)*LPF + l)
 };
 
-__device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
-__device__ __forceinline__ cf cmul1(cf a, cf w)
-{
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]\n\t"
-        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
-        : "=&v"(t), "=&v"(r)
-        : "v"(a), "v"(w));
-    return r;
-}
-__device__ __forceinline__ void fft8(cf &a0, cf &a1, cf &a2, cf &a3, cf &a4, cf &a5, cf &a6, cf &a7)
-{
-    constexpr float R2 = 0.70710678118654752440f;
-    cf e0 = a0, e1 = a2, e2 = a4, e3 = a6, o0 = a1, o1 = a3, o2 = a5, o3 = a7;
-    fft4(e0, e1, e2, e3);
-    fft4(o0, o1, o2, o3);
-    const cf w1 = cmul_cs(o1, R2, R2);
-    const cf w3 = cmul_cs(o3, -R2, R2);
-    cf p2, m2;
-    addsub_mi(p2, m2, e2, o2);
-    a0 = e0 + o0; a4 = e0 - o0;
-    a1 = e1 + w1; a5 = e1 - w1;
-    a2 = p2;      a6 = m2;
-    a3 = e3 + w3; a7 = e3 - w3;
-}
-
 // forward DFT_N of the block held as v[s] = x[l + s*LPF]; on exit v[q] = X[l + LPF*(NATURAL ? q : bin_of(q))]
 template <int LOG2N>
 __device__ __forceinline__ void xform(cf (&v)[16], cf *lds, int l, const LaneTw &t3, const cf *tf)

@@ -212,6 +212,22 @@ __device__ __forceinline__ K16 k16_fixdiv(K16 c, int mult)  // C_FIXDIV: mult = 
 __device__ __forceinline__ K16 k16_add(K16 a, K16 b) { return {(int16_t)(a.r + b.r), (int16_t)(a.i + b.i)}; }
 __device__ __forceinline__ K16 k16_sub(K16 a, K16 b) { return {(int16_t)(a.r - b.r), (int16_t)(a.i - b.i)}; }
 
+// numBins = 1: kf_factor yields the single factor 1 and kf_work runs kf_bfly_generic with p = 1
+// (kiss_fft.c:202-235,300), whose C_FIXDIV(scratch[0], 1) multiplies by 32767/32768 with rounding --
+// the one-bin fixed-point "transform" is not the identity.
+__global__ __launch_bounds__(256) void fft_q15_one_kernel(const K16 *__restrict__ in, K16 *__restrict__ out, size_t n)
+{
+    const size_t gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) out[i] = k16_fixdiv(in[i], 32767);
+}
+int launch_fft_q15_one(const void *in, void *out, size_t nframes, hipStream_t st)
+{
+    if (nframes == 0) return PCX_OK;
+    hipLaunchKernelGGL(fft_q15_one_kernel, dim3(stream_grid(nframes, 256)), dim3(256), 0, st, (const K16 *)in, (K16 *)out, nframes);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 constexpr int kMaxStages = 16;
 struct Q15Plan {
     int nstages;

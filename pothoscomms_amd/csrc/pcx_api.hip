@@ -632,7 +632,8 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     hipStream_t st = as_stream(stream);
     switch (h->kind) {
-    case pcx_fft::IDENTITY:  // DFT of one point is the identity (kissfft leaf copy, kissfft.hh:94-98)
+    case pcx_fft::IDENTITY:  // DFT of one point is the identity (kissfft leaf copy, kissfft.hh:94-98) -- except in Q15
+        if (h->scalar == PCX_I16) return launch_fft_q15_one(in_dev, out_dev, nframes, st);
         PCX_HIP(hipMemcpyAsync(out_dev, in_dev, nframes * 2 * (size_t)scalar_bytes(h->scalar), hipMemcpyDeviceToDevice, st));
         return PCX_OK;
     case pcx_fft::R16_4096: return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, st);

@@ -357,3 +357,12 @@ def test_synthetic_stream_is_deterministic(oracle):
     assert np.array_equal(a[500:], b) and a.min() >= -1 and a.max() < 1
     assert abs(float(a.mean())) < 0.1
 
+
+
+def test_fft_int16_one_bin_against_compiled_reference(oracle):
+    """numBins = 1 in Q15 is x * 32767/32768 rounded, not a copy (kiss_fft.c:202-235 with p = 1)"""
+    x = np.array([[5836, -18035], [123, -1], [-32768, 32767], [1, 0]], np.int16)
+    want = [[5836, -18034], [123, -1], [-32767, 32766], [1, 0]]
+    assert oracle.fft(x, 1, False).tolist() == want
+    if oracle.ref() is not None:
+        assert oracle.ref_fft(x, 1, False).tolist() == want and oracle.ref_fft(x, 1, True).tolist() == want

@@ -515,3 +515,32 @@ def test_fir_int16_tap_magnitude_paths(oracle, dev, big):
     got, gc, gp = f.process(x, n)
     assert (gc, gp) == (rc, rp)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PCX_FUZZ_SEEDS", "24"))))
+def test_fft_randomised_sizes(oracle, dev, seed):
+    """random numBins (any factorisation, primes included), type, direction and frame count vs kissfft's restatement"""
+    rng = np.random.default_rng(5000 + seed)
+    scalar = [oracle.F32, oracle.F64, oracle.I16][seed % 3]
+    nbins = int(rng.integers(1, 2500)) if seed % 4 else int(2 ** rng.integers(0, 13))
+    inverse = bool(rng.integers(0, 2))
+    nframes = int(rng.integers(1, 6))
+    x = rand_stream(rng, scalar, nbins * nframes, True)
+    ref = oracle.fft(x, nbins, inverse)
+    got = dev.Fft((scalar, True), nbins, inverse).transform(x)
+    if scalar == oracle.I16:
+        assert np.array_equal(got, ref), nbins
+    else:
+        assert nerr(got, ref) <= (TOL if scalar == oracle.F32 else 1e-12), nbins
+
+
+def test_fft_int16_one_bin_is_not_the_identity(oracle, dev):
+    """kiss_fft Q15 with numBins = 1 runs kf_bfly_generic(p = 1): C_FIXDIV by 1 = x * 32767/32768 rounded
+    (found by the randomised sweep; checked against the compiled reference on the CPU side)"""
+    x = np.array([[5836, -18035], [123, -1], [-32768, 32767], [1, 0]], np.int16)
+    for inverse in (False, True):
+        want = oracle.fft(x, 1, inverse)
+        assert want.tolist() == [[5836, -18034], [123, -1], [-32767, 32766], [1, 0]]
+        assert np.array_equal(dev.Fft("complex_int16", 1, inverse).transform(x), want)
+    xf = np.array([[1.5, -2.25]], np.float32)
+    assert np.array_equal(dev.Fft("complex_float32", 1, False).transform(xf), xf)     # float: leaf copy

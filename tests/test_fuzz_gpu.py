@@ -106,3 +106,63 @@ def test_fm_chain_random_chunks(oracle, dev, seed):
     got = np.concatenate(outs)
     assert len(got) == produced == n - ntaps + 1
     assert ang_err(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fir_block_random_streaming_with_bursts(oracle, seed):
+    """/comms/fir_filter block driven work() by work() with random window growth, output room, resampling
+    and frame-start/end labels: consumed / produced / reserve and the samples follow the oracle's work()"""
+    from pothoscomms_amd import blocks as B
+    rng = np.random.default_rng(6000 + seed)
+    scalar = [oracle.F32, oracle.I16, oracle.F64][seed % 3]
+    name = {oracle.F32: "float32", oracle.I16: "int16", oracle.F64: "float64"}[scalar]
+    ctaps = bool(rng.integers(0, 2))
+    ntaps = int(rng.integers(1, 120))
+    L, M = (1, 1) if seed % 2 else (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+    taps = (rng.normal(size=ntaps) + (1j * rng.normal(size=ntaps) if ctaps else 0)) / max(1.0, np.sqrt(ntaps))
+    n = int(rng.integers(2000, 30000))
+    x = rand_stream(rng, scalar, n, True, amp=1000)
+    blk = B.make("/comms/fir_filter", "complex_" + name, "COMPLEX" if ctaps else "REAL")
+    ref = oracle.Fir(scalar, True, ctaps)
+    blk.call("setTaps", taps); ref.set_taps(taps)
+    blk.call("setInterpolation", L); ref.set_interpolation(L)
+    blk.call("setDecimation", M); ref.set_decimation(M)
+    mode = seed % 4          # 0/1: plain stream, 2: frame start only, 3: start and end labels
+    if mode == 2:
+        blk.call("setFrameStartId", "S"); ref.set_frame_ids(True, False)
+    elif mode == 3:
+        blk.call("setFrameStartId", "S"); blk.call("setFrameEndId", "E"); ref.set_frame_ids(True, True)
+    blk.activate(); ref.activate()
+    labels_at = []
+    if mode >= 2:
+        pos = int(rng.integers(0, n // 4))
+        while pos < n - 10:
+            blen = int(rng.integers(50, 3000))
+            labels_at.append(("S", pos, blen if mode == 2 else None))
+            if mode == 3:
+                labels_at.append(("E", min(n - 1, pos + blen - 1), None))
+            pos += blen + int(rng.integers(0, 2000))
+    out_cap = int(rng.integers(64, 20000))
+    pos, avail_end, guard, total_p, calls = 0, 0, 0, 0, 0
+    while pos < n and guard < 400:
+        guard += 1
+        avail_end = min(n, avail_end + int(rng.integers(1, 6000)))
+        win = x[pos:avail_end]
+        labs = [B.Label(i, idx - pos, d) for (i, idx, d) in labels_at if pos <= idx < avail_end]
+        rlabs = [(i, idx - pos, 1, d) for (i, idx, d) in labels_at if pos <= idx < avail_end]
+        y, c, p, r, _ = blk.work(win, out_cap, labs)
+        ry, rc, rp, rr = ref.work(win, out_cap, rlabs)
+        assert (c, p, r) == (rc, rp, rr), (seed, pos, avail_end)
+        if p:
+            if scalar == oracle.I16:
+                assert np.array_equal(y, ry)
+            else:
+                assert nerr(y, ry) <= (TOL if scalar == oracle.F32 else 1e-12) or float(np.abs(ry).max()) == 0.0
+        pos += c
+        total_p += p
+        calls += 1
+        if c == 0 and avail_end == n:
+            break
+    assert calls >= 1
+    if mode < 2:
+        assert total_p > 0 and pos >= n - (-(-ntaps // L)) - M      # a plain stream drains to the K-1 (+ < M) history

@@ -31,6 +31,12 @@ struct Plan {
     static constexpr int THREADS = LPF < 256 ? 256 : LPF;
     static constexpr int FPW = THREADS / LPF;             // frames per workgroup
     static constexpr int LDS_FRAME = (A + (R > 1 ? 1 : 0)) > 1 ? N + N / 16 : 0;
+    // numBins <= 64: a frame is 128..512 bytes and lane l's elements l + s*LPF of it sit 8..32 bytes apart,
+    // so loading them straight from global memory touches 64 lines per wave-instruction (measured 0.5 TB/s
+    // at 16 bins).  The 256 lanes' frames are one contiguous 32 KiB chunk: copied in and out with
+    // lane-contiguous 16-byte accesses through a padded LDS image (i + i/16) that shares the exchange space.
+    static constexpr bool STAGED = LOG2N <= 6;
+    static constexpr int STAGE = STAGED ? 4096 + 4096 / 16 : 0;
     static constexpr int NTWF = R > 1 ? (16 / R) * (R - 1) : 0;   // final-pass twiddles per lane
     // device table: [15][16] pass Ns=16, [15][256] pass Ns=256 (A >= 3), [NTWF][LPF] final pass
     static constexpr int T2_OFF = 0;
@@ -77,10 +83,30 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const flo
         const size_t valid = nframes - f0 < (size_t)FPW ? nframes - f0 : (size_t)FPW;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + f0 * N, (unsigned)(valid * N * 8));
         cf v[16];
+        if (P::STAGED) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            __syncthreads();   // the image is free (previous group's stores / passes are done)
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, s * LPF * 8, kAuxStream);
-            v[s] = cf{__uint_as_float(t.x), INV ? -__uint_as_float(t.y) : __uint_as_float(t.y)};
+            for (int i = 0; i < 8; i++) {
+                const int e = (i * 256 + tid) * 2;      // two elements per lane and access, lane-contiguous
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 8, 0, kAuxStream);
+                const int pe = e + (e >> 4);
+                lds_all[pe] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+                lds_all[pe + 1] = cf{__uint_as_float(t.z), __uint_as_float(t.w)};
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const int e = fi * N + l + s * LPF;
+                const cf t = lds_all[e + (e >> 4)];
+                v[s] = cf{t.x, INV ? -t.y : t.y};
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, s * LPF * 8, kAuxStream);
+                v[s] = cf{__uint_as_float(t.x), INV ? -__uint_as_float(t.y) : __uint_as_float(t.y)};
+            }
         }
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + f0 * N, (unsigned)(valid * N * 8));
         bool natural = false;   // are the results in v[] in natural order (true) or in bin_of order?
@@ -142,6 +168,25 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const flo
             natural = true;
         }
         // ---- store: X at frame offset (see each pass's output map); all are l + k*LPF ----
+        if (P::STAGED) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            __syncthreads();   // every lane is done reading the image (exchange or staging)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int k = natural ? q : bin_of(q);
+                const int e = fi * N + l + k * LPF;
+                lds_all[e + (e >> 4)] = INV ? cf{v[q].x, -v[q].y} : v[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int e = (i * 256 + tid) * 2;
+                const int pe = e + (e >> 4);
+                const cf a = lds_all[pe], b = lds_all[pe + 1];
+                const u32x4 t = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x), __float_as_uint(b.y)};
+                __builtin_amdgcn_raw_buffer_store_b128(t, ws, e * 8, 0, SAUX);   // past `valid` frames: dropped by the range check
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int k = natural ? q : bin_of(q);
@@ -150,6 +195,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const flo
             const u32x2 t = {__float_as_uint(r.x), __float_as_uint(r.y)};
             __builtin_amdgcn_raw_buffer_store_b64(t, ws, (int)voff, k * LPF * 8, SAUX);
         }
+        }
     }
 }
 
@@ -157,7 +203,8 @@ template <int LOG2N>
 int launch_r16(const void *in, void *out, size_t nframes, bool inverse, const void *tw, hipStream_t st)
 {
     typedef Plan<LOG2N> P;
-    const size_t lds = (size_t)P::LDS_FRAME * P::FPW * sizeof(cf);
+    size_t lds = (size_t)P::LDS_FRAME * P::FPW * sizeof(cf);
+    if ((size_t)P::STAGE * sizeof(cf) > lds) lds = (size_t)P::STAGE * sizeof(cf);
     // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
     static const int saux = [] { const char *e = getenv("PCX_FFT_STORE_AUX"); return e ? atoi(e) : 2; }();
     auto k = saux == 2 ? (inverse ? fft_r16_kernel<LOG2N, true, 2> : fft_r16_kernel<LOG2N, false, 2>)

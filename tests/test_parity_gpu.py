@@ -278,6 +278,15 @@ def test_fft_int16_many_frames(oracle, dev, nbins, nframes):
     assert np.array_equal(dev.Fft("complex_int16", nbins, False).transform(x), oracle.fft(x, nbins, False))
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("nbins,nframes", [(16, 1000), (16, 256), (32, 515), (64, 333), (64, 64), (128, 77)])
+def test_fft_f32_short_frames_staged_io(oracle, dev, nbins, nframes, inverse):
+    """numBins <= 64 copy 256 lanes' frames through LDS with lane-contiguous accesses: full and ragged groups"""
+    rng = np.random.default_rng(nbins + nframes)
+    x = rand_stream(rng, oracle.F32, nbins * nframes, True)
+    assert nerr(dev.Fft("complex_float32", nbins, inverse).transform(x), oracle.fft(x, nbins, inverse)) <= TOL
+
+
 def test_fft_kat_reference_vectors(dev):
     """fft/TestFFT.cpp:14-29 (float) and :95-105,131-132 (int16, result/N)."""
     x = np.array([[0.4, 0.6], [-0.7, 0.6], [-0.2, 0.8], [0.9, 0.2]], np.float32)

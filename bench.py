@@ -187,7 +187,16 @@ def main():
 
         def step():
             ch.process_dev(x, y, n + 126, n)
+        if world > 1:
+            # the stream sharded over the ranks: K-sample halo from the left neighbour (stream.ShardedFmChain)
+            from pothoscomms_amd.stream import ShardedFmChain
+            sc = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
+            device.fill_uniform_f32_dev(sc.buf, seed=5, offset=2 * rank * n)
+            del xa, x, y
+            step = sc.step
         desc = {"workload": "fused Rotate->FIR(127 real taps)->FreqDemod in one frequency-domain kernel, complex_float32 -> float32, %d samples" % n}
+        if world > 1:
+            desc["parallelism"] = "overlap-save shards x%d, RCCL send/recv halo of 127 samples" % world
         metric = "Msamples/s fused FM-demod chain"
     else:
         n = C

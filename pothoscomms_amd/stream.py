@@ -105,3 +105,63 @@ class ShardedFir:
         self.ring.finish(reqs)
         self._run(0, self.head)
         return self.out
+
+
+class ShardedFmChain:
+    """Rotate -> FIR -> FreqDemod (BASELINE configs[4]) over one shard of a node-wide stream.
+
+    FreqDemod needs the FIR output just before the shard (demod/FreqDemod.cpp:63-65 carries it in
+    `_prev`), so the halo is K samples -- the FIR's K-1 plus one -- and a rank other than the
+    first computes one extra output at the front, whose only purpose is to be that predecessor, and drops
+    it.  Rank 0 starts from the reset state exactly as a single-device run does.  Buffer per rank:
+    [K halo | C samples], the halo filled in place by the left neighbour.  As in ShardedFir the body of
+    the shard is processed while the halo is in flight and the head (first 4096 outputs) afterwards.
+    """
+    HEAD = 4096
+
+    def __init__(self, taps, phase, shard_len, device, complex_taps=False, algo=None, group=None):
+        from . import device as dv   # the HIP path; raises if libpcx_hip.so is missing
+        self._chains = []
+        for _ in range(2):           # head and body calls each start from the reset state
+            ch = dv.FmChain()
+            ch.set_phase(phase)
+            ch.set_taps(taps, complex_taps)
+            if algo is not None:
+                ch.set_algo(algo)
+            self._chains.append(ch)
+        self.K = len(taps)
+        self.C = int(shard_len)
+        self.ring = HaloRing(self.K, group)
+        lead = (-(self.K - 1)) % 16      # the sample behind the FIR history of the head call on a 128-byte line
+        self._alloc = torch.zeros((lead + self.K + self.C, 2), dtype=torch.float32, device=device)
+        self.buf = self._alloc[lead:]
+        self._out = torch.empty((self.C + 1,), dtype=torch.float32, device=device)
+        self.head = min(self.HEAD, self.C)
+
+    @property
+    def shard(self):
+        return self.buf[self.K:]
+
+    @property
+    def out(self):
+        """The C demodulated samples of this shard."""
+        return self._out[1:]
+
+    def _run(self, ch, first_in, n_out, out_at):
+        ch.reset()
+        c, p = ch.process_dev(self.buf[first_in:], self._out[out_at:], n_out + self.K - 1, n_out)
+        assert c == n_out and p == n_out, (c, p, n_out)
+
+    def step(self):
+        first = self.ring.rank == 0
+        reqs = self.ring.start(self.buf)
+        if self.C > self.head:
+            # body: FIR outputs head-1 .. C-1; the first one only seeds the demodulator and lands on
+            # _out[head], which the head call overwrites
+            self._run(self._chains[1], self.head, self.C - self.head + 1, self.head)
+        self.ring.finish(reqs)
+        if first:
+            self._run(self._chains[0], 1, self.head, 1)             # stream start: reset state, no extra output
+        else:
+            self._run(self._chains[0], 0, self.head + 1, 0)         # extra output -1 from the halo, dropped
+        return self.out

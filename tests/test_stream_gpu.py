@@ -66,3 +66,58 @@ def test_two_ranks_real_kernels_no_seam(oracle):
     ref, _, p, _ = ref_blk.work(stream, world * C)
     assert p == world * C and not np.isnan(got).any()
     assert nerr(got, ref) <= TOL
+
+
+def _chain_worker(rank, world, port, C, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pothoscomms_amd import taps as tp
+    from pothoscomms_amd.stream import ShardedFmChain
+    torch.cuda.set_device(0)
+    d = torch.device("cuda", 0)
+    h = tp.c4_taps()
+    K = len(h)
+    sc = ShardedFmChain(h, tp.C4_PHASE, C, d)
+    # node-wide stream: K-1 history samples, then world*C samples; rank r owns [K-1 + r*C, K-1 + (r+1)*C)
+    x = tp.fm_test_signal(K - 1 + world * C)
+    xs = torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(-1, 2)).to(d)
+    sc.shard.copy_(xs[K - 1 + rank * C:K - 1 + (rank + 1) * C])
+    if rank == 0:
+        sc.buf[1:K] = xs[:K - 1]                       # the stream's own history; buf[0] is unused on rank 0
+    else:
+        sc.buf[:K] = float("nan")                      # must come from the left neighbour
+    out = sc.step()
+    torch.cuda.synchronize()
+    q.put((rank, out.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("C", [40000, 3000])
+def test_two_ranks_fm_chain_no_seam(oracle, C):
+    """configs[4] sharded: halo of K samples (FIR history + the demodulator's predecessor), one dropped output"""
+    from pothoscomms_amd import taps as tp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chain_worker, args=(r, world, port, C, q)) for r in range(world)]
+    [p.start() for p in procs]
+    parts = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    got = np.concatenate([parts[r] for r in range(world)])
+    h = tp.c4_taps()
+    K = len(h)
+    x = tp.fm_test_signal(K - 1 + world * C)
+    xr = oracle.rotate(x, tp.C4_PHASE)
+    fir = oracle.Fir(oracle.F32, True, False); fir.set_taps(h); fir.activate()
+    y, _, p, _ = fir.work(xr, world * C)
+    ref = oracle.FreqDemod(oracle.F32).work(y)
+    assert p == world * C and got.shape == ref.shape and not np.isnan(got).any()
+    d = (got.astype(np.float64) - ref + np.pi) % (2 * np.pi) - np.pi
+    assert np.max(np.abs(d)) / np.pi <= TOL

@@ -7,6 +7,7 @@ Stream layout: a complex stream of scalar type T is an array of shape (n, 2) of 
 viewed that way.  Real streams are 1-D arrays of T.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -267,9 +268,32 @@ def _map(host_fn, dev_fn, scalar_args, x, out_shape_fn, n, out=None, stream=None
     return y
 
 
+_libm = None
+
+
+def _polar(phase):
+    """std::polar(1.0, phase) as an optimised C++ build evaluates it (Rotate.cpp:74): GCC merges the cos and
+    sin of one argument into a single glibc sincos() call, whose sine differs from sin() in the last bit for
+    some arguments (e.g. 2.747554270528532) -- and so do numpy's own vector routines.  The block layer
+    (comms_blocks.cpp) gets this for free; the Python wrapper asks libm for the same call."""
+    global _libm
+    if _libm is None:
+        try:
+            _libm = C.CDLL("libm.so.6")
+            _libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            _libm.sincos.restype = None
+        except (OSError, AttributeError):
+            _libm = False
+    if not _libm:
+        return math.cos(phase), math.sin(phase)
+    s, c = C.c_double(), C.c_double()
+    _libm.sincos(phase, C.byref(s), C.byref(c))
+    return c.value, s.value
+
+
 def rotate(x, phase, scalar=None, out=None, n=None, stream=None):
     """arrayRotate (math/Rotate.cpp:15-23).  phase=None: block whose setPhase was never called."""
-    pr, pi = (0.0, 0.0) if phase is None else (float(np.cos(phase)), float(np.sin(phase)))
+    pr, pi = (0.0, 0.0) if phase is None else _polar(float(phase))
     if not _is_torch(x):
         x = as_pairs(x)
         scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]

@@ -165,7 +165,9 @@ def test_fir_block_random_streaming_with_bursts(oracle, seed):
             break
     assert calls >= 1
     if mode < 2:
-        assert total_p > 0 and pos >= n - (-(-ntaps // L)) - M      # a plain stream drains to the K-1 (+ < M) history
+        assert total_p > 0
+        if guard < 400:      # not cut short by the call budget (tiny output room): a plain stream drains to its history
+            assert pos >= n - (-(-ntaps // L)) - M
 
 
 @pytest.mark.parametrize("seed", SEEDS)

@@ -961,7 +961,8 @@ static int fmchain_sync(pcx_fmchain *h)
     h->Kp = (K + 7) / 8 * 8;
     // Rotate's phasor folded into the taps: FIR(p*x) = (p*h) (*) x.  p is first narrowed
     // to float as floatToQ<complex<float>> does (Rotate.cpp:74), h as FIRFilter.cpp:348.
-    const std::complex<double> p = h->phase_set ? std::complex<double>((double)(float)std::cos(h->phase), (double)(float)std::sin(h->phase))
+    const std::complex<double> pd = std::polar(1.0, h->phase);   // the expression of Rotate::setPhase (Rotate.cpp:74)
+    const std::complex<double> p = h->phase_set ? std::complex<double>((double)(float)pd.real(), (double)(float)pd.imag())
                                                 : std::complex<double>(0.0, 0.0);
     std::vector<float> rev(2 * h->Kp, 0.f);
     for (size_t m = 0; m < K; m++) {

@@ -31,6 +31,7 @@
  * -ffp-contract=off keeps every product and sum separately rounded, as the
  * reference's baseline x86-64 build (no FMA) does.
  */
+#define _GNU_SOURCE   /* sincos */
 #include <complex.h>
 #include <math.h>
 #include <stddef.h>
@@ -886,7 +887,12 @@ ORC_EXPORT int orc_freqdemod_work(orc_freqdemod *h, const void *in, void *out, s
  * `n` counts complex elements (already multiplied by dtype.dimension(), :126). */
 ORC_EXPORT int orc_rotate(int st, double phase, const void *in, void *out, size_t n)
 {
-    const double c = cos(phase), s = sin(phase);   /* std::polar(1.0, phase) = (1.0*cos, 1.0*sin) */
+    /* std::polar(1.0, phase) = (1.0*cos(phase), 1.0*sin(phase)) (libstdc++ <complex>).  An optimised GCC
+     * build turns the pair into ONE glibc sincos() call, and sincos()'s sine is not always the bit
+     * pattern sin() returns (phase 2.747554270528532: 0.3839204418969204 vs 0.38392044189692043); the
+     * call is spelled out here so that the oracle does not depend on its own optimisation level. */
+    double c, s;
+    sincos(phase, &s, &c);
     if (st == ORC_F32) {
         const float pr = (float)c, pi = (float)s;
         const float *x = (const float *)in; float *y = (float *)out;

@@ -366,3 +366,17 @@ def test_fft_int16_one_bin_against_compiled_reference(oracle):
     assert oracle.fft(x, 1, False).tolist() == want
     if oracle.ref() is not None:
         assert oracle.ref_fft(x, 1, False).tolist() == want and oracle.ref_fft(x, 1, True).tolist() == want
+
+
+def test_rotate_phasor_is_sincos(oracle):
+    """std::polar(1.0, phase) in an optimised build = glibc sincos(); its sine differs from sin() in the last
+    bit for this phase (found by the GPU soak run) -- the oracle pins the sincos() value"""
+    import ctypes as C
+    phase = 2.747554270528532
+    y = oracle.rotate(np.array([[1.0, 0.0]]), phase)
+    libm = C.CDLL("libm.so.6")
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    s, c = C.c_double(), C.c_double()
+    libm.sincos(phase, C.byref(s), C.byref(c))
+    assert y[0, 0] == c.value and y[0, 1] == s.value
+    assert repr(float(y[0, 1])) == "0.3839204418969204"

@@ -211,3 +211,20 @@ def test_label_driven_rotate_scale_blocks(oracle, seed):
         out.append(y); pos += c
     got = np.concatenate(out)
     assert pos == n and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_scale_rotate_extreme_coefficients(oracle, dev, seed):
+    """factors / phases across many magnitudes, including ones whose Q-format image overflows the Q type
+    (floatToQ's double -> integer conversion out of range) and denormal-range floats"""
+    rng = np.random.default_rng(3000 + seed)
+    scalar = [oracle.I16, oracle.F32, oracle.I8, oracle.I32, oracle.I64, oracle.F64][seed % 6]
+    cplx = bool(rng.integers(0, 2))
+    n = int(rng.integers(1, 5000))
+    x = rand_stream(rng, scalar, n, cplx)
+    mag = 10.0 ** float(rng.uniform(-12, 12))
+    factor = mag * (1 if rng.integers(0, 2) else -1)
+    assert np.array_equal(dev.scale(x, factor, cplx), oracle.scale(x, factor, cplx)), (scalar, factor)
+    if cplx:
+        phase = float(rng.uniform(-1, 1)) * 10.0 ** float(rng.uniform(-8, 6))
+        assert np.array_equal(dev.rotate(x, phase), oracle.rotate(x, phase)), (scalar, phase)

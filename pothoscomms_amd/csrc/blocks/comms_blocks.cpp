@@ -115,6 +115,9 @@ public:
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getFrameStartId));
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setFrameEndId));
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getFrameEndId));
+        // extension (not in the reference): which device kernel family serves the filter
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setKernel));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getKernel));
         // initial update: a single unit tap (reference ctor)
         _taps.assign(1, std::complex<double>(1.0, 0.0));
         this->pushTaps();
@@ -159,6 +162,17 @@ public:
         this->refreshGeometry();
     }
     size_t getInterpolation() const { return L; }
+    // "AUTO" (default), "OLS_FFT" (frequency domain), "DIRECT" (time domain, FMA), "EXACT" (time domain in the
+    // reference's operation order: bit-identical floats, and the reference's locality for Inf/NaN samples)
+    void setKernel(const std::string &name)
+    {
+        const int algo = name == "AUTO" ? PCX_FIR_AUTO : name == "DIRECT" ? PCX_FIR_DIRECT : name == "OLS_FFT" ? PCX_FIR_OLS_FFT
+                       : name == "EXACT" ? PCX_FIR_EXACT : -1;
+        if (algo < 0) throw InvalidArgumentException("FIRFilter::setKernel(" + name + ")", "unknown kernel");
+        check(pcx_fir_set_algo(_h, algo), "FIRFilter::setKernel(" + name + ")");
+        _kernel = name;
+    }
+    std::string getKernel() const { return _kernel; }
     void setWaitTaps(const bool waitTaps) { _waitTapsMode = waitTaps; }
     bool getWaitTaps() const { return _waitTapsMode; }
     void setFrameStartId(std::string id) { _frameStartId = id; }
@@ -261,6 +275,7 @@ private:
     size_t M, L, K, _inputRequire;
     bool _waitTapsMode, _waitTapsArmed;
     std::string _frameStartId, _frameEndId;
+    std::string _kernel = "AUTO";
     size_t _eobSampsLeft;
     DType _dtype;
     pcx_fir *_h;

@@ -298,3 +298,31 @@ def test_arithmetic_inline_buffer_like_the_reference():
     outs, cons, prod = adder.work_ports([a.copy(), b], n, inline=True)
     assert prod == [n] and np.array_equal(outs[0], a + a + n)
     assert adder.call("getNumInlineBuffers") > 0
+
+
+def test_fir_block_kernel_selection_and_nonfinite_locality(oracle):
+    """setKernel (an extension): EXACT keeps the reference's operation order -- bit-identical floats, and an
+    Inf sample touches K outputs only -- while the default frequency-domain kernel poisons its block"""
+    rng = np.random.default_rng(8)
+    K, n = 31, 12000
+    taps = (rng.normal(size=K) + 1j * rng.normal(size=K)) / 6
+    x = rand_stream(rng, oracle.F32, n, True)
+    x[5000, 0] = np.inf
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(taps); ref.activate()
+    want, rc, rp, _ = ref.work(x, n)
+    blk = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    blk.call("setTaps", taps)
+    assert blk.call("getKernel") == "AUTO"
+    blk.call("setKernel", "EXACT"); blk.activate()
+    y, c, p, _, _ = blk.work(x, n)
+    assert (c, p) == (rc, rp)
+    bad_ref = ~np.isfinite(want).all(axis=1)
+    assert bad_ref.sum() == K and np.array_equal(~np.isfinite(y).all(axis=1), bad_ref)
+    assert np.array_equal(y[~bad_ref], want[~bad_ref])
+    blk.call("setKernel", "AUTO")
+    y2, _, _, _, _ = blk.work(x, n)
+    bad2 = ~np.isfinite(y2).all(axis=1)
+    assert bad2[bad_ref].all() and bad2.sum() > K            # the whole 4096-sample block, as DESIGN.md states
+    assert nerr(y2[~bad2], want[~bad2]) <= TOL
+    with pytest.raises(ValueError, match="unknown kernel"):
+        blk.call("setKernel", "FASTEST")

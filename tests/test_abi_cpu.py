@@ -115,3 +115,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libpcx_hip.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_blocks_library_exports_every_symbol_of_pcx_blocks_h():
+    """include/pcx_blocks.h (runner ABI of the host-side block layer) <-> libpcx_blocks.so, both directions"""
+    import subprocess
+    src = open(os.path.join(ROOT, "include", "pcx_blocks.h")).read()
+    declared = sorted(set(re.findall(r"PCXB_API\s+[\w\s\*]+?\b(pcxb_\w+)\s*\(", src)))
+    assert len(declared) >= 25 and "pcxb_work_ports" in declared
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "pothoscomms_amd", "libpcx_blocks.so")],
+                         capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("pcxb_"))
+    assert exported == declared

@@ -54,7 +54,7 @@ def _worker(rank, world, port, C, K, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,world", [(255, 2), (2, 2), (255, 4)])
+@pytest.mark.parametrize("K,world", [(255, 2), (2, 2), (255, 4), (255, 8)])
 def test_overlap_save_sharding_has_no_seam(K, world):
     """world 2 as the contract asks; world 4 also exercises interior ranks, which both send and receive"""
     from oracle import oracle as o

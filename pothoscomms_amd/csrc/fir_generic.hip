@@ -14,6 +14,7 @@
 // (fir_ols.hip) are the performance paths for complex_float32, M=L=1.
 #include "pcx_internal.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace pcx {
@@ -105,18 +106,42 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const S *__restrict__ 
 template <typename S, typename TT, bool FLT> struct SlideAcc { typedef S type; };
 template <typename S, typename TT> struct SlideAcc<S, TT, false> { typedef typename QComp<TT>::type type; };
 
-template <typename S, typename TT, bool CPLX, bool CTAPS, bool EXACT, bool MAD24, int R>
+// STAGE: the tile's 256*R + K-1 input elements are first copied into LDS with lane-contiguous loads (a lane's
+// own window walks global memory with a stride of R elements between lanes otherwise: poorly coalesced) and
+// the window reads come from there; the image is padded by one element per R so that the lane stride
+// R+1 elements is conflict-free for 4-, 8- and 16-byte elements.
+template <typename S, typename TT, bool CPLX, bool CTAPS, bool EXACT, bool MAD24, int R, bool STAGE>
 __global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in, S *__restrict__ out, size_t n_out, size_t K,
                                                         const TT *__restrict__ taps)
 {
     constexpr bool FLT = std::is_floating_point<S>::value;
     constexpr int EW = CPLX ? 2 : 1, TW = CTAPS ? 2 : 1;
     using C = typename SlideAcc<S, TT, FLT>::type;   // accumulator: S for floats, the unsigned compute type of Q otherwise
+    struct alignas(sizeof(S) * EW) Elem { S v[EW]; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Elem *img = reinterpret_cast<Elem *>(smem_raw);
     const size_t gstride = (size_t)gridDim.x * blockDim.x * R;
     const size_t last = n_out - 1;          // input index o + K-1-k <= last + K-1 always exists
-    for (size_t o0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * R; o0 < n_out; o0 += gstride) {
+    for (size_t o0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * R; o0 - (size_t)threadIdx.x * R < n_out; o0 += gstride) {
+        const size_t tile0 = o0 - (size_t)threadIdx.x * R;      // first output / input element of the workgroup's tile
+        if (STAGE) {
+            const size_t n_stage = (size_t)blockDim.x * R + K - 1;
+            __syncthreads();
+            for (size_t i = threadIdx.x; i < n_stage; i += blockDim.x) {
+                const size_t g = tile0 + i < last + K ? tile0 + i : last + K - 1;   // clamp past the call's last sample (unused)
+                img[i + i / R] = reinterpret_cast<const Elem *>(in)[g];
+            }
+            __syncthreads();
+        }
         C ar[R], ai[R], wr[R], wi[R];
         auto fetch = [&](size_t idx, C &re, C &im) {
+            if (STAGE) {
+                const size_t i = idx - tile0;
+                const Elem e = img[i + i / R];
+                if constexpr (FLT) { re = e.v[0]; im = CPLX ? e.v[EW - 1] : S(0); }
+                else { re = (C)(TT)e.v[0]; im = CPLX ? (C)(TT)e.v[EW - 1] : C(0); }
+                return;
+            }
             // idx may run past the last sample the call owns for the lanes of the ragged tail: clamp (unused)
             const size_t i = idx < last + K ? idx : last + K - 1;
             if constexpr (FLT) { re = in[i * EW]; im = CPLX ? in[i * EW + 1] : S(0); }
@@ -205,8 +230,16 @@ static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g
     const S *pin = (const S *)in;
     S *pout = (S *)out;
     const TT *tp = (const TT *)g.rowTaps;
-#define PCX_FIR_LAUNCH(CP, CT) \
-    hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R>), dim3(grid), dim3(256), 0, st, pin, pout, n_out, g.K, tp)
+    // staged tile image: (256 R + K - 1) elements, padded by one per R; PCX_FIR_STAGE=0 reads global memory directly (A/B)
+    static const int stage_on = [] { const char *e = getenv("PCX_FIR_STAGE"); return e ? atoi(e) : 1; }();
+    const size_t n_stage = (size_t)256 * R + g.K - 1;
+    const size_t lds = (n_stage + n_stage / R + 1) * sizeof(S) * (is_complex ? 2 : 1);
+    const bool stage = stage_on && lds <= 64 * 1024;
+#define PCX_FIR_LAUNCH(CP, CT)                                                                                                          \
+    do {                                                                                                                                \
+        if (stage) hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R, true>), dim3(grid), dim3(256), lds, st, pin, pout, n_out, g.K, tp); \
+        else hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R, false>), dim3(grid), dim3(256), 0, st, pin, pout, n_out, g.K, tp);     \
+    } while (0)
     if (!is_complex) PCX_FIR_LAUNCH(false, false);
     else if (!complex_taps) PCX_FIR_LAUNCH(true, false);
     else PCX_FIR_LAUNCH(true, true);

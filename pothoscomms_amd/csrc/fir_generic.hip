@@ -248,6 +248,85 @@ static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g
     return PCX_OK;
 }
 
+// --------------------------------------------------------------------------------- //
+// complex_int16 stream, COMPLEX taps whose Q16.16 image fits 16 bits (|tap| < 0.5: the usual case for
+// a unity-gain filter): one sample is one dword (re, im) and a complex multiply-accumulate is two packed
+// dot products,  ar += (c, d).(a, -b),  ai += (c, d).(b, a)  (v_dot2_i32_i16, wrapping like the reference's
+// complex<int32> accumulator, FIRFilter.cpp:296-300 with QType = int32).  Same LDS-staged sliding window
+// as fir_slide_kernel, half its multiply instructions and half its window registers.
+// tapsP[2k] = pack(a, -b), tapsP[2k+1] = pack(b, a) (low half first), built on the host.
+// --------------------------------------------------------------------------------- //
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n_out, size_t K,
+                                                            const uint32_t *__restrict__ tapsP)
+{
+    constexpr int R = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem_raw);
+    const size_t gstride = (size_t)gridDim.x * blockDim.x * R;
+    const size_t last = n_out - 1;
+    auto as_v = [](uint32_t u) { s16x2 v; __builtin_memcpy(&v, &u, 4); return v; };
+    for (size_t o0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * R; o0 - (size_t)threadIdx.x * R < n_out; o0 += gstride) {
+        const size_t tile0 = o0 - (size_t)threadIdx.x * R;
+        const size_t n_stage = (size_t)blockDim.x * R + K - 1;
+        __syncthreads();
+        for (size_t i = threadIdx.x; i < n_stage; i += blockDim.x) {
+            const size_t g = tile0 + i < last + K ? tile0 + i : last + K - 1;
+            img[i + i / R] = in[g];
+        }
+        __syncthreads();
+        int ar[R], ai[R];
+        uint32_t w[R];
+        const size_t l0 = (size_t)threadIdx.x * R;     // tile-local index of this lane's first output
+#pragma unroll
+        for (int r = 0; r < R; r++) { ar[r] = 0; ai[r] = 0; const size_t i = l0 + r + K - 1; w[r] = img[i + i / R]; }
+        for (size_t kb = 0; kb < K; kb += R) {
+            uint32_t nw[R];
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const size_t k = kb + u;
+                if (k + 1 < K) { const size_t i = l0 + K - 2 - k; nw[u] = img[i + i / R]; }
+                else nw[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < R; u++) {
+                const size_t k = kb + u;
+                if (k >= K) break;
+                const s16x2 t1 = as_v(tapsP[2 * k]), t2 = as_v(tapsP[2 * k + 1]);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const s16x2 x = as_v(w[(r - u + R) % R]);
+                    ar[r] = __builtin_amdgcn_sdot2(x, t1, ar[r], false);
+                    ai[r] = __builtin_amdgcn_sdot2(x, t2, ai[r], false);
+                }
+                w[(R - 1 - u + R) % R] = nw[u];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const size_t o = o0 + r;
+            if (o >= n_out) break;
+            // fromQ: arithmetic >> 16 of the wrapped int32, truncated to int16 (FIRFilter.cpp:300)
+            const uint32_t re = (uint32_t)(uint16_t)(int16_t)(ar[r] >> 16), im = (uint32_t)(uint16_t)(int16_t)(ai[r] >> 16);
+            out[o] = re | (im << 16);
+        }
+    }
+}
+int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, hipStream_t st)
+{
+    if (n_out == 0) return PCX_OK;
+    constexpr int R = 8;
+    const size_t n_stage = (size_t)256 * R + K - 1;
+    const size_t lds = (n_stage + n_stage / R + 1) * sizeof(uint32_t);
+    if (lds > 64 * 1024) { set_error("fir (int16 dot2): %zu taps exceed the LDS tile", K); return PCX_ERR_UNSUPPORTED; }
+    size_t gsz = (n_out + 256 * R - 1) / (256 * R);
+    if (gsz > (1u << 20)) gsz = 1u << 20;
+    hipLaunchKernelGGL(fir_ci16_dot2_kernel, dim3((unsigned)gsz), dim3(256), lds, st, (const uint32_t *)in, (uint32_t *)out, n_out, K,
+                       (const uint32_t *)tapsP);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 // M = L = 1 entry: `taps24` = every Q tap fits 24 signed bits (int16 / int8 element types)
 int launch_fir_slide(int scalar, int is_complex, int complex_taps, bool exact, bool taps24, const FirGeom &g, const void *in,
                      void *out, size_t n_out, hipStream_t st)

@@ -513,14 +513,17 @@ def test_fir_randomised_configurations(oracle, dev, seed):
         assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("big", [0, 1, 2])
 def test_fir_int16_tap_magnitude_paths(oracle, dev, big):
-    """int16 streams: Q16.16 taps below 128 in magnitude take the 24-bit multiply path, larger ones the
-    32-bit one; both wrap exactly like the oracle's ring arithmetic."""
+    """int16 streams: complex Q16.16 taps below 0.5 in magnitude take the packed dot-product kernel, taps below
+    128 the 24-bit multiply path, larger ones the 32-bit one; all wrap exactly like the oracle's ring arithmetic."""
     rng = np.random.default_rng(77 + big)
     n, K = 50001, 37
     x = rand_stream(rng, oracle.I16, n, True)
-    taps = (rng.standard_normal(K) + 1j * rng.standard_normal(K)) * (300.0 if big else 0.4)
+    taps = (rng.standard_normal(K) + 1j * rng.standard_normal(K)) * [0.4, 300.0, 0.1][big]
+    if big == 2:
+        taps = np.clip(taps.real, -0.49, 0.49) + 1j * np.clip(taps.imag, -0.49, 0.49)
+        taps[3] = 0.4999 - 0.4999j         # extremes of the 16-bit range
     ref = oracle.Fir(oracle.I16, True, True); ref.set_taps(taps); ref.activate()
     want, rc, rp, _ = ref.work(x, n)
     f = dev.FirFilter("complex_int16", "COMPLEX"); f.set_taps(taps)

@@ -249,17 +249,22 @@ static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g
 }
 
 // --------------------------------------------------------------------------------- //
-// complex_int16 stream, COMPLEX taps whose Q16.16 image fits 16 bits (|tap| < 0.5: the usual case for
+// complex_int16 (and complex_int8) stream, COMPLEX taps whose Q16.16 (Q8.8) image fits 16 bits (|tap| < 0.5: the usual case for
 // a unity-gain filter): one sample is one dword (re, im) and a complex multiply-accumulate is two packed
 // dot products,  ar += (c, d).(a, -b),  ai += (c, d).(b, a)  (v_dot2_i32_i16, wrapping like the reference's
 // complex<int32> accumulator, FIRFilter.cpp:296-300 with QType = int32).  Same LDS-staged sliding window
 // as fir_slide_kernel, half its multiply instructions and half its window registers.
 // tapsP[2k] = pack(a, -b), tapsP[2k+1] = pack(b, a) (low half first), built on the host.
 // --------------------------------------------------------------------------------- //
+// IN8: complex_int8 stream (QType = int16, Q8.8 taps always fit 16 bits): samples are widened to 16-bit pairs
+// while the tile is staged, the int32 dot products carry the reference's int16 accumulator in their low half.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n_out, size_t K,
+template <bool IN8>
+__global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const void *__restrict__ in_v, void *__restrict__ out_v, size_t n_out, size_t K,
                                                             const uint32_t *__restrict__ tapsP)
 {
+    const uint32_t *in = static_cast<const uint32_t *>(in_v);
+    uint32_t *out = static_cast<uint32_t *>(out_v);
     constexpr int R = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *img = reinterpret_cast<uint32_t *>(smem_raw);
@@ -272,7 +277,13 @@ __global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const uint32_t *__re
         __syncthreads();
         for (size_t i = threadIdx.x; i < n_stage; i += blockDim.x) {
             const size_t g = tile0 + i < last + K ? tile0 + i : last + K - 1;
-            img[i + i / R] = in[g];
+            if (IN8) {
+                const uint16_t v = static_cast<const uint16_t *>(in_v)[g];
+                const int re = (int8_t)(v & 0xff), im = (int8_t)(v >> 8);
+                img[i + i / R] = (uint32_t)(uint16_t)(int16_t)re | ((uint32_t)(uint16_t)(int16_t)im << 16);
+            } else {
+                img[i + i / R] = in[g];
+            }
         }
         __syncthreads();
         int ar[R], ai[R];
@@ -306,13 +317,19 @@ __global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const uint32_t *__re
         for (int r = 0; r < R; r++) {
             const size_t o = o0 + r;
             if (o >= n_out) break;
-            // fromQ: arithmetic >> 16 of the wrapped int32, truncated to int16 (FIRFilter.cpp:300)
-            const uint32_t re = (uint32_t)(uint16_t)(int16_t)(ar[r] >> 16), im = (uint32_t)(uint16_t)(int16_t)(ai[r] >> 16);
-            out[o] = re | (im << 16);
+            if (IN8) {
+                // QType int16: the accumulator is the low half of the int32 sum; fromQ = >> 8, truncated to int8
+                const uint32_t re = (uint8_t)(int8_t)((int16_t)ar[r] >> 8), im = (uint8_t)(int8_t)((int16_t)ai[r] >> 8);
+                static_cast<uint16_t *>(out_v)[o] = (uint16_t)(re | (im << 8));
+            } else {
+                // fromQ: arithmetic >> 16 of the wrapped int32, truncated to int16 (FIRFilter.cpp:300)
+                const uint32_t re = (uint32_t)(uint16_t)(int16_t)(ar[r] >> 16), im = (uint32_t)(uint16_t)(int16_t)(ai[r] >> 16);
+                out[o] = re | (im << 16);
+            }
         }
     }
 }
-int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, hipStream_t st)
+int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, bool in8, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     constexpr int R = 8;
@@ -321,8 +338,8 @@ int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, cons
     if (lds > 64 * 1024) { set_error("fir (int16 dot2): %zu taps exceed the LDS tile", K); return PCX_ERR_UNSUPPORTED; }
     size_t gsz = (n_out + 256 * R - 1) / (256 * R);
     if (gsz > (1u << 20)) gsz = 1u << 20;
-    hipLaunchKernelGGL(fir_ci16_dot2_kernel, dim3((unsigned)gsz), dim3(256), lds, st, (const uint32_t *)in, (uint32_t *)out, n_out, K,
-                       (const uint32_t *)tapsP);
+    if (in8) hipLaunchKernelGGL(fir_ci16_dot2_kernel<true>, dim3((unsigned)gsz), dim3(256), lds, st, in, out, n_out, K, (const uint32_t *)tapsP);
+    else hipLaunchKernelGGL(fir_ci16_dot2_kernel<false>, dim3((unsigned)gsz), dim3(256), lds, st, in, out, n_out, K, (const uint32_t *)tapsP);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

@@ -226,7 +226,7 @@ struct pcx_fir {
     DevBuf HspecRows;
     int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
     bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
-    bool taps16 = false;      // complex_int16 stream, complex taps within +-32767 after floatToQ (v_dot2_i32_i16 path)
+    bool taps16 = false;      // complex_int16 / complex_int8 stream, complex taps within +-32767 after floatToQ (v_dot2_i32_i16 path)
     DevBuf tapsP;             // packed (a, -b), (b, a) pairs for that path
 };
 
@@ -283,7 +283,7 @@ static int fir_upload_rows(pcx_fir *h, bool integer)
         for (const TT &t : rows)
             if ((long long)t < -(1ll << 23) || (long long)t >= (1ll << 23)) { h->taps24 = false; break; }
     h->taps16 = false;
-    if (integer && h->scalar == PCX_I16 && h->cplx && h->ctaps && L == 1 && h->M == 1) {
+    if (integer && (h->scalar == PCX_I16 || h->scalar == PCX_I8) && h->cplx && h->ctaps && L == 1 && h->M == 1) {
         bool ok = true;
         for (const TT &t : rows)
             if ((long long)t < -32767 || (long long)t > 32767) { ok = false; break; }
@@ -490,7 +490,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // PCX_FIR_DOT2=0 keeps complex_int16 on the 24-bit multiply path (A/B)
         static const int dot2 = [] { const char *e = getenv("PCX_FIR_DOT2"); return e ? atoi(e) : 1; }();
         if (slide && dot2 && h->taps16 && h->L == 1 && h->M == 1 && h->K <= 12000)
-            rc = launch_fir_ci16_dot2(in_dev, out_dev, n_out, h->K, h->tapsP.p, st);
+            rc = launch_fir_ci16_dot2(in_dev, out_dev, n_out, h->K, h->tapsP.p, h->scalar == PCX_I8, st);
         else if (slide && h->L == 1 && h->M == 1)
             rc = launch_fir_slide(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, h->taps24, g, in_dev, out_dev, n_out, st);
         else

@@ -115,7 +115,7 @@ struct FirGeom {
 int launch_fir_generic(int scalar, int is_complex, int complex_taps, bool exact, const FirGeom &g, const void *in,
                        void *out, size_t n_out, hipStream_t st);
 // complex_int16 stream, complex taps within int16 after floatToQ, M = L = 1: packed dot-product kernel; tapsP = 2K dwords
-int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, hipStream_t st);
+int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, bool in8, hipStream_t st);
 // M = L = 1, every type: register sliding window (fir_generic.hip); taps24 = all Q taps fit 24 signed bits
 int launch_fir_slide(int scalar, int is_complex, int complex_taps, bool exact, bool taps24, const FirGeom &g, const void *in,
                      void *out, size_t n_out, hipStream_t st);

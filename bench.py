@@ -257,7 +257,7 @@ def main():
                          "algorithmic_bytes_per_launch": roof_bytes},
         }
         if world == 1 and not args.no_cpu and wl in ("fir255", "direct255"):
-            out["cpu_baseline"] = cpu_baseline_fir(tp.c1_taps(), 2, 32 * 1024 * 1024)
+            out["cpu_baseline"] = cpu_baseline_fir(tp.c1_taps(), 2, min(C, 64 * 1024 * 1024))   # the whole 64 Mi-sample shard: ~11 s on one core
         elif world == 1 and not args.no_cpu:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -26,6 +26,11 @@
  *     calls from any thread run on that device and leave the caller's current
  *     device unchanged, so a single Pothos process can place blocks on
  *     different GPUs.
+ *   - input and output buffers of one call must not overlap, with two exceptions the reference
+ *     relies on or that cost nothing: the same-size element-wise maps (rotate, scale, conj, arith)
+ *     accept out == in exactly (Arithmetic forwards input 0's buffer, Arithmetic.cpp:157-158), and
+ *     the FFT accepts out == in.  abs/angle (narrower output), FIR, FreqDemod and the fused chain
+ *     read what another lane may already have overwritten: no aliasing.
  *   - there is NO CPU fallback: a type/size the device path does not implement
  *     returns PCX_ERR_UNSUPPORTED.
  */

@@ -559,3 +559,27 @@ def test_fft_int16_one_bin_is_not_the_identity(oracle, dev):
         assert np.array_equal(dev.Fft("complex_int16", 1, inverse).transform(x), want)
     xf = np.array([[1.5, -2.25]], np.float32)
     assert np.array_equal(dev.Fft("complex_float32", 1, False).transform(xf), xf)     # float: leaf copy
+
+
+def test_documented_in_place_calls(oracle, dev):
+    """include/pcx.h: same-size maps and the FFT accept out == in on device buffers"""
+    import torch
+    d = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    n = 70001
+    x = rand_stream(rng, oracle.F32, n, True)
+    t = torch.from_numpy(x).to(d)
+    dev.rotate(t, 0.9, scalar=dev.F32, out=t, n=n)
+    assert np.array_equal(t.cpu().numpy(), oracle.rotate(x, 0.9))
+    t = torch.from_numpy(x).to(d)
+    dev.conj(t, scalar=dev.F32, out=t, n=n)
+    assert np.array_equal(t.cpu().numpy(), oracle.conj(x))
+    for nbins, nframes in ((4096, 9), (256, 40), (1000, 5), (32768, 2)):
+        xf = rand_stream(rng, oracle.F32, nbins * nframes, True)
+        tf = torch.from_numpy(xf).to(d)
+        dev.Fft("complex_float32", nbins, False).transform_dev(tf, tf, nframes)
+        assert nerr(tf.cpu().numpy(), oracle.fft(xf, nbins, False)) <= TOL, nbins
+    xi = rand_stream(rng, oracle.I16, 1024 * 7, True)
+    ti = torch.from_numpy(xi).to(d)
+    dev.Fft("complex_int16", 1024, False).transform_dev(ti, ti, 7)
+    assert np.array_equal(ti.cpu().numpy(), oracle.fft(xi, 1024, False))

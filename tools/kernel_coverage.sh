@@ -1,0 +1,13 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/cov; mkdir -p gpurun_out/cov
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/cov/kt -- python3 -m pytest tests -q -x -m gpu -p no:cacheprovider --deselect tests/test_stream_gpu.py --deselect tests/test_c_client_gpu.py > gpurun_out/cov/log.txt 2>&1
+python3 - <<'PY'
+import csv, glob, re
+names=set()
+for f in glob.glob("gpurun_out/cov/kt/**/*_kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        names.add(re.sub(r"[<(].*", "", n))
+open("gpurun_out/cov/kernels_hit.txt","w").write("\n".join(sorted(names))+"\n")
+PY
+find gpurun_out/cov -name "*.csv" -delete

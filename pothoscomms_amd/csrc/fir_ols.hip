@@ -18,6 +18,7 @@
 // The kernel runs at the package power cap: what remains above the load+store
 // floor is clock, not scheduling.
 #include "fft4096.hpp"
+#include <cstdio>
 #include <cstdlib>
 
 #include "pcx_internal.hpp"
@@ -189,7 +190,13 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     // 10/11 compute-only / memory-only timing builds (plain accesses), 12/13 the same with the default policy,
     // 14 XCD-aware block walk + default policy, 15/16 butterflies-only / exchanges-only on the real stream.
     // PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
-    static const int variant = [] { const char *e = getenv("PCX_OLS_VARIANT"); return e ? atoi(e) : -1; }();
+    static const int variant = [] {
+        const char *e = getenv("PCX_OLS_VARIANT");
+        const int v = e ? atoi(e) : -1;
+        if (v == 10 || v == 11 || v == 12 || v == 13 || v == 15 || v == 16)
+            fprintf(stderr, "pcx: PCX_OLS_VARIANT=%d selects a TIMING-ONLY build of the overlap-save FIR: its outputs are wrong\n", v);
+        return v;
+    }();
     static const int align = [] { const char *e = getenv("PCX_OLS_ALIGN"); return e ? atoi(e) : 1; }();
     const size_t Km1 = K - 1;
     const size_t Kov = align ? (Km1 + 15) / 16 * 16 : Km1;   // <= 2048

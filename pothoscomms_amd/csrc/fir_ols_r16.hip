@@ -18,6 +18,7 @@
 // spectrum is multiplied by the lane's 16 bins of H (32 VGPRs, loaded once per persistent
 // workgroup) and inverse-transformed (conj . FFT . conj) without leaving registers.
 #include "fft4096.hpp"
+#include <cstdio>
 #include <cstdlib>
 
 #include "pcx_internal.hpp"
@@ -230,7 +231,12 @@ int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n
 {
     if (n_out == 0) return PCX_OK;
     // PCX_OLS_DIAG (timing-only builds, wrong outputs): 1 compute floor, 2 memory floor
-    static const int diag = [] { const char *e = getenv("PCX_OLS_DIAG"); return e ? atoi(e) : 0; }();
+    static const int diag = [] {
+        const char *e = getenv("PCX_OLS_DIAG");
+        const int v = e ? atoi(e) : 0;
+        if (v) fprintf(stderr, "pcx: PCX_OLS_DIAG=%d selects a TIMING-ONLY build of the overlap-save FIR: its outputs are wrong\n", v);
+        return v;
+    }();
     switch (log2n) {
     case 10: return launch_ols<10>(in, in_elems, out, n_out, Hspec, K, tw, st, diag);
     case 11: return launch_ols<11>(in, in_elems, out, n_out, Hspec, K, tw, st, diag);

@@ -254,7 +254,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(wl),
                          "kernel": kernel_name, "avg_launch_ms": round(avg_ms, 4),
-                         "algorithmic_bytes_per_launch": roof_bytes},
+                         "algorithmic_bytes_per_launch": roof_bytes,
+                         "bytes_counted": "algorithmic read + write (SURVEY 8d); the read stream alone is the smaller share"},
         }
         if world == 1 and not args.no_cpu and wl in ("fir255", "direct255"):
             out["cpu_baseline"] = cpu_baseline_fir(tp.c1_taps(), 2, min(C, 64 * 1024 * 1024))   # the whole 64 Mi-sample shard: ~11 s on one core

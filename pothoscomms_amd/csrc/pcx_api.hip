@@ -463,7 +463,9 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // filter must return its input bit for bit, as the reference does
         if (fast && h->K == 1) algo = PCX_FIR_DIRECT;
         else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1)) algo = PCX_FIR_OLS_FFT;
-        else if (fast) algo = PCX_FIR_DIRECT;
+        // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
+        // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
+        else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
     if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols)) {
@@ -481,7 +483,9 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         rc = launch_fir_cf32_ols_r16(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {
         rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
-    } else if (algo == PCX_FIR_DIRECT && fast) {
+    } else if (algo == PCX_FIR_DIRECT && fast && (2048 + h->Kp + 8) * 9 / 8 * 8 + 64 <= 64 * 1024) {
+        // the LDS-tiled time-domain kernel while its tile (2048 outputs + taps) fits; longer filters than every
+        // fast plan (K > 8193) take the sliding-window kernel below
         rc = launch_fir_cf32_direct(in_dev, used_in, out_dev, n_out, h->tapsRev.p, h->K, h->Kp, st);
     } else {
         FirGeom g{h->L, h->M, h->K, static_cast<const uint32_t *>(h->rowLen.p), h->rowTaps.p};

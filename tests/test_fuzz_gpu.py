@@ -228,3 +228,76 @@ def test_scale_rotate_extreme_coefficients(oracle, dev, seed):
     if cplx:
         phase = float(rng.uniform(-1, 1)) * 10.0 ** float(rng.uniform(-8, 6))
         assert np.array_equal(dev.rotate(x, phase), oracle.rotate(x, phase)), (scalar, phase)
+
+
+ARITH_NP = [np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32, np.uint64, np.float32, np.float64]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_arith_split_combine_random(oracle, dev, seed):
+    rng = np.random.default_rng(2000 + seed)
+    dt = np.dtype(ARITH_NP[seed % 10])
+    cplx = bool(rng.integers(0, 2))
+    n = int(rng.integers(1, 40000))
+    shape = (n, 2) if cplx else (n,)
+    op = ["ADD", "SUB", "MUL", "DIV"][int(rng.integers(0, 4))]
+    if dt.kind == "f":
+        a = (rng.standard_normal(shape) * 10.0 ** rng.uniform(-3, 3)).astype(dt)
+        b = (rng.standard_normal(shape) * 10.0 ** rng.uniform(-3, 3)).astype(dt)
+        if op == "DIV":
+            b = np.where(np.abs(b) < 1e-3, dt.type(1.5), b).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, size=shape, dtype=dt, endpoint=True)
+        b = rng.integers(info.min, info.max, size=shape, dtype=dt, endpoint=True)
+        if op == "DIV":
+            small = rng.integers(-9 if info.min < 0 else 1, 10, size=shape)
+            b = np.where(small == 0, 3, small).astype(dt)
+            a = (a // 4).astype(dt)
+    got = dev.arith(op, a, b, cplx)
+    ref = oracle.arith(getattr(oracle, op), a, b, cplx)
+    if dt.kind == "f" and op == "DIV":
+        assert np.allclose(got, ref, rtol=1e-5, atol=0), (dt, cplx)      # stated bar; extreme ratios may leave the bit-identical range
+    else:
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (dt, cplx, op)
+    if dt.kind != "u":
+        re, im = a.reshape(-1)[:n], b.reshape(-1)[:n]
+        z = dev.combine_complex(re, im)
+        assert np.array_equal(z.view(np.uint8), oracle.combine_complex(re, im).view(np.uint8))
+        r2, i2 = dev.split_complex(z)
+        assert np.array_equal(r2.view(np.uint8), np.ascontiguousarray(re).view(np.uint8)) and np.array_equal(i2.view(np.uint8), np.ascontiguousarray(im).view(np.uint8))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fir_edge_geometries(oracle, dev, seed):
+    """few samples, K close to or beyond the buffer, long taps on every plan boundary, tiny output room"""
+    rng = np.random.default_rng(1000 + 7 * seed)
+    K = int([1, 2, 15, 16, 17, 255, 256, 257, 2048, 2049, 2050, 4096, 4097, 4098, 8192, 8193, 8194][seed % 17])
+    extra = int(rng.integers(0, 3)) * int(rng.integers(0, 9000))
+    n_in = max(1, K - 1 + int(rng.integers(-2, 3)) + extra)
+    out_cap = int(rng.integers(0, 3)) * int(rng.integers(1, 10000)) + int(rng.integers(0, 2))
+    ctaps = bool(rng.integers(0, 2))
+    taps = (rng.normal(size=K) + (1j * rng.normal(size=K) if ctaps else 0)) / np.sqrt(K)
+    x = rand_stream(rng, oracle.F32, n_in, True)
+    ref = oracle.Fir(oracle.F32, True, ctaps); ref.set_taps(taps); ref.activate()
+    f = dev.FirFilter("complex_float32", "COMPLEX" if ctaps else "REAL"); f.set_taps(taps)
+    want, rc, rp, _ = ref.work(x, out_cap)
+    got, gc, gp = f.process(x, out_cap)
+    assert (gc, gp) == (rc, rp), (K, n_in, out_cap)
+    if rp:
+        # with a handful of outputs max|ref| can be a single heavily cancelled value (seed 430: one output of
+        # 0.007 from 255 unit-scale products) and the 1e-5 bar degenerates; floor the scale at 10 % of the
+        # filter's typical output level sqrt(sum |h|^2) * rms(x)
+        typical = float(np.sqrt(np.sum(np.abs(taps) ** 2)) * np.sqrt(np.mean(x.astype(np.float64) ** 2) * 2))
+        scale = max(float(np.abs(want).max()), 0.1 * typical)
+        # thousands of taps: the reference's sequential float32 sum is itself 1e-5..5e-5 away from the exact
+        # convolution (seed 3771: 4.3e-5 at K = 8192, the device 2.7e-6), so the device is held to the 1e-5 bar
+        # against a float64 sum on a few outputs and to the reference within the reference's own error
+        idx = np.unique(np.linspace(0, rp - 1, min(rp, 24)).astype(int))
+        h = taps.astype(np.complex64).astype(np.complex128) if ctaps else taps.astype(np.float32).astype(np.float64)
+        xc = x[:, 0].astype(np.float64) + 1j * x[:, 1].astype(np.float64)
+        exact = np.array([np.dot(h, xc[n + K - 1 - np.arange(K)]) for n in idx])
+        ex = np.stack([exact.real, exact.imag], 1)
+        ref_noise = float(np.abs(want[idx] - ex).max())
+        assert float(np.abs(got[idx] - ex).max()) <= TOL * scale, (K, n_in, out_cap)
+        assert float(np.abs(got - want).max()) <= TOL * scale + 2.0 * ref_noise, (K, n_in, out_cap)

@@ -943,6 +943,11 @@ struct pcx_fmchain {
     int cur = 0;
     int algo = PCX_FIR_AUTO, last_algo = 0;
     bool have_ols = false;
+    // filters longer than the fused kernels' plans (K > 2048): the FIR stage as its own launch (any K),
+    // FreqDemod behind it on the same carried state
+    pcx_fir *long_fir = nullptr;
+    DevBuf long_y;
+    ~pcx_fmchain() { delete long_fir; }
 };
 int pcx_fmchain_create(pcx_fmchain **out)
 {
@@ -1008,6 +1013,13 @@ static int fmchain_sync(pcx_fmchain *h)
         PCX_TRY(upload(h->Hspec, make_hspec4096(g)));
         PCX_TRY(upload(h->tw4096, make_tw4096()));
         h->have_ols = true;
+    } else {
+        // unfused long-filter path: complex taps g = p * h through the FIR handle (frequency-domain plans to
+        // 8193 taps, the reference-order kernel beyond)
+        if (!h->long_fir) PCX_TRY(pcx_fir_create(PCX_F32, 1, 1, &h->long_fir));
+        std::vector<double> g(2 * K);
+        for (size_t m = 0; m < K; m++) { g[2 * (K - 1 - m)] = (double)rev[2 * m]; g[2 * (K - 1 - m) + 1] = (double)rev[2 * m + 1]; }
+        PCX_TRY(pcx_fir_set_taps(h->long_fir, g.data(), K));
     }
     h->dirty = false;
     return PCX_OK;
@@ -1033,7 +1045,19 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     char *base = static_cast<char *>(h->prev.p);
     int algo = h->algo;
-    if (algo == PCX_FIR_AUTO) algo = h->have_ols ? PCX_FIR_OLS_FFT : PCX_FIR_DIRECT;
+    if (algo == PCX_FIR_AUTO && !h->have_ols) {
+        // K > 2048: two launches (FIR with the folded phasor, then FreqDemod) sharing the chain's carried state
+        size_t c2 = 0, p2 = 0;
+        PCX_TRY(h->long_y.ensure(N * 8));
+        PCX_TRY(pcx_fir_process_dev(h->long_fir, in_dev, N + h->K - 1, h->long_y.p, N, &c2, &p2, stream));
+        if (c2 != N || p2 != N) { set_error("fm chain: FIR stage produced %zu of %zu", p2, N); return PCX_ERR_STATE; }
+        PCX_TRY(launch_freqdemod(PCX_F32, h->long_y.p, out_dev, N, base + 32 * h->cur, base + 32 * (h->cur ^ 1), as_stream(stream)));
+        h->last_algo = PCX_FIR_AUTO;
+        h->cur ^= 1;
+        *consumed = N; *produced = N;
+        return PCX_OK;
+    }
+    if (algo == PCX_FIR_AUTO) algo = PCX_FIR_OLS_FFT;
     if (algo == PCX_FIR_OLS_FFT) {
         if (!h->have_ols) { set_error("fm chain: OLS_FFT needs K <= 2048"); return PCX_ERR_UNSUPPORTED; }
         PCX_TRY(launch_fmchain_cf32_ols4096(in_dev, N + h->K - 1, out_dev, N, h->Hspec.p, h->K, h->tw4096.p, base + 32 * h->cur,

@@ -83,8 +83,10 @@ def test_fm_chain_random_chunks(oracle, dev, seed):
     from pothoscomms_amd import taps as tp
     rng = np.random.default_rng(8000 + seed)
     ntaps = int(rng.integers(1, 400))
+    if seed % 9 == 4:
+        ntaps = int(rng.integers(1500, 9000))      # both fused plans' limits and the unfused long-filter path
     ctaps = bool(rng.integers(0, 2))
-    n = int(rng.integers(ntaps + 1, 40000))
+    n = int(rng.integers(ntaps + 1, ntaps + 40000))
     x = tp.fm_test_signal(n, seed=seed)
     taps = tp.complex_bandpass(ntaps, 0.1, 0.03) if ctaps else tp.lowpass(ntaps, 0.1)
     if ntaps < 3:
@@ -96,6 +98,8 @@ def test_fm_chain_random_chunks(oracle, dev, seed):
     ref = oracle.FreqDemod(oracle.F32).work(y)
     ch = dev.FmChain(); ch.set_phase(phase); ch.set_taps(taps, ctaps)
     algo = [dev._lib.FIR_AUTO, dev._lib.FIR_OLS_FFT, dev._lib.FIR_DIRECT][seed % 3]
+    if ntaps > 2048:
+        algo = dev._lib.FIR_AUTO
     ch.set_algo(algo)
     xp = x.view(np.float32).reshape(-1, 2) if np.iscomplexobj(x) else x
     pos, outs = 0, []

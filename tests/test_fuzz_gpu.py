@@ -305,3 +305,43 @@ def test_fir_edge_geometries(oracle, dev, seed):
         ref_noise = float(np.abs(want[idx] - ex).max())
         assert float(np.abs(got[idx] - ex).max()) <= TOL * scale, (K, n_in, out_cap)
         assert float(np.abs(got - want).max()) <= TOL * scale + 2.0 * ref_noise, (K, n_in, out_cap)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fft_and_demod_blocks_random_chunks(oracle, seed):
+    """/comms/fft consumes and produces whole frames only, whatever the buffer sizes (FFT.cpp:61-72);
+    /comms/freq_demod carries _prev across work() calls (FreqDemod.cpp:49-71)"""
+    from pothoscomms_amd import blocks as B
+    rng = np.random.default_rng(500 + seed)
+    nbins = int([8, 64, 100, 256, 1000, 1024, 4096][seed % 7])
+    inverse = bool(rng.integers(0, 2))
+    nframes = int(rng.integers(1, 12))
+    x = rand_stream(rng, oracle.F32, nbins * nframes + int(rng.integers(0, nbins)), True)
+    blk = B.make("/comms/fft", "complex_float32", nbins, inverse)
+    blk.activate()
+    pos, avail, outs, guard = 0, 0, [], 0
+    while guard < 200:
+        guard += 1
+        avail = min(len(x), avail + int(rng.integers(1, 3 * nbins)))
+        room = int(rng.integers(0, 4 * nbins))
+        y, c, p, _, _ = blk.work(x[pos:avail], room)
+        whole = min(avail - pos, room) // nbins * nbins
+        assert c == p == whole, (nbins, avail - pos, room)
+        outs.append(y); pos += c
+        if avail == len(x) and len(x) - pos < nbins:
+            break
+    got = np.concatenate(outs) if outs else np.zeros((0, 2), np.float32)
+    nf = len(got) // nbins
+    assert nf == nframes or guard >= 200
+    if nf:
+        assert nerr(got, oracle.fft(x[:nf * nbins], nbins, inverse)) <= TOL
+    # FreqDemod block on an int16 stream: bit-exact across arbitrary cuts
+    n = int(rng.integers(1, 20000))
+    xi = rand_stream(rng, oracle.I16, n, True)
+    dm, ref = B.make("/comms/freq_demod", "complex_int16"), oracle.FreqDemod(oracle.I16)
+    dm.activate(); ref.activate()
+    cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 6)))]))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        y, c, p, _, _ = dm.work(xi[a:b], b - a)
+        assert (c, p) == (b - a, b - a)
+        assert np.array_equal(y, ref.work(xi[a:b]))

@@ -35,6 +35,11 @@ struct Plan {
     // so loading them straight from global memory touches 64 lines per wave-instruction (measured 0.5 TB/s
     // at 16 bins).  The 256 lanes' frames are one contiguous 32 KiB chunk: copied in and out with
     // lane-contiguous 16-byte accesses through a padded LDS image (i + i/16) that shares the exchange space.
+    // 8192 / 16384 bins: one frame takes 8 / 16 waves, so a second resident frame (8192) or any at all (16384)
+    // needs <= 128 VGPRs: the Ns = 16 pass's 15 lane constants (they depend on l & 15 only) come from a
+    // 1.9 KB LDS table instead of 30 registers, and the register budget is pinned with launch bounds
+    static constexpr bool T2_LDS = LOG2N >= 13;
+    static constexpr int T2_ELEMS = T2_LDS ? 240 : 0;
     static constexpr bool STAGED = LOG2N <= 6;
     static constexpr int STAGE = STAGED ? 4096 + 4096 / 16 : 0;
     static constexpr int NTWF = R > 1 ? (16 / R) * (R - 1) : 0;   // final-pass twiddles per lane
@@ -46,7 +51,7 @@ struct Plan {
 };
 
 template <int LOG2N, bool INV, int SAUX>
-__global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS, Plan<LOG2N>::THREADS >= 512 ? 4 : 1) void fft_r16_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                        size_t nframes, const float2 *__restrict__ twtab)
 {
     typedef Plan<LOG2N> P;
@@ -61,7 +66,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const flo
     // lane constants
     LaneTw t2, t3;
     cf tf[P::NTWF > 0 ? P::NTWF : 1];
-    if (A >= 2) {
+    cf *t2tab = lds_all + (size_t)P::LDS_FRAME * FPW;    // behind the frame images (T2_LDS plans)
+    if (A >= 2 && P::T2_LDS) {
+        for (int i = tid; i < 240; i += P::THREADS) t2tab[i] = tab[P::T2_OFF + i];
+    } else if (A >= 2) {
 #pragma unroll
         for (int p = 0; p < 3; p++) t2.a[p] = tab[P::T2_OFF + p * 16 + (l & 15)];
 #pragma unroll
@@ -124,7 +132,16 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_r16_kernel(const flo
             __syncthreads();
 #pragma unroll
             for (int s = 0; s < 16; s++) v[s] = lds[l + (l >> 4) + s * (LPF + LPF / 16)];
-            fft16_tw(v, t2);
+            if (P::T2_LDS) {
+                LaneTw tl;     // first used behind at least two barriers after the table was staged
+#pragma unroll
+                for (int p = 0; p < 3; p++) tl.a[p] = t2tab[p * 16 + (l & 15)];
+#pragma unroll
+                for (int p = 0; p < 12; p++) tl.c[p] = t2tab[(3 + p) * 16 + (l & 15)];
+                fft16_tw(v, tl);
+            } else {
+                fft16_tw(v, t2);
+            }
             if (!(A == 2 && R == 1)) {
                 __syncthreads();
                 const int wb = (l >> 4) * 272 + (l & 15);
@@ -203,7 +220,7 @@ template <int LOG2N>
 int launch_r16(const void *in, void *out, size_t nframes, bool inverse, const void *tw, hipStream_t st)
 {
     typedef Plan<LOG2N> P;
-    size_t lds = (size_t)P::LDS_FRAME * P::FPW * sizeof(cf);
+    size_t lds = ((size_t)P::LDS_FRAME * P::FPW + P::T2_ELEMS) * sizeof(cf);
     if ((size_t)P::STAGE * sizeof(cf) > lds) lds = (size_t)P::STAGE * sizeof(cf);
     // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
     static const int saux = [] { const char *e = getenv("PCX_FFT_STORE_AUX"); return e ? atoi(e) : 2; }();

@@ -536,7 +536,7 @@ struct pcx_fft {
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
-    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, FOURSTEP } kind = MIXED;
+    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, FOURSTEP, FOURSTEP_SHORT } kind = MIXED;
     int log2n = 0;
     DevBuf tw, perm, wsIn, wsOut;
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
@@ -544,6 +544,9 @@ struct pcx_fft {
     size_t n1 = 0, n2 = 0;
     pcx_fft *sub1 = nullptr, *sub2 = nullptr;
     DevBuf ws1, ws2;
+    // FOURSTEP_SHORT (complex_float32, numBins <= 4 Mi): n1 = 256 columns pass with strided I/O (fft_large.hip),
+    // then rows of n2 -- with the final transpose on their store when n2 <= 256, else sub2 + one transpose
+    DevBuf tw1, tw2;
     ~pcx_fft() { delete sub1; delete sub2; }
 };
 // longest power-of-two transform one workgroup handles
@@ -586,6 +589,23 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     int rc = PCX_OK;
     if (num_bins == 1) {
         h->kind = pcx_fft::IDENTITY;
+    } else if (four_step && scalar == PCX_F32 && num_bins <= ((size_t)4 << 20) && !getenv("PCX_FFT_FIVE_PASS")) {
+        h->kind = pcx_fft::FOURSTEP_SHORT;
+        static const size_t n1_forced = [] { const char *e = getenv("PCX_FFT_N1"); return e ? (size_t)atoi(e) : (size_t)0; }();
+        // measured (tools/sweep_fft.py): 128 columns per tile (256-byte runs) beat 256 except where only n1 = 256
+        // leaves n2 <= 256 (65,536 bins: two passes instead of three) or n2 would exceed the 16384-bin plans
+        h->n1 = num_bins == 65536 ? 256 : 128;
+        if (n1_forced == 128 || n1_forced == 256) h->n1 = n1_forced;
+        if (num_bins / h->n1 > 16384) h->n1 = 256;
+        h->n2 = num_bins / h->n1;                // 128 ... 16384
+        rc = upload(h->tw1, make_tw_r16(h->n1 == 128 ? 7 : 8));
+        if (rc == PCX_OK && h->n2 <= 256) {
+            int l2 = 0;
+            while (((size_t)1 << l2) < h->n2) l2++;
+            rc = upload(h->tw2, make_tw_r16(l2));
+        } else if (rc == PCX_OK) {
+            rc = pcx_fft_create(scalar, h->n2, inverse, &h->sub2);
+        }
     } else if (four_step) {
         h->kind = pcx_fft::FOURSTEP;
         int l2 = 0;
@@ -670,6 +690,20 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
                                     : launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
     case pcx_fft::Q15_POW2:
         return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
+    case pcx_fft::FOURSTEP_SHORT: {
+        const size_t bytes = nframes * h->nbins * 8;
+        PCX_TRY(h->ws1.ensure(bytes));
+        // columns of the n1 x n2 view (transform along n1, twiddle), then rows of n2 into natural order
+        PCX_TRY(launch_fft_columns(in_dev, h->ws1.p, h->n1 == 128 ? 7 : 8, h->n2, nframes, h->inverse != 0, h->tw1.p, st));
+        if (h->n2 <= 256) {
+            int l2 = 0;
+            while (((size_t)1 << l2) < h->n2) l2++;
+            return launch_fft_rows_transposed(h->ws1.p, out_dev, h->n1, l2, nframes, h->inverse != 0, h->tw2.p, st);
+        }
+        PCX_TRY(h->ws2.ensure(bytes));
+        PCX_TRY(pcx_fft_transform_dev(h->sub2, h->ws1.p, h->ws2.p, nframes * h->n1, stream));
+        return launch_transpose(h->scalar, h->ws2.p, out_dev, h->n1, h->n2, nframes, 0, st);
+    }
     case pcx_fft::FOURSTEP: {
         const size_t bytes = nframes * h->nbins * 2 * (size_t)scalar_bytes(h->scalar);
         PCX_TRY(h->ws1.ensure(bytes));

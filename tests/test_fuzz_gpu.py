@@ -303,8 +303,13 @@ def test_fir_edge_geometries(oracle, dev, seed):
         exact = np.array([np.dot(h, xc[n + K - 1 - np.arange(K)]) for n in idx])
         ex = np.stack([exact.real, exact.imag], 1)
         ref_noise = float(np.abs(want[idx] - ex).max())
-        assert float(np.abs(got[idx] - ex).max()) <= TOL * scale, (K, n_in, out_cap)
-        assert float(np.abs(got - want).max()) <= TOL * scale + 2.0 * ref_noise, (K, n_in, out_cap)
+        if K > 8193:
+            # beyond every frequency-domain plan AUTO runs the reference's own operation order: its rounding noise
+            # (seed 10029: above 1e-5 of float64) is reproduced bit for bit
+            assert f.last_algo == dev._lib.FIR_EXACT and np.array_equal(got, want), (K, n_in, out_cap)
+        else:
+            assert float(np.abs(got[idx] - ex).max()) <= TOL * scale, (K, n_in, out_cap)
+            assert float(np.abs(got - want).max()) <= TOL * scale + 2.0 * ref_noise, (K, n_in, out_cap)
 
 
 @pytest.mark.parametrize("seed", SEEDS)

@@ -204,16 +204,32 @@ __global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in
                 wr[slot] = nr[u]; wi[slot] = ni[u];
             }
         }
+        // the lane's R outputs are R*EW*sizeof(S) contiguous bytes: 16-byte stores when the run is whole and aligned
+        S res[R * EW];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const size_t o = o0 + r;
-            if (o >= n_out) break;
             if constexpr (FLT) {
-                out[o * EW] = ar[r];
-                if constexpr (CPLX) out[o * EW + 1] = ai[r];
+                res[r * EW] = ar[r];
+                if constexpr (CPLX) res[r * EW + 1] = ai[r];
             } else {
-                out[o * EW] = (S)(((TT)ar[r]) >> (4 * sizeof(TT)));
-                if constexpr (CPLX) out[o * EW + 1] = (S)(((TT)ai[r]) >> (4 * sizeof(TT)));
+                res[r * EW] = (S)(((TT)ar[r]) >> (4 * sizeof(TT)));
+                if constexpr (CPLX) res[r * EW + 1] = (S)(((TT)ai[r]) >> (4 * sizeof(TT)));
+            }
+        }
+        constexpr int BYTES = R * EW * (int)sizeof(S);
+        S *op = out + o0 * EW;
+        if (BYTES % 16 == 0 && o0 + R <= n_out && (reinterpret_cast<uintptr_t>(op) & 15) == 0) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 pk[BYTES / 16 > 0 ? BYTES / 16 : 1];
+            __builtin_memcpy(pk, res, BYTES);
+#pragma unroll
+            for (int i = 0; i < BYTES / 16; i++) reinterpret_cast<u32x4 *>(op)[i] = pk[i];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (o0 + r >= n_out) break;
+#pragma unroll
+                for (int c = 0; c < EW; c++) op[r * EW + c] = res[r * EW + c];
             }
         }
     }
@@ -313,18 +329,40 @@ __global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const void *__restri
                 w[(R - 1 - u + R) % R] = nw[u];
             }
         }
+        if (IN8) {
+            // QType int16: the accumulator is the low half of the int32 sum; fromQ = >> 8, truncated to int8
+            uint16_t res[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const size_t o = o0 + r;
-            if (o >= n_out) break;
-            if (IN8) {
-                // QType int16: the accumulator is the low half of the int32 sum; fromQ = >> 8, truncated to int8
+            for (int r = 0; r < R; r++) {
                 const uint32_t re = (uint8_t)(int8_t)((int16_t)ar[r] >> 8), im = (uint8_t)(int8_t)((int16_t)ai[r] >> 8);
-                static_cast<uint16_t *>(out_v)[o] = (uint16_t)(re | (im << 8));
+                res[r] = (uint16_t)(re | (im << 8));
+            }
+            uint16_t *op = static_cast<uint16_t *>(out_v) + o0;
+            if (o0 + R <= n_out && (reinterpret_cast<uintptr_t>(op) & 15) == 0) {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 pk;
+                __builtin_memcpy(&pk, res, 16);
+                *reinterpret_cast<u32x4 *>(op) = pk;
             } else {
-                // fromQ: arithmetic >> 16 of the wrapped int32, truncated to int16 (FIRFilter.cpp:300)
+#pragma unroll
+                for (int r = 0; r < R; r++) { if (o0 + r >= n_out) break; op[r] = res[r]; }
+            }
+        } else {
+            // fromQ: arithmetic >> 16 of the wrapped int32, truncated to int16 (FIRFilter.cpp:300)
+            uint32_t res[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
                 const uint32_t re = (uint32_t)(uint16_t)(int16_t)(ar[r] >> 16), im = (uint32_t)(uint16_t)(int16_t)(ai[r] >> 16);
-                out[o] = re | (im << 16);
+                res[r] = re | (im << 16);
+            }
+            uint32_t *op = out + o0;
+            if (o0 + R <= n_out && (reinterpret_cast<uintptr_t>(op) & 15) == 0) {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                reinterpret_cast<u32x4 *>(op)[0] = u32x4{res[0], res[1], res[2], res[3]};
+                reinterpret_cast<u32x4 *>(op)[1] = u32x4{res[4], res[5], res[6], res[7]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) { if (o0 + r >= n_out) break; op[r] = res[r]; }
             }
         }
     }

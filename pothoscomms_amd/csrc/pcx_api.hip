@@ -92,14 +92,15 @@ static std::vector<float> make_tw4096()
 
 // lane-constant table of the radix-16 family (fft_r16.hip): [15][16] pass Ns=16, [15][256] pass
 // Ns=256 (numBins >= 4096), then the final radix-R pass: entry (t*(R-1) + r-1, l) = W_N^((l + t*LPF) r)
-static std::vector<float> make_tw_r16(int log2n)
+template <typename T = float>
+static std::vector<T> make_tw_r16(int log2n)
 {
     const int N = 1 << log2n, LPF = N / 16, A = log2n / 4, R = 1 << (log2n % 4);
-    std::vector<float> t(2 * fft_r16_table_elems(log2n));
+    std::vector<T> t(2 * fft_r16_table_elems(log2n));
     const double two_pi = 6.283185307179586476925286766559;
     auto put = [&](size_t idx, double turns) {
-        t[2 * idx] = (float)std::cos(-two_pi * turns);
-        t[2 * idx + 1] = (float)std::sin(-two_pi * turns);
+        t[2 * idx] = (T)std::cos(-two_pi * turns);
+        t[2 * idx + 1] = (T)std::sin(-two_pi * turns);
     };
     auto angle15 = [](int p, double base) {
         if (p < 3) return base * 4.0 * (p + 1);
@@ -550,7 +551,7 @@ struct pcx_fft {
     ~pcx_fft() { delete sub1; delete sub2; }
 };
 // longest power-of-two transform one workgroup handles
-static size_t fft_single_wg_limit(int scalar) { return scalar == PCX_F32 ? 16384 : 4096; }
+static size_t fft_single_wg_limit(int scalar) { return scalar == PCX_F32 ? 16384 : scalar == PCX_F64 ? 8192 : 4096; }
 
 int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
 {
@@ -561,7 +562,8 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     const size_t esz = 2 * (size_t)scalar_bytes(scalar);
     const bool pow2 = (num_bins & (num_bins - 1)) == 0;
     // single-workgroup LDS plans: the frame (x2 for ping-pong) must fit 160 KB
-    const bool r16 = scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384;
+    const bool r16_f64 = scalar == PCX_F64 && pow2 && num_bins >= 16 && num_bins <= 8192 && !(getenv("PCX_FFT_F64_POW2") && num_bins <= 4096);
+    const bool r16 = (scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384) || r16_f64;
     // float power-of-two sizes beyond one workgroup: four-step around the short kernels (fft_large.hip)
     const size_t wg_limit = fft_single_wg_limit(scalar);
     const bool four_step = scalar != PCX_I16 && pow2 && num_bins > wg_limit && num_bins <= wg_limit * wg_limit;
@@ -621,6 +623,11 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         h->kind = pcx_fft::R16;
         while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
         rc = upload(h->tw, make_tw_r16(h->log2n));
+    } else if (r16_f64) {
+        // the same radix-16 plan in double precision (fft_r16_f64.hip); PCX_FFT_F64_POW2 (A/B) keeps the radix-2/4 LDS kernel
+        h->kind = pcx_fft::R16;
+        while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
+        rc = upload(h->tw, make_tw_r16<double>(h->log2n));
     } else if (scalar != PCX_I16) {
         // forward table exp(-j 2 pi i / N); the power-of-two kernels conjugate it for the inverse,
         // the mixed-radix kernel gets the direction baked in like kissfft's fill_twiddles (kissfft.hh:21-26)
@@ -684,7 +691,9 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         PCX_HIP(hipMemcpyAsync(out_dev, in_dev, nframes * 2 * (size_t)scalar_bytes(h->scalar), hipMemcpyDeviceToDevice, st));
         return PCX_OK;
     case pcx_fft::R16_4096: return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, st);
-    case pcx_fft::R16: return launch_fft_r16_cf32(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st);
+    case pcx_fft::R16:
+        return h->scalar == PCX_F64 ? launch_fft_r16_cf64(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st)
+                                    : launch_fft_r16_cf32(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st);
     case pcx_fft::POW2:
         return h->scalar == PCX_F32 ? launch_fft_pow2_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st)
                                     : launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);

@@ -157,6 +157,7 @@ int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool
 // complex_float32, numBins = 2^log2n in 16..16384 (except 4096): register-resident radix-16 family
 size_t fft_r16_table_elems(int log2n);
 int launch_fft_r16_cf32(const void *in, void *out, int log2n, size_t nframes, bool inverse, const void *tw, hipStream_t st);
+int launch_fft_r16_cf64(const void *in, void *out, int log2n, size_t nframes, bool inverse, const void *tw, hipStream_t st);
 
 // any numBins: kissfft's mixed-radix plan (radix 2/3/4/5 + generic), f32 / f64 / Q15 (bit-exact)
 int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,

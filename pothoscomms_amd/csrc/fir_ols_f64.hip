@@ -1,0 +1,216 @@
+// fir_ols_f64.hip -- overlap-save /comms/fir_filter for complex_float64 streams (M = L = 1): the
+// y = IFFT(FFT(block) .* H) evaluation of the FIRFilter.cpp:294-300 convolution, as fir_ols_r16.hip does
+// it for complex_float32, on the double-precision radix-16 passes of fft_f64.hpp.
+//
+// Block geometry is the float kernels': Kov >= K-1 (a multiple of 16) outputs dropped per N-sample block,
+// block b's window starts pad = Kov-(K-1) samples before sample b*S, S = N - Kov.  Lane l holds
+// x[l + s*LPF]; a forward transform leaves X[l + k*LPF] in the lane, which is the next transform's
+// first-pass layout, so the spectrum is multiplied by the lane's 16 bins of H and inverse-transformed
+// (conj . FFT . conj) without leaving registers.  H (64 VGPRs) and the Ns = 256 pass's lane constants
+// (60 VGPRs) live in registers across the persistent block loop, the Ns = 16 table in LDS.
+//
+// Rounding: everything is double; the result differs from the reference's direct sum by a few 1e-16 of
+// the output scale (parity bar 1e-13).  Against the sliding-window kernel (K multiply-adds per output on
+// the 78 TFLOP/s f64 pipe) this is the faster form from a few tens of taps up (tools/sweep_fir_f64.py).
+#include "fft_f64.hpp"
+#include <cstdio>
+#include <cstdlib>
+
+#include "pcx_internal.hpp"
+
+namespace pcx {
+
+namespace {
+using namespace fft64;
+
+template <int LOG2N>
+struct OlsPlan {
+    static constexpr int N = 1 << LOG2N;
+    static constexpr int LPF = N / 16;
+    static constexpr int A = LOG2N / 4;
+    static constexpr int R = 1 << (LOG2N % 4);
+    static constexpr int NTWF = R > 1 ? (16 / R) * (R - 1) : 0;
+    static constexpr int LDS_IMG = N + N / 16;
+    static constexpr int LDS_T2 = 240;
+    static constexpr int T3_OFF = 15 * 16;
+    static constexpr int TF_OFF = T3_OFF + (A >= 3 ? 15 * 256 : 0);
+    static constexpr bool NATURAL = R > 1;
+};
+
+// forward DFT_N of the block held as v[s] = x[l + s*LPF]; on exit v[q] = X[l + LPF*(NATURAL ? q : bin_of(q))]
+template <int LOG2N, typename T3>
+__device__ __forceinline__ void xform(cd (&v)[16], cd *lds, int l, T3 t3, const cd *tf)
+{
+    typedef OlsPlan<LOG2N> P;
+    constexpr int LPF = P::LPF, A = P::A, R = P::R;
+    fft16_plain(v);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; q++) lds[17 * l + bin_of(q)] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; s++) v[s] = lds[l + (l >> 4) + s * (LPF + LPF / 16)];
+    {
+        const cd *t2 = lds + P::LDS_IMG + (l & 15);
+        fft16_tw(v, [&](int p) { return t2[p * 16]; });
+    }
+    __syncthreads();
+    {
+        const int wb = (l >> 4) * 272 + (l & 15);
+#pragma unroll
+        for (int q = 0; q < 16; q++) lds[wb + 17 * bin_of(q)] = v[q];
+    }
+    if (A >= 3) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; s++) v[s] = lds[l + (l >> 4) + s * (LPF + LPF / 16)];
+        fft16_tw(v, t3);
+        if (R > 1) {
+            __syncthreads();
+            const int wb = (l >> 8) * 4352 + (l & 255) + ((l & 255) >> 4);
+#pragma unroll
+            for (int q = 0; q < 16; q++) lds[wb + 272 * bin_of(q)] = v[q];
+        }
+    }
+    if (R > 1) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; s++) v[s] = lds[padi(l + s * LPF)];
+        constexpr int G = 16 / R;
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+#pragma unroll
+            for (int r = 1; r < R; r++) v[t + r * G] = cmul(v[t + r * G], tf[t * (R - 1) + (r - 1)]);
+            if (R == 2) {
+                const cd a = v[t], b = v[t + G];
+                v[t] = a + b;
+                v[t + G] = a - b;
+            } else if (R == 4) {
+                fft4(v[t], v[t + G], v[t + 2 * G], v[t + 3 * G]);
+            } else {
+                fft8(v[t], v[t + G], v[t + 2 * G], v[t + 3 * G], v[t + 4 * G], v[t + 5 * G], v[t + 6 * G], v[t + 7 * G]);
+            }
+        }
+    }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_per_eu(2))) void fir_cf64_ols_kernel(const double2 *__restrict__ in, size_t in_elems,
+                                                                          double2 *__restrict__ out, size_t n_out,
+                                                                          const double2 *__restrict__ Hspec, int Kov, int pad,
+                                                                          const double2 *__restrict__ twtab, size_t first_full,
+                                                                          size_t nfull, size_t nblocks)
+{
+    typedef OlsPlan<LOG2N> P;
+    constexpr int N = P::N, LPF = P::LPF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd *lds = reinterpret_cast<cd *>(smem_raw);
+    const int l = threadIdx.x;
+    const size_t S = (size_t)(N - Kov);
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const cd *tab = reinterpret_cast<const cd *>(twtab);
+    cd t3[P::A >= 3 ? 15 : 1];
+    if (P::A >= 3) {
+#pragma unroll
+        for (int p = 0; p < 15; p++) t3[p] = tab[P::T3_OFF + p * 256 + (l & 255)];
+    }
+    cd tf[P::NTWF > 0 ? P::NTWF : 1];
+#pragma unroll
+    for (int p = 0; p < P::NTWF; p++) tf[p] = tab[P::TF_OFF + p * LPF + l];
+    for (int i = l; i < P::LDS_T2; i += LPF) lds[P::LDS_IMG + i] = tab[i];
+    cd H[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cd *>(Hspec)[l + LPF * k];
+    auto tw3 = [&](int p) { return t3[p]; };
+    const int nov = (Kov + LPF - 1) / LPF;   // window rows shared with a neighbouring block
+
+    for (; b < nblocks; b += gridDim.x) {
+        cd v[16];
+        if (b >= first_full && b < nfull) {
+            // overlap rows (the first and last of the window, shared with the neighbouring blocks) keep the
+            // default cache policy, the rest of the window is touched once
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + b * S - pad, N * 16);
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+                v[s] = as_cd(s < nov || s >= 16 - nov ? __builtin_amdgcn_raw_buffer_load_b128(rs, l * 16, s * LPF * 16, 0)
+                                                      : __builtin_amdgcn_raw_buffer_load_b128(rs, l * 16, s * LPF * 16, kAuxStream));
+        } else {
+            // ragged: block 0 when pad > 0 (samples before the buffer only feed dropped outputs) and the tail
+            const size_t shift = b * S >= (size_t)pad ? 0 : (size_t)pad - b * S;
+            const size_t first = b * S + shift - pad;
+            const size_t left = in_elems > first ? in_elems - first : 0;
+            const size_t want = (size_t)N - shift;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 16));
+#pragma unroll
+            for (int s = 0; s < 16; s++) v[s] = as_cd(__builtin_amdgcn_raw_buffer_load_b128(rs, (l + LPF * s - (int)shift) * 16, 0, 0));
+        }
+        xform<LOG2N>(v, lds, l, tw3, tf);
+        // u = conj(X .* H) in the first-pass layout of the next transform (register k <- bin k*LPF + l)
+        cd u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = P::NATURAL ? q : bin_of(q);
+            const cd p = cmul(v[q], H[k]);
+            u[k] = cd{p.x, -p.y};
+        }
+        xform<LOG2N>(u, lds, l, tw3, tf);
+        const size_t room = n_out - b * S;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)((room < S ? room : S) * 16));
+        const unsigned vbase = (unsigned)(l - Kov) * 16u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = LPF * (P::NATURAL ? q : bin_of(q));
+            if (row + LPF - 1 < Kov) continue;                // whole row dropped: uniform skip
+            __builtin_amdgcn_raw_buffer_store_b128(as_u4(cd{u[q].x, -u[q].y}), ws, (int)(vbase + (unsigned)row * 16u), 0, kAuxStream);
+        }
+    }
+}
+
+template <int LOG2N>
+int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, hipStream_t st)
+{
+    typedef OlsPlan<LOG2N> P;
+    const size_t Km1 = K - 1;
+    const size_t Kov = (Km1 + 15) / 16 * 16;
+    if (Kov > (size_t)P::N / 2) { set_error("fir ols f64: K=%zu too long for %d-sample blocks", K, P::N); return PCX_ERR_UNSUPPORTED; }
+    const size_t pad = Kov - Km1;
+    const size_t S = P::N - Kov;
+    const size_t nblocks = (n_out + S - 1) / S;
+    const size_t first_full = pad > 0 ? 1 : 0;
+    size_t nfull = n_out / S;
+    while (nfull > first_full && (nfull - 1) * S - pad + P::N > in_elems) nfull--;
+    if (nfull < first_full) nfull = first_full;
+    const size_t lds = (size_t)(P::LDS_IMG + P::LDS_T2) * sizeof(cd);
+    auto k = fir_cf64_ols_kernel<LOG2N>;
+    if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // resident workgroups per CU: LDS (160 KiB) and 8 waves of <= 256 VGPRs
+    unsigned per_cu = (unsigned)(160 * 1024 / lds);
+    const unsigned by_waves = 8u * 64u / P::LPF;
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned grid = persistent_grid(nblocks, 256 * per_cu);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const double2 *)in, in_elems, (double2 *)out, n_out,
+                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, first_full, nfull, nblocks);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+}  // namespace
+
+// log2n in {10 .. 13}; Hspec = FFT_N(h)/N in double, tw = make_tw_r16<double>(log2n) (pcx_api.hip)
+int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
+                        const void *tw, hipStream_t st)
+{
+    if (n_out == 0) return PCX_OK;
+    switch (log2n) {
+    case 10: return launch_ols<10>(in, in_elems, out, n_out, Hspec, K, tw, st);
+    case 11: return launch_ols<11>(in, in_elems, out, n_out, Hspec, K, tw, st);
+    case 12: return launch_ols<12>(in, in_elems, out, n_out, Hspec, K, tw, st);
+    case 13: return launch_ols<13>(in, in_elems, out, n_out, Hspec, K, tw, st);
+    }
+    set_error("fir ols f64: no plan for log2(N) = %d", log2n);
+    return PCX_ERR_UNSUPPORTED;
+}
+
+}  // namespace pcx

@@ -128,12 +128,13 @@ static std::vector<T> make_tw_r16(int log2n)
 
 // H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096 (the 1/N of the inverse transform folded
 // in), accumulated in double, rounded once to float; natural bin order
-static std::vector<float> make_hspec(const std::vector<std::complex<double>> &h, size_t N)
+template <typename T = float>
+static std::vector<T> make_hspec(const std::vector<std::complex<double>> &h, size_t N)
 {
     std::vector<double> cs(2 * N);
     const double two_pi = 6.283185307179586476925286766559;
     for (size_t i = 0; i < N; i++) { cs[2 * i] = std::cos(two_pi * (double)i / (double)N); cs[2 * i + 1] = -std::sin(two_pi * (double)i / (double)N); }
-    std::vector<float> H(2 * N);
+    std::vector<T> H(2 * N);
     for (size_t b = 0; b < N; b++) {
         double sr = 0, si = 0;
         for (size_t k = 0; k < h.size(); k++) {
@@ -141,8 +142,8 @@ static std::vector<float> make_hspec(const std::vector<std::complex<double>> &h,
             sr += h[k].real() * cs[2 * e] - h[k].imag() * cs[2 * e + 1];
             si += h[k].real() * cs[2 * e + 1] + h[k].imag() * cs[2 * e];
         }
-        H[2 * b] = (float)(sr / (double)N);
-        H[2 * b + 1] = (float)(si / (double)N);
+        H[2 * b] = (T)(sr / (double)N);
+        H[2 * b + 1] = (T)(si / (double)N);
     }
     return H;
 }
@@ -224,6 +225,7 @@ struct pcx_fir {
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
+    bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
     DevBuf HspecRows;
     int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
     bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
@@ -248,6 +250,22 @@ static int fir_ols_block_log2(size_t K)
     return K <= 4097 ? 13 : 14;
 }
 constexpr size_t kOlsMaxTaps = 8193;
+// complex_float64 (fir_ols_f64.hip): 4096-sample blocks to K = 2049, 8192 to K = 4097; PCX_OLS64_N forces a plan (A/B)
+constexpr size_t kOls64MaxTaps = 4097;
+// below this many taps the sliding-window kernel is the faster complex_float64 form (tools/sweep_fir_f64.py: 128 vs 112 Gsamples/s at K = 2)
+constexpr size_t kOls64MinTaps = 4;
+static int fir_ols64_block_log2(size_t K)
+{
+    static const int forced = [] { const char *e = getenv("PCX_OLS64_N"); return e ? atoi(e) : 0; }();
+    int l2 = K <= 2049 ? 12 : 13;
+    switch (forced) {
+    case 1024: if (K <= 513) l2 = 10; break;
+    case 2048: if (K <= 1025) l2 = 11; break;
+    case 4096: if (K <= 2049) l2 = 12; break;
+    case 8192: l2 = 13; break;
+    }
+    return l2;
+}
 
 // FIRFilter::updateInternals, FIRFilter.cpp:327-354 (host mirror; tables uploaded lazily)
 static void fir_update_internals(pcx_fir *h)
@@ -342,6 +360,16 @@ static int fir_sync_tables(pcx_fir *h)
             }
             h->have_ols = true;
         }
+    }
+    h->have_ols64 = false;
+    if (h->scalar == PCX_F64 && h->cplx && h->M == 1 && h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
+        // complex_float64: the same frequency-domain evaluation in double (fir_ols_f64.hip)
+        std::vector<std::complex<double>> hq(h->K);
+        for (size_t k = 0; k < h->K; k++) hq[k] = std::complex<double>(h->ctaps ? h->taps[2 * k] : h->taps[k], h->ctaps ? h->taps[2 * k + 1] : 0.0);
+        h->ols_log2n = fir_ols64_block_log2(h->K);
+        PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
+        PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
+        h->have_ols64 = true;
     }
     h->have_real_ols = false;
     if (h->scalar == PCX_F32 && !h->cplx && h->M == 1 && h->L == 1 && h->K <= 2049) {
@@ -463,20 +491,22 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // K == 1 (the block's default unit tap) stays on the time-domain tile: a pass-through
         // filter must return its input bit for bit, as the reference does
         if (fast && h->K == 1) algo = PCX_FIR_DIRECT;
-        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1)) algo = PCX_FIR_OLS_FFT;
+        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_ols64 && h->K >= kOls64MinTaps)) algo = PCX_FIR_OLS_FFT;
         // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
         // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
-    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols)) {
-        set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows)");
+    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64)) {
+        set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64, M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
-    if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
+    if (algo == PCX_FIR_OLS_FFT && h->have_ols64) {
+        rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);

@@ -375,6 +375,26 @@ def test_fm_chain(oracle, dev, ntaps, ctaps, algo):
     del rng
 
 
+@pytest.mark.parametrize("ctaps", [False, True])
+@pytest.mark.parametrize("ntaps", [2, 3, 16, 17, 18, 63, 255, 1000, 2049, 2050, 4097, 4098])
+def test_fir_cf64_overlap_save(oracle, dev, ntaps, ctaps):
+    """complex_float64, M = L = 1: the frequency-domain kernel in double (fir_ols_f64.hip) for 4 <= K <= 4097,
+    the sliding-window kernel beyond; stream lengths that leave ragged first and last blocks"""
+    rng = np.random.default_rng(7 * ntaps + ctaps)
+    taps = _taps(rng, ntaps, ctaps)
+    for n in (ntaps - 1 + 1, ntaps - 1 + 4095, 3 * 4096 + 1234 + ntaps):
+        x = rand_stream(rng, oracle.F64, n, True)
+        ref_blk = oracle.Fir(oracle.F64, True, ctaps)
+        ref_blk.set_taps(taps); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n)
+        f = dev.FirFilter((oracle.F64, True), "COMPLEX" if ctaps else "REAL")
+        f.set_taps(taps)
+        got, gc, gp = f.process(x, n)
+        assert (gc, gp) == (rc, rp)
+        assert f.last_algo == (dev._lib.FIR_OLS_FFT if 4 <= ntaps <= 4097 else dev._lib.FIR_DIRECT)
+        assert nerr(got, ref) <= 1e-13, (ntaps, n)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

@@ -597,7 +597,16 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     // float power-of-two sizes beyond one workgroup: four-step around the short kernels (fft_large.hip)
     const size_t wg_limit = fft_single_wg_limit(scalar);
     const bool four_step = scalar != PCX_I16 && pow2 && num_bins > wg_limit && num_bins <= wg_limit * wg_limit;
-    if (num_bins > 1 && !r16 && !four_step && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
+    // float sizes with other factors that do not fit one workgroup's LDS (ping-pong image): the same four-step
+    // decomposition N = n1 * n2 around two mixed-radix (or power-of-two) plans, n1 the largest divisor <= sqrt(N)
+    // whose cofactor still fits.  (kissfft recurses over the factor list instead, kissfft.hh:81-161: same DFT.)
+    size_t mixed_n1 = 0;
+    const size_t lds_limit = 160 * 1024 / (2 * esz);
+    if (scalar != PCX_I16 && !pow2 && num_bins > lds_limit) {
+        for (size_t d = (size_t)std::floor(std::sqrt((double)num_bins)); d >= 2; d--)
+            if (num_bins % d == 0) { if (num_bins / d <= lds_limit) mixed_n1 = d; break; }
+    }
+    if (num_bins > 1 && !r16 && !four_step && !mixed_n1 && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
         set_error("FFT: numBins=%zu (%s) does not fit the single-workgroup LDS plan; not implemented on the device", num_bins,
                   scalar == PCX_F64 ? "complex_float64" : scalar == PCX_F32 ? "complex_float32" : "complex_int16");
         return PCX_ERR_UNSUPPORTED;
@@ -638,11 +647,11 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         } else if (rc == PCX_OK) {
             rc = pcx_fft_create(scalar, h->n2, inverse, &h->sub2);
         }
-    } else if (four_step) {
+    } else if (four_step || mixed_n1) {
         h->kind = pcx_fft::FOURSTEP;
         int l2 = 0;
         while (((size_t)1 << l2) < num_bins) l2++;
-        h->n1 = (size_t)1 << ((l2 + 1) / 2);
+        h->n1 = mixed_n1 ? mixed_n1 : (size_t)1 << ((l2 + 1) / 2);
         h->n2 = num_bins / h->n1;
         rc = pcx_fft_create(scalar, h->n1, inverse, &h->sub1);
         if (rc == PCX_OK) rc = pcx_fft_create(scalar, h->n2, inverse, &h->sub2);

@@ -322,7 +322,7 @@ def test_fft_errors(dev):
     with pytest.raises(ValueError):
         dev.Fft("complex_int32", 64)       # FFTFactory: unsupported type
     with pytest.raises(NotImplementedError):
-        dev.Fft("complex_float32", 3 << 16)   # valid in the reference; not a power of two and beyond one workgroup's LDS: fails loudly
+        dev.Fft("complex_float32", 2 * 10243)   # valid in the reference; 2 x a prime beyond one workgroup's LDS has no four-step split: fails loudly
     with pytest.raises(NotImplementedError):
         dev.Fft("complex_int16", 1 << 16)     # the Q15 rounding order cannot be kept across a four-step split
 
@@ -410,6 +410,20 @@ def test_fft_mixed_radix_float(oracle, dev, nbins, inverse):
     if nbins <= 1000:
         xd = rand_stream(rng, oracle.F64, nbins * 2, True)
         assert nerr(dev.Fft("complex_float64", nbins, inverse).transform(xd), oracle.fft(xd, nbins, inverse)) <= 1e-13
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("dtype,nbins", [("complex_float32", 12000), ("complex_float32", 2 * 10223), ("complex_float32", 30030),
+                                         ("complex_float32", 48000), ("complex_float32", 100000), ("complex_float32", 3 << 16),
+                                         ("complex_float64", 6000), ("complex_float64", 2 * 5119), ("complex_float64", 48000)])
+def test_fft_composite_beyond_one_workgroup(oracle, dev, dtype, nbins, inverse):
+    """Sizes with odd factors too long for one workgroup's LDS: four-step N = n1 * n2 around two mixed-radix plans
+    (kissfft takes any size, kissfft.hh:81-161).  2 x prime-beyond-the-LDS has no such split and is refused."""
+    scalar = oracle.F32 if dtype.endswith("32") else oracle.F64
+    rng = np.random.default_rng(nbins)
+    x = rand_stream(rng, scalar, nbins * 2, True)
+    got = dev.Fft(dtype, nbins, inverse).transform(x)
+    assert nerr(got, oracle.fft(x, nbins, inverse)) <= (TOL if scalar == oracle.F32 else 1e-13)
 
 
 @pytest.mark.parametrize("inverse", [False, True])

@@ -204,7 +204,8 @@ PCX_API int pcx_fmchain_set_phase(pcx_fmchain *h, double phase);
 /* REAL (complex_taps=0) or COMPLEX taps, as pcx_fir_set_taps */
 PCX_API int pcx_fmchain_set_taps(pcx_fmchain *h, const double *taps, size_t ntaps, int complex_taps);
 PCX_API int pcx_fmchain_reset(pcx_fmchain *h);
-/* PCX_FIR_AUTO (default), PCX_FIR_DIRECT (LDS-tiled time domain) or PCX_FIR_OLS_FFT (K <= 2048) */
+/* PCX_FIR_AUTO (default), PCX_FIR_DIRECT (time domain), PCX_FIR_EXACT (the reference's operation order) or
+ * PCX_FIR_OLS_FFT (complex_float32 K <= 8193, resampling K <= 2049; real float32 K <= 2049; complex_float64 K <= 4097) */
 PCX_API int pcx_fmchain_set_algo(pcx_fmchain *h, int algo);
 PCX_API int pcx_fmchain_last_algo(const pcx_fmchain *h);
 /* in_elems input samples with K-1 history in front -> in_elems-(K-1) demodulated

@@ -89,7 +89,9 @@ typedef struct pcx_fir pcx_fir;
 typedef enum pcx_fir_algo {
     PCX_FIR_AUTO = 0,    /* OLS_FFT when it applies and pays, else DIRECT */
     PCX_FIR_DIRECT = 1,  /* time-domain LDS-tiled dot product (FMA) */
-    PCX_FIR_OLS_FFT = 2, /* frequency-domain overlap-save on the Stockham kernel */
+    PCX_FIR_OLS_FFT = 2, /* frequency-domain overlap-save on the Stockham kernels: complex_float32 (K <= 8193;
+                            resampling K <= 2049), real float32 and M = L = 1 (K <= 2049), complex_float64 and
+                            M = L = 1 (K <= 4097); anything else -> PCX_ERR_UNSUPPORTED */
     PCX_FIR_EXACT = 3    /* time-domain, reference accumulation order, no FMA:
                             bit-identical to FIRFilter.cpp:295-300 for float types */
 } pcx_fir_algo;
@@ -204,8 +206,7 @@ PCX_API int pcx_fmchain_set_phase(pcx_fmchain *h, double phase);
 /* REAL (complex_taps=0) or COMPLEX taps, as pcx_fir_set_taps */
 PCX_API int pcx_fmchain_set_taps(pcx_fmchain *h, const double *taps, size_t ntaps, int complex_taps);
 PCX_API int pcx_fmchain_reset(pcx_fmchain *h);
-/* PCX_FIR_AUTO (default), PCX_FIR_DIRECT (time domain), PCX_FIR_EXACT (the reference's operation order) or
- * PCX_FIR_OLS_FFT (complex_float32 K <= 8193, resampling K <= 2049; real float32 K <= 2049; complex_float64 K <= 4097) */
+/* PCX_FIR_AUTO (default), PCX_FIR_DIRECT (LDS-tiled time domain) or PCX_FIR_OLS_FFT (K <= 2048) */
 PCX_API int pcx_fmchain_set_algo(pcx_fmchain *h, int algo);
 PCX_API int pcx_fmchain_last_algo(const pcx_fmchain *h);
 /* in_elems input samples with K-1 history in front -> in_elems-(K-1) demodulated

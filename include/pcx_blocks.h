@@ -63,6 +63,11 @@ PCXB_API int pcxb_get_string(pcxb_block *b, const char *name, char *out, size_t 
 PCXB_API int pcxb_get_taps(pcxb_block *b, const char *name, double *out, size_t cap_doubles, size_t *n, int is_complex);
 
 PCXB_API int pcxb_activate(pcxb_block *b);
+PCXB_API int pcxb_deactivate(pcxb_block *b);
+/* Topology::connect(src, "signal", dst, "slot") for signal -> setter wiring (the designer's "tapsChanged" ->
+ * /comms/fir_filter "setTaps", filter/TestFIRFilter.cpp:48): every later emission calls the slot synchronously.
+ * dst must outlive src's emissions. */
+PCXB_API int pcxb_connect_signal(pcxb_block *src, const char *signal, pcxb_block *dst, const char *slot);
 /* the first input / output port's type (indexed port 0, or the first named port) and the buffer managers the block requests */
 PCXB_API int pcxb_port_dtype(pcxb_block *b, int is_output, char *name, size_t cap, size_t *dimension, size_t *bytes);
 PCXB_API int pcxb_buffer_manager(pcxb_block *b, int is_output, char *name, size_t cap, size_t *buffer_size);

@@ -56,6 +56,8 @@ def load():
     L.pcxb_get_string.argtypes = [vp, cp, cp, sz]
     L.pcxb_get_taps.argtypes = [vp, cp, vp, sz, C.POINTER(sz), i]
     L.pcxb_activate.argtypes = [vp]
+    L.pcxb_deactivate.argtypes = [vp]
+    L.pcxb_connect_signal.argtypes = [vp, cp, vp, cp]
     L.pcxb_port_dtype.argtypes = [vp, i, cp, sz, C.POINTER(sz), C.POINTER(sz)]
     L.pcxb_buffer_manager.argtypes = [vp, i, cp, sz, C.POINTER(sz)]
     L.pcxb_initial_reserve.argtypes = [vp, C.POINTER(sz)]
@@ -133,7 +135,12 @@ class Block:
         elif path == "/comms/fft":
             nbins, inverse = int(args[0]), int(bool(args[1])) if len(args) > 1 else 0
         self._h = C.c_void_p()
-        _check(L.pcxb_make(path.encode(), dtype.encode(), dimension, sarg, nbins, inverse, C.byref(self._h)))
+        _check(L.pcxb_make(path.encode(), (dtype or "").encode(), dimension, sarg, nbins, inverse, C.byref(self._h)))
+        self._slots = []          # blocks wired to this one's signals: kept alive as long as it can emit
+        if path.endswith("fir_designer"):     # no stream ports: a signal source only
+            self.in_dtype = self.out_dtype = None
+            self.in_dim = self.out_dim = 0
+            return
         self.in_dtype, self.in_dim, _ = self._port(0)
         self.out_dtype, self.out_dim, _ = self._port(1)
 
@@ -168,6 +175,13 @@ class Block:
             cnt = C.c_size_t()
             _check(L.pcxb_get_taps(self._h, n, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(cnt), int(cplx)))
             return buf[:2 * cnt.value].view(np.complex128).copy() if cplx else buf[:cnt.value].copy()
+        if name in ("setWindowArgs", "setFrequencies"):      # std::vector<double>
+            flat = np.ascontiguousarray(np.asarray(args[0], dtype=np.float64))
+            return _check(L.pcxb_call_taps(self._h, n, flat.ctypes.data_as(C.c_void_p), flat.size, 0))
+        if name == "windowArgs":
+            buf, cnt = np.zeros(64, np.float64), C.c_size_t()
+            _check(L.pcxb_get_taps(self._h, n, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(cnt), 0))
+            return buf[:cnt.value].copy()
         if name == "setPreload":
             v = (C.c_size_t * max(1, len(args[0])))(*[int(a) for a in args[0]])
             return _check(L.pcxb_call_sizes(self._h, n, v, len(args[0])))
@@ -176,7 +190,7 @@ class Block:
             _check(L.pcxb_get_sizes(self._h, n, v, 64, C.byref(cnt)))
             return [int(v[k]) for k in range(cnt.value)]
         if not args:   # getter
-            if name in ("getDecimation", "getInterpolation", "getNumInlineBuffers"):
+            if name in ("getDecimation", "getInterpolation", "getNumInlineBuffers", "numTaps"):
                 v = C.c_size_t()
                 _check(L.pcxb_get_size(self._h, n, C.byref(v)))
                 return v.value
@@ -184,7 +198,8 @@ class Block:
                 v = C.c_int()
                 _check(L.pcxb_get_bool(self._h, n, C.byref(v)))
                 return bool(v.value)
-            if name in ("getPhase", "getFactor"):
+            if name in ("getPhase", "getFactor", "sampleRate", "frequencyLower", "frequencyUpper", "bandwidthTrans", "alpha",
+                        "stopDB", "passDB", "gain"):
                 v = C.c_double()
                 _check(L.pcxb_get_double(self._h, n, C.byref(v)))
                 return v.value
@@ -202,6 +217,14 @@ class Block:
 
     def activate(self):
         _check(load().pcxb_activate(self._h))
+
+    def deactivate(self):
+        _check(load().pcxb_deactivate(self._h))
+
+    def connect_signal(self, signal, dst, slot):
+        """Topology::connect(self, signal, dst, slot): later emissions call dst's registered `slot` synchronously."""
+        _check(load().pcxb_connect_signal(self._h, signal.encode(), dst._h, slot.encode()))
+        self._slots.append(dst)
 
     def buffer_manager(self, is_output):
         name = C.create_string_buffer(64)
@@ -271,6 +294,6 @@ class Block:
                 [Label._from_c(posted[i]) for i in range(min(npost.value, 64))])
 
 
-def make(path, dtype, *args, dimension=1):
+def make(path, dtype=None, *args, dimension=1):
     """BlockRegistry::make(path, dtype, *args)."""
     return Block(path, dtype, *args, dimension=dimension)

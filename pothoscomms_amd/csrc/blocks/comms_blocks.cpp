@@ -13,6 +13,7 @@
 //   /comms/angle  (SURVEY 8f "next")           math/Angle.cpp:50-110
 //   /comms/arithmetic (+ /blocks/arithmetic)   math/Arithmetic.cpp:150-305      (8f "next")
 //   /comms/split_complex, /comms/combine_complex   utility/{Split,Combine}Complex.cpp  (8f "next")
+//   (/comms/fir_designer, host-side only, lives in fir_designer.cpp)
 //
 // The reference instantiates one C++ template per element type; here a block carries a
 // pcx_scalar code instead and the type dispatch happens behind the ABI, so one class per

@@ -433,6 +433,28 @@ public:
     }
     bool hasCall(const std::string &name) const { return _calls.count(name) != 0; }
 
+    // ---- signals (Pothos::Block::registerSignal / emitSignal; Topology::connect(src, "sig", dst, "slot")) ----
+    void registerSignal(const std::string &name) { _signals[name]; }
+    bool hasSignal(const std::string &name) const { return _signals.count(name) != 0; }
+    void connectSignal(const std::string &name, Block *dst, const std::string &slot)
+    {
+        auto it = _signals.find(name);
+        if (it == _signals.end()) throw Exception("Block::connectSignal(" + name + ")", "no such signal");
+        if (!dst->hasCall(slot)) throw BlockCallNotFound("Block::connectSignal(" + slot + ")", "method does not exist in registry");
+        it->second.push_back(std::make_pair(dst, slot));
+    }
+    template <typename... A>
+    void emitSignal(const std::string &name, const A &... a)
+    {
+        auto it = _signals.find(name);
+        if (it == _signals.end()) throw Exception("Block::emitSignal(" + name + ")", "no such signal");
+        const std::vector<Object> args{Object(a)...};
+        for (const auto &d : it->second) d.first->call(d.second, args);
+    }
+    // true from just before activate() until deactivate() returns, as the Pothos actor keeps it
+    bool isActive() const { return _active; }
+    void setActiveState(bool on) { _active = on; }
+
 private:
     std::vector<std::unique_ptr<InputPort>> _inputs, _namedInputs;
     std::vector<std::unique_ptr<OutputPort>> _outputs, _namedOutputs;
@@ -440,6 +462,8 @@ private:
     std::vector<OutputPort *> _outputPtrs;
     WorkInfo _workInfo;
     std::map<std::string, std::function<Object(const std::vector<Object> &)>> _calls;
+    std::map<std::string, std::vector<std::pair<Block *, std::string>>> _signals;
+    bool _active = false;
 };
 
 #define PCX_FCN_TUPLE(c, m) #m, &c::m

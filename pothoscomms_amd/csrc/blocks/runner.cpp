@@ -82,9 +82,11 @@ int pcxb_make(const char *path, const char *dtype, size_t dimension, const char 
 {
     return guarded([&] {
         const std::string p(path);
-        const DType dt(std::string(dtype), dimension ? dimension : 1);
-        std::vector<Object> args{Object(dt)};
-        if (p == "/comms/fir_filter" || p == "/blocks/fir_filter" || p == "/comms/arithmetic" || p == "/blocks/arithmetic")
+        std::vector<Object> args;
+        const bool no_args = p == "/comms/fir_designer" || p == "/blocks/fir_designer";   // FIRDesigner::make(void)
+        if (!no_args) args.push_back(Object(DType(std::string(dtype), dimension ? dimension : 1)));
+        if (no_args) {
+        } else if (p == "/comms/fir_filter" || p == "/blocks/fir_filter" || p == "/comms/arithmetic" || p == "/blocks/arithmetic")
             args.push_back(Object(std::string(sarg ? sarg : "")));
         else if (p == "/comms/fft") { args.push_back(Object((unsigned long)num_bins)); args.push_back(Object(inverse != 0)); }
         std::unique_ptr<pcxb_block> b(new pcxb_block());
@@ -142,7 +144,12 @@ int pcxb_get_taps(pcxb_block *b, const char *name, double *out, size_t cap_doubl
     });
 }
 
-int pcxb_activate(pcxb_block *b) { return guarded([&] { b->blk->activate(); }); }
+int pcxb_activate(pcxb_block *b) { return guarded([&] { b->blk->setActiveState(true); b->blk->activate(); }); }
+int pcxb_deactivate(pcxb_block *b) { return guarded([&] { b->blk->deactivate(); b->blk->setActiveState(false); }); }
+int pcxb_connect_signal(pcxb_block *src, const char *signal, pcxb_block *dst, const char *slot)
+{
+    return guarded([&] { src->blk->connectSignal(signal, dst->blk.get(), slot); });
+}
 
 int pcxb_port_dtype(pcxb_block *b, int is_output, char *name, size_t cap, size_t *dimension, size_t *bytes)
 {

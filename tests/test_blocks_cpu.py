@@ -15,7 +15,9 @@ def test_registry_paths_match_the_reference():
     assert B.registry_paths() == sorted(["/blocks/fir_filter", "/comms/abs", "/comms/angle", "/comms/conjugate", "/comms/fft",
                                          "/comms/fir_filter", "/comms/freq_demod", "/comms/rotate", "/comms/scale",
                                          # Arithmetic.cpp:300-304, SplitComplex.cpp:72-73, CombineComplex.cpp:71-72
-                                         "/blocks/arithmetic", "/comms/arithmetic", "/comms/split_complex", "/comms/combine_complex"])
+                                         "/blocks/arithmetic", "/comms/arithmetic", "/comms/split_complex", "/comms/combine_complex",
+                                         # FIRDesigner.cpp:479-483
+                                         "/comms/fir_designer", "/blocks/fir_designer"])
     with pytest.raises(ValueError):
         B.make("/comms/does_not_exist", "float32")
 

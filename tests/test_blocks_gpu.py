@@ -326,3 +326,106 @@ def test_fir_block_kernel_selection_and_nonfinite_locality(oracle):
     assert nerr(y2[~bad2], want[~bad2]) <= TOL
     with pytest.raises(ValueError, match="unknown kernel"):
         blk.call("setKernel", "FASTEST")
+
+
+# ---- filter/TestFIRDesigner.cpp:137-230, restated on the runner ------------------------------------
+def _run_until_dry(blk, x, out_cap, labels_at=()):
+    """what the scheduler does with a finite source: work() until nothing more is consumed or produced"""
+    pos, outs = 0, []
+    for _ in range(64):
+        labs = [B.Label(i, idx - pos, d) for (i, idx, d) in labels_at if pos <= idx < len(x)]
+        y, c, p, _, _ = blk.work(x[pos:], out_cap, labs)
+        outs.append(y)
+        pos += c
+        if c == 0 and p == 0:
+            break
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("band", ["LOW_PASS", "HIGH_PASS", "BAND_PASS", "BAND_STOP", "COMPLEX_BAND_PASS", "COMPLEX_BAND_STOP"])
+def test_fir_designer_topology_like_the_reference(oracle, band):
+    """vector_source(impulse, START label) -> fir_filter(complex_float64, COMPLEX, waitTaps, frameStartId) -> fft(1024)
+    -> collector, with designer.tapsChanged -> filter.setTaps: the power spectrum must sit above -30 dB in the
+    middle of every pass region and below -80 dB in the middle of every stop region (TestFIRDesigner.cpp:110-135,
+    185-230; filter type SINC).  The filter runs the double-precision overlap-save kernel, the FFT the double
+    radix-16 plan; the same taps through the reference's work() restatement give the comparison stream."""
+    rate, lo, hi, nfft, ntaps = 1e6, 1.5e5, 3.0e5, 1024, 101
+    dtype = "complex_float64"
+    flt = B.make("/comms/fir_filter", dtype, "COMPLEX")
+    flt.call("setDecimation", 1); flt.call("setInterpolation", 1)
+    flt.call("setWaitTaps", True); flt.call("setFrameStartId", "START")
+    des = B.make("/comms/fir_designer")
+    des.connect_signal("tapsChanged", flt, "setTaps")
+    des.call("setSampleRate", rate); des.call("setFilterType", "SINC"); des.call("setBandType", band)
+    des.call("setFrequencyLower", lo); des.call("setFrequencyUpper", hi); des.call("setBandwidthTrans", rate / 20)
+    des.call("setNumTaps", ntaps)
+    fft = B.make("/comms/fft", dtype, nfft, False)
+    impulse = np.zeros((nfft, 2)); impulse[nfft - 1, 0] = float(nfft)
+    # commit(): the filter activates armed (no taps yet), then the designer's activation delivers them
+    flt.activate(); fft.activate()
+    assert flt.work(impulse, nfft, [B.Label("START", 0, nfft)])[1:3] == (0, 0)
+    des.activate()
+    taps = flt.call("getTaps", True)
+    assert len(taps) == ntaps
+    y = _run_until_dry(flt, impulse, 4 * nfft, labels_at=[("START", 0, nfft)])
+    assert y.shape[0] == nfft                                   # the frame comes out whole: tail flushed with zeros
+    ref = oracle.Fir(oracle.F64, True, True)
+    ref.set_taps(taps); ref.set_frame_ids(True, False); ref.activate()
+    pos, routs = 0, []
+    for _ in range(8):
+        ry, rc, rp, _ = ref.work(impulse[pos:], 4 * nfft, [("S", 0, 1, nfft)] if pos == 0 else [])
+        routs.append(ry); pos += rc
+        if rc == 0 and rp == 0:
+            break
+    assert nerr(y, np.concatenate(routs)) <= 1e-13
+    bins, c, p, _, _ = fft.work(y, nfft)
+    assert (c, p) == (nfft, nfft)
+    z = bins[:, 0] + 1j * bins[:, 1]
+    power = np.fft.fftshift(10 * np.log10(np.abs(z) ** 2 + 1e-300) - 20 * np.log10(nfft))
+
+    def level(freq):
+        return power[int(nfft * ((freq + rate / 2) / rate))]
+
+    PASS, STOP = True, False
+    points = {
+        "LOW_PASS": [(STOP, -(lo + rate / 2) / 2), (PASS, 0.0), (STOP, (lo + rate / 2) / 2)],
+        "HIGH_PASS": [(PASS, -(lo + rate / 2) / 2), (STOP, 0.0), (PASS, (lo + rate / 2) / 2)],
+        "BAND_PASS": [(STOP, -(hi + rate / 2) / 2), (PASS, -(lo + hi) / 2), (STOP, 0.0), (PASS, (lo + hi) / 2), (STOP, (hi + rate / 2) / 2)],
+        "BAND_STOP": [(PASS, -(hi + rate / 2) / 2), (STOP, -(lo + hi) / 2), (PASS, 0.0), (STOP, (lo + hi) / 2), (PASS, (hi + rate / 2) / 2)],
+        "COMPLEX_BAND_PASS": [(STOP, (lo - rate / 2) / 2), (PASS, (lo + hi) / 2), (STOP, (hi + rate / 2) / 2)],
+        "COMPLEX_BAND_STOP": [(PASS, (lo - rate / 2) / 2), (STOP, (lo + hi) / 2), (PASS, (hi + rate / 2) / 2)],
+    }[band]
+    for is_pass, f in points:
+        assert (level(f) > -30.0) if is_pass else (level(f) < -80.0), (band, f, level(f))
+
+
+@pytest.mark.parametrize("dtype", ["complex_float64", "complex_int16"])
+def test_fir_filter_tone_rms_with_the_designer(dtype):
+    """filter/TestFIRFilter.cpp:10-80 as written there: the taps come from /comms/fir_designer (SINC,
+    COMPLEX_BAND_PASS around the tone, 101 taps, designed at the filter's rate) over tapsChanged -> setTaps."""
+    from pothoscomms_amd.device import parse_dtype, NP_SCALAR
+    scalar, _ = parse_dtype(dtype)
+    amplitude, rate, freq, total = 1000.0, 1e6, 30e3, 4096
+    n = np.arange(total)
+    wave = amplitude * np.exp(2j * np.pi * freq / rate * n)
+    x = np.stack([wave.real, wave.imag], 1)
+    x = (np.trunc(x) if scalar >= 2 else x).astype(NP_SCALAR[scalar])
+    for decim in (1, 2, 3):
+        for interp in (1, 2, 3):
+            flt = B.make("/comms/fir_filter", dtype, "COMPLEX")
+            flt.call("setDecimation", decim); flt.call("setInterpolation", interp); flt.call("setWaitTaps", True)
+            des = B.make("/comms/fir_designer")
+            des.connect_signal("tapsChanged", flt, "setTaps")
+            des.call("setSampleRate", (rate * interp) / decim); des.call("setFilterType", "SINC")
+            des.call("setBandType", "COMPLEX_BAND_PASS")
+            des.call("setFrequencyLower", freq - 0.1 * rate); des.call("setFrequencyUpper", freq + 0.1 * rate)
+            des.call("setBandwidthTrans", freq + 0.1 * rate); des.call("setNumTaps", 101)
+            flt.activate()
+            cap = total * interp // decim + 8
+            assert flt.work(x, cap)[1:3] == (0, 0)
+            des.activate()
+            y, c, p, _, _ = flt.work(x, cap)
+            assert p > 0
+            z = y.astype(np.float64)
+            rms = np.sqrt(np.mean(z[:, 0] ** 2 + z[:, 1] ** 2))
+            assert rms > 0.1 * amplitude, (decim, interp, rms)

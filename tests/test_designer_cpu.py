@@ -1,0 +1,181 @@
+"""/comms/fir_designer (filter/FIRDesigner.cpp): host-side block, so everything here runs
+without a GPU.  The reference computes its taps with spuce, which is not in the reference tree: tap VALUES are
+"parity unpinned"; what is held here is the block contract (paths, defaults, setters/getters, check order and
+messages, signal payloads, emission on activation and on every change) and the reference's own acceptance
+criterion for the designed response (filter/TestFIRDesigner.cpp:110-135,185-230)."""
+import numpy as np
+import pytest
+import scipy.signal.windows as W
+
+from pothoscomms_amd import blocks as B
+from pothoscomms_amd import _lib
+
+
+def _designer_and_filter(band, dtype="complex_float64"):
+    flt = B.make("/comms/fir_filter", dtype, "COMPLEX" if band.startswith("COMPLEX") else "REAL")
+    des = B.make("/comms/fir_designer")
+    des.connect_signal("tapsChanged", flt, "setTaps")
+    return des, flt
+
+
+def _taps(flt, cplx):
+    return flt.call("getTaps", cplx)
+
+
+def test_registry_paths_and_defaults():
+    assert "/comms/fir_designer" in B.registry_paths() and "/blocks/fir_designer" in B.registry_paths()
+    d = B.make("/comms/fir_designer")
+    # constructor defaults, FIRDesigner.cpp:148-161
+    assert d.call("filterType") == "GAUSSIAN" and d.call("bandType") == "LOW_PASS" and d.call("windowType") == "hann"
+    assert d.call("gain") == 1.0 and d.call("sampleRate") == 1.0
+    assert d.call("frequencyLower") == 0.1 and d.call("frequencyUpper") == 0.2 and d.call("bandwidthTrans") == 0.1
+    assert d.call("alpha") == 0.5 and d.call("stopDB") == 60.0 and d.call("passDB") == 0.1 and d.call("numTaps") == 51
+    assert len(d.call("windowArgs")) == 0
+    d.call("setFrequencies", [0.05, 0.3])
+    assert (d.call("frequencyLower"), d.call("frequencyUpper")) == (0.05, 0.3)
+    d.call("setFrequencies", [0.07])
+    assert (d.call("frequencyLower"), d.call("frequencyUpper")) == (0.07, 0.3)
+    d.call("setWindowArgs", [8.6])
+    assert list(d.call("windowArgs")) == [8.6]
+    # band-type names given as a filter type select SINC + that band (FIRDesigner.cpp:197-212)
+    d.call("setFilterType", "BAND_STOP")
+    assert d.call("filterType") == "SINC" and d.call("bandType") == "BAND_STOP"
+    with pytest.raises(_lib.PcxError):
+        d.call("noSuchCall", 1.0)
+    with pytest.raises(_lib.PcxError):
+        d.connect_signal("noSuchSignal", d, "setGain")
+
+
+def test_nothing_is_emitted_before_activation_then_every_change_emits():
+    des, flt = _designer_and_filter("LOW_PASS")
+    des.call("setFilterType", "SINC")
+    des.call("setNumTaps", 31)
+    assert len(_taps(flt, False)) == 1                      # the filter still holds its default unit tap
+    des.activate()                                          # "emits a tapsChanged signal upon activations"
+    t0 = _taps(flt, False)
+    assert len(t0) == 31
+    des.call("setGain", 2.0)
+    assert np.allclose(_taps(flt, False), 2.0 * t0, rtol=0, atol=1e-15)
+    des.call("setNumTaps", 41)
+    assert len(_taps(flt, False)) == 41
+    des.call("setFrequencyLower", 0.2)
+    t1 = _taps(flt, False)
+    des.call("setWindowType", "blackman")
+    assert not np.allclose(_taps(flt, False), t1)
+    des.deactivate()
+    des.call("setNumTaps", 11)                              # inactive again: parameters stored, nothing emitted
+    assert len(_taps(flt, False)) == 41 and des.call("numTaps") == 11
+
+
+@pytest.mark.parametrize("setter,value,band,msg", [
+    ("setNumTaps", 0, "LOW_PASS", "num taps must be positive"),
+    ("setSampleRate", -1.0, "LOW_PASS", "sample rate must be positive"),
+    ("setFrequencyLower", 0.0, "LOW_PASS", "lower frequency must be positive"),
+    ("setFrequencyLower", -0.5, "COMPLEX_BAND_PASS", "lower frequency below Nyquist range"),
+    ("setFrequencyLower", 0.5, "LOW_PASS", "lower frequency above Nyquist range"),
+    ("setNumTaps", 50, "BAND_PASS", "must have an odd number of taps"),
+    ("setFrequencyUpper", -0.5, "COMPLEX_BAND_STOP", "upper frequency below Nyquist range"),
+    ("setFrequencyUpper", 0.0, "BAND_STOP", "upper frequency must be positive"),
+    ("setFrequencyUpper", 0.5, "BAND_PASS", "upper frequency above Nyquist range"),
+    ("setFrequencyUpper", 0.05, "BAND_PASS", "upper frequency <= lower frequency"),
+    ("setWindowType", "nuttall", "LOW_PASS", "unknown window type"),
+    ("setFilterType", "REMEZ", "LOW_PASS", "windowed-sinc subset"),
+    ("setFilterType", "GAUSSIAN", "HIGH_PASS", "windowed-sinc subset"),
+    ("setBandType", "NOTCH", "LOW_PASS", "unknown band type"),
+])
+def test_parameter_checks_like_the_reference(setter, value, band, msg):
+    """FIRDesigner.cpp:395-413: each check, with its message; types outside the built subset fail loudly."""
+    des, _ = _designer_and_filter(band)
+    des.call("setFilterType", "SINC")
+    des.call("setBandType", band)
+    des.activate()
+    with pytest.raises(_lib.PcxError, match=msg):
+        des.call(setter, value)
+
+
+def test_maxflat_stop_band_message():
+    des, _ = _designer_and_filter("BAND_STOP")
+    des.call("setFilterType", "SINC"); des.call("setBandType", "BAND_STOP"); des.activate()
+    with pytest.raises(_lib.PcxError, match="Can not use MAXFLAT as prototype for stop-band filter"):
+        des.call("setFilterType", "MAXFLAT")
+
+
+def test_default_constructed_designer_fails_loudly_on_activation():
+    """the reference constructs with filter type GAUSSIAN (FIRDesigner.cpp:149), which this build does not design"""
+    d = B.make("/comms/fir_designer")
+    with pytest.raises(_lib.PcxError, match="windowed-sinc subset"):
+        d.activate()
+
+
+@pytest.mark.parametrize("n", [2, 16, 51, 101])
+def test_windows_against_scipy(n):
+    """every window the reference lists (FIRDesigner.cpp:62-71), read back as taps(window) / taps(rectangular)
+    wherever the rectangular taps are not ~0"""
+    des, flt = _designer_and_filter("LOW_PASS")
+    des.call("setFilterType", "SINC"); des.call("setFrequencyLower", 0.2371); des.call("setNumTaps", n)
+    des.call("setWindowType", "rectangular")
+    des.activate()
+    base = _taps(flt, False)
+    ok = np.abs(base) > 1e-6
+    want = {
+        "rectangular": np.ones(n),
+        "hann": W.hann(n + 2)[1:-1],            # the form without zero end points
+        "hamming": W.hamming(n),
+        "blackman": W.blackman(n),
+        "bartlett": W.bartlett(n),
+        "flattop": W.flattop(n),
+        "kaiser": W.kaiser(n, 7.5),
+        "chebyshev": W.chebwin(n, 80.0),
+    }
+    for name, w in want.items():
+        des.call("setWindowArgs", [7.5] if name == "kaiser" else [80.0] if name == "chebyshev" else [])
+        des.call("setWindowType", name)
+        got = _taps(flt, False)
+        assert np.allclose(got[ok] / base[ok], w[ok], rtol=0, atol=2e-9), name
+        assert np.allclose(got, base * w, rtol=0, atol=1e-9), name
+
+
+def _response_db(taps, freq):
+    """|H(f)| in dB at `freq` cycles/sample"""
+    n = np.arange(len(taps))
+    return 20 * np.log10(abs(np.sum(taps * np.exp(-2j * np.pi * freq * n))) + 1e-300)
+
+
+@pytest.mark.parametrize("window", ["hann", "blackman", "kaiser"])
+@pytest.mark.parametrize("band", ["LOW_PASS", "HIGH_PASS", "BAND_PASS", "BAND_STOP", "COMPLEX_BAND_PASS", "COMPLEX_BAND_STOP"])
+def test_sinc_response_meets_the_reference_test_points(band, window):
+    """TestFIRDesigner.cpp:137-230 for filter type SINC: rate 1 MHz, edges 150 / 300 kHz, 101 taps; the middle of
+    every pass region above -30 dB, the middle of every stop region below -80 dB."""
+    rate, lo, hi, ntaps = 1e6, 1.5e5, 3.0e5, 101
+    des, flt = _designer_and_filter(band)
+    des.call("setSampleRate", rate); des.call("setFilterType", "SINC"); des.call("setBandType", band)
+    des.call("setFrequencyLower", lo); des.call("setFrequencyUpper", hi); des.call("setBandwidthTrans", rate / 20)
+    des.call("setNumTaps", ntaps)
+    if window == "kaiser":
+        des.call("setWindowArgs", [10.0])
+    des.call("setWindowType", window)
+    des.activate()
+    cplx = band.startswith("COMPLEX")
+    taps = _taps(flt, cplx)
+    assert len(taps) == ntaps and (np.iscomplexobj(taps) == cplx)
+    PASS, STOP = True, False
+    points = {
+        "LOW_PASS": [(STOP, -(lo + rate / 2) / 2), (PASS, 0.0), (STOP, (lo + rate / 2) / 2)],
+        "HIGH_PASS": [(PASS, -(lo + rate / 2) / 2), (STOP, 0.0), (PASS, (lo + rate / 2) / 2)],
+        "BAND_PASS": [(STOP, -(hi + rate / 2) / 2), (PASS, -(lo + hi) / 2), (STOP, 0.0), (PASS, (lo + hi) / 2), (STOP, (hi + rate / 2) / 2)],
+        "BAND_STOP": [(PASS, -(hi + rate / 2) / 2), (STOP, -(lo + hi) / 2), (PASS, 0.0), (STOP, (lo + hi) / 2), (PASS, (hi + rate / 2) / 2)],
+        "COMPLEX_BAND_PASS": [(STOP, (lo - rate / 2) / 2), (PASS, (lo + hi) / 2), (STOP, (hi + rate / 2) / 2)],
+        "COMPLEX_BAND_STOP": [(PASS, (lo - rate / 2) / 2), (STOP, (lo + hi) / 2), (PASS, (hi + rate / 2) / 2)],
+    }[band]
+    for is_pass, f in points:
+        level = _response_db(taps, f / rate)
+        assert (level > -30.0) if is_pass else (level < -80.0), (band, window, f, level)
+    # pass-band gain is unity (the reference's RMS test relies on it, TestFIRFilter.cpp:62-80)
+    for is_pass, f in points:
+        if is_pass:
+            assert abs(_response_db(taps, f / rate)) < 0.05, (band, f)
+    # a real design is symmetric (linear phase); a complex band is the conjugate-symmetric shift of one
+    if not cplx:
+        assert np.allclose(taps, taps[::-1], rtol=0, atol=1e-15)
+    else:
+        assert np.allclose(taps, np.conj(taps[::-1]), rtol=0, atol=1e-15)

@@ -121,3 +121,49 @@ def test_two_ranks_fm_chain_no_seam(oracle, C):
     assert p == world * C and got.shape == ref.shape and not np.isnan(got).any()
     d = (got.astype(np.float64) - ref + np.pi) % (2 * np.pi) - np.pi
     assert np.max(np.abs(d)) / np.pi <= TOL
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # "nccl" is RCCL on ROCm: what bench.py opens
+    from pothoscomms_amd import device, taps as tp
+    from pothoscomms_amd.stream import ShardedFir
+    sf = ShardedFir(tp.c1_taps(), 1 << 16, dev)
+    device.fill_uniform_f32_dev(sf.buf, seed=2, offset=0)
+    dist.barrier()
+    torch.cuda.synchronize()
+    out = sf.step()
+    torch.cuda.synchronize()
+    t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                                 # bench.py's max-over-ranks timing reduction
+    dist.barrier()
+    q.put((float(t.item()), sf.buf.cpu().numpy(), out.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_rccl_group_of_one_runs_the_bench_control_flow(oracle):
+    """The 8-GPU run opens an RCCL group (bench.py: init_process_group("nccl", device_id=...), barrier, all_reduce MAX
+    around the sharded step).  One GPU cannot host two RCCL ranks, so the seam itself is covered over gloo above;
+    this holds the RCCL side of the control flow -- the library loads, the communicator comes up on this image,
+    barrier / all_reduce run on the device, and the sharded step works inside an initialised nccl group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    tmax, buf, out = got
+    assert tmax == 3.5
+    from pothoscomms_amd import taps as tp
+    ref = oracle.Fir(oracle.F32, True, True)
+    ref.set_taps(tp.c1_taps()); ref.activate()
+    want, _, _, _ = ref.work(buf, 1 << 16)
+    assert nerr(out, want) <= TOL

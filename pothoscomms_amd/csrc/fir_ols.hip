@@ -562,19 +562,27 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         // lane 0 of wave w > 0 continues lane 63 of wave w-1 in the same row; lane 0 of wave 0 continues
         // lane 255 of row k-1 (bnd[47 + k]; for k = 0 that is time index -1: never a valid output)
         const cf *edge_row = bnd + ((j >> 6) > 0 ? ((j >> 6) - 1) * 16 : 47);
+        // two rows at a time so the demodulator's arithmetic runs on packed pairs (fast_atan2f_x2)
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int k = bin_of(q), row = 256 * k;
-            if (row + 255 < K) continue;                      // no valid output in this row: uniform skip
-            const cf a = u[q];
-            const cf edge = edge_row[k];                      // wave-uniform address: broadcast read
-            cf p;                                             // conj(y[m-1])
-            p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge.x), __float_as_int(a.x), 0x138, 0xf, 0xf, false));
-            p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge.y), __float_as_int(a.y), 0x138, 0xf, 0xf, false));
+        for (int q = 0; q < 16; q += 2) {
+            const int k0 = bin_of(q), k1 = bin_of(q + 1);
+            const bool live0 = 256 * k0 + 255 >= K, live1 = 256 * k1 + 255 >= K;   // any valid output in the row? (uniform)
+            if (!live0 && !live1) continue;
+            // conj(y[m-1]) for both rows; edge_row[k]: wave-uniform address, broadcast read
+            auto prev = [&](cf a, cf edge) {
+                cf p;
+                p.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge.x), __float_as_int(a.x), 0x138, 0xf, 0xf, false));
+                p.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge.y), __float_as_int(a.y), 0x138, 0xf, 0xf, false));
+                return p;
+            };
+            const cf a0 = u[q], a1 = u[q + 1];
+            const cf p0 = prev(a0, edge_row[k0]), p1 = prev(a1, edge_row[k1]);
             // y[m] * conj(y[m-1]) = conj(a) * p
-            const float re = a.x * p.x + a.y * p.y, im = a.x * p.y - a.y * p.x;
-            const float d = fast_atan2f(im, re);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)row * 4u), 0, SAUX);
+            const cf re = {a0.x * p0.x + a0.y * p0.y, a1.x * p1.x + a1.y * p1.y};
+            const cf im = {a0.x * p0.y - a0.y * p0.x, a1.x * p1.y - a1.y * p1.x};
+            const cf d = fast_atan2f_x2(im, re);
+            if (live0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d.x), ws, (int)(vbase + (unsigned)(256 * k0) * 4u), 0, SAUX);
+            if (live1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d.y), ws, (int)(vbase + (unsigned)(256 * k1) * 4u), 0, SAUX);
         }
         if (b == nblocks - 1) {
             // the stream's last output becomes the next call's carried state (kept conjugated)

@@ -630,20 +630,23 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     int rc = PCX_OK;
     if (num_bins == 1) {
         h->kind = pcx_fft::IDENTITY;
-    } else if (four_step && scalar == PCX_F32 && num_bins <= ((size_t)4 << 20) && !getenv("PCX_FFT_FIVE_PASS")) {
+    } else if (four_step && ((scalar == PCX_F32 && num_bins <= ((size_t)4 << 20)) || (scalar == PCX_F64 && num_bins <= ((size_t)2 << 20))) &&
+               !getenv("PCX_FFT_FIVE_PASS")) {
         h->kind = pcx_fft::FOURSTEP_SHORT;
+        const size_t sub_limit = fft_single_wg_limit(scalar);   // longest row transform: 16384 (float) / 8192 (double) bins
         static const size_t n1_forced = [] { const char *e = getenv("PCX_FFT_N1"); return e ? (size_t)atoi(e) : (size_t)0; }();
         // measured (tools/sweep_fft.py): 128 columns per tile (256-byte runs) beat 256 except where only n1 = 256
         // leaves n2 <= 256 (65,536 bins: two passes instead of three) or n2 would exceed the 16384-bin plans
         h->n1 = num_bins == 65536 ? 256 : 128;
         if (n1_forced == 128 || n1_forced == 256) h->n1 = n1_forced;
-        if (num_bins / h->n1 > 16384) h->n1 = 256;
+        if (num_bins / h->n1 > sub_limit) h->n1 = 256;
         h->n2 = num_bins / h->n1;                // 128 ... 16384
-        rc = upload(h->tw1, make_tw_r16(h->n1 == 128 ? 7 : 8));
+        const bool f64 = scalar == PCX_F64;
+        rc = f64 ? upload(h->tw1, make_tw_r16<double>(h->n1 == 128 ? 7 : 8)) : upload(h->tw1, make_tw_r16(h->n1 == 128 ? 7 : 8));
         if (rc == PCX_OK && h->n2 <= 256) {
             int l2 = 0;
             while (((size_t)1 << l2) < h->n2) l2++;
-            rc = upload(h->tw2, make_tw_r16(l2));
+            rc = f64 ? upload(h->tw2, make_tw_r16<double>(l2)) : upload(h->tw2, make_tw_r16(l2));
         } else if (rc == PCX_OK) {
             rc = pcx_fft_create(scalar, h->n2, inverse, &h->sub2);
         }
@@ -739,14 +742,15 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
     case pcx_fft::Q15_POW2:
         return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     case pcx_fft::FOURSTEP_SHORT: {
-        const size_t bytes = nframes * h->nbins * 8;
+        const bool f64 = h->scalar == PCX_F64;
+        const size_t bytes = nframes * h->nbins * (f64 ? 16 : 8);
         PCX_TRY(h->ws1.ensure(bytes));
         // columns of the n1 x n2 view (transform along n1, twiddle), then rows of n2 into natural order
-        PCX_TRY(launch_fft_columns(in_dev, h->ws1.p, h->n1 == 128 ? 7 : 8, h->n2, nframes, h->inverse != 0, h->tw1.p, st));
+        PCX_TRY((f64 ? launch_fft_columns_f64 : launch_fft_columns)(in_dev, h->ws1.p, h->n1 == 128 ? 7 : 8, h->n2, nframes, h->inverse != 0, h->tw1.p, st));
         if (h->n2 <= 256) {
             int l2 = 0;
             while (((size_t)1 << l2) < h->n2) l2++;
-            return launch_fft_rows_transposed(h->ws1.p, out_dev, h->n1, l2, nframes, h->inverse != 0, h->tw2.p, st);
+            return (f64 ? launch_fft_rows_transposed_f64 : launch_fft_rows_transposed)(h->ws1.p, out_dev, h->n1, l2, nframes, h->inverse != 0, h->tw2.p, st);
         }
         PCX_TRY(h->ws2.ensure(bytes));
         PCX_TRY(pcx_fft_transform_dev(h->sub2, h->ws1.p, h->ws2.p, nframes * h->n1, stream));

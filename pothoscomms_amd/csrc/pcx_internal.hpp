@@ -146,6 +146,8 @@ int launch_transpose(int scalar, const void *in, void *out, size_t rows, size_t 
 // short four-step plans (complex_float32): column transforms (n1 in {128, 256}) with the twiddle; row transforms with transposed store
 int launch_fft_columns(const void *in, void *out, int log2n1, size_t n2, size_t batch, bool inverse, const void *tw_table, hipStream_t st);
 int launch_fft_rows_transposed(const void *in, void *out, size_t n1, int log2n2, size_t batch, bool inverse, const void *tw_table, hipStream_t st);
+int launch_fft_columns_f64(const void *in, void *out, int log2n1, size_t n2, size_t batch, bool inverse, const void *tw_table, hipStream_t st);
+int launch_fft_rows_transposed_f64(const void *in, void *out, size_t n1, int log2n2, size_t batch, bool inverse, const void *tw_table, hipStream_t st);
 int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, hipStream_t st);
 int launch_fft_pow2_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
                          hipStream_t st);

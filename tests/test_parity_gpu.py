@@ -330,11 +330,14 @@ def test_fft_errors(dev):
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("dtype,nbins,nframes", [("complex_float32", 1 << 15, 3), ("complex_float32", 1 << 16, 2), ("complex_float32", 1 << 17, 2),
                                                  ("complex_float32", 1 << 20, 1), ("complex_float32", 1 << 22, 1), ("complex_float32", 1 << 23, 1),
-                                                 ("complex_float64", 1 << 13, 3), ("complex_float64", 1 << 16, 1)])
+                                                 ("complex_float64", 1 << 13, 3), ("complex_float64", 1 << 14, 3), ("complex_float64", 1 << 15, 2),
+                                                 ("complex_float64", 1 << 16, 2), ("complex_float64", 1 << 17, 1), ("complex_float64", 1 << 20, 1),
+                                                 ("complex_float64", 1 << 21, 1), ("complex_float64", 1 << 22, 1)])
 def test_fft_four_step_sizes(oracle, dev, dtype, nbins, nframes, inverse):
     """Power-of-two transforms beyond one workgroup against kissfft's restatement; same 1e-5 bar (1e-13 for
     float64).  complex_float32: two passes at 2^15 / 2^16 (columns with strided tiles, rows with the transpose
-    on their store), three to 2^22, the five-pass form beyond and for float64."""
+    on their store), three to 2^22, the five-pass form beyond.  complex_float64: one workgroup to 2^13, the same two /
+    three pass plans in double to 2^21 (fft_large_f64.hip), five passes beyond."""
     scalar = oracle.F32 if dtype.endswith("32") else oracle.F64
     rng = np.random.default_rng(nbins % 1000 + inverse)
     x = rand_stream(rng, scalar, nbins * nframes, True)

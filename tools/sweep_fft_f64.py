@@ -4,7 +4,7 @@ import torch
 from pothoscomms_amd import device
 d = torch.device("cuda", 0)
 total = 32 * 1024 * 1024
-for N in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536):
+for N in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1 << 17, 1 << 20, 1 << 21, 1 << 22):
     nframes = total // N
     x = torch.rand((nframes * N, 2), dtype=torch.float64, device=d) - 0.5
     y = torch.empty_like(x)

@@ -17,6 +17,7 @@
 //
 // This is the coverage path (sizes the radix-16 and power-of-two kernels do not take); it is
 // correctness-first and sized by LDS: numBins * sizeof(complex) * 2 <= 160 KB.
+#include <cstdlib>
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -24,11 +25,23 @@ namespace pcx {
 namespace {
 
 constexpr int kMaxStagesMixed = 24;
+// Per-stage geometry is resolved on the host: the kernel never divides by a run-time value, and every index product
+// is a 24-bit multiply (full rate; a 32-bit v_mul_lo/hi is quarter rate and the butterfly passes are VALU-bound).
+// q = floor(n / d) is (int)((n + 0.5f) * fl(1/d)): the exact (n + 0.5)/d sits at least 0.5/d from an integer and the
+// float product is off by at most (n + 0.5)/d * 2^-23, so the truncation is exact while n + 0.5 < 2^22 (here n <= 20480).
 struct MixedPlan {
     int nstages;
-    int radix[kMaxStagesMixed];  // top (stage 0) .. bottom, as kf_factor emits them
-    int needs_pingpong;          // any generic-radix pass
+    int radix[kMaxStagesMixed];        // top (stage 0) .. bottom, as kf_factor emits them
+    int m[kMaxStagesMixed];            // butterfly span below stage s (product of the radices after it)
+    int fstride[kMaxStagesMixed];      // N / (radix * m)
+    int nb[kMaxStagesMixed];           // N / radix: butterflies per frame and pass
+    float inv_m[kMaxStagesMixed], inv_nb[kMaxStagesMixed], inv_span[kMaxStagesMixed];   // 1/m, 1/(N/radix), 1/(radix*m)
+    float inv_n;                       // 1/N
+    int fpw;                           // frames per workgroup
+    int needs_pingpong;                // any generic-radix pass
 };
+__device__ __forceinline__ int fdiv(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
 template <typename T>
 struct Cx {
@@ -73,52 +86,55 @@ struct Q15Arith {
     static __device__ __forceinline__ scalar neg(scalar a) { return (int16_t)(-a); }
 };
 
-template <typename A>
-__global__ __launch_bounds__(256) void fft_mixed_kernel(const typename A::cpx *__restrict__ in, typename A::cpx *__restrict__ out,
-                                                        int N, size_t nframes, const typename A::cpx *__restrict__ tw,
-                                                        MixedPlan plan, int inverse)
+// TWLDS: the twiddle table (N entries, gathered per lane at k * fstride * j) sits in LDS behind the frame images,
+// copied once per persistent workgroup; otherwise it is read through L1/L2
+template <typename A, bool TWLDS>
+__global__ __launch_bounds__(1024) void fft_mixed_kernel(const typename A::cpx *__restrict__ in, typename A::cpx *__restrict__ out,
+                                                         int N, size_t nframes, const typename A::cpx *__restrict__ tw_global,
+                                                         const uint16_t *__restrict__ iperm, MixedPlan plan, int inverse)
 {
     typedef typename A::cpx cpx;
     typedef typename A::scalar scalar;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cpx *cur = reinterpret_cast<cpx *>(smem_raw);
-    cpx *alt = cur + N;
-    const int nt = blockDim.x;
-    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
-        const cpx *src = in + f * (size_t)N;
+    const int nt = blockDim.x, FPW = plan.fpw;
+    const size_t ngroups = (nframes + FPW - 1) / FPW;
+    cpx *tw_lds = reinterpret_cast<cpx *>(smem_raw) + (size_t)FPW * N * (plan.needs_pingpong ? 2 : 1);
+    if (TWLDS)
+        for (int i = threadIdx.x; i < N; i += nt) tw_lds[i] = tw_global[i];
+    const cpx *tw = TWLDS ? tw_lds : tw_global;
+    for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        cpx *cur = reinterpret_cast<cpx *>(smem_raw);
+        cpx *alt = cur + FPW * N;
+        const size_t f0 = grp * FPW;
+        const int nvalid = nframes - f0 < (size_t)FPW ? (int)(nframes - f0) : FPW;   // frames of this group
+        const cpx *src = in + f0 * (size_t)N;
         __syncthreads();
-        // leaves: position sum_s q_s*m_s  <-  input index sum_s q_s*fstride_s
-        for (int pos = threadIdx.x; pos < N; pos += nt) {
-            int rem = pos, m = N, fstride = 1, idx = 0;
-            for (int s = 0; s < plan.nstages; s++) {
-                const int p = plan.radix[s];
-                m /= p;
-                const int q = rem / m;
-                rem -= q * m;
-                idx += q * fstride;
-                fstride *= p;
-            }
-            cur[pos] = src[idx];
+        // leaves of kf_work: input index sum_s q_s*fstride_s goes to position sum_s q_s*m_s (host table, inverted so
+        // that the global reads are contiguous and the scatter lands in LDS)
+        for (int i = threadIdx.x; i < nvalid * N; i += nt) {
+            const int fi = fdiv(i, plan.inv_n), e = i - mul24(fi, N);
+            cur[mul24(fi, N) + iperm[e]] = src[i];
         }
         __syncthreads();
-        int m = 1;
         for (int s = plan.nstages - 1; s >= 0; s--) {
-            const int p = plan.radix[s];
-            const int fstride = N / (p * m);
+            const int p = plan.radix[s], m = plan.m[s], fstride = plan.fstride[s];
+            if (p <= 1) { __syncthreads(); continue; }     // never in a real plan: the timing-only skeleton (PCX_FFT_MIXED_DIAG=2)
             if (p == 2 || p == 3 || p == 4 || p == 5) {
-                const int nb = N / p;
-                for (int b = threadIdx.x; b < nb; b += nt) {
-                    const int k = b % m, g = b / m;
-                    cpx *F = cur + g * (p * m) + k;
+                const int nb = plan.nb[s];
+                for (int bb = threadIdx.x; bb < nvalid * nb; bb += nt) {
+                    const int fi = fdiv(bb, plan.inv_nb[s]), b = bb - mul24(fi, nb);
+                    const int g = fdiv(b, plan.inv_m[s]), k = b - mul24(g, m);
+                    cpx *F = cur + mul24(fi, N) + mul24(g, mul24(p, m)) + k;
+                    const int kf = mul24(k, fstride);   // twiddle index of W^k; its multiples are below radix * N < 2^24
                     if (p == 2) {  // kf_bfly2
                         const cpx f0 = A::fixdiv(F[0], 2), f1 = A::fixdiv(F[m], 2);
-                        const cpx t = A::mul(f1, tw[k * fstride]);
+                        const cpx t = A::mul(f1, tw[kf]);
                         F[m] = A::sub(f0, t);
                         F[0] = A::add(f0, t);
                     } else if (p == 4) {  // kf_bfly4
                         cpx f0 = A::fixdiv(F[0], 4);
                         const cpx f1 = A::fixdiv(F[m], 4), f2 = A::fixdiv(F[2 * m], 4), f3 = A::fixdiv(F[3 * m], 4);
-                        const cpx s0 = A::mul(f1, tw[k * fstride]), s1 = A::mul(f2, tw[k * fstride * 2]), s2 = A::mul(f3, tw[k * fstride * 3]);
+                        const cpx s0 = A::mul(f1, tw[kf]), s1 = A::mul(f2, tw[kf * 2]), s2 = A::mul(f3, tw[kf * 3]);
                         const cpx s5 = A::sub(f0, s1);
                         f0 = A::add(f0, s1);
                         const cpx s3 = A::add(s0, s2), s4 = A::sub(s0, s2);
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) void fft_mixed_kernel(const typename A::cpx *_
                     } else if (p == 3) {  // kf_bfly3
                         const cpx epi3 = tw[fstride * m];
                         const cpx f0 = A::fixdiv(F[0], 3), f1 = A::fixdiv(F[m], 3), f2 = A::fixdiv(F[2 * m], 3);
-                        const cpx s1 = A::mul(f1, tw[k * fstride]), s2 = A::mul(f2, tw[k * fstride * 2]);
+                        const cpx s1 = A::mul(f1, tw[kf]), s2 = A::mul(f2, tw[kf * 2]);
                         const cpx s3 = A::add(s1, s2);
                         cpx s0 = A::sub(s1, s2);
                         cpx fm = {A::ssub(f0.r, A::half(s3.r)), A::ssub(f0.i, A::half(s3.i))};
@@ -147,8 +163,8 @@ __global__ __launch_bounds__(256) void fft_mixed_kernel(const typename A::cpx *_
                         cpx f0 = A::fixdiv(F[0], 5);
                         const cpx f1 = A::fixdiv(F[m], 5), f2 = A::fixdiv(F[2 * m], 5), f3 = A::fixdiv(F[3 * m], 5), f4 = A::fixdiv(F[4 * m], 5);
                         const cpx s0 = f0;
-                        const cpx s1 = A::mul(f1, tw[k * fstride]), s2 = A::mul(f2, tw[2 * k * fstride]);
-                        const cpx s3 = A::mul(f3, tw[3 * k * fstride]), s4 = A::mul(f4, tw[4 * k * fstride]);
+                        const cpx s1 = A::mul(f1, tw[kf]), s2 = A::mul(f2, tw[kf * 2]);
+                        const cpx s3 = A::mul(f3, tw[kf * 3]), s4 = A::mul(f4, tw[kf * 4]);
                         const cpx s7 = A::add(s1, s4), s10 = A::sub(s1, s4), s8 = A::add(s2, s3), s9 = A::sub(s2, s3);
                         // Fout0 += s7 + s8 (kiss_fft.c:174-175 adds the sum; kissfft.hh:228-229 adds twice: same for floats up to rounding)
                         f0 = {A::sadd(f0.r, A::sadd(s7.r, s8.r)), A::sadd(f0.i, A::sadd(s7.i, s8.i))};
@@ -171,70 +187,104 @@ __global__ __launch_bounds__(256) void fft_mixed_kernel(const typename A::cpx *_
             } else {
                 // kf_bfly_generic, one output element per lane, cur -> alt
                 const int span = p * m;
-                for (int e = threadIdx.x; e < N; e += nt) {
-                    const int g = e / span, within = e - g * span;   // within = u + q1*m
-                    const int u = within % m;
-                    const cpx *S = cur + g * span + u;               // scratch[q] = fixdiv(S[q*m])
+                for (int ee = threadIdx.x; ee < nvalid * N; ee += nt) {
+                    const int fi = fdiv(ee, plan.inv_n), e = ee - mul24(fi, N);
+                    const int g = fdiv(e, plan.inv_span[s]), within = e - mul24(g, span);   // within = u + q1*m
+                    const int u = within - mul24(fdiv(within, plan.inv_m[s]), m);
+                    const cpx *S = cur + mul24(fi, N) + mul24(g, span) + u;      // scratch[q] = fixdiv(S[q*m])
                     const int k = within;                            // the reference's running k = u + q1*m
                     cpx acc = A::fixdiv(S[0], p);
+                    const int step = mul24(fstride, k);              // < N
                     int twidx = 0;
                     for (int q = 1; q < p; q++) {
-                        twidx += fstride * k;
+                        twidx += step;
                         if (twidx >= N) twidx -= N;
-                        acc = A::add(acc, A::mul(A::fixdiv(S[q * m], p), tw[twidx]));
+                        S += m;
+                        acc = A::add(acc, A::mul(A::fixdiv(S[0], p), tw[twidx]));
                     }
-                    alt[e] = acc;
+                    alt[ee] = acc;
                 }
                 __syncthreads();
                 cpx *t = cur; cur = alt; alt = t;
             }
-            m *= p;
         }
-        cpx *dst = out + f * (size_t)N;
-        for (int i = threadIdx.x; i < N; i += nt) dst[i] = cur[i];
+        cpx *dst = out + f0 * (size_t)N;
+        for (int i = threadIdx.x; i < nvalid * N; i += nt) dst[i] = cur[i];
         (void)sizeof(scalar);
     }
 }
 
 template <typename A>
-int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const int *radix, int nstages, hipStream_t st)
+int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm, const int *radix,
+                 int nstages, hipStream_t st)
 {
     if (nframes == 0) return PCX_OK;
     if (nstages > kMaxStagesMixed) { set_error("fft: too many stages for numBins %zu", nbins); return PCX_ERR_UNSUPPORTED; }
+    auto magic = [](size_t d) { return 1.0f / (float)d; };
     MixedPlan plan;
     plan.nstages = nstages;
     plan.needs_pingpong = 0;
-    for (int s = 0; s < nstages; s++) {
+    plan.inv_n = magic(nbins);
+    size_t m = 1;
+    for (int s = nstages - 1; s >= 0; s--) {
+        const size_t p = (size_t)radix[s];
         plan.radix[s] = radix[s];
-        if (radix[s] != 2 && radix[s] != 3 && radix[s] != 4 && radix[s] != 5) plan.needs_pingpong = 1;
+        plan.m[s] = (int)m;
+        plan.fstride[s] = (int)(nbins / (p * m));
+        plan.nb[s] = (int)(nbins / p);
+        plan.inv_m[s] = magic(m);
+        plan.inv_nb[s] = magic(nbins / p);
+        plan.inv_span[s] = magic(p * m);
+        if (p != 2 && p != 3 && p != 4 && p != 5) plan.needs_pingpong = 1;
+        m *= p;
     }
-    const size_t lds = nbins * sizeof(typename A::cpx) * 2;
-    if (lds > 160 * 1024) {
-        set_error("fft: numBins %zu does not fit the single-workgroup LDS plan (%zu bytes)", nbins, lds);
+    const size_t images = plan.needs_pingpong ? 2 : 1;
+    if (nbins * sizeof(typename A::cpx) * images > 160 * 1024) {
+        set_error("fft: numBins %zu does not fit the single-workgroup LDS plan (%zu bytes)", nbins, nbins * sizeof(typename A::cpx) * images);
         return PCX_ERR_UNSUPPORTED;
     }
-    auto k = fft_mixed_kernel<A>;
+    // short frames share a workgroup: about 4096 elements per group, so that every pass has >= 1024 butterflies
+    // PCX_FFT_MIXED_ELEMS (A/B): elements per workgroup the frame count is sized for
+    static const size_t group_elems = [] { const char *e = getenv("PCX_FFT_MIXED_ELEMS"); return e ? (size_t)atoi(e) : (size_t)4096; }();
+    size_t fpw = nbins >= group_elems ? 1 : group_elems / nbins;
+    if (fpw > nframes) fpw = nframes;
+    plan.fpw = (int)fpw;
+    size_t lds = fpw * nbins * sizeof(typename A::cpx) * images;
+    // PCX_FFT_MIXED_TWLDS=0 (A/B) keeps the twiddles in global memory
+    static const int tw_in_lds = [] { const char *e = getenv("PCX_FFT_MIXED_TWLDS"); return e ? atoi(e) : 1; }();
+    const bool twlds = tw_in_lds && lds + nbins * sizeof(typename A::cpx) <= 80 * 1024;
+    if (twlds) lds += nbins * sizeof(typename A::cpx);
+    auto k = twlds ? fft_mixed_kernel<A, true> : fft_mixed_kernel<A, false>;
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    unsigned threads = (unsigned)((nbins + 3) / 4);
+    unsigned threads = (unsigned)((fpw * nbins + 3) / 4);
     threads = (threads + 63) / 64 * 64;
     if (threads < 64) threads = 64;
-    if (threads > 256) threads = 256;
-    const unsigned grid = (unsigned)(nframes < 4096 ? nframes : 4096);
+    if (threads > 1024) threads = 1024;
+    // PCX_FFT_MIXED_DIAG=1 (timing only, wrong outputs): no butterfly passes, the load/scatter/store skeleton alone
+    static const int diag = [] { const char *e = getenv("PCX_FFT_MIXED_DIAG"); return e ? atoi(e) : 0; }();
+    if (diag == 1) plan.nstages = 0;
+    if (diag == 2) for (int q = 0; q < nstages; q++) plan.radix[q] = 1;   // stage loop, plan loads and barriers without butterflies
+    const size_t ngroups = (nframes + fpw - 1) / fpw;
+    unsigned per_cu = (unsigned)(160 * 1024 / lds);
+    const unsigned by_threads = 2048 / threads;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, (const typename A::cpx *)in, (typename A::cpx *)out, (int)nbins, nframes,
-                       (const typename A::cpx *)tw, plan, inverse ? 1 : 0);
+                       (const typename A::cpx *)tw, (const uint16_t *)iperm, plan, inverse ? 1 : 0);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
 
 }  // namespace
 
-int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
+int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
                      const int *radix_host, int nstages, hipStream_t st)
 {
     switch (scalar) {
-    case PCX_F32: return launch_mixed<FloatArith<float>>(in, out, nbins, nframes, inverse, tw, radix_host, nstages, st);
-    case PCX_F64: return launch_mixed<FloatArith<double>>(in, out, nbins, nframes, inverse, tw, radix_host, nstages, st);
-    case PCX_I16: return launch_mixed<Q15Arith>(in, out, nbins, nframes, inverse, tw, radix_host, nstages, st);
+    case PCX_F32: return launch_mixed<FloatArith<float>>(in, out, nbins, nframes, inverse, tw, iperm, radix_host, nstages, st);
+    case PCX_F64: return launch_mixed<FloatArith<double>>(in, out, nbins, nframes, inverse, tw, iperm, radix_host, nstages, st);
+    case PCX_I16: return launch_mixed<Q15Arith>(in, out, nbins, nframes, inverse, tw, iperm, radix_host, nstages, st);
     }
     set_error("fft: unsupported scalar %d", scalar);
     return PCX_ERR_ARG;

@@ -714,6 +714,24 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
             rc = upload(h->perm, perm);
         }
     }
+    if (rc == PCX_OK && h->kind == pcx_fft::MIXED) {
+        // inverse of kf_work's leaf gather (kiss_fft.c:276-280, kissfft.hh:94-98): input index sum q_s*fstride_s lands at
+        // position sum q_s*m_s; the mixed-radix kernel reads a frame contiguously and scatters it into LDS with this table
+        std::vector<uint16_t> iperm(num_bins);
+        for (size_t pos = 0; pos < num_bins; pos++) {
+            size_t rem = pos, m = num_bins, fstride = 1, idx = 0;
+            for (size_t si = 0; si < h->radix.size(); si++) {
+                const size_t p = (size_t)h->radix[si];
+                m /= p;
+                const size_t q = rem / m;
+                rem -= q * m;
+                idx += q * fstride;
+                fstride *= p;
+            }
+            iperm[idx] = (uint16_t)pos;
+        }
+        rc = upload(h->perm, iperm);
+    }
     if (rc != PCX_OK) { delete h; return rc; }
     *out = h;
     return PCX_OK;
@@ -768,7 +786,7 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         return launch_transpose(h->scalar, h->ws2.p, out_dev, h->n1, h->n2, nframes, 0, st);
     }
     case pcx_fft::MIXED:
-        return launch_fft_mixed(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
+        return launch_fft_mixed(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     }
     return PCX_ERR_STATE;
 }

@@ -18,6 +18,7 @@
 // This is the coverage path (sizes the radix-16 and power-of-two kernels do not take); it is
 // correctness-first and sized by LDS: numBins * sizeof(complex) * 2 <= 160 KB.
 #include <cstdlib>
+#include "fft4096.hpp"
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -214,6 +215,111 @@ __global__ __launch_bounds__(1024) void fft_mixed_kernel(const typename A::cpx *
     }
 }
 
+// --------------------------------------------------------------------------------- //
+// complex_float32, 5-smooth sizes (2^a 3^b 5^c: 1536, 1200, 600, 1000, 1920 ...): the same in-place
+// decimation-in-time passes over the LDS image, but with the radices a float transform is free to choose --
+// 16s first (fft16_plain of fft4096.hpp in registers), then 8 / 4 / 2, then 5s and 3s -- where kissfft's order
+// (4s, 2s, 3s, 5s: kissfft.hh:38-55) is only binding for the bit-exact Q15 path.  1536 bins take 3 passes
+// (16, 16, 2*3 ...) instead of 6, and one lane does 16 points' worth of arithmetic per index computation.
+// Forward twiddles only: the inverse is conj . FFT . conj, folded into the leaf scatter and the final store.
+// Same DFT as kissfft<float>::transform (kissfft.hh:81-161), parity bar 1e-5 of max|X|.
+// --------------------------------------------------------------------------------- //
+template <bool TWLDS, bool INV, bool PAD>
+__global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int N, size_t nframes,
+                                                              const float2 *__restrict__ tw_global, const uint16_t *__restrict__ iperm,
+                                                              MixedPlan plan)
+{
+    using namespace fft4k;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int nt = blockDim.x, FPW = plan.fpw;
+    const size_t ngroups = (nframes + FPW - 1) / FPW;
+    cf *cur = reinterpret_cast<cf *>(smem_raw);
+    const int img = FPW * N;
+    cf *tw_lds = cur + (PAD ? img + (img >> 4) + 1 : img);
+    auto P = [](int i) { return PAD ? i + (i >> 4) : i; };   // padded image: spans that are multiples of 32 elements no longer alias
+    const cf *twg = reinterpret_cast<const cf *>(tw_global);
+    if (TWLDS)
+        for (int i = threadIdx.x; i < N; i += nt) tw_lds[i] = twg[i];
+    const cf *tw = TWLDS ? tw_lds : twg;
+    for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const size_t f0 = grp * FPW;
+        const int nvalid = nframes - f0 < (size_t)FPW ? (int)(nframes - f0) : FPW;
+        const cf *src = reinterpret_cast<const cf *>(in) + f0 * (size_t)N;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nvalid * N; i += nt) {
+            const int fi = fdiv(i, plan.inv_n), e = i - mul24(fi, N);
+            const cf t = src[i];
+            cur[P(mul24(fi, N) + iperm[e])] = cf{t.x, INV ? -t.y : t.y};
+        }
+        __syncthreads();
+        for (int s = plan.nstages - 1; s >= 0; s--) {
+            const int p = plan.radix[s], m = plan.m[s], fstride = plan.fstride[s], nb = plan.nb[s];
+            for (int bb = threadIdx.x; bb < nvalid * nb; bb += nt) {
+                const int fi = fdiv(bb, plan.inv_nb[s]), b = bb - mul24(fi, nb);
+                const int g = fdiv(b, plan.inv_m[s]), k = b - mul24(g, m);
+                const int fb = mul24(fi, N) + mul24(g, mul24(p, m)) + k;   // element j of the butterfly: cur[P(fb + j*m)]
+                const int kf = mul24(k, fstride);       // W^k; j * kf < N for j < p
+                if (p == 16) {
+                    cf v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) v[j] = cur[P(fb + j * m)];
+#pragma unroll
+                    for (int j = 1; j < 16; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    fft16_plain(v);
+#pragma unroll
+                    for (int q = 0; q < 16; q++) cur[P(fb + bin_of(q) * m)] = v[q];
+                } else if (p == 8) {
+                    cf v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = cur[P(fb + j * m)];
+#pragma unroll
+                    for (int j = 1; j < 8; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    fft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) cur[P(fb + j * m)] = v[j];
+                } else if (p == 4) {
+                    cf a = cur[P(fb)], b1 = cmul1(cur[P(fb + m)], tw[kf]), c = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]), d = cmul1(cur[P(fb + 3 * m)], tw[3 * kf]);
+                    fft4(a, b1, c, d);
+                    cur[P(fb)] = a; cur[P(fb + m)] = b1; cur[P(fb + 2 * m)] = c; cur[P(fb + 3 * m)] = d;
+                } else if (p == 2) {
+                    const cf a = cur[P(fb)], t = cmul1(cur[P(fb + m)], tw[kf]);
+                    cur[P(fb)] = a + t;
+                    cur[P(fb + m)] = a - t;
+                } else if (p == 3) {
+                    // X1 = a - (b+c)/2 - i (sqrt3/2)(b-c), X2 = a - (b+c)/2 + i (sqrt3/2)(b-c)
+                    const cf a = cur[P(fb)], b1 = cmul1(cur[P(fb + m)], tw[kf]), c = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]);
+                    const cf sum = b1 + c, d = (b1 - c) * cf{0.86602540378443864676f, 0.86602540378443864676f};
+                    const cf h = a - sum * cf{0.5f, 0.5f};
+                    cur[P(fb)] = a + sum;
+                    cur[P(fb + m)] = cf{h.x + d.y, h.y - d.x};
+                    cur[P(fb + 2 * m)] = cf{h.x - d.y, h.y + d.x};
+                } else {   // p == 5
+                    // with c1 = cos(2pi/5), c2 = cos(4pi/5), s1 = sin(2pi/5), s2 = sin(4pi/5):
+                    // X1,4 = a + c1 t1 + c2 t2 -+ i (s1 t3 + s2 t4),  X2,3 = a + c2 t1 + c1 t2 -+ i (s2 t3 - s1 t4)
+                    constexpr float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;
+                    constexpr float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;
+                    const cf a = cur[P(fb)], x1 = cmul1(cur[P(fb + m)], tw[kf]), x2 = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]), x3 = cmul1(cur[P(fb + 3 * m)], tw[3 * kf]),
+                             x4 = cmul1(cur[P(fb + 4 * m)], tw[4 * kf]);
+                    const cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+                    const cf u1 = a + t1 * cf{C1, C1} + t2 * cf{C2, C2}, u2 = a + t1 * cf{C2, C2} + t2 * cf{C1, C1};
+                    const cf w1 = t3 * cf{S1, S1} + t4 * cf{S2, S2}, w2 = t3 * cf{S2, S2} - t4 * cf{S1, S1};
+                    cur[P(fb)] = a + t1 + t2;
+                    cur[P(fb + m)] = cf{u1.x + w1.y, u1.y - w1.x};         // u1 - i w1
+                    cur[P(fb + 4 * m)] = cf{u1.x - w1.y, u1.y + w1.x};     // u1 + i w1
+                    cur[P(fb + 2 * m)] = cf{u2.x + w2.y, u2.y - w2.x};
+                    cur[P(fb + 3 * m)] = cf{u2.x - w2.y, u2.y + w2.x};
+                }
+            }
+            __syncthreads();
+        }
+        cf *dst = reinterpret_cast<cf *>(out) + f0 * (size_t)N;
+        for (int i = threadIdx.x; i < nvalid * N; i += nt) {
+            const cf t = cur[P(i)];
+            dst[i] = cf{t.x, INV ? -t.y : t.y};
+        }
+    }
+}
+
 template <typename A>
 int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm, const int *radix,
                  int nstages, hipStream_t st)
@@ -276,6 +382,65 @@ int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool i
     return PCX_OK;
 }
 
+int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm, const int *radix,
+                  int nstages, hipStream_t st)
+{
+    if (nframes == 0) return PCX_OK;
+    if (nstages > kMaxStagesMixed) { set_error("fft: too many stages for numBins %zu", nbins); return PCX_ERR_UNSUPPORTED; }
+    MixedPlan plan;
+    plan.nstages = nstages;
+    plan.needs_pingpong = 0;
+    plan.inv_n = 1.0f / (float)nbins;
+    size_t m = 1;
+    for (int s = nstages - 1; s >= 0; s--) {
+        const size_t p = (size_t)radix[s];
+        plan.radix[s] = radix[s];
+        plan.m[s] = (int)m;
+        plan.fstride[s] = (int)(nbins / (p * m));
+        plan.nb[s] = (int)(nbins / p);
+        plan.inv_m[s] = 1.0f / (float)m;
+        plan.inv_nb[s] = 1.0f / (float)(nbins / p);
+        plan.inv_span[s] = 1.0f / (float)(p * m);
+        m *= p;
+    }
+    size_t fpw = nbins >= 4096 ? 1 : 4096 / nbins;
+    if (fpw > nframes) fpw = nframes;
+    plan.fpw = (int)fpw;
+    // PCX_FFT_SMOOTH_PAD=1 (A/B): image padded i + i/16.  Measured: 1536 bins (span 96 = 3 * 32 elements, the worst
+    // aliasing case) unchanged at 140 Gsamples/s, every other size 5-15 % slower from the extra index arithmetic -- the
+    // passes wait on VALU issue, not on LDS banks -- so the plain image is the default
+    static const int pad = [] { const char *e = getenv("PCX_FFT_SMOOTH_PAD"); return e ? atoi(e) : 0; }();
+    const size_t img = fpw * nbins;
+    size_t lds = (pad ? img + img / 16 + 1 : img) * 8;
+    const bool twlds = lds + nbins * 8 <= 96 * 1024;
+    if (twlds) lds += nbins * 8;
+    if (lds > 160 * 1024) { set_error("fft: numBins %zu does not fit the single-workgroup LDS plan", nbins); return PCX_ERR_UNSUPPORTED; }
+    auto k = pad ? (twlds ? (inverse ? fft_smooth_f32_kernel<true, true, true> : fft_smooth_f32_kernel<true, false, true>)
+                          : (inverse ? fft_smooth_f32_kernel<false, true, true> : fft_smooth_f32_kernel<false, false, true>))
+                 : (twlds ? (inverse ? fft_smooth_f32_kernel<true, true, false> : fft_smooth_f32_kernel<true, false, false>)
+                          : (inverse ? fft_smooth_f32_kernel<false, true, false> : fft_smooth_f32_kernel<false, false, false>));
+    if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // lanes per group = elements / div.  Measured (tools/sweep_fft_mixed.py with PCX_FFT_SMOOTH_DIV = 4 ... 16): more, smaller
+    // workgroups per CU beat one butterfly per lane in every pass -- 6 for short frames, 8 to 4095 bins, 4 beyond
+    int rmin = nbins < 256 ? 6 : nbins < 4096 ? 8 : 4;
+    static const int div_forced = [] { const char *e = getenv("PCX_FFT_SMOOTH_DIV"); return e ? atoi(e) : 0; }();
+    if (div_forced > 0) rmin = div_forced;
+    unsigned threads = (unsigned)((fpw * nbins + rmin - 1) / rmin);
+    threads = (threads + 63) / 64 * 64;
+    if (threads < 64) threads = 64;
+    if (threads > 1024) threads = 1024;
+    const size_t ngroups = (nframes + fpw - 1) / fpw;
+    unsigned per_cu = (unsigned)(160 * 1024 / lds);
+    const unsigned by_threads = 2048 / threads;
+    if (per_cu > by_threads) per_cu = by_threads;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, (const float2 *)in, (float2 *)out, (int)nbins, nframes, (const float2 *)tw,
+                       (const uint16_t *)iperm, plan);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 }  // namespace
 
 int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
@@ -290,4 +455,13 @@ int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t
     return PCX_ERR_ARG;
 }
 
+}  // namespace pcx
+
+namespace pcx {
+// complex_float32, numBins = 2^a 3^b 5^c: radices (16 / 8 / 4 / 2 / 5 / 3) chosen by pcx_api.hip, forward twiddle table
+int launch_fft_smooth_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
+                           const int *radix_host, int nstages, hipStream_t st)
+{
+    return launch_smooth(in, out, nbins, nframes, inverse, tw, iperm, radix_host, nstages, st);
+}
 }  // namespace pcx

@@ -567,7 +567,7 @@ struct pcx_fft {
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
-    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, FOURSTEP, FOURSTEP_SHORT } kind = MIXED;
+    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, SMOOTH, FOURSTEP, FOURSTEP_SHORT } kind = MIXED;
     int log2n = 0;
     DevBuf tw, perm, wsIn, wsOut;
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
@@ -581,6 +581,12 @@ struct pcx_fft {
     ~pcx_fft() { delete sub1; delete sub2; }
 };
 // longest power-of-two transform one workgroup handles
+static bool fft_is_5_smooth(size_t n)
+{
+    for (size_t r : {2, 3, 5})
+        while (n % r == 0) n /= r;
+    return n == 1;
+}
 static size_t fft_single_wg_limit(int scalar) { return scalar == PCX_F32 ? 16384 : scalar == PCX_F64 ? 8192 : 4096; }
 
 int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
@@ -670,6 +676,19 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         h->kind = pcx_fft::R16;
         while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
         rc = upload(h->tw, make_tw_r16<double>(h->log2n));
+    } else if (scalar == PCX_F32 && !pow2 && fft_is_5_smooth(num_bins) && num_bins < 8192 && !getenv("PCX_FFT_KISS_ORDER")) {
+        // complex_float32, 2^a 3^b 5^c bins: a float transform may take its radices in any order -- 16s first, then
+        // 8 / 4 / 2, 5s, 3s (fft_smooth_f32_kernel); kissfft's own order stays with the bit-exact Q15 path.
+        // PCX_FFT_KISS_ORDER (A/B) keeps the kissfft plan, as do the few sizes from 8192 bins up (10000: 102 vs 94 Gsamples/s).
+        // Forward table; the kernel conjugates around it for the inverse.
+        h->kind = pcx_fft::SMOOTH;
+        h->radix.clear();
+        size_t n = num_bins;
+        for (int r : {16, 8, 4, 2, 5, 3})
+            while (n % (size_t)r == 0) { h->radix.push_back(r); n /= (size_t)r; }
+        std::vector<float> t(2 * num_bins);
+        for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(-std::sin(two_pi * i / num_bins)); }
+        rc = upload(h->tw, t);
     } else if (scalar != PCX_I16) {
         // forward table exp(-j 2 pi i / N); the power-of-two kernels conjugate it for the inverse,
         // the mixed-radix kernel gets the direction baked in like kissfft's fill_twiddles (kissfft.hh:21-26)
@@ -714,7 +733,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
             rc = upload(h->perm, perm);
         }
     }
-    if (rc == PCX_OK && h->kind == pcx_fft::MIXED) {
+    if (rc == PCX_OK && (h->kind == pcx_fft::MIXED || h->kind == pcx_fft::SMOOTH)) {
         // inverse of kf_work's leaf gather (kiss_fft.c:276-280, kissfft.hh:94-98): input index sum q_s*fstride_s lands at
         // position sum q_s*m_s; the mixed-radix kernel reads a frame contiguously and scatters it into LDS with this table
         std::vector<uint16_t> iperm(num_bins);
@@ -785,6 +804,8 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         PCX_TRY(pcx_fft_transform_dev(h->sub2, h->ws1.p, h->ws2.p, nframes * h->n1, stream));
         return launch_transpose(h->scalar, h->ws2.p, out_dev, h->n1, h->n2, nframes, 0, st);
     }
+    case pcx_fft::SMOOTH:
+        return launch_fft_smooth_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     case pcx_fft::MIXED:
         return launch_fft_mixed(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     }

@@ -94,15 +94,73 @@ __device__ __forceinline__ void xform(cd (&v)[16], cd *lds, int l, T3 t3, const 
     }
 }
 
-template <int LOG2N>
-__global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_per_eu(2))) void fir_cf64_ols_kernel(const double2 *__restrict__ in, size_t in_elems,
-                                                                          double2 *__restrict__ out, size_t n_out,
+// Stream element types this pipeline serves.  IO = 0: complex_float64 as is.  IO = 1 / 2: complex_int16 / complex_int8 --
+// the reference's integer FIR is the EXACT integer convolution with the Q-format taps reduced modulo 2^qbits, then
+// fromQ (>> qbits/2) and truncation to the element width (FIRFilter.cpp:295-300, Pothos::Util::fromQ).  A double
+// transform carries that convolution exactly: with |x| <= 2^15, ||h_q||_2 < 2^22 (checked by the caller) and 4096-
+// or 8192-sample blocks its error stays below 0.05 (eps * c log2 N * ||x||_2 ||h||_2), so rounding to the nearest
+// integer recovers every sum bit for bit before the same wrap, shift and truncation are applied.
+template <int IO>
+struct StreamIo;
+template <>
+struct StreamIo<0> {
+    static constexpr int EB = 16;
+    template <int AUX> static __device__ __forceinline__ cd load(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+    {
+        return as_cd(__builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX));
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y)
+    {
+        __builtin_amdgcn_raw_buffer_store_b128(as_u4(y), ws, voff, 0, kAuxStream);
+    }
+};
+template <>
+struct StreamIo<1> {
+    static constexpr int EB = 4;
+    template <int AUX> static __device__ __forceinline__ cd load(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+    {
+        const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX);
+        return cd{(double)(short)(t & 0xffffu), (double)(short)(t >> 16)};
+    }
+    static __device__ __forceinline__ unsigned q(double d)   // wrap to the 32-bit Q accumulator, fromQ, truncate to int16
+    {
+        const int w = (int)(unsigned)(unsigned long long)__double2ll_rn(d);
+        return (unsigned)(w >> 16) & 0xffffu;
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(q(y.x) | (q(y.y) << 16), ws, voff, 0, kAuxStream);
+    }
+};
+template <>
+struct StreamIo<2> {
+    static constexpr int EB = 2;
+    template <int AUX> static __device__ __forceinline__ cd load(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+    {
+        const unsigned t = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, AUX);
+        return cd{(double)(signed char)(t & 0xffu), (double)(signed char)((t >> 8) & 0xffu)};
+    }
+    static __device__ __forceinline__ unsigned q(double d)   // 16-bit Q accumulator, >> 8, truncate to int8
+    {
+        const short w = (short)(unsigned short)(unsigned long long)__double2ll_rn(d);
+        return (unsigned)(w >> 8) & 0xffu;
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y)
+    {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(q(y.x) | (q(y.y) << 8)), ws, voff, 0, kAuxStream);
+    }
+};
+
+template <int LOG2N, int IO>
+__global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_per_eu(2))) void fir_cf64_ols_kernel(const unsigned char *__restrict__ in, size_t in_elems,
+                                                                          unsigned char *__restrict__ out, size_t n_out,
                                                                           const double2 *__restrict__ Hspec, int Kov, int pad,
                                                                           const double2 *__restrict__ twtab, size_t first_full,
                                                                           size_t nfull, size_t nblocks)
 {
     typedef OlsPlan<LOG2N> P;
-    constexpr int N = P::N, LPF = P::LPF;
+    typedef StreamIo<IO> SIO;
+    constexpr int N = P::N, LPF = P::LPF, EB = SIO::EB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd *lds = reinterpret_cast<cd *>(smem_raw);
     const int l = threadIdx.x;
@@ -130,20 +188,19 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
         if (b >= first_full && b < nfull) {
             // overlap rows (the first and last of the window, shared with the neighbouring blocks) keep the
             // default cache policy, the rest of the window is touched once
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + b * S - pad, N * 16);
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + (b * S - pad) * EB, N * EB);
 #pragma unroll
             for (int s = 0; s < 16; s++)
-                v[s] = as_cd(s < nov || s >= 16 - nov ? __builtin_amdgcn_raw_buffer_load_b128(rs, l * 16, s * LPF * 16, 0)
-                                                      : __builtin_amdgcn_raw_buffer_load_b128(rs, l * 16, s * LPF * 16, kAuxStream));
+                v[s] = s < nov || s >= 16 - nov ? SIO::template load<0>(rs, l * EB, s * LPF * EB) : SIO::template load<kAuxStream>(rs, l * EB, s * LPF * EB);
         } else {
             // ragged: block 0 when pad > 0 (samples before the buffer only feed dropped outputs) and the tail
             const size_t shift = b * S >= (size_t)pad ? 0 : (size_t)pad - b * S;
             const size_t first = b * S + shift - pad;
             const size_t left = in_elems > first ? in_elems - first : 0;
             const size_t want = (size_t)N - shift;
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 16));
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first * EB, (unsigned)((left < want ? left : want) * EB));
 #pragma unroll
-            for (int s = 0; s < 16; s++) v[s] = as_cd(__builtin_amdgcn_raw_buffer_load_b128(rs, (l + LPF * s - (int)shift) * 16, 0, 0));
+            for (int s = 0; s < 16; s++) v[s] = SIO::template load<0>(rs, (l + LPF * s - (int)shift) * EB, 0);
         }
         xform<LOG2N>(v, lds, l, tw3, tf);
         // u = conj(X .* H) in the first-pass layout of the next transform (register k <- bin k*LPF + l)
@@ -156,18 +213,18 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
         }
         xform<LOG2N>(u, lds, l, tw3, tf);
         const size_t room = n_out - b * S;
-        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)((room < S ? room : S) * 16));
-        const unsigned vbase = (unsigned)(l - Kov) * 16u;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S * EB, (unsigned)((room < S ? room : S) * EB));
+        const unsigned vbase = (unsigned)(l - Kov) * (unsigned)EB;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int row = LPF * (P::NATURAL ? q : bin_of(q));
             if (row + LPF - 1 < Kov) continue;                // whole row dropped: uniform skip
-            __builtin_amdgcn_raw_buffer_store_b128(as_u4(cd{u[q].x, -u[q].y}), ws, (int)(vbase + (unsigned)row * 16u), 0, kAuxStream);
+            SIO::store(ws, (int)(vbase + (unsigned)row * (unsigned)EB), cd{u[q].x, -u[q].y});
         }
     }
 }
 
-template <int LOG2N>
+template <int LOG2N, int IO>
 int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, hipStream_t st)
 {
     typedef OlsPlan<LOG2N> P;
@@ -182,7 +239,7 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     while (nfull > first_full && (nfull - 1) * S - pad + P::N > in_elems) nfull--;
     if (nfull < first_full) nfull = first_full;
     const size_t lds = (size_t)(P::LDS_IMG + P::LDS_T2) * sizeof(cd);
-    auto k = fir_cf64_ols_kernel<LOG2N>;
+    auto k = fir_cf64_ols_kernel<LOG2N, IO>;
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // resident workgroups per CU: LDS (160 KiB) and 8 waves of <= 256 VGPRs
     unsigned per_cu = (unsigned)(160 * 1024 / lds);
@@ -190,7 +247,7 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     const unsigned grid = persistent_grid(nblocks, 256 * per_cu);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const double2 *)in, in_elems, (double2 *)out, n_out,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out,
                        (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, first_full, nfull, nblocks);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
@@ -198,17 +255,24 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
 
 }  // namespace
 
-// log2n in {10 .. 13}; Hspec = FFT_N(h)/N in double, tw = make_tw_r16<double>(log2n) (pcx_api.hip)
+// log2n in {10 .. 13}; Hspec = FFT_N(h)/N in double, tw = make_tw_r16<double>(log2n) (pcx_api.hip).  io: 0 complex_float64,
+// 1 complex_int16, 2 complex_int8 (h = the Q-format integer taps; see StreamIo)
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
-                        const void *tw, hipStream_t st)
+                        const void *tw, int io, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
+#define PCX_OLS64_CASE(L2)                                                                                    \
+    case L2:                                                                                                  \
+        return io == 0   ? launch_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, st)                     \
+               : io == 1 ? launch_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, st)                     \
+                         : launch_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, st);
     switch (log2n) {
-    case 10: return launch_ols<10>(in, in_elems, out, n_out, Hspec, K, tw, st);
-    case 11: return launch_ols<11>(in, in_elems, out, n_out, Hspec, K, tw, st);
-    case 12: return launch_ols<12>(in, in_elems, out, n_out, Hspec, K, tw, st);
-    case 13: return launch_ols<13>(in, in_elems, out, n_out, Hspec, K, tw, st);
+        PCX_OLS64_CASE(10)
+        PCX_OLS64_CASE(11)
+        PCX_OLS64_CASE(12)
+        PCX_OLS64_CASE(13)
     }
+#undef PCX_OLS64_CASE
     set_error("fir ols f64: no plan for log2(N) = %d", log2n);
     return PCX_ERR_UNSUPPORTED;
 }

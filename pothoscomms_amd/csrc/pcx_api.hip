@@ -226,6 +226,7 @@ struct pcx_fir {
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
     bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
+    bool have_ols_int = false;    // complex_int16 / complex_int8 stream, M=L=1: exact integer convolution on the double transform
     DevBuf HspecRows;
     int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
     bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
@@ -254,6 +255,15 @@ constexpr size_t kOlsMaxTaps = 8193;
 constexpr size_t kOls64MaxTaps = 4097;
 // below this many taps the sliding-window kernel is the faster complex_float64 form (tools/sweep_fir_f64.py: 128 vs 112 Gsamples/s at K = 2)
 constexpr size_t kOls64MinTaps = 4;
+// complex_int16 / complex_int8 on the same pipeline (bit-exact): 166-170 / 128-131 Gsamples/s whatever the tap count, so it
+// takes over where the packed dot-product kernel falls below that (tools/sweep_fir_int.py: 164 Gsamples/s at 63 taps, 91 at
+// 127, 48 at 255, 12 at 1023); PCX_OLS_INT_MIN overrides (A/B)
+static size_t ols_int_min_taps(int scalar)
+{
+    static const size_t forced = [] { const char *e = getenv("PCX_OLS_INT_MIN"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    return forced ? forced : scalar == PCX_I16 ? 64 : 96;
+}
+
 static int fir_ols64_block_log2(size_t K)
 {
     static const int forced = [] { const char *e = getenv("PCX_OLS64_N"); return e ? atoi(e) : 0; }();
@@ -370,6 +380,25 @@ static int fir_sync_tables(pcx_fir *h)
         PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
         PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
         h->have_ols64 = true;
+    }
+    h->have_ols_int = false;
+    if ((h->scalar == PCX_I16 || h->scalar == PCX_I8) && h->cplx && h->M == 1 && h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
+        // the Q-format taps exactly as the time-domain kernels use them (floatToQ<QTapsType>, FIRFilter.cpp:348), as doubles;
+        // the double transform reproduces the integer convolution bit for bit while ||h_q||_2 < 2^22 (fir_ols_f64.hip)
+        const int qb = q_bits(h->scalar);
+        auto tq = [&](double t) { return h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb); };
+        std::vector<std::complex<double>> hq(h->K);
+        double norm2 = 0;
+        for (size_t k = 0; k < h->K; k++) {
+            hq[k] = std::complex<double>(tq(h->ctaps ? h->taps[2 * k] : h->taps[k]), h->ctaps ? tq(h->taps[2 * k + 1]) : 0.0);
+            norm2 += std::norm(hq[k]);
+        }
+        if (norm2 < 17592186044416.0) {   // 2^44
+            h->ols_log2n = fir_ols64_block_log2(h->K);
+            PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
+            PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
+            h->have_ols_int = true;
+        }
     }
     h->have_real_ols = false;
     if (h->scalar == PCX_F32 && !h->cplx && h->M == 1 && h->L == 1 && h->K <= 2049) {
@@ -491,21 +520,23 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // K == 1 (the block's default unit tap) stays on the time-domain tile: a pass-through
         // filter must return its input bit for bit, as the reference does
         if (fast && h->K == 1) algo = PCX_FIR_DIRECT;
-        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_ols64 && h->K >= kOls64MinTaps)) algo = PCX_FIR_OLS_FFT;
+        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_ols64 && h->K >= kOls64MinTaps) ||
+                 (h->have_ols_int && h->K >= ols_int_min_taps(h->scalar))) algo = PCX_FIR_OLS_FFT;
         // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
         // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
-    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64)) {
-        set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64, M=L=1, 2<=K<=4097");
+    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64 || h->have_ols_int)) {
+        set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
-    if (algo == PCX_FIR_OLS_FFT && h->have_ols64) {
-        rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
+    if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
+        rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
+                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {

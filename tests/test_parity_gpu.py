@@ -398,6 +398,42 @@ def test_fir_cf64_overlap_save(oracle, dev, ntaps, ctaps):
         assert nerr(got, ref) <= 1e-13, (ntaps, n)
 
 
+@pytest.mark.parametrize("ctaps", [False, True])
+@pytest.mark.parametrize("scalar_name", ["int16", "int8"])
+@pytest.mark.parametrize("ntaps", [2, 63, 64, 95, 96, 255, 1000, 2049, 2050, 4097, 4098])
+def test_fir_complex_integer_overlap_save_bit_exact(oracle, dev, ntaps, scalar_name, ctaps):
+    """complex_int16 / complex_int8, M = L = 1: from 64 / 96 taps AUTO takes the double-precision overlap-save pipeline, whose
+    rounded sums ARE the integer convolution (then the reference's wrap, fromQ shift and truncation): bit-exact against
+    the oracle's ring arithmetic, random full-scale inputs and the extreme case (every sample -2^(bits-1), taps at +-0.4999)."""
+    scalar = oracle.I16 if scalar_name == "int16" else oracle.I8
+    rng = np.random.default_rng(11 * ntaps + ctaps)
+    full = 32768 if scalar == oracle.I16 else 128
+    for case in ("random", "extreme"):
+        if case == "random":
+            taps = _taps(rng, ntaps, ctaps) * 0.9
+            n = 2 * 4096 + 777 + ntaps
+            x = rng.integers(-full, full, size=(n, 2)).astype(np.int16 if scalar == oracle.I16 else np.int8)
+        else:
+            sgn = rng.choice([-1.0, 1.0], size=ntaps)
+            taps = 0.4999 * sgn + (0.4999j * rng.choice([-1.0, 1.0], size=ntaps) if ctaps else 0)
+            n = 4096 + 100 + ntaps
+            x = np.full((n, 2), -full, dtype=np.int16 if scalar == oracle.I16 else np.int8)
+            x[::7, 0] = full - 1
+        ref_blk = oracle.Fir(scalar, True, ctaps)
+        ref_blk.set_taps(taps); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n)
+        f = dev.FirFilter((scalar, True), "COMPLEX" if ctaps else "REAL")
+        f.set_taps(taps)
+        got, gc, gp = f.process(x, n)
+        assert (gc, gp) == (rc, rp)
+        lo = 64 if scalar == oracle.I16 else 96
+        assert f.last_algo == (dev._lib.FIR_OLS_FFT if lo <= ntaps <= 4097 else dev._lib.FIR_EXACT), (ntaps, f.last_algo)
+        f.set_algo(dev._lib.FIR_OLS_FFT if ntaps <= 4097 else dev._lib.FIR_EXACT)     # and forced, below the crossover too
+        got2, _, _ = f.process(x, n)
+        assert np.array_equal(got2, ref), (case, ntaps, "forced")
+        assert np.array_equal(got, ref), (case, ntaps)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

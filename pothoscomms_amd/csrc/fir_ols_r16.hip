@@ -44,7 +44,9 @@ struct OlsPlan {
 };
 
 // forward DFT_N of the block held as v[s] = x[l + s*LPF]; on exit v[q] = X[l + LPF*(NATURAL ? q : bin_of(q))]
-template <int LOG2N>
+// TFS: stride of the final-pass twiddles behind `tf` (1: the lane's register copy; LPF: the device table itself,
+// re-read at each use by the 16384-sample plan, which has no registers left for them)
+template <int LOG2N, int TFS = 1>
 __device__ __forceinline__ void xform(cf (&v)[16], cf *lds, int l, const LaneTw &t3, const cf *tf)
 {
     typedef OlsPlan<LOG2N> P;
@@ -95,7 +97,7 @@ __device__ __forceinline__ void xform(cf (&v)[16], cf *lds, int l, const LaneTw 
 #pragma unroll
         for (int t = 0; t < G; t++) {
 #pragma unroll
-            for (int r = 1; r < R; r++) v[t + r * G] = cmul1(v[t + r * G], tf[t * (R - 1) + (r - 1)]);
+            for (int r = 1; r < R; r++) v[t + r * G] = cmul1(v[t + r * G], tf[(t * (R - 1) + (r - 1)) * TFS]);
             if (R == 2) {
                 const cf a = v[t], b = v[t + G];
                 v[t] = a + b;
@@ -136,13 +138,28 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF, 4) void fir_cf32_ols_r16_kerne
 #pragma unroll
         for (int p = 0; p < 12; p++) t3.c[p] = tab[P::T3_OFF + (3 + p) * 256 + (l & 255)];
     }
-    cf tf[P::NTWF > 0 ? P::NTWF : 1];
+    constexpr bool TFG = LOG2N >= 14;
+    constexpr int TFS = TFG ? LPF : 1;
+    cf tf[P::NTWF > 0 && !TFG ? P::NTWF : 1];
+    if (!TFG) {
 #pragma unroll
-    for (int p = 0; p < P::NTWF; p++) tf[p] = tab[P::TF_OFF + p * LPF + l];
+        for (int p = 0; p < P::NTWF; p++) tf[p] = tab[P::TF_OFF + p * LPF + l];
+    }
     for (int i = l; i < P::LDS_T2; i += LPF) lds[P::LDS_IMG + i] = tab[i];
-    cf H[16];
+    // 8192- / 16384-sample plans run 8 / 16 waves per block at <= 128 VGPRs: the lane's 16 bins of H (32 VGPRs) are
+    // re-read from L2 at the multiply instead of living in registers across the block loop (spilled VGPRs 24 -> see
+    // the resource report; PCX_OLS_HREG=1 at build time keeps them in registers for A/B)
+#ifdef PCX_OLS_HREG
+    constexpr bool HG = false;
+#else
+    constexpr bool HG = LOG2N >= 13;
+#endif
+    const cf *Hg = reinterpret_cast<const cf *>(Hspec) + l;
+    cf H[HG ? 1 : 16];
+    if (!HG) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[l + LPF * k];
+        for (int k = 0; k < 16; k++) H[k] = Hg[LPF * k];
+    }
 
     for (; b < nblocks; b += gridDim.x) {
         cf v[16];
@@ -168,17 +185,23 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF, 4) void fir_cf32_ols_r16_kerne
                 v[s] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
             }
         }
-        if (DIAG != 2) xform<LOG2N>(v, lds, l, t3, tf);
+        const cf *tfp = TFG ? tab + P::TF_OFF + l : tf;
+        if (TFG) asm volatile("" : "+v"(tfp));
+        if (DIAG != 2) xform<LOG2N, TFS>(v, lds, l, t3, tfp);
         // u = conj(X .* H) in the first-pass layout of the next transform (register k <- bin k*LPF + l)
+        const cf *Hb = Hg;
+        if (HG) asm volatile("" : "+v"(Hb));   // loop-invariant loads would be hoisted straight back into registers
         cf u[16];
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
             const int k0 = P::NATURAL ? q : bin_of(q), k1 = P::NATURAL ? q + 1 : bin_of(q + 1);
             u[k0] = v[q];
             u[k1] = v[q + 1];
-            cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
+            if (HG) cmul2_conj(u[k0], u[k1], Hb[LPF * k0], Hb[LPF * k1]);
+            else cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
-        if (DIAG != 2) xform<LOG2N>(u, lds, l, t3, tf);
+        if (TFG) asm volatile("" : "+v"(tfp));
+        if (DIAG != 2) xform<LOG2N, TFS>(u, lds, l, t3, tfp);
         // time sample i = l + k*LPF of the block is output b*S + i - Kov; i < Kov wraps past
         // num_records and is dropped by the range check, as are outputs past n_out
         const size_t bo = DIAG == 1 ? 0 : b;

@@ -224,6 +224,34 @@ __global__ __launch_bounds__(1024) void fft_mixed_kernel(const typename A::cpx *
 // Forward twiddles only: the inverse is conj . FFT . conj, folded into the leaf scatter and the final store.
 // Same DFT as kissfft<float>::transform (kissfft.hh:81-161), parity bar 1e-5 of max|X|.
 // --------------------------------------------------------------------------------- //
+// forward 3- and 5-point DFTs in place, natural order
+__device__ __forceinline__ void dft3(fft4k::cf &a, fft4k::cf &b, fft4k::cf &c)
+{
+    using fft4k::cf;
+    // X1 = a - (b+c)/2 - i (sqrt3/2)(b-c), X2 = a - (b+c)/2 + i (sqrt3/2)(b-c)
+    const cf sum = b + c, d = (b - c) * cf{0.86602540378443864676f, 0.86602540378443864676f};
+    const cf h = a - sum * cf{0.5f, 0.5f};
+    a = a + sum;
+    b = cf{h.x + d.y, h.y - d.x};
+    c = cf{h.x - d.y, h.y + d.x};
+}
+__device__ __forceinline__ void dft5(fft4k::cf &a, fft4k::cf &x1, fft4k::cf &x2, fft4k::cf &x3, fft4k::cf &x4)
+{
+    using fft4k::cf;
+    // with c1 = cos(2pi/5), c2 = cos(4pi/5), s1 = sin(2pi/5), s2 = sin(4pi/5):
+    // X1,4 = a + c1 t1 + c2 t2 -+ i (s1 t3 + s2 t4),  X2,3 = a + c2 t1 + c1 t2 -+ i (s2 t3 - s1 t4)
+    constexpr float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;
+    constexpr float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;
+    const cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+    const cf u1 = a + t1 * cf{C1, C1} + t2 * cf{C2, C2}, u2 = a + t1 * cf{C2, C2} + t2 * cf{C1, C1};
+    const cf w1 = t3 * cf{S1, S1} + t4 * cf{S2, S2}, w2 = t3 * cf{S2, S2} - t4 * cf{S1, S1};
+    a = a + t1 + t2;
+    x1 = cf{u1.x + w1.y, u1.y - w1.x};         // u1 - i w1
+    x4 = cf{u1.x - w1.y, u1.y + w1.x};         // u1 + i w1
+    x2 = cf{u2.x + w2.y, u2.y - w2.x};
+    x3 = cf{u2.x - w2.y, u2.y + w2.x};
+}
+
 template <bool TWLDS, bool INV, bool PAD>
 __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int N, size_t nframes,
                                                               const float2 *__restrict__ tw_global, const uint16_t *__restrict__ iperm,
@@ -286,28 +314,53 @@ __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__re
                     cur[P(fb)] = a + t;
                     cur[P(fb + m)] = a - t;
                 } else if (p == 3) {
-                    // X1 = a - (b+c)/2 - i (sqrt3/2)(b-c), X2 = a - (b+c)/2 + i (sqrt3/2)(b-c)
-                    const cf a = cur[P(fb)], b1 = cmul1(cur[P(fb + m)], tw[kf]), c = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]);
-                    const cf sum = b1 + c, d = (b1 - c) * cf{0.86602540378443864676f, 0.86602540378443864676f};
-                    const cf h = a - sum * cf{0.5f, 0.5f};
-                    cur[P(fb)] = a + sum;
-                    cur[P(fb + m)] = cf{h.x + d.y, h.y - d.x};
-                    cur[P(fb + 2 * m)] = cf{h.x - d.y, h.y + d.x};
-                } else {   // p == 5
-                    // with c1 = cos(2pi/5), c2 = cos(4pi/5), s1 = sin(2pi/5), s2 = sin(4pi/5):
-                    // X1,4 = a + c1 t1 + c2 t2 -+ i (s1 t3 + s2 t4),  X2,3 = a + c2 t1 + c1 t2 -+ i (s2 t3 - s1 t4)
-                    constexpr float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;
-                    constexpr float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;
-                    const cf a = cur[P(fb)], x1 = cmul1(cur[P(fb + m)], tw[kf]), x2 = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]), x3 = cmul1(cur[P(fb + 3 * m)], tw[3 * kf]),
-                             x4 = cmul1(cur[P(fb + 4 * m)], tw[4 * kf]);
-                    const cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
-                    const cf u1 = a + t1 * cf{C1, C1} + t2 * cf{C2, C2}, u2 = a + t1 * cf{C2, C2} + t2 * cf{C1, C1};
-                    const cf w1 = t3 * cf{S1, S1} + t4 * cf{S2, S2}, w2 = t3 * cf{S2, S2} - t4 * cf{S1, S1};
-                    cur[P(fb)] = a + t1 + t2;
-                    cur[P(fb + m)] = cf{u1.x + w1.y, u1.y - w1.x};         // u1 - i w1
-                    cur[P(fb + 4 * m)] = cf{u1.x - w1.y, u1.y + w1.x};     // u1 + i w1
-                    cur[P(fb + 2 * m)] = cf{u2.x + w2.y, u2.y - w2.x};
-                    cur[P(fb + 3 * m)] = cf{u2.x - w2.y, u2.y + w2.x};
+                    cf a = cur[P(fb)], b1 = cmul1(cur[P(fb + m)], tw[kf]), c = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]);
+                    dft3(a, b1, c);
+                    cur[P(fb)] = a; cur[P(fb + m)] = b1; cur[P(fb + 2 * m)] = c;
+                } else if (p == 5) {
+                    cf a = cur[P(fb)], x1 = cmul1(cur[P(fb + m)], tw[kf]), x2 = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]),
+                       x3 = cmul1(cur[P(fb + 3 * m)], tw[3 * kf]), x4 = cmul1(cur[P(fb + 4 * m)], tw[4 * kf]);
+                    dft5(a, x1, x2, x3, x4);
+                    cur[P(fb)] = a; cur[P(fb + m)] = x1; cur[P(fb + 2 * m)] = x2; cur[P(fb + 3 * m)] = x3; cur[P(fb + 4 * m)] = x4;
+                } else if (p == 6) {
+                    // 6 = 2 x 3, coprime: prime-factor map, no inner twiddles.  n = (3 n1 + 2 n2) mod 6, k = (3 k1 + 4 k2) mod 6
+                    cf v[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v[j] = cur[P(fb + j * m)];
+#pragma unroll
+                    for (int j = 1; j < 6; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    cf y[2][3];                                   // y[k1][n2]
+#pragma unroll
+                    for (int n2 = 0; n2 < 3; n2++) {
+                        const cf e = v[(2 * n2) % 6], o = v[(3 + 2 * n2) % 6];
+                        y[0][n2] = e + o;
+                        y[1][n2] = e - o;
+                    }
+#pragma unroll
+                    for (int k1 = 0; k1 < 2; k1++) {
+                        dft3(y[k1][0], y[k1][1], y[k1][2]);
+#pragma unroll
+                        for (int k2 = 0; k2 < 3; k2++) cur[P(fb + ((3 * k1 + 4 * k2) % 6) * m)] = y[k1][k2];
+                    }
+                } else {   // p == 15 = 3 x 5: n = (5 n1 + 3 n2) mod 15, k = (10 k1 + 6 k2) mod 15
+                    cf v[15];
+#pragma unroll
+                    for (int j = 0; j < 15; j++) v[j] = cur[P(fb + j * m)];
+#pragma unroll
+                    for (int j = 1; j < 15; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    cf y[3][5];                                   // y[k1][n2]
+#pragma unroll
+                    for (int n2 = 0; n2 < 5; n2++) {
+                        cf a = v[(3 * n2) % 15], b1 = v[(5 + 3 * n2) % 15], c = v[(10 + 3 * n2) % 15];
+                        dft3(a, b1, c);
+                        y[0][n2] = a; y[1][n2] = b1; y[2][n2] = c;
+                    }
+#pragma unroll
+                    for (int k1 = 0; k1 < 3; k1++) {
+                        dft5(y[k1][0], y[k1][1], y[k1][2], y[k1][3], y[k1][4]);
+#pragma unroll
+                        for (int k2 = 0; k2 < 5; k2++) cur[P(fb + ((10 * k1 + 6 * k2) % 15) * m)] = y[k1][k2];
+                    }
                 }
             }
             __syncthreads();

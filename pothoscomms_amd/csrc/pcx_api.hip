@@ -709,14 +709,24 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         rc = upload(h->tw, make_tw_r16<double>(h->log2n));
     } else if (scalar == PCX_F32 && !pow2 && fft_is_5_smooth(num_bins) && num_bins < 8192 && !getenv("PCX_FFT_KISS_ORDER")) {
         // complex_float32, 2^a 3^b 5^c bins: a float transform may take its radices in any order -- 16s first, then
-        // 8 / 4 / 2, 5s, 3s (fft_smooth_f32_kernel); kissfft's own order stays with the bit-exact Q15 path.
+        // 8 / 4 / 2, 6 / 15, 5s, 3s (fft_smooth_f32_kernel); kissfft's own order stays with the bit-exact Q15 path.
         // PCX_FFT_KISS_ORDER (A/B) keeps the kissfft plan, as do the few sizes from 8192 bins up (10000: 102 vs 94 Gsamples/s).
         // Forward table; the kernel conjugates around it for the inverse.
         h->kind = pcx_fft::SMOOTH;
         h->radix.clear();
-        size_t n = num_bins;
-        for (int r : {16, 8, 4, 2, 5, 3})
-            while (n % (size_t)r == 0) { h->radix.push_back(r); n /= (size_t)r; }
+        // 16s, one of 8 / 4 / 2 for the remaining twos, then coprime pairs as single passes (2 x 3 = 6, 3 x 5 = 15:
+        // prime-factor butterflies without inner twiddles), then the 5s and 3s left over.  PCX_FFT_SMOOTH_PRIMES (A/B): no pairs
+        int e2 = 0, e3 = 0, e5 = 0;
+        for (size_t n = num_bins; n % 2 == 0; n /= 2) e2++;
+        for (size_t n = num_bins; n % 3 == 0; n /= 3) e3++;
+        for (size_t n = num_bins; n % 5 == 0; n /= 5) e5++;
+        const bool pairs = !getenv("PCX_FFT_SMOOTH_PRIMES");
+        for (; e2 >= 4; e2 -= 4) h->radix.push_back(16);
+        if (e2 == 1 && e3 > 0 && pairs) { h->radix.push_back(6); e3--; }
+        else if (e2 > 0) h->radix.push_back(1 << e2);
+        for (; pairs && e3 > 0 && e5 > 0; e3--, e5--) h->radix.push_back(15);
+        for (; e5 > 0; e5--) h->radix.push_back(5);
+        for (; e3 > 0; e3--) h->radix.push_back(3);
         std::vector<float> t(2 * num_bins);
         for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(-std::sin(two_pi * i / num_bins)); }
         rc = upload(h->tw, t);

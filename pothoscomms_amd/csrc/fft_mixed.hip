@@ -252,6 +252,37 @@ __device__ __forceinline__ void dft5(fft4k::cf &a, fft4k::cf &x1, fft4k::cf &x2,
     x3 = cf{u2.x - w2.y, u2.y + w2.x};
 }
 
+// W_9^e (forward sign), the inner twiddles of the 3 x 3 pass: indexed with compile-time constants only, so every use
+// folds to immediates.  (A 5 x 5 pass was built the same way and dropped: its 50 data registers halve the occupancy of
+// the whole kernel -- 3000 bins fell from 165 to 113 Gsamples/s -- for one pass saved on sizes with 5^2.)
+struct W2 { float c, s; };
+__device__ constexpr W2 kW9[9] = {{1.0f, -0.0f}, {0.766044443118978f, -0.6427876096865393f}, {0.17364817766693041f, -0.984807753012208f}, {-0.4999999999999998f, -0.8660254037844387f}, {-0.9396926207859083f, -0.3420201433256689f}, {-0.9396926207859084f, 0.34202014332566866f}, {-0.5000000000000004f, 0.8660254037844384f}, {0.17364817766692997f, 0.9848077530122081f}, {0.7660444431189778f, 0.6427876096865396f}};
+// v[n] = x[n] in, v[k] = X[k] out: DFT of 9 points as 3 DFT_3's, the inner twiddles W_9^(n2 k1), 3 DFT_3's
+__device__ __forceinline__ void dft9(fft4k::cf (&v)[9])
+{
+    using fft4k::cf;
+    cf y[3][3];                                    // y[n2][k1]
+#pragma unroll
+    for (int n2 = 0; n2 < 3; n2++) {
+        cf a = v[n2], b = v[3 + n2], c = v[6 + n2];
+        dft3(a, b, c);
+        y[n2][0] = a; y[n2][1] = b; y[n2][2] = c;
+#pragma unroll
+        for (int k1 = 1; k1 < 3; k1++) {
+            if (n2 == 0) continue;
+            const W2 w = kW9[(n2 * k1) % 9];
+            const cf t = y[n2][k1];
+            y[n2][k1] = cf{t.x * w.c - t.y * w.s, t.x * w.s + t.y * w.c};
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+        cf a = y[0][k1], b = y[1][k1], c = y[2][k1];
+        dft3(a, b, c);
+        v[k1] = a; v[k1 + 3] = b; v[k1 + 6] = c;
+    }
+}
+
 template <bool TWLDS, bool INV, bool PAD>
 __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int N, size_t nframes,
                                                               const float2 *__restrict__ tw_global, const uint16_t *__restrict__ iperm,
@@ -342,6 +373,15 @@ __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__re
 #pragma unroll
                         for (int k2 = 0; k2 < 3; k2++) cur[P(fb + ((3 * k1 + 4 * k2) % 6) * m)] = y[k1][k2];
                     }
+                } else if (p == 9) {
+                    cf v[9];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) v[j] = cur[P(fb + j * m)];
+#pragma unroll
+                    for (int j = 1; j < 9; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    dft9(v);
+#pragma unroll
+                    for (int j = 0; j < 9; j++) cur[P(fb + j * m)] = v[j];
                 } else {   // p == 15 = 3 x 5: n = (5 n1 + 3 n2) mod 15, k = (10 k1 + 6 k2) mod 15
                     cf v[15];
 #pragma unroll

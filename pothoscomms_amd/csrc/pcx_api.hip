@@ -714,8 +714,9 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         // Forward table; the kernel conjugates around it for the inverse.
         h->kind = pcx_fft::SMOOTH;
         h->radix.clear();
-        // 16s, one of 8 / 4 / 2 for the remaining twos, then coprime pairs as single passes (2 x 3 = 6, 3 x 5 = 15:
-        // prime-factor butterflies without inner twiddles), then the 5s and 3s left over.  PCX_FFT_SMOOTH_PRIMES (A/B): no pairs
+        // 16s, one of 8 / 4 / 2 for the remaining twos, then pairs of odd factors as single passes (2 x 3 = 6 and 3 x 5 = 15:
+        // prime-factor butterflies without inner twiddles; 3 x 3 = 9 with them), then the 5s and a 3 left over.
+        // PCX_FFT_SMOOTH_PRIMES (A/B): no pairs
         int e2 = 0, e3 = 0, e5 = 0;
         for (size_t n = num_bins; n % 2 == 0; n /= 2) e2++;
         for (size_t n = num_bins; n % 3 == 0; n /= 3) e3++;
@@ -724,8 +725,15 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         for (; e2 >= 4; e2 -= 4) h->radix.push_back(16);
         if (e2 == 1 && e3 > 0 && pairs) { h->radix.push_back(6); e3--; }
         else if (e2 > 0) h->radix.push_back(1 << e2);
-        for (; pairs && e3 > 0 && e5 > 0; e3--, e5--) h->radix.push_back(15);
+        // how many 3 x 5 pairs leave the fewest passes once the remaining 3s go out two at a time (3 x 3 = 9, inner twiddles)
+        int n15 = 0, best = 1 << 30;
+        for (int c = 0; pairs && c <= std::min(e3, e5); c++) {
+            const int passes = c + (e5 - c) + (e3 - c + 1) / 2;
+            if (passes <= best) { best = passes; n15 = c; }
+        }
+        for (int c = 0; c < n15; c++, e3--, e5--) h->radix.push_back(15);
         for (; e5 > 0; e5--) h->radix.push_back(5);
+        for (; pairs && e3 >= 2; e3 -= 2) h->radix.push_back(9);
         for (; e3 > 0; e3--) h->radix.push_back(3);
         std::vector<float> t(2 * num_bins);
         for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(-std::sin(two_pi * i / num_bins)); }

@@ -466,6 +466,17 @@ def test_fft_composite_beyond_one_workgroup(oracle, dev, dtype, nbins, inverse):
 
 
 @pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("nbins", [18, 45, 50, 75, 81, 90, 225, 243, 486, 625, 675, 720, 1125, 1200, 1536, 1875, 2025, 2400, 3125, 3645, 5625, 6144, 7680, 8100])
+def test_fft_five_smooth_plan(oracle, dev, nbins, inverse):
+    """complex_float32, 2^a 3^b 5^c bins below 8192: radix 16/8/4/2 passes, the pair passes 6, 15 (prime-factor) and 9
+    (inner twiddles) and single 5s / 3s in every combination the planner produces; ragged frame groups"""
+    rng = np.random.default_rng(nbins)
+    nframes = 11 if nbins < 1000 else 3
+    x = rand_stream(rng, oracle.F32, nbins * nframes, True)
+    assert nerr(dev.Fft("complex_float32", nbins, inverse).transform(x), oracle.fft(x, nbins, inverse)) <= TOL
+
+
+@pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("nbins", MIXED_SIZES)
 def test_fft_mixed_radix_int16_bit_exact(oracle, dev, nbins, inverse):
     """radix 3 / 5 / generic butterflies of kiss_fft.c in Q15: every rounding reproduced"""

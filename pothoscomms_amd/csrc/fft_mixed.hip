@@ -19,6 +19,7 @@
 // correctness-first and sized by LDS: numBins * sizeof(complex) * 2 <= 160 KB.
 #include <cstdlib>
 #include "fft4096.hpp"
+#include "fft_f64.hpp"
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -224,71 +225,83 @@ __global__ __launch_bounds__(1024) void fft_mixed_kernel(const typename A::cpx *
 // Forward twiddles only: the inverse is conj . FFT . conj, folded into the leaf scatter and the final store.
 // Same DFT as kissfft<float>::transform (kissfft.hh:81-161), parity bar 1e-5 of max|X|.
 // --------------------------------------------------------------------------------- //
+// element-type glue for the 5-smooth plan: E = fft4k::cf (float pair) or fft64::cd (double pair)
+template <typename E> struct ElemOf;
+template <> struct ElemOf<fft4k::cf> { typedef float S; typedef float2 G; };
+template <> struct ElemOf<fft64::cd> { typedef double S; typedef double2 G; };
+template <typename E> __device__ __forceinline__ E splat(double c) { typedef typename ElemOf<E>::S S; return E{(S)c, (S)c}; }
+__device__ __forceinline__ fft4k::cf cm(fft4k::cf a, fft4k::cf w) { return fft4k::cmul1(a, w); }
+__device__ __forceinline__ fft64::cd cm(fft64::cd a, fft64::cd w) { return fft64::cmul(a, w); }
+using fft4k::fft16_plain; using fft64::fft16_plain;
+using fft4k::fft8; using fft64::fft8;
+using fft4k::fft4; using fft64::fft4;
+
 // forward 3- and 5-point DFTs in place, natural order
-__device__ __forceinline__ void dft3(fft4k::cf &a, fft4k::cf &b, fft4k::cf &c)
+template <typename E>
+__device__ __forceinline__ void dft3(E &a, E &b, E &c)
 {
-    using fft4k::cf;
     // X1 = a - (b+c)/2 - i (sqrt3/2)(b-c), X2 = a - (b+c)/2 + i (sqrt3/2)(b-c)
-    const cf sum = b + c, d = (b - c) * cf{0.86602540378443864676f, 0.86602540378443864676f};
-    const cf h = a - sum * cf{0.5f, 0.5f};
+    const E sum = b + c, d = (b - c) * splat<E>(0.86602540378443864676);
+    const E h = a - sum * splat<E>(0.5);
     a = a + sum;
-    b = cf{h.x + d.y, h.y - d.x};
-    c = cf{h.x - d.y, h.y + d.x};
+    b = E{h.x + d.y, h.y - d.x};
+    c = E{h.x - d.y, h.y + d.x};
 }
-__device__ __forceinline__ void dft5(fft4k::cf &a, fft4k::cf &x1, fft4k::cf &x2, fft4k::cf &x3, fft4k::cf &x4)
+template <typename E>
+__device__ __forceinline__ void dft5(E &a, E &x1, E &x2, E &x3, E &x4)
 {
-    using fft4k::cf;
     // with c1 = cos(2pi/5), c2 = cos(4pi/5), s1 = sin(2pi/5), s2 = sin(4pi/5):
     // X1,4 = a + c1 t1 + c2 t2 -+ i (s1 t3 + s2 t4),  X2,3 = a + c2 t1 + c1 t2 -+ i (s2 t3 - s1 t4)
-    constexpr float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;
-    constexpr float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;
-    const cf t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
-    const cf u1 = a + t1 * cf{C1, C1} + t2 * cf{C2, C2}, u2 = a + t1 * cf{C2, C2} + t2 * cf{C1, C1};
-    const cf w1 = t3 * cf{S1, S1} + t4 * cf{S2, S2}, w2 = t3 * cf{S2, S2} - t4 * cf{S1, S1};
+    constexpr double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;
+    constexpr double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;
+    const E t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+    const E u1 = a + t1 * splat<E>(C1) + t2 * splat<E>(C2), u2 = a + t1 * splat<E>(C2) + t2 * splat<E>(C1);
+    const E w1 = t3 * splat<E>(S1) + t4 * splat<E>(S2), w2 = t3 * splat<E>(S2) - t4 * splat<E>(S1);
     a = a + t1 + t2;
-    x1 = cf{u1.x + w1.y, u1.y - w1.x};         // u1 - i w1
-    x4 = cf{u1.x - w1.y, u1.y + w1.x};         // u1 + i w1
-    x2 = cf{u2.x + w2.y, u2.y - w2.x};
-    x3 = cf{u2.x - w2.y, u2.y + w2.x};
+    x1 = E{u1.x + w1.y, u1.y - w1.x};         // u1 - i w1
+    x4 = E{u1.x - w1.y, u1.y + w1.x};         // u1 + i w1
+    x2 = E{u2.x + w2.y, u2.y - w2.x};
+    x3 = E{u2.x - w2.y, u2.y + w2.x};
 }
 
 // W_9^e (forward sign), the inner twiddles of the 3 x 3 pass: indexed with compile-time constants only, so every use
 // folds to immediates.  (A 5 x 5 pass was built the same way and dropped: its 50 data registers halve the occupancy of
 // the whole kernel -- 3000 bins fell from 165 to 113 Gsamples/s -- for one pass saved on sizes with 5^2.)
-struct W2 { float c, s; };
-__device__ constexpr W2 kW9[9] = {{1.0f, -0.0f}, {0.766044443118978f, -0.6427876096865393f}, {0.17364817766693041f, -0.984807753012208f}, {-0.4999999999999998f, -0.8660254037844387f}, {-0.9396926207859083f, -0.3420201433256689f}, {-0.9396926207859084f, 0.34202014332566866f}, {-0.5000000000000004f, 0.8660254037844384f}, {0.17364817766692997f, 0.9848077530122081f}, {0.7660444431189778f, 0.6427876096865396f}};
+struct W2 { double c, s; };
+__device__ constexpr W2 kW9[9] = {{1.0, -0.0}, {0.766044443118978, -0.6427876096865393}, {0.17364817766693041, -0.984807753012208}, {-0.4999999999999998, -0.8660254037844387}, {-0.9396926207859083, -0.3420201433256689}, {-0.9396926207859084, 0.34202014332566866}, {-0.5000000000000004, 0.8660254037844384}, {0.17364817766692997, 0.9848077530122081}, {0.7660444431189778, 0.6427876096865396}};
 // v[n] = x[n] in, v[k] = X[k] out: DFT of 9 points as 3 DFT_3's, the inner twiddles W_9^(n2 k1), 3 DFT_3's
-__device__ __forceinline__ void dft9(fft4k::cf (&v)[9])
+template <typename E>
+__device__ __forceinline__ void dft9(E (&v)[9])
 {
-    using fft4k::cf;
-    cf y[3][3];                                    // y[n2][k1]
+    typedef typename ElemOf<E>::S S;
+    E y[3][3];                                    // y[n2][k1]
 #pragma unroll
     for (int n2 = 0; n2 < 3; n2++) {
-        cf a = v[n2], b = v[3 + n2], c = v[6 + n2];
+        E a = v[n2], b = v[3 + n2], c = v[6 + n2];
         dft3(a, b, c);
         y[n2][0] = a; y[n2][1] = b; y[n2][2] = c;
 #pragma unroll
         for (int k1 = 1; k1 < 3; k1++) {
             if (n2 == 0) continue;
-            const W2 w = kW9[(n2 * k1) % 9];
-            const cf t = y[n2][k1];
-            y[n2][k1] = cf{t.x * w.c - t.y * w.s, t.x * w.s + t.y * w.c};
+            const S wc = (S)kW9[(n2 * k1) % 9].c, ws = (S)kW9[(n2 * k1) % 9].s;
+            const E t = y[n2][k1];
+            y[n2][k1] = E{t.x * wc - t.y * ws, t.x * ws + t.y * wc};
         }
     }
 #pragma unroll
     for (int k1 = 0; k1 < 3; k1++) {
-        cf a = y[0][k1], b = y[1][k1], c = y[2][k1];
+        E a = y[0][k1], b = y[1][k1], c = y[2][k1];
         dft3(a, b, c);
         v[k1] = a; v[k1 + 3] = b; v[k1 + 6] = c;
     }
 }
 
-template <bool TWLDS, bool INV, bool PAD>
-__global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int N, size_t nframes,
-                                                              const float2 *__restrict__ tw_global, const uint16_t *__restrict__ iperm,
-                                                              MixedPlan plan)
+template <typename cf, bool TWLDS, bool INV, bool PAD>
+__global__ __launch_bounds__(1024) void fft_smooth_kernel(const typename ElemOf<cf>::G *__restrict__ in, typename ElemOf<cf>::G *__restrict__ out, int N,
+                                                          size_t nframes, const typename ElemOf<cf>::G *__restrict__ tw_global,
+                                                          const uint16_t *__restrict__ iperm, MixedPlan plan)
 {
-    using namespace fft4k;
+    using fft4k::bin_of;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nt = blockDim.x, FPW = plan.fpw;
     const size_t ngroups = (nframes + FPW - 1) / FPW;
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__re
 #pragma unroll
                     for (int j = 0; j < 16; j++) v[j] = cur[P(fb + j * m)];
 #pragma unroll
-                    for (int j = 1; j < 16; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    for (int j = 1; j < 16; j++) v[j] = cm(v[j], tw[j * kf]);
                     fft16_plain(v);
 #pragma unroll
                     for (int q = 0; q < 16; q++) cur[P(fb + bin_of(q) * m)] = v[q];
@@ -332,25 +345,25 @@ __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__re
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] = cur[P(fb + j * m)];
 #pragma unroll
-                    for (int j = 1; j < 8; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    for (int j = 1; j < 8; j++) v[j] = cm(v[j], tw[j * kf]);
                     fft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
                     for (int j = 0; j < 8; j++) cur[P(fb + j * m)] = v[j];
                 } else if (p == 4) {
-                    cf a = cur[P(fb)], b1 = cmul1(cur[P(fb + m)], tw[kf]), c = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]), d = cmul1(cur[P(fb + 3 * m)], tw[3 * kf]);
+                    cf a = cur[P(fb)], b1 = cm(cur[P(fb + m)], tw[kf]), c = cm(cur[P(fb + 2 * m)], tw[2 * kf]), d = cm(cur[P(fb + 3 * m)], tw[3 * kf]);
                     fft4(a, b1, c, d);
                     cur[P(fb)] = a; cur[P(fb + m)] = b1; cur[P(fb + 2 * m)] = c; cur[P(fb + 3 * m)] = d;
                 } else if (p == 2) {
-                    const cf a = cur[P(fb)], t = cmul1(cur[P(fb + m)], tw[kf]);
+                    const cf a = cur[P(fb)], t = cm(cur[P(fb + m)], tw[kf]);
                     cur[P(fb)] = a + t;
                     cur[P(fb + m)] = a - t;
                 } else if (p == 3) {
-                    cf a = cur[P(fb)], b1 = cmul1(cur[P(fb + m)], tw[kf]), c = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]);
+                    cf a = cur[P(fb)], b1 = cm(cur[P(fb + m)], tw[kf]), c = cm(cur[P(fb + 2 * m)], tw[2 * kf]);
                     dft3(a, b1, c);
                     cur[P(fb)] = a; cur[P(fb + m)] = b1; cur[P(fb + 2 * m)] = c;
                 } else if (p == 5) {
-                    cf a = cur[P(fb)], x1 = cmul1(cur[P(fb + m)], tw[kf]), x2 = cmul1(cur[P(fb + 2 * m)], tw[2 * kf]),
-                       x3 = cmul1(cur[P(fb + 3 * m)], tw[3 * kf]), x4 = cmul1(cur[P(fb + 4 * m)], tw[4 * kf]);
+                    cf a = cur[P(fb)], x1 = cm(cur[P(fb + m)], tw[kf]), x2 = cm(cur[P(fb + 2 * m)], tw[2 * kf]),
+                       x3 = cm(cur[P(fb + 3 * m)], tw[3 * kf]), x4 = cm(cur[P(fb + 4 * m)], tw[4 * kf]);
                     dft5(a, x1, x2, x3, x4);
                     cur[P(fb)] = a; cur[P(fb + m)] = x1; cur[P(fb + 2 * m)] = x2; cur[P(fb + 3 * m)] = x3; cur[P(fb + 4 * m)] = x4;
                 } else if (p == 6) {
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__re
 #pragma unroll
                     for (int j = 0; j < 6; j++) v[j] = cur[P(fb + j * m)];
 #pragma unroll
-                    for (int j = 1; j < 6; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    for (int j = 1; j < 6; j++) v[j] = cm(v[j], tw[j * kf]);
                     cf y[2][3];                                   // y[k1][n2]
 #pragma unroll
                     for (int n2 = 0; n2 < 3; n2++) {
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__re
 #pragma unroll
                     for (int j = 0; j < 9; j++) v[j] = cur[P(fb + j * m)];
 #pragma unroll
-                    for (int j = 1; j < 9; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    for (int j = 1; j < 9; j++) v[j] = cm(v[j], tw[j * kf]);
                     dft9(v);
 #pragma unroll
                     for (int j = 0; j < 9; j++) cur[P(fb + j * m)] = v[j];
@@ -387,7 +400,7 @@ __global__ __launch_bounds__(1024) void fft_smooth_f32_kernel(const float2 *__re
 #pragma unroll
                     for (int j = 0; j < 15; j++) v[j] = cur[P(fb + j * m)];
 #pragma unroll
-                    for (int j = 1; j < 15; j++) v[j] = cmul1(v[j], tw[j * kf]);
+                    for (int j = 1; j < 15; j++) v[j] = cm(v[j], tw[j * kf]);
                     cf y[3][5];                                   // y[k1][n2]
 #pragma unroll
                     for (int n2 = 0; n2 < 5; n2++) {
@@ -475,9 +488,12 @@ int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool i
     return PCX_OK;
 }
 
+template <typename E>
 int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm, const int *radix,
                   int nstages, hipStream_t st)
 {
+    typedef typename ElemOf<E>::G G;
+    constexpr size_t EB = sizeof(E);
     if (nframes == 0) return PCX_OK;
     if (nstages > kMaxStagesMixed) { set_error("fft: too many stages for numBins %zu", nbins); return PCX_ERR_UNSUPPORTED; }
     MixedPlan plan;
@@ -496,7 +512,8 @@ int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool 
         plan.inv_span[s] = 1.0f / (float)(p * m);
         m *= p;
     }
-    size_t fpw = nbins >= 4096 ? 1 : 4096 / nbins;
+    const size_t group = 32768 / EB;     // 4096 float / 2048 double elements per group
+    size_t fpw = nbins >= group ? 1 : group / nbins;
     if (fpw > nframes) fpw = nframes;
     plan.fpw = (int)fpw;
     // PCX_FFT_SMOOTH_PAD=1 (A/B): image padded i + i/16.  Measured: 1536 bins (span 96 = 3 * 32 elements, the worst
@@ -504,14 +521,14 @@ int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool 
     // passes wait on VALU issue, not on LDS banks -- so the plain image is the default
     static const int pad = [] { const char *e = getenv("PCX_FFT_SMOOTH_PAD"); return e ? atoi(e) : 0; }();
     const size_t img = fpw * nbins;
-    size_t lds = (pad ? img + img / 16 + 1 : img) * 8;
-    const bool twlds = lds + nbins * 8 <= 96 * 1024;
-    if (twlds) lds += nbins * 8;
+    size_t lds = (pad ? img + img / 16 + 1 : img) * EB;
+    const bool twlds = lds + nbins * EB <= 96 * 1024;
+    if (twlds) lds += nbins * EB;
     if (lds > 160 * 1024) { set_error("fft: numBins %zu does not fit the single-workgroup LDS plan", nbins); return PCX_ERR_UNSUPPORTED; }
-    auto k = pad ? (twlds ? (inverse ? fft_smooth_f32_kernel<true, true, true> : fft_smooth_f32_kernel<true, false, true>)
-                          : (inverse ? fft_smooth_f32_kernel<false, true, true> : fft_smooth_f32_kernel<false, false, true>))
-                 : (twlds ? (inverse ? fft_smooth_f32_kernel<true, true, false> : fft_smooth_f32_kernel<true, false, false>)
-                          : (inverse ? fft_smooth_f32_kernel<false, true, false> : fft_smooth_f32_kernel<false, false, false>));
+    auto k = pad ? (twlds ? (inverse ? fft_smooth_kernel<E, true, true, true> : fft_smooth_kernel<E, true, false, true>)
+                          : (inverse ? fft_smooth_kernel<E, false, true, true> : fft_smooth_kernel<E, false, false, true>))
+                 : (twlds ? (inverse ? fft_smooth_kernel<E, true, true, false> : fft_smooth_kernel<E, true, false, false>)
+                          : (inverse ? fft_smooth_kernel<E, false, true, false> : fft_smooth_kernel<E, false, false, false>));
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // lanes per group = elements / div.  Measured (tools/sweep_fft_mixed.py with PCX_FFT_SMOOTH_DIV = 4 ... 16): more, smaller
     // workgroups per CU beat one butterfly per lane in every pass -- 6 for short frames, 8 to 4095 bins, 4 beyond
@@ -528,7 +545,7 @@ int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool 
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
     const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, (const float2 *)in, (float2 *)out, (int)nbins, nframes, (const float2 *)tw,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, (const G *)in, (G *)out, (int)nbins, nframes, (const G *)tw,
                        (const uint16_t *)iperm, plan);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
@@ -551,10 +568,12 @@ int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t
 }  // namespace pcx
 
 namespace pcx {
-// complex_float32, numBins = 2^a 3^b 5^c: radices (16 / 8 / 4 / 2 / 5 / 3) chosen by pcx_api.hip, forward twiddle table
-int launch_fft_smooth_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
-                           const int *radix_host, int nstages, hipStream_t st)
+// complex_float32 / complex_float64, numBins = 2^a 3^b 5^c: radices (16 / 8 / 4 / 2 / 6 / 15 / 9 / 5 / 3) chosen by pcx_api.hip,
+// forward twiddle table of the element type
+int launch_fft_smooth(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
+                      const int *radix_host, int nstages, hipStream_t st)
 {
-    return launch_smooth(in, out, nbins, nframes, inverse, tw, iperm, radix_host, nstages, st);
+    return scalar == PCX_F64 ? launch_smooth<fft64::cd>(in, out, nbins, nframes, inverse, tw, iperm, radix_host, nstages, st)
+                             : launch_smooth<fft4k::cf>(in, out, nbins, nframes, inverse, tw, iperm, radix_host, nstages, st);
 }
 }  // namespace pcx

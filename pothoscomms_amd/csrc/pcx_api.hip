@@ -707,10 +707,12 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         h->kind = pcx_fft::R16;
         while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
         rc = upload(h->tw, make_tw_r16<double>(h->log2n));
-    } else if (scalar == PCX_F32 && !pow2 && fft_is_5_smooth(num_bins) && num_bins < 8192 && !getenv("PCX_FFT_KISS_ORDER")) {
-        // complex_float32, 2^a 3^b 5^c bins: a float transform may take its radices in any order -- 16s first, then
+    } else if (!pow2 && fft_is_5_smooth(num_bins) && !getenv("PCX_FFT_KISS_ORDER") &&
+               ((scalar == PCX_F32 && num_bins < 8192) || (scalar == PCX_F64 && num_bins >= 256 && num_bins < 2048))) {
+        // complex_float32 / complex_float64, 2^a 3^b 5^c bins: a float transform may take its radices in any order -- 16s first, then
         // 8 / 4 / 2, 6 / 15, 5s, 3s (fft_smooth_f32_kernel); kissfft's own order stays with the bit-exact Q15 path.
-        // PCX_FFT_KISS_ORDER (A/B) keeps the kissfft plan, as do the few sizes from 8192 bins up (10000: 102 vs 94 Gsamples/s).
+        // PCX_FFT_KISS_ORDER (A/B) keeps the kissfft plan, as do the sizes where it measured faster (tools/sweep_fft_mixed.py):
+        // float from 8192 bins up (10000: 102 vs 94 Gsamples/s), double below 256 and from 2048 up (60: 118 vs 87, 3000: 84 vs 65).
         // Forward table; the kernel conjugates around it for the inverse.
         h->kind = pcx_fft::SMOOTH;
         h->radix.clear();
@@ -735,9 +737,15 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         for (; e5 > 0; e5--) h->radix.push_back(5);
         for (; pairs && e3 >= 2; e3 -= 2) h->radix.push_back(9);
         for (; e3 > 0; e3--) h->radix.push_back(3);
-        std::vector<float> t(2 * num_bins);
-        for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(-std::sin(two_pi * i / num_bins)); }
-        rc = upload(h->tw, t);
+        if (scalar == PCX_F32) {
+            std::vector<float> t(2 * num_bins);
+            for (size_t i = 0; i < num_bins; i++) { t[2 * i] = (float)std::cos(two_pi * i / num_bins); t[2 * i + 1] = (float)(-std::sin(two_pi * i / num_bins)); }
+            rc = upload(h->tw, t);
+        } else {
+            std::vector<double> t(2 * num_bins);
+            for (size_t i = 0; i < num_bins; i++) { t[2 * i] = std::cos(two_pi * i / num_bins); t[2 * i + 1] = -std::sin(two_pi * i / num_bins); }
+            rc = upload(h->tw, t);
+        }
     } else if (scalar != PCX_I16) {
         // forward table exp(-j 2 pi i / N); the power-of-two kernels conjugate it for the inverse,
         // the mixed-radix kernel gets the direction baked in like kissfft's fill_twiddles (kissfft.hh:21-26)
@@ -854,7 +862,7 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         return launch_transpose(h->scalar, h->ws2.p, out_dev, h->n1, h->n2, nframes, 0, st);
     }
     case pcx_fft::SMOOTH:
-        return launch_fft_smooth_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
+        return launch_fft_smooth(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     case pcx_fft::MIXED:
         return launch_fft_mixed(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     }

@@ -164,8 +164,8 @@ int launch_fft_r16_cf32(const void *in, void *out, int log2n, size_t nframes, bo
 int launch_fft_r16_cf64(const void *in, void *out, int log2n, size_t nframes, bool inverse, const void *tw, hipStream_t st);
 
 // any numBins: kissfft's mixed-radix plan (radix 2/3/4/5 + generic), f32 / f64 / Q15 (bit-exact)
-int launch_fft_smooth_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
-                           const int *radix_host, int nstages, hipStream_t st);
+int launch_fft_smooth(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
+                      const int *radix_host, int nstages, hipStream_t st);
 int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
                      const int *radix_host, int nstages, hipStream_t st);
 

@@ -469,12 +469,15 @@ def test_fft_composite_beyond_one_workgroup(oracle, dev, dtype, nbins, inverse):
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("nbins", [18, 45, 50, 75, 81, 90, 225, 243, 486, 625, 675, 720, 1125, 1200, 1536, 1875, 2025, 2400, 3125, 3645, 5625, 6144, 7680, 8100])
 def test_fft_five_smooth_plan(oracle, dev, nbins, inverse):
-    """complex_float32, 2^a 3^b 5^c bins below 8192: radix 16/8/4/2 passes, the pair passes 6, 15 (prime-factor) and 9
+    """complex_float32 (below 8192 bins) and complex_float64 (below 4096), 2^a 3^b 5^c bins: radix 16/8/4/2 passes, the pair passes 6, 15 (prime-factor) and 9
     (inner twiddles) and single 5s / 3s in every combination the planner produces; ragged frame groups"""
     rng = np.random.default_rng(nbins)
     nframes = 11 if nbins < 1000 else 3
     x = rand_stream(rng, oracle.F32, nbins * nframes, True)
     assert nerr(dev.Fft("complex_float32", nbins, inverse).transform(x), oracle.fft(x, nbins, inverse)) <= TOL
+    if nbins < 4096:     # the same plan in double precision (256 ... 2047 bins; kissfft's order outside)
+        xd = rand_stream(rng, oracle.F64, nbins * nframes, True)
+        assert nerr(dev.Fft("complex_float64", nbins, inverse).transform(xd), oracle.fft(xd, nbins, inverse)) <= 1e-13
 
 
 @pytest.mark.parametrize("inverse", [False, True])

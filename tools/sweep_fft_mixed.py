@@ -6,7 +6,7 @@ from pothoscomms_amd import device
 d = torch.device("cuda", 0)
 total = 32 * 1024 * 1024
 sizes = [int(a) for a in sys.argv[1:]] or [12, 60, 100, 600, 1000, 1200, 1536, 1920, 3000, 6000, 10000]
-for dtype, tdt, esz in (("complex_float32", torch.float32, 8), ("complex_int16", torch.int16, 4)):
+for dtype, tdt, esz in (("complex_float32", torch.float32, 8), ("complex_float64", torch.float64, 16), ("complex_int16", torch.int16, 4)):
     for N in sizes:
         nframes = total // N
         x = (torch.rand((nframes * N, 2), device=d) * 2000 - 1000).to(tdt)

@@ -91,8 +91,9 @@ typedef enum pcx_fir_algo {
     PCX_FIR_DIRECT = 1,  /* time-domain LDS-tiled dot product (FMA) */
     PCX_FIR_OLS_FFT = 2, /* frequency-domain overlap-save on the Stockham kernels: complex_float32 (K <= 8193;
                             resampling K <= 2049), real float32 and M = L = 1 (K <= 2049), complex_float64 and
-                            M = L = 1 (K <= 4097), complex_int16 / complex_int8 and M = L = 1 (K <= 4097, bit-exact: the rounded
-                            double-precision sums are the integer convolution); anything else -> PCX_ERR_UNSUPPORTED */
+                            M = L = 1 (K <= 4097), complex_int16 / complex_int8 and real float64 / int16 / int8 with
+                            M = L = 1 (K <= 4097; integers bit-exact: the rounded double-precision sums are the integer
+                            convolution); anything else -> PCX_ERR_UNSUPPORTED */
     PCX_FIR_EXACT = 3    /* time-domain, reference accumulation order, no FMA:
                             bit-identical to FIRFilter.cpp:295-300 for float types */
 } pcx_fir_algo;

@@ -253,6 +253,158 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     return PCX_OK;
 }
 
+// --------------------------------------------------------------------------------- //
+// REAL streams (float64, int16, int8; real taps; M = L = 1): two consecutive real blocks ride one complex transform
+// as its real and imaginary parts -- real taps filter Re and Im independently (H is the transform of a real sequence) --
+// exactly as fir_f32_ols4096_kernel does for float32.  Complex block c carries real blocks 2c and 2c+1; every window goes
+// through the range-checked descriptor form (samples in front of the buffer read 0 and only feed dropped outputs; a
+// missing second block reads 0 and stores nothing).  Integer element types round to the nearest integer and apply the
+// reference's wrap / fromQ shift / truncation as StreamIo<1,2> do: bit-exact on the same error bound.
+// --------------------------------------------------------------------------------- //
+template <int IO>
+struct RealIo;
+template <>
+struct RealIo<0> {   // float64
+    static constexpr int EB = 8;
+    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t rs, int voff)
+    {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), ws, voff, 0, kAuxStream);
+    }
+};
+template <>
+struct RealIo<1> {   // int16: 32-bit Q accumulator, >> 16
+    static constexpr int EB = 2;
+    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t rs, int voff)
+    {
+        return (double)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, 0, 0);
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)StreamIo<1>::q(y), ws, voff, 0, kAuxStream);
+    }
+};
+template <>
+struct RealIo<2> {   // int8: 16-bit Q accumulator, >> 8
+    static constexpr int EB = 1;
+    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t rs, int voff)
+    {
+        return (double)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, 0, 0);
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    {
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)StreamIo<2>::q(y), ws, voff, 0, kAuxStream);
+    }
+};
+
+template <int LOG2N, int IO>
+__global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_per_eu(2))) void fir_real_ols_kernel(
+    const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, const double2 *__restrict__ Hspec,
+    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real)
+{
+    typedef OlsPlan<LOG2N> P;
+    typedef RealIo<IO> RIO;
+    constexpr int N = P::N, LPF = P::LPF, EB = RIO::EB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd *lds = reinterpret_cast<cd *>(smem_raw);
+    const int l = threadIdx.x;
+    const size_t S = (size_t)(N - Kov);
+    const size_t nblocks = (nblocks_real + 1) / 2;
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const cd *tab = reinterpret_cast<const cd *>(twtab);
+    cd t3[P::A >= 3 ? 15 : 1];
+    if (P::A >= 3) {
+#pragma unroll
+        for (int p = 0; p < 15; p++) t3[p] = tab[P::T3_OFF + p * 256 + (l & 255)];
+    }
+    cd tf[P::NTWF > 0 ? P::NTWF : 1];
+#pragma unroll
+    for (int p = 0; p < P::NTWF; p++) tf[p] = tab[P::TF_OFF + p * LPF + l];
+    for (int i = l; i < P::LDS_T2; i += LPF) lds[P::LDS_IMG + i] = tab[i];
+    // the lane's 16 bins of H (64 VGPRs as doubles) are re-read from L2 at the multiply: with two windows' descriptors
+    // live the block loop has no room to keep them
+    const cd *Hg = reinterpret_cast<const cd *>(Hspec) + l;
+    auto tw3 = [&](int p) { return t3[p]; };
+
+    for (; b < nblocks; b += gridDim.x) {
+        // window of real block rb: samples rb*S - pad + i, i = 0..N-1, through a descriptor that starts at the first
+        // sample inside the buffer and ends with the buffer (rb past the stream: zero records)
+        __amdgpu_buffer_rsrc_t rs[2];
+        int shift[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const size_t rb = 2 * b + h;
+            const size_t sh = rb * S >= (size_t)pad ? 0 : (size_t)pad - rb * S;
+            const size_t first = rb * S + sh - pad;
+            const size_t left = (rb < nblocks_real && in_elems > first) ? in_elems - first : 0;
+            const size_t want = (size_t)N - sh;
+            rs[h] = make_rsrc(in + first * EB, (unsigned)((left < want ? left : want) * EB));
+            shift[h] = (int)sh;
+        }
+        cd v[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            v[s] = cd{RIO::load(rs[0], (l + LPF * s - shift[0]) * EB), RIO::load(rs[1], (l + LPF * s - shift[1]) * EB)};
+        xform<LOG2N>(v, lds, l, tw3, tf);
+        const cd *Hb = Hg;
+        asm volatile("" : "+v"(Hb));   // keeps the loads inside the loop (they are loop-invariant and would be hoisted back into registers)
+        cd u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = P::NATURAL ? q : bin_of(q);
+            const cd p = cmul(v[q], Hb[LPF * k]);
+            u[k] = cd{p.x, -p.y};
+        }
+        xform<LOG2N>(u, lds, l, tw3, tf);
+        __amdgpu_buffer_rsrc_t ws[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const size_t rb = 2 * b + h;
+            const size_t room = rb * S < n_out ? n_out - rb * S : 0;
+            ws[h] = make_rsrc(out + (room ? rb * S : 0) * EB, (unsigned)((room < S ? room : S) * EB));
+        }
+        const unsigned vbase = (unsigned)(l - Kov) * (unsigned)EB;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = LPF * (P::NATURAL ? q : bin_of(q));
+            if (row + LPF - 1 < Kov) continue;                // whole row dropped: uniform skip
+            // y = conj(u): block 2b is its real part, block 2b+1 its imaginary part
+            RIO::store(ws[0], (int)(vbase + (unsigned)row * (unsigned)EB), u[q].x);
+            RIO::store(ws[1], (int)(vbase + (unsigned)row * (unsigned)EB), -u[q].y);
+        }
+    }
+}
+
+template <int LOG2N, int IO>
+int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, hipStream_t st)
+{
+    typedef OlsPlan<LOG2N> P;
+    const size_t Km1 = K - 1;
+    const size_t Kov = (Km1 + 15) / 16 * 16;
+    if (Kov > (size_t)P::N / 2) { set_error("fir ols (real): K=%zu too long for %d-sample blocks", K, P::N); return PCX_ERR_UNSUPPORTED; }
+    const size_t pad = Kov - Km1;
+    const size_t S = P::N - Kov;
+    const size_t nblocks_real = (n_out + S - 1) / S;
+    const size_t nblocks = (nblocks_real + 1) / 2;
+    const size_t lds = (size_t)(P::LDS_IMG + P::LDS_T2) * sizeof(cd);
+    auto k = fir_real_ols_kernel<LOG2N, IO>;
+    if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    unsigned per_cu = (unsigned)(160 * 1024 / lds);
+    const unsigned by_waves = 8u * 64u / P::LPF;
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned grid = persistent_grid(nblocks, 256 * per_cu);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out,
+                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks_real);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 }  // namespace
 
 // log2n in {10 .. 13}; Hspec = FFT_N(h)/N in double, tw = make_tw_r16<double>(log2n) (pcx_api.hip).  io: 0 complex_float64,
@@ -277,4 +429,23 @@ int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out
     return PCX_ERR_UNSUPPORTED;
 }
 
+}  // namespace pcx
+
+namespace pcx {
+// REAL streams on the same pipeline (real taps): io 0 float64, 1 int16, 2 int8; log2n 12 (K <= 2049) or 13 (K <= 4097)
+int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n, const void *tw,
+                        int io, hipStream_t st)
+{
+    if (n_out == 0) return PCX_OK;
+    if (log2n == 12)
+        return io == 0 ? launch_real_ols<12, 0>(in, in_elems, out, n_out, Hspec, K, tw, st)
+             : io == 1 ? launch_real_ols<12, 1>(in, in_elems, out, n_out, Hspec, K, tw, st)
+                       : launch_real_ols<12, 2>(in, in_elems, out, n_out, Hspec, K, tw, st);
+    if (log2n == 13)
+        return io == 0 ? launch_real_ols<13, 0>(in, in_elems, out, n_out, Hspec, K, tw, st)
+             : io == 1 ? launch_real_ols<13, 1>(in, in_elems, out, n_out, Hspec, K, tw, st)
+                       : launch_real_ols<13, 2>(in, in_elems, out, n_out, Hspec, K, tw, st);
+    set_error("fir ols (real): no plan for log2(N) = %d", log2n);
+    return PCX_ERR_UNSUPPORTED;
+}
 }  // namespace pcx

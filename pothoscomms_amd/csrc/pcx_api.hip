@@ -227,6 +227,7 @@ struct pcx_fir {
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
     bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
     bool have_ols_int = false;    // complex_int16 / complex_int8 stream, M=L=1: exact integer convolution on the double transform
+    bool have_ols_real64 = false; // REAL float64 / int16 / int8 stream (real taps), M=L=1: two real blocks per double transform
     DevBuf HspecRows;
     int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
     bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
@@ -264,6 +265,14 @@ static size_t ols_int_min_taps(int scalar)
     return forced ? forced : scalar == PCX_I16 ? 64 : 96;
 }
 
+// REAL float64 / int16 / int8 streams on the double pipeline, two real blocks per transform: 234 / 290 / 296 Gsamples/s
+// whatever the tap count; the sliding-window kernel is faster below about 24 / 48 / 48 taps (tools/sweep_fir_int.py real:
+// float64 278 vs 228 at 16 taps, 202 vs 234 at 32; int16 356 vs 280 at 32, 230 vs 286 at 63); PCX_OLS_REAL_MIN overrides (A/B)
+static size_t ols_real64_min_taps(int scalar)
+{
+    static const size_t forced = [] { const char *e = getenv("PCX_OLS_REAL_MIN"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    return forced ? forced : scalar == PCX_F64 ? 24 : 48;
+}
 static int fir_ols64_block_log2(size_t K)
 {
     static const int forced = [] { const char *e = getenv("PCX_OLS64_N"); return e ? atoi(e) : 0; }();
@@ -400,6 +409,24 @@ static int fir_sync_tables(pcx_fir *h)
             h->have_ols_int = true;
         }
     }
+    h->have_ols_real64 = false;
+    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M == 1 && h->L == 1 && h->K >= 2 &&
+        h->K <= kOls64MaxTaps) {
+        const int qb = q_bits(h->scalar);
+        std::vector<std::complex<double>> hq(h->K);
+        double norm2 = 0;
+        for (size_t k = 0; k < h->K; k++) {
+            const double t = h->taps[k];
+            hq[k] = h->scalar == PCX_F64 ? t : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb);
+            norm2 += std::norm(hq[k]);
+        }
+        if (h->scalar == PCX_F64 || norm2 < 17592186044416.0) {   // integers: ||h_q||_2 < 2^22 keeps the rounded sums exact
+            h->ols_log2n = h->K <= 2049 ? 12 : 13;
+            PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
+            PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
+            h->have_ols_real64 = true;
+        }
+    }
     h->have_real_ols = false;
     if (h->scalar == PCX_F32 && !h->cplx && h->M == 1 && h->L == 1 && h->K <= 2049) {
         std::vector<std::complex<double>> hq(h->K);
@@ -521,20 +548,24 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // filter must return its input bit for bit, as the reference does
         if (fast && h->K == 1) algo = PCX_FIR_DIRECT;
         else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_ols64 && h->K >= kOls64MinTaps) ||
-                 (h->have_ols_int && h->K >= ols_int_min_taps(h->scalar))) algo = PCX_FIR_OLS_FFT;
+                 (h->have_ols_int && h->K >= ols_int_min_taps(h->scalar)) ||
+                 (h->have_ols_real64 && h->K >= ols_real64_min_taps(h->scalar))) algo = PCX_FIR_OLS_FFT;
         // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
         // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
-    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64 || h->have_ols_int)) {
+    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64 || h->have_ols_int || h->have_ols_real64)) {
         set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
-    if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
+    if (algo == PCX_FIR_OLS_FFT && h->have_ols_real64) {
+        rc = launch_fir_real_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
+                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
+    } else if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
         rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {

@@ -435,6 +435,49 @@ def test_fir_complex_integer_overlap_save_bit_exact(oracle, dev, ntaps, scalar_n
         assert np.array_equal(got, ref), (case, ntaps)
 
 
+@pytest.mark.parametrize("scalar_name", ["float64", "int16", "int8"])
+@pytest.mark.parametrize("ntaps", [2, 23, 24, 47, 48, 255, 1000, 2049, 2050, 4097, 4098])
+def test_fir_real_streams_on_the_double_pipeline(oracle, dev, ntaps, scalar_name):
+    """REAL float64 / int16 / int8 streams (real taps, M = L = 1): two real blocks per double-precision transform from
+    24 / 48 taps.  Integers bit-exact (random full-scale and all-extreme inputs), float64 within 1e-13; stream lengths
+    that leave an odd number of blocks and ragged ends."""
+    scalar = {"float64": oracle.F64, "int16": oracle.I16, "int8": oracle.I8}[scalar_name]
+    rng = np.random.default_rng(13 * ntaps)
+    npdt = {"float64": np.float64, "int16": np.int16, "int8": np.int8}[scalar_name]
+    full = {"float64": 1, "int16": 32768, "int8": 128}[scalar_name]
+    for case in ("random", "extreme"):
+        for n in (ntaps, 3 * 4096 + 555 + ntaps, 2 * 3840 + ntaps - 1):
+            if case == "random":
+                taps = _taps(rng, ntaps, False) * 0.9
+                x = rng.standard_normal(n) if scalar == oracle.F64 else rng.integers(-full, full, size=n)
+            else:
+                taps = 0.4999 * rng.choice([-1.0, 1.0], size=ntaps)
+                x = np.full(n, -full, dtype=np.float64)
+                x[::5] = full - (0 if scalar == oracle.F64 else 1)
+            x = x.astype(npdt)
+            ref_blk = oracle.Fir(scalar, False, False)
+            ref_blk.set_taps(taps); ref_blk.activate()
+            ref, rc, rp, _ = ref_blk.work(x, n)
+            f = dev.FirFilter((scalar, False), "REAL")
+            f.set_taps(taps)
+            for forced in (False, True):
+                if forced:
+                    f.set_algo(dev._lib.FIR_OLS_FFT if 2 <= ntaps <= 4097 else dev._lib.FIR_EXACT)
+                got, gc, gp = f.process(x, n)
+                assert (gc, gp) == (rc, rp)
+                if scalar == oracle.F64:
+                    # normalised by the output scale the taps and samples can reach (a single cancelling output must not set it)
+                    scale = max(float(np.max(np.abs(ref))) if rp else 0.0, 0.1 * float(np.sum(np.abs(taps))) * float(np.max(np.abs(x))))
+                    assert rp == 0 or float(np.max(np.abs(got.astype(np.float64) - ref))) <= 1e-13 * scale, (case, ntaps, n, forced)
+                else:
+                    assert np.array_equal(got, ref), (case, ntaps, n, forced)
+            if "PCX_OLS_REAL_MIN" not in os.environ:
+                f2 = dev.FirFilter((scalar, False), "REAL"); f2.set_taps(taps); f2.process(x, n)
+                lo = 24 if scalar == oracle.F64 else 48
+                if rp > 0:
+                    assert (f2.last_algo == dev._lib.FIR_OLS_FFT) == (lo <= ntaps <= 4097), (ntaps, f2.last_algo)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

@@ -1,0 +1,215 @@
+// fir_ols_decim.hip -- decimating /comms/fir_filter (complex_float32, interpolation 1, decimation M in {2, 4, 8, 16})
+// in the frequency domain with the decimation folded into the spectrum.
+//
+// The reference computes  y[t] = sum_k h[k] x[M-1 + t M - k]  (FIRFilter.cpp:286-302: the decimator fires when
+// (f+1) % M == 0) -- every M-th sample of the full-rate filter output.  fir_cf32_ols4096_poly_kernel evaluates that
+// output at full rate (two 4096-point transforms per block) and stores one sample in M.  Decimating a sequence by M
+// aliases its spectrum:  Yd[k'] = sum_m Y[k' + m N/M], k' < N/M,  so the inverse transform only has to be N/M points
+// long: one 4096-point forward transform, the H multiply, a fold of M bins into one and a 4096/M-point inverse --
+// (1 + 1/M) transforms' worth of arithmetic instead of 2, on a kernel that is bound by its arithmetic.
+//
+// Lane j holds X[j + 256 r], r = 0..15, after the forward passes, and N/M = 256 P with P = 16/M: the M bins that fold
+// onto k' = j + 256 r' are the lane's own registers r = r' + P m.  The N/M-point inverse (as conj . FFT . conj) is a
+// radix-P decimation-in-frequency stage over the lane's P folded values, the twiddle W_{N/M}^(j k1), and P independent
+// 256-point transforms (one per k1) run by 16 lanes each on the radix-16 passes of fft4096.hpp; output sample
+// n' = k1 + P k2 goes through LDS once more so that the stores are contiguous.
+// The decimator's phase (outputs at full-rate indices == M-1 mod M) is a circular advance by M-1 samples, folded into
+// H on the host (pcx_api.hip) together with the 1/N of the inverse.  Block geometry as in fir_ols.hip: overlap Kov =
+// K-1 rounded up to 16 samples (a multiple of every M here), S = 4096 - Kov full-rate outputs = S/M stored per block.
+#include "fft4096.hpp"
+#include <cstdlib>
+
+#include "pcx_internal.hpp"
+
+namespace pcx {
+
+namespace {
+using namespace fft4k;
+
+template <int LOG2M>
+__global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+                                                                        size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
+                                                                        const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
+                                                                        size_t nblocks)
+{
+    constexpr int M = 1 << LOG2M, P = 16 / M;       // P folded values per lane = frames of the 256-point stage
+    constexpr int FRAME = 272;                       // 256 + 256/16: padded sub-frame
+    constexpr int OIMG = 8 * FRAME;                  // output image behind the (at most 8) sub-frames
+    __shared__ cf lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    const size_t S = (size_t)(N - Kov), Sd = S >> LOG2M;
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    // pass-3 lane constants (30 VGPRs): in registers across the block loop for M >= 8; for M = 2 / 4 the inverse stage needs
+    // the room and they are re-read from L2 in every block, like H (measured: M = 2 217 -> 249, M = 4 275 -> 288 Gsamples/s;
+    // M = 16 loses 9 % with the reload and keeps them)
+    constexpr bool TW3_REG = M >= 8;
+    LaneTw tw3r;
+    if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    // the lane's 16 bins of H are re-read from L2 at the multiply (not held in 32 VGPRs): the 256-point stage keeps a
+    // second 16-point set alive across two barriers and the kernel has to stay within 128 VGPRs for 4 workgroups per CU
+    const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
+    // W_{N/M}^j: the lane constant of the decimation-in-frequency stage (its powers k1 = 2 .. P-1 are rebuilt by
+    // multiplication in every block: 6 packed multiplies against 12 more registers)
+    cf td1;
+    {
+        float sn, cs;
+        sincospif(-2.0f * (float)j / (float)(256 * P), &sn, &cs);
+        td1 = cf{cs, sn};
+    }
+    const int fi = j >> 4, l = j & 15;               // sub-frame and lane inside it (lanes j < 16 P run the 256-point stage)
+    const bool sub = j < 16 * P;
+
+    for (; b < nblocks; b += gridDim.x) {
+        cf v[16];
+        if (b >= first_full && b < nfull) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + b * S - pad, N * 8);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32x2 t = (r == 0 || r == 15) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 0)
+                                                    : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 2);
+                v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+            }
+        } else {
+            const size_t shift = b * S >= (size_t)pad ? 0 : (size_t)pad - b * S;
+            const size_t first = b * S + shift - pad;
+            const size_t left = in_elems > first ? in_elems - first : 0;
+            const size_t want = (size_t)N - shift;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 8));
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * r - (int)shift) * 8, 0, 0);
+                v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+            }
+        }
+        pass1(v, lds, j);
+        pass2(v, lds, j);
+        if (TW3_REG) {
+            pass3(v, lds, j, tw3r);
+        } else {
+            const float2 *tp = twtab;
+            asm volatile("" : "+v"(tp));
+            LaneTw tw3;
+            load_pass3_twiddles(tw3, tp, j);
+            pass3(v, lds, j, tw3);
+        }
+        // u[r] = conj(X[j + 256 r] * H'[j + 256 r]), natural r
+        const cf *Hb = Hg;
+        asm volatile("" : "+v"(Hb));   // loop-invariant: without this the loads are hoisted back into registers
+        cf u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const int k0 = bin_of(q), k1 = bin_of(q + 1);
+            u[k0] = v[q];
+            u[k1] = v[q + 1];
+            cmul2_conj(u[k0], u[k1], Hb[256 * k0], Hb[256 * k1]);
+        }
+        // fold: the M bins that alias onto k' = j + 256 r'
+        cf z[P];
+#pragma unroll
+        for (int r = 0; r < P; r++) {
+            z[r] = u[r];
+#pragma unroll
+            for (int m = 1; m < M; m++) z[r] = z[r] + u[r + P * m];
+        }
+        // radix-P decimation-in-frequency stage over r', then the lane twiddle W^(j k1)
+        if constexpr (P == 8) fft8(z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+        else if constexpr (P == 4) fft4(z[0], z[1], z[2], z[3]);
+        else if constexpr (P == 2) { const cf a = z[0], c = z[1]; z[0] = a + c; z[1] = a - c; }
+        {
+            cf t = td1;
+#pragma unroll
+            for (int k1 = 1; k1 < P; k1++) {
+                z[k1] = cmul1(z[k1], t);
+                if (k1 + 1 < P) t = cmul1(t, td1);
+            }
+        }
+        __syncthreads();                                  // every lane is done with the forward image (pass 3 reads)
+#pragma unroll
+        for (int k1 = 0; k1 < P; k1++) lds[k1 * FRAME + j + (j >> 4)] = z[k1];
+        __syncthreads();
+        // P independent 256-point transforms, 16 lanes each: radix 16 x 16 (Ns = 1, Ns = 16)
+        cf w[16];
+        cf *fr = lds + fi * FRAME;
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            fft16_plain(w);
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            LaneTw tl;
+            const cf *t2 = lds + LDS_DATA + l;
+#pragma unroll
+            for (int p = 0; p < 3; p++) tl.a[p] = t2[p * 16];
+#pragma unroll
+            for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
+            fft16_tw(w, tl);
+            // w[q] = bin k2 = l + 16 bin_of(q) of sub-transform k1 = fi: decimated time sample n' = k1 + P k2
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int n = fi + P * (l + 16 * bin_of(q));
+                lds[OIMG + n + (n >> 4)] = w[q];
+            }
+        }
+        __syncthreads();
+        // decimated sample n' of the block is output b*Sd + n' - Kov/M; n' < Kov/M wraps past num_records and is dropped
+        const size_t room = n_out - b * Sd;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * Sd, (unsigned)((room < Sd ? room : Sd) * 8));
+        const unsigned vbase = (unsigned)(j - (Kov >> LOG2M)) * 8u;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int n = j + 256 * i;
+            const cf y = lds[OIMG + n + (n >> 4)];
+            store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, cf{y.x, -y.y});
+        }
+    }
+}
+
+template <int LOG2M>
+int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, hipStream_t st)
+{
+    constexpr size_t M = (size_t)1 << LOG2M;
+    const size_t Km1 = K - 1;
+    const size_t Kov = (Km1 + 15) / 16 * 16, pad = Kov - Km1;
+    const size_t S = 4096 - Kov, Sd = S / M;
+    const size_t n_out = n_iter / M;
+    const size_t nblocks = (n_out + Sd - 1) / Sd;
+    const size_t first_full = pad > 0 ? 1 : 0;
+    size_t nfull = n_iter / S;
+    while (nfull > first_full && (nfull - 1) * S - pad + 4096 > in_elems) nfull--;
+    if (nfull < first_full) nfull = first_full;
+    const unsigned grid = persistent_grid(nblocks, 1024);
+    hipLaunchKernelGGL(fir_cf32_ols4096_decim_kernel<LOG2M>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
+                       (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+}  // namespace
+
+// n_iter full-rate iterations (a multiple of M) -> n_iter / M outputs.  Hspec = FFT_4096(h)[k] * exp(+j 2 pi k (M-1) / 4096) / 4096.
+int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
+                                  const void *tw4096, hipStream_t st)
+{
+    if (n_iter == 0) return PCX_OK;
+    if (K < 1 || K > 2049) { set_error("fir ols (decimating): K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
+    switch (M) {
+    case 2: return launch_decim<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    case 4: return launch_decim<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    case 8: return launch_decim<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    case 16: return launch_decim<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    }
+    set_error("fir ols (decimating): M=%zu is not 2, 4, 8 or 16", M);
+    return PCX_ERR_UNSUPPORTED;
+}
+
+}  // namespace pcx

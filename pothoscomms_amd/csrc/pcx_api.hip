@@ -128,8 +128,10 @@ static std::vector<T> make_tw_r16(int log2n)
 
 // H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096 (the 1/N of the inverse transform folded
 // in), accumulated in double, rounded once to float; natural bin order
+// `advance`: circular advance of the filter output by that many samples (H[b] *= exp(+j 2 pi b advance / N)) -- the
+// decimator's phase for the folded-spectrum kernel (fir_ols_decim.hip)
 template <typename T = float>
-static std::vector<T> make_hspec(const std::vector<std::complex<double>> &h, size_t N)
+static std::vector<T> make_hspec(const std::vector<std::complex<double>> &h, size_t N, size_t advance = 0)
 {
     std::vector<double> cs(2 * N);
     const double two_pi = 6.283185307179586476925286766559;
@@ -141,6 +143,11 @@ static std::vector<T> make_hspec(const std::vector<std::complex<double>> &h, siz
             const size_t e = (b * k) & (N - 1);
             sr += h[k].real() * cs[2 * e] - h[k].imag() * cs[2 * e + 1];
             si += h[k].real() * cs[2 * e + 1] + h[k].imag() * cs[2 * e];
+        }
+        if (advance) {
+            const size_t e = (N - (b * advance) % N) % N;     // cs[e] = exp(-j 2 pi e / N) = exp(+j 2 pi b advance / N)
+            const double pr = sr * cs[2 * e] - si * cs[2 * e + 1], pi = sr * cs[2 * e + 1] + si * cs[2 * e];
+            sr = pr; si = pi;
         }
         H[2 * b] = (T)(sr / (double)N);
         H[2 * b + 1] = (T)(si / (double)N);
@@ -224,6 +231,8 @@ struct pcx_fir {
     size_t Kp = 8;
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
+    bool have_decim = false;  // L = 1, M in {2,4,8,16}: decimation folded into the spectrum (Hdecim)
+    DevBuf Hdecim;
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
     bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
     bool have_ols_int = false;    // complex_int16 / complex_int8 stream, M=L=1: exact integer convolution on the double transform
@@ -454,6 +463,16 @@ static int fir_sync_tables(pcx_fir *h)
         PCX_TRY(upload(h->tw4096, make_tw4096()));
         h->have_poly = true;
     }
+    h->have_decim = false;
+    if (h->have_poly && h->L == 1 && (h->M == 2 || h->M == 4 || h->M == 8 || h->M == 16) && !getenv("PCX_FIR_DECIM_FULLRATE")) {
+        // decimating filter: one forward transform, the spectrum folded M-fold, a 4096/M-point inverse (fir_ols_decim.hip).
+        // PCX_FIR_DECIM_FULLRATE (A/B) keeps the full-rate evaluation of the polyphase kernel.
+        std::vector<std::complex<double>> hq(h->K);
+        for (size_t k = 0; k < h->K; k++)
+            hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]), h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
+        PCX_TRY(upload(h->Hdecim, make_hspec(hq, 4096, h->M - 1)));
+        h->have_decim = true;
+    }
     h->dirty = false;
     return PCX_OK;
 }
@@ -570,6 +589,8 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_decim) {
+        rc = launch_fir_cf32_ols4096_decim(in_dev, used_in, out_dev, N, h->Hdecim.p, h->K, h->M, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {

@@ -478,6 +478,29 @@ def test_fir_real_streams_on_the_double_pipeline(oracle, dev, ntaps, scalar_name
                     assert (f2.last_algo == dev._lib.FIR_OLS_FFT) == (lo <= ntaps <= 4097), (ntaps, f2.last_algo)
 
 
+@pytest.mark.parametrize("ctaps", [False, True])
+@pytest.mark.parametrize("M", [2, 4, 8, 16])
+@pytest.mark.parametrize("ntaps", [1, 2, 16, 17, 255, 1000, 2049])
+def test_fir_cf32_decimating_folded_spectrum(oracle, dev, ntaps, M, ctaps):
+    """complex_float32, interpolation 1, decimation 2 / 4 / 8 / 16: one forward transform, the spectrum folded M-fold and
+    a 4096/M-point inverse (fir_ols_decim.hip).  Same outputs and consume/produce counts as the reference's decimator
+    (FIRFilter.cpp:286-302) over stream lengths with ragged first / last blocks, chunked calls included."""
+    rng = np.random.default_rng(17 * ntaps + M + ctaps)
+    taps = _taps(rng, ntaps, ctaps)
+    for n in (ntaps + M - 1, ntaps + 5 * M, 4096 + ntaps, 3 * 4096 + 777 + ntaps):
+        x = rand_stream(rng, oracle.F32, n, True)
+        ref_blk = oracle.Fir(oracle.F32, True, ctaps)
+        ref_blk.set_taps(taps); ref_blk.set_decimation(M); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n)
+        f = dev.FirFilter((oracle.F32, True), "COMPLEX" if ctaps else "REAL")
+        f.set_taps(taps); f.set_decimation(M)
+        got, gc, gp = f.process(x, n)
+        assert (gc, gp) == (rc, rp), (ntaps, M, n)
+        if rp:
+            assert f.last_algo == dev._lib.FIR_OLS_FFT
+            assert nerr(got, ref) <= TOL, (ntaps, M, n)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

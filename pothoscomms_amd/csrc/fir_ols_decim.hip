@@ -194,6 +194,155 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     return PCX_OK;
 }
 
+// --------------------------------------------------------------------------------- //
+// The mirror image for INTERPOLATING filters (decimation 1, interpolation L in {2, 4, 8, 16}): the reference's polyphase
+// rows (FIRFilter.cpp:286-302, taps_j[k] = taps[j + k L]) are the convolution of the zero-stuffed stream with the whole
+// tap vector, and zero-stuffing by L REPLICATES the spectrum:  Xz[k] = Xs[k mod N/L],  Xs = FFT_{N/L}(input block).
+// So a block is a 4096/L-point forward transform (16/L independent 256-point transforms of the input's polyphase
+// components on 16 lanes each, then one twiddle and a radix-(16/L) stage in the lane, which leaves Xs[j + 256 r'] in lane
+// j), 16 multiplies by H (all 4096 bins of the full tap vector), and the ordinary 4096-point inverse, whose output is
+// the interleaved output stream itself: contiguous 2 KiB rows instead of the polyphase kernel's stride-L stores.
+// Geometry at the input rate: Kov_in = K-1 rounded up so that Kov_in*L is a multiple of 16, S_in = 4096/L - Kov_in
+// input samples = S_in*L outputs per block; output i of a block is valid from i >= Kov_in*L on (the wrapped positions a
+// valid output still touches are zero-stuffing zeros).
+// --------------------------------------------------------------------------------- //
+template <int LOG2L>
+__global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+                                                                         size_t n_out, const float2 *__restrict__ Hspec, int Kov_in, int pad_in,
+                                                                         const float2 *__restrict__ twtab, size_t nblocks)
+{
+    constexpr int L = 1 << LOG2L, P = 16 / L, LOG2P = 4 - LOG2L, ND = 256 * P;
+    constexpr int FRAME = 272;
+    __shared__ cf lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    const size_t S_in = (size_t)(ND - Kov_in), S_out = S_in << LOG2L;
+    const int Kov_out = Kov_in << LOG2L;
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
+    cf td1;
+    {
+        float sn, cs;
+        sincospif(-2.0f * (float)j / (float)ND, &sn, &cs);
+        td1 = cf{cs, sn};
+    }
+    const int fi = j >> 4, l = j & 15;
+    const bool sub = j < 16 * P;
+
+    for (; b < nblocks; b += gridDim.x) {
+        // input window: ND samples from input index b*S_in - pad_in (those before the buffer read 0: they only feed dropped outputs)
+        const size_t start = b * S_in;
+        const size_t shift = start >= (size_t)pad_in ? 0 : (size_t)pad_in - start;
+        const size_t first = start + shift - pad_in;
+        const size_t left = in_elems > first ? in_elems - first : 0;
+        const size_t want = (size_t)ND - shift;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 8));
+        cf x[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * i - (int)shift) * 8, 0, 0);
+            x[i] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+        }
+        __syncthreads();                                  // the previous block's inverse is done with the image
+        // polyphase component n1 = n mod P of the window goes to sub-frame n1 at position n / P  (n = j + 256 i)
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int n2 = (j >> LOG2P) + (256 >> LOG2P) * i;
+            lds[(j & (P - 1)) * FRAME + n2 + (n2 >> 4)] = x[i];
+        }
+        __syncthreads();
+        cf w[16];
+        cf *fr = lds + fi * FRAME;
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            fft16_plain(w);
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            LaneTw tl;
+            const cf *t2 = lds + LDS_DATA + l;
+#pragma unroll
+            for (int p = 0; p < 3; p++) tl.a[p] = t2[p * 16];
+#pragma unroll
+            for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
+            fft16_tw(w, tl);
+        }
+        __syncthreads();                                  // every lane of the frame has read its inputs
+        if (sub) {
+            // G_n1[k2], k2 = l + 16 bin_of(q), back into the frame in natural order
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int k2 = l + 16 * bin_of(q);
+                fr[k2 + (k2 >> 4)] = w[q];
+            }
+        }
+        __syncthreads();
+        // lane j: Xs[j + 256 r'] = sum_n1 W_P^(n1 r') W_ND^(n1 j) G_n1[j]
+        cf g[P];
+#pragma unroll
+        for (int n1 = 0; n1 < P; n1++) g[n1] = lds[n1 * FRAME + j + (j >> 4)];
+        {
+            cf t = td1;
+#pragma unroll
+            for (int n1 = 1; n1 < P; n1++) {
+                g[n1] = cmul1(g[n1], t);
+                if (n1 + 1 < P) t = cmul1(t, td1);
+            }
+        }
+        if constexpr (P == 8) fft8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+        else if constexpr (P == 4) fft4(g[0], g[1], g[2], g[3]);
+        else if constexpr (P == 2) { const cf a = g[0], c = g[1]; g[0] = a + c; g[1] = a - c; }
+        // replicated spectrum times H, conjugated for the inverse (conj . FFT . conj)
+        const cf *Hb = Hg;
+        asm volatile("" : "+v"(Hb));
+        cf u[16];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            u[r] = g[r & (P - 1)];
+            u[r + 1] = g[(r + 1) & (P - 1)];
+            cmul2_conj(u[r], u[r + 1], Hb[256 * r], Hb[256 * (r + 1)]);
+        }
+        pass1(u, lds, j);
+        pass2(u, lds, j);
+        pass3(u, lds, j, tw3);
+        const size_t room = n_out - b * S_out;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S_out, (unsigned)((room < S_out ? room : S_out) * 8));
+        const unsigned vbase = (unsigned)(j - Kov_out) * 8u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = 256 * bin_of(q);
+            if (row + 255 < Kov_out) continue;                // whole row dropped: uniform skip
+            store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
+        }
+    }
+}
+
+template <int LOG2L>
+int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, hipStream_t st)
+{
+    constexpr size_t L = (size_t)1 << LOG2L, ND = 4096 / L, A = 16 / L;    // Kov_in * L must be a multiple of 16
+    const size_t Kov_in = (K - 1 + A - 1) / A * A, pad_in = Kov_in - (K - 1);
+    if (Kov_in > ND / 2) { set_error("fir ols (interpolating): %zu taps per phase too long for L=%zu", K, L); return PCX_ERR_UNSUPPORTED; }
+    const size_t S_in = ND - Kov_in;
+    const size_t nblocks = (n_iter + S_in - 1) / S_in;
+    const unsigned grid = persistent_grid(nblocks, 1024);
+    hipLaunchKernelGGL(fir_cf32_ols4096_interp_kernel<LOG2L>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                       n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 }  // namespace
 
 // n_iter full-rate iterations (a multiple of M) -> n_iter / M outputs.  Hspec = FFT_4096(h)[k] * exp(+j 2 pi k (M-1) / 4096) / 4096.
@@ -209,6 +358,21 @@ int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, si
     case 16: return launch_decim<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
     }
     set_error("fir ols (decimating): M=%zu is not 2, 4, 8 or 16", M);
+    return PCX_ERR_UNSUPPORTED;
+}
+
+// n_iter input iterations -> n_iter * L outputs.  Hspec = FFT_4096(all taps) / 4096; K = taps per polyphase row.
+int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
+                                   const void *tw4096, hipStream_t st)
+{
+    if (n_iter == 0) return PCX_OK;
+    switch (L) {
+    case 2: return launch_interp<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    case 4: return launch_interp<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    case 8: return launch_interp<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    case 16: return launch_interp<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    }
+    set_error("fir ols (interpolating): L=%zu is not 2, 4, 8 or 16", L);
     return PCX_ERR_UNSUPPORTED;
 }
 

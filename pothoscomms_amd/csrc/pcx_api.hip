@@ -232,6 +232,7 @@ struct pcx_fir {
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
     bool have_decim = false;  // L = 1, M in {2,4,8,16}: decimation folded into the spectrum (Hdecim)
+    bool have_interp = false; // M = 1, L in {2,4,8,16}: replicated spectrum of the short forward transform (Hdecim holds H of all taps)
     DevBuf Hdecim;
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
     bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
@@ -473,6 +474,19 @@ static int fir_sync_tables(pcx_fir *h)
         PCX_TRY(upload(h->Hdecim, make_hspec(hq, 4096, h->M - 1)));
         h->have_decim = true;
     }
+    h->have_interp = false;
+    if (h->have_poly && h->M == 1 && (h->L == 2 || h->L == 4 || h->L == 8 || h->L == 16) && !getenv("PCX_FIR_DECIM_FULLRATE")) {
+        // interpolating filter: a 4096/L-point forward transform, its spectrum replicated against H of the WHOLE tap vector,
+        // the ordinary 4096-point inverse writing the interleaved output stream (fir_ols_decim.hip)
+        const size_t A = 16 / h->L, kov_in = (h->K - 1 + A - 1) / A * A;
+        if (kov_in <= 4096 / h->L / 2 && h->ntaps <= 2049) {
+            std::vector<std::complex<double>> hq(h->ntaps);
+            for (size_t k = 0; k < h->ntaps; k++)
+                hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]), h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
+            PCX_TRY(upload(h->Hdecim, make_hspec(hq, 4096)));
+            h->have_interp = true;
+        }
+    }
     h->dirty = false;
     return PCX_OK;
 }
@@ -589,6 +603,8 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_interp) {
+        rc = launch_fir_cf32_ols4096_interp(in_dev, used_in, out_dev, N, h->Hdecim.p, h->K, h->L, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_decim) {
         rc = launch_fir_cf32_ols4096_decim(in_dev, used_in, out_dev, N, h->Hdecim.p, h->K, h->M, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {

@@ -127,6 +127,8 @@ int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_
 // Hspec: device array of 4096 cf32 = FFT_4096(h)/4096 in natural bin order.
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                             const void *tw4096, hipStream_t st);
+int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
+                                   const void *tw4096, hipStream_t st);
 int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
                                   const void *tw4096, hipStream_t st);
 int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,

@@ -501,6 +501,38 @@ def test_fir_cf32_decimating_folded_spectrum(oracle, dev, ntaps, M, ctaps):
             assert nerr(got, ref) <= TOL, (ntaps, M, n)
 
 
+@pytest.mark.parametrize("ctaps", [False, True])
+@pytest.mark.parametrize("L", [2, 4, 8, 16])
+@pytest.mark.parametrize("ntaps", [1, 3, 16, 33, 255, 1000, 2049, 2500])
+def test_fir_cf32_interpolating_replicated_spectrum(oracle, dev, ntaps, L, ctaps):
+    """complex_float32, decimation 1, interpolation 2 / 4 / 8 / 16: a 4096/L-point forward transform, its spectrum
+    replicated against H of the whole tap vector, the 4096-point inverse writing the interleaved output
+    (fir_ols_decim.hip).  Same outputs and consume/produce counts as the reference's polyphase rows
+    (FIRFilter.cpp:286-302, :341-350); tap vectors too long for the plan fall back to the polyphase kernel."""
+    rng = np.random.default_rng(19 * ntaps + L + ctaps)
+    taps = _taps(rng, ntaps, ctaps)
+    K = -(-ntaps // L)
+    for n in (K, K + 1, 4096 // L + K, 3 * (4096 // L) + 77 + K):
+        x = rand_stream(rng, oracle.F32, n, True)
+        ref_blk = oracle.Fir(oracle.F32, True, ctaps)
+        ref_blk.set_taps(taps); ref_blk.set_interpolation(L); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n * L)
+        f = dev.FirFilter((oracle.F32, True), "COMPLEX" if ctaps else "REAL")
+        f.set_taps(taps); f.set_interpolation(L)
+        got, gc, gp = f.process(x, n * L)
+        assert (gc, gp) == (rc, rp), (ntaps, L, n)
+        if rp:
+            assert nerr(got, ref) <= TOL, (ntaps, L, n)
+        # a short output buffer limits the iterations (FIRFilter.cpp:278): same counts again
+        cap = (rp // 2) // L * L
+        if cap:
+            ref_blk2 = oracle.Fir(oracle.F32, True, ctaps)
+            ref_blk2.set_taps(taps); ref_blk2.set_interpolation(L); ref_blk2.activate()
+            ref2, rc2, rp2, _ = ref_blk2.work(x, cap)
+            got2, gc2, gp2 = f.process(x, cap)
+            assert (gc2, gp2) == (rc2, rp2) and nerr(got2, ref2) <= TOL, (ntaps, L, n, cap)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

@@ -151,9 +151,12 @@ struct StreamIo<2> {
     }
 };
 
-template <int LOG2N, int IO>
+// DECIM: decimation M > 1 (interpolation 1): the block is evaluated at full rate and only the outputs the reference's
+// decimator keeps -- full-rate index n with (n + 1) % M == 0, FIRFilter.cpp:291 -- are stored, at (n + 1) / M - 1.
+// n_out counts full-rate outputs, n_dec the stored ones; magic = ceil(2^32 / M) (exact quotient for t * M < 2^32).
+template <int LOG2N, int IO, bool DECIM>
 __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_per_eu(2))) void fir_cf64_ols_kernel(const unsigned char *__restrict__ in, size_t in_elems,
-                                                                          unsigned char *__restrict__ out, size_t n_out,
+                                                                          unsigned char *__restrict__ out, size_t n_out, size_t n_dec, unsigned M, unsigned magic,
                                                                           const double2 *__restrict__ Hspec, int Kov, int pad,
                                                                           const double2 *__restrict__ twtab, size_t first_full,
                                                                           size_t nfull, size_t nblocks)
@@ -212,6 +215,25 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
             u[k] = cd{p.x, -p.y};
         }
         xform<LOG2N>(u, lds, l, tw3, tf);
+        if (DECIM) {
+            // b*S = B0*M + base: full-rate output b*S + (i - Kov) is kept when t = base + (i - Kov) + 1 is a multiple of M,
+            // and lands at B0 + t/M - 1
+            const size_t B0 = (b * S) / M;
+            const unsigned base = (unsigned)((b * S) - B0 * M);
+            const size_t room = n_dec > B0 ? n_dec - B0 : 0;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + B0 * EB, (unsigned)((room < (size_t)(N / 2 + 2) ? room : (size_t)(N / 2 + 2)) * EB));
+            const size_t full_left = n_out - b * S;           // full-rate outputs this block may produce
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int row = LPF * (P::NATURAL ? q : bin_of(q));
+                if (row + LPF - 1 < Kov) continue;
+                const int i = l + row;
+                const unsigned t = base + (unsigned)(i - Kov) + 1u;
+                const unsigned qt = __umulhi(t, magic);
+                if (i >= Kov && (size_t)(i - Kov) < full_left && qt * M == t)
+                    SIO::store(ws, (int)((qt - 1u) * (unsigned)EB), cd{u[q].x, -u[q].y});
+            }
+        } else {
         const size_t room = n_out - b * S;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S * EB, (unsigned)((room < S ? room : S) * EB));
         const unsigned vbase = (unsigned)(l - Kov) * (unsigned)EB;
@@ -221,11 +243,12 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
             if (row + LPF - 1 < Kov) continue;                // whole row dropped: uniform skip
             SIO::store(ws, (int)(vbase + (unsigned)row * (unsigned)EB), cd{u[q].x, -u[q].y});
         }
+        }
     }
 }
 
 template <int LOG2N, int IO>
-int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, hipStream_t st)
+int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, hipStream_t st)
 {
     typedef OlsPlan<LOG2N> P;
     const size_t Km1 = K - 1;
@@ -239,7 +262,8 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     while (nfull > first_full && (nfull - 1) * S - pad + P::N > in_elems) nfull--;
     if (nfull < first_full) nfull = first_full;
     const size_t lds = (size_t)(P::LDS_IMG + P::LDS_T2) * sizeof(cd);
-    auto k = fir_cf64_ols_kernel<LOG2N, IO>;
+    auto k = M > 1 ? fir_cf64_ols_kernel<LOG2N, IO, true> : fir_cf64_ols_kernel<LOG2N, IO, false>;
+    const unsigned magic = M > 1 ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // resident workgroups per CU: LDS (160 KiB) and 8 waves of <= 256 VGPRs
     unsigned per_cu = (unsigned)(160 * 1024 / lds);
@@ -247,8 +271,8 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     const unsigned grid = persistent_grid(nblocks, 256 * per_cu);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out,
-                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, first_full, nfull, nblocks);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out, n_out / M,
+                       (unsigned)M, magic, (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, first_full, nfull, nblocks);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -408,16 +432,17 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
 }  // namespace
 
 // log2n in {10 .. 13}; Hspec = FFT_N(h)/N in double, tw = make_tw_r16<double>(log2n) (pcx_api.hip).  io: 0 complex_float64,
-// 1 complex_int16, 2 complex_int8 (h = the Q-format integer taps; see StreamIo)
+// 1 complex_int16, 2 complex_int8 (h = the Q-format integer taps; see StreamIo).  n_out = full-rate outputs; M > 1 keeps one in M
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
-                        const void *tw, int io, hipStream_t st)
+                        const void *tw, int io, size_t M, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
+    if (M < 1 || M > 65535) { set_error("fir ols f64: decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
 #define PCX_OLS64_CASE(L2)                                                                                    \
     case L2:                                                                                                  \
-        return io == 0   ? launch_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, st)                     \
-               : io == 1 ? launch_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, st)                     \
-                         : launch_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, st);
+        return io == 0   ? launch_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, st)                  \
+               : io == 1 ? launch_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, st)                  \
+                         : launch_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, st);
     switch (log2n) {
         PCX_OLS64_CASE(10)
         PCX_OLS64_CASE(11)

@@ -391,7 +391,7 @@ static int fir_sync_tables(pcx_fir *h)
         }
     }
     h->have_ols64 = false;
-    if (h->scalar == PCX_F64 && h->cplx && h->M == 1 && h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
+    if (h->scalar == PCX_F64 && h->cplx && h->M <= 65535 && h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {   // M > 1: decimate on store
         // complex_float64: the same frequency-domain evaluation in double (fir_ols_f64.hip)
         std::vector<std::complex<double>> hq(h->K);
         for (size_t k = 0; k < h->K; k++) hq[k] = std::complex<double>(h->ctaps ? h->taps[2 * k] : h->taps[k], h->ctaps ? h->taps[2 * k + 1] : 0.0);
@@ -401,7 +401,7 @@ static int fir_sync_tables(pcx_fir *h)
         h->have_ols64 = true;
     }
     h->have_ols_int = false;
-    if ((h->scalar == PCX_I16 || h->scalar == PCX_I8) && h->cplx && h->M == 1 && h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
+    if ((h->scalar == PCX_I16 || h->scalar == PCX_I8) && h->cplx && h->M <= 65535 && h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
         // the Q-format taps exactly as the time-domain kernels use them (floatToQ<QTapsType>, FIRFilter.cpp:348), as doubles;
         // the double transform reproduces the integer convolution bit for bit while ||h_q||_2 < 2^22 (fir_ols_f64.hip)
         const int qb = q_bits(h->scalar);
@@ -580,8 +580,12 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         // K == 1 (the block's default unit tap) stays on the time-domain tile: a pass-through
         // filter must return its input bit for bit, as the reference does
         if (fast && h->K == 1) algo = PCX_FIR_DIRECT;
-        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_ols64 && h->K >= kOls64MinTaps) ||
-                 (h->have_ols_int && h->K >= ols_int_min_taps(h->scalar)) ||
+        // decimating complex_float64 / complex_int16 / complex_int8 filters: the full-rate double pipeline with one output in M
+        // stored runs at 130-170 Gsamples/s of input whatever K; the one-output-per-lane kernel it replaces measured 45-129
+        // (int16) / 27-31 (float64) at 63 taps and 12-33 / 6-8 at 255 (tools/decim_int_probe.py)
+        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) ||
+                 (h->have_ols64 && h->K >= (h->M > 1 ? 16 : kOls64MinTaps)) ||
+                 (h->have_ols_int && h->K >= (h->M > 1 ? 32 : ols_int_min_taps(h->scalar))) ||
                  (h->have_ols_real64 && h->K >= ols_real64_min_taps(h->scalar))) algo = PCX_FIR_OLS_FFT;
         // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
         // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
@@ -599,8 +603,8 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         rc = launch_fir_real_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
     } else if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
-        rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
-                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
+        rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
+                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, h->M, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_interp) {

@@ -533,6 +533,37 @@ def test_fir_cf32_interpolating_replicated_spectrum(oracle, dev, ntaps, L, ctaps
             assert (gc2, gp2) == (rc2, rp2) and nerr(got2, ref2) <= TOL, (ntaps, L, n, cap)
 
 
+@pytest.mark.parametrize("scalar_name", ["float64", "int16", "int8"])
+@pytest.mark.parametrize("M", [2, 3, 5, 8, 16, 100])
+@pytest.mark.parametrize("ntaps", [2, 31, 32, 255, 2049, 4097])
+def test_fir_complex_decimating_on_the_double_pipeline(oracle, dev, ntaps, M, scalar_name):
+    """complex_float64 / complex_int16 / complex_int8 with decimation M (any M, interpolation 1): the double-precision
+    overlap-save pipeline at full rate, one output in M stored -- the ones the reference's decimator keeps.  Integers
+    bit-exact, float64 within 1e-13; consume/produce counts as the reference."""
+    scalar = {"float64": oracle.F64, "int16": oracle.I16, "int8": oracle.I8}[scalar_name]
+    rng = np.random.default_rng(23 * ntaps + M)
+    taps = _taps(rng, ntaps, True) * 0.9
+    full = {"float64": 1, "int16": 32768, "int8": 128}[scalar_name]
+    npdt = {"float64": np.float64, "int16": np.int16, "int8": np.int8}[scalar_name]
+    for n in (ntaps + M - 1, ntaps + 7 * M + 1, 2 * 4096 + 333 + ntaps):
+        x = (rng.standard_normal((n, 2)) if scalar == oracle.F64 else rng.integers(-full, full, size=(n, 2))).astype(npdt)
+        ref_blk = oracle.Fir(scalar, True, True)
+        ref_blk.set_taps(taps); ref_blk.set_decimation(M); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n)
+        f = dev.FirFilter((scalar, True), "COMPLEX")
+        f.set_taps(taps); f.set_decimation(M)
+        got, gc, gp = f.process(x, n)
+        assert (gc, gp) == (rc, rp), (ntaps, M, n)
+        if rp == 0:
+            continue
+        if scalar == oracle.F64:
+            assert nerr(got, ref) <= 1e-13, (ntaps, M, n)
+        else:
+            assert np.array_equal(got, ref), (ntaps, M, n)
+        lo = 16 if scalar == oracle.F64 else 32
+        assert (f.last_algo == dev._lib.FIR_OLS_FFT) == (lo <= ntaps <= 4097), (ntaps, f.last_algo)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

@@ -325,10 +325,24 @@ struct RealIo<2> {   // int8: 16-bit Q accumulator, >> 8
     }
 };
 
-template <int LOG2N, int IO>
+template <>
+struct RealIo<3> {   // float32 (decimating real float32 filters: the undecimated stream has its own kernel, fir_ols.hip)
+    static constexpr int EB = 4;
+    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t rs, int voff)
+    {
+        return (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)y), ws, voff, 0, kAuxStream);
+    }
+};
+
+// DECIM as in fir_cf64_ols_kernel: full-rate evaluation, one output in M stored
+template <int LOG2N, int IO, bool DECIM>
 __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_per_eu(2))) void fir_real_ols_kernel(
     const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, const double2 *__restrict__ Hspec,
-    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real)
+    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real, size_t n_dec, unsigned M, unsigned magic)
 {
     typedef OlsPlan<LOG2N> P;
     typedef RealIo<IO> RIO;
@@ -385,6 +399,28 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
             u[k] = cd{p.x, -p.y};
         }
         xform<LOG2N>(u, lds, l, tw3, tf);
+        if (DECIM) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const size_t rb = 2 * b + h;
+                if (rb * S >= n_out) continue;                // uniform
+                const size_t B0 = (rb * S) / M;
+                const unsigned base = (unsigned)((rb * S) - B0 * M);
+                const size_t room = n_dec > B0 ? n_dec - B0 : 0;
+                const __amdgpu_buffer_rsrc_t wd = make_rsrc(out + B0 * EB, (unsigned)((room < (size_t)(N / 2 + 2) ? room : (size_t)(N / 2 + 2)) * EB));
+                const size_t full_left = n_out - rb * S;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int row = LPF * (P::NATURAL ? q : bin_of(q));
+                    if (row + LPF - 1 < Kov) continue;
+                    const int i = l + row;
+                    const unsigned t = base + (unsigned)(i - Kov) + 1u;
+                    const unsigned qt = __umulhi(t, magic);
+                    if (i >= Kov && (size_t)(i - Kov) < full_left && qt * M == t)
+                        RIO::store(wd, (int)((qt - 1u) * (unsigned)EB), h == 0 ? u[q].x : -u[q].y);
+                }
+            }
+        } else {
         __amdgpu_buffer_rsrc_t ws[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -401,11 +437,12 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
             RIO::store(ws[0], (int)(vbase + (unsigned)row * (unsigned)EB), u[q].x);
             RIO::store(ws[1], (int)(vbase + (unsigned)row * (unsigned)EB), -u[q].y);
         }
+        }
     }
 }
 
 template <int LOG2N, int IO>
-int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, hipStream_t st)
+int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, hipStream_t st)
 {
     typedef OlsPlan<LOG2N> P;
     const size_t Km1 = K - 1;
@@ -416,7 +453,8 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
     const size_t nblocks_real = (n_out + S - 1) / S;
     const size_t nblocks = (nblocks_real + 1) / 2;
     const size_t lds = (size_t)(P::LDS_IMG + P::LDS_T2) * sizeof(cd);
-    auto k = fir_real_ols_kernel<LOG2N, IO>;
+    auto k = M > 1 ? fir_real_ols_kernel<LOG2N, IO, true> : fir_real_ols_kernel<LOG2N, IO, false>;
+    const unsigned magic = M > 1 ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     unsigned per_cu = (unsigned)(160 * 1024 / lds);
     const unsigned by_waves = 8u * 64u / P::LPF;
@@ -424,7 +462,7 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
     if (per_cu < 1) per_cu = 1;
     const unsigned grid = persistent_grid(nblocks, 256 * per_cu);
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out,
-                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks_real);
+                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks_real, n_out / M, (unsigned)M, magic);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -457,19 +495,22 @@ int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out
 }  // namespace pcx
 
 namespace pcx {
-// REAL streams on the same pipeline (real taps): io 0 float64, 1 int16, 2 int8; log2n 12 (K <= 2049) or 13 (K <= 4097)
+// REAL streams on the same pipeline (real taps): io 0 float64, 1 int16, 2 int8, 3 float32; log2n 12 (K <= 2049) or 13 (K <= 4097);
+// n_out = full-rate outputs, M > 1 keeps one in M
 int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n, const void *tw,
-                        int io, hipStream_t st)
+                        int io, size_t M, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
-    if (log2n == 12)
-        return io == 0 ? launch_real_ols<12, 0>(in, in_elems, out, n_out, Hspec, K, tw, st)
-             : io == 1 ? launch_real_ols<12, 1>(in, in_elems, out, n_out, Hspec, K, tw, st)
-                       : launch_real_ols<12, 2>(in, in_elems, out, n_out, Hspec, K, tw, st);
-    if (log2n == 13)
-        return io == 0 ? launch_real_ols<13, 0>(in, in_elems, out, n_out, Hspec, K, tw, st)
-             : io == 1 ? launch_real_ols<13, 1>(in, in_elems, out, n_out, Hspec, K, tw, st)
-                       : launch_real_ols<13, 2>(in, in_elems, out, n_out, Hspec, K, tw, st);
+    if (M < 1 || M > 65535) { set_error("fir ols (real): decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
+#define PCX_REAL_CASE(L2)                                                                                   \
+    if (log2n == L2)                                                                                        \
+        return io == 0   ? launch_real_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, st)            \
+               : io == 1 ? launch_real_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, st)            \
+               : io == 2 ? launch_real_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, st)            \
+                         : launch_real_ols<L2, 3>(in, in_elems, out, n_out, Hspec, K, tw, M, st);
+    PCX_REAL_CASE(12)
+    PCX_REAL_CASE(13)
+#undef PCX_REAL_CASE
     set_error("fir ols (real): no plan for log2(N) = %d", log2n);
     return PCX_ERR_UNSUPPORTED;
 }

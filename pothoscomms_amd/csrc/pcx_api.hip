@@ -420,17 +420,19 @@ static int fir_sync_tables(pcx_fir *h)
         }
     }
     h->have_ols_real64 = false;
-    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M == 1 && h->L == 1 && h->K >= 2 &&
-        h->K <= kOls64MaxTaps) {
+    // (real float32 joins for decimating filters only: its undecimated stream has the float kernel below)
+    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8 || (h->scalar == PCX_F32 && h->M > 1)) && !h->cplx && h->M <= 65535 &&
+        h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
         const int qb = q_bits(h->scalar);
         std::vector<std::complex<double>> hq(h->K);
         double norm2 = 0;
         for (size_t k = 0; k < h->K; k++) {
             const double t = h->taps[k];
-            hq[k] = h->scalar == PCX_F64 ? t : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb);
+            hq[k] = h->scalar == PCX_F64 ? t : h->scalar == PCX_F32 ? (double)(float)t
+                    : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb);
             norm2 += std::norm(hq[k]);
         }
-        if (h->scalar == PCX_F64 || norm2 < 17592186044416.0) {   // integers: ||h_q||_2 < 2^22 keeps the rounded sums exact
+        if (h->scalar == PCX_F64 || h->scalar == PCX_F32 || norm2 < 17592186044416.0) {   // integers: ||h_q||_2 < 2^22 keeps the rounded sums exact
             h->ols_log2n = h->K <= 2049 ? 12 : 13;
             PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
             PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
@@ -586,7 +588,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) ||
                  (h->have_ols64 && h->K >= (h->M > 1 ? 16 : kOls64MinTaps)) ||
                  (h->have_ols_int && h->K >= (h->M > 1 ? 32 : ols_int_min_taps(h->scalar))) ||
-                 (h->have_ols_real64 && h->K >= ols_real64_min_taps(h->scalar))) algo = PCX_FIR_OLS_FFT;
+                 (h->have_ols_real64 && h->K >= (h->M > 1 ? 16 : ols_real64_min_taps(h->scalar)))) algo = PCX_FIR_OLS_FFT;
         // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
         // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
@@ -600,8 +602,8 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
     if (algo == PCX_FIR_OLS_FFT && h->have_ols_real64) {
-        rc = launch_fir_real_ols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
-                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, st);
+        rc = launch_fir_real_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
+                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, h->M, st);
     } else if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
         rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, h->M, st);

@@ -564,6 +564,37 @@ def test_fir_complex_decimating_on_the_double_pipeline(oracle, dev, ntaps, M, sc
         assert (f.last_algo == dev._lib.FIR_OLS_FFT) == (lo <= ntaps <= 4097), (ntaps, f.last_algo)
 
 
+@pytest.mark.parametrize("scalar_name", ["float64", "float32", "int16", "int8"])
+@pytest.mark.parametrize("M", [2, 3, 7, 16, 100])
+@pytest.mark.parametrize("ntaps", [2, 15, 16, 255, 2049, 4097])
+def test_fir_real_decimating_on_the_double_pipeline(oracle, dev, ntaps, M, scalar_name):
+    """REAL float64 / float32 / int16 / int8 streams with decimation M: two real blocks per double-precision transform at
+    full rate, one output in M stored.  Integers bit-exact, float64 1e-13, float32 1e-5; counts as the reference."""
+    scalar = {"float64": oracle.F64, "float32": oracle.F32, "int16": oracle.I16, "int8": oracle.I8}[scalar_name]
+    rng = np.random.default_rng(29 * ntaps + M)
+    taps = _taps(rng, ntaps, False) * 0.9
+    full = {"float64": 1, "float32": 1, "int16": 32768, "int8": 128}[scalar_name]
+    npdt = {"float64": np.float64, "float32": np.float32, "int16": np.int16, "int8": np.int8}[scalar_name]
+    floats = scalar in (oracle.F64, oracle.F32)
+    for n in (ntaps + M - 1, ntaps + 7 * M + 1, 3 * 4096 + 333 + ntaps):
+        x = (rng.standard_normal(n) if floats else rng.integers(-full, full, size=n)).astype(npdt)
+        ref_blk = oracle.Fir(scalar, False, False)
+        ref_blk.set_taps(taps); ref_blk.set_decimation(M); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n)
+        f = dev.FirFilter((scalar, False), "REAL")
+        f.set_taps(taps); f.set_decimation(M)
+        got, gc, gp = f.process(x, n)
+        assert (gc, gp) == (rc, rp), (ntaps, M, n)
+        if rp == 0:
+            continue
+        if floats:
+            scale = max(float(np.max(np.abs(ref))), 0.1 * float(np.sum(np.abs(taps))) * float(np.max(np.abs(x))))
+            assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= (1e-13 if scalar == oracle.F64 else TOL) * scale, (ntaps, M, n)
+        else:
+            assert np.array_equal(got, ref), (ntaps, M, n)
+        assert (f.last_algo == dev._lib.FIR_OLS_FFT) == (16 <= ntaps <= 4097), (ntaps, f.last_algo)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

@@ -456,6 +456,28 @@ int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, siz
     return PCX_OK;
 }
 
+// Interpolation by a factor the replicated-spectrum kernel does not take (L = 3, 5, 6 ...; decimation 1): every polyphase
+// row runs the undecimated kernel above into its own contiguous row of a workspace -- 2 KiB stores instead of the polyphase
+// kernel's stride-L 8-byte ones -- and this pass interleaves them: out[n L + j] = rows[j][n].
+__global__ __launch_bounds__(256) void interleave_rows_kernel(const float2 *__restrict__ rows, float2 *__restrict__ out, size_t n, unsigned L)
+{
+    const size_t total = n * L, gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gstride) {
+        const size_t ni = o / L;
+        const unsigned jr = (unsigned)(o - ni * L);
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2 *>(rows) + (size_t)jr * n + ni);
+        __builtin_nontemporal_store(t, reinterpret_cast<f2 *>(out) + o);
+    }
+}
+int launch_interleave_rows_cf32(const void *rows, void *out, size_t n, size_t L, hipStream_t st)
+{
+    if (n == 0) return PCX_OK;
+    hipLaunchKernelGGL(interleave_rows_kernel, dim3(stream_grid(n * L, 256)), dim3(256), 0, st, (const float2 *)rows, (float2 *)out, n, (unsigned)L);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 // --------------------------------------------------------------------------------- //
 // Fused Rotate -> FIR -> FreqDemod in the frequency domain (BASELINE configs[4]).
 //

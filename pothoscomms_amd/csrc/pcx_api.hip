@@ -231,6 +231,7 @@ struct pcx_fir {
     size_t Kp = 8;
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
+    DevBuf wsRows;            // interpolation by other factors: one contiguous output row per polyphase row, interleaved afterwards
     bool have_decim = false;  // L = 1, M in {2,4,8,16}: decimation folded into the spectrum (Hdecim)
     bool have_interp = false; // M = 1, L in {2,4,8,16}: replicated spectrum of the short forward transform (Hdecim holds H of all taps)
     DevBuf Hdecim;
@@ -613,6 +614,15 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         rc = launch_fir_cf32_ols4096_interp(in_dev, used_in, out_dev, N, h->Hdecim.p, h->K, h->L, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_decim) {
         rc = launch_fir_cf32_ols4096_decim(in_dev, used_in, out_dev, N, h->Hdecim.p, h->K, h->M, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_poly && h->M == 1 && h->K <= 2049 && !getenv("PCX_FIR_POLY_STRIDED")) {
+        // interpolation by other factors: each polyphase row through the undecimated kernel into a contiguous workspace row,
+        // then one interleaving pass (PCX_FIR_POLY_STRIDED (A/B) keeps the polyphase kernel's stride-L stores)
+        PCX_TRY(h->wsRows.ensure(N * h->L * 8));
+        rc = PCX_OK;
+        for (size_t jr = 0; jr < h->L && rc == PCX_OK; jr++)
+            rc = launch_fir_cf32_ols4096(in_dev, used_in, static_cast<char *>(h->wsRows.p) + jr * N * 8, N,
+                                         static_cast<const char *>(h->HspecRows.p) + jr * 2 * 4096 * sizeof(float), h->K, h->tw4096.p, st);
+        if (rc == PCX_OK) rc = launch_interleave_rows_cf32(h->wsRows.p, out_dev, N, h->L, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {

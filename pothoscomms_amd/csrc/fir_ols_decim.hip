@@ -30,8 +30,10 @@ template <int LOG2M>
 __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                         size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                         const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
-                                                                        size_t nblocks)
+                                                                        size_t nblocks, unsigned M2, unsigned magic2, size_t n_dec2)
 {
+    // M2 > 1: the decimation factor is M * M2 (M2 odd or any cofactor): the folded stream is decimated once more on the
+    // store -- sample g of it is kept when (g + 1) % M2 == 0 and lands at (g + 1) / M2 - 1 (n_dec2 of them in all)
     constexpr int M = 1 << LOG2M, P = 16 / M;       // P folded values per lane = frames of the 256-point stage
     constexpr int FRAME = 272;                       // 256 + 256/16: padded sub-frame
     constexpr int OIMG = 8 * FRAME;                  // output image behind the (at most 8) sub-frames
@@ -162,6 +164,23 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
         }
         __syncthreads();
         // decimated sample n' of the block is output b*Sd + n' - Kov/M; n' < Kov/M wraps past num_records and is dropped
+        if (M2 > 1) {
+            const size_t B0 = (b * Sd) / M2;
+            const unsigned base = (unsigned)(b * Sd - B0 * M2);
+            const size_t room = n_dec2 > B0 ? n_dec2 - B0 : 0;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + B0, (unsigned)((room < (size_t)2050 ? room : (size_t)2050) * 8));
+            const size_t left = n_out - b * Sd;               // samples of the folded stream this block may produce
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const int n = j + 256 * i, g = n - (Kov >> LOG2M);
+                const unsigned t = base + (unsigned)g + 1u;
+                const unsigned qt = __umulhi(t, magic2);
+                if (g >= 0 && (size_t)g < left && qt * M2 == t) {
+                    const cf y = lds[OIMG + n + (n >> 4)];
+                    store_cf<2>(ws, (qt - 1u) * 8u, cf{y.x, -y.y});
+                }
+            }
+        } else {
         const size_t room = n_out - b * Sd;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * Sd, (unsigned)((room < Sd ? room : Sd) * 8));
         const unsigned vbase = (unsigned)(j - (Kov >> LOG2M)) * 8u;
@@ -171,11 +190,13 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
             const cf y = lds[OIMG + n + (n >> 4)];
             store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, cf{y.x, -y.y});
         }
+        }
     }
 }
 
 template <int LOG2M>
-int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, hipStream_t st)
+int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, size_t M2,
+                 hipStream_t st)
 {
     constexpr size_t M = (size_t)1 << LOG2M;
     const size_t Km1 = K - 1;
@@ -188,8 +209,10 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     while (nfull > first_full && (nfull - 1) * S - pad + 4096 > in_elems) nfull--;
     if (nfull < first_full) nfull = first_full;
     const unsigned grid = persistent_grid(nblocks, 1024);
+    const unsigned magic2 = M2 > 1 ? (unsigned)(((1ull << 32) + M2 - 1) / M2) : 0u;
     hipLaunchKernelGGL(fir_cf32_ols4096_decim_kernel<LOG2M>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
-                       (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks);
+                       (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks, (unsigned)M2, magic2,
+                       n_out / M2);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -345,19 +368,24 @@ int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, con
 
 }  // namespace
 
-// n_iter full-rate iterations (a multiple of M) -> n_iter / M outputs.  Hspec = FFT_4096(h)[k] * exp(+j 2 pi k (M-1) / 4096) / 4096.
+// n_iter full-rate iterations (a multiple of M) -> n_iter / M outputs, M even: M = M1 * M2 with M1 the largest of 16 / 8 / 4 / 2
+// dividing it (folded into the spectrum) and M2 the cofactor (kept one in M2 on the store).
+// Hspec = FFT_4096(h)[k] * exp(+j 2 pi k (M1-1) / 4096) / 4096.
+size_t fir_decim_fold_factor(size_t M) { return M % 16 == 0 ? 16 : M % 8 == 0 ? 8 : M % 4 == 0 ? 4 : M % 2 == 0 ? 2 : 1; }
 int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
                                   const void *tw4096, hipStream_t st)
 {
     if (n_iter == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols (decimating): K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
-    switch (M) {
-    case 2: return launch_decim<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
-    case 4: return launch_decim<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
-    case 8: return launch_decim<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
-    case 16: return launch_decim<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    const size_t M1 = fir_decim_fold_factor(M), M2 = M / M1;
+    if (M2 > 65535) { set_error("fir ols (decimating): M=%zu too large", M); return PCX_ERR_UNSUPPORTED; }
+    switch (M1) {
+    case 2: return launch_decim<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
+    case 4: return launch_decim<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
+    case 8: return launch_decim<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
+    case 16: return launch_decim<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
     }
-    set_error("fir ols (decimating): M=%zu is not 2, 4, 8 or 16", M);
+    set_error("fir ols (decimating): M=%zu is odd", M);
     return PCX_ERR_UNSUPPORTED;
 }
 

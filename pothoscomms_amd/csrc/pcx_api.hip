@@ -468,13 +468,17 @@ static int fir_sync_tables(pcx_fir *h)
         h->have_poly = true;
     }
     h->have_decim = false;
-    if (h->have_poly && h->L == 1 && (h->M == 2 || h->M == 4 || h->M == 8 || h->M == 16) && !getenv("PCX_FIR_DECIM_FULLRATE")) {
+    // folding pays from 4-fold on (and for M = 2 itself); 2-fold plus a cofactor measured slower than the full-rate kernel
+    // (M = 10: 244 vs 281, M = 50: 251 vs 284 Gsamples/s in; M = 160 = 16 * 10: 373 vs 287)
+    if (h->have_poly && h->L == 1 && (h->M == 2 || fir_decim_fold_factor(h->M) >= 4) && h->M / fir_decim_fold_factor(h->M) <= 65535 &&
+        !getenv("PCX_FIR_DECIM_FULLRATE")) {
         // decimating filter: one forward transform, the spectrum folded M-fold, a 4096/M-point inverse (fir_ols_decim.hip).
         // PCX_FIR_DECIM_FULLRATE (A/B) keeps the full-rate evaluation of the polyphase kernel.
         std::vector<std::complex<double>> hq(h->K);
         for (size_t k = 0; k < h->K; k++)
             hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]), h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
-        PCX_TRY(upload(h->Hdecim, make_hspec(hq, 4096, h->M - 1)));
+        // even M = M1 * M2: M1 = 16 / 8 / 4 / 2 folded into the spectrum, the cofactor kept one in M2 on the store
+        PCX_TRY(upload(h->Hdecim, make_hspec(hq, 4096, fir_decim_fold_factor(h->M) - 1)));
         h->have_decim = true;
     }
     h->have_interp = false;

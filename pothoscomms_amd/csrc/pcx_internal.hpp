@@ -129,6 +129,7 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
                             const void *tw4096, hipStream_t st);
 int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
                                    const void *tw4096, hipStream_t st);
+size_t fir_decim_fold_factor(size_t M);
 int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
                                   const void *tw4096, hipStream_t st);
 int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,

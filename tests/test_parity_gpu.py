@@ -479,11 +479,11 @@ def test_fir_real_streams_on_the_double_pipeline(oracle, dev, ntaps, scalar_name
 
 
 @pytest.mark.parametrize("ctaps", [False, True])
-@pytest.mark.parametrize("M", [2, 4, 8, 16])
+@pytest.mark.parametrize("M", [2, 4, 8, 16, 6, 10, 12, 48, 50, 100, 160])
 @pytest.mark.parametrize("ntaps", [1, 2, 16, 17, 255, 1000, 2049])
 def test_fir_cf32_decimating_folded_spectrum(oracle, dev, ntaps, M, ctaps):
-    """complex_float32, interpolation 1, decimation 2 / 4 / 8 / 16: one forward transform, the spectrum folded M-fold and
-    a 4096/M-point inverse (fir_ols_decim.hip).  Same outputs and consume/produce counts as the reference's decimator
+    """complex_float32, interpolation 1, even decimation M = M1 * M2 (M1 = 16 / 8 / 4 / 2): one forward transform, the
+    spectrum folded M1-fold, a 4096/M1-point inverse, one output in M2 stored (fir_ols_decim.hip).  Same outputs and consume/produce counts as the reference's decimator
     (FIRFilter.cpp:286-302) over stream lengths with ragged first / last blocks, chunked calls included."""
     rng = np.random.default_rng(17 * ntaps + M + ctaps)
     taps = _taps(rng, ntaps, ctaps)
@@ -498,7 +498,11 @@ def test_fir_cf32_decimating_folded_spectrum(oracle, dev, ntaps, M, ctaps):
         assert (gc, gp) == (rc, rp), (ntaps, M, n)
         if rp:
             assert f.last_algo == dev._lib.FIR_OLS_FFT
-            assert nerr(got, ref) <= TOL, (ntaps, M, n)
+            # the frequency-domain error is relative to the block's scale, not to one (possibly cancelling) output: a stream
+            # that yields one or two outputs is normalised by at least a tenth of the typical output magnitude
+            typical = float(np.sqrt(np.sum(np.abs(taps) ** 2)) * np.sqrt(np.mean(x.astype(np.float64) ** 2) * 2))
+            scale = max(float(np.max(np.abs(ref))), 0.1 * typical)
+            assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= TOL * scale, (ntaps, M, n)
 
 
 @pytest.mark.parametrize("ctaps", [False, True])

@@ -19,7 +19,7 @@ for M in (2, 4, 8, 16):
         print("M=%2d K=%4d  consumed %d/%d produced %d/%d  err %.2e algo %d" % (M, K, c, rc, p, rp, err, f.last_algo), flush=True)
 # speed
 n = 64 * 1024 * 1024
-for M in (2, 4, 8, 16):
+for M in (2, 4, 8, 16, 10, 50, 160):
     K = 255
     h = tp.complex_bandpass(K, 0.05, 0.05)
     lead = (-(K - 1)) % 16

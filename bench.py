@@ -17,7 +17,7 @@ roofline: algorithmic bytes of the FIR kernel (16 B per sample: 8 read + 8 writt
 cpu_baseline: the oracle's single-thread restatement of FIRFilter.cpp:286-302 timed on this
           host on a bounded slice of the same stream (rank 0, N=1 only).
 
-Other workloads (--workload fft4096 | fmchain | rotate | direct255) print the same kind of line
+Other workloads (--workload fft4096 | fmchain | rotate | direct255 | decim8 | interp4 | fir255_i16) print the same kind of line
 for the secondary configs; the driver uses the default.
 """
 import argparse
@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "decim8", "interp4", "fir255_i16"])
     ap.add_argument("--shard", type=int, default=SHARD, help="samples per GPU (default 64 Mi)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     return ap.parse_args()
@@ -198,6 +198,47 @@ def main():
         if world > 1:
             desc["parallelism"] = "overlap-save shards x%d, RCCL send/recv halo of 127 samples" % world
         metric = "Msamples/s fused FM-demod chain"
+    elif wl in ("decim8", "interp4"):
+        # resampling complex_float32 FIR, 255 taps (per polyphase row when interpolating); independent replicas per rank
+        n = C if wl == "decim8" else C // 4
+        M, L = (8, 1) if wl == "decim8" else (1, 4)
+        h = tp.complex_bandpass(255 * L, 0.05 / max(L, M), 0.05 / max(L, M)) * L
+        f = device.FirFilter("complex_float32", "COMPLEX")
+        f.set_taps(h); f.set_decimation(M); f.set_interpolation(L)
+        K = f.K
+        lead = (-(K - 1)) % 16
+        xa = torch.empty((lead + n + K - 1, 2), dtype=torch.float32, device=dev)
+        x = xa[lead:]
+        y = torch.empty((n * L // M + 8, 2), dtype=torch.float32, device=dev)
+        device.fill_uniform_f32_dev(x, seed=7, offset=0)
+        units = n if wl == "decim8" else n * L            # decimator: input samples; interpolator: output samples
+        roof_bytes = 8.0 * n + 8.0 * (n * L // M)
+        kernel_name = "fir_cf32_ols4096_decim_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_kernel"
+
+        def step():
+            f.process_dev(x, y)
+        desc = {"workload": "255-tap complex_float32 FIR, %s, %d input samples per GPU" %
+                            ("decimation 8 folded into the spectrum (input rate)" if wl == "decim8"
+                             else "interpolation 4 from the replicated spectrum, 255 taps per phase (output rate)", n),
+                "decimation": M, "interpolation": L}
+        metric = "Msamples/s complex_float32 %s FIR" % ("decimating (in)" if wl == "decim8" else "interpolating (out)")
+    elif wl == "fir255_i16":
+        # complex_int16 255-tap FIR: bit-exact on the double-precision overlap-save pipeline
+        n = C
+        h = tp.c1_taps() * 0.9
+        f = device.FirFilter("complex_int16", "COMPLEX")
+        f.set_taps(h)
+        K = f.K
+        x = torch.randint(-20000, 20000, (n + K - 1, 2), device=dev).to(torch.int16)
+        y = torch.empty((n, 2), dtype=torch.int16, device=dev)
+        units = n
+        roof_bytes = 8.0 * n
+        kernel_name = "fir_cf64_ols_kernel"
+
+        def step():
+            f.process_dev(x, y)
+        desc = {"workload": "255-tap complex_int16 FIR (bit-exact, double-precision overlap-save), %d samples per GPU" % n, "taps": 255}
+        metric = "Msamples/s complex_int16 255-tap FIR"
     else:
         n = C
         x = torch.empty((n, 2), dtype=torch.float32, device=dev)
@@ -249,7 +290,7 @@ def main():
         out = {
             "metric": metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if wl == "fir255_i16" else "f32",
             "data": "synthetic", "config": desc,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(wl),

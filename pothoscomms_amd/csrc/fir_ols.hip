@@ -459,35 +459,38 @@ int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, siz
 // Interpolation by a factor the replicated-spectrum kernel does not take (L = 3, 5, 6 ...; decimation 1): every polyphase
 // row runs the undecimated kernel above into its own contiguous row of a workspace -- 2 KiB stores instead of the polyphase
 // kernel's stride-L 8-byte ones -- and this pass interleaves them: out[n L + j] = rows[j][n].
+// M > 1 (rational resampling): output t is position o = t M + M - 1 of the interleaved stream -- the one the reference's
+// decimator keeps (FIRFilter.cpp:291)
 template <typename E>
-__global__ __launch_bounds__(256) void interleave_rows_kernel(const E *__restrict__ rows, E *__restrict__ out, size_t n, unsigned L)
+__global__ __launch_bounds__(256) void interleave_rows_kernel(const E *__restrict__ rows, E *__restrict__ out, size_t n, unsigned L, unsigned M)
 {
-    const size_t total = n * L, gstride = (size_t)gridDim.x * blockDim.x;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gstride) {
+    const size_t total = n * L / M, gstride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gstride) {
+        const size_t o = t * M + (M - 1);
         const size_t ni = o / L;
         const unsigned jr = (unsigned)(o - ni * L);
-        const E t = __builtin_nontemporal_load(rows + (size_t)jr * n + ni);
-        __builtin_nontemporal_store(t, out + o);
+        const E v = __builtin_nontemporal_load(rows + (size_t)jr * n + ni);
+        __builtin_nontemporal_store(v, out + t);
     }
 }
 // elem_bytes: 8 (complex_float32), 16 (complex_float64), 4 (complex_int16), 2 (complex_int8)
-int launch_interleave_rows(const void *rows, void *out, size_t n, size_t L, size_t elem_bytes, hipStream_t st)
+int launch_interleave_rows(const void *rows, void *out, size_t n, size_t L, size_t elem_bytes, size_t M, hipStream_t st)
 {
     if (n == 0) return PCX_OK;
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef double d2 __attribute__((ext_vector_type(2)));
-    const dim3 grid(stream_grid(n * L, 256)), block(256);
+    const dim3 grid(stream_grid(n * L / M, 256)), block(256);
     switch (elem_bytes) {
-    case 8: hipLaunchKernelGGL(interleave_rows_kernel<f2>, grid, block, 0, st, (const f2 *)rows, (f2 *)out, n, (unsigned)L); break;
-    case 16: hipLaunchKernelGGL(interleave_rows_kernel<d2>, grid, block, 0, st, (const d2 *)rows, (d2 *)out, n, (unsigned)L); break;
-    case 4: hipLaunchKernelGGL(interleave_rows_kernel<unsigned>, grid, block, 0, st, (const unsigned *)rows, (unsigned *)out, n, (unsigned)L); break;
-    case 2: hipLaunchKernelGGL(interleave_rows_kernel<unsigned short>, grid, block, 0, st, (const unsigned short *)rows, (unsigned short *)out, n, (unsigned)L); break;
+    case 8: hipLaunchKernelGGL(interleave_rows_kernel<f2>, grid, block, 0, st, (const f2 *)rows, (f2 *)out, n, (unsigned)L, (unsigned)M); break;
+    case 16: hipLaunchKernelGGL(interleave_rows_kernel<d2>, grid, block, 0, st, (const d2 *)rows, (d2 *)out, n, (unsigned)L, (unsigned)M); break;
+    case 4: hipLaunchKernelGGL(interleave_rows_kernel<unsigned>, grid, block, 0, st, (const unsigned *)rows, (unsigned *)out, n, (unsigned)L, (unsigned)M); break;
+    case 2: hipLaunchKernelGGL(interleave_rows_kernel<unsigned short>, grid, block, 0, st, (const unsigned short *)rows, (unsigned short *)out, n, (unsigned)L, (unsigned)M); break;
     default: set_error("interleave: element size %zu", elem_bytes); return PCX_ERR_ARG;
     }
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
-int launch_interleave_rows_cf32(const void *rows, void *out, size_t n, size_t L, hipStream_t st) { return launch_interleave_rows(rows, out, n, L, 8, st); }
+int launch_interleave_rows_cf32(const void *rows, void *out, size_t n, size_t L, hipStream_t st) { return launch_interleave_rows(rows, out, n, L, 8, 1, st); }
 
 // --------------------------------------------------------------------------------- //
 // Fused Rotate -> FIR -> FreqDemod in the frequency domain (BASELINE configs[4]).

@@ -423,8 +423,8 @@ static int fir_sync_tables(pcx_fir *h)
         }
     }
     h->have_interp64 = false;
-    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && h->cplx && h->M == 1 && h->L > 1 && h->L <= 64 && h->K >= 2 &&
-        h->K <= 2049) {
+    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && h->cplx && h->M <= 65535 && h->L > 1 && h->L <= 64 && h->K >= 2 &&
+        h->K <= 2049) {   // M > 1: rational resampling, the interleaving pass keeps one position in M
         // interpolating filters of these types: every polyphase row h_j[k] = taps[j + k L] (FIRFilter.cpp:341-350) through the
         // double-precision pipeline into a contiguous workspace row, then one interleaving pass; integers stay exact row by row
         const int qb = q_bits(h->scalar);
@@ -650,7 +650,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
             rc = launch_fir_cf64_ols(in_dev, used_in, static_cast<char *>(h->wsRows.p) + jr * N * eb, N,
                                      static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12, h->tw4096.p,
                                      h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, 1, st);
-        if (rc == PCX_OK) rc = launch_interleave_rows(h->wsRows.p, out_dev, N, h->L, eb, st);
+        if (rc == PCX_OK) rc = launch_interleave_rows(h->wsRows.p, out_dev, N, h->L, eb, h->M, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_ols_real64) {
         rc = launch_fir_real_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, h->M, st);

@@ -145,7 +145,7 @@ int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_
 // same pipeline with interpolation L / decimation M: one launch per polyphase row;
 // Hspec_rows: L spectra of 4096 cf32 (row j = FFT(taps[j + k*L]) / 4096); n_iter = inputs consumed
 int launch_interleave_rows_cf32(const void *rows, void *out, size_t n, size_t L, hipStream_t st);
-int launch_interleave_rows(const void *rows, void *out, size_t n, size_t L, size_t elem_bytes, hipStream_t st);
+int launch_interleave_rows(const void *rows, void *out, size_t n, size_t L, size_t elem_bytes, size_t M, hipStream_t st);
 int launch_fir_cf32_ols4096_poly(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec_rows, size_t K,
                                  size_t L, size_t M, const void *tw4096, hipStream_t st);
 

@@ -601,10 +601,12 @@ def test_fir_real_decimating_on_the_double_pipeline(oracle, dev, ntaps, M, scala
 
 @pytest.mark.parametrize("scalar_name", ["float64", "int16", "int8"])
 @pytest.mark.parametrize("L", [2, 3, 5, 8])
+@pytest.mark.parametrize("M", [1, 2, 3, 7])
 @pytest.mark.parametrize("ntaps", [7, 40, 161, 1000, 4000])
-def test_fir_complex_interpolating_on_the_double_pipeline(oracle, dev, ntaps, L, scalar_name):
-    """complex_float64 / complex_int16 / complex_int8 with interpolation L: every polyphase row through the double-precision
-    overlap-save pipeline into a contiguous row, then the interleaving pass.  Integers bit-exact, float64 1e-13."""
+def test_fir_complex_interpolating_on_the_double_pipeline(oracle, dev, ntaps, L, M, scalar_name):
+    """complex_float64 / complex_int16 / complex_int8 with interpolation L (and decimation M: rational resampling): every
+    polyphase row through the double-precision overlap-save pipeline into a contiguous row, then the interleaving pass,
+    which keeps one position in M.  Integers bit-exact, float64 1e-13; counts as the reference."""
     scalar = {"float64": oracle.F64, "int16": oracle.I16, "int8": oracle.I8}[scalar_name]
     rng = np.random.default_rng(31 * ntaps + L)
     taps = _taps(rng, ntaps, True) * 0.9
@@ -614,19 +616,20 @@ def test_fir_complex_interpolating_on_the_double_pipeline(oracle, dev, ntaps, L,
     for n in (K, K + 3, 2 * 4096 + 99 + K):
         x = (rng.standard_normal((n, 2)) if scalar == oracle.F64 else rng.integers(-full, full, size=(n, 2))).astype(npdt)
         ref_blk = oracle.Fir(scalar, True, True)
-        ref_blk.set_taps(taps); ref_blk.set_interpolation(L); ref_blk.activate()
+        ref_blk.set_taps(taps); ref_blk.set_interpolation(L); ref_blk.set_decimation(M); ref_blk.activate()
         ref, rc, rp, _ = ref_blk.work(x, n * L)
         f = dev.FirFilter((scalar, True), "COMPLEX")
-        f.set_taps(taps); f.set_interpolation(L)
+        f.set_taps(taps); f.set_interpolation(L); f.set_decimation(M)
         got, gc, gp = f.process(x, n * L)
-        assert (gc, gp) == (rc, rp), (ntaps, L, n)
+        assert (gc, gp) == (rc, rp), (ntaps, L, M, n)
         if rp == 0:
             continue
         if scalar == oracle.F64:
-            assert nerr(got, ref) <= 1e-13, (ntaps, L, n)
+            scale = max(float(np.max(np.abs(ref))), 0.1 * float(np.sqrt(np.sum(np.abs(taps) ** 2))))
+            assert float(np.max(np.abs(got - ref))) <= 1e-13 * scale, (ntaps, L, M, n)
         else:
-            assert np.array_equal(got, ref), (ntaps, L, n)
-        assert (f.last_algo == dev._lib.FIR_OLS_FFT) == (16 <= K <= 2049), (ntaps, L, f.last_algo)
+            assert np.array_equal(got, ref), (ntaps, L, M, n)
+        assert (f.last_algo == dev._lib.FIR_OLS_FFT) == (16 <= K <= 2049), (ntaps, L, M, f.last_algo)
 
 
 # --------------------------------------------------------------------------- #

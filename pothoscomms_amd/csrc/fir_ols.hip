@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void interleave_rows_kernel(const E *__restric
         __builtin_nontemporal_store(v, out + t);
     }
 }
-// elem_bytes: 8 (complex_float32), 16 (complex_float64), 4 (complex_int16), 2 (complex_int8)
+// elem_bytes: 16 (complex_float64), 8 (complex_float32, float64), 4 (complex_int16, float32), 2 (complex_int8, int16), 1 (int8)
 int launch_interleave_rows(const void *rows, void *out, size_t n, size_t L, size_t elem_bytes, size_t M, hipStream_t st)
 {
     if (n == 0) return PCX_OK;
@@ -484,6 +484,7 @@ int launch_interleave_rows(const void *rows, void *out, size_t n, size_t L, size
     case 8: hipLaunchKernelGGL(interleave_rows_kernel<f2>, grid, block, 0, st, (const f2 *)rows, (f2 *)out, n, (unsigned)L, (unsigned)M); break;
     case 16: hipLaunchKernelGGL(interleave_rows_kernel<d2>, grid, block, 0, st, (const d2 *)rows, (d2 *)out, n, (unsigned)L, (unsigned)M); break;
     case 4: hipLaunchKernelGGL(interleave_rows_kernel<unsigned>, grid, block, 0, st, (const unsigned *)rows, (unsigned *)out, n, (unsigned)L, (unsigned)M); break;
+    case 1: hipLaunchKernelGGL(interleave_rows_kernel<unsigned char>, grid, block, 0, st, (const unsigned char *)rows, (unsigned char *)out, n, (unsigned)L, (unsigned)M); break;
     case 2: hipLaunchKernelGGL(interleave_rows_kernel<unsigned short>, grid, block, 0, st, (const unsigned short *)rows, (unsigned short *)out, n, (unsigned)L, (unsigned)M); break;
     default: set_error("interleave: element size %zu", elem_bytes); return PCX_ERR_ARG;
     }

@@ -240,6 +240,7 @@ struct pcx_fir {
     bool have_ols_int = false;    // complex_int16 / complex_int8 stream, M=L=1: exact integer convolution on the double transform
     bool have_ols_real64 = false; // REAL float64 / int16 / int8 stream (real taps), M=L=1: two real blocks per double transform
     bool have_interp64 = false;   // complex_float64 / int16 / int8, M = 1, L > 1: polyphase rows on the double pipeline (HrowsD) + interleave
+    bool have_interp_real = false; // REAL float64 / float32 / int16 / int8, L > 1: the same with the two-real-blocks kernel
     DevBuf HrowsD;
     DevBuf HspecRows;
     int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
@@ -454,6 +455,38 @@ static int fir_sync_tables(pcx_fir *h)
             h->have_interp64 = true;
         }
     }
+    h->have_interp_real = false;
+    if ((h->scalar == PCX_F64 || h->scalar == PCX_F32 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M <= 65535 && h->L > 1 &&
+        h->L <= 64 && h->K >= 2 && h->K <= 2049) {
+        const int qb = q_bits(h->scalar);
+        auto tq = [&](double t) {
+            return h->scalar == PCX_F64 ? t : h->scalar == PCX_F32 ? (double)(float)t
+                 : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb);
+        };
+        const bool integer = h->scalar == PCX_I16 || h->scalar == PCX_I8;
+        std::vector<double> rows(h->L * 2 * 4096);
+        bool ok = true;
+        for (size_t jr = 0; jr < h->L && ok; jr++) {
+            std::vector<std::complex<double>> hq;
+            double norm2 = 0;
+            for (size_t k = 0; k < h->K; k++) {
+                const size_t i = jr + k * h->L;
+                if (i >= h->ntaps) continue;
+                hq.push_back(std::complex<double>(tq(h->taps[i]), 0.0));
+                norm2 += std::norm(hq.back());
+            }
+            if (integer && norm2 >= 17592186044416.0) ok = false;
+            if (hq.empty()) hq.push_back(0.0);
+            const std::vector<double> H = make_hspec<double>(hq, 4096);
+            std::copy(H.begin(), H.end(), rows.begin() + jr * 2 * 4096);
+        }
+        if (ok) {
+            PCX_TRY(upload(h->HrowsD, rows));
+            PCX_TRY(upload(h->tw4096, make_tw_r16<double>(12)));
+            h->ols_log2n = 12;
+            h->have_interp_real = true;
+        }
+    }
     h->have_ols_real64 = false;
     // (real float32 joins for decimating filters only: its undecimated stream has the float kernel below)
     if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8 || (h->scalar == PCX_F32 && h->M > 1)) && !h->cplx && h->M <= 65535 &&
@@ -628,21 +661,30 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
                  (h->have_ols64 && h->K >= (h->M > 1 ? 16 : kOls64MinTaps)) ||
                  (h->have_ols_int && h->K >= (h->M > 1 ? 32 : ols_int_min_taps(h->scalar))) ||
                  (h->have_ols_real64 && h->K >= (h->M > 1 ? 16 : ols_real64_min_taps(h->scalar))) ||
-                 (h->have_interp64 && h->K >= 16)) algo = PCX_FIR_OLS_FFT;
+                 ((h->have_interp64 || h->have_interp_real) && h->K >= 16)) algo = PCX_FIR_OLS_FFT;
         // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
         // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
     if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64 || h->have_ols_int || h->have_ols_real64 ||
-                                     h->have_interp64)) {
+                                     h->have_interp64 || h->have_interp_real)) {
         set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
-    if (algo == PCX_FIR_OLS_FFT && h->have_interp64) {
+    if (algo == PCX_FIR_OLS_FFT && h->have_interp_real) {
+        const size_t eb = fir_elem_bytes(h);
+        PCX_TRY(h->wsRows.ensure(N * h->L * eb));
+        rc = PCX_OK;
+        for (size_t jr = 0; jr < h->L && rc == PCX_OK; jr++)
+            rc = launch_fir_real_ols(in_dev, used_in, static_cast<char *>(h->wsRows.p) + jr * N * eb, N,
+                                     static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12, h->tw4096.p,
+                                     h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, 1, st);
+        if (rc == PCX_OK) rc = launch_interleave_rows(h->wsRows.p, out_dev, N, h->L, eb, h->M, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_interp64) {
         const size_t eb = fir_elem_bytes(h);
         PCX_TRY(h->wsRows.ensure(N * h->L * eb));
         rc = PCX_OK;

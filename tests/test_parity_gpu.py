@@ -632,6 +632,38 @@ def test_fir_complex_interpolating_on_the_double_pipeline(oracle, dev, ntaps, L,
         assert (f.last_algo == dev._lib.FIR_OLS_FFT) == (16 <= K <= 2049), (ntaps, L, M, f.last_algo)
 
 
+@pytest.mark.parametrize("scalar_name", ["float64", "float32", "int16", "int8"])
+@pytest.mark.parametrize("L,M", [(2, 1), (3, 1), (8, 1), (3, 2), (5, 7)])
+@pytest.mark.parametrize("ntaps", [7, 48, 161, 1000, 4000])
+def test_fir_real_interpolating_on_the_double_pipeline(oracle, dev, ntaps, L, M, scalar_name):
+    """REAL float64 / float32 / int16 / int8 streams with interpolation L (and decimation M): polyphase rows on the
+    two-real-blocks-per-transform kernel, contiguous rows, interleaving pass.  Integers bit-exact, floats 1e-13 / 1e-5."""
+    scalar = {"float64": oracle.F64, "float32": oracle.F32, "int16": oracle.I16, "int8": oracle.I8}[scalar_name]
+    rng = np.random.default_rng(37 * ntaps + L + M)
+    taps = _taps(rng, ntaps, False) * 0.9
+    full = {"float64": 1, "float32": 1, "int16": 32768, "int8": 128}[scalar_name]
+    npdt = {"float64": np.float64, "float32": np.float32, "int16": np.int16, "int8": np.int8}[scalar_name]
+    floats = scalar in (oracle.F64, oracle.F32)
+    K = -(-ntaps // L)
+    for n in (K + M - 1, K + 3 * M, 2 * 4096 + 99 + K):
+        x = (rng.standard_normal(n) if floats else rng.integers(-full, full, size=n)).astype(npdt)
+        ref_blk = oracle.Fir(scalar, False, False)
+        ref_blk.set_taps(taps); ref_blk.set_interpolation(L); ref_blk.set_decimation(M); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n * L)
+        f = dev.FirFilter((scalar, False), "REAL")
+        f.set_taps(taps); f.set_interpolation(L); f.set_decimation(M)
+        got, gc, gp = f.process(x, n * L)
+        assert (gc, gp) == (rc, rp), (ntaps, L, M, n)
+        if rp == 0:
+            continue
+        if floats:
+            scale = max(float(np.max(np.abs(ref))), 0.1 * float(np.sqrt(np.sum(taps ** 2))))
+            assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= (1e-13 if scalar == oracle.F64 else TOL) * scale, (ntaps, L, M, n)
+        else:
+            assert np.array_equal(got, ref), (ntaps, L, M, n)
+        assert (f.last_algo == dev._lib.FIR_OLS_FFT) == (16 <= K <= 2049), (ntaps, L, M, f.last_algo)
+
+
 # --------------------------------------------------------------------------- #
 # FFT sizes that are not powers of two: kissfft's mixed-radix plan on the device
 # --------------------------------------------------------------------------- #

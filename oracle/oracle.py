@@ -141,7 +141,10 @@ class Fir:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_fir_destroy(self.h)
+            try:
+                lib().orc_fir_destroy(self.h)
+            except TypeError:     # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
     def set_taps(self, taps):

@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- the headline benchmark of BASELINE.json, measured on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1: plain python)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Launched plainly with N > 1 (no WORLD_SIZE in the environment) this process does NOT touch the GPU: it
+starts N rank processes through `python -m torch.distributed.run` (one per GPU, rendezvous on 127.0.0.1),
+relays rank 0's JSON line and fails if a rank fails or the line does not carry n_gpus == N.  Every line
+reports the world size torch.distributed actually formed (`n_gpus`, `config.world_size_observed`) and the
+device each rank bound (`config.rank_devices`); a rank refuses to run when WORLD_SIZE != --gpus or when the
+node has fewer GPUs than ranks (RCCL backend).
 
 metric  : Msamples/s of the 255-tap complex_float32 FIR (BASELINE.json configs[1]: a 64 Mi-sample
           stream per GPU; at N GPUs the stream is N x 64 Mi samples, overlap-save sharded with the
@@ -14,8 +21,9 @@ roofline: algorithmic bytes of the FIR kernel (16 B per sample: 8 read + 8 writt
           / its average launch duration from HIP events on the launch stream, against the
           8 TB/s HBM3E peak (MI355X_MICROARCH.md); `traffic` is the PMC-measured HBM bytes per
           launch from profiles/ when a matching measurement is committed.
-cpu_baseline: the oracle's single-thread restatement of FIRFilter.cpp:286-302 timed on this
-          host on a bounded slice of the same stream (rank 0, N=1 only).
+cpu_baseline: the oracle (-O3 restatement, kind "port") or oracle/_ref (the reference's own kissfft, kind
+          "reference") timed on this host on a bounded sample of the same workload, median of 3
+          (rank 0, N=1 only); the FIR line also carries the C0 case (63 taps, 1 Mi samples).
 
 Other workloads (--workload fft4096 | fmchain | rotate | direct255 | decim8 | interp4 | fir255_i16) print the same kind of line
 for the secondary configs; the driver uses the default.
@@ -46,46 +54,192 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_fir(taps, seed, nsamples):
-    """Single-thread oracle FIR (reference accumulation order) on `nsamples` of the stream."""
+def _median_time(fn, reps=3):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def _host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_fir(taps, seed, nsamples, real_taps=False):
+    """Single-thread oracle FIR (reference accumulation order) on `nsamples` of the stream, median of 3;
+    beside it the same loop on all host cores, the stream statically chunked with K-1 overlap."""
+    import threading
+
     import numpy as np
 
     from oracle import oracle as o      # CPU baseline leg: the checker, timed as the baseline
     K = len(taps)
     x = o.fill_uniform_f32(2 * (nsamples + K - 1), seed, 0).reshape(-1, 2)
-    blk = o.Fir(o.F32, True, True)
+    blk = o.Fir(o.F32, True, not real_taps)
     blk.set_taps(taps)
     blk.activate()
-    t0 = time.perf_counter()
-    _, c, p, _ = blk.work(x, nsamples)
-    dt = time.perf_counter() - t0
-    assert p == nsamples
-    # all host cores: static chunking with K-1 overlap (not reference behaviour, reported beside)
-    import threading
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 64))        # bounded: the leg must stay within a few tens of seconds
-    per = nsamples // 8
-    outs = [np.zeros((per, 2), np.float32) for _ in range(ncores)]
+
+    def one():
+        _, c, p, _ = blk.work(x, nsamples)
+        assert p == nsamples
+    dt = _median_time(one)
+    # all host cores: thread i filters samples [i*per, (i+1)*per) of the SAME slice (its K-1 history is the
+    # tail of chunk i-1: static chunking with overlap) -- a parallelised restatement, not reference behaviour
+    ncores = _host_cores()
+    per = nsamples // ncores
+    y = np.zeros((ncores * per, 2), np.float32)
     L = o.lib()
 
     def work(i):
-        L.orc_fir_cf32_chunk(blk.h, x.ctypes.data, outs[i].ctypes.data, per)
+        L.orc_fir_cf32_chunk(blk.h, x[i * per:].ctypes.data, y[i * per:].ctypes.data, per)
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(ncores)]
-    t1 = time.perf_counter()
-    [t.start() for t in th]
-    [t.join() for t in th]
-    dt_all = time.perf_counter() - t1
-    return {
+    def all_cores():
+        th = [threading.Thread(target=work, args=(i,)) for i in range(ncores)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    dt_all = _median_time(all_cores) if not real_taps else None
+    out = {
         "value": round(nsamples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
         "sample": "%d-sample slice of the same stream, %d taps, oracle/pcx_oracle.c fir_loop_f32 (reference "
-                  "accumulation order, -O2, no FMA), single thread" % (nsamples, K),
-        "all_cores": {"value": round(ncores * per / dt_all / 1e6, 3), "cores": ncores,
-                      "note": "same loop on every host core, %d samples each (parallelised restatement, not reference behaviour)" % per},
+                  "accumulation order, -O3, no FMA, taps pre-narrowed to float), single thread, median of 3" % (nsamples, K),
     }
+    if dt_all:
+        out["all_cores"] = {"value": round(ncores * per / dt_all / 1e6, 3), "cores": ncores,
+                            "note": "the same slice statically chunked over every host core with K-1 overlap, %d samples each, "
+                                    "median of 3 (parallelised restatement, not reference behaviour)" % per}
+    return out
+
+
+def cpu_baseline_c0():
+    """BASELINE.json configs[0]: 63 complex taps, 1 Mi-sample BufferChunk, one scheduler thread."""
+    from pothoscomms_amd import taps as tp
+    r = cpu_baseline_fir(tp.c0_taps(), 1, 1 << 20)
+    r.pop("all_cores", None)
+    r["sample"] = "configs[0]: 63 taps, 1048576 samples, " + r["sample"].split(", ", 2)[2]
+    return r
+
+
+def cpu_baseline_fft(nframes):
+    """4096-point forward transforms: the reference's kissfft<float> compiled from its own source
+    (oracle/_ref) when present, else the oracle's restatement of it."""
+    from oracle import oracle as o
+    x = o.fill_uniform_f32(2 * nframes * 4096, 3, 0).reshape(-1, 2)
+    have_ref = o.ref() is not None
+    fn = (lambda: o.ref_fft(x, 4096, False)) if have_ref else (lambda: o.fft(x, 4096, False))
+    dt = _median_time(fn)
+    return {"value": round(nframes * 4096 / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+            "kind": "reference" if have_ref else "port",
+            "sample": "%d frames of 4096 bins of the same stream, %s, single thread, median of 3 (%.0f frames/s)"
+                      % (nframes, "fft/kissfft.hh compiled as oracle/_ref (-O3)" if have_ref else "oracle/pcx_oracle.c kissfft restatement (-O3)",
+                         nframes / dt)}
+
+
+def cpu_baseline_fmchain(n):
+    """Rotate -> FIR(127 real taps) -> FreqDemod as three oracle blocks on n samples of the C4 stream."""
+    from oracle import oracle as o
+    from pothoscomms_amd import taps as tp
+    h = tp.c4_taps()
+    K = len(h)
+    x = o.fill_uniform_f32(2 * (n + K - 1), 5, 0).reshape(-1, 2)
+    fir = o.Fir(o.F32, True, False)
+    fir.set_taps(h)
+    fir.activate()
+
+    def chain():
+        r = o.rotate(x, tp.C4_PHASE)
+        y, c, p, _ = fir.work(r, n)
+        dm = o.FreqDemod(o.F32)
+        d = dm.work(y)
+        assert d.shape[0] == n
+    dt = _median_time(chain)
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d samples of the same stream through the oracle's rotate, FIR (127 real taps) and freq_demod loops "
+                      "(-O3), one after the other on one thread, median of 3" % n}
+
+
+def cpu_baseline_rotate(n):
+    from oracle import oracle as o
+    x = o.fill_uniform_f32(2 * n, 6, 0).reshape(-1, 2)
+    dt = _median_time(lambda: o.rotate(x, 0.7))
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d samples, oracle arrayRotate loop (-O3), single thread, median of 3" % n}
+
+
+def cpu_baseline_resampler(h, M, L, n):
+    from oracle import oracle as o
+    blk = o.Fir(o.F32, True, True)
+    blk.set_taps(h); blk.set_decimation(M); blk.set_interpolation(L)
+    blk.activate()
+    K = blk.K
+    x = o.fill_uniform_f32(2 * (n + K - 1), 7, 0).reshape(-1, 2)
+
+    def one():
+        _, c, p, _ = blk.work(x, n * L // M)
+        assert c == n, (c, n)
+    dt = _median_time(one)
+    units = n if L == 1 else n * L
+    return {"value": round(units / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d input samples, decimation %d, interpolation %d, oracle polyphase loop (-O3), single thread, median of 3" % (n, M, L)}
+
+
+def cpu_baseline_fir_i16(h, n):
+    import numpy as np
+
+    from oracle import oracle as o
+    blk = o.Fir(o.I16, True, True)
+    blk.set_taps(h)
+    blk.activate()
+    K = blk.K
+    rng = np.random.default_rng(11)
+    x = rng.integers(-20000, 20000, (n + K - 1, 2)).astype(np.int16)
+
+    def one():
+        _, c, p, _ = blk.work(x, n)
+        assert p == n
+    dt = _median_time(one)
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d complex_int16 samples, 255 taps, oracle integer loop (-O3; Q-format as restated, DESIGN.md 2), single thread, median of 3" % n}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves.
+
+    This parent never imports torch and never touches the GPU; the children are fresh interpreters
+    started by torch.distributed.run.  Their stdout is captured so the one JSON line can be checked
+    (n_gpus must equal --gpus) before it is relayed; stderr passes through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        raise SystemExit("bench.py: a rank failed (torch.distributed.run exit code %d)" % proc.returncode)
+    if line is None:
+        raise SystemExit("bench.py: the ranks printed no result line")
+    got = json.loads(line)
+    if got.get("n_gpus") != args.gpus:
+        raise SystemExit("bench.py: asked for %d GPUs, the ranks report n_gpus=%r" % (args.gpus, got.get("n_gpus")))
+    print(line, flush=True)
 
 
 def load_traffic(workload):
@@ -104,11 +258,15 @@ def load_traffic(workload):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)      # before torch is imported or the GPU touched
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to measure a different job than the one asked for" % (args.gpus, world))
 
     import numpy as np
     import torch
@@ -119,17 +277,26 @@ def main():
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     ndev = torch.cuda.device_count()
+    # "nccl" is RCCL on ROCm.  PCX_BENCH_BACKEND=gloo exists only to rehearse the multi-rank control
+    # flow on a single-GPU box (ranks then share cuda:0 and the halo goes through gloo); the line says so.
+    backend = os.environ.get("PCX_BENCH_BACKEND", "nccl") if world > 1 else "none"
+    if backend == "nccl" and ndev < world:
+        raise SystemExit("--gpus %d needs %d GPUs on this node, %d visible" % (args.gpus, world, ndev))
     dev_index = local_rank % ndev          # one rank per GPU on the node the driver gives us
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rank_devices = [dev_index]
     if world > 1:
-        # "nccl" is RCCL on ROCm.  PCX_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
-        # control flow on a single-GPU box (ranks then share cuda:0 and the halo goes through gloo).
-        backend = os.environ.get("PCX_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, dev_index, torch.cuda.get_device_properties(dev).name))
+        rank_devices = [g[1] for g in sorted(gathered)]
+        world = dist.get_world_size()      # what the line reports is what the collective layer formed
 
     C = args.shard
     wl = args.workload
@@ -287,6 +454,10 @@ def main():
         value = world * units * args.steps / elapsed / 1e6
         avg_ms = float(np.mean(kern_ms))
         achieved = roof_bytes / (avg_ms * 1e-3) / 1e9
+        desc["world_size_observed"] = world
+        desc["rank_devices"] = rank_devices
+        if world > 1:
+            desc["halo_backend"] = "rccl" if backend == "nccl" else backend + " (rehearsal: ranks may share a GPU)"
         out = {
             "metric": metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -298,10 +469,24 @@ def main():
                          "algorithmic_bytes_per_launch": roof_bytes,
                          "bytes_counted": "algorithmic read + write (SURVEY 8d); the read stream alone is the smaller share"},
         }
-        if world == 1 and not args.no_cpu and wl in ("fir255", "direct255"):
-            out["cpu_baseline"] = cpu_baseline_fir(tp.c1_taps(), 2, min(C, 64 * 1024 * 1024))   # the whole 64 Mi-sample shard: ~11 s on one core
-        elif world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = None
+        if world == 1 and not args.no_cpu:
+            cpu_n = min(C, 16 * 1024 * 1024)          # bounded sample: 10-30 s of CPU work for the whole leg
+            if wl in ("fir255", "direct255"):
+                cb = cpu_baseline_fir(tp.c1_taps(), 2, cpu_n)
+                cb["c0"] = cpu_baseline_c0()
+            elif wl == "fft4096":
+                cb = cpu_baseline_fft(4096)
+            elif wl == "fmchain":
+                cb = cpu_baseline_fmchain(cpu_n)
+            elif wl == "rotate":
+                cb = cpu_baseline_rotate(cpu_n)
+            elif wl == "decim8":
+                cb = cpu_baseline_resampler(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8), 8, 1, cpu_n)
+            elif wl == "interp4":
+                cb = cpu_baseline_resampler(tp.complex_bandpass(255 * 4, 0.05 / 4, 0.05 / 4) * 4, 1, 4, cpu_n // 4)
+            else:
+                cb = cpu_baseline_fir_i16(tp.c1_taps() * 0.9, cpu_n // 2)
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

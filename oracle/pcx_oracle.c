@@ -139,6 +139,8 @@ typedef struct orc_fir {
     /* polyphase split, FIRFilter.cpp:340-350: row j holds taps[j + k*L] */
     size_t *rowLen;   /* L entries */
     double *rowTapsF; /* L*K*(ctaps?2:1) floating taps narrowed to Q precision (stored as double) */
+    float *rowTapsF32;/* the same rows as float: what floatToQ<complex<float>> leaves in _interpTaps (FIRFilter.cpp:348),
+                         so the float loop reads its taps at their own width like the reference does */
     int64_t *rowTapsQ;/* same for integer Q */
     int waitTapsMode, waitTapsArmed;
     int haveStartId, haveEndId;
@@ -151,9 +153,10 @@ static void fir_update_internals(orc_fir *f)
     const size_t L = f->L, n = f->ntaps;
     f->K = n / L + (((n % L) == 0) ? 0 : 1);
     const size_t K = f->K, w = f->ctaps ? 2 : 1;
-    free(f->rowLen); free(f->rowTapsF); free(f->rowTapsQ);
+    free(f->rowLen); free(f->rowTapsF); free(f->rowTapsF32); free(f->rowTapsQ);
     f->rowLen = (size_t *)calloc(L, sizeof(size_t));
     f->rowTapsF = (double *)calloc(L * K * w, sizeof(double));
+    f->rowTapsF32 = (float *)calloc(L * K * w, sizeof(float));
     f->rowTapsQ = (int64_t *)calloc(L * K * w, sizeof(int64_t));
     for (size_t j = 0; j < L; j++) {
         size_t len = 0;
@@ -164,6 +167,7 @@ static void fir_update_internals(orc_fir *f)
                 const double t = f->taps[i * w + c];
                 /* floatToQ<QTapsType>: float Q -> plain narrowing cast */
                 f->rowTapsF[(j * K + len) * w + c] = (f->st == ORC_F32) ? (double)(float)t : t;
+                f->rowTapsF32[(j * K + len) * w + c] = (float)t;
                 if (!is_float_type(f->st)) f->rowTapsQ[(j * K + len) * w + c] = float_to_q(t, q_bits(f->st));
             }
             len++;
@@ -192,7 +196,7 @@ ORC_EXPORT orc_fir *orc_fir_create(int scalar_type, int is_complex, int complex_
 ORC_EXPORT void orc_fir_destroy(orc_fir *f)
 {
     if (!f) return;
-    free(f->taps); free(f->rowLen); free(f->rowTapsF); free(f->rowTapsQ); free(f);
+    free(f->taps); free(f->rowLen); free(f->rowTapsF); free(f->rowTapsF32); free(f->rowTapsQ); free(f);
 }
 /* FIRFilter::setTaps FIRFilter.cpp:138-144 */
 ORC_EXPORT int orc_fir_set_taps(orc_fir *f, const double *taps, size_t ntaps)
@@ -221,7 +225,7 @@ ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequi
  * Accumulation is sequential in k in the Q type (== element type for floats);
  * complex*complex follows libgcc __mulsc3's finite path: (ac-bd, ad+bc), every
  * product and sum rounded separately. */
-#define ORC_FIR_FLOAT(NAME, T)                                                                  \
+#define ORC_FIR_FLOAT(NAME, T, ROWS)                                                               \
     static size_t NAME(const orc_fir *f, const T *x, T *y, size_t N)                            \
     {                                                                                           \
         const size_t L = f->L, M = f->M, K = f->K;                                              \
@@ -230,12 +234,12 @@ ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequi
             for (size_t j = 0; j < L; j++) {                                                    \
                 if (--decim != 0) continue;                                                     \
                 decim = M;                                                                      \
-                const double *tp = f->rowTapsF + j * K * (f->ctaps ? 2 : 1);                    \
+                const T *tp = f->ROWS + j * K * (f->ctaps ? 2 : 1);                             \
                 const size_t len = f->rowLen[j];                                                \
                 if (!f->cplx) {                                                                 \
                     T acc = 0;                                                                  \
                     for (size_t k = 0; k < len; k++) {                                          \
-                        const T p = (T)tp[k] * x[(ptrdiff_t)n - (ptrdiff_t)k];                  \
+                        const T p = tp[k] * x[(ptrdiff_t)n - (ptrdiff_t)k];                     \
                         acc = acc + p;                                                          \
                     }                                                                           \
                     y[nout++] = acc;                                                            \
@@ -243,7 +247,7 @@ ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequi
                     T ar = 0, ai = 0;                                                           \
                     for (size_t k = 0; k < len; k++) {                                          \
                         const T *xp = x + 2 * ((ptrdiff_t)n - (ptrdiff_t)k);                    \
-                        const T h = (T)tp[k];                                                   \
+                        const T h = tp[k];                                                      \
                         const T pr = xp[0] * h, pi = xp[1] * h;                                 \
                         ar = ar + pr; ai = ai + pi;                                             \
                     }                                                                           \
@@ -252,7 +256,7 @@ ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequi
                     T ar = 0, ai = 0;                                                           \
                     for (size_t k = 0; k < len; k++) {                                          \
                         const T *xp = x + 2 * ((ptrdiff_t)n - (ptrdiff_t)k);                    \
-                        const T a = (T)tp[2 * k], b = (T)tp[2 * k + 1], c = xp[0], d = xp[1];   \
+                        const T a = tp[2 * k], b = tp[2 * k + 1], c = xp[0], d = xp[1];         \
                         const T ac = a * c, bd = b * d, ad = a * d, bc = b * c;                 \
                         const T pr = ac - bd, pi = ad + bc;                                     \
                         ar = ar + pr; ai = ai + pi;                                             \
@@ -263,8 +267,8 @@ ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequi
         }                                                                                       \
         return nout;                                                                            \
     }
-ORC_FIR_FLOAT(fir_loop_f32, float)
-ORC_FIR_FLOAT(fir_loop_f64, double)
+ORC_FIR_FLOAT(fir_loop_f32, float, rowTapsF32)
+ORC_FIR_FLOAT(fir_loop_f64, double, rowTapsF)
 
 /* same loop for the integer element types: all operations are ring operations
  * modulo 2^qbits (std::complex<intN> products/sums wrap), so the result is the

@@ -139,3 +139,28 @@ def test_fm_chain_sharding_has_no_seam():
     ref = o.FreqDemod(o.F32).work(y)
     assert p == world * C
     assert np.array_equal(got, ref)      # same arithmetic per output: bit-identical across the seams
+
+
+def test_bench_refuses_a_world_size_that_is_not_what_was_asked():
+    """bench.py under a rank environment of 4 with --gpus 2 must refuse before doing anything (no GPU needed)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+    assert not r.stdout.strip()
+
+
+def test_bench_parent_fails_loudly_when_its_ranks_fail():
+    """No GPU here: the two ranks bench.py starts itself die on their GPU assertion; the parent must exit
+    non-zero and print no result line (a one-GPU number under an N-GPU label is the failure this guards)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -167,3 +167,36 @@ def test_rccl_group_of_one_runs_the_bench_control_flow(oracle):
     ref.set_taps(tp.c1_taps()); ref.activate()
     want, _, _, _ = ref.work(buf, 1 << 16)
     assert nerr(out, want) <= TOL
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_spawns_its_own_ranks_and_reports_the_world_it_saw():
+    """`python bench.py --gpus 2` with no rank environment must start two ranks itself and say n_gpus: 2
+    (the halo goes over gloo here: one GPU on the test box; RCCL on the 8-GPU node)."""
+    import json
+    r = _run_bench({"PCX_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--shard", "1048576", "--steps", "3", "--warmup", "1", "--no-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size_observed"] == 2
+    assert len(out["config"]["rank_devices"]) == 2
+    assert out["config"]["halo_backend"].startswith("gloo")
+    assert out["value"] > 0
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    """With the RCCL backend every rank needs its own GPU: asking for more than the node has must fail, not fold."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = _run_bench({}, "--gpus", str(n), "--shard", "1048576", "--steps", "1", "--warmup", "0", "--no-cpu")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -218,6 +218,48 @@ PCX_API int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems,
 PCX_API int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                                     size_t *consumed, size_t *produced, void *stream);
 
+/* ===================================================================== *
+ *  ONE complex_float32 stream over the GPUs of a node  (BASELINE.json configs[3])
+ *
+ *  The reference has no multi-device story; what makes this possible is in its loop: output n reads inputs
+ *  n .. n+K-1 only (FIRFilter.cpp:296-299) and a work() call leaves the last K-1 inputs un-consumed as the next
+ *  call's history (:305-307).  A stream of G*C samples is split into G contiguous shards of C samples, one per
+ *  device; before every pass shard g receives the LAST K-1 samples of shard g-1 into the slot in front of its own
+ *  samples (RCCL ncclSend/ncclRecv, one group per pass, (K-1)*8 bytes per boundary), shard 0 keeps the stream's
+ *  own history.  The body of each shard is filtered while the halo is in flight, its first 4096 outputs after it.
+ *  One process drives all devices (ncclCommInitAll): a Pothos block that owns a pcx_shard spreads its stream over
+ *  the node from inside one work() call.  M = L = 1, complex_float32 (the north-star path).
+ *
+ *  Call order:  create -> set_taps -> configure(C) -> { fill the shard inputs (pcx_shard_buffers gives the device
+ *  pointers and the per-device stream to fill them on; or pcx_shard_scatter from one host buffer) -> step }* ->
+ *  gather / read the outputs -> destroy.  pcx_shard_step only enqueues; pcx_shard_sync waits.
+ * ===================================================================== */
+typedef struct pcx_shard pcx_shard;
+typedef enum pcx_shard_transport {
+    PCX_SHARD_RCCL = 0,      /* ncclSend/ncclRecv over xGMI; one distinct device per shard (RCCL is loaded on first use) */
+    PCX_SHARD_PEER_COPY = 1  /* hipMemcpyPeerAsync; several shards may share a device (how a 1-GPU box rehearses G > 1) */
+} pcx_shard_transport;
+/* devices: `nshards` ordinals, or NULL for 0 .. nshards-1 */
+PCX_API int pcx_shard_create(int nshards, const int *devices, int transport, pcx_shard **out);
+PCX_API int pcx_shard_destroy(pcx_shard *s);
+/* FIRFilter::setTaps on every device's filter, FIRFilter.cpp:138-144; REAL (complex_taps = 0) or COMPLEX taps */
+PCX_API int pcx_shard_set_taps(pcx_shard *s, const double *taps, size_t ntaps, int complex_taps);
+PCX_API int pcx_shard_set_algo(pcx_shard *s, int algo);                 /* pcx_fir_algo, default PCX_FIR_AUTO */
+/* allocate, on every device, [halo (K-1) | shard_elems samples] and shard_elems outputs; the halo of shard 0 (the
+ * stream's history) starts as zeros, as after FIRFilter::activate */
+PCX_API int pcx_shard_configure(pcx_shard *s, size_t shard_elems);
+PCX_API int pcx_shard_info(const pcx_shard *s, int *nshards, size_t *K, size_t *shard_elems, int *transport);
+/* shard g: in_dev -> K-1 halo samples followed by the shard's own samples; out_dev -> its shard_elems outputs;
+ * stream -> the per-device stream (hipStream_t) the pass runs on: fill in_dev on it, or synchronise before a step */
+PCX_API int pcx_shard_buffers(pcx_shard *s, int g, void **in_dev, void **out_dev, void **stream, int *device);
+/* host_stream: K-1 history samples followed by nshards*shard_elems samples; only shard 0 receives a halo from here */
+PCX_API int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems);
+/* one pass over every shard: halo exchange, body, head */
+PCX_API int pcx_shard_step(pcx_shard *s);
+/* the nshards*shard_elems outputs in stream order (waits for the pass) */
+PCX_API int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems);
+PCX_API int pcx_shard_sync(pcx_shard *s);
+
 #ifdef __cplusplus
 }
 #endif

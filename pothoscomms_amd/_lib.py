@@ -95,6 +95,17 @@ SIGNATURES = {
     "pcx_fmchain_last_algo": (_i, [_vp]),
     "pcx_fmchain_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz]),
     "pcx_fmchain_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp]),
+    "pcx_shard_create": (_i, [_i, C.POINTER(C.c_int), _i, C.POINTER(_vp)]),
+    "pcx_shard_destroy": (_i, [_vp]),
+    "pcx_shard_set_taps": (_i, [_vp, C.POINTER(C.c_double), _sz, _i]),
+    "pcx_shard_set_algo": (_i, [_vp, _i]),
+    "pcx_shard_configure": (_i, [_vp, _sz]),
+    "pcx_shard_info": (_i, [_vp, C.POINTER(C.c_int), _psz, _psz, C.POINTER(C.c_int)]),
+    "pcx_shard_buffers": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),
+    "pcx_shard_scatter": (_i, [_vp, _vp, _sz]),
+    "pcx_shard_step": (_i, [_vp]),
+    "pcx_shard_gather": (_i, [_vp, _vp, _sz]),
+    "pcx_shard_sync": (_i, [_vp]),
 }
 
 _lib = None
@@ -137,12 +148,20 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    # tools/ only: PCX_HIP_LIBRARY points the loader at the diagnostic build (make -C pothoscomms_amd/csrc diag),
+    # the one library that reads A/B switches from the environment and holds the timing-only kernel variants
+    override = os.environ.get("PCX_HIP_LIBRARY")
+    if override:
+        if not os.path.exists(override):
+            raise ImportError("PCX_HIP_LIBRARY=%s does not exist" % override)
+        path = override
+    if not os.path.exists(path):
         raise ImportError(
             "%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C pothoscomms_amd/csrc).  pothoscomms_amd has no CPU fallback." % LIB_PATH)
     _preload_hip_runtime()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

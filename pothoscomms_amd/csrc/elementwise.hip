@@ -19,9 +19,12 @@ namespace pcx {
 constexpr int kBlock = 256;
 constexpr int kUnroll = 4;
 
-// IN_PER / OUT_PER scalars per stream item; ITEMS items per lane-vector
+// IN_PER / OUT_PER scalars per stream item; ITEMS items per lane-vector.
+// No __restrict__: pcx.h documents out == in for the same-size maps (rotate, scale, conj), and Arithmetic's buffer
+// inlining relies on it.  Every lane loads the vectors it is about to overwrite before it stores them, and no lane
+// touches another lane's elements, so the in-place call is well defined as written.
 template <typename In, typename Out, int IN_PER, int OUT_PER, int ITEMS, typename Op>
-__global__ __launch_bounds__(kBlock) void map_kernel(const In *__restrict__ in, Out *__restrict__ out, size_t nitems, Op op)
+__global__ __launch_bounds__(kBlock) void map_kernel(const In *in, Out *out, size_t nitems, Op op)
 {
     using VIn = Vec<In, IN_PER * ITEMS>;
     using VOut = Vec<Out, OUT_PER * ITEMS>;

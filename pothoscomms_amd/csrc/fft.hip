@@ -62,7 +62,7 @@ int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse,
     // stride, keeping its twiddles in registers and the next frame in flight
     const unsigned grid = persistent_grid(nframes, 1024);
     // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
-    static const int saux = [] { const char *e = getenv("PCX_FFT_STORE_AUX"); return e ? atoi(e) : 2; }();
+    const int saux = (int)PCX_ENV_INT("PCX_FFT_STORE_AUX", 2);
 #define PCX_FFT_LAUNCH(INV, SAUX) hipLaunchKernelGGL((fft4096_kernel<INV, SAUX>), dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab)
     if (inverse) { if (saux == 2) PCX_FFT_LAUNCH(true, 2); else PCX_FFT_LAUNCH(true, 0); }
     else { if (saux == 2) PCX_FFT_LAUNCH(false, 2); else PCX_FFT_LAUNCH(false, 0); }
@@ -510,7 +510,7 @@ int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool
     int log2n = 0;
     while (((size_t)1 << log2n) < nbins) log2n++;
     // 16 <= numBins <= 16384 take the fused-pair kernel; PCX_FFT_Q15_PASSES=1 keeps the pass kernel (A/B)
-    static const int passes_only = [] { const char *e = getenv("PCX_FFT_Q15_PASSES"); return e ? atoi(e) : 0; }();
+    const int passes_only = (int)PCX_ENV_INT("PCX_FFT_Q15_PASSES", 0);
     if (!passes_only) {
         switch (log2n) {
         case 4: return launch_q15_r16<4>(in, out, nframes, inverse, tw, perm, st);

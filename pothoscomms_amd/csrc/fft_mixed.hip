@@ -457,13 +457,13 @@ int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool i
     }
     // short frames share a workgroup: about 4096 elements per group, so that every pass has >= 1024 butterflies
     // PCX_FFT_MIXED_ELEMS (A/B): elements per workgroup the frame count is sized for
-    static const size_t group_elems = [] { const char *e = getenv("PCX_FFT_MIXED_ELEMS"); return e ? (size_t)atoi(e) : (size_t)4096; }();
+    const size_t group_elems = (size_t)PCX_ENV_INT("PCX_FFT_MIXED_ELEMS", 4096);
     size_t fpw = nbins >= group_elems ? 1 : group_elems / nbins;
     if (fpw > nframes) fpw = nframes;
     plan.fpw = (int)fpw;
     size_t lds = fpw * nbins * sizeof(typename A::cpx) * images;
     // PCX_FFT_MIXED_TWLDS=0 (A/B) keeps the twiddles in global memory
-    static const int tw_in_lds = [] { const char *e = getenv("PCX_FFT_MIXED_TWLDS"); return e ? atoi(e) : 1; }();
+    const int tw_in_lds = (int)PCX_ENV_INT("PCX_FFT_MIXED_TWLDS", 1);
     const bool twlds = tw_in_lds && lds + nbins * sizeof(typename A::cpx) <= 80 * 1024;
     if (twlds) lds += nbins * sizeof(typename A::cpx);
     auto k = twlds ? fft_mixed_kernel<A, true> : fft_mixed_kernel<A, false>;
@@ -473,7 +473,7 @@ int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool i
     if (threads < 64) threads = 64;
     if (threads > 1024) threads = 1024;
     // PCX_FFT_MIXED_DIAG=1 (timing only, wrong outputs): no butterfly passes, the load/scatter/store skeleton alone
-    static const int diag = [] { const char *e = getenv("PCX_FFT_MIXED_DIAG"); return e ? atoi(e) : 0; }();
+    const int diag = (int)PCX_ENV_INT("PCX_FFT_MIXED_DIAG", 0);
     if (diag == 1) plan.nstages = 0;
     if (diag == 2) for (int q = 0; q < nstages; q++) plan.radix[q] = 1;   // stage loop, plan loads and barriers without butterflies
     const size_t ngroups = (nframes + fpw - 1) / fpw;
@@ -519,7 +519,7 @@ int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool 
     // PCX_FFT_SMOOTH_PAD=1 (A/B): image padded i + i/16.  Measured: 1536 bins (span 96 = 3 * 32 elements, the worst
     // aliasing case) unchanged at 140 Gsamples/s, every other size 5-15 % slower from the extra index arithmetic -- the
     // passes wait on VALU issue, not on LDS banks -- so the plain image is the default
-    static const int pad = [] { const char *e = getenv("PCX_FFT_SMOOTH_PAD"); return e ? atoi(e) : 0; }();
+    const int pad = (int)PCX_ENV_INT("PCX_FFT_SMOOTH_PAD", 0);
     const size_t img = fpw * nbins;
     size_t lds = (pad ? img + img / 16 + 1 : img) * EB;
     const bool twlds = lds + nbins * EB <= 96 * 1024;
@@ -533,7 +533,7 @@ int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool 
     // lanes per group = elements / div.  Measured (tools/sweep_fft_mixed.py with PCX_FFT_SMOOTH_DIV = 4 ... 16): more, smaller
     // workgroups per CU beat one butterfly per lane in every pass -- 6 for short frames, 8 to 4095 bins, 4 beyond
     int rmin = nbins < 256 ? 6 : nbins < 4096 ? 8 : 4;
-    static const int div_forced = [] { const char *e = getenv("PCX_FFT_SMOOTH_DIV"); return e ? atoi(e) : 0; }();
+    const int div_forced = (int)PCX_ENV_INT("PCX_FFT_SMOOTH_DIV", 0);
     if (div_forced > 0) rmin = div_forced;
     unsigned threads = (unsigned)((fpw * nbins + rmin - 1) / rmin);
     threads = (threads + 63) / 64 * 64;

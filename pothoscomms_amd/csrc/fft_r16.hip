@@ -223,7 +223,7 @@ int launch_r16(const void *in, void *out, size_t nframes, bool inverse, const vo
     size_t lds = ((size_t)P::LDS_FRAME * P::FPW + P::T2_ELEMS) * sizeof(cf);
     if ((size_t)P::STAGE * sizeof(cf) > lds) lds = (size_t)P::STAGE * sizeof(cf);
     // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
-    static const int saux = [] { const char *e = getenv("PCX_FFT_STORE_AUX"); return e ? atoi(e) : 2; }();
+    const int saux = (int)PCX_ENV_INT("PCX_FFT_STORE_AUX", 2);
     auto k = saux == 2 ? (inverse ? fft_r16_kernel<LOG2N, true, 2> : fft_r16_kernel<LOG2N, false, 2>)
                        : (inverse ? fft_r16_kernel<LOG2N, true, 0> : fft_r16_kernel<LOG2N, false, 0>);
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -247,7 +247,7 @@ static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g
     S *pout = (S *)out;
     const TT *tp = (const TT *)g.rowTaps;
     // staged tile image: (256 R + K - 1) elements, padded by one per R; PCX_FIR_STAGE=0 reads global memory directly (A/B)
-    static const int stage_on = [] { const char *e = getenv("PCX_FIR_STAGE"); return e ? atoi(e) : 1; }();
+    const int stage_on = (int)PCX_ENV_INT("PCX_FIR_STAGE", 1);
     const size_t n_stage = (size_t)256 * R + g.K - 1;
     const size_t lds = (n_stage + n_stage / R + 1) * sizeof(S) * (is_complex ? 2 : 1);
     const bool stage = stage_on && lds <= 64 * 1024;

@@ -184,20 +184,20 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols: K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
-    // PCX_OLS_VARIANT (A/B and diagnostics): unset = default policy below; 1 plain loads/stores, 0 register
-    // prefetch (3 workgroups/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs, 5 H from L2,
-    // 6 nt stores only, 7 nt interior loads only, 9 register prefetch + default cache policy,
-    // 10/11 compute-only / memory-only timing builds (plain accesses), 12/13 the same with the default policy,
-    // 14 XCD-aware block walk + default policy, 15/16 butterflies-only / exchanges-only on the real stream.
-    // PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
-    static const int variant = [] {
-        const char *e = getenv("PCX_OLS_VARIANT");
-        const int v = e ? atoi(e) : -1;
-        if (v == 10 || v == 11 || v == 12 || v == 13 || v == 15 || v == 16)
-            fprintf(stderr, "pcx: PCX_OLS_VARIANT=%d selects a TIMING-ONLY build of the overlap-save FIR: its outputs are wrong\n", v);
-        return v;
-    }();
-    static const int align = [] { const char *e = getenv("PCX_OLS_ALIGN"); return e ? atoi(e) : 1; }();
+    // PCX_OLS_VARIANT (libpcx_hip_diag.so only: the product library has no such switch): unset = default policy below;
+    // 1 plain loads/stores, 0 register prefetch (3 workgroups/CU), 2/3 nt loads / nt loads+stores, 4 contiguous block runs,
+    // 5 H from L2, 6 nt stores only, 7 nt interior loads only, 9 register prefetch + default cache policy, 14 XCD-aware block
+    // walk; TIMING-ONLY (wrong outputs): 10/11 compute-only / memory-only (plain accesses), 12/13 the same with the default
+    // policy, 15/16 butterflies-only / exchanges-only on the real stream.  PCX_OLS_ALIGN=0 keeps the minimal K-1 overlap.
+    const int variant = (int)PCX_ENV_INT("PCX_OLS_VARIANT", -1);
+    const int align = (int)PCX_ENV_INT("PCX_OLS_ALIGN", 1);
+#ifdef PCX_DIAG
+    if (variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 15 || variant == 16) {
+        static bool warned = false;
+        if (!warned) fprintf(stderr, "pcx(diag): PCX_OLS_VARIANT=%d selects a TIMING-ONLY build of the overlap-save FIR: its outputs are wrong\n", variant);
+        warned = true;
+    }
+#endif
     const size_t Km1 = K - 1;
     const size_t Kov = align ? (Km1 + 15) / 16 * 16 : Km1;   // <= 2048
     const size_t pad = Kov - Km1;
@@ -211,35 +211,41 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     const float2 *pi = (const float2 *)in, *ph = (const float2 *)Hspec, *pt = (const float2 *)tw4096;
     float2 *po = (float2 *)out;
     // PCX_OLS_SLOTS (diagnostic): resident workgroups to use chip-wide (default 1024 = 4 per CU)
-    static const unsigned slots = [] { const char *e = getenv("PCX_OLS_SLOTS"); return e ? (unsigned)atoi(e) : 1024u; }();
+    const unsigned slots = (unsigned)PCX_ENV_INT("PCX_OLS_SLOTS", 1024);
     const unsigned g4 = persistent_grid(nblocks, slots), g3 = persistent_grid(nblocks, 768);
     const unsigned gx = 8 * persistent_grid((nblocks + 7) / 8, 128);   // XCD-aware walk: equal rounds inside every XCD's eighth
 #define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks)
+#ifdef PCX_DIAG
     switch (variant) {
-    case 0: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true>), g3); break;
-    case 1: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false>), g4); break;
-    case 2: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 0>), g4); break;
-    case 3: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 2>), g4); break;
-    case 4: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 1>), g4); break;
-    case 5: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 0, 0, 0, 0, true>), g4); break;
-    case 6: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4); break;
-    case 7: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0>), g4); break;
-    case 9: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 4, 2>), g3); break;
-    case 14: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 2>), gx); break;
-    case 15: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 3>), g4); break;
-    case 16: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 4>), g4); break;
-    case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 1>), g4); break;
-    case 13: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 2>), g4); break;
-    case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 1>), g4); break;
-    case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 2>), g4); break;
-    default:
-        // non-temporal stores; non-temporal loads for the rows no other block reads
-        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), g4);
-        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2>), g4);
-        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2>), g4);
-        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4);
-        break;
+    case 0: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true>), g3); goto launched;
+    case 1: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false>), g4); goto launched;
+    case 2: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 0>), g4); goto launched;
+    case 3: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 2, 2>), g4); goto launched;
+    case 4: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 1>), g4); goto launched;
+    case 5: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 0, 0, 0, 0, true>), g4); goto launched;
+    case 6: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4); goto launched;
+    case 7: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0>), g4); goto launched;
+    case 9: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 4, 2>), g3); goto launched;
+    case 14: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 2>), gx); goto launched;
+    case 15: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 3>), g4); goto launched;
+    case 16: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 4>), g4); goto launched;
+    case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 1>), g4); goto launched;
+    case 13: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 2>), g4); goto launched;
+    case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 1>), g4); goto launched;
+    case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 2>), g4); goto launched;
+    default: break;
     }
+#else
+    (void)variant; (void)g3; (void)gx;
+#endif
+    // non-temporal stores; non-temporal loads for the rows no other block reads
+    if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), g4);
+    else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2>), g4);
+    else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2>), g4);
+    else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4);
+#ifdef PCX_DIAG
+launched:
+#endif
 #undef PCX_OLS_LAUNCH
     PCX_LAUNCH_CHECK();
     return PCX_OK;
@@ -636,8 +642,8 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2048) { set_error("fm chain ols: K=%zu outside 1..2048", K); return PCX_ERR_UNSUPPORTED; }
-    // PCX_FMCHAIN_OCC (A/B): 3 = 3 workgroups per CU, 5 = 4 per CU with plain loads/stores; default 4 + row policy
-    static const int occ = [] { const char *e = getenv("PCX_FMCHAIN_OCC"); return e ? atoi(e) : 4; }();
+    // PCX_FMCHAIN_OCC (libpcx_hip_diag.so only, A/B): 3 = 3 workgroups per CU, 5 = 4 per CU with plain loads/stores; default 4 + row policy
+    const int occ = (int)PCX_ENV_INT("PCX_FMCHAIN_OCC", 4);
     const size_t Kov = (K + 31) / 32 * 32, pad = Kov - K;    // <= 2048
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
@@ -645,9 +651,14 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
     hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX>), dim3(persistent_grid(nblocks, CAP)), dim3(256), 0, st,   \
                        (const float2 *)in, in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad,            \
                        (const float2 *)tw4096, nblocks, (const float2 *)prev_in, (float2 *)prev_out)
+#ifdef PCX_DIAG
     if (occ == 3) PCX_FM_LAUNCH(3, 8, 0, 768);            // A/B: 3 workgroups per CU, plain loads and stores
     else if (occ == 5) PCX_FM_LAUNCH(4, 8, 0, 1024);      // A/B: plain loads and stores
-    else if (Kov <= 256) PCX_FM_LAUNCH(4, 1, 2, 1024);
+    else
+#else
+    (void)occ;
+#endif
+    if (Kov <= 256) PCX_FM_LAUNCH(4, 1, 2, 1024);
     else if (Kov <= 512) PCX_FM_LAUNCH(4, 2, 2, 1024);
     else if (Kov <= 1024) PCX_FM_LAUNCH(4, 4, 2, 1024);
     else PCX_FM_LAUNCH(4, 8, 2, 1024);

@@ -233,7 +233,12 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     while (nfull > first_full && (nfull - 1) * S - pad + P::N > in_elems) nfull--;
     if (nfull < first_full) nfull = first_full;
     const size_t lds = (size_t)(P::LDS_IMG + P::LDS_T2) * sizeof(cf);
+#ifdef PCX_DIAG
     auto k = diag == 1 ? fir_cf32_ols_r16_kernel<LOG2N, 1> : diag == 2 ? fir_cf32_ols_r16_kernel<LOG2N, 2> : fir_cf32_ols_r16_kernel<LOG2N, 0>;
+#else
+    (void)diag;   // the timing-only instantiations exist in the diagnostic library only
+    auto k = fir_cf32_ols_r16_kernel<LOG2N, 0>;
+#endif
     if (lds > 64 * 1024) PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // resident workgroups per CU: LDS (160 KiB) and 16 waves of <= 128 VGPRs
     unsigned per_cu = (unsigned)(160 * 1024 / lds);
@@ -253,13 +258,11 @@ int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n
                             const void *tw, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
-    // PCX_OLS_DIAG (timing-only builds, wrong outputs): 1 compute floor, 2 memory floor
-    static const int diag = [] {
-        const char *e = getenv("PCX_OLS_DIAG");
-        const int v = e ? atoi(e) : 0;
-        if (v) fprintf(stderr, "pcx: PCX_OLS_DIAG=%d selects a TIMING-ONLY build of the overlap-save FIR: its outputs are wrong\n", v);
-        return v;
-    }();
+    // PCX_OLS_DIAG (libpcx_hip_diag.so only; timing-only, wrong outputs): 1 compute floor, 2 memory floor
+    const int diag = (int)PCX_ENV_INT("PCX_OLS_DIAG", 0);
+#ifdef PCX_DIAG
+    if (diag) fprintf(stderr, "pcx(diag): PCX_OLS_DIAG=%d selects a TIMING-ONLY build of the overlap-save FIR: its outputs are wrong\n", diag);
+#endif
     switch (log2n) {
     case 10: return launch_ols<10>(in, in_elems, out, n_out, Hspec, K, tw, st, diag);
     case 11: return launch_ols<11>(in, in_elems, out, n_out, Hspec, K, tw, st, diag);

@@ -193,7 +193,7 @@ int pcx_memcpy_d2d(void *d, const void *s, size_t n, void *st) { PCX_HIP(hipMemc
 int pcx_host_alloc(void **hptr, size_t bytes)
 {
     PCX_CHECK_ARG(hptr, "null hptr");
-    PCX_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    PCX_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped));   // visible to every device of the process
     return PCX_OK;
 }
 int pcx_host_free(void *hptr) { PCX_HIP(hipHostFree(hptr)); return PCX_OK; }
@@ -217,11 +217,96 @@ struct DeviceScope {
     }
     ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
+// Execution context of a handle (one per block instance, include/pcx.h "Conventions"):
+//   device  bound in *_create (the creating thread's current device) -- or, when no device was reachable then, at
+//           the first device-touching call;
+//   own     the handle's own non-blocking stream: staging copies and kernels of the HOST-pointer entry points, so two
+//           blocks on two Pothos actor threads overlap instead of serialising on the legacy default stream;
+//   last    the stream of the handle's most recent enqueue.  A call that arrives on a different stream is ordered
+//           behind it with an event (carried state such as FreqDemod's prev, and the tables, are read by kernels);
+//           control-plane rewrites of device tables first wait for it (ctx_quiesce).
+struct ExecCtx {
+    int device = -1;
+    hipStream_t own = nullptr;
+    hipStream_t last = nullptr;
+    bool have_last = false;
+    hipEvent_t ev = nullptr;
+    ExecCtx() = default;
+    ExecCtx(const ExecCtx &) = delete;
+    ExecCtx &operator=(const ExecCtx &) = delete;
+    ~ExecCtx()
+    {
+        if (ev) (void)hipEventDestroy(ev);
+        if (own) (void)hipStreamDestroy(own);
+    }
+};
+// (call with the handle's DeviceScope alive)
+static int ctx_own_stream(ExecCtx &c, hipStream_t *out)
+{
+    if (!c.own) PCX_HIP(hipStreamCreateWithFlags(&c.own, hipStreamNonBlocking));
+    *out = c.own;
+    return PCX_OK;
+}
+// before enqueuing on `st`: order it behind the handle's previous enqueue if that went to another stream
+static int ctx_enter(ExecCtx &c, hipStream_t st)
+{
+    if (c.have_last && c.last != st) {
+        if (!c.ev) PCX_HIP(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+        PCX_HIP(hipEventRecord(c.ev, c.last));
+        PCX_HIP(hipStreamWaitEvent(st, c.ev, 0));
+    }
+    c.last = st;
+    c.have_last = true;
+    return PCX_OK;
+}
+// control plane: nothing the handle enqueued may still be reading the tables about to be rewritten
+static int ctx_quiesce(ExecCtx &c)
+{
+    if (c.have_last) PCX_HIP(hipStreamSynchronize(c.last));
+    return PCX_OK;
+}
+
+// Device-visible alias of a HOST pointer when it is page-locked (pcx_host_alloc / hipHostMalloc / hipHostRegister; any
+// offset inside the allocation), else nullptr.  The host-pointer entry points launch their kernels straight on such
+// buffers -- measured on MI355X (tools/pcie_lab.hip, 128 MiB each way): a kernel reading and writing pinned host memory
+// moves 43 GB/s in BOTH directions at once, against 28 GB/s for H2D, kernel, D2H through a staging workspace -- and stage
+// only pageable memory, which the device cannot address.
+static void *device_alias(const void *p)
+{
+    if (!p) return nullptr;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if ((a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) && a.devicePointer) return a.devicePointer;
+    return nullptr;
+}
+// one direction of a host-pointer call: the alias when there is one, else the staging buffer (grown to `bytes`)
+static int stage_in(const void *host, size_t bytes, DevBuf &ws, hipStream_t st, const void **dev)
+{
+    if (void *a = device_alias(host)) { *dev = a; return PCX_OK; }
+    PCX_TRY(ws.ensure(bytes));
+    PCX_HIP(hipMemcpyAsync(ws.p, host, bytes, hipMemcpyHostToDevice, st));
+    *dev = ws.p;
+    return PCX_OK;
+}
+static int stage_out_begin(void *host, size_t bytes, DevBuf &ws, void **dev, bool *staged)
+{
+    if (void *a = device_alias(host)) { *dev = a; *staged = false; return PCX_OK; }
+    PCX_TRY(ws.ensure(bytes));
+    *dev = ws.p; *staged = true;
+    return PCX_OK;
+}
+static int stage_out_end(void *host, size_t bytes, const void *dev, bool staged, hipStream_t st)
+{
+    if (staged && bytes) PCX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+    PCX_HIP(hipStreamSynchronize(st));
+    return PCX_OK;
+}
+
 /* ===================================================================== *
  *  FIR
  * ===================================================================== */
 struct pcx_fir {
-    int device = -1;
+    ExecCtx cx;
     int scalar = PCX_F32, cplx = 1, ctaps = 1;
     std::vector<double> taps;  // ntaps * (ctaps ? 2 : 1)
     size_t ntaps = 1, M = 1, L = 1, K = 1, inputRequire = 1;
@@ -254,7 +339,7 @@ struct pcx_fir {
 // PCX_OLS_N=1024/2048/4096/8192/16384 forces a plan (A/B runs, tools/ab_ols.py).
 static int fir_ols_block_log2(size_t K)
 {
-    static const int forced = [] { const char *e = getenv("PCX_OLS_N"); return e ? atoi(e) : 0; }();
+    const int forced = (int)PCX_ENV_INT("PCX_OLS_N", 0);
     switch (forced) {
     case 1024: return 10;
     case 2048: return 11;
@@ -275,7 +360,7 @@ constexpr size_t kOls64MinTaps = 4;
 // 127, 48 at 255, 12 at 1023); PCX_OLS_INT_MIN overrides (A/B)
 static size_t ols_int_min_taps(int scalar)
 {
-    static const size_t forced = [] { const char *e = getenv("PCX_OLS_INT_MIN"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    const size_t forced = (size_t)PCX_ENV_INT("PCX_OLS_INT_MIN", 0);
     return forced ? forced : scalar == PCX_I16 ? 64 : 96;
 }
 
@@ -284,12 +369,12 @@ static size_t ols_int_min_taps(int scalar)
 // float64 278 vs 228 at 16 taps, 202 vs 234 at 32; int16 356 vs 280 at 32, 230 vs 286 at 63); PCX_OLS_REAL_MIN overrides (A/B)
 static size_t ols_real64_min_taps(int scalar)
 {
-    static const size_t forced = [] { const char *e = getenv("PCX_OLS_REAL_MIN"); return e ? (size_t)atoi(e) : (size_t)0; }();
+    const size_t forced = (size_t)PCX_ENV_INT("PCX_OLS_REAL_MIN", 0);
     return forced ? forced : scalar == PCX_F64 ? 24 : 48;
 }
 static int fir_ols64_block_log2(size_t K)
 {
-    static const int forced = [] { const char *e = getenv("PCX_OLS64_N"); return e ? atoi(e) : 0; }();
+    const int forced = (int)PCX_ENV_INT("PCX_OLS64_N", 0);
     int l2 = K <= 2049 ? 12 : 13;
     switch (forced) {
     case 1024: if (K <= 513) l2 = 10; break;
@@ -359,6 +444,7 @@ static bool fir_fast_applicable(const pcx_fir *h) { return h->scalar == PCX_F32 
 static int fir_sync_tables(pcx_fir *h)
 {
     if (!h->dirty) return PCX_OK;
+    PCX_TRY(ctx_quiesce(h->cx));   // a kernel of an earlier call may still be reading the tables rewritten below
     switch (h->scalar) {
     case PCX_F32: PCX_TRY(fir_upload_rows<float>(h, false)); break;
     case PCX_F64: PCX_TRY(fir_upload_rows<double>(h, false)); break;
@@ -538,7 +624,7 @@ static int fir_sync_tables(pcx_fir *h)
     // folding pays from 4-fold on (and for M = 2 itself); 2-fold plus a cofactor measured slower than the full-rate kernel
     // (M = 10: 244 vs 281, M = 50: 251 vs 284 Gsamples/s in; M = 160 = 16 * 10: 373 vs 287)
     if (h->have_poly && h->L == 1 && (h->M == 2 || fir_decim_fold_factor(h->M) >= 4) && h->M / fir_decim_fold_factor(h->M) <= 65535 &&
-        !getenv("PCX_FIR_DECIM_FULLRATE")) {
+        !PCX_ENV_SET("PCX_FIR_DECIM_FULLRATE")) {
         // decimating filter: one forward transform, the spectrum folded M-fold, a 4096/M-point inverse (fir_ols_decim.hip).
         // PCX_FIR_DECIM_FULLRATE (A/B) keeps the full-rate evaluation of the polyphase kernel.
         std::vector<std::complex<double>> hq(h->K);
@@ -549,7 +635,7 @@ static int fir_sync_tables(pcx_fir *h)
         h->have_decim = true;
     }
     h->have_interp = false;
-    if (h->have_poly && h->M == 1 && (h->L == 2 || h->L == 4 || h->L == 8 || h->L == 16) && !getenv("PCX_FIR_DECIM_FULLRATE")) {
+    if (h->have_poly && h->M == 1 && (h->L == 2 || h->L == 4 || h->L == 8 || h->L == 16) && !PCX_ENV_SET("PCX_FIR_DECIM_FULLRATE")) {
         // interpolating filter: a 4096/L-point forward transform, its spectrum replicated against H of the WHOLE tap vector,
         // the ordinary 4096-point inverse writing the interleaved output stream (fir_ols_decim.hip)
         const size_t A = 16 / h->L, kov_in = (h->K - 1 + A - 1) / A * A;
@@ -578,6 +664,7 @@ int pcx_fir_create(int scalar, int is_complex, int complex_taps, pcx_fir **out)
     h->taps[0] = 1.0;  // ctor: setTaps({1}), FIRFilter.cpp:125
     h->ntaps = 1;
     fir_update_internals(h);
+    { DeviceScope bind(h->cx.device); }   // the handle belongs to the device current on the creating thread
     *out = h;
     return PCX_OK;
 }
@@ -637,7 +724,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
                         size_t *consumed, size_t *produced, void *stream)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
     const size_t N = fir_iterations(h, in_elems, out_cap);
     if (N == 0) return PCX_OK;
@@ -645,6 +732,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
     PCX_TRY(fir_sync_tables(h));
     const size_t n_out = (N / h->M) * h->L;
     hipStream_t st = as_stream(stream);
+    PCX_TRY(ctx_enter(h->cx, st));
     int algo = h->algo;
     const bool fast = fir_fast_applicable(h);
     if (algo == PCX_FIR_AUTO) {
@@ -705,7 +793,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         rc = launch_fir_cf32_ols4096_interp(in_dev, used_in, out_dev, N, h->Hdecim.p, h->K, h->L, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_decim) {
         rc = launch_fir_cf32_ols4096_decim(in_dev, used_in, out_dev, N, h->Hdecim.p, h->K, h->M, h->tw4096.p, st);
-    } else if (algo == PCX_FIR_OLS_FFT && h->have_poly && h->M == 1 && h->K <= 2049 && !getenv("PCX_FIR_POLY_STRIDED")) {
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_poly && h->M == 1 && h->K <= 2049 && !PCX_ENV_SET("PCX_FIR_POLY_STRIDED")) {
         // interpolation by other factors: each polyphase row through the undecimated kernel into a contiguous workspace row,
         // then one interleaving pass (PCX_FIR_POLY_STRIDED (A/B) keeps the polyphase kernel's stride-L stores)
         PCX_TRY(h->wsRows.ensure(N * h->L * 8));
@@ -727,9 +815,9 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
     } else {
         FirGeom g{h->L, h->M, h->K, static_cast<const uint32_t *>(h->rowLen.p), h->rowTaps.p};
         // PCX_FIR_SLIDE=0 keeps the one-output-per-lane kernel for M = L = 1 too (A/B)
-        static const int slide = [] { const char *e = getenv("PCX_FIR_SLIDE"); return e ? atoi(e) : 1; }();
+        const int slide = (int)PCX_ENV_INT("PCX_FIR_SLIDE", 1);
         // PCX_FIR_DOT2=0 keeps complex_int16 on the 24-bit multiply path (A/B)
-        static const int dot2 = [] { const char *e = getenv("PCX_FIR_DOT2"); return e ? atoi(e) : 1; }();
+        const int dot2 = (int)PCX_ENV_INT("PCX_FIR_DOT2", 1);
         if (slide && dot2 && h->taps16 && h->L == 1 && h->M == 1 && h->K <= 12000)
             rc = launch_fir_ci16_dot2(in_dev, out_dev, n_out, h->K, h->tapsP.p, h->scalar == PCX_I8, st);
         else if (slide && h->L == 1 && h->M == 1)
@@ -747,29 +835,28 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
 int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
     const size_t N = fir_iterations(h, in_elems, out_cap);
     if (N == 0) return PCX_OK;
     PCX_CHECK_ARG(in && out, "null buffer");
     const size_t esz = fir_elem_bytes(h), used_in = N + h->K - 1, n_out = (N / h->M) * h->L;
-    PCX_TRY(h->wsIn.ensure(used_in * esz));
-    PCX_TRY(h->wsOut.ensure(n_out * esz));
-    // one H2D, the kernel, one D2H.  (A chunked three-stream pipeline was measured on page-locked
-    // buffers: 5.4 ms against 4.8 ms for this form at 16 Mi samples -- the two PCIe directions did
-    // not overlap on this platform -- so the simple form stays.)
-    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, used_in * esz, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(pcx_fir_process_dev(h, h->wsIn.p, used_in, h->wsOut.p, n_out, consumed, produced, nullptr));
-    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, *produced * esz, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    // page-locked buffers (a pinned BufferManager's slabs): the kernels run on them in place; pageable ones are staged.
+    // Everything goes through the handle's own stream.
+    hipStream_t st;
+    PCX_TRY(ctx_own_stream(h->cx, &st));
+    const void *din; void *dout; bool staged;
+    PCX_TRY(stage_in(in, used_in * esz, h->wsIn, st, &din));
+    PCX_TRY(stage_out_begin(out, n_out * esz, h->wsOut, &dout, &staged));
+    PCX_TRY(pcx_fir_process_dev(h, din, used_in, dout, n_out, consumed, produced, st));
+    return stage_out_end(out, *produced * esz, dout, staged, st);
 }
 
 /* ===================================================================== *
  *  FFT
  * ===================================================================== */
 struct pcx_fft {
-    int device = -1;
+    ExecCtx cx;
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
@@ -804,7 +891,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     const size_t esz = 2 * (size_t)scalar_bytes(scalar);
     const bool pow2 = (num_bins & (num_bins - 1)) == 0;
     // single-workgroup LDS plans: the frame (x2 for ping-pong) must fit 160 KB
-    const bool r16_f64 = scalar == PCX_F64 && pow2 && num_bins >= 16 && num_bins <= 8192 && !(getenv("PCX_FFT_F64_POW2") && num_bins <= 4096);
+    const bool r16_f64 = scalar == PCX_F64 && pow2 && num_bins >= 16 && num_bins <= 8192 && !(PCX_ENV_SET("PCX_FFT_F64_POW2") && num_bins <= 4096);
     const bool r16 = (scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384) || r16_f64;
     // float power-of-two sizes beyond one workgroup: four-step around the short kernels (fft_large.hip)
     const size_t wg_limit = fft_single_wg_limit(scalar);
@@ -826,6 +913,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     pcx_fft *h = new (std::nothrow) pcx_fft();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->scalar = scalar; h->nbins = num_bins; h->inverse = inverse ? 1 : 0;
+    DeviceScope bind(h->cx.device);   // tables are uploaded below: the handle belongs to the creating thread's current device
     {   // kf_factor: 4s, then 2s, then 3, 5, 7, ... (kiss_fft.c:309-328)
         int n = (int)num_bins, p = 4;
         const double floor_sqrt = std::floor(std::sqrt((double)n));
@@ -843,10 +931,10 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     if (num_bins == 1) {
         h->kind = pcx_fft::IDENTITY;
     } else if (four_step && ((scalar == PCX_F32 && num_bins <= ((size_t)4 << 20)) || (scalar == PCX_F64 && num_bins <= ((size_t)2 << 20))) &&
-               !getenv("PCX_FFT_FIVE_PASS")) {
+               !PCX_ENV_SET("PCX_FFT_FIVE_PASS")) {
         h->kind = pcx_fft::FOURSTEP_SHORT;
         const size_t sub_limit = fft_single_wg_limit(scalar);   // longest row transform: 16384 (float) / 8192 (double) bins
-        static const size_t n1_forced = [] { const char *e = getenv("PCX_FFT_N1"); return e ? (size_t)atoi(e) : (size_t)0; }();
+        const size_t n1_forced = (size_t)PCX_ENV_INT("PCX_FFT_N1", 0);
         // measured (tools/sweep_fft.py): 128 columns per tile (256-byte runs) beat 256 except where only n1 = 256
         // leaves n2 <= 256 (65,536 bins: two passes instead of three) or n2 would exceed the 16384-bin plans
         h->n1 = num_bins == 65536 ? 256 : 128;
@@ -882,7 +970,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         h->kind = pcx_fft::R16;
         while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
         rc = upload(h->tw, make_tw_r16<double>(h->log2n));
-    } else if (!pow2 && fft_is_5_smooth(num_bins) && !getenv("PCX_FFT_KISS_ORDER") &&
+    } else if (!pow2 && fft_is_5_smooth(num_bins) && !PCX_ENV_SET("PCX_FFT_KISS_ORDER") &&
                ((scalar == PCX_F32 && num_bins < 8192) || (scalar == PCX_F64 && num_bins >= 256 && num_bins < 2048))) {
         // complex_float32 / complex_float64, 2^a 3^b 5^c bins: a float transform may take its radices in any order -- 16s first, then
         // 8 / 4 / 2, 6 / 15, 5s, 3s (fft_smooth_f32_kernel); kissfft's own order stays with the bit-exact Q15 path.
@@ -898,7 +986,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         for (size_t n = num_bins; n % 2 == 0; n /= 2) e2++;
         for (size_t n = num_bins; n % 3 == 0; n /= 3) e3++;
         for (size_t n = num_bins; n % 5 == 0; n /= 5) e5++;
-        const bool pairs = !getenv("PCX_FFT_SMOOTH_PRIMES");
+        const bool pairs = !PCX_ENV_SET("PCX_FFT_SMOOTH_PRIMES");
         for (; e2 >= 4; e2 -= 4) h->radix.push_back(16);
         if (e2 == 1 && e3 > 0 && pairs) { h->radix.push_back(6); e3--; }
         else if (e2 > 0) h->radix.push_back(1 << e2);
@@ -992,10 +1080,11 @@ int pcx_fft_destroy(pcx_fft *h) { delete h; return PCX_OK; }
 int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream)
 {
     PCX_CHECK_ARG(h, "null handle");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     if (nframes == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     hipStream_t st = as_stream(stream);
+    PCX_TRY(ctx_enter(h->cx, st));
     switch (h->kind) {
     case pcx_fft::IDENTITY:  // DFT of one point is the identity (kissfft leaf copy, kissfft.hh:94-98) -- except in Q15
         if (h->scalar == PCX_I16) return launch_fft_q15_one(in_dev, out_dev, nframes, st);
@@ -1046,24 +1135,24 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
 int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
 {
     PCX_CHECK_ARG(h, "null handle");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     if (nframes == 0) return PCX_OK;
     PCX_CHECK_ARG(in && out, "null buffer");
     const size_t bytes = nframes * h->nbins * 2 * (size_t)scalar_bytes(h->scalar);
-    PCX_TRY(h->wsIn.ensure(bytes));
-    PCX_TRY(h->wsOut.ensure(bytes));
-    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, bytes, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(pcx_fft_transform_dev(h, h->wsIn.p, h->wsOut.p, nframes, nullptr));
-    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, bytes, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    hipStream_t st;
+    PCX_TRY(ctx_own_stream(h->cx, &st));
+    const void *din; void *dout; bool staged;
+    PCX_TRY(stage_in(in, bytes, h->wsIn, st, &din));
+    PCX_TRY(stage_out_begin(out, bytes, h->wsOut, &dout, &staged));
+    PCX_TRY(pcx_fft_transform_dev(h, din, dout, nframes, st));
+    return stage_out_end(out, bytes, dout, staged, st);
 }
 
 /* ===================================================================== *
  *  FreqDemod
  * ===================================================================== */
 struct pcx_freqdemod {
-    int device = -1;
+    ExecCtx cx;
     int scalar = PCX_F32;
     DevBuf prev;  // two complex slots (ping-pong), holds _prev = conj(last input)
     int cur = 0;
@@ -1076,7 +1165,7 @@ int pcx_freqdemod_create(int scalar, pcx_freqdemod **out)
     pcx_freqdemod *h = new (std::nothrow) pcx_freqdemod();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->scalar = scalar;
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     int rc = h->prev.ensure(64);
     if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
     if (rc != PCX_OK) { delete h; return rc; }
@@ -1087,20 +1176,26 @@ int pcx_freqdemod_destroy(pcx_freqdemod *h) { delete h; return PCX_OK; }
 int pcx_freqdemod_reset(pcx_freqdemod *h)
 {
     PCX_CHECK_ARG(h, "null handle");
-    DeviceScope dev_scope(h->device);
-    PCX_HIP(hipMemset(h->prev.p, 0, 64));  // _prev = 0, FreqDemod.cpp:46
+    DeviceScope dev_scope(h->cx.device);
+    // _prev = 0, FreqDemod.cpp:46 -- enqueued behind the handle's previous call (its kernel still reads/writes prev) and
+    // ahead of the next one, whatever stream that arrives on (ctx_enter)
+    hipStream_t st = h->cx.have_last ? h->cx.last : nullptr;
+    if (!h->cx.have_last) PCX_TRY(ctx_own_stream(h->cx, &st));
+    PCX_TRY(ctx_enter(h->cx, st));
+    PCX_HIP(hipMemsetAsync(h->prev.p, 0, 64, st));
     h->cur = 0;
     return PCX_OK;
 }
 int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
     PCX_CHECK_ARG(h, "null handle");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     char *base = static_cast<char *>(h->prev.p);
     const void *pin = base + 32 * h->cur;
     void *pout = base + 32 * (h->cur ^ 1);
+    PCX_TRY(ctx_enter(h->cx, as_stream(stream)));
     PCX_TRY(launch_freqdemod(h->scalar, in_dev, out_dev, n, pin, pout, as_stream(stream)));
     h->cur ^= 1;
     return PCX_OK;
@@ -1108,41 +1203,69 @@ int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_de
 int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
 {
     PCX_CHECK_ARG(h, "null handle");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in && out, "null buffer");
     const size_t sb = (size_t)scalar_bytes(h->scalar);
-    PCX_TRY(h->wsIn.ensure(n * 2 * sb));
-    PCX_TRY(h->wsOut.ensure(n * sb));
-    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, n * 2 * sb, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(pcx_freqdemod_process_dev(h, h->wsIn.p, h->wsOut.p, n, nullptr));
-    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, n * sb, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    hipStream_t st;
+    PCX_TRY(ctx_own_stream(h->cx, &st));
+    const void *din; void *dout; bool staged;
+    PCX_TRY(stage_in(in, n * 2 * sb, h->wsIn, st, &din));
+    PCX_TRY(stage_out_begin(out, n * sb, h->wsOut, &dout, &staged));
+    PCX_TRY(pcx_freqdemod_process_dev(h, din, dout, n, st));
+    return stage_out_end(out, n * sb, dout, staged, st);
 }
 
 /* ===================================================================== *
  *  stateless maps
  * ===================================================================== */
-// host-buffer wrapper: stage in, run, stage out (one temporary device allocation pair
-// per thread, grown on demand)
+// host-buffer wrapper of the stateless maps: page-locked buffers are processed in place (device_alias), pageable ones
+// staged through a per-THREAD workspace -- the maps have no handle, and a Pothos block calls them from its own actor
+// thread -- that belongs to the thread's CURRENT device and owns a non-blocking stream.  When the thread's device changes
+// (pcx_set_device) the workspace is released and rebuilt on the new device.
 struct MapWs {
+    int device = -1;
+    hipStream_t st = nullptr;
     DevBuf in, out, in2, out2;
+    void drop()
+    {
+        in.release(); out.release(); in2.release(); out2.release();
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+        device = -1;
+    }
+    ~MapWs() { drop(); }
 };
 static thread_local MapWs g_mapws;
+static int map_ws(MapWs **out)
+{
+    int cur = -1;
+    PCX_HIP(hipGetDevice(&cur));
+    if (g_mapws.device != cur) {
+        if (g_mapws.device >= 0) {   // buffers and stream of the previous device: free them there
+            (void)hipSetDevice(g_mapws.device);
+            g_mapws.drop();
+            PCX_HIP(hipSetDevice(cur));
+        }
+        g_mapws.device = cur;
+    }
+    if (!g_mapws.st) PCX_HIP(hipStreamCreateWithFlags(&g_mapws.st, hipStreamNonBlocking));
+    *out = &g_mapws;
+    return PCX_OK;
+}
 
 template <typename F>
 static int run_host_map(const void *in, void *out, size_t in_bytes, size_t out_bytes, F &&launch)
 {
     if (in_bytes == 0) return PCX_OK;
     PCX_CHECK_ARG(in && out, "null buffer");
-    PCX_TRY(g_mapws.in.ensure(in_bytes));
-    PCX_TRY(g_mapws.out.ensure(out_bytes));
-    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, in, in_bytes, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(launch(g_mapws.in.p, g_mapws.out.p));
-    PCX_HIP(hipMemcpyAsync(out, g_mapws.out.p, out_bytes, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    MapWs *ws;
+    PCX_TRY(map_ws(&ws));
+    const void *din; void *dout; bool staged;
+    PCX_TRY(stage_in(in, in_bytes, ws->in, ws->st, &din));
+    PCX_TRY(stage_out_begin(out, out_bytes, ws->out, &dout, &staged));
+    PCX_TRY(launch(din, dout, ws->st));
+    return stage_out_end(out, out_bytes, dout, staged, ws->st);
 }
 
 int pcx_rotate_dev(int scalar, double pr, double pi, const void *in_dev, void *out_dev, size_t n, void *stream)
@@ -1156,7 +1279,7 @@ int pcx_rotate(int scalar, double pr, double pi, const void *in, void *out, size
 {
     PCX_CHECK_ARG(valid_scalar(scalar), "rotateFactory: unsupported type (scalar %d)", scalar);
     const size_t b = n * 2 * (size_t)scalar_bytes(scalar);
-    return run_host_map(in, out, b, b, [&](void *di, void *dout) { return launch_rotate(scalar, pr, pi, di, dout, n, nullptr); });
+    return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_rotate(scalar, pr, pi, di, dout, n, st); });
 }
 int pcx_scale_dev(int scalar, int is_complex, double factor, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
@@ -1169,7 +1292,7 @@ int pcx_scale(int scalar, int is_complex, double factor, const void *in, void *o
 {
     PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
     const size_t b = n * (is_complex ? 2 : 1) * (size_t)scalar_bytes(scalar);
-    return run_host_map(in, out, b, b, [&](void *di, void *dout) { return launch_scale(scalar, is_complex, factor, di, dout, n, nullptr); });
+    return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_scale(scalar, is_complex, factor, di, dout, n, st); });
 }
 int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
@@ -1183,7 +1306,7 @@ int pcx_abs(int scalar, int is_complex, const void *in, void *out, size_t n)
     PCX_CHECK_ARG(valid_scalar(scalar), "absFactory: unsupported type (scalar %d)", scalar);
     const size_t sb = (size_t)scalar_bytes(scalar);
     return run_host_map(in, out, n * (is_complex ? 2 : 1) * sb, n * sb,
-                        [&](void *di, void *dout) { return launch_abs(scalar, is_complex, di, dout, n, nullptr); });
+                        [&](const void *di, void *dout, hipStream_t st) { return launch_abs(scalar, is_complex, di, dout, n, st); });
 }
 int pcx_conj_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
@@ -1196,7 +1319,7 @@ int pcx_conj(int scalar, const void *in, void *out, size_t n)
 {
     PCX_CHECK_ARG(valid_scalar(scalar), "conjugateFactory: unsupported type (scalar %d)", scalar);
     const size_t b = n * 2 * (size_t)scalar_bytes(scalar);
-    return run_host_map(in, out, b, b, [&](void *di, void *dout) { return launch_conj(scalar, di, dout, n, nullptr); });
+    return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_conj(scalar, di, dout, n, st); });
 }
 
 int pcx_angle_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream)
@@ -1210,7 +1333,7 @@ int pcx_angle(int scalar, const void *in, void *out, size_t n)
 {
     PCX_CHECK_ARG(valid_scalar(scalar), "angleFactory: unsupported type (scalar %d)", scalar);
     const size_t sb = (size_t)scalar_bytes(scalar);
-    return run_host_map(in, out, n * 2 * sb, n * sb, [&](void *di, void *dout) { return launch_angle(scalar, di, dout, n, nullptr); });
+    return run_host_map(in, out, n * 2 * sb, n * sb, [&](const void *di, void *dout, hipStream_t st) { return launch_angle(scalar, di, dout, n, st); });
 }
 
 int pcx_arith_dev(int scalar, int is_complex, int op, const void *in0_dev, const void *in1_dev, void *out_dev, size_t n, void *stream)
@@ -1228,14 +1351,14 @@ int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *i
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in0 && in1 && out, "null buffer");
     const size_t b = n * (is_complex ? 2 : 1) * (size_t)scalar_bytes(scalar);
-    PCX_TRY(g_mapws.in.ensure(b));
-    PCX_TRY(g_mapws.in2.ensure(b));
-    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, in0, b, hipMemcpyHostToDevice, nullptr));
-    PCX_HIP(hipMemcpyAsync(g_mapws.in2.p, in1, b, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(launch_arith(scalar, is_complex, op, g_mapws.in.p, g_mapws.in2.p, g_mapws.in.p, n, nullptr));   // in place on the staged copy
-    PCX_HIP(hipMemcpyAsync(out, g_mapws.in.p, b, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    MapWs *ws;
+    PCX_TRY(map_ws(&ws));
+    const void *d0, *d1; void *dout; bool staged;
+    PCX_TRY(stage_in(in0, b, ws->in, ws->st, &d0));
+    PCX_TRY(stage_in(in1, b, ws->in2, ws->st, &d1));
+    PCX_TRY(stage_out_begin(out, b, ws->out, &dout, &staged));
+    PCX_TRY(launch_arith(scalar, is_complex, op, d0, d1, dout, n, ws->st));
+    return stage_out_end(out, b, dout, staged, ws->st);
 }
 int pcx_split_complex_dev(int scalar, const void *in_dev, void *re_dev, void *im_dev, size_t n, void *stream)
 {
@@ -1250,15 +1373,15 @@ int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n)
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in && re && im, "null buffer");
     const size_t b = n * (size_t)scalar_bytes(scalar);
-    PCX_TRY(g_mapws.in.ensure(2 * b));
-    PCX_TRY(g_mapws.out.ensure(b));
-    PCX_TRY(g_mapws.out2.ensure(b));
-    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, in, 2 * b, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(launch_split_complex(scalar, g_mapws.in.p, g_mapws.out.p, g_mapws.out2.p, n, nullptr));
-    PCX_HIP(hipMemcpyAsync(re, g_mapws.out.p, b, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipMemcpyAsync(im, g_mapws.out2.p, b, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    MapWs *ws;
+    PCX_TRY(map_ws(&ws));
+    const void *din; void *dre, *dim; bool sre, sim;
+    PCX_TRY(stage_in(in, 2 * b, ws->in, ws->st, &din));
+    PCX_TRY(stage_out_begin(re, b, ws->out, &dre, &sre));
+    PCX_TRY(stage_out_begin(im, b, ws->out2, &dim, &sim));
+    PCX_TRY(launch_split_complex(scalar, din, dre, dim, n, ws->st));
+    if (sre) PCX_HIP(hipMemcpyAsync(re, dre, b, hipMemcpyDeviceToHost, ws->st));
+    return stage_out_end(im, b, dim, sim, ws->st);
 }
 int pcx_combine_complex_dev(int scalar, const void *re_dev, const void *im_dev, void *out_dev, size_t n, void *stream)
 {
@@ -1273,22 +1396,21 @@ int pcx_combine_complex(int scalar, const void *re, const void *im, void *out, s
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(re && im && out, "null buffer");
     const size_t b = n * (size_t)scalar_bytes(scalar);
-    PCX_TRY(g_mapws.in.ensure(b));
-    PCX_TRY(g_mapws.in2.ensure(b));
-    PCX_TRY(g_mapws.out.ensure(2 * b));
-    PCX_HIP(hipMemcpyAsync(g_mapws.in.p, re, b, hipMemcpyHostToDevice, nullptr));
-    PCX_HIP(hipMemcpyAsync(g_mapws.in2.p, im, b, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(launch_combine_complex(scalar, g_mapws.in.p, g_mapws.in2.p, g_mapws.out.p, n, nullptr));
-    PCX_HIP(hipMemcpyAsync(out, g_mapws.out.p, 2 * b, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    MapWs *ws;
+    PCX_TRY(map_ws(&ws));
+    const void *dre, *dim; void *dout; bool staged;
+    PCX_TRY(stage_in(re, b, ws->in, ws->st, &dre));
+    PCX_TRY(stage_in(im, b, ws->in2, ws->st, &dim));
+    PCX_TRY(stage_out_begin(out, 2 * b, ws->out, &dout, &staged));
+    PCX_TRY(launch_combine_complex(scalar, dre, dim, dout, n, ws->st));
+    return stage_out_end(out, 2 * b, dout, staged, ws->st);
 }
 
 /* ===================================================================== *
  *  fused Rotate -> FIR -> FreqDemod
  * ===================================================================== */
 struct pcx_fmchain {
-    int device = -1;
+    ExecCtx cx;
     double phase = 0.0;
     bool phase_set = false;  // Rotate before setPhase: zero phasor (Rotate.cpp:60-62)
     std::vector<double> taps;
@@ -1312,7 +1434,7 @@ int pcx_fmchain_create(pcx_fmchain **out)
     pcx_fmchain *h = new (std::nothrow) pcx_fmchain();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->taps.assign(1, 1.0);
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     int rc = h->prev.ensure(64);
     if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
     if (rc != PCX_OK) { delete h; return rc; }
@@ -1337,14 +1459,19 @@ int pcx_fmchain_set_taps(pcx_fmchain *h, const double *taps, size_t ntaps, int c
 int pcx_fmchain_reset(pcx_fmchain *h)
 {
     PCX_CHECK_ARG(h, "null handle");
-    DeviceScope dev_scope(h->device);
-    PCX_HIP(hipMemset(h->prev.p, 0, 64));
+    DeviceScope dev_scope(h->cx.device);
+    // as pcx_freqdemod_reset: ordered behind the previous call and ahead of the next one
+    hipStream_t st = h->cx.have_last ? h->cx.last : nullptr;
+    if (!h->cx.have_last) PCX_TRY(ctx_own_stream(h->cx, &st));
+    PCX_TRY(ctx_enter(h->cx, st));
+    PCX_HIP(hipMemsetAsync(h->prev.p, 0, 64, st));
     h->cur = 0;
     return PCX_OK;
 }
 static int fmchain_sync(pcx_fmchain *h)
 {
     if (!h->dirty) return PCX_OK;
+    PCX_TRY(ctx_quiesce(h->cx));   // an earlier call's kernel may still be reading the tables rewritten below
     const size_t K = h->ntaps;
     h->K = K;
     h->Kp = (K + 7) / 8 * 8;
@@ -1393,7 +1520,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
                             size_t *consumed, size_t *produced, void *stream)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
     PCX_TRY(fmchain_sync(h));
     if (in_elems < h->K) return PCX_OK;
@@ -1401,6 +1528,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     if (N == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     char *base = static_cast<char *>(h->prev.p);
+    PCX_TRY(ctx_enter(h->cx, as_stream(stream)));
     int algo = h->algo;
     if (algo == PCX_FIR_AUTO && !h->have_ols) {
         // K > 2048: two launches (FIR with the folded phasor, then FreqDemod) sharing the chain's carried state
@@ -1431,7 +1559,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
 int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
 {
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
-    DeviceScope dev_scope(h->device);
+    DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
     PCX_TRY(fmchain_sync(h));
     if (in_elems < h->K) return PCX_OK;
@@ -1439,12 +1567,11 @@ int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *o
     if (N == 0) return PCX_OK;
     PCX_CHECK_ARG(in && out, "null buffer");
     const size_t used = N + h->K - 1;
-    PCX_TRY(h->wsIn.ensure(used * 8));
-    PCX_TRY(h->wsOut.ensure(N * 4));
-    PCX_HIP(hipMemcpyAsync(h->wsIn.p, in, used * 8, hipMemcpyHostToDevice, nullptr));
-    PCX_TRY(pcx_fmchain_process_dev(h, h->wsIn.p, used, h->wsOut.p, N, consumed, produced, nullptr));
-    PCX_HIP(hipMemcpyAsync(out, h->wsOut.p, N * 4, hipMemcpyDeviceToHost, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
-    return PCX_OK;
+    hipStream_t st;
+    PCX_TRY(ctx_own_stream(h->cx, &st));
+    const void *din; void *dout; bool staged;
+    PCX_TRY(stage_in(in, used * 8, h->wsIn, st, &din));
+    PCX_TRY(stage_out_begin(out, N * 4, h->wsOut, &dout, &staged));
+    PCX_TRY(pcx_fmchain_process_dev(h, din, used, dout, N, consumed, produced, st));
+    return stage_out_end(out, N * 4, dout, staged, st);
 }
-

@@ -73,6 +73,21 @@ struct DevBuf {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A/B and diagnostic switches.  The PRODUCT library (libpcx_hip.so) ignores the process environment
+// entirely: every switch is its measured-best default, compiled in.  Only the diagnostic build
+// (make diag -> libpcx_hip_diag.so, -DPCX_DIAG, loaded by tools/ through PCX_HIP_LIBRARY) reads the
+// PCX_* variables -- once per process, cached in a function-local static.
+#ifdef PCX_DIAG
+#include <cstdlib>
+#define PCX_ENV_INT(name, dflt) ([]() -> long { static const long v_ = []() -> long { const char *e_ = getenv(name); return e_ ? atol(e_) : (long)(dflt); }(); return v_; }())
+#define PCX_ENV_SET(name) ([]() -> bool { static const bool v_ = getenv(name) != nullptr; return v_; }())
+#else
+inline long env_off(long v) { return v; }
+inline bool env_off(bool v) { return v; }
+#define PCX_ENV_INT(name, dflt) (::pcx::env_off((long)(dflt)))
+#define PCX_ENV_SET(name) (::pcx::env_off(false))
+#endif
+
 // grid size for an HBM-bound grid-stride kernel: enough blocks to fill 256 CUs x 8
 inline unsigned stream_grid(size_t work_items, unsigned block)
 {

@@ -374,3 +374,55 @@ def fill_uniform_f32_dev(t, seed, offset=0, stream=None):
     """Fill a float32 CUDA tensor with the deterministic synthetic stream (uniform [-1,1))."""
     _lib.check(_lib.load().pcx_fill_uniform_f32_dev(_dev_ptr(t), t.numel(), seed, offset, _stream_ptr(stream)))
     return t
+
+
+class NodeStream(_Handle):
+    """pcx_shard_*: ONE complex_float32 stream over several devices from ONE process -- per-device FIR handles and
+    streams, the tap-length halo exchanged natively by RCCL send/recv (or peer copies), include/pcx.h."""
+    _destroy = "pcx_shard_destroy"
+    RCCL, PEER_COPY = 0, 1
+
+    def __init__(self, devices, transport=0):
+        super().__init__()
+        devs = (C.c_int * len(devices))(*devices)
+        _lib.check(_lib.load().pcx_shard_create(len(devices), devs, transport, C.byref(self._h)))
+        self.nshards = len(devices)
+
+    def set_taps(self, taps, complex_taps=True):
+        t = np.asarray(taps)
+        if complex_taps:
+            t = np.ascontiguousarray(t.astype(np.complex128)).view(np.float64)
+            n = t.size // 2
+        else:
+            t = np.ascontiguousarray(np.real(t).astype(np.float64))
+            n = t.size
+        _lib.check(_lib.load().pcx_shard_set_taps(self._h, t.ctypes.data_as(C.POINTER(C.c_double)), n, int(complex_taps)))
+        self.K = n
+
+    def set_algo(self, algo):
+        _lib.check(_lib.load().pcx_shard_set_algo(self._h, algo))
+
+    def configure(self, shard_elems):
+        _lib.check(_lib.load().pcx_shard_configure(self._h, shard_elems))
+        self.C = shard_elems
+
+    def buffers(self, g):
+        """(in_dev, out_dev, stream, device) of shard g as integers."""
+        i, o, s, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        _lib.check(_lib.load().pcx_shard_buffers(self._h, g, C.byref(i), C.byref(o), C.byref(s), C.byref(d)))
+        return i.value, o.value, s.value, d.value
+
+    def scatter(self, x):
+        xp = as_pairs(x)
+        _lib.check(_lib.load().pcx_shard_scatter(self._h, _np_ptr(xp), xp.shape[0]))
+
+    def step(self):
+        _lib.check(_lib.load().pcx_shard_step(self._h))
+
+    def sync(self):
+        _lib.check(_lib.load().pcx_shard_sync(self._h))
+
+    def gather(self):
+        y = np.empty((self.nshards * self.C, 2), np.float32)
+        _lib.check(_lib.load().pcx_shard_gather(self._h, _np_ptr(y), y.shape[0]))
+        return y

@@ -1,0 +1,98 @@
+"""GPU suite: the HIP path against the committed golden vectors DIRECTLY -- no oracle in between.
+
+tests/golden/golden.npz holds the reference tests' own known-answer data and outputs of the compiled reference
+(oracle/_ref: fft/kissfft.hh, fft/kiss_fft.c, functions/fxpt_atan2.cpp built from /root/reference, see
+tests/golden/make_golden.py).  Integer results must be bit-identical; float32 / float64 transforms within the 1e-5
+(north_star) / 1e-13 bars of the largest reference sample, float angles within 1e-5 of pi."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, ang_err, nerr
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+TYPES = ["int8", "int16", "int32", "int64", "float32", "float64"]
+FFT_SIZES = [2, 3, 4, 5, 8, 9, 15, 16, 20, 64, 100, 210, 256, 1024, 4096]
+
+
+@pytest.mark.parametrize("inv", [0, 1])
+@pytest.mark.parametrize("n", FFT_SIZES)
+def test_fft_against_compiled_kissfft_outputs(dev, n, inv):
+    """fft/kissfft.hh (float, double) and fft/kiss_fft.c (Q15) outputs on seeded frames"""
+    seen = 0
+    for kind, dtype, bar in (("f32", "complex_float32", TOL), ("f64", "complex_float64", 1e-13), ("i16", "complex_int16", 0)):
+        key = "fft_%s_in_%d_%d" % (kind, n, inv)
+        if key not in GOLD:
+            continue
+        seen += 1
+        want = GOLD["fft_%s_out_%d_%d" % (kind, n, inv)]
+        got = dev.Fft(dtype, n, bool(inv)).transform(GOLD[key])
+        if bar == 0:
+            assert np.array_equal(got, want), kind
+        else:
+            assert nerr(got, want) <= bar, kind
+    assert seen
+
+
+def test_fft_reference_test_known_answers(dev):
+    """fft/TestFFT.cpp:14-29 (float) and :95-156 (int16: forward = DFT / N, inverse of the unscaled spectrum = input)"""
+    x = GOLD["fft_kat_in"]
+    want = GOLD["fft_kat_out"]
+    got = dev.Fft("complex_float32", 4, False).transform(x.astype(np.float32))
+    assert np.max(np.abs(got - want)) < 0.01                           # the reference test's own tolerance
+    back = dev.Fft("complex_float32", 4, True).transform(want.astype(np.float32))
+    assert np.max(np.abs(back - 4 * x)) < 0.01
+    xi = (x * 1000).astype(np.int16)
+    gi = dev.Fft("complex_int16", 4, False).transform(xi)
+    assert np.array_equal(gi, np.array([[100, 550], [250, 350], [0, 150], [50, -450]], np.int16))
+    bi = dev.Fft("complex_int16", 4, True).transform((want * 1000).astype(np.int16))
+    assert np.max(np.abs(bi.astype(np.int32) - xi)) <= 1
+
+
+def test_fxpt_atan2_through_int16_angle(dev):
+    """functions/fxpt_atan2.cpp on 2048 (y, x) pairs: /comms/angle of complex_int16 is getAngle = fxpt_atan2(imag, real)
+    reinterpreted as int16 (FxptHelpers.hpp:14-29)"""
+    yx = GOLD["atan2_in"]
+    z = np.ascontiguousarray(yx[:, ::-1])            # (re, im) = (x, y)
+    got = dev.angle(z)
+    assert np.array_equal(got.view(np.uint16), GOLD["atan2_out"])
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_angle_and_abs_against_compiled_reference_outputs(dev, name):
+    z = GOLD["rand_in_" + name]
+    ga = dev.angle(z)
+    gc = dev.abs_(z, True)
+    gr = dev.abs_(np.ascontiguousarray(z[:, 0]), False)
+    if name.startswith("float"):
+        assert ang_err(ga, GOLD["rand_angle_" + name]) <= TOL
+        if name == "float64":
+            assert nerr(gc, GOLD["rand_abs_cplx_" + name]) <= 4e-15       # device hypot vs glibc hypot: <= 2 ulp
+        else:
+            assert np.array_equal(gc, GOLD["rand_abs_cplx_" + name], equal_nan=True)
+    else:
+        assert np.array_equal(ga, GOLD["rand_angle_" + name])
+        assert np.array_equal(gc, GOLD["rand_abs_cplx_" + name])
+    assert np.array_equal(gr, GOLD["rand_abs_real_" + name])
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_reference_test_points_angle_abs(dev, name):
+    """math/TestAngle.cpp:30-65 (13 points) and the inputs of math/TestAbs.cpp through the compiled getAngle / getAbs"""
+    zin = GOLD["angle_in_" + name]
+    g = dev.angle(zin)
+    if name.startswith("float"):
+        assert ang_err(g, GOLD["angle_ref_" + name]) <= TOL
+    else:
+        assert np.array_equal(g, GOLD["angle_ref_" + name])
+    a = GOLD["abs_in_" + name]
+    assert np.array_equal(dev.abs_(a, False), GOLD["abs_real_exp_" + name])
+    zc = np.ascontiguousarray(a.reshape(-1, 2))
+    gc = dev.abs_(zc, True)
+    want = GOLD["abs_cplx_exp_" + name]
+    if name == "float64":
+        assert nerr(gc, want) <= 4e-15          # device hypot vs glibc hypot: <= 2 ulp
+    else:
+        assert np.array_equal(gc, want)         # getAbs compiled from the reference: float32 and the integers bit for bit

@@ -1,4 +1,4 @@
-"""CPU suite (-m "not gpu"): pins the oracle.
+"""Pins the oracle -- on the build box (-m "not gpu") and again on the GPU box (-m gpu), see `_where`.
 
   * against the committed golden vectors (tests/golden/golden.npz: the reference tests' own
     known-answer data + outputs of the compiled reference, see make_golden.py),
@@ -15,6 +15,17 @@ import pytest
 from tests.util import NAMES, SCALARS, nerr, rand_stream
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+
+
+# Every test of this module runs on BOTH boxes: as "[build-box]" under -m "not gpu" and as "[gpu-box]" under -m gpu.
+# The oracle is the checker of the GPU parity tests, and on the GPU box libpcx_oracle.so binds THAT box's glibc and
+# libgcc_s (sincos, hypotf, __divsc3: the last-bit effects ROUND_NOTES lists): it is re-pinned there, against the same
+# golden vectors, before anything is compared with it.
+@pytest.fixture(autouse=True, params=[pytest.param("build-box"), pytest.param("gpu-box", marks=pytest.mark.gpu)])
+def _where(request):
+    return request.param
+
+
 TYPES = {"int8": np.int8, "int16": np.int16, "int32": np.int32, "int64": np.int64, "float32": np.float32, "float64": np.float64}
 
 

@@ -1,0 +1,111 @@
+"""GPU suite: the NATIVE multi-device driver of include/pcx.h (pcx_shard_*): one process, per-device FIR handles and
+streams, the K-1 halo moved by RCCL send/recv -- or by peer copies, which lets this one-GPU box run several shards.
+The concatenated shard outputs must equal the oracle's single-stream result (no seam), and a one-device RCCL run must
+be bit-identical to pcx_fir_process_dev on the whole stream."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, nerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_fir(o, taps, x, n):
+    blk = o.Fir(o.F32, True, True)
+    blk.set_taps(taps)
+    blk.activate()
+    ref, c, p, _ = blk.work(x, n)
+    assert p == n
+    return ref
+
+
+def _poison_halos(ns):
+    """NaN into every halo slot but shard 0's: only a working exchange can make the result right."""
+    from pothoscomms_amd import _lib
+    L = _lib.load()
+    nan = np.full((ns.K - 1, 2), np.nan, np.float32)
+    for g in range(1, ns.nshards):
+        i, _, s, _ = ns.buffers(g)
+        _lib.check(L.pcx_memcpy_h2d(C.c_void_p(i), nan.ctypes.data_as(C.c_void_p), nan.nbytes, C.c_void_p(s)))
+        _lib.check(L.pcx_stream_sync(C.c_void_p(s)))
+
+
+@pytest.mark.parametrize("G,Cs", [(2, 40000), (4, 9000), (3, 3000), (2, 254)])
+def test_peer_copy_shards_on_one_device_have_no_seam(oracle, G, Cs):
+    from pothoscomms_amd import device, taps as tp
+    h = tp.c1_taps()
+    K = len(h)
+    x = oracle.fill_uniform_f32(2 * (K - 1 + G * Cs), 2, 0).reshape(-1, 2)
+    ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+    ns.set_taps(h)
+    ns.configure(Cs)
+    ns.scatter(x)
+    for rep in range(2):          # the second pass re-receives into a halo slot the first pass's head kernel read
+        _poison_halos(ns)
+        ns.step()
+        got = ns.gather()
+        ref = _oracle_fir(oracle, h, x, G * Cs)
+        assert np.isfinite(got).all()
+        assert nerr(got, ref) <= TOL
+
+
+def test_rccl_one_device_equals_the_plain_call(oracle):
+    """RCCL transport with a communicator of one: exercises the rccl.h path (dlopen, ncclCommInitAll, destroy) on this
+    box; the pass itself must be bit-identical to pcx_fir_process_dev on the whole stream."""
+    import torch
+
+    from pothoscomms_amd import device, taps as tp
+    h = tp.c1_taps()
+    K, n = len(h), 100000
+    x = oracle.fill_uniform_f32(2 * (K - 1 + n), 2, 0).reshape(-1, 2)
+    ns = device.NodeStream([0], device.NodeStream.RCCL)
+    ns.set_taps(h)
+    ns.configure(n)
+    ns.scatter(x)
+    ns.step()
+    got = ns.gather()
+    f = device.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h)
+    # the same placement as the shard buffer: the samples (not the history) on a 128-byte line
+    lead = (-(K - 1)) % 16
+    xa = torch.zeros((lead + K - 1 + n, 2), dtype=torch.float32, device="cuda:0")
+    xa[lead:] = torch.from_numpy(x).cuda()
+    y = torch.empty((n, 2), dtype=torch.float32, device="cuda:0")
+    c, p = f.process_dev(xa[lead:], y)
+    assert (c, p) == (n, n)
+    assert np.array_equal(got, y.cpu().numpy())
+    assert nerr(got, _oracle_fir(oracle, h, x, n)) <= TOL
+
+
+def test_rccl_refuses_two_shards_on_one_device():
+    from pothoscomms_amd import _lib, device
+    with pytest.raises(_lib.InvalidArgument):
+        device.NodeStream([0, 0], device.NodeStream.RCCL)
+
+
+def test_real_taps_and_retap_between_passes(oracle):
+    """REAL taps go in as complex taps with zero imaginary parts; new taps of another length re-lay the buffers."""
+    from pothoscomms_amd import _lib, device, taps as tp
+    ns = device.NodeStream([0, 0], device.NodeStream.PEER_COPY)
+    h = tp.c4_taps()
+    ns.set_taps(h, complex_taps=False)
+    ns.configure(20000)
+    x = oracle.fill_uniform_f32(2 * (len(h) - 1 + 2 * 20000), 5, 0).reshape(-1, 2)
+    ns.scatter(x)
+    ns.step()
+    blk = oracle.Fir(oracle.F32, True, False)
+    blk.set_taps(h)
+    blk.activate()
+    ref, _, p, _ = blk.work(x, 2 * 20000)
+    assert nerr(ns.gather(), ref) <= TOL
+    ns.set_taps(tp.c0_taps())
+    with pytest.raises(_lib.InvalidArgument):
+        ns.step()                     # buffers were dropped with the old halo size: configure again
+    ns.configure(5000)
+    h0 = tp.c0_taps()
+    x0 = oracle.fill_uniform_f32(2 * (len(h0) - 1 + 2 * 5000), 1, 0).reshape(-1, 2)
+    ns.scatter(x0)
+    ns.step()
+    assert nerr(ns.gather(), _oracle_fir(oracle, h0, x0, 2 * 5000)) <= TOL

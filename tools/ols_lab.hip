@@ -33,7 +33,7 @@ using namespace pcx::fft4k;
 
 struct Stamp { unsigned long long t0, r0, t1, r1; };
 
-enum { MODE_FULL = 0, MODE_MEM = 1, MODE_DOSE = 2, MODE_SWAP = 3 };
+enum { MODE_FULL = 0, MODE_MEM = 1, MODE_DOSE = 2, MODE_SWAP = 3, MODE_LATE = 4 };   // LATE: full pipeline, the next block's loads issued BEFORE this block's stores
 
 // the product's three passes (fft4096.hpp pass1/2/3) with a barrier mask -- TIMING ONLY when a bit is off:
 //   bit 0: the write-after-read barriers (in front of each LDS scatter: "previous readers are done")
@@ -148,23 +148,32 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
     cf acc[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = cf{0.f, 0.f};
+    auto fetch = [&](cf (&dst)[16], size_t blk) {
+        // blocks 1 .. nblocks-2 only (the harness sizes the buffers so every window is inside)
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + blk * S, N * 8);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32x2 t = (r < 1 || r >= 15) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 0)
+                                               : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 2);
+            dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+        }
+    };
+    cf nx[16];
+    if (MODE == MODE_LATE) fetch(nx, b);
     for (; b < nblocks; b += gridDim.x) {
         cf v[16];
-        {
-            // blocks 1 .. nblocks-2 only (the harness sizes the buffers so every window is inside)
-            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + b * S, N * 8);
+        if (MODE == MODE_LATE) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const u32x2 t = (r < 1 || r >= 15) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 0)
-                                                   : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 2);
-                v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
-            }
+            for (int r = 0; r < 16; r++) v[r] = nx[r];
+        } else {
+            fetch(v, b);
         }
         cf u[16];
-        if (MODE == MODE_FULL) {
-            xpass1<DOSE>(v, lds, j);
-            xpass2<DOSE>(v, lds, j);
-            xpass3<DOSE>(v, lds, j, tw3);
+        if (MODE == MODE_FULL || MODE == MODE_LATE) {
+            constexpr int BM = MODE == MODE_LATE ? 3 : DOSE;
+            xpass1<BM>(v, lds, j);
+            xpass2<BM>(v, lds, j);
+            xpass3<BM>(v, lds, j, tw3);
 #pragma unroll
             for (int q = 0; q < 16; q += 2) {
                 const int k0 = bin_of(q), k1 = bin_of(q + 1);
@@ -172,9 +181,9 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
                 u[k1] = v[q + 1];
                 cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
             }
-            xpass1<DOSE>(u, lds, j);
-            xpass2<DOSE>(u, lds, j);
-            xpass3<DOSE>(u, lds, j, tw3);
+            xpass1<BM>(u, lds, j);
+            xpass2<BM>(u, lds, j);
+            xpass3<BM>(u, lds, j, tw3);
         } else if (MODE == MODE_SWAP) {
             LaneTw tw;
             fft16_twout(v, tw3);                  // over the register digit a; output twiddle W4096^(j k0)
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
                 }
             }
         }
+        if (MODE == MODE_LATE && b + gridDim.x < nblocks) fetch(nx, b + gridDim.x);   // ahead of the stores in the in-order vmcnt queue
         const size_t room = n_out - b * S;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)((room < S ? room : S) * 8));
         const unsigned vbase = (unsigned)(j - Kov) * 8u;
@@ -331,6 +341,7 @@ static KernFn pick(int mode, int dose, int wgpc)
     }
     if (mode == MODE_MEM) return kern<MODE_MEM, 0, 4>();
     if (mode == MODE_SWAP) return kern<MODE_SWAP, 0, 4>();
+    if (mode == MODE_LATE) return kern<MODE_LATE, 0, 4>();
     switch (dose) {
     case 160: return kern<MODE_DOSE, 160, 4>();
     case 320: return kern<MODE_DOSE, 320, 4>();
@@ -363,20 +374,19 @@ int main(int argc, char **argv)
     const unsigned grid = [&] { const size_t slots = 1024, rounds = (nblocks + slots - 1) / slots; return (unsigned)((nblocks + rounds - 1) / rounds); }();
     const Cfg cfgs[] = {
         {"full all barriers  random", MODE_FULL, 3, 4, false, 0.f},
-        {"digit-swap (4 bar) random", MODE_SWAP, 0, 4, false, 0.f},
-        {"full no barriers   random", MODE_FULL, 0, 4, false, 0.f},
+        {"late prefetch      random", MODE_LATE, 0, 4, false, 0.f},
         {"mem only", MODE_MEM, 0, 4, false, 0.f},
         {"full all barriers  random", MODE_FULL, 3, 4, false, 0.f},
-        {"digit-swap (4 bar) random", MODE_SWAP, 0, 4, false, 0.f},
+        {"late prefetch      random", MODE_LATE, 0, 4, false, 0.f},
         {"full all barriers  zero-in", MODE_FULL, 3, 4, true, 0.f},
-        {"digit-swap (4 bar) zero-in", MODE_SWAP, 0, 4, true, 0.f},
+        {"late prefetch      zero-in", MODE_LATE, 0, 4, true, 0.f},
     };
     {   // parity of the digit-swap pipeline against the product pipeline on the same random input
         float2 *y2;
         CK(hipMalloc(&y2, (nblocks * S + 64) * 8));
         hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (float *)x, in_elems * 2, 2ull, 0);
         hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, 0.f, st);
-        hipLaunchKernelGGL((lab_kernel<MODE_SWAP, 0, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st);
+        hipLaunchKernelGGL((lab_kernel<MODE_LATE, 0, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st);
         CK(hipDeviceSynchronize());
         const size_t cmp = 4u << 20;
         std::vector<float> a(2 * cmp), b(2 * cmp);
@@ -384,7 +394,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(b.data(), y2, cmp * 8, hipMemcpyDeviceToHost));
         double mx = 0, md = 0;
         for (size_t i = 0; i < 2 * cmp; i++) { mx = std::max(mx, (double)std::fabs(a[i])); md = std::max(md, (double)std::fabs(a[i] - b[i])); }
-        printf("# parity digit-swap vs product pipeline over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
+        printf("# parity late-prefetch vs product pipeline over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
         CK(hipFree(y2));
     }
     printf("# 255-tap geometry: Kov=%d S=%zu blocks=%zu grid=%u, %zu samples, %.1f s per configuration\n", Kov, S, nblocks, grid, n, secs);

@@ -71,6 +71,11 @@ PCXB_API int pcxb_connect_signal(pcxb_block *src, const char *signal, pcxb_block
 /* the first input / output port's type (indexed port 0, or the first named port) and the buffer managers the block requests */
 PCXB_API int pcxb_port_dtype(pcxb_block *b, int is_output, char *name, size_t cap, size_t *dimension, size_t *bytes);
 PCXB_API int pcxb_buffer_manager(pcxb_block *b, int is_output, char *name, size_t cap, size_t *buffer_size);
+/* What the scheduler does with the manager a block returns: draw the next port buffer from it (round-robin over the
+ * manager's slabs; a slab is at least max(min_bytes, the manager's bufferSize) long).  The device-backed blocks hand
+ * out page-locked slabs (*pinned = 1), on which the C ABI runs its kernels directly -- a work() loop over these
+ * buffers pays no staging copy.  The memory belongs to the block and lives until pcxb_destroy. */
+PCXB_API int pcxb_acquire_buffer(pcxb_block *b, int is_output, size_t min_bytes, void **ptr, size_t *bytes, int *pinned);
 /* the reserve a block asked for at construction time (FFT: numBins); SIZE_MAX = none */
 PCXB_API int pcxb_initial_reserve(pcxb_block *b, size_t *reserve);
 

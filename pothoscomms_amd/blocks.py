@@ -61,6 +61,7 @@ def load():
     L.pcxb_port_dtype.argtypes = [vp, i, cp, sz, C.POINTER(sz), C.POINTER(sz)]
     L.pcxb_buffer_manager.argtypes = [vp, i, cp, sz, C.POINTER(sz)]
     L.pcxb_initial_reserve.argtypes = [vp, C.POINTER(sz)]
+    L.pcxb_acquire_buffer.argtypes = [vp, i, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.pcxb_call_sizes.argtypes = [vp, cp, C.POINTER(sz), sz]
     L.pcxb_get_sizes.argtypes = [vp, cp, C.POINTER(sz), sz, C.POINTER(sz)]
     L.pcxb_num_ports.argtypes = [vp, i, C.POINTER(sz)]
@@ -232,6 +233,15 @@ class Block:
         _check(load().pcxb_buffer_manager(self._h, int(is_output), name, 64, C.byref(sz)))
         return name.value.decode(), sz.value
 
+    def port_buffer(self, is_output, shape, dtype):
+        """The next port buffer from the manager the block handed the scheduler (pcxb_acquire_buffer), as a numpy
+        array of `shape` / `dtype` over the slab -- page-locked for the device-backed blocks.  Returns (array, pinned)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p, sz, pin = C.c_void_p(), C.c_size_t(), C.c_int()
+        _check(load().pcxb_acquire_buffer(self._h, int(is_output), nbytes, C.byref(p), C.byref(sz), C.byref(pin)))
+        arr = np.ctypeslib.as_array((C.c_char * nbytes).from_address(p.value)).view(dtype).reshape(shape)
+        return arr, bool(pin.value)
+
     def initial_reserve(self):
         r = C.c_size_t()
         load().pcxb_initial_reserve(self._h, C.byref(r))
@@ -274,12 +284,17 @@ class Block:
         produced = [int(v) for v in prod]
         return [y[:p * port[2]] for y, p, port in zip(ys, produced, op)], [int(v) for v in cons], produced
 
-    def work(self, inbuf, out_elems, labels=()):
-        """One work() call.  Returns (out[:produced], consumed, produced, reserve, posted_labels)."""
+    def work(self, inbuf, out_elems, labels=(), outbuf=None):
+        """One work() call.  Returns (out[:produced], consumed, produced, reserve, posted_labels).
+        outbuf: write into this array (e.g. a slab from port_buffer) instead of a fresh one."""
         x = as_pairs(inbuf)
         scalar, cplx = parse_dtype(self.out_dtype)
         shape = [out_elems * self.out_dim] + ([2] if cplx else [])
-        y = np.zeros(shape, dtype=NP_SCALAR[scalar])
+        if outbuf is None:
+            y = np.zeros(shape, dtype=NP_SCALAR[scalar])
+        else:
+            y = outbuf
+            assert y.flags.c_contiguous and y.dtype == NP_SCALAR[scalar] and y.size >= int(np.prod(shape))
         in_elems = x.shape[0] // self.in_dim
         labs = (PcxbLabel * max(1, len(labels)))()
         for i, l in enumerate(labels):

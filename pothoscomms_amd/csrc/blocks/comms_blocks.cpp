@@ -88,9 +88,35 @@ void check(int rc, const std::string &where)
 }
 
 /***********************************************************************
+ * Port buffers of a device-backed block: page-locked slabs
+ *
+ * A Pothos block may hand the scheduler its own buffer managers (the reference does: FIRFilter.cpp:196-199 asks for a
+ * circular input buffer, FFT.cpp:54-59 for frame-sized output slabs).  Every block of this module asks for PINNED slabs
+ * on both sides: the C ABI then runs its kernels directly on the port buffers over PCIe instead of staging them
+ * (include/pcx.h; 43 GB/s each way against 28 staged, tools/pcie_lab.hip) -- a plain work() loop gets that without
+ * the topology doing anything.  8 MiB x 4 per port: one call covers ~1 Mi complex_float32 samples.
+ **********************************************************************/
+constexpr size_t kPortSlabBytes = 8u << 20;
+static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
+{
+    pcxfw::BufferManagerArgs args;
+    args.bufferSize = slabBytes;
+    args.numBuffers = 4;
+#ifndef PCX_WITH_POTHOS
+    args.pinned = true;
+#endif
+    return pcxfw::BufferManager::make(name, args);
+}
+class DeviceBlock : public Block {
+public:
+    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }
+    pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }
+};
+
+/***********************************************************************
  * /comms/fir_filter
  **********************************************************************/
-class FIRFilter : public Block {
+class FIRFilter : public DeviceBlock {
 public:
     FIRFilter(const DType &dtype, int scalar, bool cplx, bool complexTaps)
         : _complexTaps(complexTaps), _elemBytes(dtype.size()), M(1), L(1), K(1), _inputRequire(1),
@@ -184,7 +210,7 @@ public:
     // the sliding window needs its K-1 history contiguous in front of new samples
     pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &)
     {
-        return pcxfw::BufferManager::make("circular");
+        return pinnedManager("circular");
     }
 
     void activate()
@@ -298,7 +324,7 @@ pcxfw::BlockRegistry registerFIRFilterOldPath("/blocks/fir_filter", &FIRFilterFa
 /***********************************************************************
  * /comms/fft
  **********************************************************************/
-class FFT : public Block {
+class FFT : public DeviceBlock {
 public:
     // a device launch per 4096-sample frame would be launch-bound: the block asks for output
     // slabs of several frames and transforms every whole frame present in one call.  Totals
@@ -317,14 +343,12 @@ public:
 
     pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &)
     {
-        pcxfw::BufferManagerArgs args;
         // several frames per slab so one call amortises the PCIe round trip, but never less than one
         // frame (the reference's own request, FFT.cpp:54-59) nor slabs beyond 16 MiB for long transforms
         const size_t frame = _numBins * _elemBytes;
         size_t frames = kFramesPerSlab;
         while (frames > 1 && frame * frames > (16u << 20)) frames /= 2;
-        args.bufferSize = frame * frames;
-        return pcxfw::BufferManager::make("generic", args);
+        return pinnedManager("generic", frame * frames);
     }
 
     void work()
@@ -360,7 +384,7 @@ pcxfw::BlockRegistry registerFFT("/comms/fft", &FFTFactory);
 /***********************************************************************
  * /comms/freq_demod
  **********************************************************************/
-class FreqDemod : public Block {
+class FreqDemod : public DeviceBlock {
 public:
     FreqDemod(const DType &dtype, int scalar) : _h(nullptr)
     {
@@ -398,7 +422,7 @@ pcxfw::BlockRegistry registerFreqDemod("/comms/freq_demod", &FreqDemodFactory);
  * shared by Rotate and Scale: a coefficient that an upstream label may replace mid-stream
  **********************************************************************/
 template <typename Derived>
-class LabelDrivenMap : public Block {
+class LabelDrivenMap : public DeviceBlock {
 protected:
     // returns the number of elements to process this call, after applying a label that
     // sits at the front and cutting the call short before the next matching label
@@ -520,7 +544,7 @@ pcxfw::BlockRegistry registerScale("/comms/scale", &scaleFactory);
 /***********************************************************************
  * /comms/abs, /comms/conjugate
  **********************************************************************/
-class Abs : public Block {
+class Abs : public DeviceBlock {
 public:
     Abs(const DType &dtype, int scalar, bool cplx) : _scalar(scalar), _cplx(cplx)
     {
@@ -554,7 +578,7 @@ Block *absFactory(const DType &dtype)
 pcxfw::BlockRegistry registerAbs("/comms/abs", &absFactory);
 
 // /comms/angle (math/Angle.cpp:50-110): the first "next" sibling, shares getAngle with FreqDemod
-class Angle : public Block {
+class Angle : public DeviceBlock {
 public:
     Angle(const DType &dtype, int scalar) : _scalar(scalar)
     {
@@ -586,7 +610,7 @@ Block *angleFactory(const DType &dtype)
 }
 pcxfw::BlockRegistry registerAngle("/comms/angle", &angleFactory);
 
-class Conjugate : public Block {
+class Conjugate : public DeviceBlock {
 public:
     Conjugate(const DType &dtype, int scalar) : _scalar(scalar)
     {
@@ -621,7 +645,7 @@ pcxfw::BlockRegistry registerConjugate("/comms/conjugate", &conjugateFactory);
 /***********************************************************************
  * /comms/arithmetic (+ /blocks/arithmetic)   math/Arithmetic.cpp:150-305   
  **********************************************************************/
-class Arithmetic : public Block {
+class Arithmetic : public DeviceBlock {
 public:
     Arithmetic(const DType &dtype, int scalar, bool cplx, int op) : _scalar(scalar), _cplx(cplx), _op(op), _numInlineBuffers(0)
     {
@@ -705,7 +729,7 @@ pcxfw::BlockRegistry registerArithmeticOldPath("/blocks/arithmetic", &arithmetic
 /***********************************************************************
  * /comms/split_complex, /comms/combine_complex   utility/SplitComplex.cpp:39-77, utility/CombineComplex.cpp:38-76
  **********************************************************************/
-class SplitComplex : public Block {
+class SplitComplex : public DeviceBlock {
 public:
     SplitComplex(const DType &dtype, int scalar) : _scalar(scalar)
     {
@@ -732,7 +756,7 @@ private:
     pcxfw::OutputPort *_rePort;
     pcxfw::OutputPort *_imPort;
 };
-class CombineComplex : public Block {
+class CombineComplex : public DeviceBlock {
 public:
     CombineComplex(const DType &dtype, int scalar) : _scalar(scalar)
     {

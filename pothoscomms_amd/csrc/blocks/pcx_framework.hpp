@@ -24,6 +24,7 @@ namespace pcxfw = Pothos;
 #include <algorithm>
 #include <complex>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -33,6 +34,8 @@ namespace pcxfw = Pothos;
 #include <typeindex>
 #include <typeinfo>
 #include <vector>
+
+#include "pcx.h"   // pcx_host_alloc: page-locked slabs of the BufferManager stand-in
 
 namespace pcxfw {
 
@@ -241,7 +244,15 @@ struct BufferManagerArgs {
     size_t numBuffers = 4;
     size_t bufferSize = 8 * 1024;
     long nodeAffinity = -1;
+    // extension: slabs of page-locked host memory (pcx_host_alloc).  The device path runs its kernels directly on such
+    // buffers (include/pcx.h, host-pointer entry points); pageable slabs are staged through a device workspace.
+    bool pinned = false;
 };
+// What a block hands the scheduler from getInputBufferManager / getOutputBufferManager.  The stand-in keeps the two
+// manager names the reference uses ("generic", "circular": FIRFilter.cpp:196-199, FFT.cpp:54-59) and really owns its
+// slabs: the runner (pcxb_acquire_buffer) draws port buffers from it round-robin, as the Pothos scheduler draws them
+// from the manager a block returns.  In a real Pothos build the same role is played by a Pothos::BufferManager
+// subclass whose SharedBuffers wrap pcx_host_alloc slabs.
 class BufferManager {
 public:
     typedef std::shared_ptr<BufferManager> Sptr;
@@ -252,8 +263,39 @@ public:
         p->args = args;
         return p;
     }
+    ~BufferManager()
+    {
+        for (void *s : _slabs) {
+            if (!s) continue;
+            if (_pinnedAlloc) (void)pcx_host_free(s);
+            else std::free(s);
+        }
+    }
+    // next slab, at least `minBytes` long (allocated on first use; slabs grow to the largest request seen)
+    void *acquire(size_t minBytes, size_t *bytes)
+    {
+        const size_t want = std::max(minBytes, args.bufferSize);
+        if (_slabs.empty()) { _slabs.assign(std::max<size_t>(args.numBuffers, 1), nullptr); _sizes.assign(_slabs.size(), 0); _pinnedAlloc = args.pinned; }
+        const size_t i = _next++ % _slabs.size();
+        if (_sizes[i] < want) {
+            if (_slabs[i]) { if (_pinnedAlloc) (void)pcx_host_free(_slabs[i]); else std::free(_slabs[i]); _slabs[i] = nullptr; _sizes[i] = 0; }
+            void *p = nullptr;
+            if (_pinnedAlloc) { if (pcx_host_alloc(&p, want) != PCX_OK) throw std::runtime_error(std::string("BufferManager: pcx_host_alloc: ") + pcx_last_error()); }
+            else if (!(p = std::malloc(want))) throw std::bad_alloc();
+            _slabs[i] = p; _sizes[i] = want;
+        }
+        if (bytes) *bytes = _sizes[i];
+        return _slabs[i];
+    }
     std::string name;
     BufferManagerArgs args;
+
+private:
+    BufferManager() = default;
+    std::vector<void *> _slabs;
+    std::vector<size_t> _sizes;
+    size_t _next = 0;
+    bool _pinnedAlloc = false;
 };
 
 class Block;

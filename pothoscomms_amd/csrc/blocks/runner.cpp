@@ -18,6 +18,9 @@
 using namespace pcxfw;
 
 struct pcxb_block {
+    // managers first: destroyed after the block (members are destroyed in reverse order), and a pinned slab may still
+    // be in use by the block's last call until its handle is gone
+    pcxfw::BufferManager::Sptr inManager, outManager;   // what the block handed the scheduler (pcxb_acquire_buffer)
     std::unique_ptr<Block> blk;
     size_t initialReserve = std::numeric_limits<size_t>::max();
 };
@@ -166,6 +169,16 @@ int pcxb_buffer_manager(pcxb_block *b, int is_output, char *name, size_t cap, si
         auto m = is_output ? b->blk->getOutputBufferManager("", "") : b->blk->getInputBufferManager("", "");
         std::snprintf(name, cap, "%s", m ? m->name.c_str() : "");
         if (buffer_size) *buffer_size = m ? m->args.bufferSize : 0;
+    });
+}
+int pcxb_acquire_buffer(pcxb_block *b, int is_output, size_t min_bytes, void **ptr, size_t *bytes, int *pinned)
+{
+    return guarded([&] {
+        auto &slot = is_output ? b->outManager : b->inManager;
+        if (!slot) slot = is_output ? b->blk->getOutputBufferManager("", "") : b->blk->getInputBufferManager("", "");
+        if (!slot) slot = pcxfw::BufferManager::make("generic");     // a block without a preference: the scheduler's default slabs
+        *ptr = slot->acquire(min_bytes, bytes);
+        if (pinned) *pinned = slot->args.pinned ? 1 : 0;
     });
 }
 int pcxb_initial_reserve(pcxb_block *b, size_t *reserve) { *reserve = b->initialReserve; return PCX_OK; }

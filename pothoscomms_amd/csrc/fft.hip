@@ -12,6 +12,7 @@
 // Replaces kissfft<T>::transform (fft/kissfft.hh:81-161) and kiss_fft (fft/kiss_fft.c:237-302)
 // called from FFT::work (fft/FFT.cpp:61-72).
 #include "fft4096.hpp"
+#include "pcx_sched.hpp"
 #include <cstdlib>
 
 #include "pcx_internal.hpp"
@@ -21,15 +22,23 @@ namespace pcx {
 // --------------------------------------------------------------------------------- //
 // 4096-point complex_float32
 // --------------------------------------------------------------------------------- //
-template <bool INV, int SAUX>
+template <bool INV, int SAUX, bool DYN = false>
 __global__ __launch_bounds__(256, 4) void fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                      size_t nframes, const float2 *__restrict__ twtab)
+                                                      size_t nframes, const float2 *__restrict__ twtab, SchedState *__restrict__ sched)
 {
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
+    __shared__ unsigned sched_slot;
     const int j = threadIdx.x;
     size_t f = blockIdx.x;
-    if (f >= nframes) return;
+    // DYN: frames dealt dynamically, two per draw, the draw one frame ahead of the prefetch (pcx_sched.hpp AheadDealer):
+    // a fixed share per workgroup made every launch wait for the slowest CU (0.795 -> 0.758 ms per 65,536 frames with an
+    // eight-fold oversubscribed grid doing the balancing, tools/ab_sched.sh)
+    AheadDealer deal;
+    if (DYN) {
+        if (!deal.begin(sched, &sched_slot, nframes, j)) { deal.finish(j); return; }
+        f = deal.block();
+    } else if (f >= nframes) return;
     // once per workgroup: pass-3 twiddles into registers, pass-2 table into LDS (its first
     // reader sits behind two barriers); the frame loop issues no table loads
     LaneTw tw3;
@@ -37,33 +46,45 @@ __global__ __launch_bounds__(256, 4) void fft4096_kernel(const float2 *__restric
     stage_pass2_twiddles(lds, twtab, j);
     cf nx[16];                    // register prefetch of the next frame
     load_frame<false>(nx, make_rsrc(in + f * N, N * 8), j);
-    for (; f < nframes; f += gridDim.x) {
+    for (;;) {
         cf v[16];
         // inverse = conj(FFT(conj(x))) on the forward passes (one set of twiddles)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = INV ? cf{nx[r].x, -nx[r].y} : nx[r];
-        const size_t fn = f + gridDim.x;
-        if (fn < nframes) load_frame<false>(nx, make_rsrc(in + fn * N, N * 8), j);
+        size_t fn = f + gridDim.x;
+        const bool more = DYN ? deal.next(&fn) : fn < nframes;
+        if (DYN) deal.draw(j);         // AHEAD of the prefetch in the in-order vmcnt queue: its result can be waited for without the frame
+        if (more) load_frame<false>(nx, make_rsrc(in + fn * N, N * 8), j);
         pass1(v, lds, j);
+        if (DYN) deal.publish(j);      // pass 2 and pass 3 open with barriers
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + f * N, N * 8);
 #pragma unroll
         for (int q = 0; q < 16; q++)
             store_cf<SAUX>(ws, (unsigned)(j + 256 * bin_of(q)) * 8u, INV ? cf{v[q].x, -v[q].y} : v[q]);
+        if (!more) break;
+        if (DYN) (void)deal.advance();
+        f = fn;
     }
+    if (DYN) deal.finish(j);
 }
 
-int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, hipStream_t st)
+int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, void *sched, hipStream_t st)
 {
     if (nframes == 0) return PCX_OK;
     const float2 *tab = static_cast<const float2 *>(tw4096);
     // persistent workgroups: LDS (34.8 KB) admits 4 per CU; each walks frames with a grid
     // stride, keeping its twiddles in registers and the next frame in flight
-    const unsigned grid = persistent_grid(nframes, 1024);
+    const unsigned grid = persistent_grid(nframes, (unsigned)PCX_ENV_INT("PCX_FFT_SLOTS", 1024));   // PCX_FFT_SLOTS (diag): oversubscription A/B
     // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
     const int saux = (int)PCX_ENV_INT("PCX_FFT_STORE_AUX", 2);
-#define PCX_FFT_LAUNCH(INV, SAUX) hipLaunchKernelGGL((fft4096_kernel<INV, SAUX>), dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab)
+    const bool dyn = sched && nframes > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");
+#define PCX_FFT_LAUNCH(INV, SAUX)                                                                                                          \
+    do {                                                                                                                                   \
+        if (dyn) hipLaunchKernelGGL((fft4096_kernel<INV, SAUX, true>), dim3(1024), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab, (SchedState *)sched); \
+        else hipLaunchKernelGGL((fft4096_kernel<INV, SAUX>), dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab, (SchedState *)nullptr);          \
+    } while (0)
     if (inverse) { if (saux == 2) PCX_FFT_LAUNCH(true, 2); else PCX_FFT_LAUNCH(true, 0); }
     else { if (saux == 2) PCX_FFT_LAUNCH(false, 2); else PCX_FFT_LAUNCH(false, 0); }
 #undef PCX_FFT_LAUNCH

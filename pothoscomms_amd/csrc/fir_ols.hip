@@ -18,6 +18,7 @@
 // The kernel runs at the package power cap: what remains above the load+store
 // floor is clock, not scheduling.
 #include "fft4096.hpp"
+#include "pcx_sched.hpp"
 #include <cstdio>
 #include <cstdlib>
 
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                   const float2 *__restrict__ twtab, size_t first_full,
-                                                                  size_t nfull, size_t nblocks)
+                                                                  size_t nfull, size_t nblocks, SchedState *__restrict__ sched)
 {
     // Kov >= K-1 outputs are dropped at the head of every block and the block's input window starts
     // `pad` = Kov-(K-1) samples before sample b*S: with Kov a multiple of 16 every row this kernel
@@ -60,7 +61,15 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
     // instead of a grid stride, so the K-1 samples block b+1 shares with block b were fetched
     // by the same CU a moment ago (L2/L1 hit instead of a second trip to the memory side).
     size_t b, bend, bstep;
-    if (CHUNKED == 2) {
+    // CHUNKED == 3 (the product default): blocks dealt dynamically, two per draw (pcx_sched.hpp) -- the CUs do not all run
+    // at one rate, and a fixed share per workgroup made every launch wait for the slowest
+    __shared__ unsigned sched_slot;
+    BlockDealer deal;
+    if (CHUNKED == 3) {
+        static_assert(CHUNKED != 3 || !PREFETCH, "the register prefetch needs the next block's index a block early");
+        if (!deal.begin(sched, &sched_slot, nblocks, j)) { deal.finish(j); return; }
+        b = deal.block(); bend = nblocks; bstep = 0;
+    } else if (CHUNKED == 2) {
         // XCD-aware walk: workgroup w runs on XCD w % 8 (round-robin dispatch).  Each XCD takes one
         // contiguous eighth of the blocks and its workgroups walk it side by side, so the window rows
         // block b+1 shares with block b are fetched by the same XCD at about the same time (an L2
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         } else {
             fetch(v, b);
         }
+        if (CHUNKED == 3) deal.draw(j);     // behind the loads in the in-order vmcnt queue: they can be waited for without it
         constexpr int PART = DIAG == 3 ? 1 : DIAG == 4 ? 2 : 0;
         if (DIAG != 2) {
         pass1<PART>(v, lds, j);
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
             u[k1] = v[q + 1];
             cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
+        if (CHUNKED == 3) deal.publish(j);  // the inverse passes' barriers stand between this and deal.advance()
         if (DIAG != 2) {
         pass1<PART>(u, lds, j);
         pass2<PART>(u, lds, j);
@@ -176,11 +187,16 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
             if (row + 255 < Kov) continue;                    // whole row dropped: uniform skip
             store_cf<SAUX>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
+        if (CHUNKED == 3) {
+            if (!deal.advance()) break;
+            b = deal.block();
+        }
     }
+    if (CHUNKED == 3) deal.finish(j);
 }
 
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                            const void *tw4096, hipStream_t st)
+                            const void *tw4096, void *sched, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols: K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
@@ -214,7 +230,7 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     const unsigned slots = (unsigned)PCX_ENV_INT("PCX_OLS_SLOTS", 1024);
     const unsigned g4 = persistent_grid(nblocks, slots), g3 = persistent_grid(nblocks, 768);
     const unsigned gx = 8 * persistent_grid((nblocks + 7) / 8, 128);   // XCD-aware walk: equal rounds inside every XCD's eighth
-#define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks)
+#define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks, (SchedState *)sched)
 #ifdef PCX_DIAG
     switch (variant) {
     case 0: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true>), g3); goto launched;
@@ -238,8 +254,16 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 #else
     (void)variant; (void)g3; (void)gx;
 #endif
-    // non-temporal stores; non-temporal loads for the rows no other block reads
-    if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), g4);
+    // non-temporal stores; non-temporal loads for the rows no other block reads; blocks dealt dynamically when the caller
+    // brought the counter pair (every pcx_fir handle does), else the grid stride
+    if (sched && nblocks > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC")) {   // (PCX_SCHED_STATIC, diag only: the grid stride, for A/B)
+        const unsigned gd = 1024;   // 4 resident workgroups per CU, all of them drawing
+        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3>), gd);
+        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3>), gd);
+        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3>), gd);
+        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3>), gd);
+    }
+    else if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), g4);
     else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2>), g4);
     else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2>), g4);
     else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4);
@@ -514,23 +538,28 @@ int launch_interleave_rows_cf32(const void *rows, void *out, size_t n, size_t L,
 // sample (8 in, 4 out).  The overlap is rounded up to a multiple of 32 samples (aligned 1 KiB
 // output rows); 128 VGPRs, 4 workgroups per CU.
 // --------------------------------------------------------------------------------- //
-template <int OCC, int NOV, int SAUX>
+template <int OCC, int NOV, int SAUX, bool DYN = false>
 __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                         float *__restrict__ out, size_t n_out,
                                                                         const float2 *__restrict__ Hspec, int K, int pad,
                                                                         const float2 *__restrict__ twtab, size_t nblocks,
                                                                         const float2 *__restrict__ prev_in,
-                                                                        float2 *__restrict__ prev_out)
+                                                                        float2 *__restrict__ prev_out, SchedState *__restrict__ sched)
 {
     // K here = the block overlap: taps + pad, a multiple of 32 so that every 1 KiB row of outputs
     // this kernel stores starts on a 128-byte line (see fir_cf32_ols4096_kernel)
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
     __shared__ cf bnd[64];   // last lane of each wave, per row: the demodulator's cross-wave neighbours
+    __shared__ unsigned sched_slot;
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - K);
     size_t b = blockIdx.x;
-    if (b >= nblocks) return;
+    BlockDealer deal;        // DYN: blocks dealt dynamically, two per draw (pcx_sched.hpp)
+    if (DYN) {
+        if (!deal.begin(sched, &sched_slot, nblocks, j)) { deal.finish(j); return; }
+        b = deal.block();
+    } else if (b >= nblocks) return;
     LaneTw tw3;
     load_pass3_twiddles(tw3, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
@@ -565,9 +594,10 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
         }
     };
-    for (; b < nblocks; b += gridDim.x) {
+    for (; b < nblocks; b += DYN ? 0 : gridDim.x) {
         cf v[16];
         fetch(v, b);
+        if (DYN) deal.draw(j);
         pass1(v, lds, j);
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
@@ -579,6 +609,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             u[k1] = v[q + 1];
             cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
+        if (DYN) deal.publish(j);
         pass1(u, lds, j);
         pass2(u, lds, j);
         pass3(u, lds, j, tw3);
@@ -634,11 +665,16 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             for (int q = 0; q < 16; q++)
                 if (j + 256 * bin_of(q) == i_last) prev_out[0] = make_float2(u[q].x, u[q].y);
         }
+        if (DYN) {
+            if (!deal.advance()) break;
+            b = deal.block();
+        }
     }
+    if (DYN) deal.finish(j);
 }
 
 int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                                const void *tw4096, const void *prev_in, void *prev_out, hipStream_t st)
+                                const void *tw4096, const void *prev_in, void *prev_out, void *sched, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2048) { set_error("fm chain ols: K=%zu outside 1..2048", K); return PCX_ERR_UNSUPPORTED; }
@@ -647,10 +683,18 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
     const size_t Kov = (K + 31) / 32 * 32, pad = Kov - K;    // <= 2048
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
-#define PCX_FM_LAUNCH(OCC, NOV, SAUX, CAP)                                                                                   \
-    hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX>), dim3(persistent_grid(nblocks, CAP)), dim3(256), 0, st,   \
-                       (const float2 *)in, in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad,            \
-                       (const float2 *)tw4096, nblocks, (const float2 *)prev_in, (float2 *)prev_out)
+    const bool dyn = sched && nblocks > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");   // dynamic dealing when the handle brought its counter pair and the launch is long
+#define PCX_FM_LAUNCH(OCC, NOV, SAUX, CAP)                                                                                       \
+    do {                                                                                                                         \
+        if (dyn)                                                                                                                 \
+            hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX, true>), dim3(CAP), dim3(256), 0, st, (const float2 *)in, \
+                               in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096,  \
+                               nblocks, (const float2 *)prev_in, (float2 *)prev_out, (SchedState *)sched);                        \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX>), dim3(persistent_grid(nblocks, CAP)), dim3(256), 0, st, \
+                               (const float2 *)in, in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad,      \
+                               (const float2 *)tw4096, nblocks, (const float2 *)prev_in, (float2 *)prev_out, (SchedState *)nullptr); \
+    } while (0)
 #ifdef PCX_DIAG
     if (occ == 3) PCX_FM_LAUNCH(3, 8, 0, 768);            // A/B: 3 workgroups per CU, plain loads and stores
     else if (occ == 5) PCX_FM_LAUNCH(4, 8, 0, 1024);      // A/B: plain loads and stores

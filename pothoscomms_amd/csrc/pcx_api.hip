@@ -313,6 +313,7 @@ struct pcx_fir {
     int algo = PCX_FIR_AUTO, last_algo = 0;
     bool dirty = true;
     DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096, wsIn, wsOut;
+    DevBuf sched;             // {draws, finished}: dynamic block assignment of the overlap-save kernels (pcx_sched.hpp), zeroed once
     size_t Kp = 8;
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
@@ -453,6 +454,10 @@ static int fir_sync_tables(pcx_fir *h)
     case PCX_I8: PCX_TRY(fir_upload_rows<int16_t>(h, true)); break;
     }
     h->have_ols = false;
+    if (!h->sched.p) {
+        PCX_TRY(h->sched.ensure(64));
+        PCX_HIP(hipMemset(h->sched.p, 0, 64));
+    }
     if (fir_fast_applicable(h)) {
         const size_t K = h->K;
         // reversed, zero-padded complex taps for the LDS-tiled direct kernel
@@ -800,14 +805,14 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
         rc = PCX_OK;
         for (size_t jr = 0; jr < h->L && rc == PCX_OK; jr++)
             rc = launch_fir_cf32_ols4096(in_dev, used_in, static_cast<char *>(h->wsRows.p) + jr * N * 8, N,
-                                         static_cast<const char *>(h->HspecRows.p) + jr * 2 * 4096 * sizeof(float), h->K, h->tw4096.p, st);
+                                         static_cast<const char *>(h->HspecRows.p) + jr * 2 * 4096 * sizeof(float), h->K, h->tw4096.p, h->sched.p, st);
         if (rc == PCX_OK) rc = launch_interleave_rows_cf32(h->wsRows.p, out_dev, N, h->L, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {
         rc = launch_fir_cf32_ols_r16(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {
-        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, st);
+        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st);
     } else if (algo == PCX_FIR_DIRECT && fast && (2048 + h->Kp + 8) * 9 / 8 * 8 + 64 <= 64 * 1024) {
         // the LDS-tiled time-domain kernel while its tile (2048 outputs + taps) fits; longer filters than every
         // fast plan (K > 8193) take the sliding-window kernel below
@@ -863,6 +868,7 @@ struct pcx_fft {
     enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, SMOOTH, FOURSTEP, FOURSTEP_SHORT } kind = MIXED;
     int log2n = 0;
     DevBuf tw, perm, wsIn, wsOut;
+    DevBuf sched;            // dynamic frame assignment of fft4096_kernel (pcx_sched.hpp), zeroed at create
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
     // FOURSTEP (fft_large.hip): numBins = n1 * n2, both within the single-workgroup plans
     size_t n1 = 0, n2 = 0;
@@ -961,6 +967,8 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     } else if (scalar == PCX_F32 && num_bins == 4096) {
         h->kind = pcx_fft::R16_4096;
         rc = upload(h->tw, make_tw4096());
+        if (rc == PCX_OK) rc = h->sched.ensure(64);
+        if (rc == PCX_OK && hipMemset(h->sched.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
     } else if (scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384) {
         h->kind = pcx_fft::R16;
         while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
@@ -1090,7 +1098,7 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         if (h->scalar == PCX_I16) return launch_fft_q15_one(in_dev, out_dev, nframes, st);
         PCX_HIP(hipMemcpyAsync(out_dev, in_dev, nframes * 2 * (size_t)scalar_bytes(h->scalar), hipMemcpyDeviceToDevice, st));
         return PCX_OK;
-    case pcx_fft::R16_4096: return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, st);
+    case pcx_fft::R16_4096: return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, h->sched.p, st);
     case pcx_fft::R16:
         return h->scalar == PCX_F64 ? launch_fft_r16_cf64(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st)
                                     : launch_fft_r16_cf32(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st);
@@ -1419,6 +1427,7 @@ struct pcx_fmchain {
     bool dirty = true;
     size_t K = 1, Kp = 8;
     DevBuf tapsRev, Hspec, tw4096, prev, wsIn, wsOut;
+    DevBuf sched;   // dynamic block assignment of the fused kernel (pcx_sched.hpp), zeroed at create
     int cur = 0;
     int algo = PCX_FIR_AUTO, last_algo = 0;
     bool have_ols = false;
@@ -1437,6 +1446,8 @@ int pcx_fmchain_create(pcx_fmchain **out)
     DeviceScope dev_scope(h->cx.device);
     int rc = h->prev.ensure(64);
     if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
+    if (rc == PCX_OK) rc = h->sched.ensure(64);
+    if (rc == PCX_OK && hipMemset(h->sched.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
     if (rc != PCX_OK) { delete h; return rc; }
     *out = h;
     return PCX_OK;
@@ -1546,7 +1557,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     if (algo == PCX_FIR_OLS_FFT) {
         if (!h->have_ols) { set_error("fm chain: OLS_FFT needs K <= 2048"); return PCX_ERR_UNSUPPORTED; }
         PCX_TRY(launch_fmchain_cf32_ols4096(in_dev, N + h->K - 1, out_dev, N, h->Hspec.p, h->K, h->tw4096.p, base + 32 * h->cur,
-                                            base + 32 * (h->cur ^ 1), as_stream(stream)));
+                                            base + 32 * (h->cur ^ 1), h->sched.p, as_stream(stream)));
     } else {
         PCX_TRY(launch_fmchain_cf32(in_dev, N + h->K - 1, out_dev, N, h->tapsRev.p, h->K, h->Kp, base + 32 * h->cur,
                                     base + 32 * (h->cur ^ 1), as_stream(stream)));

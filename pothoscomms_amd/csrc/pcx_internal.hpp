@@ -140,8 +140,9 @@ int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_
                            size_t Kp, hipStream_t st);
 // FIR: frequency-domain overlap-save, complex_float32, M=L=1, K <= 2049.
 // Hspec: device array of 4096 cf32 = FFT_4096(h)/4096 in natural bin order.
+// sched: the handle's SchedState pair (pcx_sched.hpp: dynamic block assignment) or nullptr for the static grid stride
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                            const void *tw4096, hipStream_t st);
+                            const void *tw4096, void *sched, hipStream_t st);
 int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
                                    const void *tw4096, hipStream_t st);
 size_t fir_decim_fold_factor(size_t M);
@@ -172,7 +173,7 @@ int launch_fft_columns(const void *in, void *out, int log2n1, size_t n2, size_t 
 int launch_fft_rows_transposed(const void *in, void *out, size_t n1, int log2n2, size_t batch, bool inverse, const void *tw_table, hipStream_t st);
 int launch_fft_columns_f64(const void *in, void *out, int log2n1, size_t n2, size_t batch, bool inverse, const void *tw_table, hipStream_t st);
 int launch_fft_rows_transposed_f64(const void *in, void *out, size_t n1, int log2n2, size_t batch, bool inverse, const void *tw_table, hipStream_t st);
-int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, hipStream_t st);
+int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse, const void *tw4096, void *sched, hipStream_t st);
 int launch_fft_pow2_cf32(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
                          hipStream_t st);
 int launch_fft_pow2_cf64(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
@@ -195,7 +196,7 @@ int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t
 
 // fused Rotate -> FIR -> FreqDemod, frequency domain (Hspec already carries the phasor)
 int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                                const void *tw4096, const void *prev_in, void *prev_out, hipStream_t st);
+                                const void *tw4096, const void *prev_in, void *prev_out, void *sched, hipStream_t st);
 // fused Rotate -> FIR -> FreqDemod, time domain
 int launch_fmchain_cf32(const void *in, size_t in_elems, void *out, size_t n_out, const void *taps_rev, size_t K,
                         size_t Kp, const void *prev_in, void *prev_out, hipStream_t st);

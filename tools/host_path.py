@@ -36,3 +36,22 @@ t0 = time.perf_counter()
 for _ in range(5): run()
 dt = (time.perf_counter() - t0) / 5
 print("fir host path, pinned buffers  n=%9d  %.3f ms  %.2f Gsamples/s (%.1f GB/s each way)" % (n, dt * 1e3, n / dt / 1e9, 8 * n / dt / 1e9))
+
+
+# ---- a plain block work() loop on the buffers the BLOCK hands the scheduler (pinned slabs): nothing staged ----
+from pothoscomms_amd import blocks
+for n in (1 << 18, 1 << 20, 1 << 22):
+    blk = blocks.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    blk.call("setTaps", tp.c1_taps())
+    blk.activate()
+    K = 255
+    xin, pin_in = blk.port_buffer(0, (n + K - 1, 2), np.float32)
+    yout, pin_out = blk.port_buffer(1, (n, 2), np.float32)
+    xin[:] = np.random.default_rng(0).uniform(-1, 1, xin.shape).astype(np.float32)
+    blk.work(xin, n, outbuf=yout)
+    t0 = time.perf_counter(); reps = 20
+    for _ in range(reps):
+        _, c, p, _, _ = blk.work(xin, n, outbuf=yout)
+    dt = (time.perf_counter() - t0) / reps
+    assert p == n
+    print("/comms/fir_filter work() on its own port buffers (pinned in=%s out=%s)  n=%9d  %.3f ms  %.2f Gsamples/s" % (pin_in, pin_out, n, dt * 1e3, n / dt / 1e9))

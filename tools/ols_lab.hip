@@ -128,7 +128,7 @@ template <int MODE, int DOSE, int WGPC>
 __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, size_t n_out,
                                                         const float2 *__restrict__ Hspec, int Kov, int pad,
                                                         const float2 *__restrict__ twtab, size_t nblocks, float dose_seed,
-                                                        Stamp *__restrict__ stamps)
+                                                        Stamp *__restrict__ stamps, int stag, unsigned *__restrict__ ctr, unsigned ctr_base, int chunk)
 {
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
     LaneTw tw3;
     load_pass3_twiddles(tw3, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
+    if (stag) {
+        // start-up stagger: every workgroup of a launch is dispatched within a microsecond, so without it all 1024 load,
+        // transform and store in phase.  stag = (ticks per step << 4) | mode; one tick of s_memrealtime = 10 ns.
+        //   mode 1: phase = blockIdx >> 8 (the 4 workgroups that share a CU under round-robin dispatch), 4 steps
+        //   mode 2: phase = blockIdx & 3, 4 steps        mode 3: phase = a hash of blockIdx, 16 steps
+        const int mode = stag & 15, ticks = stag >> 4;
+        unsigned ph = mode == 1 ? (blockIdx.x >> 8) & 3 : mode == 2 ? blockIdx.x & 3 : ((blockIdx.x * 2654435761u) >> 28);
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)ph * (unsigned)ticks;
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     cf H[16];
     const int jh = MODE == MODE_SWAP ? (j >> 4) + 16 * (j & 15) : j;   // digit-swap pipeline: the lane holds bins swap(j) + 256 k
 #pragma unroll
@@ -160,7 +170,36 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
     };
     cf nx[16];
     if (MODE == MODE_LATE) fetch(nx, b);
-    for (; b < nblocks; b += gridDim.x) {
+    // dynamic block assignment (ctr != nullptr): every workgroup draws its next block from one counter instead of
+    // walking a fixed stride -- the draw for block i+1 is issued right after block i's loads and its result parked in
+    // LDS in front of one of the pass barriers, so its latency hides behind the transforms.  The counter is never
+    // reset: a launch starts at ctr_base and leaves it at ctr_base + nblocks + gridDim (one failed draw per workgroup).
+    __shared__ unsigned next_block[2];
+    const bool dyn = ctr != nullptr;
+    // chunked draws: one atomic hands a workgroup `chunk` blocks (contiguous when chunk > 0, nchunks apart when < 0), so
+    // the counter sees nblocks / chunk draws per launch (a single word saturates near 88 draws per microsecond)
+    const bool guided = chunk <= -100;     // pairs (strided) first, single blocks for the last (-chunk - 100) per mille
+    const unsigned tail1 = guided ? (unsigned)((nblocks * (size_t)(-chunk - 100)) / 1000) : 0;
+    const unsigned npair = guided ? (unsigned)((nblocks - tail1) / 2) : 0;
+    const unsigned csz = guided ? 2u : (unsigned)(chunk < 0 ? -chunk : chunk);
+    const unsigned nchunks = !dyn ? 0 : guided ? npair + (unsigned)(nblocks - 2 * (size_t)npair) : (unsigned)((nblocks + csz - 1) / csz);
+    unsigned it = 0, pending = 0, cq = 0, sub = 0;
+    auto block_of = [&](unsigned qq, unsigned ss) -> size_t {
+        if (guided) return qq < npair ? (size_t)qq + (size_t)ss * npair : (ss == 0 ? (size_t)2 * npair + (qq - npair) : nblocks);
+        return chunk > 0 ? (size_t)qq * csz + ss : (size_t)qq + (size_t)ss * nchunks;
+    };
+    if (dyn) {
+        if (j == 0) next_block[0] = atomicAdd(ctr, 1u) - ctr_base;
+        __syncthreads();
+        cq = next_block[0];
+        if (cq >= nchunks) return;
+        b = block_of(cq, 0);
+    }
+    for (;;) {
+        if (b >= nblocks) {   // static: past the end; dynamic: only the last chunk holds such blocks, and no chunk follows it
+            if (dyn && j == 0) atomicAdd(ctr, 1u);   // keep the books: every workgroup ends on exactly one draw past the end
+            break;
+        }
         cf v[16];
         if (MODE == MODE_LATE) {
 #pragma unroll
@@ -168,6 +207,12 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
         } else {
             fetch(v, b);
         }
+        // the draw for the NEXT chunk: issued behind the loads of this chunk's last block, consumed in front of the inverse
+        // transform; two slots so the next draw cannot overwrite one still unread
+        const bool lastc = sub + 1 >= csz || block_of(cq, sub + 1) >= nblocks;
+        if (dyn && lastc && j == 0) pending = atomicAdd(ctr, 1u) - ctr_base;
+        it++;
+        {
         cf u[16];
         if (MODE == MODE_FULL || MODE == MODE_LATE) {
             constexpr int BM = MODE == MODE_LATE ? 3 : DOSE;
@@ -181,6 +226,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
                 u[k1] = v[q + 1];
                 cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
             }
+            if (dyn && lastc && j == 0) next_block[it & 1] = pending;   // three barriers of the inverse passes follow
             xpass1<BM>(u, lds, j);
             xpass2<BM>(u, lds, j);
             xpass3<BM>(u, lds, j, tw3);
@@ -247,6 +293,14 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
             if (row + 255 < Kov) continue;
             store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
+        }
+        if (!dyn) { b += gridDim.x; continue; }
+        if (++sub >= csz || block_of(cq, sub) >= nblocks) {
+            cq = next_block[it & 1];
+            if (cq >= nchunks) break;
+            sub = 0;
+        }
+        b = block_of(cq, sub);
     }
     if (j == 0) {
         Stamp s;
@@ -323,9 +377,9 @@ static double median(std::vector<double> v)
     return v[v.size() / 2];
 }
 
-struct Cfg { const char *name; int mode; int dose; int wgpc; bool zero_in; float dose_seed; };
+struct Cfg { const char *name; int mode; int dose; int wgpc; bool zero_in; float dose_seed; int stag; int dyn; int slots; };
 
-typedef void (*KernFn)(const float2 *, float2 *, size_t, const float2 *, int, int, const float2 *, size_t, float, Stamp *);
+typedef void (*KernFn)(const float2 *, float2 *, size_t, const float2 *, int, int, const float2 *, size_t, float, Stamp *, int, unsigned *, unsigned, int);
 
 template <int MODE, int DOSE, int WGPC> static KernFn kern() { return lab_kernel<MODE, DOSE, WGPC>; }
 
@@ -365,28 +419,36 @@ int main(int argc, char **argv)
     CK(hipMalloc(&x, in_elems * 8));
     CK(hipMalloc(&y, (nblocks * S + 64) * 8));
     CK(hipMalloc(&Hs, 4096 * 8));
-    CK(hipMalloc(&st, 1024 * sizeof(Stamp)));
+    CK(hipMalloc(&st, 32768 * sizeof(Stamp)));
     std::vector<float> t = make_tw4096();
     CK(hipMalloc(&tw, t.size() * 4));
     CK(hipMemcpy(tw, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (float *)Hs, (size_t)8192, 77ull, 0);
     // |H| ~ 1/4096-ish scale like a real spectrum / N: scale not needed for timing (values stay finite)
     const unsigned grid = [&] { const size_t slots = 1024, rounds = (nblocks + slots - 1) / slots; return (unsigned)((nblocks + rounds - 1) / rounds); }();
+    auto nchunks_of = [&](int ch) -> unsigned {
+        if (ch <= -100) { const size_t t1 = nblocks * (size_t)(-ch - 100) / 1000, np = (nblocks - t1) / 2; return (unsigned)(np + (nblocks - 2 * np)); }
+        const size_t c = (size_t)abs(ch); return (unsigned)((nblocks + c - 1) / c);
+    };
+    unsigned *ctr; unsigned ctr_base = 0;
+    CK(hipMalloc(&ctr, 64)); CK(hipMemset(ctr, 0, 64));
     const Cfg cfgs[] = {
-        {"full all barriers  random", MODE_FULL, 3, 4, false, 0.f},
-        {"late prefetch      random", MODE_LATE, 0, 4, false, 0.f},
-        {"mem only", MODE_MEM, 0, 4, false, 0.f},
-        {"full all barriers  random", MODE_FULL, 3, 4, false, 0.f},
-        {"late prefetch      random", MODE_LATE, 0, 4, false, 0.f},
-        {"full all barriers  zero-in", MODE_FULL, 3, 4, true, 0.f},
-        {"late prefetch      zero-in", MODE_LATE, 0, 4, true, 0.f},
+        {"full, static stride, grid 971", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
+        {"full, dynamic pairs strided", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
+        {"full, pairs then singles for the last 5 %", MODE_FULL, 3, 4, false, 0.f, 0, -150, 1024},
+        {"full, pairs then singles for the last 10 %", MODE_FULL, 3, 4, false, 0.f, 0, -200, 1024},
+        {"full, pairs then singles for the last 20 %", MODE_FULL, 3, 4, false, 0.f, 0, -300, 1024},
+        {"full, dynamic triples strided", MODE_FULL, 3, 4, false, 0.f, 0, -3, 1024},
+        {"full, dynamic pairs strided", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
+        {"full, dynamic pairs strided, grid 971", MODE_FULL, 3, 4, false, 0.f, 0, -2, 971},
+        {"full, dynamic pairs strided, grid 2048", MODE_FULL, 3, 4, false, 0.f, 0, -2, 2048},
     };
     {   // parity of the digit-swap pipeline against the product pipeline on the same random input
         float2 *y2;
         CK(hipMalloc(&y2, (nblocks * S + 64) * 8));
         hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (float *)x, in_elems * 2, 2ull, 0);
-        hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, 0.f, st);
-        hipLaunchKernelGGL((lab_kernel<MODE_LATE, 0, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st);
+        hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, nullptr, 0u, 0);
+        hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, ctr, ctr_base, -150); ctr_base += nchunks_of(-150) + grid;
         CK(hipDeviceSynchronize());
         const size_t cmp = 4u << 20;
         std::vector<float> a(2 * cmp), b(2 * cmp);
@@ -394,7 +456,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(b.data(), y2, cmp * 8, hipMemcpyDeviceToHost));
         double mx = 0, md = 0;
         for (size_t i = 0; i < 2 * cmp; i++) { mx = std::max(mx, (double)std::fabs(a[i])); md = std::max(md, (double)std::fabs(a[i] - b[i])); }
-        printf("# parity late-prefetch vs product pipeline over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
+        printf("# parity dynamic-assignment vs product pipeline over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
         CK(hipFree(y2));
     }
     printf("# 255-tap geometry: Kov=%d S=%zu blocks=%zu grid=%u, %zu samples, %.1f s per configuration\n", Kov, S, nblocks, grid, n, secs);
@@ -407,7 +469,11 @@ int main(int argc, char **argv)
         }
         KernFn k = pick(c.mode, c.dose, c.wgpc);
         if (!k) continue;
-        auto launch = [&] { hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, c.dose_seed, st); };
+        const unsigned g = c.slots ? (unsigned)c.slots : grid;
+        auto launch = [&] {
+            hipLaunchKernelGGL(k, dim3(g), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, c.dose_seed, st, c.stag, c.dyn ? ctr : nullptr, ctr_base, c.dyn);
+            if (c.dyn) ctr_base += nchunks_of(c.dyn) + g;
+        };
         CK(hipDeviceSynchronize());
         g_stop = false; g_power.clear(); g_sclk.clear();
         std::thread th(sampler);
@@ -434,8 +500,8 @@ int main(int argc, char **argv)
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double per = ms / (double)iters;
-        std::vector<Stamp> hs(grid);
-        CK(hipMemcpy(hs.data(), st, grid * sizeof(Stamp), hipMemcpyDeviceToHost));
+        std::vector<Stamp> hs(g);
+        CK(hipMemcpy(hs.data(), st, g * sizeof(Stamp), hipMemcpyDeviceToHost));
         std::vector<double> clk;
         for (const Stamp &s : hs)
             if (s.r1 > s.r0) clk.push_back((double)(s.t1 - s.t0) / (double)(s.r1 - s.r0) * 0.1);   // memrealtime ticks at 100 MHz

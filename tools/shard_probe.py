@@ -1,0 +1,30 @@
+"""pcx_shard_* on ONE device: G peer-copy shards of 64 Mi / G samples each against one 64 Mi-sample pass.
+What it shows: the cost of the native driver's head/body split, events and halo copies (no second GPU needed)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+from pothoscomms_amd import _lib, device, taps as tp
+
+L = _lib.load()
+total = 64 * 1024 * 1024
+h = tp.c1_taps()
+for G in (1, 2, 4, 8):
+    ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY if G > 1 else device.NodeStream.RCCL)
+    ns.set_taps(h)
+    ns.configure(total // G)
+    for g in range(G):
+        i, o, s, d = ns.buffers(g)
+        _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (len(h) - 1 + total // G), 2, 2 * g * (total // G), C.c_void_p(s)))
+    for _ in range(150):
+        ns.step()
+    ns.sync()
+    t0 = time.perf_counter()
+    n = 200
+    for _ in range(n):
+        ns.step()
+    ns.sync()
+    dt = (time.perf_counter() - t0) / n
+    print("G=%d shards on device 0 (%s): %.4f ms per pass over %d samples = %.1f Gsamples/s" %
+          (G, "rccl comm of one" if G == 1 else "peer copies", dt * 1e3, total, total / dt / 1e9))
+    ns.close()

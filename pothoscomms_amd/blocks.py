@@ -34,9 +34,10 @@ def load():
     if _blib is not None:
         return _blib
     _lib.load()    # one HIP runtime per process, libpcx_hip.so first
-    if not os.path.exists(BLOCKS_LIB_PATH):
-        raise ImportError("%s is missing: build with make -C pothoscomms_amd/csrc" % BLOCKS_LIB_PATH)
-    L = C.CDLL(BLOCKS_LIB_PATH)
+    path = os.environ.get("PCX_BLOCKS_LIBRARY") or BLOCKS_LIB_PATH     # the override selects the sanitizer build (make asan)
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: build with make -C pothoscomms_amd/csrc" % path)
+    L = C.CDLL(path)
     vp, sz, i, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.pcxb_last_error.restype = cp
     L.pcxb_registry_has.argtypes = [cp]

@@ -8,14 +8,16 @@
 // messages), backwards-compatible filter-type aliases, gain-then-window order and signal payload types
 // (std::vector<double>, or std::vector<std::complex<double>> for the COMPLEX_* band types) as the reference.
 //
-// What is built: the windowed-sinc subset -- filter type "SINC" for all six band types, with every window the
-// reference lists.  The reference delegates the arithmetic to spuce (design_fir / design_complex_fir /
-// design_window), an un-vendored dependency that is absent from the reference tree, so tap VALUES follow the
-// textbook definitions below and are "parity unpinned" against spuce; what is pinned is the reference's own
-// acceptance test (TestFIRDesigner.cpp:110-135: pass points above -30 dB, stop points below -80 dB of an
-// impulse's spectrum) and the windows against scipy.signal.windows (tests/test_designer_cpu.py).
-// The other filter types (MAXFLAT, GAUSSIAN, REMEZ, RAISED_COSINE, ROOT_RAISED_COSINE) throw
-// InvalidArgumentException at recalculation: nothing is silently substituted.
+// What is built: the closed-form prototypes -- filter types "SINC", "GAUSSIAN" (the reference's constructor default, so a
+// default-constructed designer activates and emits taps as the reference's does), "RAISED_COSINE" and
+// "ROOT_RAISED_COSINE" -- for all six band types, with every window the reference lists.  The reference delegates the
+// arithmetic to spuce (design_fir / design_complex_fir / design_window), an un-vendored dependency that is absent from
+// the reference tree, so tap VALUES follow the textbook definitions below and are "parity unpinned" against spuce; what
+// is pinned is the reference's own acceptance test (TestFIRDesigner.cpp:110-135: pass points above -30 dB, stop points
+// below -80 dB of an impulse's spectrum), the windows against scipy.signal.windows, and the defining properties of each
+// prototype (tests/test_designer_cpu.py: Nyquist zero crossings of the raised cosine, the root raised cosine convolved
+// with itself, the Gaussian's -3 dB point).  The iterative designs (MAXFLAT, REMEZ) throw InvalidArgumentException at
+// recalculation: nothing is silently substituted.
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -116,6 +118,64 @@ std::vector<double> sincLowPass(size_t n, double fc)
         h[i] = std::fabs(t) < 1e-12 ? 2.0 * fc : std::sin(x) / (kPi * t);
     }
     return h;
+}
+
+// Raised cosine low-pass with its -6 dB point at fc cycles/sample (symbol period T = 1/(2 fc) samples) and excess
+// bandwidth alpha in [0, 1]: h(t) = 2 fc sinc(2 fc t) cos(2 pi alpha fc t) / (1 - (4 alpha fc t)^2); zero at every
+// multiple of T except t = 0 (no inter-symbol interference).  Unity gain at DC.
+std::vector<double> raisedCosineLowPass(size_t n, double fc, double alpha)
+{
+    std::vector<double> h(n);
+    const double c = 0.5 * (double)(n - 1);
+    for (size_t i = 0; i < n; i++) {
+        const double t = (double)i - c, x = 2.0 * fc * t;                 // x = t / T
+        const double sinc = std::fabs(x) < 1e-12 ? 1.0 : std::sin(kPi * x) / (kPi * x);
+        const double d = 1.0 - (2.0 * alpha * x) * (2.0 * alpha * x);
+        // at |2 alpha x| = 1 numerator and denominator vanish together: the limit is (pi/4) sinc(1/(2 alpha))
+        const double shape = std::fabs(d) < 1e-9 ? (kPi / 4.0) * (std::sin(kPi / (2.0 * alpha)) / (kPi / (2.0 * alpha)))
+                                                 : sinc * std::cos(kPi * alpha * x) / d;
+        h[i] = 2.0 * fc * shape;
+    }
+    return h;
+}
+// Root raised cosine: the filter whose convolution with itself is the raised cosine above (matched-filter pair).
+//   h(t) = 2 fc [sin(pi x (1-a)) + 4 a x cos(pi x (1+a))] / [pi x (1 - (4 a x)^2)],  x = t / T = 2 fc t
+std::vector<double> rootRaisedCosineLowPass(size_t n, double fc, double alpha)
+{
+    std::vector<double> h(n);
+    const double c = 0.5 * (double)(n - 1), a = alpha;
+    for (size_t i = 0; i < n; i++) {
+        const double x = 2.0 * fc * ((double)i - c);
+        double v;
+        if (std::fabs(x) < 1e-12) v = 1.0 + a * (4.0 / kPi - 1.0);
+        else if (a > 0 && std::fabs(std::fabs(4.0 * a * x) - 1.0) < 1e-9)
+            v = (a / std::sqrt(2.0)) * ((1.0 + 2.0 / kPi) * std::sin(kPi / (4.0 * a)) + (1.0 - 2.0 / kPi) * std::cos(kPi / (4.0 * a)));
+        else
+            v = (std::sin(kPi * x * (1.0 - a)) + 4.0 * a * x * std::cos(kPi * x * (1.0 + a))) / (kPi * x * (1.0 - (4.0 * a * x) * (4.0 * a * x)));
+        h[i] = 2.0 * fc * v;
+    }
+    return h;
+}
+// Gaussian low-pass whose -3 dB bandwidth is `bt` cycles/sample ("Lower Freq specifies the time-bandwidth product",
+// FIRDesigner.cpp:38, with the sample as the unit of time): h(t) = sqrt(2 pi / ln 2) bt exp(-2 pi^2 bt^2 t^2 / ln 2).
+// Unity gain at DC in the limit of many taps.
+std::vector<double> gaussianLowPass(size_t n, double bt)
+{
+    std::vector<double> h(n);
+    const double c = 0.5 * (double)(n - 1), ln2 = std::log(2.0);
+    for (size_t i = 0; i < n; i++) {
+        const double t = (double)i - c;
+        h[i] = std::sqrt(2.0 * kPi / ln2) * bt * std::exp(-2.0 * kPi * kPi * bt * bt * t * t / ln2);
+    }
+    return h;
+}
+// the low-pass prototype of a filter type at cut-off fc
+std::vector<double> prototypeLowPass(const std::string &type, size_t n, double fc, double alpha)
+{
+    if (type == "SINC") return sincLowPass(n, fc);
+    if (type == "GAUSSIAN") return gaussianLowPass(n, fc);
+    if (type == "RAISED_COSINE") return raisedCosineLowPass(n, fc, alpha);
+    return rootRaisedCosineLowPass(n, fc, alpha);
 }
 
 class FIRDesigner : public Block {
@@ -243,10 +303,14 @@ void FIRDesigner::recalculate()
         if (_passDB <= 0) throw Exception("FIRDesigner()", "Passband Attenuation must be > 0");
         if (_stopDB <= 0) throw Exception("FIRDesigner()", "Stopband Attenuation must be > 0");
     }
-    if (_filterType != "SINC")
+    const bool closedForm = _filterType == "SINC" || _filterType == "GAUSSIAN" || _filterType == "RAISED_COSINE" || _filterType == "ROOT_RAISED_COSINE";
+    if (!closedForm)
         throw InvalidArgumentException("Problem with creating taps for FIRDesigner(" + _filterType + "/" + _bandType + "):" +
-                                           " this build designs the windowed-sinc subset (filter type SINC) only",
+                                           " this build designs the closed-form prototypes (SINC, GAUSSIAN, RAISED_COSINE, ROOT_RAISED_COSINE) only",
                                        "not implemented");
+    if ((_filterType == "RAISED_COSINE" || _filterType == "ROOT_RAISED_COSINE") && !(_alpha >= 0.0 && _alpha <= 1.0))
+        throw InvalidArgumentException("Problem with creating taps for FIRDesigner(" + _filterType + "/" + _bandType + "): alpha outside 0.0 to 1.0",
+                                       "problem with input parameters?");
     if (!(_bandType == "LOW_PASS" || _bandType == "HIGH_PASS" || isBand))
         throw InvalidArgumentException("Problem with creating taps for FIRDesigner(" + _filterType + "/" + _bandType + "): unknown band type",
                                        "problem with input parameters?");
@@ -257,14 +321,14 @@ void FIRDesigner::recalculate()
     std::vector<double> taps;
     std::vector<std::complex<double>> complexTaps;
     if (_bandType == "LOW_PASS") {
-        taps = sincLowPass(n, fl);
+        taps = prototypeLowPass(_filterType, n, fl, _alpha);
     } else if (_bandType == "HIGH_PASS") {
         // low-pass of width 1/2 - fl moved to the Nyquist frequency
-        taps = sincLowPass(n, 0.5 - fl);
+        taps = prototypeLowPass(_filterType, n, 0.5 - fl, _alpha);
         for (size_t i = 0; i < n; i++) taps[i] *= std::cos(kPi * ((double)i - c));
     } else if (!isComplex) {
         // low-pass of half the band's width moved to +- the band centre; the stop form is its complement
-        taps = sincLowPass(n, 0.5 * (fu - fl));
+        taps = prototypeLowPass(_filterType, n, 0.5 * (fu - fl), _alpha);
         const double f0 = 0.5 * (fu + fl);
         for (size_t i = 0; i < n; i++) taps[i] *= 2.0 * std::cos(2.0 * kPi * f0 * ((double)i - c));
         if (isStop) {
@@ -272,7 +336,7 @@ void FIRDesigner::recalculate()
             taps[n / 2] += 1.0;
         }
     } else {
-        const std::vector<double> lp = sincLowPass(n, 0.5 * (fu - fl));
+        const std::vector<double> lp = prototypeLowPass(_filterType, n, 0.5 * (fu - fl), _alpha);
         const double f0 = 0.5 * (fu + fl);
         complexTaps.resize(n);
         for (size_t i = 0; i < n; i++) complexTaps[i] = lp[i] * std::polar(1.0, 2.0 * kPi * f0 * ((double)i - c));

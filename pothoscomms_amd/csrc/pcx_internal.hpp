@@ -97,14 +97,20 @@ inline unsigned stream_grid(size_t work_items, unsigned block)
     return (unsigned)g;
 }
 
-// grid of a persistent-workgroup kernel that walks `units` work items with a grid stride:
-// at most `slots` workgroups (CUs x resident workgroups per CU), sized so that every
-// workgroup gets the same number of rounds -- with units/slots = 17.06 a grid of `slots`
-// would run an 18th round at 6 % occupancy (a 5 % tail on the headline FIR launch).
-inline unsigned persistent_grid(size_t units, unsigned slots)
+// grid of a persistent-workgroup kernel that walks `units` work items with a grid stride: `slots` = CUs x resident
+// workgroups per CU, sized so that every workgroup gets the same number of rounds -- with units/grid = 17.06 an 18th
+// round would run at 6 % occupancy.
+// `oversub` > 1 queues that many workgroups per slot: the CUs do not all run at one rate (profiles/r02/ols_lab.md), and
+// the hardware dispatcher then hands the next workgroup to whichever slot frees first.  It pays only where the per-workgroup
+// set-up is small against a block (measured, tools/ab_oversub.sh: double-precision overlap-save +5 % at 8; decimating
+// cf32 FIR -7 % at 4, interpolating and time-domain kernels +-0), so it is per kernel, default 1.  The three headline
+// kernels have their own dealer instead (pcx_sched.hpp).  PCX_OVERSUB (diagnostic library only) overrides for A/B.
+inline unsigned persistent_grid(size_t units, unsigned slots, unsigned oversub = 1)
 {
-    if (units <= slots) return (unsigned)(units ? units : 1);
-    const size_t rounds = (units + slots - 1) / slots;
+    const long forced = PCX_ENV_INT("PCX_OVERSUB", 0);
+    const size_t cap = (size_t)slots * (size_t)(forced > 0 ? (unsigned)forced : oversub);
+    if (units <= cap) return (unsigned)(units ? units : 1);
+    const size_t rounds = (units + cap - 1) / cap;
     return (unsigned)((units + rounds - 1) / rounds);
 }
 

@@ -54,7 +54,9 @@ def test_reference_test_vectors(dev, name, opname):
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("opname", OPS)
 def test_arith_vs_oracle(oracle, dev, name, cplx, opname):
-    rng = np.random.default_rng(hash((name, cplx, opname)) % (1 << 31))
+    # a stable digest, not hash(): str hashes are salted per process and a failure must be reproducible
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("%s/%d/%s" % (name, int(cplx), opname)).encode()))
     for n in (1, 7, 1000, 70001):      # ragged tails behind the 16-byte vectors
         a, b = operands(rng, name, (n, 2) if cplx else (n,), opname == "DIV")
         got = dev.arith(opname, a, b, cplx)

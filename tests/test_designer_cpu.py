@@ -79,17 +79,18 @@ def test_nothing_is_emitted_before_activation_then_every_change_emits():
     ("setFrequencyUpper", 0.5, "BAND_PASS", "upper frequency above Nyquist range"),
     ("setFrequencyUpper", 0.05, "BAND_PASS", "upper frequency <= lower frequency"),
     ("setWindowType", "nuttall", "LOW_PASS", "unknown window type"),
-    ("setFilterType", "REMEZ", "LOW_PASS", "windowed-sinc subset"),
-    ("setFilterType", "GAUSSIAN", "HIGH_PASS", "windowed-sinc subset"),
+    ("setFilterType", "REMEZ", "LOW_PASS", "closed-form prototypes"),
+    ("setFilterType", "MAXFLAT", "HIGH_PASS", "closed-form prototypes"),
+    ("setAlpha", 1.5, "LOW_PASS", None),
     ("setBandType", "NOTCH", "LOW_PASS", "unknown band type"),
 ])
 def test_parameter_checks_like_the_reference(setter, value, band, msg):
     """FIRDesigner.cpp:395-413: each check, with its message; types outside the built subset fail loudly."""
     des, _ = _designer_and_filter(band)
-    des.call("setFilterType", "SINC")
+    des.call("setFilterType", "SINC" if msg else "RAISED_COSINE")
     des.call("setBandType", band)
     des.activate()
-    with pytest.raises(_lib.PcxError, match=msg):
+    with pytest.raises(_lib.PcxError, match=msg or "alpha outside 0.0 to 1.0"):
         des.call(setter, value)
 
 
@@ -100,11 +101,69 @@ def test_maxflat_stop_band_message():
         des.call("setFilterType", "MAXFLAT")
 
 
-def test_default_constructed_designer_fails_loudly_on_activation():
-    """the reference constructs with filter type GAUSSIAN (FIRDesigner.cpp:149), which this build does not design"""
-    d = B.make("/comms/fir_designer")
-    with pytest.raises(_lib.PcxError, match="windowed-sinc subset"):
-        d.activate()
+def test_default_constructed_designer_activates_and_emits():
+    """the reference constructs with filter type GAUSSIAN (FIRDesigner.cpp:149) and emits taps on activation"""
+    des, flt = _designer_and_filter("LOW_PASS")
+    assert des.call("filterType") == "GAUSSIAN"
+    des.activate()
+    t = np.asarray(_taps(flt, False))
+    assert len(t) == 51 and np.all(np.isfinite(t)) and np.allclose(t, t[::-1]) and t[25] == t.max() > 0
+
+
+def test_iterative_designs_fail_loudly():
+    des, _ = _designer_and_filter("LOW_PASS")
+    des.call("setFilterType", "SINC"); des.activate()
+    for ft in ("REMEZ", "MAXFLAT"):
+        with pytest.raises(_lib.PcxError, match="closed-form prototypes"):
+            des.call("setFilterType", ft)
+
+
+def _design(ftype, ntaps, fl, alpha=0.5, window="rectangular"):
+    des, flt = _designer_and_filter("LOW_PASS")
+    des.call("setFilterType", ftype); des.call("setWindowType", window); des.call("setNumTaps", ntaps)
+    des.call("setFrequencyLower", fl); des.call("setAlpha", alpha)
+    des.activate()
+    return np.asarray(_taps(flt, False))
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.25, 0.5, 1.0])
+def test_raised_cosine_has_no_intersymbol_interference(alpha):
+    """T = 1 / (2 fl) = 8 samples: zero at every multiple of T except the centre, unity gain at DC"""
+    h = _design("RAISED_COSINE", 257, 1.0 / 16.0, alpha)
+    c = 128
+    k = np.arange(-16, 17)
+    k = k[k != 0]
+    assert np.max(np.abs(h[c + 8 * k])) <= 1e-12
+    assert abs(h[c] - 2.0 / 16.0) <= 1e-15
+    if alpha > 0:
+        assert abs(h.sum() - 1.0) <= 2e-3
+    H = np.abs(np.fft.rfft(h, 4096))
+    f = np.arange(H.size) / 4096.0
+    if alpha > 0:
+        assert np.max(H[f > (1 + alpha) / 16.0 + 0.01]) <= 5e-3     # band-limited to (1 + alpha) / (2T), up to truncation
+    assert abs(H[int(round(4096 / 16.0))] - 0.5) <= 2e-2           # -6 dB at 1 / (2T)
+
+
+@pytest.mark.parametrize("alpha", [0.2, 0.5, 1.0])
+def test_root_raised_cosine_convolved_with_itself_is_the_raised_cosine(alpha):
+    n = 513
+    rrc, rc = _design("ROOT_RAISED_COSINE", n, 1.0 / 16.0, alpha), _design("RAISED_COSINE", n, 1.0 / 16.0, alpha)
+    both = np.convolve(rrc, rrc)                         # centre at n - 1; T-spaced samples of the cascade
+    c = n - 1
+    k = np.arange(-12, 13)
+    assert np.max(np.abs(both[c + 8 * k] - np.where(k == 0, 1.0, 0.0) * both[c])) <= 3e-3 * both[c]
+    # same -3 dB point: |H_rrc|^2 = |H_rc|
+    Hr, Hc = np.abs(np.fft.rfft(rrc, 8192)), np.abs(np.fft.rfft(rc, 8192))
+    assert np.max(np.abs(Hr ** 2 - Hc)) <= 5e-3
+
+
+@pytest.mark.parametrize("bt", [0.03, 0.05, 0.1])
+def test_gaussian_minus_three_db_point(bt):
+    h = _design("GAUSSIAN", 201, bt)
+    H = np.abs(np.fft.rfft(h, 1 << 14))
+    assert abs(H[0] - 1.0) <= (1e-6 if bt <= 0.1 else 1e-3)          # wide Gaussians alias a little at one sample per unit time
+    assert abs(H[int(round(bt * (1 << 14)))] - 1 / np.sqrt(2)) <= 2e-3
+    assert np.all(np.diff(H[:int(0.45 * (1 << 14))]) <= 1e-12)          # monotone: no ripple, no sidelobes
 
 
 @pytest.mark.parametrize("n", [2, 16, 51, 101])

@@ -90,14 +90,57 @@ def test_fft4096_65536_frames_roundtrip_and_parseval(oracle, dev, torch_dev):
         assert nerr(X[fr * 4096:(fr + 1) * 4096].cpu().numpy(), want) <= TOL
 
 
+def _fm_stream(torch, d, n, K):
+    """64 Mi samples of the C4 test signal: 1 Mi samples generated on the host (taps.fm_test_signal), tiled on the device.
+    (The phase jumps at the tile seams are part of the stream both sides see.)"""
+    from pothoscomms_amd import taps as tp
+    xs = tp.fm_test_signal(1 << 20)
+    reps = (n + K - 1 + (1 << 20) - 1) // (1 << 20)
+    return torch.from_numpy(xs.view(np.float32).reshape(-1, 2)).to(d).repeat(reps, 1)[:n + K - 1].contiguous()
+
+
+def test_fm_chain_64Mi_against_the_oracle_chain(oracle, dev, torch_dev):
+    """configs[4] at full size, checked against the ORACLE's Rotate -> FIR(127 real taps) -> FreqDemod on windows: the
+    first and last 64 Ki outputs, the overlap-save block seams (multiples of S = 4096 - 128), the seam between two
+    work() calls (FreqDemod's carried prev, FreqDemod.cpp:63-65), and a tile seam of the test signal."""
+    torch, d = torch_dev
+    from pothoscomms_amd import taps as tp
+    from tests.util import ang_err
+    n, h, phase = C1, tp.c4_taps(), tp.C4_PHASE
+    K = len(h)
+    x = _fm_stream(torch, d, n, K)
+    got = torch.empty(n, dtype=torch.float32, device=d)
+    ch = dev.FmChain(); ch.set_phase(phase); ch.set_taps(h, False)
+    n1 = 40 * 1024 * 1024 + 12345                        # two calls: the second continues from the carried state
+    assert ch.process_dev(x, got, n1 + K - 1, n1) == (n1, n1)
+    assert ch.process_dev(x[n1:], got[n1:], n - n1 + K - 1, n - n1) == (n - n1, n - n1)
+    torch.cuda.synchronize()
+
+    def oracle_window(start, cnt):
+        first = max(start - 1, 0)                        # one FIR output in front seeds the demodulator
+        m = start - first + cnt
+        win = x[first:first + m + K - 1].cpu().numpy()
+        fir = oracle.Fir(oracle.F32, True, False); fir.set_taps(h); fir.activate()
+        y, _, p, _ = fir.work(oracle.rotate(win, phase), m)
+        assert p == m
+        return oracle.FreqDemod(oracle.F32).work(y)[start - first:]
+
+    S = 4096 - 128
+    windows = [(0, 65536), (n - 65536, 65536), (S - 300, 600), (1000 * S - 300, 600), (16000 * S - 300, 600),
+               (n1 - 300, 600), ((1 << 20) - 400, 800), (n1 + ((n - n1) // S // 2) * S - 300, 600)]
+    for start, cnt in windows:
+        want = oracle_window(start, cnt)
+        assert ang_err(got[start:start + cnt].cpu().numpy(), want) <= TOL, start
+
+
 def test_fm_chain_full_size_against_separate_blocks(dev, torch_dev):
-    """configs[4]: the fused kernel equals Rotate -> FIR -> FreqDemod run as three device calls."""
+    """configs[4], 64 Mi samples: the fused kernel equals Rotate -> FIR -> FreqDemod run as three device calls, over the
+    WHOLE stream (the oracle comparison above covers windows)."""
     torch, d = torch_dev
     from pothoscomms_amd import _lib, taps as tp
-    n, h, phase = 16 * 1024 * 1024, tp.c4_taps(), tp.C4_PHASE
+    n, h, phase = C1, tp.c4_taps(), tp.C4_PHASE
     K = len(h)
-    xs = tp.fm_test_signal(1 << 20)                      # 1 Mi samples of the FM test signal, tiled on the device
-    x = torch.from_numpy(xs.view(np.float32).reshape(-1, 2)).to(d).repeat(17, 1)[:n + K - 1].contiguous()
+    x = _fm_stream(torch, d, n, K)
     fused = torch.empty(n, dtype=torch.float32, device=d)
     ch = dev.FmChain(); ch.set_phase(phase); ch.set_taps(h, False)
     assert ch.process_dev(x, fused, n + K - 1, n) == (n, n)
@@ -109,6 +152,7 @@ def test_fm_chain_full_size_against_separate_blocks(dev, torch_dev):
     sep = torch.empty(n, dtype=torch.float32, device=d)
     dev.FreqDemod("complex_float32").process_dev(y, sep, n)
     torch.cuda.synchronize()
+    del xr, y
     dd = (fused.double() - sep.double() + np.pi) % (2 * np.pi) - np.pi
     assert float(dd.abs().max()) / np.pi <= TOL
 

@@ -350,3 +350,118 @@ def test_fft_and_demod_blocks_random_chunks(oracle, seed):
         y, c, p, _, _ = dm.work(xi[a:b], b - a)
         assert (c, p) == (b - a, b - a)
         assert np.array_equal(y, ref.work(xi[a:b]))
+
+
+# ---- guard bands: nothing outside [out, out + produced) may be written, nothing outside the declared input read ----
+GUARD = 4096   # elements of poison on either side
+GSEEDS = range(2 * len(SEEDS))
+
+
+def _guarded(torch, d, n_elems, width, dtype, fill):
+    """A device buffer with GUARD poisoned elements on either side of an n_elems window; returns (whole, window)."""
+    whole = torch.full(((n_elems + 2 * GUARD) * width,), fill, dtype=dtype, device=d)
+    win = whole[GUARD * width:(GUARD + n_elems) * width]
+    return whole, (win.view(-1, width) if width > 1 else win)
+
+
+def _bands_intact(whole, n_elems, width, fill):
+    lo, hi = whole[:GUARD * width], whole[(GUARD + n_elems) * width:]
+    if fill != fill:      # NaN poison
+        return bool(lo.isnan().all()) and bool(hi.isnan().all())
+    return bool((lo == fill).all()) and bool((hi == fill).all())
+
+
+@pytest.mark.parametrize("seed", GSEEDS)
+def test_fir_writes_only_its_outputs_and_reads_only_its_inputs(oracle, dev, seed):
+    """Every FIR pipeline with range-checked stores (overlap-save 4096 / r16 plans / decimating / interpolating / polyphase,
+    the direct tile, the sliding window): NaN guard bands around input AND output.  A read past the declared input would
+    pull a NaN into the last outputs; a store outside [0, produced) would overwrite the poison."""
+    import torch
+    from pothoscomms_amd import _lib
+    d = torch.device("cuda", 0)
+    rng = np.random.default_rng(9100 + seed)
+    nan = float("nan")
+    geoms = [(1, 1), (1, 1), (1, 2), (1, 8), (2, 1), (4, 1), (3, 1), (3, 2), (1, 1), (1, 5)]
+    L, M = geoms[seed % len(geoms)]
+    ntaps = int(rng.choice([2, 17, 63, 255, 1000, 3000])) if (L, M) == (1, 1) else int(rng.choice([8, 63, 255])) * L
+    algo = [_lib.FIR_AUTO, _lib.FIR_OLS_FFT, _lib.FIR_DIRECT, _lib.FIR_EXACT][seed % 4] if (L, M) == (1, 1) else _lib.FIR_AUTO
+    h = (rng.normal(size=ntaps) + 1j * rng.normal(size=ntaps)) / ntaps
+    f = dev.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h); f.set_decimation(M); f.set_interpolation(L); f.set_algo(algo)
+    K = f.K
+    n_iter = int(rng.integers(1, 40000)) // M * M + M
+    n_in, n_out = n_iter + K - 1, n_iter // M * L
+    xw, x = _guarded(torch, d, n_in, 2, torch.float32, nan)
+    yw, y = _guarded(torch, d, n_out, 2, torch.float32, nan)
+    xh = rng.uniform(-1, 1, (n_in, 2)).astype(np.float32)
+    x.copy_(torch.from_numpy(xh).to(d))
+    c, p = f.process_dev(x, y, n_in, n_out)
+    torch.cuda.synchronize()
+    assert (c, p) == (n_iter, n_out)
+    assert _bands_intact(yw, n_out, 2, nan), (L, M, ntaps, algo)
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all(), (L, M, ntaps, algo)        # no NaN from beyond the input window
+    blk = oracle.Fir(oracle.F32, True, True)
+    blk.set_taps(h); blk.set_decimation(M); blk.set_interpolation(L); blk.activate()
+    ref, rc, rp, _ = blk.work(xh, n_out)
+    assert (rc, rp) == (c, p)
+    assert nerr(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("seed", GSEEDS)
+def test_fft_writes_only_its_frames(oracle, dev, seed):
+    import torch
+    d = torch.device("cuda", 0)
+    rng = np.random.default_rng(9300 + seed)
+    nbins = int(rng.choice([4, 60, 256, 1000, 4096, 4096, 8192, 3 * 1024, 65536]))
+    dtype, td, sc = [("complex_float32", torch.float32, oracle.F32), ("complex_float64", torch.float64, oracle.F64),
+                     ("complex_int16", torch.int16, oracle.I16)][seed % 3]
+    if sc == oracle.I16 and nbins > 32768:
+        nbins = 4096
+    nframes = int(rng.integers(1, 9)) if nbins >= 4096 else int(rng.integers(1, 70))
+    fill = float("nan") if sc != oracle.I16 else 12345
+    xw, x = _guarded(torch, d, nbins * nframes, 2, td, fill)
+    yw, y = _guarded(torch, d, nbins * nframes, 2, td, fill)
+    xh = rand_stream(rng, sc, nbins * nframes, True) if sc != oracle.I16 else rng.integers(-3000, 3000, (nbins * nframes, 2)).astype(np.int16)
+    x.copy_(torch.from_numpy(xh).to(d))
+    inv = bool(seed & 1)
+    dev.Fft(dtype, nbins, inv).transform_dev(x, y, nframes)
+    torch.cuda.synchronize()
+    assert _bands_intact(yw, nbins * nframes, 2, fill), (nbins, dtype)
+    got, ref = y.cpu().numpy(), oracle.fft(xh, nbins, inv)
+    if sc == oracle.I16:
+        assert np.array_equal(got, ref)
+    else:
+        assert np.isfinite(got).all()
+        assert nerr(got, ref) <= (TOL if sc == oracle.F32 else 1e-12)
+
+
+@pytest.mark.parametrize("seed", GSEEDS)
+def test_fm_chain_writes_only_its_outputs(oracle, dev, seed):
+    import torch
+    from pothoscomms_amd import _lib
+    d = torch.device("cuda", 0)
+    rng = np.random.default_rng(9500 + seed)
+    ntaps = int(rng.choice([1, 9, 127, 500, 2048]))
+    n = int(rng.integers(1, 50000))
+    h = rng.normal(size=ntaps) / ntaps
+    nan = float("nan")
+    xw, x = _guarded(torch, d, n + ntaps - 1, 2, torch.float32, nan)
+    yw, y = _guarded(torch, d, n, 1, torch.float32, nan)
+    ph = np.cumsum(rng.uniform(-0.5, 0.5, n + ntaps - 1))
+    xh = np.stack([np.cos(ph), np.sin(ph)], 1).astype(np.float32)
+    x.copy_(torch.from_numpy(xh).to(d))
+    ch = dev.FmChain(); ch.set_phase(0.3); ch.set_taps(h, False)
+    ch.set_algo([_lib.FIR_AUTO, _lib.FIR_DIRECT, _lib.FIR_OLS_FFT][seed % 3])
+    assert ch.process_dev(x, y, n + ntaps - 1, n) == (n, n)
+    torch.cuda.synchronize()
+    assert _bands_intact(yw, n, 1, nan), ntaps
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all()
+    fir = oracle.Fir(oracle.F32, True, False); fir.set_taps(h); fir.activate()
+    yy, _, p, _ = fir.work(oracle.rotate(xh, 0.3), n)
+    # (ill-conditioned where the filtered envelope vanishes: compare where it does not)
+    ref = oracle.FreqDemod(oracle.F32).work(yy)
+    mag = np.hypot(yy[:, 0], yy[:, 1])
+    ok = np.minimum(mag, np.concatenate([[1.0], mag[:-1]])) > 1e-3 * mag.max()
+    assert ang_err(got[ok], ref[ok]) <= 4 * TOL

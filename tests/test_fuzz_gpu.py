@@ -463,5 +463,5 @@ def test_fm_chain_writes_only_its_outputs(oracle, dev, seed):
     # (ill-conditioned where the filtered envelope vanishes: compare where it does not)
     ref = oracle.FreqDemod(oracle.F32).work(yy)
     mag = np.hypot(yy[:, 0], yy[:, 1])
-    ok = np.minimum(mag, np.concatenate([[1.0], mag[:-1]])) > 1e-3 * mag.max()
-    assert ang_err(got[ok], ref[ok]) <= 4 * TOL
+    ok = np.minimum(mag, np.concatenate([[1.0], mag[:-1]])) > 3e-2 * mag.max()   # the angle of a product of two samples: error ~ FIR error / |y|
+    assert ang_err(got[ok], ref[ok]) <= 2 * TOL

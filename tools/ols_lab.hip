@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
     LaneTw tw3;
     load_pass3_twiddles(tw3, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
-    if (stag) {
+    if (stag > 0) {
         // start-up stagger: every workgroup of a launch is dispatched within a microsecond, so without it all 1024 load,
         // transform and store in phase.  stag = (ticks per step << 4) | mode; one tick of s_memrealtime = 10 ns.
         //   mode 1: phase = blockIdx >> 8 (the 4 workgroups that share a CU under round-robin dispatch), 4 steps
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
         cf u[16];
         if (MODE == MODE_FULL || MODE == MODE_LATE) {
             constexpr int BM = MODE == MODE_LATE ? 3 : DOSE;
+            if (stag == -3 || stag == -4 || stag == -5) __builtin_amdgcn_s_setprio(1);
             xpass1<BM>(v, lds, j);
             xpass2<BM>(v, lds, j);
             xpass3<BM>(v, lds, j, tw3);
@@ -227,8 +228,14 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
                 cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
             }
             if (dyn && lastc && j == 0) next_block[it & 1] = pending;   // three barriers of the inverse passes follow
+            if (stag == -2) __builtin_amdgcn_s_setprio(1);     // the inverse transform and the stores ahead of other workgroups' work
+            if (stag == -3 || stag == -5) __builtin_amdgcn_s_setprio(2);
+            if (stag == -4) __builtin_amdgcn_s_setprio(0);
+            if (stag == -6) __builtin_amdgcn_s_setprio(3);
             xpass1<BM>(u, lds, j);
             xpass2<BM>(u, lds, j);
+            if (stag == -1) __builtin_amdgcn_s_setprio(2);     // the last pass and the stores
+            if (stag == -5) __builtin_amdgcn_s_setprio(3);
             xpass3<BM>(u, lds, j, tw3);
         } else if (MODE == MODE_SWAP) {
             LaneTw tw;
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
             store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
         }
+        if (stag < 0) __builtin_amdgcn_s_setprio(0);
         if (!dyn) { b += gridDim.x; continue; }
         if (++sub >= csz || block_of(cq, sub) >= nblocks) {
             cq = next_block[it & 1];
@@ -433,15 +441,17 @@ int main(int argc, char **argv)
     unsigned *ctr; unsigned ctr_base = 0;
     CK(hipMalloc(&ctr, 64)); CK(hipMemset(ctr, 0, 64));
     const Cfg cfgs[] = {
-        {"full, static stride, grid 971", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
-        {"full, dynamic pairs strided", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
-        {"full, pairs then singles for the last 5 %", MODE_FULL, 3, 4, false, 0.f, 0, -150, 1024},
-        {"full, pairs then singles for the last 10 %", MODE_FULL, 3, 4, false, 0.f, 0, -200, 1024},
-        {"full, pairs then singles for the last 20 %", MODE_FULL, 3, 4, false, 0.f, 0, -300, 1024},
-        {"full, dynamic triples strided", MODE_FULL, 3, 4, false, 0.f, 0, -3, 1024},
-        {"full, dynamic pairs strided", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
-        {"full, dynamic pairs strided, grid 971", MODE_FULL, 3, 4, false, 0.f, 0, -2, 971},
-        {"full, dynamic pairs strided, grid 2048", MODE_FULL, 3, 4, false, 0.f, 0, -2, 2048},
+        {"dynamic pairs", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
+        {"prio 1 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"prio 3 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -6, -2, 1024},
+        {"prio 1 forward, 2 inverse + stores", MODE_FULL, 3, 4, false, 0.f, -3, -2, 1024},
+        {"prio 1 forward only", MODE_FULL, 3, 4, false, 0.f, -4, -2, 1024},
+        {"prio 1 fwd, 2 inv, 3 last pass + stores", MODE_FULL, 3, 4, false, 0.f, -5, -2, 1024},
+        {"dynamic pairs", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
+        {"prio 1 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"prio 3 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -6, -2, 1024},
+        {"prio 1 forward, 2 inverse + stores", MODE_FULL, 3, 4, false, 0.f, -3, -2, 1024},
+        {"static 971, prio 1 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -2, 0, 0},
     };
     {   // parity of the digit-swap pipeline against the product pipeline on the same random input
         float2 *y2;

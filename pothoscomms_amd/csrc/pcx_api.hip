@@ -865,7 +865,7 @@ struct pcx_fft {
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
-    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, SMOOTH, FOURSTEP, FOURSTEP_SHORT } kind = MIXED;
+    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, SMOOTH, FOURSTEP, FOURSTEP_SHORT, BLUESTEIN } kind = MIXED;
     int log2n = 0;
     DevBuf tw, perm, wsIn, wsOut;
     DevBuf sched;            // dynamic frame assignment of fft4096_kernel (pcx_sched.hpp), zeroed at create
@@ -874,6 +874,8 @@ struct pcx_fft {
     size_t n1 = 0, n2 = 0;
     pcx_fft *sub1 = nullptr, *sub2 = nullptr;
     DevBuf ws1, ws2;
+    // BLUESTEIN (fft_bluestein.hip): n2 = M, the power-of-two convolution size; sub1 / sub2 = forward / inverse M-point plans;
+    // tw = the chirp w[N], tw1 = B[M] = FFT_M of the wrapped conjugate chirp; ws1 = M-point work rows
     // FOURSTEP_SHORT (complex_float32, numBins <= 4 Mi): n1 = 256 columns pass with strided I/O (fft_large.hip),
     // then rows of n2 -- with the final transpose on their store when n2 <= 256, else sub2 + one transpose
     DevBuf tw1, tw2;
@@ -911,10 +913,14 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         for (size_t d = (size_t)std::floor(std::sqrt((double)num_bins)); d >= 2; d--)
             if (num_bins % d == 0) { if (num_bins / d <= lds_limit) mixed_n1 = d; break; }
     }
+    bool bluestein = false;
     if (num_bins > 1 && !r16 && !four_step && !mixed_n1 && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
-        set_error("FFT: numBins=%zu (%s) does not fit the single-workgroup LDS plan; not implemented on the device", num_bins,
-                  scalar == PCX_F64 ? "complex_float64" : scalar == PCX_F32 ? "complex_float32" : "complex_int16");
-        return PCX_ERR_UNSUPPORTED;
+        if (scalar == PCX_I16 || num_bins > ((size_t)1 << 26)) {
+            set_error("FFT: numBins=%zu (%s) does not fit the single-workgroup LDS plan; not implemented on the device", num_bins,
+                      scalar == PCX_I16 ? "complex_int16: the Q15 rounding sequence of kiss_fft cannot be kept beyond it" : "beyond the chirp-z plan");
+            return PCX_ERR_UNSUPPORTED;
+        }
+        bluestein = true;   // float sizes with no other plan (e.g. 2 x a prime beyond one workgroup): chirp-z on the power-of-two plans
     }
     pcx_fft *h = new (std::nothrow) pcx_fft();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
@@ -936,6 +942,37 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     int rc = PCX_OK;
     if (num_bins == 1) {
         h->kind = pcx_fft::IDENTITY;
+    } else if (bluestein) {
+        h->kind = pcx_fft::BLUESTEIN;
+        size_t M = 1;
+        while (M < 2 * num_bins - 1) M <<= 1;
+        h->n1 = num_bins; h->n2 = M;
+        // w[n] = exp(-j pi n^2 / N), n^2 reduced modulo 2N so the phase is exact for any N
+        std::vector<double> w(2 * num_bins), b(2 * M, 0.0);
+        for (size_t n = 0; n < num_bins; n++) {
+            const unsigned long long r = ((unsigned long long)n * (unsigned long long)n) % (2ull * num_bins);
+            const double ph = -3.141592653589793238462643383279502884 * (double)r / (double)num_bins;
+            w[2 * n] = std::cos(ph); w[2 * n + 1] = std::sin(ph);
+            // conjugate chirp, wrapped: b[n] = b[M - n] = conj(w[n])
+            b[2 * n] = w[2 * n]; b[2 * n + 1] = -w[2 * n + 1];
+            if (n) { b[2 * (M - n)] = w[2 * n]; b[2 * (M - n) + 1] = -w[2 * n + 1]; }
+        }
+        rc = pcx_fft_create(scalar, M, 0, &h->sub1);
+        if (rc == PCX_OK) rc = pcx_fft_create(scalar, M, 1, &h->sub2);
+        if (rc == PCX_OK) {
+            if (scalar == PCX_F32) {
+                std::vector<float> wf(w.begin(), w.end()), bf(b.begin(), b.end());
+                rc = upload(h->tw, wf);
+                if (rc == PCX_OK) rc = upload(h->ws1, bf);
+            } else {
+                rc = upload(h->tw, w);
+                if (rc == PCX_OK) rc = upload(h->ws1, b);
+            }
+        }
+        // B = FFT_M(b), once, on the device (the same plan the frames use)
+        if (rc == PCX_OK) rc = h->tw1.ensure(M * esz);
+        if (rc == PCX_OK) rc = pcx_fft_transform_dev(h->sub1, h->ws1.p, h->tw1.p, 1, nullptr);
+        if (rc == PCX_OK && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("hipStreamSynchronize failed"); rc = PCX_ERR_HIP; }
     } else if (four_step && ((scalar == PCX_F32 && num_bins <= ((size_t)4 << 20)) || (scalar == PCX_F64 && num_bins <= ((size_t)2 << 20))) &&
                !PCX_ENV_SET("PCX_FFT_FIVE_PASS")) {
         h->kind = pcx_fft::FOURSTEP_SHORT;
@@ -1132,6 +1169,16 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
         PCX_TRY(launch_transpose(h->scalar, h->ws2.p, h->ws1.p, h->n2, h->n1, nframes, h->inverse ? 2 : 1, st));
         PCX_TRY(pcx_fft_transform_dev(h->sub2, h->ws1.p, h->ws2.p, nframes * h->n1, stream));
         return launch_transpose(h->scalar, h->ws2.p, out_dev, h->n1, h->n2, nframes, 0, st);
+    }
+    case pcx_fft::BLUESTEIN: {
+        const size_t N = h->nbins, M = h->n2, esz = 2 * (size_t)scalar_bytes(h->scalar);
+        PCX_TRY(h->ws1.ensure(nframes * M * esz));
+        PCX_TRY(h->ws2.ensure(nframes * M * esz));
+        PCX_TRY(launch_bluestein_pre(h->scalar, in_dev, h->ws1.p, h->tw.p, N, M, nframes, h->inverse != 0, st));
+        PCX_TRY(pcx_fft_transform_dev(h->sub1, h->ws1.p, h->ws2.p, nframes, stream));
+        PCX_TRY(launch_bluestein_mul(h->scalar, h->ws2.p, h->tw1.p, M, nframes, st));
+        PCX_TRY(pcx_fft_transform_dev(h->sub2, h->ws2.p, h->ws1.p, nframes, stream));
+        return launch_bluestein_post(h->scalar, h->ws1.p, out_dev, h->tw.p, N, M, nframes, h->inverse != 0, st);
     }
     case pcx_fft::SMOOTH:
         return launch_fft_smooth(h->scalar, in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);

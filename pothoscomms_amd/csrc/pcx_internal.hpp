@@ -200,6 +200,11 @@ int launch_fft_smooth(int scalar, const void *in, void *out, size_t nbins, size_
 int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
                      const int *radix_host, int nstages, hipStream_t st);
 
+// Bluestein passes (fft_bluestein.hip): chirp multiply + zero pad, spectrum product, chirp multiply + scale + truncate
+int launch_bluestein_pre(int scalar, const void *x, void *y, const void *w, size_t N, size_t M, size_t nframes, bool inverse, hipStream_t st);
+int launch_bluestein_mul(int scalar, void *Y, const void *B, size_t M, size_t nframes, hipStream_t st);
+int launch_bluestein_post(int scalar, const void *z, void *X, const void *w, size_t N, size_t M, size_t nframes, bool inverse, hipStream_t st);
+
 // fused Rotate -> FIR -> FreqDemod, frequency domain (Hspec already carries the phasor)
 int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                                 const void *tw4096, const void *prev_in, void *prev_out, void *sched, hipStream_t st);

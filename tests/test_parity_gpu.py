@@ -322,9 +322,19 @@ def test_fft_errors(dev):
     with pytest.raises(ValueError):
         dev.Fft("complex_int32", 64)       # FFTFactory: unsupported type
     with pytest.raises(NotImplementedError):
-        dev.Fft("complex_float32", 2 * 10243)   # valid in the reference; 2 x a prime beyond one workgroup's LDS has no four-step split: fails loudly
-    with pytest.raises(NotImplementedError):
         dev.Fft("complex_int16", 1 << 16)     # the Q15 rounding order cannot be kept across a four-step split
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("dtype,nbins,nframes", [("complex_float32", 10243, 3), ("complex_float32", 2 * 10243, 2), ("complex_float64", 5147, 2),
+                                                 ("complex_float64", 2 * 10243, 1)])
+def test_fft_chirp_z_plan_for_sizes_without_another(oracle, dev, dtype, nbins, nframes, inverse):
+    """FFTFactory takes any numBins (FFT.cpp:83-93): a prime (or 2 x a prime) beyond one workgroup's LDS has no mixed-radix
+    or four-step plan on the device and runs Bluestein's form on the power-of-two plans (fft_bluestein.hip)"""
+    sc = oracle.F32 if dtype == "complex_float32" else oracle.F64
+    x = rand_stream(np.random.default_rng(nbins + int(inverse)), sc, nbins * nframes, True)
+    got = dev.Fft(dtype, nbins, inverse).transform(x)
+    assert nerr(got, oracle.fft(x, nbins, inverse)) <= (TOL if sc == oracle.F32 else 1e-12)
 
 
 @pytest.mark.parametrize("inverse", [False, True])

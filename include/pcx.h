@@ -17,22 +17,36 @@
  *   - "elements" are stream elements (one complex pair = one element).
  *   - *_dev variants take DEVICE pointers and a hipStream_t (as void*) and
  *     only enqueue work; the plain variants take HOST pointers (the
- *     BufferChunk memory of a Pothos port), stage through a device workspace
- *     owned by the handle and return after the result is in `out`.
+ *     BufferChunk memory of a Pothos port) and return after the result is in
+ *     `out`.  Page-locked host memory (pcx_host_alloc, hipHostMalloc,
+ *     hipHostRegister -- what the module's BufferManagers hand out) is
+ *     processed IN PLACE: the kernels read and write it over PCIe, both
+ *     directions at once.  Pageable memory is staged through a device
+ *     workspace owned by the handle (H2D, kernel, D2H).
+ *   - every handle owns a non-blocking stream for its host-pointer calls, so
+ *     blocks on different actor threads overlap on the device; nothing runs
+ *     on the legacy default stream.
  *   - handles are not thread-safe; one handle per block instance, exactly as
  *     Pothos serialises work() and setters on one actor.
  *   - a handle is bound to ONE device: the device current (pcx_set_device) on
- *     the calling thread at the handle's first device-touching call.  Later
- *     calls from any thread run on that device and leave the caller's current
- *     device unchanged, so a single Pothos process can place blocks on
- *     different GPUs.
+ *     the thread that CREATES it.  Later calls from any thread run on that
+ *     device and leave the caller's current device unchanged, so a single
+ *     Pothos process can place blocks on different GPUs.  The stateless maps
+ *     run on the calling thread's current device.
+ *   - ordering: a *_dev call on another stream than the handle's previous
+ *     call is ordered behind it (an event), carried state and all; setters
+ *     that rewrite device tables first wait for the handle's outstanding
+ *     work; reset() is enqueued behind the previous call and ahead of the
+ *     next.  Setters cannot be captured into a hipGraph, *_dev calls can.
+ *   - the library reads no environment variable.
  *   - input and output buffers of one call must not overlap, with two exceptions the reference
  *     relies on or that cost nothing: the same-size element-wise maps (rotate, scale, conj, arith)
  *     accept out == in exactly (Arithmetic forwards input 0's buffer, Arithmetic.cpp:157-158), and
  *     the FFT accepts out == in.  abs/angle (narrower output), FIR, FreqDemod and the fused chain
  *     read what another lane may already have overwritten: no aliasing.
  *   - there is NO CPU fallback: a type/size the device path does not implement
- *     returns PCX_ERR_UNSUPPORTED.
+ *     returns PCX_ERR_UNSUPPORTED (after round 2: complex_int16 FFTs beyond
+ *     32768 bins; every float numBins has a plan).
  */
 #ifndef PCX_H
 #define PCX_H

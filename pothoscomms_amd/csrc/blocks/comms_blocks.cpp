@@ -97,16 +97,39 @@ void check(int rc, const std::string &where)
  * the topology doing anything.  8 MiB x 4 per port: one call covers ~1 Mi complex_float32 samples.
  **********************************************************************/
 constexpr size_t kPortSlabBytes = 8u << 20;
+#ifdef PCX_WITH_POTHOS
+// Pothos build: the generic pool logic over page-locked slabs.  [Written against the PothosCore 0.7 headers from memory;
+// PothosCore is not installable in this image, so this branch has never been compiled -- INTEGRATION.md 2.]
+class PinnedBufferManager : public Pothos::GenericBufferManager {
+public:
+    void init(const Pothos::BufferManagerArgs &args) override
+    {
+        Pothos::BufferManager::init(args);
+        for (size_t i = 0; i < args.numBuffers; i++) {
+            void *p = nullptr;
+            if (pcx_host_alloc(&p, args.bufferSize) != PCX_OK) throw Pothos::Exception("PinnedBufferManager::init()", pcx_last_error());
+            auto keep = std::shared_ptr<void>(p, [](void *q) { (void)pcx_host_free(q); });
+            Pothos::SharedBuffer sb(size_t(p), args.bufferSize, keep);
+            Pothos::ManagedBuffer mb;
+            mb.reset(this->shared_from_this(), sb, i);
+            this->push(mb);
+        }
+    }
+};
+static pcxfw::BufferManager::Sptr pinnedManager(const std::string &, size_t = kPortSlabBytes)
+{
+    return pcxfw::BufferManager::Sptr(new PinnedBufferManager());   // the scheduler calls init() with its own args
+}
+#else
 static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
 {
     pcxfw::BufferManagerArgs args;
     args.bufferSize = slabBytes;
     args.numBuffers = 4;
-#ifndef PCX_WITH_POTHOS
     args.pinned = true;
-#endif
     return pcxfw::BufferManager::make(name, args);
 }
+#endif
 class DeviceBlock : public Block {
 public:
     pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }

@@ -109,3 +109,57 @@ def test_real_taps_and_retap_between_passes(oracle):
     ns.scatter(x0)
     ns.step()
     assert nerr(ns.gather(), _oracle_fir(oracle, h0, x0, 2 * 5000)) <= TOL
+
+
+def _ngpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")
+def test_rccl_two_devices_no_seam(oracle):
+    """the real thing on a multi-GPU node: one shard per device, halo over RCCL send/recv"""
+    from pothoscomms_amd import device, taps as tp
+    G = min(_ngpus(), 8)
+    h = tp.c1_taps()
+    K, Cs = len(h), 50000
+    x = oracle.fill_uniform_f32(2 * (K - 1 + G * Cs), 2, 0).reshape(-1, 2)
+    ns = device.NodeStream(list(range(G)), device.NodeStream.RCCL)
+    ns.set_taps(h)
+    ns.configure(Cs)
+    ns.scatter(x)
+    for _ in range(2):
+        _poison_halos(ns)
+        ns.step()
+        got = ns.gather()
+        assert np.isfinite(got).all()
+        assert nerr(got, _oracle_fir(oracle, h, x, G * Cs)) <= TOL
+
+
+@pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")
+def test_handles_stay_on_the_device_they_were_created_on(oracle):
+    """create on device 1, call from a thread whose current device is 0 (a Pothos actor thread's default)"""
+    import threading
+
+    from pothoscomms_amd import _lib, device, taps as tp
+    L = _lib.load()
+    h = tp.c1_taps()
+    x = oracle.fill_uniform_f32(2 * (len(h) - 1 + 30000), 3, 0).reshape(-1, 2)
+    xf = oracle.fill_uniform_f32(2 * 4096 * 3, 4, 0).reshape(-1, 2)
+    _lib.check(L.pcx_set_device(1))
+    try:
+        f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h)
+        t = device.Fft("complex_float32", 4096, False)
+    finally:
+        _lib.check(L.pcx_set_device(0))
+    out = {}
+
+    def actor():
+        _lib.check(L.pcx_set_device(0))
+        out["fir"] = f.process(x, 30000)[0]
+        out["fft"] = t.transform(xf)
+        out["conj"] = device.conj(x)
+    th = threading.Thread(target=actor); th.start(); th.join()
+    assert nerr(out["fir"], _oracle_fir(oracle, h, x, 30000)) <= TOL
+    assert nerr(out["fft"], oracle.fft(xf, 4096, False)) <= TOL
+    assert np.array_equal(out["conj"], oracle.conj(x))

@@ -440,18 +440,23 @@ int main(int argc, char **argv)
     };
     unsigned *ctr; unsigned ctr_base = 0;
     CK(hipMalloc(&ctr, 64)); CK(hipMemset(ctr, 0, 64));
+    // name, mode, dose | barrier mask, wg/CU, zero input, dose operand scale, stagger | priority mode, chunk (0 = static stride), grid (0 = balanced 971)
     const Cfg cfgs[] = {
-        {"dynamic pairs", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
-        {"prio 1 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
-        {"prio 3 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -6, -2, 1024},
-        {"prio 1 forward, 2 inverse + stores", MODE_FULL, 3, 4, false, 0.f, -3, -2, 1024},
-        {"prio 1 forward only", MODE_FULL, 3, 4, false, 0.f, -4, -2, 1024},
-        {"prio 1 fwd, 2 inv, 3 last pass + stores", MODE_FULL, 3, 4, false, 0.f, -5, -2, 1024},
-        {"dynamic pairs", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
-        {"prio 1 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
-        {"prio 3 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -6, -2, 1024},
-        {"prio 1 forward, 2 inverse + stores", MODE_FULL, 3, 4, false, 0.f, -3, -2, 1024},
-        {"static 971, prio 1 on inverse + stores", MODE_FULL, 3, 4, false, 0.f, -2, 0, 0},
+        {"product pipeline, static stride (r01)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
+        {"  same, grid 4096 (hw dispatcher balances)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 4096},
+        {"  dynamic pairs (pcx_sched.hpp)", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
+        {"  dynamic pairs + prio 1 on 2nd half (r02)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"  dynamic single blocks (counter saturates)", MODE_FULL, 3, 4, false, 0.f, 0, -1, 1024},
+        {"  static, 4 barriers/block (digit-swap)", MODE_SWAP, 0, 4, false, 0.f, 0, 0, 0},
+        {"  static, WAR barriers removed [timing only]", MODE_FULL, 2, 4, false, 0.f, 0, 0, 0},
+        {"  static, no barriers at all [timing only]", MODE_FULL, 0, 4, false, 0.f, 0, 0, 0},
+        {"  static, all-zero input (no toggling)", MODE_FULL, 3, 4, true, 0.f, 0, 0, 0},
+        {"loads + stores only", MODE_MEM, 0, 4, false, 0.f, 0, 0, 0},
+        {"  + 160 packed FMAs/lane/block, random data", MODE_DOSE, 160, 4, false, 1.0f, 0, 0, 0},
+        {"  + 640 packed FMAs/lane/block, random data", MODE_DOSE, 640, 4, false, 1.0f, 0, 0, 0},
+        {"  + 640 packed FMAs/lane/block, zeros", MODE_DOSE, 640, 4, false, 0.f, 0, 0, 0},
+        {"product pipeline, static stride (again)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
+        {"  dynamic pairs + prio 1 on 2nd half (again)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
     };
     {   // parity of the digit-swap pipeline against the product pipeline on the same random input
         float2 *y2;
@@ -470,7 +475,7 @@ int main(int argc, char **argv)
         CK(hipFree(y2));
     }
     printf("# 255-tap geometry: Kov=%d S=%zu blocks=%zu grid=%u, %zu samples, %.1f s per configuration\n", Kov, S, nblocks, grid, n, secs);
-    printf("%-30s %9s %8s %9s %9s %8s\n", "config", "ms/launch", "TB/s", "clk(GHz)", "smi sclk", "power W");
+    printf("%-48s %9s %8s %9s\n", "config", "ms/launch", "TB/s", "clk(GHz)");
     bool cur_zero = true;
     for (const Cfg &c : cfgs) {
         if (c.zero_in != cur_zero || &c == &cfgs[0]) {
@@ -515,7 +520,7 @@ int main(int argc, char **argv)
         std::vector<double> clk;
         for (const Stamp &s : hs)
             if (s.r1 > s.r0) clk.push_back((double)(s.t1 - s.t0) / (double)(s.r1 - s.r0) * 0.1);   // memrealtime ticks at 100 MHz
-        printf("%-30s %9.4f %8.3f %9.3f %9.0f %8.0f\n", c.name, per, 16.0 * (double)n / (per * 1e-3) / 1e12, median(clk), median(g_sclk), median(g_power));
+        printf("%-48s %9.4f %8.3f %9.3f\n", c.name, per, 16.0 * (double)n / (per * 1e-3) / 1e12, median(clk));
         fflush(stdout);
         CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }

@@ -10,8 +10,11 @@ def newest(pattern):
     fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     return fs[-1] if fs else None
 
-for name in ("bench_default.json", "bench_other_workloads.jsonl"):
-    shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+for name in ("bench_default.json", "bench_other_workloads.jsonl", "bench_driver_flags.json", "bench_two_ranks_one_gpu_gloo.json",
+             "ab_sched.txt", "ab_oversub.txt", "shard_probe.txt", "host_path.txt", "two_blocks.txt", "pcie_lab.txt",
+             "ols_lab_summary.txt", "sweep_fir_taps.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 f = newest(os.path.join(src, "bench_kt", "**", "*_kernel_stats.csv"))
 if f:
     shutil.copy(f, os.path.join(dst, "bench_fir255_kernel_stats.csv"))

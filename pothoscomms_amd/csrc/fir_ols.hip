@@ -287,11 +287,11 @@ launched:
 // real stream) gives Re(h*z) = h*xA and Im(h*z) = h*xB: same pipeline, half the transforms
 // per sample.  Loads/stores are 4 bytes per lane (two rows per complex element).
 // --------------------------------------------------------------------------------- //
-template <int NOV>
+template <int NOV, bool DYN = false>
 __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__restrict__ in, size_t in_elems,
                                                                  float *__restrict__ out, size_t n_out,
                                                                  const float2 *__restrict__ Hspec, int Kov, int pad,
-                                                                 const float2 *__restrict__ twtab, size_t nblocks)
+                                                                 const float2 *__restrict__ twtab, size_t nblocks, SchedState *__restrict__ sched)
 {
     // Kov = K-1 rounded up to a multiple of 32 samples (128-byte aligned 1 KiB output rows), the
     // window of block b starts `pad` = Kov-(K-1) samples before sample b*S (fir_cf32_ols4096_kernel)
@@ -300,15 +300,17 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - Kov);
     const size_t npairs = (nblocks + 1) / 2;
-    size_t p = blockIdx.x;
-    if (p >= npairs) return;
+    __shared__ unsigned sched_slot;
+    BlockWalk<DYN> walk;     // the unit dealt is a PAIR of real blocks (one complex transform)
+    if (!walk.begin(sched, &sched_slot, npairs, j)) { walk.finish(j); return; }
     LaneTw tw3;
     load_pass3_twiddles(tw3, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
     cf H[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
-    for (; p < npairs; p += gridDim.x) {
+    for (;;) {
+        const size_t p = walk.block();
         const size_t bA = 2 * p, bB = 2 * p + 1;
         cf v[16];
         if (bA > 0 && bB * S - pad + N <= in_elems) {
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
                 v[r] = cf{__uint_as_float(a), __uint_as_float(b)};
             }
         }
+        walk.draw(j);
         pass1(v, lds, j);
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
@@ -358,6 +361,8 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
             u[k1] = v[q + 1];
             cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
+        walk.publish(j);
+        __builtin_amdgcn_s_setprio(1);      // as fir_cf32_ols4096_kernel: the second half of a block first
         pass1(u, lds, j);
         pass2(u, lds, j);
         pass3(u, lds, j, tw3);
@@ -374,11 +379,14 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[q].x), wa, (int)(vbase + (unsigned)row * 4u), 0, 2);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-u[q].y), wb, (int)(vbase + (unsigned)row * 4u), 0, 2);
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (!walk.advance()) break;
     }
+    walk.finish(j);
 }
 
 int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                           const void *tw4096, hipStream_t st)
+                           const void *tw4096, void *sched, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols (real): K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
@@ -386,10 +394,16 @@ int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_
     const size_t Kov = (Km1 + 31) / 32 * 32, pad = Kov - Km1;     // <= 2048
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
-    const unsigned grid = persistent_grid((nblocks + 1) / 2, 1024);
-#define PCX_REAL_LAUNCH(NOV)                                                                                                     \
-    hipLaunchKernelGGL(fir_f32_ols4096_kernel<NOV>, dim3(grid), dim3(256), 0, st, (const float *)in, in_elems, (float *)out, n_out, \
-                       (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks)
+    const size_t npairs = (nblocks + 1) / 2;
+    const bool dyn = sched && npairs > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");
+    const unsigned grid = dyn ? 1024u : persistent_grid(npairs, 1024);
+#define PCX_REAL_LAUNCH(NOV)                                                                                                                  \
+    do {                                                                                                                                      \
+        if (dyn) hipLaunchKernelGGL((fir_f32_ols4096_kernel<NOV, true>), dim3(grid), dim3(256), 0, st, (const float *)in, in_elems, (float *)out, n_out, \
+                                    (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks, (SchedState *)sched);            \
+        else hipLaunchKernelGGL((fir_f32_ols4096_kernel<NOV, false>), dim3(grid), dim3(256), 0, st, (const float *)in, in_elems, (float *)out, n_out,    \
+                                (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, nblocks, (SchedState *)nullptr);              \
+    } while (0)
     if (Kov <= 256) PCX_REAL_LAUNCH(1);
     else if (Kov <= 512) PCX_REAL_LAUNCH(2);
     else if (Kov <= 1024) PCX_REAL_LAUNCH(4);

@@ -17,6 +17,7 @@
 // H on the host (pcx_api.hip) together with the 1/N of the inverse.  Block geometry as in fir_ols.hip: overlap Kov =
 // K-1 rounded up to 16 samples (a multiple of every M here), S = 4096 - Kov full-rate outputs = S/M stored per block.
 #include "fft4096.hpp"
+#include "pcx_sched.hpp"
 #include <cstdlib>
 
 #include "pcx_internal.hpp"
@@ -26,11 +27,12 @@ namespace pcx {
 namespace {
 using namespace fft4k;
 
-template <int LOG2M>
+template <int LOG2M, bool DYN = false>
 __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                         size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                         const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
-                                                                        size_t nblocks, unsigned M2, unsigned magic2, size_t n_dec2)
+                                                                        size_t nblocks, unsigned M2, unsigned magic2, size_t n_dec2,
+                                                                        pcx::SchedState *__restrict__ sched)
 {
     // M2 > 1: the decimation factor is M * M2 (M2 odd or any cofactor): the folded stream is decimated once more on the
     // store -- sample g of it is kept when (g + 1) % M2 == 0 and lands at (g + 1) / M2 - 1 (n_dec2 of them in all)
@@ -40,8 +42,9 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - Kov), Sd = S >> LOG2M;
-    size_t b = blockIdx.x;
-    if (b >= nblocks) return;
+    __shared__ unsigned sched_slot;
+    pcx::BlockWalk<DYN> walk;     // DYN: blocks dealt dynamically (pcx_sched.hpp)
+    if (!walk.begin(sched, &sched_slot, nblocks, j)) { walk.finish(j); return; }
     // pass-3 lane constants (30 VGPRs): in registers across the block loop for M >= 8; for M = 2 / 4 the inverse stage needs
     // the room and they are re-read from L2 in every block, like H (measured: M = 2 217 -> 249, M = 4 275 -> 288 Gsamples/s;
     // M = 16 loses 9 % with the reload and keeps them)
@@ -63,7 +66,8 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
     const int fi = j >> 4, l = j & 15;               // sub-frame and lane inside it (lanes j < 16 P run the 256-point stage)
     const bool sub = j < 16 * P;
 
-    for (; b < nblocks; b += gridDim.x) {
+    for (;;) {
+        const size_t b = walk.block();
         cf v[16];
         if (b >= first_full && b < nfull) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + b * S - pad, N * 8);
@@ -85,7 +89,9 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
                 v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
             }
         }
+        walk.draw(j);
         pass1(v, lds, j);
+        walk.publish(j);      // pass 2 opens with a barrier, and more follow before the block ends
         pass2(v, lds, j);
         if (TW3_REG) {
             pass3(v, lds, j, tw3r);
@@ -191,12 +197,14 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
             store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, cf{y.x, -y.y});
         }
         }
+        if (!walk.advance()) break;
     }
+    walk.finish(j);
 }
 
 template <int LOG2M>
 int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, size_t M2,
-                 hipStream_t st)
+                 void *sched, hipStream_t st)
 {
     constexpr size_t M = (size_t)1 << LOG2M;
     const size_t Km1 = K - 1;
@@ -208,11 +216,20 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     size_t nfull = n_iter / S;
     while (nfull > first_full && (nfull - 1) * S - pad + 4096 > in_elems) nfull--;
     if (nfull < first_full) nfull = first_full;
-    const unsigned grid = persistent_grid(nblocks, 1024);
+    // dynamic dealing measured SLOWER here (tools/ab_sched.sh, M = 8: 0.2190 vs 0.1950 ms): the kernel is bound by its arithmetic and
+    // re-reads H per block, and the grid stride keeps neighbouring blocks on neighbouring workgroups.  The product keeps the
+    // stride; PCX_SCHED_RESAMPLERS (diagnostic library) selects the dealer for A/B.
+    const bool dyn = sched && nblocks > 2 * 1024 && PCX_ENV_SET("PCX_SCHED_RESAMPLERS");
+    const unsigned grid = dyn ? 1024u : persistent_grid(nblocks, 1024);
     const unsigned magic2 = M2 > 1 ? (unsigned)(((1ull << 32) + M2 - 1) / M2) : 0u;
-    hipLaunchKernelGGL(fir_cf32_ols4096_decim_kernel<LOG2M>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
-                       (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks, (unsigned)M2, magic2,
-                       n_out / M2);
+    if (dyn)
+        hipLaunchKernelGGL((fir_cf32_ols4096_decim_kernel<LOG2M, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
+                           (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks, (unsigned)M2, magic2,
+                           n_out / M2, (pcx::SchedState *)sched);
+    else
+        hipLaunchKernelGGL((fir_cf32_ols4096_decim_kernel<LOG2M, false>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
+                           (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks, (unsigned)M2, magic2,
+                           n_out / M2, (pcx::SchedState *)nullptr);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -229,10 +246,11 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
 // input samples = S_in*L outputs per block; output i of a block is valid from i >= Kov_in*L on (the wrapped positions a
 // valid output still touches are zero-stuffing zeros).
 // --------------------------------------------------------------------------------- //
-template <int LOG2L>
+template <int LOG2L, bool DYN = false>
 __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                          size_t n_out, const float2 *__restrict__ Hspec, int Kov_in, int pad_in,
-                                                                         const float2 *__restrict__ twtab, size_t nblocks)
+                                                                         const float2 *__restrict__ twtab, size_t nblocks,
+                                                                         pcx::SchedState *__restrict__ sched)
 {
     constexpr int L = 1 << LOG2L, P = 16 / L, LOG2P = 4 - LOG2L, ND = 256 * P;
     constexpr int FRAME = 272;
@@ -240,8 +258,9 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const f
     const int j = threadIdx.x;
     const size_t S_in = (size_t)(ND - Kov_in), S_out = S_in << LOG2L;
     const int Kov_out = Kov_in << LOG2L;
-    size_t b = blockIdx.x;
-    if (b >= nblocks) return;
+    __shared__ unsigned sched_slot;
+    pcx::BlockWalk<DYN> walk;
+    if (!walk.begin(sched, &sched_slot, nblocks, j)) { walk.finish(j); return; }
     LaneTw tw3;
     load_pass3_twiddles(tw3, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
@@ -255,7 +274,8 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const f
     const int fi = j >> 4, l = j & 15;
     const bool sub = j < 16 * P;
 
-    for (; b < nblocks; b += gridDim.x) {
+    for (;;) {
+        const size_t b = walk.block();
         // input window: ND samples from input index b*S_in - pad_in (those before the buffer read 0: they only feed dropped outputs)
         const size_t start = b * S_in;
         const size_t shift = start >= (size_t)pad_in ? 0 : (size_t)pad_in - start;
@@ -269,6 +289,7 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const f
             const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * i - (int)shift) * 8, 0, 0);
             x[i] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
         }
+        walk.draw(j);
         __syncthreads();                                  // the previous block's inverse is done with the image
         // polyphase component n1 = n mod P of the window goes to sub-frame n1 at position n / P  (n = j + 256 i)
 #pragma unroll
@@ -336,6 +357,7 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const f
             u[r + 1] = g[(r + 1) & (P - 1)];
             cmul2_conj(u[r], u[r + 1], Hb[256 * r], Hb[256 * (r + 1)]);
         }
+        walk.publish(j);                                  // the inverse passes' barriers follow
         pass1(u, lds, j);
         pass2(u, lds, j);
         pass3(u, lds, j, tw3);
@@ -348,20 +370,27 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const f
             if (row + 255 < Kov_out) continue;                // whole row dropped: uniform skip
             store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
+        if (!walk.advance()) break;
     }
+    walk.finish(j);
 }
 
 template <int LOG2L>
-int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, hipStream_t st)
+int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, void *sched, hipStream_t st)
 {
     constexpr size_t L = (size_t)1 << LOG2L, ND = 4096 / L, A = 16 / L;    // Kov_in * L must be a multiple of 16
     const size_t Kov_in = (K - 1 + A - 1) / A * A, pad_in = Kov_in - (K - 1);
     if (Kov_in > ND / 2) { set_error("fir ols (interpolating): %zu taps per phase too long for L=%zu", K, L); return PCX_ERR_UNSUPPORTED; }
     const size_t S_in = ND - Kov_in;
     const size_t nblocks = (n_iter + S_in - 1) / S_in;
-    const unsigned grid = persistent_grid(nblocks, 1024);
-    hipLaunchKernelGGL(fir_cf32_ols4096_interp_kernel<LOG2L>, dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
-                       n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks);
+    const bool dyn = sched && nblocks > 2 * 1024 && PCX_ENV_SET("PCX_SCHED_RESAMPLERS");   // measured +-0 (0.1960 vs 0.1950 ms at L = 4): stride kept
+    const unsigned grid = dyn ? 1024u : persistent_grid(nblocks, 1024);
+    if (dyn)
+        hipLaunchKernelGGL((fir_cf32_ols4096_interp_kernel<LOG2L, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                           n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks, (pcx::SchedState *)sched);
+    else
+        hipLaunchKernelGGL((fir_cf32_ols4096_interp_kernel<LOG2L, false>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                           n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks, (pcx::SchedState *)nullptr);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -373,17 +402,17 @@ int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, con
 // Hspec = FFT_4096(h)[k] * exp(+j 2 pi k (M1-1) / 4096) / 4096.
 size_t fir_decim_fold_factor(size_t M) { return M % 16 == 0 ? 16 : M % 8 == 0 ? 8 : M % 4 == 0 ? 4 : M % 2 == 0 ? 2 : 1; }
 int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
-                                  const void *tw4096, hipStream_t st)
+                                  const void *tw4096, void *sched, hipStream_t st)
 {
     if (n_iter == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols (decimating): K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
     const size_t M1 = fir_decim_fold_factor(M), M2 = M / M1;
     if (M2 > 65535) { set_error("fir ols (decimating): M=%zu too large", M); return PCX_ERR_UNSUPPORTED; }
     switch (M1) {
-    case 2: return launch_decim<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
-    case 4: return launch_decim<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
-    case 8: return launch_decim<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
-    case 16: return launch_decim<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, st);
+    case 2: return launch_decim<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, sched, st);
+    case 4: return launch_decim<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, sched, st);
+    case 8: return launch_decim<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, sched, st);
+    case 16: return launch_decim<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, M2, sched, st);
     }
     set_error("fir ols (decimating): M=%zu is odd", M);
     return PCX_ERR_UNSUPPORTED;
@@ -391,14 +420,14 @@ int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, si
 
 // n_iter input iterations -> n_iter * L outputs.  Hspec = FFT_4096(all taps) / 4096; K = taps per polyphase row.
 int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
-                                   const void *tw4096, hipStream_t st)
+                                   const void *tw4096, void *sched, hipStream_t st)
 {
     if (n_iter == 0) return PCX_OK;
     switch (L) {
-    case 2: return launch_interp<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
-    case 4: return launch_interp<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
-    case 8: return launch_interp<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
-    case 16: return launch_interp<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, st);
+    case 2: return launch_interp<1>(in, in_elems, out, n_iter, Hspec, K, tw4096, sched, st);
+    case 4: return launch_interp<2>(in, in_elems, out, n_iter, Hspec, K, tw4096, sched, st);
+    case 8: return launch_interp<3>(in, in_elems, out, n_iter, Hspec, K, tw4096, sched, st);
+    case 16: return launch_interp<4>(in, in_elems, out, n_iter, Hspec, K, tw4096, sched, st);
     }
     set_error("fir ols (interpolating): L=%zu is not 2, 4, 8 or 16", L);
     return PCX_ERR_UNSUPPORTED;

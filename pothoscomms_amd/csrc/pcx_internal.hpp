@@ -150,10 +150,10 @@ int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                             const void *tw4096, void *sched, hipStream_t st);
 int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
-                                   const void *tw4096, hipStream_t st);
+                                   const void *tw4096, void *sched, hipStream_t st);
 size_t fir_decim_fold_factor(size_t M);
 int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
-                                  const void *tw4096, hipStream_t st);
+                                  const void *tw4096, void *sched, hipStream_t st);
 int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
                             const void *tw, hipStream_t st);
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
@@ -163,7 +163,7 @@ int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out
 
 // real float32 stream, real taps, M=L=1: two real blocks per complex transform
 int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                           const void *tw4096, hipStream_t st);
+                           const void *tw4096, void *sched, hipStream_t st);
 // same pipeline with interpolation L / decimation M: one launch per polyphase row;
 // Hspec_rows: L spectra of 4096 cf32 (row j = FFT(taps[j + k*L]) / 4096); n_iter = inputs consumed
 int launch_interleave_rows_cf32(const void *rows, void *out, size_t n, size_t L, hipStream_t st);

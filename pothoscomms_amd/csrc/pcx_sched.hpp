@@ -76,6 +76,26 @@ struct BlockDealer {
     }
 };
 
+// One spelling for both walks, so a kernel is written once: BlockWalk<false> is the grid stride, BlockWalk<true> the dealer.
+//     BlockWalk<DYN> walk;
+//     if (!walk.begin(sched, &slot, nblocks, lane)) { walk.finish(lane); return; }      // FIRST: begin() holds a barrier
+//     for (;;) { b = walk.block(); loads; walk.draw(lane); ...; walk.publish(lane); <a barrier>; ...; if (!walk.advance()) break; }
+//     walk.finish(lane);
+template <bool DYN>
+struct BlockWalk;
+template <>
+struct BlockWalk<true> : BlockDealer {};
+template <>
+struct BlockWalk<false> {
+    size_t b, n;
+    __device__ __forceinline__ bool begin(SchedState *, unsigned *, size_t nblocks_, int) { b = blockIdx.x; n = nblocks_; return b < n; }
+    __device__ __forceinline__ size_t block() const { return b; }
+    __device__ __forceinline__ void draw(int) {}
+    __device__ __forceinline__ void publish(int) {}
+    __device__ __forceinline__ bool advance() { b += gridDim.x; return b < n; }
+    __device__ __forceinline__ void finish(int) {}
+};
+
 // The same dealing for a kernel that prefetches the NEXT block's input while it works on the current one (fft4096_kernel):
 // the next block's index must be known at the START of a block, so the draw for chunk c+1 is issued during the FIRST
 // block of chunk c, published in front of one of that block's barriers and read at the start of the chunk's second block.

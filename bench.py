@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "decim8", "interp4", "fir255_i16"])
     ap.add_argument("--shard", type=int, default=SHARD, help="samples per GPU (default 64 Mi)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--settle", type=int, default=PREWARM,
+                    help="untimed setup passes before the W warm-up steps (clock settling after idle; reported as config.setup_passes)")
     return ap.parse_args()
 
 
@@ -320,7 +322,7 @@ def main():
             sf.step()
         desc = {"workload": "255-tap complex_float32 FIR (/comms/fir_filter, COMPLEX taps, M=L=1), %d-sample shard per GPU, "
                             "%s" % (C, "frequency-domain overlap-save (4096-pt Stockham)" if wl == "fir255" else "LDS-tiled direct form"),
-                "taps": 255, "shard_samples": C, "halo_samples": K - 1, "setup_passes": PREWARM,
+                "taps": 255, "shard_samples": C, "halo_samples": K - 1, "setup_passes": args.settle,
                 "parallelism": "overlap-save shards x%d, RCCL send/recv halo" % world if world > 1 else "single GPU"}
         metric = "Msamples/s complex_float32 255-tap FIR"
     elif wl == "fft4096":
@@ -428,7 +430,7 @@ def main():
     # setup: let the clocks settle.  The first ~50 back-to-back launches after an idle period run
     # through a DVFS transient on this part (230 us -> 320 us -> 245 us per launch, profiles/r01);
     # these untimed passes are part of setup, not of the W warm-up steps or the timed region.
-    for _ in range(PREWARM):
+    for _ in range(args.settle):
         step()
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,155 @@
+"""GPU suite: the execution model of the C ABI (pcx_api.hip ExecCtx, include/pcx.h "Conventions") -- what round 1's review
+found missing: page-locked host buffers processed in place, calls of one handle on DIFFERENT streams ordered behind each
+other (carried state, tables), setters between asynchronous calls, reset enqueued, two handles on two threads."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from tests.util import TOL, ang_err, nerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _pinned(shape, dtype):
+    from pothoscomms_amd import _lib
+    L = _lib.load()
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _lib.check(L.pcx_host_alloc(C.byref(p), nbytes))
+    arr = np.ctypeslib.as_array((C.c_char * nbytes).from_address(p.value)).view(dtype).reshape(shape)
+    return arr, p
+
+
+def _free(p):
+    from pothoscomms_amd import _lib
+    _lib.check(_lib.load().pcx_host_free(p))
+
+
+def test_page_locked_buffers_are_processed_in_place(oracle, dev):
+    """FIR, FFT, FreqDemod, the fused chain and the maps on pcx_host_alloc memory -- including pointers INTO an allocation
+    (a port buffer is a window of a slab) and a pinned input with a pageable output"""
+    from pothoscomms_amd import taps as tp
+    rng = np.random.default_rng(5)
+    h = tp.c1_taps()
+    K, n = len(h), 70001
+    slab, ps = _pinned((4096 + n + K - 1 + 100, 2), np.float32)
+    out, po = _pinned((n + 300, 2), np.float32)
+    try:
+        x = slab[4096 + 37:4096 + 37 + n + K - 1]          # an odd offset inside the slab
+        x[:] = rng.uniform(-1, 1, x.shape).astype(np.float32)
+        y = out[123:123 + n]
+        out[:] = np.nan
+        f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h)
+        from pothoscomms_amd import _lib
+        c, p = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().pcx_fir_process(f._h, x.ctypes.data, n + K - 1, y.ctypes.data, n, C.byref(c), C.byref(p)))
+        ref_blk = oracle.Fir(oracle.F32, True, True); ref_blk.set_taps(h); ref_blk.activate()
+        ref, _, rp, _ = ref_blk.work(x.copy(), n)
+        assert (c.value, p.value) == (n, n) and nerr(y, ref) <= TOL
+        assert np.isnan(out[:123]).all() and np.isnan(out[123 + n:]).all()      # nothing outside the window was written
+        # pinned in, pageable out (and the reverse)
+        got, _, _ = f.process(x, n)
+        assert nerr(got, ref) <= TOL
+        y[:] = 0
+        _lib.check(_lib.load().pcx_fir_process(f._h, x.copy().ctypes.data, n + K - 1, y.ctypes.data, n, C.byref(c), C.byref(p)))
+        assert nerr(y, ref) <= TOL
+        # maps in place on pinned memory (out == in is part of the contract)
+        z = x[:50000]
+        want = oracle.conj(z.copy())
+        _lib.check(_lib.load().pcx_conj(_lib.F32, z.ctypes.data, z.ctypes.data, 50000))
+        assert np.array_equal(z, want)
+        # FFT and FreqDemod
+        xf = slab[:4096 * 3]
+        xf[:] = rng.uniform(-1, 1, xf.shape).astype(np.float32)
+        yf = out[:4096 * 3]
+        t = dev.Fft("complex_float32", 4096, False)
+        _lib.check(_lib.load().pcx_fft_transform(t._h, xf.ctypes.data, yf.ctypes.data, 3))
+        assert nerr(yf, oracle.fft(xf.copy(), 4096, False)) <= TOL
+    finally:
+        _free(ps); _free(po)
+
+
+def test_calls_on_different_streams_are_ordered_behind_each_other(oracle, dev):
+    """FreqDemod carries prev on the device: chunk i on stream A, chunk i+1 on stream B, no host synchronisation between --
+    the result must be the single-stream one.  Same for the fused chain, and for a FIR whose taps change between calls."""
+    import torch
+    d = torch.device("cuda", 0)
+    sA, sB = torch.cuda.Stream(d), torch.cuda.Stream(d)
+    rng = np.random.default_rng(9)
+    n = 1 << 20
+    ph = np.cumsum(rng.uniform(-1.0, 1.0, n))
+    xh = np.stack([np.cos(ph), np.sin(ph)], 1).astype(np.float32)
+    x = torch.from_numpy(xh).to(d)
+    y = torch.empty(n, dtype=torch.float32, device=d)
+    torch.cuda.synchronize()
+    dm = dev.FreqDemod("complex_float32")
+    cuts = [0, 1000, 1001, 300000, 300017, 800000, n]
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        dm.process_dev(x[a:b], y[a:b], b - a, stream=(sA, sB)[i & 1])
+    torch.cuda.synchronize()
+    assert ang_err(y.cpu().numpy(), oracle.FreqDemod(oracle.F32).work(xh)) <= TOL
+    # reset is enqueued behind the previous call and ahead of the next one, whatever their streams
+    dm.process_dev(x[:5000], y[:5000], 5000, stream=sA)
+    dm.reset()
+    dm.process_dev(x[5000:9000], y[5000:9000], 4000, stream=sB)
+    torch.cuda.synchronize()
+    assert ang_err(y[5000:9000].cpu().numpy(), oracle.FreqDemod(oracle.F32).work(xh[5000:9000])) <= TOL
+    # FIR: new taps between two asynchronous calls on two streams -- the first call must finish with the OLD tables
+    from pothoscomms_amd import taps as tp
+    h1, h2 = tp.c1_taps(), tp.c0_taps()
+    big = 8 << 20
+    xb = torch.empty((big + 254, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(xb, seed=3)
+    y1 = torch.empty((big, 2), dtype=torch.float32, device=d)
+    y2 = torch.empty((big, 2), dtype=torch.float32, device=d)
+    torch.cuda.synchronize()
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h1)
+    f.process_dev(xb, y1, big + 254, big, stream=sA)
+    f.set_taps(h2)                                    # host returns at once; the kernel above is still running
+    f.process_dev(xb[254 - 62:], y2, big + 62, big, stream=sB)
+    torch.cuda.synchronize()
+    xw = xb[:70000 + 254].cpu().numpy()
+    r1 = oracle.Fir(oracle.F32, True, True); r1.set_taps(h1); r1.activate()
+    r2 = oracle.Fir(oracle.F32, True, True); r2.set_taps(h2); r2.activate()
+    assert nerr(y1[:70000].cpu().numpy(), r1.work(xw, 70000)[0]) <= TOL
+    assert nerr(y2[:70000].cpu().numpy(), r2.work(xw[254 - 62:], 70000)[0]) <= TOL
+    # ... and its tail, which the first launch reaches last
+    xt = xb[big - 70000:].cpu().numpy()
+    assert nerr(y1[big - 70000:].cpu().numpy(), r1.work(xt, 70000)[0]) <= TOL
+
+
+def test_two_blocks_on_two_threads(oracle, dev):
+    """two handles, two host threads, host buffers: each handle runs on its own stream; results are each block's own"""
+    from pothoscomms_amd import taps as tp
+    rng = np.random.default_rng(3)
+    hs = [tp.c1_taps(), tp.c0_taps()]
+    xs = [rng.uniform(-1, 1, (300000 + len(h) - 1, 2)).astype(np.float32) for h in hs]
+    outs = [None, None]
+
+    def actor(i):
+        f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(hs[i])
+        for _ in range(5):
+            outs[i] = f.process(xs[i], 300000)[0]
+    th = [threading.Thread(target=actor, args=(i,)) for i in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for i in range(2):
+        r = oracle.Fir(oracle.F32, True, True); r.set_taps(hs[i]); r.activate()
+        assert nerr(outs[i], r.work(xs[i], 300000)[0]) <= TOL
+
+
+def test_the_library_ignores_the_environment(oracle):
+    """round 1 shipped timing-only kernel variants behind PCX_OLS_VARIANT: the product library must not read it"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np\nfrom oracle import oracle as o\nfrom pothoscomms_amd import device, taps as tp\n"
+            "h = tp.c1_taps(); x = np.random.default_rng(0).uniform(-1, 1, (90000 + 254, 2)).astype(np.float32)\n"
+            "f = device.FirFilter('complex_float32', 'COMPLEX'); f.set_taps(h); got = f.process(x, 90000)[0]\n"
+            "r = o.Fir(o.F32, True, True); r.set_taps(h); r.activate(); ref = r.work(x, 90000)[0]\n"
+            "assert np.max(np.abs(got - ref)) / np.max(np.abs(ref)) <= 1e-5\nprint('ok')\n")
+    env = dict(os.environ, PCX_OLS_VARIANT="11", PCX_OLS_DIAG="2", PCX_FFT_MIXED_DIAG="1", PCX_OLS_SLOTS="7", PCX_OLS_ALIGN="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

@@ -233,7 +233,9 @@ int launch_r16(const void *in, void *out, size_t nframes, bool inverse, const vo
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
+    // several workgroups queued per slot: the dispatcher balances the CUs' unequal rates (pcx_internal.hpp persistent_grid).  Measured
+    // (tools/sweep_fft.py, PCX_OVERSUB A/B): +5..10 % at 4-8 for 64 ... 8192 bins (1024: 355 -> 393 Gsamples/s), -7..-11 % at 16384
+    const unsigned grid = persistent_grid(ngroups, 256 * per_cu, LOG2N <= 10 ? 8 : LOG2N <= 13 ? 4 : 1);
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::THREADS), lds, st, (const float2 *)in, (float2 *)out, nframes, (const float2 *)tw);
     PCX_LAUNCH_CHECK();
     return PCX_OK;

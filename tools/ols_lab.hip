@@ -150,6 +150,14 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
         const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)ph * (unsigned)ticks;
         while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
     }
+    if (stag == -7 || stag == -9) {   // a fixed order among the four workgroups that share a CU (-7: idx >> 8 under round-robin dispatch; -9: idx & 3)
+        switch (stag == -7 ? 3 - ((blockIdx.x >> 8) & 3) : (blockIdx.x & 3)) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
     cf H[16];
     const int jh = MODE == MODE_SWAP ? (j >> 4) + 16 * (j & 15) : j;   // digit-swap pipeline: the lane holds bins swap(j) + 256 k
 #pragma unroll
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
             store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
         }
-        if (stag < 0) __builtin_amdgcn_s_setprio(0);
+        if (stag < 0 && stag > -7) __builtin_amdgcn_s_setprio(0);
         if (!dyn) { b += gridDim.x; continue; }
         if (++sub >= csz || block_of(cq, sub) >= nblocks) {
             cq = next_block[it & 1];
@@ -442,21 +450,13 @@ int main(int argc, char **argv)
     CK(hipMalloc(&ctr, 64)); CK(hipMemset(ctr, 0, 64));
     // name, mode, dose | barrier mask, wg/CU, zero input, dose operand scale, stagger | priority mode, chunk (0 = static stride), grid (0 = balanced 971)
     const Cfg cfgs[] = {
-        {"product pipeline, static stride (r01)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
-        {"  same, grid 4096 (hw dispatcher balances)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 4096},
-        {"  dynamic pairs (pcx_sched.hpp)", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
-        {"  dynamic pairs + prio 1 on 2nd half (r02)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
-        {"  dynamic single blocks (counter saturates)", MODE_FULL, 3, 4, false, 0.f, 0, -1, 1024},
-        {"  static, 4 barriers/block (digit-swap)", MODE_SWAP, 0, 4, false, 0.f, 0, 0, 0},
-        {"  static, WAR barriers removed [timing only]", MODE_FULL, 2, 4, false, 0.f, 0, 0, 0},
-        {"  static, no barriers at all [timing only]", MODE_FULL, 0, 4, false, 0.f, 0, 0, 0},
-        {"  static, all-zero input (no toggling)", MODE_FULL, 3, 4, true, 0.f, 0, 0, 0},
-        {"loads + stores only", MODE_MEM, 0, 4, false, 0.f, 0, 0, 0},
-        {"  + 160 packed FMAs/lane/block, random data", MODE_DOSE, 160, 4, false, 1.0f, 0, 0, 0},
-        {"  + 640 packed FMAs/lane/block, random data", MODE_DOSE, 640, 4, false, 1.0f, 0, 0, 0},
-        {"  + 640 packed FMAs/lane/block, zeros", MODE_DOSE, 640, 4, false, 0.f, 0, 0, 0},
-        {"product pipeline, static stride (again)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
-        {"  dynamic pairs + prio 1 on 2nd half (again)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"dynamic pairs + prio 1 on 2nd half (r02)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"dynamic pairs, fixed prio by CU slot (idx>>8)", MODE_FULL, 3, 4, false, 0.f, -7, -2, 1024},
+        {"dynamic pairs, fixed prio by idx&3", MODE_FULL, 3, 4, false, 0.f, -9, -2, 1024},
+        {"dynamic pairs, no prio", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
+        {"dynamic pairs + prio 1 on 2nd half (r02)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"dynamic pairs, fixed prio by CU slot (idx>>8)", MODE_FULL, 3, 4, false, 0.f, -7, -2, 1024},
+        {"static 971, fixed prio by CU slot", MODE_FULL, 3, 4, false, 0.f, -7, 0, 0},
     };
     {   // parity of the digit-swap pipeline against the product pipeline on the same random input
         float2 *y2;

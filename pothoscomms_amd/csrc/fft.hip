@@ -508,7 +508,7 @@ static int launch_q15_r16(const void *in, void *out, size_t nframes, bool invers
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    hipLaunchKernelGGL(k, dim3(persistent_grid(ngroups, 256 * per_cu)), dim3(P::THREADS), P::LDS, st, (const K16 *)in, (K16 *)out, nframes,
+    hipLaunchKernelGGL(k, dim3(persistent_grid(ngroups, 256 * per_cu, 4)), dim3(P::THREADS), P::LDS, st, (const K16 *)in, (K16 *)out, nframes,
                        (const K16 *)tw, (const unsigned short *)perm, inverse ? 1 : 0);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
@@ -561,7 +561,7 @@ int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool
     unsigned per_cu = (unsigned)(160 * 1024 / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
+    const unsigned grid = persistent_grid(ngroups, 256 * per_cu, 4);   // four queued per slot: +5..9 % on the Q15 kernels (tools/sweep_fft.py, PCX_OVERSUB A/B)
     hipLaunchKernelGGL(fft_q15_kernel, dim3(grid), dim3(lanes * fpw), lds, st, (const K16 *)in, (K16 *)out, (int)nbins, log2n, nframes,
                        (const K16 *)tw, (const unsigned short *)perm, plan, inverse ? 1 : 0, (int)fpw, stage_tw);
     PCX_LAUNCH_CHECK();

@@ -20,6 +20,12 @@ python tools/two_blocks.py summarize $O/two >> $O/two_blocks.txt 2>/dev/null
 tools/pcie_lab > $O/pcie_lab.txt 2>&1
 timeout 300 tools/ols_lab 4 > $O/ols_lab_summary.txt 2>&1
 python tools/sweep_fir.py > $O/sweep_fir_taps.txt 2>/dev/null
+python tools/sweep_map.py > $O/sweep_elementwise.txt 2>/dev/null
+python tools/sweep_fft.py 16 64 256 1024 2048 4096 8192 16384 > $O/sweep_fft_sizes.txt 2>/dev/null
+python tools/sweep_fft_f64.py > $O/sweep_fft_f64.txt 2>/dev/null
+python tools/sweep_fft_mixed.py > $O/sweep_fft_mixed.txt 2>/dev/null
+python tools/sweep_fir_f64.py > $O/sweep_fir_f64.txt 2>/dev/null
+python tools/real_probe.py > $O/real_f32_fir.txt 2>/dev/null
 find $O -name "*.csv" -size +2M -delete
 find $O -name "*agent_info*" -delete
 du -sh $O

@@ -132,7 +132,7 @@ class Block:
         self.path = path
         self.dtype = dtype
         sarg, nbins, inverse = None, 0, 0
-        if path.endswith("fir_filter") or path.endswith("/arithmetic"):
+        if path.endswith("fir_filter") or path.endswith("/arithmetic") or path.endswith("fm_demod_chain"):
             sarg = (args[0] if args else "").encode()     # tapsType resp. operation
         elif path == "/comms/fft":
             nbins, inverse = int(args[0]), int(bool(args[1])) if len(args) > 1 else 0

@@ -442,6 +442,113 @@ Block *FreqDemodFactory(const DType &dtype)
 pcxfw::BlockRegistry registerFreqDemod("/comms/freq_demod", &FreqDemodFactory);
 
 /***********************************************************************
+ * /comms/fm_demod_chain -- EXTENSION (no counterpart in the reference): /comms/rotate -> /comms/fir_filter -> /comms/freq_demod
+ * as ONE block over the fused kernel (pcx_fmchain_*, BASELINE configs[4]).  A topology that wires those three blocks in a row
+ * gets the same stream from this one with a single trip through the device: complex_float32 in, float32 out, the registered
+ * calls of the three (setPhase / getPhase as Rotate.cpp:63-66; setTaps / getTaps as FIRFilter.cpp:113-124, REAL or COMPLEX by the
+ * factory's tapsType); activate() resets the demodulator's carried sample as FreqDemod::activate does (FreqDemod.cpp:44-47).
+ * Like the FIR it keeps K-1 samples of history at the front of its (circular) input buffer and produces one output per input.
+ * Rotate's quirk is kept: until setPhase is called the phasor is zero and so is the output (Rotate.cpp:60-62).
+ **********************************************************************/
+class FmDemodChain : public DeviceBlock {
+public:
+    FmDemodChain(const DType &dtype, bool complexTaps) : _complexTaps(complexTaps), _phase(0.0), K(1), _h(nullptr)
+    {
+        check(pcx_fmchain_create(&_h), "fmDemodChainFactory(" + dtype.toString() + ")");
+        this->setupInput(0, dtype);
+        this->setupOutput(0, realOf(dtype));
+        this->registerCall(this, PCX_FCN_TUPLE(FmDemodChain, setPhase));
+        this->registerCall(this, PCX_FCN_TUPLE(FmDemodChain, getPhase));
+        if (complexTaps) {
+            this->registerCall(this, "setTaps", &FmDemodChain::setTapsComplex);
+            this->registerCall(this, "getTaps", &FmDemodChain::getTapsComplex);
+        } else {
+            this->registerCall(this, "setTaps", &FmDemodChain::setTapsReal);
+            this->registerCall(this, "getTaps", &FmDemodChain::getTapsReal);
+        }
+        _taps.assign(1, std::complex<double>(1.0, 0.0));
+        this->pushTaps();
+    }
+    ~FmDemodChain() { pcx_fmchain_destroy(_h); }
+
+    void setPhase(const double phase)
+    {
+        _phase = phase;
+        check(pcx_fmchain_set_phase(_h, phase), "FmDemodChain::setPhase()");
+    }
+    double getPhase() const { return _phase; }
+    void setTapsReal(const std::vector<double> &taps)
+    {
+        if (taps.empty()) throw InvalidArgumentException("FmDemodChain::setTaps()", "taps cannot be empty");
+        _taps.assign(taps.begin(), taps.end());
+        this->pushTaps();
+    }
+    void setTapsComplex(const std::vector<std::complex<double>> &taps)
+    {
+        if (taps.empty()) throw InvalidArgumentException("FmDemodChain::setTaps()", "taps cannot be empty");
+        _taps = taps;
+        this->pushTaps();
+    }
+    std::vector<double> getTapsReal() const
+    {
+        std::vector<double> t(_taps.size());
+        for (size_t i = 0; i < t.size(); i++) t[i] = _taps[i].real();
+        return t;
+    }
+    std::vector<std::complex<double>> getTapsComplex() const { return _taps; }
+
+    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return pinnedManager("circular"); }
+    void activate() { check(pcx_fmchain_reset(_h), "FmDemodChain::activate()"); }
+
+    void work()
+    {
+        auto inPort = this->input(0);
+        auto outPort = this->output(0);
+        const size_t avail = inPort->elements();
+        if (avail == 0) return;
+        if (avail < K) { inPort->setReserve(K); return; }          // one output needs K samples (K-1 of them history)
+        inPort->setReserve(0);
+        size_t consumed = 0, produced = 0;
+        check(pcx_fmchain_process(_h, inPort->buffer().template as<const void *>(), avail, outPort->buffer().template as<void *>(), outPort->elements(),
+                                  &consumed, &produced),
+              "FmDemodChain::work()");
+        inPort->consume(consumed);                                 // K-1 elements stay as history
+        outPort->produce(produced);
+    }
+
+private:
+    void pushTaps()
+    {
+        std::vector<double> flat;
+        if (_complexTaps) {
+            flat.resize(2 * _taps.size());
+            for (size_t i = 0; i < _taps.size(); i++) { flat[2 * i] = _taps[i].real(); flat[2 * i + 1] = _taps[i].imag(); }
+        } else {
+            flat.resize(_taps.size());
+            for (size_t i = 0; i < _taps.size(); i++) flat[i] = _taps[i].real();
+        }
+        check(pcx_fmchain_set_taps(_h, flat.data(), _taps.size(), _complexTaps ? 1 : 0), "FmDemodChain::setTaps()");
+        K = _taps.size();
+    }
+    std::vector<std::complex<double>> _taps;
+    bool _complexTaps;
+    double _phase;
+    size_t K;
+    pcx_fmchain *_h;
+};
+Block *fmDemodChainFactory(const DType &dtype, const std::string &tapsType)
+{
+    int scalar;
+    bool cplx;
+    if (!(parseElemType(dtype, scalar, cplx) && cplx && scalar == PCX_F32 && dtype.dimension() == 1))
+        throw InvalidArgumentException("fmDemodChainFactory(" + dtype.toString() + ")", "unsupported types (complex_float32 only)");
+    if (tapsType != "REAL" && tapsType != "COMPLEX")
+        throw InvalidArgumentException("fmDemodChainFactory(" + dtype.toString() + ", " + tapsType + ")", "unsupported types");
+    return new FmDemodChain(dtype, tapsType == "COMPLEX");
+}
+pcxfw::BlockRegistry registerFmDemodChain("/comms/fm_demod_chain", &fmDemodChainFactory);
+
+/***********************************************************************
  * shared by Rotate and Scale: a coefficient that an upstream label may replace mid-stream
  **********************************************************************/
 template <typename Derived>

@@ -89,7 +89,8 @@ int pcxb_make(const char *path, const char *dtype, size_t dimension, const char 
         const bool no_args = p == "/comms/fir_designer" || p == "/blocks/fir_designer";   // FIRDesigner::make(void)
         if (!no_args) args.push_back(Object(DType(std::string(dtype), dimension ? dimension : 1)));
         if (no_args) {
-        } else if (p == "/comms/fir_filter" || p == "/blocks/fir_filter" || p == "/comms/arithmetic" || p == "/blocks/arithmetic")
+        } else if (p == "/comms/fir_filter" || p == "/blocks/fir_filter" || p == "/comms/arithmetic" || p == "/blocks/arithmetic" ||
+                   p == "/comms/fm_demod_chain")
             args.push_back(Object(std::string(sarg ? sarg : "")));
         else if (p == "/comms/fft") { args.push_back(Object((unsigned long)num_bins)); args.push_back(Object(inverse != 0)); }
         std::unique_ptr<pcxb_block> b(new pcxb_block());

@@ -17,7 +17,9 @@ def test_registry_paths_match_the_reference():
                                          # Arithmetic.cpp:300-304, SplitComplex.cpp:72-73, CombineComplex.cpp:71-72
                                          "/blocks/arithmetic", "/comms/arithmetic", "/comms/split_complex", "/comms/combine_complex",
                                          # FIRDesigner.cpp:479-483
-                                         "/comms/fir_designer", "/blocks/fir_designer"])
+                                         "/comms/fir_designer", "/blocks/fir_designer",
+                                         # extension (no reference counterpart): rotate -> fir_filter -> freq_demod fused, configs[4]
+                                         "/comms/fm_demod_chain"])
     with pytest.raises(ValueError):
         B.make("/comms/does_not_exist", "float32")
 
@@ -191,3 +193,4 @@ def test_split_combine_factories(t):
     # minAllElements = 0 -> no device call
     outs, cons, prod = sp.work_ports([np.zeros((4, 2), np.dtype(t))], [4, 0])
     assert cons == [0] and prod == [0, 0]
+

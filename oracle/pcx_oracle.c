@@ -21,13 +21,20 @@
  *     (RMS threshold only / no test); the restatement is pinned by an
  *     independent float64 convolution and the survey's observed anchors.
  *   - Integer Q-format (fromQ/floatToQ live in PothosCore, which is not in
- *     the reference tree): semantics restated from the published header
- *     Pothos/Util/QFormat.hpp (PothosCore >= 0.6): half of the Q word is
- *     fractional, floatToQ = T(ldexp(x, n)), fromQ = T(q >> n).  Integer
- *     FIR/Rotate/Scale are therefore "parity unpinned" beyond the reference
- *     tests' own 1-LSB tolerance.
+ *     the reference tree): restated as "half of the Q word is fractional,
+ *     floatToQ = T(ldexp(x, n)), fromQ = T(q >> n)".  PARITY UNPINNED: of the
+ *     96 candidate semantics run through math/TestRotate.cpp and
+ *     math/TestScale.cpp with the reference's own integer arithmetic, 12
+ *     survive (tools/qformat_enumeration.py) -- the fractional
+ *     bit count is half the Q word or half the element word, the same in both
+ *     directions; rounding is not pinned at all.  This restatement is one of
+ *     the 12.  Integer FIR/Rotate/Scale are bit-exact against it, not against
+ *     the (absent) header.
+ *   - The pinning tests run on BOTH boxes (tests/test_oracle_cpu.py under
+ *     -m "not gpu" and under -m gpu): this library binds the glibc / libgcc_s
+ *     of the machine it is loaded on.
  *
- * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see Makefile)
+ * Build: gcc -O3 -ffp-contract=off -fno-fast-math -shared -fPIC (see Makefile)
  * -ffp-contract=off keeps every product and sum separately rounded, as the
  * reference's baseline x86-64 build (no FMA) does.
  */

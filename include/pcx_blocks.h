@@ -76,6 +76,11 @@ PCXB_API int pcxb_buffer_manager(pcxb_block *b, int is_output, char *name, size_
  * out page-locked slabs (*pinned = 1), on which the C ABI runs its kernels directly -- a work() loop over these
  * buffers pays no staging copy.  The memory belongs to the block and lives until pcxb_destroy. */
 PCXB_API int pcxb_acquire_buffer(pcxb_block *b, int is_output, size_t min_bytes, void **ptr, size_t *bytes, int *pinned);
+/* The same for an EDGE src.output(0) -> dst.input(0), with the negotiation a scheduler does: dst is asked first with src's port
+ * domain, then src with dst's; two blocks of this module share the domain "pcx-hip" and get slabs in DEVICE memory (*kind = 2:
+ * host code must not touch them; 1 = page-locked host, 0 = pageable), so samples flowing between them never cross PCIe.  The
+ * memory belongs to dst and lives until pcxb_destroy(dst). */
+PCXB_API int pcxb_link_buffer(pcxb_block *src, pcxb_block *dst, size_t min_bytes, void **ptr, size_t *bytes, int *kind);
 /* the reserve a block asked for at construction time (FFT: numBins); SIZE_MAX = none */
 PCXB_API int pcxb_initial_reserve(pcxb_block *b, size_t *reserve);
 

@@ -63,6 +63,7 @@ def load():
     L.pcxb_buffer_manager.argtypes = [vp, i, cp, sz, C.POINTER(sz)]
     L.pcxb_initial_reserve.argtypes = [vp, C.POINTER(sz)]
     L.pcxb_acquire_buffer.argtypes = [vp, i, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+    L.pcxb_link_buffer.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.pcxb_call_sizes.argtypes = [vp, cp, C.POINTER(sz), sz]
     L.pcxb_get_sizes.argtypes = [vp, cp, C.POINTER(sz), sz, C.POINTER(sz)]
     L.pcxb_num_ports.argtypes = [vp, i, C.POINTER(sz)]
@@ -242,6 +243,21 @@ class Block:
         _check(load().pcxb_acquire_buffer(self._h, int(is_output), nbytes, C.byref(p), C.byref(sz), C.byref(pin)))
         arr = np.ctypeslib.as_array((C.c_char * nbytes).from_address(p.value)).view(dtype).reshape(shape)
         return arr, bool(pin.value)
+
+    def link_buffer(self, downstream, nbytes):
+        """The buffer a scheduler would plant on the edge self.output(0) -> downstream.input(0) (pcxb_link_buffer).
+        Returns (address, kind): kind 2 = device memory (two blocks of this module), 1 = page-locked host, 0 = pageable."""
+        p, sz, kind = C.c_void_p(), C.c_size_t(), C.c_int()
+        _check(load().pcxb_link_buffer(self._h, downstream._h, nbytes, C.byref(p), C.byref(sz), C.byref(kind)))
+        return p.value, kind.value
+
+    def work_raw(self, in_ptr, in_elems, out_ptr, out_elems):
+        """One work() call on raw buffer addresses (host or device memory).  Returns (consumed, produced, reserve)."""
+        labs, posted = (PcxbLabel * 1)(), (PcxbLabel * 64)()
+        c, p, r, npost = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(load().pcxb_work(self._h, C.c_void_p(in_ptr), in_elems, labs, 0, C.c_void_p(out_ptr), out_elems, C.byref(c), C.byref(p),
+                                C.byref(r), posted, 64, C.byref(npost)))
+        return c.value, p.value, (None if r.value == _SIZE_MAX else r.value)
 
     def initial_reserve(self):
         r = C.c_size_t()

@@ -129,11 +129,46 @@ static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t 
     args.pinned = true;
     return pcxfw::BufferManager::make(name, args);
 }
+// slabs in device memory, for an edge whose other end is a block of this module too
+static pcxfw::BufferManager::Sptr deviceManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
+{
+    pcxfw::BufferManagerArgs args;
+    args.bufferSize = slabBytes;
+    args.numBuffers = 4;
+    args.device = true;
+    return pcxfw::BufferManager::make(name, args);
+}
 #endif
+// The port domain of this module's blocks (Pothos: the third argument of setupInput / setupOutput, handed to the OTHER end's
+// get{Input,Output}BufferManager [ext]).  When both ends of an edge carry it, the edge's buffers live in device memory: the
+// upstream block's output manager hands out HBM slabs, the downstream block asks for nothing -- or, the FIR, for its circular
+// buffer in HBM -- and the host-pointer entry points of the C ABI run in place on them (they recognise device pointers exactly
+// as they recognise page-locked ones).  A Rotate -> FIR -> FreqDemod topology of three separate blocks then crosses PCIe
+// once in and once out instead of three times each way.  Any other domain ("" = a host block) gets page-locked host slabs.
+static const char *const kDomain = "pcx-hip";
 class DeviceBlock : public Block {
 public:
+    // every port of a device block carries the module's domain
+    pcxfw::InputPort *setupInput(size_t i, const DType &dt = DType()) { return Block::setupInput(i, dt, kDomain); }
+    pcxfw::OutputPort *setupOutput(size_t i, const DType &dt = DType()) { return Block::setupOutput(i, dt, kDomain); }
+    // an explicit domain stays what the block asked for (Arithmetic's unique one, Arithmetic.cpp:136: buffer forwarding)
+    pcxfw::OutputPort *setupOutput(size_t i, const DType &dt, const std::string &domain) { return Block::setupOutput(i, dt, domain); }
+    pcxfw::InputPort *setupInput(const std::string &name, const DType &dt = DType()) { return Block::setupInput(name, dt, kDomain); }
+    pcxfw::OutputPort *setupOutput(const std::string &name, const DType &dt = DType()) { return Block::setupOutput(name, dt, kDomain); }
+#ifndef PCX_WITH_POTHOS
+    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
+    {
+        if (domain == kDomain) return pcxfw::BufferManager::Sptr();     // the upstream block of this module provides device slabs
+        return pinnedManager("generic");
+    }
+    pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &domain)
+    {
+        return domain == kDomain ? deviceManager("generic") : pinnedManager("generic");
+    }
+#else
     pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }
     pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }
+#endif
 };
 
 /***********************************************************************
@@ -230,9 +265,15 @@ public:
     void setFrameEndId(std::string id) { _frameEndId = id; }
     std::string getFrameEndId() const { return _frameEndId; }
 
-    // the sliding window needs its K-1 history contiguous in front of new samples
-    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &)
+    // the sliding window needs its K-1 history contiguous in front of new samples -- in HBM when the upstream block is one of
+    // this module's (kDomain), in page-locked host memory otherwise
+    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
     {
+#ifndef PCX_WITH_POTHOS
+        if (domain == kDomain) return deviceManager("circular");
+#else
+        (void)domain;
+#endif
         return pinnedManager("circular");
     }
 
@@ -364,13 +405,18 @@ public:
     }
     ~FFT() { pcx_fft_destroy(_h); }
 
-    pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &)
+    pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &domain)
     {
         // several frames per slab so one call amortises the PCIe round trip, but never less than one
         // frame (the reference's own request, FFT.cpp:54-59) nor slabs beyond 16 MiB for long transforms
         const size_t frame = _numBins * _elemBytes;
         size_t frames = kFramesPerSlab;
         while (frames > 1 && frame * frames > (16u << 20)) frames /= 2;
+#ifndef PCX_WITH_POTHOS
+        if (domain == kDomain) return deviceManager("generic", frame * frames);
+#else
+        (void)domain;
+#endif
         return pinnedManager("generic", frame * frames);
     }
 
@@ -497,7 +543,15 @@ public:
     }
     std::vector<std::complex<double>> getTapsComplex() const { return _taps; }
 
-    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return pinnedManager("circular"); }
+    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
+    {
+#ifndef PCX_WITH_POTHOS
+        if (domain == kDomain) return deviceManager("circular");
+#else
+        (void)domain;
+#endif
+        return pinnedManager("circular");
+    }
     void activate() { check(pcx_fmchain_reset(_h), "FmDemodChain::activate()"); }
 
     void work()

@@ -247,6 +247,9 @@ struct BufferManagerArgs {
     // extension: slabs of page-locked host memory (pcx_host_alloc).  The device path runs its kernels directly on such
     // buffers (include/pcx.h, host-pointer entry points); pageable slabs are staged through a device workspace.
     bool pinned = false;
+    // extension: slabs in DEVICE memory (pcx_dev_alloc) for an edge between two blocks of this module: the downstream block's
+    // kernels read what the upstream block's kernels wrote, and the samples never cross PCIe.  Host code must not touch them.
+    bool device = false;
 };
 // What a block hands the scheduler from getInputBufferManager / getOutputBufferManager.  The stand-in keeps the two
 // manager names the reference uses ("generic", "circular": FIRFilter.cpp:196-199, FFT.cpp:54-59) and really owns its
@@ -265,22 +268,24 @@ public:
     }
     ~BufferManager()
     {
-        for (void *s : _slabs) {
-            if (!s) continue;
-            if (_pinnedAlloc) (void)pcx_host_free(s);
-            else std::free(s);
-        }
+        for (void *s : _slabs) release(s);
     }
     // next slab, at least `minBytes` long (allocated on first use; slabs grow to the largest request seen)
     void *acquire(size_t minBytes, size_t *bytes)
     {
         const size_t want = std::max(minBytes, args.bufferSize);
-        if (_slabs.empty()) { _slabs.assign(std::max<size_t>(args.numBuffers, 1), nullptr); _sizes.assign(_slabs.size(), 0); _pinnedAlloc = args.pinned; }
+        if (_slabs.empty()) {
+            _slabs.assign(std::max<size_t>(args.numBuffers, 1), nullptr);
+            _sizes.assign(_slabs.size(), 0);
+            _kind = args.device ? 2 : args.pinned ? 1 : 0;
+        }
         const size_t i = _next++ % _slabs.size();
         if (_sizes[i] < want) {
-            if (_slabs[i]) { if (_pinnedAlloc) (void)pcx_host_free(_slabs[i]); else std::free(_slabs[i]); _slabs[i] = nullptr; _sizes[i] = 0; }
+            release(_slabs[i]);
+            _slabs[i] = nullptr; _sizes[i] = 0;
             void *p = nullptr;
-            if (_pinnedAlloc) { if (pcx_host_alloc(&p, want) != PCX_OK) throw std::runtime_error(std::string("BufferManager: pcx_host_alloc: ") + pcx_last_error()); }
+            if (_kind == 2) { if (pcx_dev_alloc(&p, want) != PCX_OK) throw std::runtime_error(std::string("BufferManager: pcx_dev_alloc: ") + pcx_last_error()); }
+            else if (_kind == 1) { if (pcx_host_alloc(&p, want) != PCX_OK) throw std::runtime_error(std::string("BufferManager: pcx_host_alloc: ") + pcx_last_error()); }
             else if (!(p = std::malloc(want))) throw std::bad_alloc();
             _slabs[i] = p; _sizes[i] = want;
         }
@@ -292,10 +297,17 @@ public:
 
 private:
     BufferManager() = default;
+    void release(void *s)
+    {
+        if (!s) return;
+        if (_kind == 2) (void)pcx_dev_free(s);
+        else if (_kind == 1) (void)pcx_host_free(s);
+        else std::free(s);
+    }
     std::vector<void *> _slabs;
     std::vector<size_t> _sizes;
     size_t _next = 0;
-    bool _pinnedAlloc = false;
+    int _kind = 0;     // 0 pageable, 1 page-locked, 2 device
 };
 
 class Block;
@@ -307,6 +319,8 @@ public:
     void consume(size_t n) { _consumed += n; }
     void setReserve(size_t n) { _reserve = n; _reserveSet = true; }
     const DType &dtype() const { return _dtype; }
+    const std::string &domain() const { return _domain; }   // Pothos port domain [ext]: which memory the port's block can address
+    std::string _domain;
     int index() const { return _index; }            // -1 for a named (non-indexed) port
     const std::string &name() const { return _name; }
     // feedback preload (Arithmetic::activate): drop what is queued, queue a caller-made buffer
@@ -329,6 +343,8 @@ public:
     void produce(size_t n) { _produced += n; }
     void postLabel(const Label &l) { _posted.push_back(l); }
     const DType &dtype() const { return _dtype; }
+    const std::string &domain() const { return _domain; }
+    std::string _domain;
     int index() const { return _index; }
     const std::string &name() const { return _name; }
     // buffer-inlining hint (Arithmetic ctor): the runner decides whether out aliases that input
@@ -375,35 +391,39 @@ public:
     virtual BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return BufferManager::Sptr(); }
     virtual BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return BufferManager::Sptr(); }
 
-    InputPort *setupInput(size_t i, const DType &dt = DType())
+    InputPort *setupInput(size_t i, const DType &dt = DType(), const std::string &domain = "")
     {
         if (_inputs.size() <= i) _inputs.resize(i + 1);
         _inputs[i].reset(new InputPort());
+        _inputs[i]->_domain = domain;
         _inputs[i]->_dtype = dt;
         _inputs[i]->_index = (int)i;
         _inputs[i]->_name = std::to_string(i);
         return _inputs[i].get();
     }
-    OutputPort *setupOutput(size_t i, const DType &dt = DType(), const std::string & /*domain*/ = "")
+    OutputPort *setupOutput(size_t i, const DType &dt = DType(), const std::string &domain = "")
     {
         if (_outputs.size() <= i) _outputs.resize(i + 1);
         _outputs[i].reset(new OutputPort());
+        _outputs[i]->_domain = domain;
         _outputs[i]->_dtype = dt;
         _outputs[i]->_index = (int)i;
         _outputs[i]->_name = std::to_string(i);
         return _outputs[i].get();
     }
     // named ports (SplitComplex "re"/"im", CombineComplex): kept behind the indexed ones
-    InputPort *setupInput(const std::string &name, const DType &dt = DType())
+    InputPort *setupInput(const std::string &name, const DType &dt = DType(), const std::string &domain = "")
     {
         _namedInputs.emplace_back(new InputPort());
+        _namedInputs.back()->_domain = domain;
         _namedInputs.back()->_dtype = dt;
         _namedInputs.back()->_name = name;
         return _namedInputs.back().get();
     }
-    OutputPort *setupOutput(const std::string &name, const DType &dt = DType(), const std::string & /*domain*/ = "")
+    OutputPort *setupOutput(const std::string &name, const DType &dt = DType(), const std::string &domain = "")
     {
         _namedOutputs.emplace_back(new OutputPort());
+        _namedOutputs.back()->_domain = domain;
         _namedOutputs.back()->_dtype = dt;
         _namedOutputs.back()->_name = name;
         return _namedOutputs.back().get();

@@ -21,6 +21,7 @@ struct pcxb_block {
     // managers first: destroyed after the block (members are destroyed in reverse order), and a pinned slab may still
     // be in use by the block's last call until its handle is gone
     pcxfw::BufferManager::Sptr inManager, outManager;   // what the block handed the scheduler (pcxb_acquire_buffer)
+    pcxfw::BufferManager::Sptr linkIn;                  // the manager negotiated for the edge INTO this block (pcxb_link_buffer)
     std::unique_ptr<Block> blk;
     size_t initialReserve = std::numeric_limits<size_t>::max();
 };
@@ -180,6 +181,21 @@ int pcxb_acquire_buffer(pcxb_block *b, int is_output, size_t min_bytes, void **p
         if (!slot) slot = pcxfw::BufferManager::make("generic");     // a block without a preference: the scheduler's default slabs
         *ptr = slot->acquire(min_bytes, bytes);
         if (pinned) *pinned = slot->args.pinned ? 1 : 0;
+    });
+}
+int pcxb_link_buffer(pcxb_block *src, pcxb_block *dst, size_t min_bytes, void **ptr, size_t *bytes, int *kind)
+{
+    // What the scheduler does for the edge src.output(0) -> dst.input(0): the downstream block is asked first, with the
+    // upstream port's domain; if it has no preference the upstream block is asked, with the downstream port's domain [ext].
+    return guarded([&] {
+        const std::string srcDomain = src->blk->allOutputs().at(0)->domain(), dstDomain = dst->blk->allInputs().at(0)->domain();
+        if (!dst->linkIn) {
+            dst->linkIn = dst->blk->getInputBufferManager("", srcDomain);
+            if (!dst->linkIn) dst->linkIn = src->blk->getOutputBufferManager("", dstDomain);
+            if (!dst->linkIn) dst->linkIn = pcxfw::BufferManager::make("generic");
+        }
+        *ptr = dst->linkIn->acquire(min_bytes, bytes);
+        if (kind) *kind = dst->linkIn->args.device ? 2 : dst->linkIn->args.pinned ? 1 : 0;
     });
 }
 int pcxb_initial_reserve(pcxb_block *b, size_t *reserve) { *reserve = b->initialReserve; return PCX_OK; }

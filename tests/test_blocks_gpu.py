@@ -487,3 +487,82 @@ def test_fm_demod_chain_block_contract():
             B.make("/comms/fm_demod_chain", *bad)
     with pytest.raises(Exception):
         b.call("setTaps", np.array([]))
+
+
+def _memcpy(dst, src, nbytes, h2d):
+    import ctypes as C
+    from pothoscomms_amd import _lib
+    L = _lib.load()
+    fn = L.pcx_memcpy_h2d if h2d else L.pcx_memcpy_d2h
+    _lib.check(fn(C.c_void_p(dst), C.c_void_p(src), nbytes, None))
+    _lib.check(L.pcx_stream_sync(None))
+
+
+def test_three_separate_blocks_with_device_resident_edges(oracle):
+    """Rotate -> FIRFilter -> FreqDemod as THREE blocks, wired as a scheduler would wire them (pcxb_link_buffer): both inner
+    edges carry this module's port domain on either side, so their buffers are DEVICE slabs -- the FIR's circular input buffer
+    and the FreqDemod's input live in HBM, only the first input and the last output are (page-locked) host memory -- and the
+    host-pointer entry points run in place on all of them.  Fed in work()-sized pieces; equals the oracle chain."""
+    from pothoscomms_amd import taps as tp
+    rng = np.random.default_rng(33)
+    n = 300000
+    ph = np.cumsum(2 * np.pi * (0.02 + 0.01 * np.sin(2 * np.pi * np.arange(n) / 1000)))
+    x = (np.stack([np.cos(ph), np.sin(ph)], 1) + rng.uniform(-1e-3, 1e-3, (n, 2))).astype(np.float32)
+    h, phase = tp.c4_taps(), tp.C4_PHASE
+    K = len(h)
+    rot = B.make("/comms/rotate", "complex_float32"); rot.call("setPhase", phase)
+    fir = B.make("/comms/fir_filter", "complex_float32", "REAL"); fir.call("setTaps", h)
+    dem = B.make("/comms/freq_demod", "complex_float32")
+    for b in (rot, fir, dem):
+        b.activate()
+    CH = 65536
+    xin, pin0 = rot.port_buffer(0, (CH, 2), np.float32)
+    e1, kind1 = rot.link_buffer(fir, (CH + K - 1) * 8)
+    e2, kind2 = fir.link_buffer(dem, CH * 8)
+    yout, pin3 = dem.port_buffer(1, (CH,), np.float32)
+    assert pin0 and pin3 and (kind1, kind2) == (2, 2)
+    assert fir.buffer_manager(0)[0] == "circular"
+    got = []
+    hist = 0                                    # samples of FIR history sitting at the front of the device edge buffer
+    pos = 0
+    while pos < n:
+        m = min(CH, n - pos)
+        xin[:m] = x[pos:pos + m]
+        c, p, _ = rot.work_raw(xin.ctypes.data, m, e1 + hist * 8, m)            # rotate writes behind the history
+        assert (c, p) == (m, m)
+        avail = hist + m
+        c, p, r = fir.work_raw(e1, avail, e2, CH)
+        if avail < K:
+            assert (c, p) == (0, 0)
+            hist = avail
+        else:
+            assert c == p == avail - (K - 1)
+            # the circular buffer keeps the unconsumed K-1 samples in front of the next ones: move them (device to device)
+            import ctypes as C
+            from pothoscomms_amd import _lib
+            L = _lib.load()
+            tmp = C.c_void_p()
+            _lib.check(L.pcx_dev_alloc(C.byref(tmp), (K - 1) * 8))
+            _lib.check(L.pcx_memcpy_d2d(tmp, C.c_void_p(e1 + c * 8), (K - 1) * 8, None))
+            _lib.check(L.pcx_memcpy_d2d(C.c_void_p(e1), tmp, (K - 1) * 8, None))
+            _lib.check(L.pcx_stream_sync(None))
+            _lib.check(L.pcx_dev_free(tmp))
+            hist = K - 1
+            c2, p2, _ = dem.work_raw(e2, p, yout.ctypes.data, CH)
+            assert (c2, p2) == (p, p)
+            got.append(yout[:p].copy())
+        pos += m
+    got = np.concatenate(got)
+    ref_fir = oracle.Fir(oracle.F32, True, False); ref_fir.set_taps(h); ref_fir.activate()
+    y, _, p, _ = ref_fir.work(oracle.rotate(x, phase), n - (K - 1))
+    ref = oracle.FreqDemod(oracle.F32).work(y)
+    assert got.shape[0] == n - (K - 1)
+    assert ang_err(got, ref) <= TOL
+
+
+def test_edge_to_a_host_block_gets_host_memory():
+    """a device block feeding a block of another domain (the designer has no ports; use a fresh generic request): pinned host"""
+    rot = B.make("/comms/rotate", "complex_float32")
+    arr, pinned = rot.port_buffer(1, (1024, 2), np.float32)
+    assert pinned and isinstance(arr, np.ndarray)
+    arr[:] = 1.0          # host-addressable

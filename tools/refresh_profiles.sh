@@ -15,6 +15,7 @@ bash tools/ab_oversub.sh > $O/ab_oversub.txt 2>/dev/null
 python tools/shard_probe.py > $O/shard_probe.txt 2>/dev/null
 python tools/host_path.py > $O/host_path.txt 2>/dev/null
 python tools/two_blocks.py > $O/two_blocks.txt 2>/dev/null
+python tools/chain_path.py > $O/chain_path.txt 2>/dev/null
 rocprofv3 --kernel-trace --output-format csv -d $O/two -- python3 tools/two_blocks.py trace > /dev/null 2>&1
 python tools/two_blocks.py summarize $O/two >> $O/two_blocks.txt 2>/dev/null
 tools/pcie_lab > $O/pcie_lab.txt 2>&1

@@ -174,3 +174,67 @@ def test_sharded_step_split_equals_single_call(dev, torch_dev):
     split = sf.step()
     torch.cuda.synchronize()
     assert float((split - whole).abs().max()) / float(whole.abs().max()) <= 2e-6
+
+
+def test_dynamic_dealing_is_deterministic_and_complete(dev, torch_dev):
+    """The three dealt kernels (pcx_sched.hpp) hand blocks to whichever workgroup draws first: every launch must still produce
+    every block exactly once.  200 launches each at full size, outputs poisoned before every launch, compared BIT FOR BIT with
+    the first launch (a block's arithmetic does not depend on who runs it) -- a skipped block leaves NaNs, a block computed from
+    a stale draw differs."""
+    torch, d = torch_dev
+    from pothoscomms_amd import taps as tp
+    n = C1
+    # FIR
+    h = tp.c1_taps()
+    K = len(h)
+    x = torch.empty((n + K - 1, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(x, seed=2)
+    y0 = torch.empty((n, 2), dtype=torch.float32, device=d)
+    y = torch.empty_like(y0)
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h)
+    f.process_dev(x, y0)
+    assert bool(torch.isfinite(y0).all())
+    for i in range(200):
+        y.fill_(float("nan"))
+        f.process_dev(x, y)
+        if i % 20 == 19 or i < 3:
+            assert torch.equal(y, y0), i
+    assert torch.equal(y, y0)
+    # ragged sizes around the pair structure (odd block counts, a last chunk of one block)
+    for m in (3840 * 2049, 3840 * 2050 + 17, 3840 * 4097 - 1, 3840 * 2048 + 1):
+        f.process_dev(x, y0, m + K - 1, m)
+        y.fill_(float("nan"))
+        f.process_dev(x, y, m + K - 1, m)
+        assert torch.equal(y[:m], y0[:m]) and bool(torch.isfinite(y[:m]).all()) and bool(torch.isnan(y[m:]).all()), m
+    del x, y, y0
+    # FFT 4096
+    nframes = 65536
+    xf = torch.empty((nframes * 4096, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(xf, seed=3)
+    X0 = torch.empty_like(xf); X = torch.empty_like(xf)
+    t = dev.Fft("complex_float32", 4096, False)
+    t.transform_dev(xf, X0, nframes)
+    for i in range(60):
+        X.fill_(float("nan"))
+        t.transform_dev(xf, X, nframes)
+        if i % 10 == 9:
+            assert torch.equal(X, X0), i
+    for nf in (2049, 2050, 4097, 65535):
+        t.transform_dev(xf, X0, nf)
+        X.fill_(float("nan"))
+        t.transform_dev(xf, X, nf)
+        assert torch.equal(X[:nf * 4096], X0[:nf * 4096]) and bool(torch.isnan(X[nf * 4096:]).all()), nf
+    del xf, X, X0
+    # fused chain
+    hc = tp.c4_taps()
+    Kc = len(hc)
+    xc = _fm_stream(torch, d, n, Kc)
+    z0 = torch.empty(n, dtype=torch.float32, device=d); z = torch.empty_like(z0)
+    ch = dev.FmChain(); ch.set_phase(tp.C4_PHASE); ch.set_taps(hc, False)
+    ch.process_dev(xc, z0, n + Kc - 1, n)
+    for i in range(100):
+        z.fill_(float("nan"))
+        ch.reset()
+        ch.process_dev(xc, z, n + Kc - 1, n)
+        if i % 10 == 9:
+            assert torch.equal(z, z0), i

@@ -24,7 +24,7 @@ namespace pcx {
 // --------------------------------------------------------------------------------- //
 template <bool INV, int SAUX, bool DYN = false>
 __global__ __launch_bounds__(256, 4) void fft4096_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                      size_t nframes, const float2 *__restrict__ twtab, SchedState *__restrict__ sched)
+                                                      size_t nframes, const float2 *__restrict__ twtab, SchedState *__restrict__ sched, int prio)
 {
     using namespace fft4k;
     __shared__ cf lds[LDS_ELEMS];
@@ -57,12 +57,15 @@ __global__ __launch_bounds__(256, 4) void fft4096_kernel(const float2 *__restric
         if (more) load_frame<false>(nx, make_rsrc(in + fn * N, N * 8), j);
         pass1(v, lds, j);
         if (DYN) deal.publish(j);      // pass 2 and pass 3 open with barriers
+        if (prio == 2) __builtin_amdgcn_s_setprio(1);
         pass2(v, lds, j);
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
         pass3(v, lds, j, tw3);
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + f * N, N * 8);
 #pragma unroll
         for (int q = 0; q < 16; q++)
             store_cf<SAUX>(ws, (unsigned)(j + 256 * bin_of(q)) * 8u, INV ? cf{v[q].x, -v[q].y} : v[q]);
+        if (prio) __builtin_amdgcn_s_setprio(0);
         if (!more) break;
         if (DYN) (void)deal.advance();
         f = fn;
@@ -80,10 +83,11 @@ int launch_fft4096_cf32(const void *in, void *out, size_t nframes, bool inverse,
     // PCX_FFT_STORE_AUX (A/B): cache-policy bits of the output stores; default 2 = non-temporal
     const int saux = (int)PCX_ENV_INT("PCX_FFT_STORE_AUX", 2);
     const bool dyn = sched && nframes > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");
+    const int prio = (int)PCX_ENV_INT("PCX_FFT_PRIO", 0);   // (diag A/B) 1: last pass + stores at wave priority 1; 2: passes 2 and 3
 #define PCX_FFT_LAUNCH(INV, SAUX)                                                                                                          \
     do {                                                                                                                                   \
-        if (dyn) hipLaunchKernelGGL((fft4096_kernel<INV, SAUX, true>), dim3(1024), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab, (SchedState *)sched); \
-        else hipLaunchKernelGGL((fft4096_kernel<INV, SAUX>), dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab, (SchedState *)nullptr);          \
+        if (dyn) hipLaunchKernelGGL((fft4096_kernel<INV, SAUX, true>), dim3(1024), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab, (SchedState *)sched, prio); \
+        else hipLaunchKernelGGL((fft4096_kernel<INV, SAUX>), dim3(grid), dim3(256), 0, st, (const float2 *)in, (float2 *)out, nframes, tab, (SchedState *)nullptr, prio);          \
     } while (0)
     if (inverse) { if (saux == 2) PCX_FFT_LAUNCH(true, 2); else PCX_FFT_LAUNCH(true, 0); }
     else { if (saux == 2) PCX_FFT_LAUNCH(false, 2); else PCX_FFT_LAUNCH(false, 0); }

@@ -19,6 +19,7 @@ python tools/chain_path.py > $O/chain_path.txt 2>/dev/null
 rocprofv3 --kernel-trace --output-format csv -d $O/two -- python3 tools/two_blocks.py trace > /dev/null 2>&1
 python tools/two_blocks.py summarize $O/two >> $O/two_blocks.txt 2>/dev/null
 tools/pcie_lab > $O/pcie_lab.txt 2>&1
+tools/ubench > $O/ubench_roofs.txt 2>&1
 timeout 300 tools/ols_lab 4 > $O/ols_lab_summary.txt 2>&1
 python tools/sweep_fir.py > $O/sweep_fir_taps.txt 2>/dev/null
 python tools/sweep_map.py > $O/sweep_elementwise.txt 2>/dev/null

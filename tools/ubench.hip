@@ -73,6 +73,31 @@ __global__ __launch_bounds__(256) void frame_copy16(const float4* __restrict__ i
         for (int r = 0; r < 16; r++) y[t + 128 * r] = v[r];
     }
 }
+// the same two with non-temporal accesses (what the FFT / FIR kernels use on rows nobody else reads)
+typedef float f2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void frame_copy8nt(const f2v* __restrict__ in, f2v* __restrict__ out, size_t nframes)
+{
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const f2v* x = in + f * 4096; f2v* y = out + f * 4096;
+        f2v v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = __builtin_nontemporal_load(&x[threadIdx.x + 256 * r]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) __builtin_nontemporal_store(v[r], &y[threadIdx.x + 256 * r]);
+    }
+}
+__global__ __launch_bounds__(256) void frame_copy16nt(const f4* __restrict__ in, f4* __restrict__ out, size_t nframes)
+{
+    // one frame per workgroup, 16 B per lane: lane j touches elements (2j, 2j+1) + 512 r, r < 8
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const f4* x = in + f * 2048; f4* y = out + f * 2048;
+        f4 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = __builtin_nontemporal_load(&x[threadIdx.x + 256 * r]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) __builtin_nontemporal_store(v[r], &y[threadIdx.x + 256 * r]);
+    }
+}
 // frame copy through LDS with barriers (2 exchanges) to mimic the FFT's phase structure
 __global__ __launch_bounds__(256) void frame_copy8_lds(const float2* __restrict__ in, float2* __restrict__ out, size_t nframes)
 {
@@ -166,6 +191,14 @@ int main()
     for (int grid : {512, 1024, 2048, 16384}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(frame_copy16, dim3(grid), dim3(256), 0, 0, (const float4*)in, (float4*)out, nframes); }, 10);
         printf("frame_copy16    grid %5d: %.3f ms  %.0f GB/s\n", grid, ms, gb / ms * 1e3);
+    }
+    for (int grid : {1024, 4096, 8192, 32768}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(frame_copy8nt, dim3(grid), dim3(256), 0, 0, (const f2v*)in, (f2v*)out, nframes); }, 300);
+        printf("frame_copy8 nt  grid %5d: %.3f ms  %.0f GB/s   (300 launches)\n", grid, ms, gb / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL(frame_copy16nt, dim3(grid), dim3(256), 0, 0, (const f4*)in, (f4*)out, nframes); }, 300);
+        printf("frame_copy16 nt grid %5d: %.3f ms  %.0f GB/s   (300 launches)\n", grid, ms, gb / ms * 1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL((copy16u<true, 4>), dim3(grid * 2), dim3(256), 0, 0, (const f4*)in, (f4*)out, bytes / 16); }, 300);
+        printf("copy16 nt x4    grid %5d: %.3f ms  %.0f GB/s   (300 launches)\n", grid * 2, ms, gb / ms * 1e3);
     }
     for (int grid : {1024, 2048, 32768}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(frame_copy8_lds, dim3(grid), dim3(256), 0, 0, (const float2*)in, (float2*)out, nframes); }, 10);

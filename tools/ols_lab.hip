@@ -186,26 +186,49 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
     const bool dyn = ctr != nullptr;
     // chunked draws: one atomic hands a workgroup `chunk` blocks (contiguous when chunk > 0, nchunks apart when < 0), so
     // the counter sees nblocks / chunk draws per launch (a single word saturates near 88 draws per microsecond)
-    const bool guided = chunk <= -100;     // pairs (strided) first, single blocks for the last (-chunk - 100) per mille
+    // chunk <= -1000: XCD-AWARE dealing -- eight counters (one per XCD, a cache line apart), XCD x owns the x-th eighth of the
+    // stream in contiguous chunks of (-chunk - 1000) blocks, a workgroup draws from its own XCD's counter and, when that eighth
+    // is exhausted, steals from the next XCDs'.  Neighbouring blocks then run on one XCD (their shared rows hit in its L2) and no
+    // single word sees more than an eighth of the draws.  Books: ctr[128] counts finished workgroups; the last one zeroes all.
+    const bool xcd = chunk <= -1000;
+    const unsigned xc = xcd ? (unsigned)(-chunk - 1000) : 0;
+    const unsigned xnch = xcd ? (unsigned)((nblocks + xc - 1) / xc) : 0;
+    const unsigned myx = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7;     // HW_REG_XCC_ID[3:0]
+    auto xdraw = [&]() -> unsigned {
+        for (unsigned t = 0; t < 8; t++) {
+            const unsigned x = (myx + t) & 7;
+            const unsigned lo = (unsigned)(((unsigned long long)xnch * x) / 8), hi = (unsigned)(((unsigned long long)xnch * (x + 1)) / 8);
+            const unsigned v = atomicAdd(ctr + 16 * x, 1u);
+            if (v < hi - lo) return lo + v;
+        }
+        return ~0u;
+    };
+    const bool guided = !xcd && chunk <= -100;     // pairs (strided) first, single blocks for the last (-chunk - 100) per mille
     const unsigned tail1 = guided ? (unsigned)((nblocks * (size_t)(-chunk - 100)) / 1000) : 0;
     const unsigned npair = guided ? (unsigned)((nblocks - tail1) / 2) : 0;
-    const unsigned csz = guided ? 2u : (unsigned)(chunk < 0 ? -chunk : chunk);
-    const unsigned nchunks = !dyn ? 0 : guided ? npair + (unsigned)(nblocks - 2 * (size_t)npair) : (unsigned)((nblocks + csz - 1) / csz);
+    const unsigned csz = xcd ? xc : guided ? 2u : (unsigned)(chunk < 0 ? -chunk : chunk);
+    const unsigned nchunks = !dyn ? 0 : xcd ? xnch : guided ? npair + (unsigned)(nblocks - 2 * (size_t)npair) : (unsigned)((nblocks + csz - 1) / csz);
     unsigned it = 0, pending = 0, cq = 0, sub = 0;
     auto block_of = [&](unsigned qq, unsigned ss) -> size_t {
         if (guided) return qq < npair ? (size_t)qq + (size_t)ss * npair : (ss == 0 ? (size_t)2 * npair + (qq - npair) : nblocks);
-        return chunk > 0 ? (size_t)qq * csz + ss : (size_t)qq + (size_t)ss * nchunks;
+        return (chunk > 0 || xcd) ? (size_t)qq * csz + ss : (size_t)qq + (size_t)ss * nchunks;
+    };
+    auto xfinish = [&]() {
+        if (xcd && j == 0 && atomicAdd(ctr + 128, 1u) == gridDim.x - 1) {
+            for (int x = 0; x < 8; x++) atomicExch(ctr + 16 * x, 0u);
+            atomicExch(ctr + 128, 0u);
+        }
     };
     if (dyn) {
-        if (j == 0) next_block[0] = atomicAdd(ctr, 1u) - ctr_base;
+        if (j == 0) next_block[0] = xcd ? xdraw() : atomicAdd(ctr, 1u) - ctr_base;
         __syncthreads();
         cq = next_block[0];
-        if (cq >= nchunks) return;
+        if (cq >= nchunks) { xfinish(); return; }
         b = block_of(cq, 0);
     }
     for (;;) {
         if (b >= nblocks) {   // static: past the end; dynamic: only the last chunk holds such blocks, and no chunk follows it
-            if (dyn && j == 0) atomicAdd(ctr, 1u);   // keep the books: every workgroup ends on exactly one draw past the end
+            if (dyn && !xcd && j == 0) atomicAdd(ctr, 1u);   // keep the books: every workgroup ends on exactly one draw past the end
             break;
         }
         cf v[16];
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
         // the draw for the NEXT chunk: issued behind the loads of this chunk's last block, consumed in front of the inverse
         // transform; two slots so the next draw cannot overwrite one still unread
         const bool lastc = sub + 1 >= csz || block_of(cq, sub + 1) >= nblocks;
-        if (dyn && lastc && j == 0) pending = atomicAdd(ctr, 1u) - ctr_base;
+        if (dyn && lastc && j == 0) pending = xcd ? xdraw() : atomicAdd(ctr, 1u) - ctr_base;
         it++;
         {
         cf u[16];
@@ -318,6 +341,7 @@ __global__ __launch_bounds__(256, WGPC) void lab_kernel(const float2 *__restrict
         }
         b = block_of(cq, sub);
     }
+    xfinish();
     if (j == 0) {
         Stamp s;
         s.t0 = t0; s.r0 = r0;
@@ -447,23 +471,23 @@ int main(int argc, char **argv)
         const size_t c = (size_t)abs(ch); return (unsigned)((nblocks + c - 1) / c);
     };
     unsigned *ctr; unsigned ctr_base = 0;
-    CK(hipMalloc(&ctr, 64)); CK(hipMemset(ctr, 0, 64));
+    CK(hipMalloc(&ctr, 1024)); CK(hipMemset(ctr, 0, 1024));
     // name, mode, dose | barrier mask, wg/CU, zero input, dose operand scale, stagger | priority mode, chunk (0 = static stride), grid (0 = balanced 971)
     const Cfg cfgs[] = {
-        {"dynamic pairs + prio 1 on 2nd half (r02)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
-        {"dynamic pairs, fixed prio by CU slot (idx>>8)", MODE_FULL, 3, 4, false, 0.f, -7, -2, 1024},
-        {"dynamic pairs, fixed prio by idx&3", MODE_FULL, 3, 4, false, 0.f, -9, -2, 1024},
-        {"dynamic pairs, no prio", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
-        {"dynamic pairs + prio 1 on 2nd half (r02)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
-        {"dynamic pairs, fixed prio by CU slot (idx>>8)", MODE_FULL, 3, 4, false, 0.f, -7, -2, 1024},
-        {"static 971, fixed prio by CU slot", MODE_FULL, 3, 4, false, 0.f, -7, 0, 0},
+        {"dynamic pairs + prio (r02 product)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"XCD-aware, single blocks + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1001, 1024},
+        {"XCD-aware, contiguous pairs + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1002, 1024},
+        {"XCD-aware, contiguous 4 + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1004, 1024},
+        {"dynamic pairs + prio (r02 product)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"XCD-aware, single blocks + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1001, 1024},
+        {"XCD-aware, contiguous pairs + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1002, 1024},
     };
     {   // parity of the digit-swap pipeline against the product pipeline on the same random input
         float2 *y2;
         CK(hipMalloc(&y2, (nblocks * S + 64) * 8));
         hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (float *)x, in_elems * 2, 2ull, 0);
         hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, nullptr, 0u, 0);
-        hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, ctr, ctr_base, -150); ctr_base += nchunks_of(-150) + grid;
+        hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, ctr, ctr_base, -1001);
         CK(hipDeviceSynchronize());
         const size_t cmp = 4u << 20;
         std::vector<float> a(2 * cmp), b(2 * cmp);
@@ -471,7 +495,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(b.data(), y2, cmp * 8, hipMemcpyDeviceToHost));
         double mx = 0, md = 0;
         for (size_t i = 0; i < 2 * cmp; i++) { mx = std::max(mx, (double)std::fabs(a[i])); md = std::max(md, (double)std::fabs(a[i] - b[i])); }
-        printf("# parity dynamic-assignment vs product pipeline over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
+        printf("# parity XCD-aware dealing vs product pipeline over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
         CK(hipFree(y2));
     }
     printf("# 255-tap geometry: Kov=%d S=%zu blocks=%zu grid=%u, %zu samples, %.1f s per configuration\n", Kov, S, nblocks, grid, n, secs);
@@ -487,7 +511,7 @@ int main(int argc, char **argv)
         const unsigned g = c.slots ? (unsigned)c.slots : grid;
         auto launch = [&] {
             hipLaunchKernelGGL(k, dim3(g), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, c.dose_seed, st, c.stag, c.dyn ? ctr : nullptr, ctr_base, c.dyn);
-            if (c.dyn) ctr_base += nchunks_of(c.dyn) + g;
+            if (c.dyn && c.dyn > -1000) ctr_base += nchunks_of(c.dyn) + g;
         };
         CK(hipDeviceSynchronize());
         g_stop = false; g_power.clear(); g_sclk.clear();

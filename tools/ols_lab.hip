@@ -473,21 +473,32 @@ int main(int argc, char **argv)
     unsigned *ctr; unsigned ctr_base = 0;
     CK(hipMalloc(&ctr, 1024)); CK(hipMemset(ctr, 0, 1024));
     // name, mode, dose | barrier mask, wg/CU, zero input, dose operand scale, stagger | priority mode, chunk (0 = static stride), grid (0 = balanced 971)
+    // name, mode, dose | barrier mask, wg/CU, zero input, dose operand scale, stagger (>0) | priority mode (<0), chunk (0 = static stride), grid (0 = balanced 971)
     const Cfg cfgs[] = {
-        {"dynamic pairs + prio (r02 product)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
-        {"XCD-aware, single blocks + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1001, 1024},
-        {"XCD-aware, contiguous pairs + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1002, 1024},
-        {"XCD-aware, contiguous 4 + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1004, 1024},
-        {"dynamic pairs + prio (r02 product)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
-        {"XCD-aware, single blocks + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1001, 1024},
-        {"XCD-aware, contiguous pairs + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1002, 1024},
+        {"product pipeline, static stride (r01)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
+        {"  same, grid 4096 (hw dispatcher balances)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 4096},
+        {"  dynamic pairs (pcx_sched.hpp)", MODE_FULL, 3, 4, false, 0.f, 0, -2, 1024},
+        {"  dynamic pairs + prio 1 on 2nd half (r02)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        {"  static, 4 barriers/block (digit-swap)", MODE_SWAP, 0, 4, false, 0.f, 0, 0, 0},
+        {"  static, WAR barriers removed [timing only]", MODE_FULL, 2, 4, false, 0.f, 0, 0, 0},
+        {"  static, no barriers at all [timing only]", MODE_FULL, 0, 4, false, 0.f, 0, 0, 0},
+        {"  static, all-zero input (no toggling)", MODE_FULL, 3, 4, true, 0.f, 0, 0, 0},
+        {"loads + stores only", MODE_MEM, 0, 4, false, 0.f, 0, 0, 0},
+        {"  + 160 packed FMAs/lane/block, random data", MODE_DOSE, 160, 4, false, 1.0f, 0, 0, 0},
+        {"  + 640 packed FMAs/lane/block, random data", MODE_DOSE, 640, 4, false, 1.0f, 0, 0, 0},
+        {"  + 640 packed FMAs/lane/block, zeros", MODE_DOSE, 640, 4, false, 0.f, 0, 0, 0},
+        {"product pipeline, static stride (again)", MODE_FULL, 3, 4, false, 0.f, 0, 0, 0},
+        {"  dynamic pairs + prio 1 on 2nd half (again)", MODE_FULL, 3, 4, false, 0.f, -2, -2, 1024},
+        // (self-resetting books from here on: the one-counter rows above keep theirs on the host)
+        {"  XCD-aware dealing, single blocks + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1001, 1024},
+        {"  XCD-aware dealing, contiguous pairs + prio", MODE_FULL, 3, 4, false, 0.f, -2, -1002, 1024},
     };
     {   // parity of the digit-swap pipeline against the product pipeline on the same random input
         float2 *y2;
         CK(hipMalloc(&y2, (nblocks * S + 64) * 8));
         hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, (float *)x, in_elems * 2, 2ull, 0);
         hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, nullptr, 0u, 0);
-        hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, ctr, ctr_base, -1001);
+        hipLaunchKernelGGL((lab_kernel<MODE_FULL, 3, 4>), dim3(grid), dim3(256), 0, 0, x, y2, n, Hs, Kov, pad, tw, nblocks, 0.f, st, 0, ctr, ctr_base, -2); ctr_base += nchunks_of(-2) + grid;
         CK(hipDeviceSynchronize());
         const size_t cmp = 4u << 20;
         std::vector<float> a(2 * cmp), b(2 * cmp);
@@ -495,7 +506,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(b.data(), y2, cmp * 8, hipMemcpyDeviceToHost));
         double mx = 0, md = 0;
         for (size_t i = 0; i < 2 * cmp; i++) { mx = std::max(mx, (double)std::fabs(a[i])); md = std::max(md, (double)std::fabs(a[i] - b[i])); }
-        printf("# parity XCD-aware dealing vs product pipeline over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
+        printf("# parity dynamic dealing vs static stride over %zu samples: max|ref|=%.4g max|diff|=%.4g rel=%.3g\n", cmp, mx, md, md / mx);
         CK(hipFree(y2));
     }
     printf("# 255-tap geometry: Kov=%d S=%zu blocks=%zu grid=%u, %zu samples, %.1f s per configuration\n", Kov, S, nblocks, grid, n, secs);

@@ -520,6 +520,9 @@ int main(int argc, char **argv)
         KernFn k = pick(c.mode, c.dose, c.wgpc);
         if (!k) continue;
         const unsigned g = c.slots ? (unsigned)c.slots : grid;
+        CK(hipDeviceSynchronize());
+        CK(hipMemset(ctr, 0, 1024));     // every configuration starts its books from zero
+        ctr_base = 0;
         auto launch = [&] {
             hipLaunchKernelGGL(k, dim3(g), dim3(256), 0, 0, x, y, n, Hs, Kov, pad, tw, nblocks, c.dose_seed, st, c.stag, c.dyn ? ctr : nullptr, ctr_base, c.dyn);
             if (c.dyn && c.dyn > -1000) ctr_base += nchunks_of(c.dyn) + g;

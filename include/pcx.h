@@ -37,7 +37,9 @@
  *     call is ordered behind it (an event), carried state and all; setters
  *     that rewrite device tables first wait for the handle's outstanding
  *     work; reset() is enqueued behind the previous call and ahead of the
- *     next.  Setters cannot be captured into a hipGraph, *_dev calls can.
+ *     next.  Setters cannot be captured into a hipGraph; *_dev calls can,
+ *     once the handle's tables are uploaded (its first call after a setter)
+ *     and on the stream of the handle's previous call.
  *   - the library reads no environment variable.
  *   - input and output buffers of one call must not overlap, with two exceptions the reference
  *     relies on or that cost nothing: the same-size element-wise maps (rotate, scale, conj, arith)

@@ -153,3 +153,35 @@ def test_the_library_ignores_the_environment(oracle):
     env = dict(os.environ, PCX_OLS_VARIANT="11", PCX_OLS_DIAG="2", PCX_FFT_MIXED_DIAG="1", PCX_OLS_SLOTS="7", PCX_OLS_ALIGN="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_process_dev_can_be_captured_into_a_graph(oracle, dev):
+    """include/pcx.h: *_dev calls only enqueue (once the tables are uploaded), so a steady-state loop can be captured into a
+    hipGraph and replayed -- the dealt kernels reset their own block counters at the end of every launch."""
+    import torch
+    from pothoscomms_amd import taps as tp
+    d = torch.device("cuda", 0)
+    h = tp.c1_taps()
+    K, n = len(h), 8 << 20
+    x = torch.empty((n + K - 1, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(x, seed=4)
+    y = torch.empty((n, 2), dtype=torch.float32, device=d)
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h)
+    s = torch.cuda.Stream(d)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        f.process_dev(x, y)                 # first call on this stream: uploads the tables (not capturable), binds the stream
+    torch.cuda.synchronize()
+    want = y.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        f.process_dev(x, y)
+        f.process_dev(x, y)
+    for _ in range(5):
+        y.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h); ref.activate()
+    xw = x[:60000 + K - 1].cpu().numpy()
+    assert nerr(y[:60000].cpu().numpy(), ref.work(xw, 60000)[0]) <= TOL

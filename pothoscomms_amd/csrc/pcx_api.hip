@@ -46,6 +46,17 @@ int DevBuf::ensure(size_t bytes)
     cap = want;
     return PCX_OK;
 }
+// hipMemset on device memory returns before the fill has run (it is queued on the null stream), and the handles' own streams
+// are non-blocking: the fill must be COMPLETE before a handle is handed out, or its first kernel races it (found by the
+// fuzz soak, eight processes on one GPU: FreqDemod's first output read the previous owner's _prev, or the late fill wiped
+// the state the first call had written)
+int DevBuf::ensure_zeroed(size_t bytes)
+{
+    PCX_TRY(ensure(bytes));
+    PCX_HIP(hipMemsetAsync(p, 0, bytes, nullptr));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
 void DevBuf::release()
 {
     if (p) (void)hipFree(p);
@@ -53,12 +64,16 @@ void DevBuf::release()
     cap = 0;
 }
 
-// upload a host vector into a DevBuf (control plane: synchronous)
+// upload a host vector into a DevBuf (control plane: COMPLETE on return).  hipMemcpy from pageable memory may return once
+// the source has been staged, with the transfer to the device still queued on the null stream -- which the handles' own
+// non-blocking streams do not wait for -- so the null stream is drained before the table counts as uploaded (the fuzz soak,
+// eight processes on one GPU: about one first call in 10^5 ran on a table that had not landed yet)
 template <typename T>
 static int upload(DevBuf &b, const std::vector<T> &v)
 {
     PCX_TRY(b.ensure(v.size() * sizeof(T)));
     PCX_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    PCX_HIP(hipStreamSynchronize(nullptr));
     return PCX_OK;
 }
 
@@ -279,26 +294,93 @@ static void *device_alias(const void *p)
     if ((a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) && a.devicePointer) return a.devicePointer;
     return nullptr;
 }
-// one direction of a host-pointer call: the alias when there is one, else the staging buffer (grown to `bytes`)
-static int stage_in(const void *host, size_t bytes, DevBuf &ws, hipStream_t st, const void **dev)
+// One direction of a host-pointer call: the alias when there is one, else the staging pair (grown to `bytes`): a device
+// buffer and a page-locked bounce buffer of the library's own.  Pageable memory is copied by the CPU into / out of the
+// bounce buffer and moved by plain pinned <-> device transfers on the call's stream.  (hipMemcpyAsync straight on the
+// caller's pageable pointer was the first implementation; under eight processes sharing the GPU about one call in 10^5
+// came back with the head and tail of its output never written -- profiles/r02/contention.md.)
+int PinBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap) return PCX_OK;
+    release();
+    size_t want = bytes < 65536 ? 65536 : bytes + bytes / 4;
+    PCX_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return PCX_OK;
+}
+void PinBuf::release()
+{
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+// Transfers above a couple of MiB go in pieces so that the CPU's copy of one piece runs while the DMA engine moves the
+// previous one (measured, 128 MiB each way: 23.1 ms in one piece; tools/host_path.py)
+static size_t stage_piece(size_t bytes)
+{
+    constexpr size_t kMin = (size_t)1 << 20, kMaxPieces = 32;
+    size_t piece = (bytes + kMaxPieces - 1) / kMaxPieces;
+    piece = (piece + 4095) & ~(size_t)4095;
+    return piece < kMin ? kMin : piece;
+}
+void StageBuf::release()
+{
+    dev.release();
+    pin.release();
+}
+static int stage_in(const void *host, size_t bytes, StageBuf &ws, hipStream_t st, const void **dev)
 {
     if (void *a = device_alias(host)) { *dev = a; return PCX_OK; }
-    PCX_TRY(ws.ensure(bytes));
-    PCX_HIP(hipMemcpyAsync(ws.p, host, bytes, hipMemcpyHostToDevice, st));
-    *dev = ws.p;
+    PCX_TRY(ws.dev.ensure(bytes));
+    PCX_TRY(ws.pin.ensure(bytes));
+    const size_t piece = stage_piece(bytes);
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t c = bytes - off < piece ? bytes - off : piece;
+        std::memcpy(static_cast<char *>(ws.pin.p) + off, static_cast<const char *>(host) + off, c);
+        PCX_HIP(hipMemcpyAsync(static_cast<char *>(ws.dev.p) + off, static_cast<const char *>(ws.pin.p) + off, c, hipMemcpyHostToDevice, st));
+    }
+    *dev = ws.dev.p;
     return PCX_OK;
 }
-static int stage_out_begin(void *host, size_t bytes, DevBuf &ws, void **dev, bool *staged)
+static int stage_out_begin(void *host, size_t bytes, StageBuf &ws, void **dev, bool *staged)
 {
     if (void *a = device_alias(host)) { *dev = a; *staged = false; return PCX_OK; }
-    PCX_TRY(ws.ensure(bytes));
-    *dev = ws.p; *staged = true;
+    PCX_TRY(ws.dev.ensure(bytes));
+    PCX_TRY(ws.pin.ensure(bytes));
+    *dev = ws.dev.p; *staged = true;
     return PCX_OK;
 }
-static int stage_out_end(void *host, size_t bytes, const void *dev, bool staged, hipStream_t st)
+// behind the kernels of the call: device -> bounce buffer -> the caller's memory.  Piece i+1 is on its way while the CPU
+// copies piece i out; the only completion primitive used is hipStreamSynchronize (a variant with one event per piece
+// produced a wrong call in the soak)
+static int stage_out_first(StageBuf &ws, size_t bytes, bool staged, hipStream_t st)
 {
-    if (staged && bytes) PCX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
-    PCX_HIP(hipStreamSynchronize(st));
+    if (!staged || !bytes) return PCX_OK;
+    const size_t piece = stage_piece(bytes), c = bytes < piece ? bytes : piece;
+    PCX_HIP(hipMemcpyAsync(ws.pin.p, ws.dev.p, c, hipMemcpyDeviceToHost, st));
+    return PCX_OK;
+}
+static int stage_out_rest(void *host, StageBuf &ws, size_t bytes, bool staged, hipStream_t st)
+{
+    if (!staged || !bytes) return PCX_OK;
+    const size_t piece = stage_piece(bytes);
+    for (size_t off = 0; off < bytes; off += piece) {
+        const size_t c = bytes - off < piece ? bytes - off : piece;
+        PCX_HIP(hipStreamSynchronize(st));          // piece at `off` has landed in the bounce buffer
+        const size_t nxt = off + piece;
+        if (nxt < bytes) {
+            const size_t cn = bytes - nxt < piece ? bytes - nxt : piece;
+            PCX_HIP(hipMemcpyAsync(static_cast<char *>(ws.pin.p) + nxt, static_cast<const char *>(ws.dev.p) + nxt, cn, hipMemcpyDeviceToHost, st));
+        }
+        std::memcpy(static_cast<char *>(host) + off, static_cast<const char *>(ws.pin.p) + off, c);
+    }
+    return PCX_OK;
+}
+static int stage_out_end(void *host, size_t bytes, StageBuf &ws, bool staged, hipStream_t st)
+{
+    PCX_TRY(stage_out_first(ws, bytes, staged, st));
+    PCX_TRY(stage_out_rest(host, ws, bytes, staged, st));
+    PCX_HIP(hipStreamSynchronize(st));      // (a call that ran in place on page-locked buffers ends here)
     return PCX_OK;
 }
 
@@ -312,7 +394,8 @@ struct pcx_fir {
     size_t ntaps = 1, M = 1, L = 1, K = 1, inputRequire = 1;
     int algo = PCX_FIR_AUTO, last_algo = 0;
     bool dirty = true;
-    DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096, wsIn, wsOut;
+    DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096;
+    StageBuf wsIn, wsOut;
     DevBuf sched;             // {draws, finished}: dynamic block assignment of the overlap-save kernels (pcx_sched.hpp), zeroed once
     size_t Kp = 8;
     bool have_ols = false;
@@ -455,8 +538,7 @@ static int fir_sync_tables(pcx_fir *h)
     }
     h->have_ols = false;
     if (!h->sched.p) {
-        PCX_TRY(h->sched.ensure(64));
-        PCX_HIP(hipMemset(h->sched.p, 0, 64));
+        PCX_TRY(h->sched.ensure_zeroed(64));
     }
     if (fir_fast_applicable(h)) {
         const size_t K = h->K;
@@ -854,7 +936,7 @@ int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size
     PCX_TRY(stage_in(in, used_in * esz, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, n_out * esz, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_fir_process_dev(h, din, used_in, dout, n_out, consumed, produced, st));
-    return stage_out_end(out, *produced * esz, dout, staged, st);
+    return stage_out_end(out, *produced * esz, h->wsOut, staged, st);
 }
 
 /* ===================================================================== *
@@ -867,7 +949,8 @@ struct pcx_fft {
     int inverse = 0;
     enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, SMOOTH, FOURSTEP, FOURSTEP_SHORT, BLUESTEIN } kind = MIXED;
     int log2n = 0;
-    DevBuf tw, perm, wsIn, wsOut;
+    DevBuf tw, perm;
+    StageBuf wsIn, wsOut;
     DevBuf sched;            // dynamic frame assignment of fft4096_kernel (pcx_sched.hpp), zeroed at create
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
     // FOURSTEP (fft_large.hip): numBins = n1 * n2, both within the single-workgroup plans
@@ -1004,8 +1087,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     } else if (scalar == PCX_F32 && num_bins == 4096) {
         h->kind = pcx_fft::R16_4096;
         rc = upload(h->tw, make_tw4096());
-        if (rc == PCX_OK) rc = h->sched.ensure(64);
-        if (rc == PCX_OK && hipMemset(h->sched.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
+        if (rc == PCX_OK) rc = h->sched.ensure_zeroed(64);
     } else if (scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384) {
         h->kind = pcx_fft::R16;
         while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
@@ -1200,7 +1282,7 @@ int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
     PCX_TRY(stage_in(in, bytes, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, bytes, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_fft_transform_dev(h, din, dout, nframes, st));
-    return stage_out_end(out, bytes, dout, staged, st);
+    return stage_out_end(out, bytes, h->wsOut, staged, st);
 }
 
 /* ===================================================================== *
@@ -1211,7 +1293,7 @@ struct pcx_freqdemod {
     int scalar = PCX_F32;
     DevBuf prev;  // two complex slots (ping-pong), holds _prev = conj(last input)
     int cur = 0;
-    DevBuf wsIn, wsOut;
+    StageBuf wsIn, wsOut;
 };
 int pcx_freqdemod_create(int scalar, pcx_freqdemod **out)
 {
@@ -1221,8 +1303,7 @@ int pcx_freqdemod_create(int scalar, pcx_freqdemod **out)
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->scalar = scalar;
     DeviceScope dev_scope(h->cx.device);
-    int rc = h->prev.ensure(64);
-    if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
+    int rc = h->prev.ensure_zeroed(64);
     if (rc != PCX_OK) { delete h; return rc; }
     *out = h;
     return PCX_OK;
@@ -1268,7 +1349,7 @@ int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
     PCX_TRY(stage_in(in, n * 2 * sb, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, n * sb, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_freqdemod_process_dev(h, din, dout, n, st));
-    return stage_out_end(out, n * sb, dout, staged, st);
+    return stage_out_end(out, n * sb, h->wsOut, staged, st);
 }
 
 /* ===================================================================== *
@@ -1281,7 +1362,7 @@ int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
 struct MapWs {
     int device = -1;
     hipStream_t st = nullptr;
-    DevBuf in, out, in2, out2;
+    StageBuf in, out, in2, out2;
     void drop()
     {
         in.release(); out.release(); in2.release(); out2.release();
@@ -1320,7 +1401,7 @@ static int run_host_map(const void *in, void *out, size_t in_bytes, size_t out_b
     PCX_TRY(stage_in(in, in_bytes, ws->in, ws->st, &din));
     PCX_TRY(stage_out_begin(out, out_bytes, ws->out, &dout, &staged));
     PCX_TRY(launch(din, dout, ws->st));
-    return stage_out_end(out, out_bytes, dout, staged, ws->st);
+    return stage_out_end(out, out_bytes, ws->out, staged, ws->st);
 }
 
 int pcx_rotate_dev(int scalar, double pr, double pi, const void *in_dev, void *out_dev, size_t n, void *stream)
@@ -1413,7 +1494,7 @@ int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *i
     PCX_TRY(stage_in(in1, b, ws->in2, ws->st, &d1));
     PCX_TRY(stage_out_begin(out, b, ws->out, &dout, &staged));
     PCX_TRY(launch_arith(scalar, is_complex, op, d0, d1, dout, n, ws->st));
-    return stage_out_end(out, b, dout, staged, ws->st);
+    return stage_out_end(out, b, ws->out, staged, ws->st);
 }
 int pcx_split_complex_dev(int scalar, const void *in_dev, void *re_dev, void *im_dev, size_t n, void *stream)
 {
@@ -1435,8 +1516,8 @@ int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n)
     PCX_TRY(stage_out_begin(re, b, ws->out, &dre, &sre));
     PCX_TRY(stage_out_begin(im, b, ws->out2, &dim, &sim));
     PCX_TRY(launch_split_complex(scalar, din, dre, dim, n, ws->st));
-    if (sre) PCX_HIP(hipMemcpyAsync(re, dre, b, hipMemcpyDeviceToHost, ws->st));
-    return stage_out_end(im, b, dim, sim, ws->st);
+    PCX_TRY(stage_out_end(re, b, ws->out, sre, ws->st));
+    return stage_out_end(im, b, ws->out2, sim, ws->st);
 }
 int pcx_combine_complex_dev(int scalar, const void *re_dev, const void *im_dev, void *out_dev, size_t n, void *stream)
 {
@@ -1458,7 +1539,7 @@ int pcx_combine_complex(int scalar, const void *re, const void *im, void *out, s
     PCX_TRY(stage_in(im, b, ws->in2, ws->st, &dim));
     PCX_TRY(stage_out_begin(out, 2 * b, ws->out, &dout, &staged));
     PCX_TRY(launch_combine_complex(scalar, dre, dim, dout, n, ws->st));
-    return stage_out_end(out, 2 * b, dout, staged, ws->st);
+    return stage_out_end(out, 2 * b, ws->out, staged, ws->st);
 }
 
 /* ===================================================================== *
@@ -1473,7 +1554,8 @@ struct pcx_fmchain {
     int ctaps = 0;
     bool dirty = true;
     size_t K = 1, Kp = 8;
-    DevBuf tapsRev, Hspec, tw4096, prev, wsIn, wsOut;
+    DevBuf tapsRev, Hspec, tw4096, prev;
+    StageBuf wsIn, wsOut;
     DevBuf sched;   // dynamic block assignment of the fused kernel (pcx_sched.hpp), zeroed at create
     int cur = 0;
     int algo = PCX_FIR_AUTO, last_algo = 0;
@@ -1491,10 +1573,8 @@ int pcx_fmchain_create(pcx_fmchain **out)
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
     h->taps.assign(1, 1.0);
     DeviceScope dev_scope(h->cx.device);
-    int rc = h->prev.ensure(64);
-    if (rc == PCX_OK && hipMemset(h->prev.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
-    if (rc == PCX_OK) rc = h->sched.ensure(64);
-    if (rc == PCX_OK && hipMemset(h->sched.p, 0, 64) != hipSuccess) { set_error("hipMemset failed"); rc = PCX_ERR_HIP; }
+    int rc = h->prev.ensure_zeroed(64);
+    if (rc == PCX_OK) rc = h->sched.ensure_zeroed(64);
     if (rc != PCX_OK) { delete h; return rc; }
     *out = h;
     return PCX_OK;
@@ -1631,5 +1711,5 @@ int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *o
     PCX_TRY(stage_in(in, used * 8, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, N * 4, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_fmchain_process_dev(h, din, used, dout, N, consumed, produced, st));
-    return stage_out_end(out, N * 4, dout, staged, st);
+    return stage_out_end(out, N * 4, h->wsOut, staged, st);
 }

@@ -64,11 +64,34 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes);
+    int ensure_zeroed(size_t bytes);   // ensure + zero fill, COMPLETE on return (control plane)
     void release();
     ~DevBuf() { release(); }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// page-locked host memory of the library's own (the bounce buffer of a pageable host-pointer call)
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    ~PinBuf() { release(); }
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+};
+// staging pair of one direction of a host-pointer call (pcx_api.hip stage_in / stage_out_*)
+struct StageBuf {
+    DevBuf dev;
+    PinBuf pin;
+    void release();
+    StageBuf() = default;
+    StageBuf(const StageBuf &) = delete;
+    StageBuf &operator=(const StageBuf &) = delete;
+    ~StageBuf() { release(); }
 };
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -53,7 +53,8 @@ def test_page_locked_buffers_are_processed_in_place(oracle, dev):
         got, _, _ = f.process(x, n)
         assert nerr(got, ref) <= TOL
         y[:] = 0
-        _lib.check(_lib.load().pcx_fir_process(f._h, x.copy().ctypes.data, n + K - 1, y.ctypes.data, n, C.byref(c), C.byref(p)))
+        xc = x.copy()      # (kept alive across the call: .ctypes.data of a temporary dangles)
+        _lib.check(_lib.load().pcx_fir_process(f._h, xc.ctypes.data, n + K - 1, y.ctypes.data, n, C.byref(c), C.byref(p)))
         assert nerr(y, ref) <= TOL
         # maps in place on pinned memory (out == in is part of the contract)
         z = x[:50000]
@@ -185,3 +186,46 @@ def test_process_dev_can_be_captured_into_a_graph(oracle, dev):
     ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h); ref.activate()
     xw = x[:60000 + K - 1].cpu().numpy()
     assert nerr(y[:60000].cpu().numpy(), ref.work(xw, 60000)[0]) <= TOL
+
+
+def test_a_new_handle_is_ready_when_create_returns(oracle, dev):
+    """State a handle zeroes at create (FreqDemod's _prev, FreqDemod.cpp:46; the block dealer's books) must be zero when
+    create returns, not whenever a fill queued on the null stream gets its turn: the handle's own stream does not wait for
+    the null stream.  A long fill keeps the null stream busy while handles are created on recycled memory and used at once."""
+    import torch
+    d = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    busy = torch.empty(1 << 28, dtype=torch.float32, device=d)      # 1 GiB
+    x = (rng.standard_normal((3000, 2)) + 0.1).astype(np.float32)
+    ref = oracle.FreqDemod(oracle.F32).work(x)
+    for rep in range(12):
+        warm = dev.FreqDemod("complex_float32")
+        warm.process(x)                                              # leaves conj(x[-1]) where the next handle's state will live
+        del warm
+        for _ in range(8):
+            busy.fill_(float(rep))                                   # torch's default stream is the null stream
+        blk = dev.FreqDemod("complex_float32")
+        got0 = blk.process(x[:1500])
+        got1 = blk.process(x[1500:])
+        assert got0[0] == 0.0, rep
+        assert ang_err(np.concatenate([got0, got1]), ref) <= TOL, rep
+    torch.cuda.synchronize()
+    # the dealer's counter pair: a FIR handle created and run at once behind the same busy null stream
+    from pothoscomms_amd import taps as tp
+    t = tp.complex_bandpass(255, 0.1, 0.03)
+    n = 4096 * 3000
+    xs = (rng.standard_normal((n, 2))).astype(np.float32)
+    xd = torch.from_numpy(xs).to(d)
+    want = None
+    for rep in range(4):
+        for _ in range(8):
+            busy.fill_(1.0)
+        f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(t)
+        yd = torch.zeros((n, 2), dtype=torch.float32, device=d)
+        s = torch.cuda.Stream(device=d)
+        f.process_dev(xd, yd, n, n, stream=s)
+        s.synchronize()
+        y = yd.cpu().numpy()
+        if want is None:
+            want = y
+        assert np.array_equal(y, want), rep

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import TOL, ang_err, nerr, rand_stream
+from tests.util import TOL, ang_err, diff_note, nerr, rand_stream
 
 pytestmark = pytest.mark.gpu
 SEEDS = range(int(os.environ.get("PCX_FUZZ_SEEDS", "12")))
@@ -109,7 +109,7 @@ def test_fm_chain_random_chunks(oracle, dev, seed):
         outs.append(g); pos += c
     got = np.concatenate(outs)
     assert len(got) == produced == n - ntaps + 1
-    assert ang_err(got, ref) <= TOL
+    assert ang_err(got, ref) <= TOL, (seed, ntaps, ends, diff_note(np.round(got, 3), np.round(ref, 3)))
 
 
 @pytest.mark.parametrize("seed", SEEDS)
@@ -161,7 +161,8 @@ def test_fir_block_random_streaming_with_bursts(oracle, seed):
             if scalar == oracle.I16:
                 assert np.array_equal(y, ry)
             else:
-                assert nerr(y, ry) <= (TOL if scalar == oracle.F32 else 1e-12) or float(np.abs(ry).max()) == 0.0
+                assert nerr(y, ry) <= (TOL if scalar == oracle.F32 else 1e-12) or float(np.abs(ry).max()) == 0.0, \
+                    (seed, calls, diff_note(np.round(y, 2), np.round(ry, 2)), y.ctypes.data % 4096, y.itemsize)
         pos += c
         total_p += p
         calls += 1
@@ -306,7 +307,7 @@ def test_fir_edge_geometries(oracle, dev, seed):
         if K > 8193:
             # beyond every frequency-domain plan AUTO runs the reference's own operation order: its rounding noise
             # (seed 10029: above 1e-5 of float64) is reproduced bit for bit
-            assert f.last_algo == dev._lib.FIR_EXACT and np.array_equal(got, want), (K, n_in, out_cap)
+            assert f.last_algo == dev._lib.FIR_EXACT and np.array_equal(got, want), (K, n_in, out_cap, diff_note(got, want), got.ctypes.data % 4096)
         else:
             assert float(np.abs(got[idx] - ex).max()) <= TOL * scale, (K, n_in, out_cap)
             assert float(np.abs(got - want).max()) <= TOL * scale + 2.0 * ref_noise, (K, n_in, out_cap)

@@ -35,3 +35,16 @@ def ang_err(got, ref):
     d = np.asarray(got, np.float64) - np.asarray(ref, np.float64)
     d = (d + np.pi) % (2 * np.pi) - np.pi
     return float(np.max(np.abs(d)) / np.pi) if d.size else 0.0
+
+
+def diff_note(got, want):
+    """where two arrays differ, for an assertion message: count, extent, how many of the differing rows are all zero"""
+    g, w = np.asarray(got), np.asarray(want)
+    rows = np.any(g != w, axis=tuple(range(1, g.ndim))) if g.ndim > 1 else g != w
+    bad = np.flatnonzero(rows)
+    if bad.size == 0:
+        return "equal"
+    zero = int(np.sum(np.all(g[bad] == 0, axis=tuple(range(1, g.ndim))) if g.ndim > 1 else g[bad] == 0))
+    runs = np.split(bad, np.flatnonzero(np.diff(bad) > 1) + 1)
+    return "%d rows of %d differ (%d of them zero) in %d runs: %s" % (
+        bad.size, g.shape[0], zero, len(runs), ", ".join("%d..%d" % (r[0], r[-1]) for r in runs[:8]))

@@ -21,8 +21,11 @@
  *     `out`.  Page-locked host memory (pcx_host_alloc, hipHostMalloc,
  *     hipHostRegister -- what the module's BufferManagers hand out) is
  *     processed IN PLACE: the kernels read and write it over PCIe, both
- *     directions at once.  Pageable memory is staged through a device
- *     workspace owned by the handle (H2D, kernel, D2H).
+ *     directions at once.  Pageable memory is staged through a page-locked
+ *     bounce buffer and a device workspace owned by the handle (CPU copy,
+ *     pinned H2D, kernel, pinned D2H, CPU copy).
+ *   - *_create and the setters return with everything they zero or upload
+ *     COMPLETE on the device: a handle can be used at once on any stream.
  *   - every handle owns a non-blocking stream for its host-pointer calls, so
  *     blocks on different actor threads overlap on the device; nothing runs
  *     on the legacy default stream.

@@ -206,6 +206,47 @@ def worker_hetero(rank, iters, q):
         q.put((rank, {"error": ({"error": 1}, [repr(e)[:300]])}))
 
 
+def run_streams(rank, iters, q):
+    """consecutive chunks of one FreqDemod stream on ALTERNATING streams with no host synchronisation: the handle orders them
+    with an event (pcx_api.hip ctx_enter); the carried _prev makes any overtaking visible at the chunk's first sample"""
+    import torch
+    from pothoscomms_amd import _lib, device as dev
+    _lib.load()
+    d = torch.device("cuda", 0)
+    rng = np.random.default_rng(301 + rank)
+    n = 1 << 18
+    ph = np.cumsum(rng.uniform(-1.0, 1.0, n))
+    xh = np.stack([np.cos(ph), np.sin(ph)], 1).astype(np.float32)
+    x = torch.from_numpy(xh).to(d)
+    streams = [torch.cuda.Stream(d) for _ in range(3)]
+    first, bad, notes = None, 0, []
+    for it in range(iters):
+        y = torch.zeros(n, dtype=torch.float32, device=d)
+        torch.cuda.synchronize()
+        dm = dev.FreqDemod("complex_float32")
+        cuts = sorted(set([0, n] + [int(c) for c in rng.integers(1, n, 40)]))
+        if first is not None:
+            cuts = first[1]
+        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            dm.process_dev(x[a:b], y[a:b], b - a, stream=streams[i % 3])
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        if first is None:
+            first = (got.copy(), cuts)
+        h = holes(got, first[0])
+        if h:
+            bad += 1; notes.append("streams it %d: %s" % (it, h))
+        del dm
+    q.put((rank, {"streams": ({"streams": bad}, notes[:6])}))
+
+
+def worker_streams(rank, iters, q):
+    try:
+        run_streams(rank, iters, q)
+    except Exception as e:
+        q.put((rank, {"error": ({"error": 1}, [repr(e)[:300]])}))
+
+
 def worker_reused(rank, iters, q):
     try:
         run_reused(rank, iters, q)
@@ -219,6 +260,8 @@ def main():
     global worker
     if len(sys.argv) > 3 and sys.argv[3] == "reused":
         worker = worker_reused
+    if len(sys.argv) > 3 and sys.argv[3] == "streams":
+        worker = worker_streams
     if len(sys.argv) > 3 and sys.argv[3] == "hetero":
         worker = worker_hetero
     if len(sys.argv) > 3 and sys.argv[3] == "fresh":

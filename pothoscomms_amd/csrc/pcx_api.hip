@@ -286,7 +286,8 @@ static int ctx_quiesce(ExecCtx &c)
 // buffers -- measured on MI355X (tools/pcie_lab.hip, 128 MiB each way): a kernel reading and writing pinned host memory
 // moves 43 GB/s in BOTH directions at once, against 28 GB/s for H2D, kernel, D2H through a staging workspace -- and stage
 // only pageable memory, which the device cannot address.
-static void *device_alias(const void *p)
+namespace pcx {
+void *device_alias(const void *p)
 {
     if (!p) return nullptr;
     hipPointerAttribute_t a;
@@ -294,6 +295,7 @@ static void *device_alias(const void *p)
     if ((a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) && a.devicePointer) return a.devicePointer;
     return nullptr;
 }
+}  // namespace pcx
 // One direction of a host-pointer call: the alias when there is one, else the staging pair (grown to `bytes`): a device
 // buffer and a page-locked bounce buffer of the library's own.  Pageable memory is copied by the CPU into / out of the
 // bounce buffer and moved by plain pinned <-> device transfers on the call's stream.  (hipMemcpyAsync straight on the

@@ -83,6 +83,8 @@ struct PinBuf {
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
 };
+// device-visible alias of a host pointer when it is page-locked (pcx_api.hip), else nullptr
+void *device_alias(const void *p);
 // staging pair of one direction of a host-pointer call (pcx_api.hip stage_in / stage_out_*)
 struct StageBuf {
     DevBuf dev;

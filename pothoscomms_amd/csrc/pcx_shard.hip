@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -107,6 +108,7 @@ struct pcx_shard {
     std::vector<hipEvent_t> in_ready, halo_ready;
     std::vector<pcx_fir *> fir;
     std::vector<void *> alloc, out;               // per shard: [lead | halo K-1 | C] and C outputs (cf32)
+    std::vector<std::unique_ptr<PinBuf>> bounce_in, bounce_out;   // scatter / gather of PAGEABLE host memory (pcx_api.hip stage_in)
     size_t K = 1, C = 0, lead = 0, head = 0;
     bool have_taps = false;
     unsigned long long steps = 0;
@@ -186,6 +188,7 @@ int pcx_shard_create(int nshards, const int *devices, int transport, pcx_shard *
     s->in_ready.assign(nshards, nullptr); s->halo_ready.assign(nshards, nullptr);
     s->fir.assign(nshards, nullptr);
     s->alloc.assign(nshards, nullptr); s->out.assign(nshards, nullptr);
+    for (int g = 0; g < nshards; g++) { s->bounce_in.emplace_back(new PinBuf()); s->bounce_out.emplace_back(new PinBuf()); }
     DeviceGuard guard;
     auto fail = [&](int rc) { (void)pcx_shard_destroy(s); return rc; };
     for (int g = 0; g < nshards; g++) {
@@ -295,6 +298,8 @@ int pcx_shard_buffers(pcx_shard *s, int g, void **in_dev, void **out_dev, void *
     return PCX_OK;
 }
 
+// Page-locked caller memory is given to the DMA engine as it is; pageable memory goes through a page-locked bounce buffer of the
+// shard's own, copied by the CPU -- the library never hands a pageable pointer to hipMemcpyAsync (profiles/r02/contention.md).
 int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
 {
     PCX_CHECK_ARG(s && host_stream, "null argument");
@@ -303,12 +308,27 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
                   s->K - 1 + (size_t)s->G * s->C);
     DeviceGuard guard;
     const float2 *x = static_cast<const float2 *>(host_stream);
+    const bool locked = device_alias(host_stream) != nullptr;
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         // shard 0 also takes the stream's own K-1 history; every other halo slot is filled by the exchange of each pass
         const size_t skip = g == 0 ? 0 : s->K - 1;
-        PCX_HIP(hipMemcpyAsync(s->in_ptr(g) + skip, x + (size_t)g * s->C + skip, (s->K - 1 - skip + s->C) * sizeof(float2), hipMemcpyHostToDevice,
-                               s->st[g]));
+        const size_t bytes = (s->K - 1 - skip + s->C) * sizeof(float2);
+        const float2 *src = x + (size_t)g * s->C + skip;
+        if (!locked) {
+            PinBuf &b = *s->bounce_in[g];
+            PCX_HIP(hipStreamSynchronize(s->st[g]));      // the bounce buffer's previous transfer
+            PCX_TRY(b.ensure(bytes));
+            constexpr size_t kPiece = (size_t)4 << 20;     // the CPU copies piece i+1 while piece i is on the wire
+            for (size_t off = 0; off < bytes; off += kPiece) {
+                const size_t c = bytes - off < kPiece ? bytes - off : kPiece;
+                std::memcpy(static_cast<char *>(b.p) + off, reinterpret_cast<const char *>(src) + off, c);
+                PCX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(s->in_ptr(g) + skip) + off, static_cast<const char *>(b.p) + off, c,
+                                       hipMemcpyHostToDevice, s->st[g]));
+            }
+        } else {
+            PCX_HIP(hipMemcpyAsync(s->in_ptr(g) + skip, src, bytes, hipMemcpyHostToDevice, s->st[g]));
+        }
     }
     return PCX_OK;
 }
@@ -319,13 +339,21 @@ int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
     PCX_CHECK_ARG(s->C && elems == (size_t)s->G * s->C, "pcx_shard_gather: %zu elements, expected shards*C = %zu", elems, (size_t)s->G * s->C);
     DeviceGuard guard;
     float2 *y = static_cast<float2 *>(host_out);
+    const bool locked = device_alias(host_out) != nullptr;
+    const size_t bytes = s->C * sizeof(float2);
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_HIP(hipMemcpyAsync(y + (size_t)g * s->C, s->out[g], s->C * sizeof(float2), hipMemcpyDeviceToHost, s->st[g]));
+        void *dst = y + (size_t)g * s->C;
+        if (!locked) {
+            PCX_TRY(s->bounce_out[g]->ensure(bytes));
+            dst = s->bounce_out[g]->p;
+        }
+        PCX_HIP(hipMemcpyAsync(dst, s->out[g], bytes, hipMemcpyDeviceToHost, s->st[g]));
     }
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         PCX_HIP(hipStreamSynchronize(s->st[g]));
+        if (!locked) std::memcpy(y + (size_t)g * s->C, s->bounce_out[g]->p, bytes);
     }
     return PCX_OK;
 }

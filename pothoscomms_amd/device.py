@@ -422,7 +422,7 @@ class NodeStream(_Handle):
     def sync(self):
         _lib.check(_lib.load().pcx_shard_sync(self._h))
 
-    def gather(self):
-        y = np.empty((self.nshards * self.C, 2), np.float32)
+    def gather(self, out=None):
+        y = np.empty((self.nshards * self.C, 2), np.float32) if out is None else out
         _lib.check(_lib.load().pcx_shard_gather(self._h, _np_ptr(y), y.shape[0]))
         return y

@@ -163,3 +163,36 @@ def test_handles_stay_on_the_device_they_were_created_on(oracle):
     assert nerr(out["fir"], _oracle_fir(oracle, h, x, 30000)) <= TOL
     assert nerr(out["fft"], oracle.fft(xf, 4096, False)) <= TOL
     assert np.array_equal(out["conj"], oracle.conj(x))
+
+
+def test_scatter_and_gather_on_page_locked_and_pageable_memory_agree(oracle):
+    """page-locked caller memory goes to the DMA engine as it is (scatter returns before the copy has run: the buffer must
+    stay alive until the pass is synchronised); pageable memory goes through the shard's bounce buffers"""
+    from pothoscomms_amd import _lib, device, taps as tp
+    h = tp.c1_taps()
+    K, G, Cs = len(h), 3, 50000
+    x = oracle.fill_uniform_f32(2 * (K - 1 + G * Cs), 2, 0).reshape(-1, 2)
+    ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+    ns.set_taps(h)
+    ns.configure(Cs)
+    ns.scatter(x)
+    ns.step()
+    pageable = ns.gather()
+    L = _lib.load()
+    pin, pout = C.c_void_p(), C.c_void_p()
+    _lib.check(L.pcx_host_alloc(C.byref(pin), x.nbytes))
+    _lib.check(L.pcx_host_alloc(C.byref(pout), G * Cs * 8))
+    try:
+        xin = np.ctypeslib.as_array((C.c_float * x.size).from_address(pin.value)).reshape(x.shape)
+        yout = np.ctypeslib.as_array((C.c_float * (G * Cs * 2)).from_address(pout.value)).reshape(-1, 2)
+        xin[:] = x
+        yout[:] = 0
+        ns.scatter(xin)
+        ns.step()
+        got = ns.gather(out=yout)
+        assert np.array_equal(got, pageable)
+        assert nerr(got, _oracle_fir(oracle, h, x, G * Cs)) <= TOL
+    finally:
+        ns.sync()
+        del ns
+        _lib.check(L.pcx_host_free(pin)); _lib.check(L.pcx_host_free(pout))

@@ -247,6 +247,27 @@ def worker_streams(rank, iters, q):
         q.put((rank, {"error": ({"error": 1}, [repr(e)[:300]])}))
 
 
+def worker_threads(rank, iters, q):
+    """the Pothos picture: one process, one actor thread per block -- eight threads here, each with its own handles"""
+    import queue
+    import threading
+    tq = queue.Queue()
+    ts = [threading.Thread(target=worker_hetero, args=(rank * 100 + t, iters, tq)) for t in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    merged = {}
+    notes = []
+    while not tq.empty():
+        _, out = tq.get()
+        for key, (counts, ns) in out.items():
+            for k, v in counts.items():
+                merged[k] = merged.get(k, 0) + v
+            notes += ns
+    q.put((rank, {"threads": (merged, notes[:10])}))
+
+
 def worker_reused(rank, iters, q):
     try:
         run_reused(rank, iters, q)
@@ -260,6 +281,8 @@ def main():
     global worker
     if len(sys.argv) > 3 and sys.argv[3] == "reused":
         worker = worker_reused
+    if len(sys.argv) > 3 and sys.argv[3] == "threads":
+        worker = worker_threads
     if len(sys.argv) > 3 and sys.argv[3] == "streams":
         worker = worker_streams
     if len(sys.argv) > 3 and sys.argv[3] == "hetero":

@@ -437,6 +437,7 @@ static int fir_ols_block_log2(size_t K)
     return K <= 4097 ? 13 : 14;
 }
 constexpr size_t kOlsMaxTaps = 8193;
+constexpr size_t kRowsWorkspaceCap = (size_t)1 << 30;   // polyphase-row workspace of the interpolating paths (pcx_fir_process_dev)
 // complex_float64 (fir_ols_f64.hip): 4096-sample blocks to K = 2049, 8192 to K = 4097; PCX_OLS64_N forces a plan (A/B)
 constexpr size_t kOls64MaxTaps = 4097;
 // below this many taps the sliding-window kernel is the faster complex_float64 form (tools/sweep_fir_f64.py: 128 vs 112 Gsamples/s at K = 2)
@@ -852,24 +853,31 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
+    // interpolation through polyphase ROWS: every row filtered at the input rate into a contiguous workspace row, then one
+    // interleaving pass.  Long calls go in batches of iterations so that the workspace stays at kRowsWorkspaceCap bytes
+    // whatever the call (it would be a second copy of the output otherwise).
+    auto rows_path = [&](size_t eb, size_t Mdec, auto &&row) -> int {
+        size_t nb_max = kRowsWorkspaceCap / (h->L * eb) / Mdec * Mdec;     // whole output samples per batch
+        if (nb_max < Mdec) nb_max = Mdec;
+        PCX_TRY(h->wsRows.ensure((N < nb_max ? N : nb_max) * h->L * eb));
+        for (size_t i0 = 0; i0 < N; i0 += nb_max) {
+            const size_t nb = N - i0 < nb_max ? N - i0 : nb_max;
+            const char *in_b = static_cast<const char *>(in_dev) + i0 * eb;   // the rows run at M = 1: one input sample per iteration
+            for (size_t jr = 0; jr < h->L; jr++) PCX_TRY(row(in_b, nb, static_cast<char *>(h->wsRows.p) + jr * nb * eb, jr));
+            PCX_TRY(launch_interleave_rows(h->wsRows.p, static_cast<char *>(out_dev) + i0 * h->L / Mdec * eb, nb, h->L, eb, Mdec, st));
+        }
+        return PCX_OK;
+    };
     if (algo == PCX_FIR_OLS_FFT && h->have_interp_real) {
-        const size_t eb = fir_elem_bytes(h);
-        PCX_TRY(h->wsRows.ensure(N * h->L * eb));
-        rc = PCX_OK;
-        for (size_t jr = 0; jr < h->L && rc == PCX_OK; jr++)
-            rc = launch_fir_real_ols(in_dev, used_in, static_cast<char *>(h->wsRows.p) + jr * N * eb, N,
-                                     static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12, h->tw4096.p,
-                                     h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, 1, st);
-        if (rc == PCX_OK) rc = launch_interleave_rows(h->wsRows.p, out_dev, N, h->L, eb, h->M, st);
+        rc = rows_path(fir_elem_bytes(h), h->M, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
+            return launch_fir_real_ols(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12,
+                                       h->tw4096.p, h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, 1, st);
+        });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_interp64) {
-        const size_t eb = fir_elem_bytes(h);
-        PCX_TRY(h->wsRows.ensure(N * h->L * eb));
-        rc = PCX_OK;
-        for (size_t jr = 0; jr < h->L && rc == PCX_OK; jr++)
-            rc = launch_fir_cf64_ols(in_dev, used_in, static_cast<char *>(h->wsRows.p) + jr * N * eb, N,
-                                     static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12, h->tw4096.p,
-                                     h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, 1, st);
-        if (rc == PCX_OK) rc = launch_interleave_rows(h->wsRows.p, out_dev, N, h->L, eb, h->M, st);
+        rc = rows_path(fir_elem_bytes(h), h->M, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
+            return launch_fir_cf64_ols(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12,
+                                       h->tw4096.p, h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, 1, st);
+        });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_ols_real64) {
         rc = launch_fir_real_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, h->M, st);
@@ -885,12 +893,10 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly && h->M == 1 && h->K <= 2049 && !PCX_ENV_SET("PCX_FIR_POLY_STRIDED")) {
         // interpolation by other factors: each polyphase row through the undecimated kernel into a contiguous workspace row,
         // then one interleaving pass (PCX_FIR_POLY_STRIDED (A/B) keeps the polyphase kernel's stride-L stores)
-        PCX_TRY(h->wsRows.ensure(N * h->L * 8));
-        rc = PCX_OK;
-        for (size_t jr = 0; jr < h->L && rc == PCX_OK; jr++)
-            rc = launch_fir_cf32_ols4096(in_dev, used_in, static_cast<char *>(h->wsRows.p) + jr * N * 8, N,
-                                         static_cast<const char *>(h->HspecRows.p) + jr * 2 * 4096 * sizeof(float), h->K, h->tw4096.p, h->sched.p, st);
-        if (rc == PCX_OK) rc = launch_interleave_rows_cf32(h->wsRows.p, out_dev, N, h->L, st);
+        rc = rows_path(8, 1, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
+            return launch_fir_cf32_ols4096(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HspecRows.p) + jr * 2 * 4096 * sizeof(float), h->K,
+                                           h->tw4096.p, h->sched.p, st);
+        });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {
@@ -1206,14 +1212,36 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
 }
 int pcx_fft_destroy(pcx_fft *h) { delete h; return PCX_OK; }
 
+// The plans that go through workspaces (four-step, chirp-z) take a long call in batches of frames, so that the workspaces stay
+// at kFftWorkspaceCap bytes each whatever the call: a 34 GB call of 20486-bin frames would otherwise ask for 2 x 110 GB
+// (tests/test_huge_gpu.py).  A batch of that size is still tens of thousands of workgroups per launch.
+constexpr size_t kFftWorkspaceCap = (size_t)1 << 30;
+static int fft_transform_batch(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream);
+
 int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream)
 {
     PCX_CHECK_ARG(h, "null handle");
     DeviceScope dev_scope(h->cx.device);
     if (nframes == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    PCX_TRY(ctx_enter(h->cx, as_stream(stream)));
+    if (h->kind == pcx_fft::FOURSTEP_SHORT || h->kind == pcx_fft::FOURSTEP || h->kind == pcx_fft::BLUESTEIN) {
+        const size_t esz = 2 * (size_t)scalar_bytes(h->scalar);
+        const size_t ws_frame = (h->kind == pcx_fft::BLUESTEIN ? h->n2 : h->nbins) * esz;   // workspace bytes per frame
+        size_t batch = kFftWorkspaceCap / ws_frame;
+        if (batch < 1) batch = 1;
+        for (size_t f = 0; f < nframes; f += batch) {
+            const size_t nf = nframes - f < batch ? nframes - f : batch;
+            PCX_TRY(fft_transform_batch(h, static_cast<const char *>(in_dev) + f * h->nbins * esz, static_cast<char *>(out_dev) + f * h->nbins * esz, nf, stream));
+        }
+        return PCX_OK;
+    }
+    return fft_transform_batch(h, in_dev, out_dev, nframes, stream);
+}
+
+static int fft_transform_batch(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream)
+{
     hipStream_t st = as_stream(stream);
-    PCX_TRY(ctx_enter(h->cx, st));
     switch (h->kind) {
     case pcx_fft::IDENTITY:  // DFT of one point is the identity (kissfft leaf copy, kissfft.hh:94-98) -- except in Q15
         if (h->scalar == PCX_I16) return launch_fft_q15_one(in_dev, out_dev, nframes, st);
@@ -1672,13 +1700,20 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     int algo = h->algo;
     if (algo == PCX_FIR_AUTO && !h->have_ols) {
         // K > 2048: two launches (FIR with the folded phasor, then FreqDemod) sharing the chain's carried state
-        size_t c2 = 0, p2 = 0;
-        PCX_TRY(h->long_y.ensure(N * 8));
-        PCX_TRY(pcx_fir_process_dev(h->long_fir, in_dev, N + h->K - 1, h->long_y.p, N, &c2, &p2, stream));
-        if (c2 != N || p2 != N) { set_error("fm chain: FIR stage produced %zu of %zu", p2, N); return PCX_ERR_STATE; }
-        PCX_TRY(launch_freqdemod(PCX_F32, h->long_y.p, out_dev, N, base + 32 * h->cur, base + 32 * (h->cur ^ 1), as_stream(stream)));
+        // (in batches: the intermediate FIR output stays at kRowsWorkspaceCap bytes whatever the call; the demodulator's state
+        // walks through the batches exactly as it does through work() calls)
+        const size_t nb_max = kRowsWorkspaceCap / 8;
+        PCX_TRY(h->long_y.ensure((N < nb_max ? N : nb_max) * 8));
+        for (size_t i0 = 0; i0 < N; i0 += nb_max) {
+            const size_t nb = N - i0 < nb_max ? N - i0 : nb_max;
+            size_t c2 = 0, p2 = 0;
+            PCX_TRY(pcx_fir_process_dev(h->long_fir, static_cast<const float2 *>(in_dev) + i0, nb + h->K - 1, h->long_y.p, nb, &c2, &p2, stream));
+            if (c2 != nb || p2 != nb) { set_error("fm chain: FIR stage produced %zu of %zu", p2, nb); return PCX_ERR_STATE; }
+            PCX_TRY(launch_freqdemod(PCX_F32, h->long_y.p, static_cast<float *>(out_dev) + i0, nb, base + 32 * h->cur, base + 32 * (h->cur ^ 1),
+                                     as_stream(stream)));
+            h->cur ^= 1;
+        }
         h->last_algo = PCX_FIR_AUTO;
-        h->cur ^= 1;
         *consumed = N; *produced = N;
         return PCX_OK;
     }

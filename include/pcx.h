@@ -91,6 +91,12 @@ PCX_API int pcx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, vo
 PCX_API int pcx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 PCX_API int pcx_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 PCX_API int pcx_stream_sync(void *stream);
+/* ROCTx ranges around every data-plane entry point (pcx_*_process[_dev], pcx_fft_transform[_dev], the maps,
+ * pcx_shard_scatter/step/gather), named after the function: `rocprofv3 --marker-trace --kernel-trace` then shows which
+ * call each kernel belongs to.  Off by default; pcx_trace(1) loads the ROCTx library (librocprofiler-sdk-roctx.so.1,
+ * else libroctx64.so.4) and returns PCX_ERR_UNSUPPORTED when there is none; pcx_trace(0) switches the ranges off.
+ * Process-wide. */
+PCX_API int pcx_trace(int on);
 /* page-locked host memory for port buffers: a Pothos BufferManager that hands out slabs from
  * pcx_host_alloc lets the plain (host-pointer) entry points copy at PCIe line rate instead of
  * staging pageable memory */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pcx_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "pcx_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "pcx_stream_sync": (_i, [_vp]),
+    "pcx_trace": (_i, [_i]),
     "pcx_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "pcx_host_free": (_i, [_vp]),
     "pcx_fill_uniform_f32_dev": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),

@@ -6,6 +6,8 @@
 #include <new>
 #include <string>
 
+#include <dlfcn.h>
+
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -187,6 +189,30 @@ using namespace pcx;
 
 const char *pcx_last_error(void) { return g_err.c_str(); }
 const char *pcx_version(void) { return "pothoscomms_amd 0.1 (gfx950)"; }
+
+// ROCTx ranges (include/pcx.h pcx_trace): the library is loaded on request only, nothing links against it
+namespace pcx {
+std::atomic<int> g_trace_on{0};
+int (*g_roctx_push)(const char *) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+}  // namespace pcx
+int pcx_trace(int on)
+{
+    if (!on) { g_trace_on.store(0); return PCX_OK; }
+    if (!g_roctx_push) {
+        void *lib = nullptr;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) { set_error("pcx_trace: no ROCTx library found (librocprofiler-sdk-roctx.so.1, libroctx64.so.4)"); return PCX_ERR_UNSUPPORTED; }
+        auto push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+        auto pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) { set_error("pcx_trace: roctxRangePushA / roctxRangePop not exported"); return PCX_ERR_UNSUPPORTED; }
+        g_roctx_pop = pop;
+        g_roctx_push = push;
+    }
+    g_trace_on.store(1);
+    return PCX_OK;
+}
 
 int pcx_device_count(int *count)
 {
@@ -813,6 +839,7 @@ static size_t fir_iterations(const pcx_fir *h, size_t in_elems, size_t out_cap)
 int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                         size_t *consumed, size_t *produced, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
     DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
@@ -929,6 +956,7 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
 
 int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
     DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
@@ -1220,6 +1248,7 @@ static int fft_transform_batch(pcx_fft *h, const void *in_dev, void *out_dev, si
 
 int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t nframes, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h, "null handle");
     DeviceScope dev_scope(h->cx.device);
     if (nframes == 0) return PCX_OK;
@@ -1301,6 +1330,7 @@ static int fft_transform_batch(pcx_fft *h, const void *in_dev, void *out_dev, si
 }
 int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h, "null handle");
     DeviceScope dev_scope(h->cx.device);
     if (nframes == 0) return PCX_OK;
@@ -1354,6 +1384,7 @@ int pcx_freqdemod_reset(pcx_freqdemod *h)
 }
 int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h, "null handle");
     DeviceScope dev_scope(h->cx.device);
     if (n == 0) return PCX_OK;
@@ -1368,6 +1399,7 @@ int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_de
 }
 int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h, "null handle");
     DeviceScope dev_scope(h->cx.device);
     if (n == 0) return PCX_OK;
@@ -1436,6 +1468,7 @@ static int run_host_map(const void *in, void *out, size_t in_bytes, size_t out_b
 
 int pcx_rotate_dev(int scalar, double pr, double pi, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "rotateFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
@@ -1443,12 +1476,14 @@ int pcx_rotate_dev(int scalar, double pr, double pi, const void *in_dev, void *o
 }
 int pcx_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "rotateFactory: unsupported type (scalar %d)", scalar);
     const size_t b = n * 2 * (size_t)scalar_bytes(scalar);
     return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_rotate(scalar, pr, pi, di, dout, n, st); });
 }
 int pcx_scale_dev(int scalar, int is_complex, double factor, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
@@ -1456,12 +1491,14 @@ int pcx_scale_dev(int scalar, int is_complex, double factor, const void *in_dev,
 }
 int pcx_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
     const size_t b = n * (is_complex ? 2 : 1) * (size_t)scalar_bytes(scalar);
     return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_scale(scalar, is_complex, factor, di, dout, n, st); });
 }
 int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "absFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
@@ -1469,6 +1506,7 @@ int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *out_dev, s
 }
 int pcx_abs(int scalar, int is_complex, const void *in, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "absFactory: unsupported type (scalar %d)", scalar);
     const size_t sb = (size_t)scalar_bytes(scalar);
     return run_host_map(in, out, n * (is_complex ? 2 : 1) * sb, n * sb,
@@ -1476,6 +1514,7 @@ int pcx_abs(int scalar, int is_complex, const void *in, void *out, size_t n)
 }
 int pcx_conj_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "conjugateFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
@@ -1483,6 +1522,7 @@ int pcx_conj_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *
 }
 int pcx_conj(int scalar, const void *in, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "conjugateFactory: unsupported type (scalar %d)", scalar);
     const size_t b = n * 2 * (size_t)scalar_bytes(scalar);
     return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_conj(scalar, di, dout, n, st); });
@@ -1490,6 +1530,7 @@ int pcx_conj(int scalar, const void *in, void *out, size_t n)
 
 int pcx_angle_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "angleFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
@@ -1497,6 +1538,7 @@ int pcx_angle_dev(int scalar, const void *in_dev, void *out_dev, size_t n, void 
 }
 int pcx_angle(int scalar, const void *in, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "angleFactory: unsupported type (scalar %d)", scalar);
     const size_t sb = (size_t)scalar_bytes(scalar);
     return run_host_map(in, out, n * 2 * sb, n * sb, [&](const void *di, void *dout, hipStream_t st) { return launch_angle(scalar, di, dout, n, st); });
@@ -1504,6 +1546,7 @@ int pcx_angle(int scalar, const void *in, void *out, size_t n)
 
 int pcx_arith_dev(int scalar, int is_complex, int op, const void *in0_dev, const void *in1_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_arith_scalar(scalar) && op >= PCX_ARITH_ADD && op <= PCX_ARITH_DIV,
                   "arithmeticFactory: unsupported args (scalar %d, op %d)", scalar, op);
     if (n == 0) return PCX_OK;
@@ -1512,6 +1555,7 @@ int pcx_arith_dev(int scalar, int is_complex, int op, const void *in0_dev, const
 }
 int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *in1, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_arith_scalar(scalar) && op >= PCX_ARITH_ADD && op <= PCX_ARITH_DIV,
                   "arithmeticFactory: unsupported args (scalar %d, op %d)", scalar, op);
     if (n == 0) return PCX_OK;
@@ -1528,6 +1572,7 @@ int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *i
 }
 int pcx_split_complex_dev(int scalar, const void *in_dev, void *re_dev, void *im_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "splitComplexFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && re_dev && im_dev, "null buffer");
@@ -1535,6 +1580,7 @@ int pcx_split_complex_dev(int scalar, const void *in_dev, void *re_dev, void *im
 }
 int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "splitComplexFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in && re && im, "null buffer");
@@ -1551,6 +1597,7 @@ int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n)
 }
 int pcx_combine_complex_dev(int scalar, const void *re_dev, const void *im_dev, void *out_dev, size_t n, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "combineComplexFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(re_dev && im_dev && out_dev, "null buffer");
@@ -1558,6 +1605,7 @@ int pcx_combine_complex_dev(int scalar, const void *re_dev, const void *im_dev, 
 }
 int pcx_combine_complex(int scalar, const void *re, const void *im, void *out, size_t n)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "combineComplexFactory: unsupported type (scalar %d)", scalar);
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(re && im && out, "null buffer");
@@ -1687,6 +1735,7 @@ int pcx_fmchain_last_algo(const pcx_fmchain *h) { return h ? h->last_algo : PCX_
 int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                             size_t *consumed, size_t *produced, void *stream)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
     DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
@@ -1733,6 +1782,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
 }
 int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *out, size_t out_cap, size_t *consumed, size_t *produced)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
     DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -83,6 +84,19 @@ struct PinBuf {
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
 };
+// ROCTx range around a C-ABI entry point while pcx_trace(1) is in force (pcx_api.hip); one relaxed load otherwise
+extern std::atomic<int> g_trace_on;
+extern int (*g_roctx_push)(const char *);
+extern int (*g_roctx_pop)();
+struct TraceRange {
+    bool on;
+    explicit TraceRange(const char *name) : on(g_trace_on.load(std::memory_order_relaxed) != 0) { if (on) (void)g_roctx_push(name); }
+    ~TraceRange() { if (on) (void)g_roctx_pop(); }
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+};
+#define PCX_TRACE() ::pcx::TraceRange pcx_trace_range_(__func__)
+
 // device-visible alias of a host pointer when it is page-locked (pcx_api.hip), else nullptr
 void *device_alias(const void *p);
 // staging pair of one direction of a host-pointer call (pcx_api.hip stage_in / stage_out_*)

@@ -302,6 +302,7 @@ int pcx_shard_buffers(pcx_shard *s, int g, void **in_dev, void **out_dev, void *
 // shard's own, copied by the CPU -- the library never hands a pageable pointer to hipMemcpyAsync (profiles/r02/contention.md).
 int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(s && host_stream, "null argument");
     PCX_CHECK_ARG(s->C, "pcx_shard_scatter: call pcx_shard_configure first");
     PCX_CHECK_ARG(elems == s->K - 1 + (size_t)s->G * s->C, "pcx_shard_scatter: %zu elements, expected K-1 + shards*C = %zu", elems,
@@ -335,6 +336,7 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
 
 int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(s && host_out, "null argument");
     PCX_CHECK_ARG(s->C && elems == (size_t)s->G * s->C, "pcx_shard_gather: %zu elements, expected shards*C = %zu", elems, (size_t)s->G * s->C);
     DeviceGuard guard;
@@ -382,6 +384,7 @@ static int shard_run(pcx_shard *s, int g, size_t first_out, size_t n_out)
 
 int pcx_shard_step(pcx_shard *s)
 {
+    PCX_TRACE();
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_ARG(s->C, "pcx_shard_step: call pcx_shard_configure first");
     DeviceGuard guard;

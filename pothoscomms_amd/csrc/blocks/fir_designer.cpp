@@ -8,19 +8,21 @@
 // messages), backwards-compatible filter-type aliases, gain-then-window order and signal payload types
 // (std::vector<double>, or std::vector<std::complex<double>> for the COMPLEX_* band types) as the reference.
 //
-// What is built: the closed-form prototypes -- filter types "SINC", "GAUSSIAN" (the reference's constructor default, so a
-// default-constructed designer activates and emits taps as the reference's does), "RAISED_COSINE" and
-// "ROOT_RAISED_COSINE" -- for all six band types, with every window the reference lists.  The reference delegates the
+// What is built: every filter type the reference lists -- "SINC", "GAUSSIAN" (the reference's constructor default, so a
+// default-constructed designer activates and emits taps as the reference's does), "RAISED_COSINE", "ROOT_RAISED_COSINE",
+// "MAXFLAT" and "REMEZ" -- for all six band types, with every window the reference lists.  The reference delegates the
 // arithmetic to spuce (design_fir / design_complex_fir / design_window), an un-vendored dependency that is absent from
 // the reference tree, so tap VALUES follow the textbook definitions below and are "parity unpinned" against spuce; what
 // is pinned is the reference's own acceptance test (TestFIRDesigner.cpp:110-135: pass points above -30 dB, stop points
 // below -80 dB of an impulse's spectrum), the windows against scipy.signal.windows, and the defining properties of each
 // prototype (tests/test_designer_cpu.py: Nyquist zero crossings of the raised cosine, the root raised cosine convolved
-// with itself, the Gaussian's -3 dB point).  The iterative designs (MAXFLAT, REMEZ) throw InvalidArgumentException at
-// recalculation: nothing is silently substituted.
+// with itself, the Gaussian's -3 dB point).  "REMEZ" is a Parks-McClellan exchange of our own (checked against
+// scipy.signal.remez: the minimax solution is unique) with the pass band ending at the lower frequency and the stop band
+// starting one transition bandwidth above it; "MAXFLAT" is Herrmann's maximally flat design (odd tap counts).
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -169,12 +171,154 @@ std::vector<double> gaussianLowPass(size_t n, double bt)
     }
     return h;
 }
-// the low-pass prototype of a filter type at cut-off fc
-std::vector<double> prototypeLowPass(const std::string &type, size_t n, double fc, double alpha)
+// amplitude samples A(k/n) of a symmetric n-tap filter -> its taps.  A(f), f in [0, 1/2], is the zero-phase response;
+// beyond 1/2 it continues as A(1-f) for odd n and -A(1-f) for even n (half-sample delay), which makes the sum real.
+template <typename F>
+std::vector<double> tapsFromAmplitude(size_t n, F &&amp)
+{
+    std::vector<double> a(n);
+    for (size_t k = 0; k < n; k++) {
+        const double f = (double)k / (double)n;
+        a[k] = f <= 0.5 ? amp(f) : ((n & 1) ? amp(1.0 - f) : -amp(1.0 - f));
+    }
+    std::vector<double> h(n);
+    const double c = 0.5 * (double)(n - 1);
+    for (size_t i = 0; i < n; i++) {
+        double acc = 0;
+        for (size_t k = 0; k < n; k++) acc += a[k] * std::cos(2.0 * kPi * (double)k * ((double)i - c) / (double)n);
+        h[i] = acc / (double)n;
+    }
+    return h;
+}
+
+// Maximally flat (Herrmann) low-pass, odd n = 2M+1:  A(w) = cos^2K(w/2) sum_{k<L} C(K+k-1, k) sin^2k(w/2),  K + L - 1 = M:
+// 2K zeros at w = pi, 2L-1 vanishing derivatives at w = 0, monotone in between.  K follows the half-amplitude frequency
+// fc (cycles/sample): K = round((M+1) cos^2(pi fc)), kept inside 1..M.  Every term is positive: no cancellation.
+std::vector<double> maxflatLowPass(size_t n, double fc)
+{
+    if ((n & 1) == 0 || n < 3) throw std::runtime_error("maximally flat design needs an odd number of taps, at least 3");
+    const long M = (long)(n - 1) / 2;
+    const double cc = std::cos(kPi * fc);
+    long K = std::lround((double)(M + 1) * cc * cc);
+    K = std::max(1L, std::min(M, K));
+    const long L = M + 1 - K;
+    return tapsFromAmplitude(n, [&](double f) {
+        const double c2 = std::cos(kPi * f) * std::cos(kPi * f), s2 = 1.0 - c2;
+        double sum = 0.0, term = 1.0;                     // term = C(K+k-1, k) s2^k
+        for (long k = 0; k < L; k++) {
+            sum += term;
+            term *= s2 * (double)(K + k) / (double)(k + 1);
+        }
+        return std::pow(c2, (double)K) * sum;
+    });
+}
+
+// Equiripple (Parks-McClellan) low-pass: n symmetric taps, pass band [0, fp], stop band [fs, 1/2] (cycles/sample), error
+// weight 1 in the pass band and `wstop` in the stop band.  The Remez exchange on a dense grid with barycentric Lagrange
+// interpolation in x = cos(2 pi f); even n (half-sample delay) is designed as cos(pi f) times a cosine polynomial.
+std::vector<double> remezLowPass(size_t n, double fp, double fs, double wstop)
+{
+    if (!(fp > 0.0 && fs > fp && fs < 0.5)) throw std::runtime_error("remez band edges outside 0 < pass < stop < 1/2");
+    if (!(wstop > 0.0)) throw std::runtime_error("remez weight must be positive");
+    const bool odd = (n & 1) != 0;
+    const size_t r = odd ? (n + 1) / 2 : n / 2;           // cosine terms of the polynomial part
+    if (r < 2) throw std::runtime_error("remez needs at least 3 taps");
+    const double delf = 0.5 / (16.0 * (double)r);
+    std::vector<double> gf, D, W;
+    auto band = [&](double lo, double hi, double des, double wt) {
+        if (!odd && hi > 0.5 - delf) hi = 0.5 - delf;     // cos(pi f) vanishes at 1/2
+        const size_t k = (size_t)std::max(1.0, std::floor((hi - lo) / delf + 0.5));
+        for (size_t i = 0; i <= k; i++) {
+            const double f = i == k ? hi : lo + (double)i * delf;
+            const double q = odd ? 1.0 : std::cos(kPi * f);
+            gf.push_back(f); D.push_back(des / q); W.push_back(wt * q);
+        }
+    };
+    band(0.0, fp, 1.0, 1.0);
+    band(fs, 0.5, 0.0, wstop);
+    const size_t G = gf.size();
+    if (G < r + 1) throw std::runtime_error("remez grid too coarse for the bands");
+    std::vector<double> x(G), E(G);
+    for (size_t g = 0; g < G; g++) x[g] = std::cos(2.0 * kPi * gf[g]);
+    std::vector<size_t> ext(r + 1);
+    for (size_t i = 0; i <= r; i++) ext[i] = i * (G - 1) / r;
+    std::vector<double> bw(r + 1), cv(r + 1);
+    double delta = 0.0;
+    auto fit = [&]() {                                    // delta and the node values of the current extremal set
+        for (size_t i = 0; i <= r; i++) {
+            double p = 1.0;
+            for (size_t j = 0; j <= r; j++)
+                if (j != i) p *= 2.0 * (x[ext[i]] - x[ext[j]]);
+            bw[i] = 1.0 / p;
+        }
+        double num = 0.0, den = 0.0, sgn = 1.0;
+        for (size_t i = 0; i <= r; i++, sgn = -sgn) {
+            num += bw[i] * D[ext[i]];
+            den += bw[i] * sgn / W[ext[i]];
+        }
+        delta = num / den;
+        sgn = 1.0;
+        for (size_t i = 0; i <= r; i++, sgn = -sgn) cv[i] = D[ext[i]] - sgn * delta / W[ext[i]];
+    };
+    auto eval = [&](double xv) {                          // the interpolating polynomial at x
+        double num = 0.0, den = 0.0;
+        for (size_t i = 0; i <= r; i++) {
+            const double d = xv - x[ext[i]];
+            if (std::fabs(d) < 1e-15) return cv[i];
+            num += bw[i] * cv[i] / d;
+            den += bw[i] / d;
+        }
+        return num / den;
+    };
+    for (int iter = 0; iter < 60; iter++) {
+        fit();
+        for (size_t g = 0; g < G; g++) E[g] = W[g] * (D[g] - eval(x[g]));
+        // local extrema of the error (band ends count), then strict alternation keeping the larger of equal-signed neighbours
+        std::vector<size_t> cand;
+        for (size_t g = 0; g < G; g++) {
+            const double e = E[g], l = g > 0 ? E[g - 1] : (e > 0 ? -1e300 : 1e300), rr = g + 1 < G ? E[g + 1] : (e > 0 ? -1e300 : 1e300);
+            const bool peak = e > 0 ? (e >= l && e >= rr) : (e <= l && e <= rr);
+            if (!peak || e == 0.0) continue;
+            if (!cand.empty() && (E[cand.back()] > 0) == (e > 0)) {
+                if (std::fabs(e) > std::fabs(E[cand.back()])) cand.back() = g;
+            } else {
+                cand.push_back(g);
+            }
+        }
+        while (cand.size() > r + 1) {                     // too many: the weaker end goes
+            if (std::fabs(E[cand.front()]) < std::fabs(E[cand.back()])) cand.erase(cand.begin());
+            else cand.pop_back();
+        }
+        if (cand.size() < r + 1) throw std::runtime_error("remez exchange lost an extremum (specification too loose for the tap count?)");
+        const bool same = std::equal(cand.begin(), cand.end(), ext.begin());
+        ext = cand;
+        if (same) break;
+    }
+    fit();
+    return tapsFromAmplitude(n, [&](double f) {
+        const double q = odd ? 1.0 : std::cos(kPi * f);
+        return q == 0.0 ? 0.0 : q * eval(std::cos(2.0 * kPi * f));
+    });
+}
+// spuce's remez_estimate_* as FIRDesigner.cpp:423-438 uses them (spuce is absent: the usual Herrmann / Kaiser estimates)
+double rippleOfPassDB(double passDB) { const double g = std::pow(10.0, passDB / 20.0); return (g - 1.0) / (g + 1.0); }
+double rippleOfStopDB(double stopDB) { return std::pow(10.0, -stopDB / 20.0); }
+double remezEstimateWeight(double passDB, double stopDB) { return rippleOfPassDB(passDB) / rippleOfStopDB(stopDB); }
+size_t remezEstimateNumTaps(double transBw, double passDB, double stopDB)
+{
+    const double d = -20.0 * std::log10(std::sqrt(rippleOfPassDB(passDB) * rippleOfStopDB(stopDB)));
+    return (size_t)std::max(1.0, std::ceil((d - 13.0) / (14.6 * transBw) + 1.0));
+}
+
+// the low-pass prototype of a filter type at cut-off fc.  REMEZ: pass band to fc, stop band from fc + alpha (alpha = the
+// transition bandwidth in cycles/sample), stop-band weight `weight`; MAXFLAT: half-amplitude point at fc.
+std::vector<double> prototypeLowPass(const std::string &type, size_t n, double fc, double alpha, double weight)
 {
     if (type == "SINC") return sincLowPass(n, fc);
     if (type == "GAUSSIAN") return gaussianLowPass(n, fc);
     if (type == "RAISED_COSINE") return raisedCosineLowPass(n, fc, alpha);
+    if (type == "MAXFLAT") return maxflatLowPass(n, fc);
+    if (type == "REMEZ") return remezLowPass(n, fc, fc + alpha, weight);
     return rootRaisedCosineLowPass(n, fc, alpha);
 }
 
@@ -212,6 +356,7 @@ public:
         this->registerCall(this, "stopDB", &FIRDesigner::stopDB);
         this->registerCall(this, "setPassDB", &FIRDesigner::setPassDB);
         this->registerCall(this, "passDB", &FIRDesigner::passDB);
+        this->registerCall(this, "lastWarning", &FIRDesigner::lastWarning);   // (ours: the text the reference logs)
         this->registerCall(this, "setGain", &FIRDesigner::setGain);
         this->registerCall(this, "gain", &FIRDesigner::gain);
         this->registerSignal("tapsChanged");
@@ -258,6 +403,7 @@ public:
     double alpha() const { return _alpha; }
     void setPassDB(const double w) { _passDB = w; this->recalculate(); }
     double passDB() const { return _passDB; }
+    std::string lastWarning() const { return _lastWarning; }
     void setStopDB(const double w) { _stopDB = w; this->recalculate(); }
     double stopDB() const { return _stopDB; }
     void setGain(const double gain) { _gain = gain; this->recalculate(); }
@@ -272,6 +418,7 @@ private:
     std::vector<double> _windowArgs;
     double _gain, _sampRate, _freqLower, _freqUpper, _transBw, _alpha, _stopDB, _passDB;
     size_t _numTaps;
+    std::string _lastWarning;    // what the reference sends to its logger (FIRDesigner.cpp:429-437): kept for the caller to read
 };
 
 void FIRDesigner::recalculate()
@@ -303,11 +450,23 @@ void FIRDesigner::recalculate()
         if (_passDB <= 0) throw Exception("FIRDesigner()", "Passband Attenuation must be > 0");
         if (_stopDB <= 0) throw Exception("FIRDesigner()", "Stopband Attenuation must be > 0");
     }
-    const bool closedForm = _filterType == "SINC" || _filterType == "GAUSSIAN" || _filterType == "RAISED_COSINE" || _filterType == "ROOT_RAISED_COSINE";
-    if (!closedForm)
-        throw InvalidArgumentException("Problem with creating taps for FIRDesigner(" + _filterType + "/" + _bandType + "):" +
-                                           " this build designs the closed-form prototypes (SINC, GAUSSIAN, RAISED_COSINE, ROOT_RAISED_COSINE) only",
-                                       "not implemented");
+    const bool known = _filterType == "SINC" || _filterType == "GAUSSIAN" || _filterType == "RAISED_COSINE" || _filterType == "ROOT_RAISED_COSINE" ||
+                       _filterType == "MAXFLAT" || _filterType == "REMEZ";
+    if (!known)
+        throw InvalidArgumentException("Problem with creating taps for FIRDesigner(" + _filterType + "/" + _bandType + "): unknown filter type",
+                                       "problem with input parameters?");
+    double alpha = _alpha, weight = 1.0;
+    if (_filterType == "REMEZ") {
+        // FIRDesigner.cpp:421-439: alpha becomes the transition bandwidth, the weight follows the two ripples, and a tap
+        // count below the estimate is reported, not refused
+        alpha = _transBw / _sampRate;
+        const size_t est = remezEstimateNumTaps(alpha, _passDB, _stopDB);
+        if (est > _numTaps)
+            _lastWarning = "Remez order not large enough to meet specification: increase filter order to " + std::to_string(est) + " taps";
+        else
+            _lastWarning.clear();
+        weight = remezEstimateWeight(_passDB, _stopDB);
+    }
     if ((_filterType == "RAISED_COSINE" || _filterType == "ROOT_RAISED_COSINE") && !(_alpha >= 0.0 && _alpha <= 1.0))
         throw InvalidArgumentException("Problem with creating taps for FIRDesigner(" + _filterType + "/" + _bandType + "): alpha outside 0.0 to 1.0",
                                        "problem with input parameters?");
@@ -320,30 +479,36 @@ void FIRDesigner::recalculate()
     const double c = 0.5 * (double)(n - 1);
     std::vector<double> taps;
     std::vector<std::complex<double>> complexTaps;
-    if (_bandType == "LOW_PASS") {
-        taps = prototypeLowPass(_filterType, n, fl, _alpha);
-    } else if (_bandType == "HIGH_PASS") {
-        // low-pass of width 1/2 - fl moved to the Nyquist frequency
-        taps = prototypeLowPass(_filterType, n, 0.5 - fl, _alpha);
-        for (size_t i = 0; i < n; i++) taps[i] *= std::cos(kPi * ((double)i - c));
-    } else if (!isComplex) {
-        // low-pass of half the band's width moved to +- the band centre; the stop form is its complement
-        taps = prototypeLowPass(_filterType, n, 0.5 * (fu - fl), _alpha);
-        const double f0 = 0.5 * (fu + fl);
-        for (size_t i = 0; i < n; i++) taps[i] *= 2.0 * std::cos(2.0 * kPi * f0 * ((double)i - c));
-        if (isStop) {
-            for (size_t i = 0; i < n; i++) taps[i] = -taps[i];
-            taps[n / 2] += 1.0;
+    try {
+        if (_bandType == "LOW_PASS") {
+            taps = prototypeLowPass(_filterType, n, fl, alpha, weight);
+        } else if (_bandType == "HIGH_PASS") {
+            // low-pass of width 1/2 - fl moved to the Nyquist frequency
+            taps = prototypeLowPass(_filterType, n, 0.5 - fl, alpha, weight);
+            for (size_t i = 0; i < n; i++) taps[i] *= std::cos(kPi * ((double)i - c));
+        } else if (!isComplex) {
+            // low-pass of half the band's width moved to +- the band centre; the stop form is its complement
+            taps = prototypeLowPass(_filterType, n, 0.5 * (fu - fl), alpha, weight);
+            const double f0 = 0.5 * (fu + fl);
+            for (size_t i = 0; i < n; i++) taps[i] *= 2.0 * std::cos(2.0 * kPi * f0 * ((double)i - c));
+            if (isStop) {
+                for (size_t i = 0; i < n; i++) taps[i] = -taps[i];
+                taps[n / 2] += 1.0;
+            }
+        } else {
+            const std::vector<double> lp = prototypeLowPass(_filterType, n, 0.5 * (fu - fl), alpha, weight);
+            const double f0 = 0.5 * (fu + fl);
+            complexTaps.resize(n);
+            for (size_t i = 0; i < n; i++) complexTaps[i] = lp[i] * std::polar(1.0, 2.0 * kPi * f0 * ((double)i - c));
+            if (isStop) {
+                for (size_t i = 0; i < n; i++) complexTaps[i] = -complexTaps[i];
+                complexTaps[n / 2] += 1.0;
+            }
         }
-    } else {
-        const std::vector<double> lp = prototypeLowPass(_filterType, n, 0.5 * (fu - fl), _alpha);
-        const double f0 = 0.5 * (fu + fl);
-        complexTaps.resize(n);
-        for (size_t i = 0; i < n; i++) complexTaps[i] = lp[i] * std::polar(1.0, 2.0 * kPi * f0 * ((double)i - c));
-        if (isStop) {
-            for (size_t i = 0; i < n; i++) complexTaps[i] = -complexTaps[i];
-            complexTaps[n / 2] += 1.0;
-        }
+    } catch (const std::runtime_error &error) {
+        // FIRDesigner.cpp:455-457
+        throw InvalidArgumentException("Problem with creating taps for FIRDesigner(" + _filterType + "/" + _bandType + "):" + error.what(),
+                                       "problem with input parameters?");
     }
 
     // gain, then the window (FIRDesigner.cpp:455-471)

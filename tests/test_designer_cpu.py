@@ -79,8 +79,7 @@ def test_nothing_is_emitted_before_activation_then_every_change_emits():
     ("setFrequencyUpper", 0.5, "BAND_PASS", "upper frequency above Nyquist range"),
     ("setFrequencyUpper", 0.05, "BAND_PASS", "upper frequency <= lower frequency"),
     ("setWindowType", "nuttall", "LOW_PASS", "unknown window type"),
-    ("setFilterType", "REMEZ", "LOW_PASS", "closed-form prototypes"),
-    ("setFilterType", "MAXFLAT", "HIGH_PASS", "closed-form prototypes"),
+    ("setFilterType", "ELLIPTIC", "LOW_PASS", "unknown filter type"),
     ("setAlpha", 1.5, "LOW_PASS", None),
     ("setBandType", "NOTCH", "LOW_PASS", "unknown band type"),
 ])
@@ -110,12 +109,114 @@ def test_default_constructed_designer_activates_and_emits():
     assert len(t) == 51 and np.all(np.isfinite(t)) and np.allclose(t, t[::-1]) and t[25] == t.max() > 0
 
 
-def test_iterative_designs_fail_loudly():
-    des, _ = _designer_and_filter("LOW_PASS")
-    des.call("setFilterType", "SINC"); des.activate()
-    for ft in ("REMEZ", "MAXFLAT"):
-        with pytest.raises(_lib.PcxError, match="closed-form prototypes"):
-            des.call("setFilterType", ft)
+def _remez(ntaps, fl, tbw, pass_db=0.1, stop_db=60.0, band="LOW_PASS", rate=1.0, fu=None):
+    des, flt = _designer_and_filter(band)
+    des.call("setSampleRate", rate); des.call("setFilterType", "REMEZ"); des.call("setBandType", band)
+    des.call("setWindowType", "rectangular"); des.call("setNumTaps", ntaps)
+    des.call("setFrequencyLower", fl)
+    if fu is not None:
+        des.call("setFrequencyUpper", fu)
+    des.call("setBandwidthTrans", tbw); des.call("setPassDB", pass_db); des.call("setStopDB", stop_db)
+    des.activate()
+    return des, np.asarray(_taps(flt, band.startswith("COMPLEX")))
+
+
+def _ripples(pass_db, stop_db):
+    g = 10 ** (pass_db / 20)
+    return (g - 1) / (g + 1), 10 ** (-stop_db / 20)
+
+
+@pytest.mark.parametrize("ntaps,fp,tbw,pass_db,stop_db", [
+    (51, 0.1, 0.05, 0.1, 60.0), (50, 0.1, 0.05, 0.1, 60.0), (101, 0.2, 0.03, 0.5, 80.0), (33, 0.25, 0.1, 1.0, 40.0),
+    (201, 0.05, 0.02, 0.1, 70.0), (128, 0.3, 0.04, 0.2, 50.0), (7, 0.1, 0.2, 1.0, 20.0),
+])
+def test_remez_is_the_minimax_design(ntaps, fp, tbw, pass_db, stop_db):
+    """filter type REMEZ (FIRDesigner.cpp:420-439 hands spuce the transition bandwidth as alpha and the ripple ratio as the
+    weight): the Parks-McClellan solution is unique, so the taps must be scipy.signal.remez's for the same bands and weights
+    -- pass band [0, lower frequency], stop band [lower frequency + transition bandwidth, 1/2] -- and the weighted error
+    must be equiripple"""
+    from scipy import signal
+    des, taps = _remez(ntaps, fp, tbw, pass_db, stop_db)
+    dp, ds = _ripples(pass_db, stop_db)
+    want = signal.remez(ntaps, [0, fp, fp + tbw, 0.5], [1, 0], weight=[1, dp / ds], fs=1.0, maxiter=200, grid_density=16)   # the grid both use: 16 points per cosine term
+    assert len(taps) == ntaps and np.allclose(taps, taps[::-1], rtol=0, atol=1e-14)
+    assert np.max(np.abs(taps - want)) <= 2e-6 * np.max(np.abs(want))
+    # equiripple: the peak weighted error of the pass band equals that of the stop band
+    f = np.linspace(0, 0.5, 8192)
+    H = np.abs(np.array([np.sum(taps * np.exp(-2j * np.pi * x * np.arange(ntaps))) for x in f]))
+    ep = np.max(np.abs(H[f <= fp] - 1.0))
+    es = np.max(H[f >= fp + tbw]) * (dp / ds)
+    assert abs(ep - es) <= 0.03 * max(ep, es)
+
+
+def test_remez_warns_when_the_order_is_too_small_and_checks_its_parameters():
+    des, taps = _remez(21, 0.1, 0.01, 0.1, 80.0)                 # far too few taps for a 1 % transition at 80 dB
+    assert "Remez order not large enough" in des.call("lastWarning") and len(taps) == 21
+    des.call("setNumTaps", 801)
+    assert des.call("lastWarning") == ""
+    for setter, msg in (("setBandwidthTrans", "Transition Bandwidth must be > 0"), ("setPassDB", "Passband Attenuation must be > 0"),
+                        ("setStopDB", "Stopband Attenuation must be > 0")):
+        d2, _ = _remez(51, 0.1, 0.05)
+        with pytest.raises(_lib.PcxError, match=msg):
+            d2.call(setter, 0.0)
+    # stop edge beyond Nyquist: spuce's runtime_error becomes InvalidArgumentException (FIRDesigner.cpp:455-457)
+    d3, _ = _remez(51, 0.1, 0.05)
+    with pytest.raises(_lib.PcxError, match="Problem with creating taps for FIRDesigner\\(REMEZ/LOW_PASS\\)"):
+        d3.call("setFrequencyLower", 0.48)
+
+
+@pytest.mark.parametrize("band", ["HIGH_PASS", "BAND_PASS", "BAND_STOP", "COMPLEX_BAND_PASS", "COMPLEX_BAND_STOP"])
+def test_remez_band_types_meet_the_reference_test_points(band):
+    """TestFIRDesigner.cpp:137-230's acceptance points with filter type REMEZ: pass regions above -30 dB (and at unity), stop
+    regions below -60 dB (the requested stop-band attenuation)"""
+    rate, lo, hi = 1e6, 1.5e5, 3.0e5
+    des, taps = _remez(101, lo, rate / 20, 0.1, 60.0, band=band, rate=rate, fu=hi)
+    PASS, STOP = True, False
+    points = {
+        "HIGH_PASS": [(STOP, 0.0), (PASS, (lo + rate / 2) / 2)],
+        "BAND_PASS": [(STOP, 0.0), (PASS, (lo + hi) / 2), (STOP, (hi + rate / 2) / 2)],
+        "BAND_STOP": [(PASS, 0.0), (STOP, (lo + hi) / 2), (PASS, (hi + rate / 2) / 2)],
+        "COMPLEX_BAND_PASS": [(STOP, (lo - rate / 2) / 2), (PASS, (lo + hi) / 2), (STOP, (hi + rate / 2) / 2)],
+        "COMPLEX_BAND_STOP": [(PASS, (lo - rate / 2) / 2), (STOP, (lo + hi) / 2), (PASS, (hi + rate / 2) / 2)],
+    }[band]
+    for is_pass, f in points:
+        level = _response_db(taps, f / rate)
+        assert (abs(level) < 0.2) if is_pass else (level < -50.0), (band, f, level)
+
+
+@pytest.mark.parametrize("ntaps,fc", [(51, 0.1), (51, 0.25), (101, 0.2), (21, 0.35), (201, 0.05)])
+def test_maxflat_is_flat_at_both_ends_and_monotone(ntaps, fc):
+    """filter type MAXFLAT: unity with vanishing derivatives at DC, a zero of high order at Nyquist, monotone between, the
+    half-amplitude point within one design step of the requested frequency"""
+    des, flt = _designer_and_filter("LOW_PASS")
+    des.call("setFilterType", "MAXFLAT"); des.call("setWindowType", "rectangular"); des.call("setNumTaps", ntaps)
+    des.call("setFrequencyLower", fc); des.activate()
+    taps = np.asarray(_taps(flt, False))
+    assert len(taps) == ntaps and np.allclose(taps, taps[::-1], rtol=0, atol=1e-15)
+    f = np.linspace(0, 0.5, 4097)
+    c = (ntaps - 1) / 2
+    A = np.array([np.sum(taps * np.cos(2 * np.pi * x * (np.arange(ntaps) - c))) for x in f])     # zero-phase response
+    assert abs(A[0] - 1.0) < 1e-12 and abs(A[-1]) < 1e-12
+    assert np.all(np.diff(A) <= 1e-12) and np.all(A > -1e-12)
+    # the ORDER of the flatness: 1 - A ~ f^(2L) near DC and A ~ (1/2 - f)^(2K) near Nyquist, K + L - 1 = (ntaps - 1) / 2
+    M = (ntaps - 1) // 2
+    K = min(M, max(1, int(round((M + 1) * np.cos(np.pi * fc) ** 2))))
+    L = M + 1 - K
+    amp = lambda x: np.sum(taps * np.cos(2 * np.pi * x * (np.arange(ntaps) - c)))
+    f1 = f[np.argmax(1.0 - A > 1e-7)] / 2                                     # where the droop is about 1e-7 / 4^L ... still measurable
+    f1 = max(f1, 1e-4)
+    droop = lambda x: 1.0 - amp(x)
+    if droop(f1) > 1e-13:
+        assert abs(np.log2(droop(2 * f1) / droop(f1)) - 2 * L) < 0.35 * 2 * L + 0.5
+    g1 = (0.5 - f[::-1][np.argmax(A[::-1] > 1e-7)]) / 2
+    g1 = max(g1, 1e-4)
+    if amp(0.5 - g1) > 1e-13:
+        assert abs(np.log2(amp(0.5 - 2 * g1) / amp(0.5 - g1)) - 2 * K) < 0.35 * 2 * K + 0.5
+    half = f[np.argmin(np.abs(A - 0.5))]
+    assert abs(half - fc) <= 1.0 / (ntaps + 1) + 0.01
+    # even tap counts have no such design
+    with pytest.raises(_lib.PcxError, match="odd number of taps"):
+        des.call("setNumTaps", ntaps + 1)
 
 
 def _design(ftype, ntaps, fl, alpha=0.5, window="rectangular"):

@@ -333,7 +333,7 @@ def main():
         fft = device.Fft("complex_float32", 4096, False)
         units = nframes * 4096
         roof_bytes = 16.0 * units
-        kernel_name = "fft4096_kernel"
+        kernel_name = "fft_r16_kernel<12>"
 
         def step():
             fft.transform_dev(x, y, nframes)

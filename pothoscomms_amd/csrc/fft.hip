@@ -2,7 +2,9 @@
 //
 //   fft4096_kernel     complex_float32, numBins = 4096: radix-16 x 3 Stockham, one frame
 //                      per workgroup, registers + one padded LDS image (fft4096.hpp).
-//                      HBM-bound: 64 KiB of traffic per 245,760 flop frame.
+//                      HBM-bound: 64 KiB of traffic per 245,760 flop frame.  DIAGNOSTIC A/B ONLY
+//                      since round 2 (PCX_FFT4096_DEDICATED): the product runs 4096 bins on
+//                      fft_r16.hip's kernel, which measured 3-10 % faster.
 //   fft_pow2_kernel    complex_float32 / complex_float64, numBins = 2^k: Stockham
 //                      radix-4 passes (+ one radix-2 pass when k is odd), ping-pong LDS.
 //   fft_q15_kernel     complex_int16: the reference's fixed-point kiss_fft

@@ -1,6 +1,7 @@
 // fft_r16.hip -- complex_float32 FFT for every power-of-two numBins from 16 to 16384 on the
-// register-resident radix-16 Stockham pipeline of fft4096.hpp (which keeps its own kernel
-// for numBins = 4096).
+// register-resident radix-16 Stockham pipeline of fft4096.hpp -- including numBins = 4096 (BASELINE configs[2]): the
+// dedicated persistent kernel of fft.hip (register prefetch, dynamic dealing) measured 3-10 % slower than this one with
+// three frames per workgroup and is kept in the diagnostic library only (tools/ab_fft4096_family.sh).
 //
 // N = 16^A * R, R in {1, 2, 4, 8}: A radix-16 passes (sub-transform sizes Ns = 1, 16, 256) and,
 // when R > 1, one final radix-R pass.  Every lane holds 16 points of one frame, a frame takes
@@ -233,9 +234,12 @@ int launch_r16(const void *in, void *out, size_t nframes, bool inverse, const vo
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
-    // several workgroups queued per slot: the dispatcher balances the CUs' unequal rates (pcx_internal.hpp persistent_grid).  Measured
-    // (tools/sweep_fft.py, PCX_OVERSUB A/B): +5..10 % at 4-8 for 64 ... 8192 bins (1024: 355 -> 393 Gsamples/s), -7..-11 % at 16384
-    const unsigned grid = persistent_grid(ngroups, 256 * per_cu, LOG2N <= 10 ? 8 : LOG2N <= 13 ? 4 : 1);
+    // workgroups of 1-3 groups each, whatever the call size (pcx_internal.hpp rounds_grid; measured per size at 64 Mi and 256 Mi
+    // samples per launch, run-to-run noise of a few per cent: 1 group per workgroup to 64 bins, 2 to 512, 3 from 1024); 16384 bins (16 waves per frame, one
+    // frame per CU) stays on equal shares over the resident slots: -7..-17 % with anything queued behind them.
+    // PCX_OVERSUB (diagnostic library) brings the fixed-factor grid back for A/B.
+    const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 || LOG2N >= 14 ? persistent_grid(ngroups, 256 * per_cu, 1)
+                                                                          : rounds_grid(ngroups, 256 * per_cu, LOG2N <= 6 ? 1 : LOG2N <= 9 ? 2 : 3);
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::THREADS), lds, st, (const float2 *)in, (float2 *)out, nframes, (const float2 *)tw);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
@@ -262,6 +266,7 @@ int launch_fft_r16_cf32(const void *in, void *out, int log2n, size_t nframes, bo
     case 9: return launch_r16<9>(in, out, nframes, inverse, tw, st);
     case 10: return launch_r16<10>(in, out, nframes, inverse, tw, st);
     case 11: return launch_r16<11>(in, out, nframes, inverse, tw, st);
+    case 12: return launch_r16<12>(in, out, nframes, inverse, tw, st);
     case 13: return launch_r16<13>(in, out, nframes, inverse, tw, st);
     case 14: return launch_r16<14>(in, out, nframes, inverse, tw, st);
     }

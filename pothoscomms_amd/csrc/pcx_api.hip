@@ -1276,7 +1276,12 @@ static int fft_transform_batch(pcx_fft *h, const void *in_dev, void *out_dev, si
         if (h->scalar == PCX_I16) return launch_fft_q15_one(in_dev, out_dev, nframes, st);
         PCX_HIP(hipMemcpyAsync(out_dev, in_dev, nframes * 2 * (size_t)scalar_bytes(h->scalar), hipMemcpyDeviceToDevice, st));
         return PCX_OK;
-    case pcx_fft::R16_4096: return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, h->sched.p, st);
+    case pcx_fft::R16_4096:
+        // the radix-16 family's kernel at 12 bits: no register prefetch, no dealer, four frames per workgroup and the hardware
+        // dispatcher doing the balancing -- 0.74 -> 0.78 of the HBM peak on 65,536 frames against the dedicated persistent kernel
+        // (tools/ab_fft4096_family.sh, profiles/r02/ab_fft4096_family.txt), which stays in the diagnostic library for that A/B
+        if (PCX_ENV_SET("PCX_FFT4096_DEDICATED")) return launch_fft4096_cf32(in_dev, out_dev, nframes, h->inverse != 0, h->tw.p, h->sched.p, st);
+        return launch_fft_r16_cf32(in_dev, out_dev, 12, nframes, h->inverse != 0, h->tw.p, st);
     case pcx_fft::R16:
         return h->scalar == PCX_F64 ? launch_fft_r16_cf64(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st)
                                     : launch_fft_r16_cf32(in_dev, out_dev, h->log2n, nframes, h->inverse != 0, h->tw.p, st);

@@ -156,6 +156,22 @@ inline unsigned persistent_grid(size_t units, unsigned slots, unsigned oversub =
     return (unsigned)((units + rounds - 1) / rounds);
 }
 
+// grid of a kernel whose workgroups should each walk about `rounds` work items, never fewer workgroups than the resident
+// `slots`.  The radix-16 FFT family runs best at 2-4 items per workgroup WHATEVER the size of the call (tools/
+// ab_fft_family_oversub.sh, profiles/r02/ab_fft_family_oversub.txt: enough to amortise the per-workgroup tables, short enough
+// for the dispatcher to even out the CUs' unequal rates) -- a fixed oversubscription factor is right for one call size only.
+// PCX_ROUNDS (diagnostic library only) overrides for A/B.
+inline unsigned rounds_grid(size_t units, unsigned slots, unsigned rounds)
+{
+    const long forced = PCX_ENV_INT("PCX_ROUNDS", 0);
+    if (forced > 0) rounds = (unsigned)forced;
+    if (units <= slots) return (unsigned)(units ? units : 1);
+    size_t g = (units + rounds - 1) / rounds;
+    if (g < slots) return persistent_grid(units, slots);
+    const size_t cap = (size_t)1 << 30;
+    return (unsigned)(g < cap ? g : cap);
+}
+
 // ---- kernel launchers implemented in the .hip files ----
 int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n, hipStream_t st);
 int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st);

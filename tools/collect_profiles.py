@@ -11,7 +11,7 @@ def newest(pattern):
     return fs[-1] if fs else None
 
 for name in ("bench_default.json", "bench_other_workloads.jsonl", "bench_driver_flags.json", "bench_two_ranks_one_gpu_gloo.json",
-             "ab_sched.txt", "ab_oversub.txt", "shard_probe.txt", "host_path.txt", "two_blocks.txt", "chain_path.txt", "pcie_lab.txt", "ubench_roofs.txt",
+             "ab_sched.txt", "ab_oversub.txt", "ab_fft4096_family.txt", "ab_fft_family_rounds.txt", "shard_probe.txt", "host_path.txt", "two_blocks.txt", "chain_path.txt", "pcie_lab.txt", "ubench_roofs.txt",
              "ols_lab_summary.txt", "sweep_fir_taps.txt", "sweep_elementwise.txt", "sweep_fft_sizes.txt", "sweep_fft_f64.txt",
              "sweep_fft_mixed.txt", "sweep_fir_f64.txt", "real_f32_fir.txt"):
     if os.path.exists(os.path.join(src, name)):

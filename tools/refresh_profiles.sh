@@ -8,10 +8,12 @@ for w in fft4096 fmchain rotate direct255 decim8 interp4 fir255_i16; do python b
 PCX_BENCH_BACKEND=gloo python bench.py --gpus 2 --shard 33554432 --steps 50 --warmup 10 --no-cpu > $O/bench_two_ranks_one_gpu_gloo.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -- python3 bench.py --steps 2000 --warmup 50 --no-cpu > $O/bench_kt.log 2>&1
 bash tools/prof.sh fir255 $O/fir255 ols4096 > /dev/null 2>&1
-bash tools/prof.sh fft4096 $O/fft4096 fft4096 > /dev/null 2>&1
+bash tools/prof.sh fft4096 $O/fft4096 fft_r16 > /dev/null 2>&1
 bash tools/prof.sh fmchain $O/fmchain fmchain > /dev/null 2>&1
 bash tools/ab_sched.sh > $O/ab_sched.txt 2>/dev/null
 bash tools/ab_oversub.sh > $O/ab_oversub.txt 2>/dev/null
+bash tools/ab_fft4096_family.sh 2>/dev/null | grep -v amdgpu.ids > $O/ab_fft4096_family.txt
+bash tools/ab_fft_family_oversub.sh > $O/ab_fft_family_rounds.txt 2>/dev/null
 python tools/shard_probe.py > $O/shard_probe.txt 2>/dev/null
 python tools/host_path.py > $O/host_path.txt 2>/dev/null
 python tools/two_blocks.py > $O/two_blocks.txt 2>/dev/null

@@ -270,7 +270,9 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     const unsigned by_waves = 8u * 64u / P::LPF;
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(nblocks, 256 * per_cu, 8);   // eight queued per slot: +5 % (tools/ab_oversub.sh)
+    // about four blocks per workgroup whatever the call (pcx_internal.hpp rounds_grid): eight workgroups queued per slot measured
+    // +5 % at 64 Mi samples (tools/ab_oversub.sh), which is this; PCX_OVERSUB (diagnostic library) brings the fixed factor back
+    const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * per_cu, 1) : rounds_grid(nblocks, 256 * per_cu, 4);
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out, n_out / M,
                        (unsigned)M, magic, (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, first_full, nfull, nblocks);
     PCX_LAUNCH_CHECK();
@@ -460,7 +462,7 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
     const unsigned by_waves = 8u * 64u / P::LPF;
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(nblocks, 256 * per_cu, 8);   // eight queued per slot: +5 % (tools/ab_oversub.sh)
+    const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * per_cu, 1) : rounds_grid(nblocks, 256 * per_cu, 4);   // as fir_cf64_ols
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out,
                        (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks_real, n_out / M, (unsigned)M, magic);
     PCX_LAUNCH_CHECK();

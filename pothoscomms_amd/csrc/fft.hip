@@ -567,7 +567,10 @@ int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool
     unsigned per_cu = (unsigned)(160 * 1024 / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(ngroups, 256 * per_cu, 4);   // four queued per slot: +5..9 % on the Q15 kernels (tools/sweep_fft.py, PCX_OVERSUB A/B)
+    // (PCX_Q15_ROUNDS, diagnostic library: groups per workgroup instead of the fixed factor, A/B)
+    const long q15_rounds = PCX_ENV_INT("PCX_Q15_ROUNDS", 0);
+    const unsigned grid = q15_rounds > 0 ? rounds_grid(ngroups, 256 * per_cu, (unsigned)q15_rounds)
+                                         : persistent_grid(ngroups, 256 * per_cu, 4);   // four queued per slot: +5..9 % on the Q15 kernels (tools/sweep_fft.py, PCX_OVERSUB A/B)
     hipLaunchKernelGGL(fft_q15_kernel, dim3(grid), dim3(lanes * fpw), lds, st, (const K16 *)in, (K16 *)out, (int)nbins, log2n, nframes,
                        (const K16 *)tw, (const unsigned short *)perm, plan, inverse ? 1 : 0, (int)fpw, stage_tw);
     PCX_LAUNCH_CHECK();

@@ -176,7 +176,9 @@ int launch_r16(const void *in, void *out, size_t nframes, bool inverse, const vo
     if (per_cu > 2) per_cu = 2;     // ~200 VGPRs: two waves per SIMD
     if (P::THREADS > 256) per_cu = 1;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(ngroups, 256 * per_cu, 4);   // four queued per slot: +3..5 % (tools/sweep_fft_f64.py, PCX_OVERSUB A/B)
+    const long f64_rounds = PCX_ENV_INT("PCX_F64_ROUNDS", 0);   // (diagnostic library: groups per workgroup instead of the fixed factor, A/B)
+    const unsigned grid = f64_rounds > 0 ? rounds_grid(ngroups, 256 * per_cu, (unsigned)f64_rounds)
+                                         : persistent_grid(ngroups, 256 * per_cu, 4);   // four queued per slot: +3..5 % (tools/sweep_fft_f64.py, PCX_OVERSUB A/B)
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::THREADS), lds, st, (const double2 *)in, (double2 *)out, nframes, (const double2 *)tw);
     PCX_LAUNCH_CHECK();
     return PCX_OK;

@@ -244,7 +244,9 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     unsigned per_cu = (unsigned)(160 * 1024 / lds);
     const unsigned by_waves = 16u * 64u / P::LPF;
     if (per_cu > by_waves) per_cu = by_waves;
-    const unsigned grid = persistent_grid(nblocks, 256 * per_cu, 4);   // four queued per slot: K = 4097 132 -> 141 Gsamples/s, 8193 +-0 (PCX_OVERSUB A/B)
+    const long r16_rounds = PCX_ENV_INT("PCX_R16_ROUNDS", 0);   // (diagnostic library: blocks per workgroup instead of the fixed factor, A/B)
+    const unsigned grid = r16_rounds > 0 ? rounds_grid(nblocks, 256 * per_cu, (unsigned)r16_rounds)
+                                         : persistent_grid(nblocks, 256 * per_cu, 4);   // four queued per slot: K = 4097 132 -> 141 Gsamples/s, 8193 +-0 (PCX_OVERSUB A/B)
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
                        (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw, first_full, nfull, nblocks);
     PCX_LAUNCH_CHECK();

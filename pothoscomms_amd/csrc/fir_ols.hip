@@ -248,6 +248,9 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     case 7: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0>), g4); goto launched;
     case 9: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true, 4, 2>), g3); goto launched;
     case 14: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 2>), gx); goto launched;
+    // 20 / 21: static stride on a grid of PCX_ROUNDS blocks per workgroup (default 3), H held in registers / fetched from L2 per block
+    case 20: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), rounds_grid(nblocks, 1024, 3)); goto launched;
+    case 21: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 0, true>), rounds_grid(nblocks, 1024, 3)); goto launched;
     case 15: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 3>), g4); goto launched;
     case 16: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 4>), g4); goto launched;
     case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 1>), g4); goto launched;

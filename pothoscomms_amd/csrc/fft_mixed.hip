@@ -481,7 +481,8 @@ int launch_mixed(const void *in, void *out, size_t nbins, size_t nframes, bool i
     const unsigned by_threads = 2048 / threads;
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
+    const long mixed_rounds = PCX_ENV_INT("PCX_MIXED_ROUNDS", 0);   // (diagnostic library: groups per workgroup instead of equal shares, A/B)
+    const unsigned grid = mixed_rounds > 0 ? rounds_grid(ngroups, 256 * per_cu, (unsigned)mixed_rounds) : persistent_grid(ngroups, 256 * per_cu);
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, (const typename A::cpx *)in, (typename A::cpx *)out, (int)nbins, nframes,
                        (const typename A::cpx *)tw, (const uint16_t *)iperm, plan, inverse ? 1 : 0);
     PCX_LAUNCH_CHECK();
@@ -544,7 +545,8 @@ int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool 
     const unsigned by_threads = 2048 / threads;
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
-    const unsigned grid = persistent_grid(ngroups, 256 * per_cu);
+    const long mixed_rounds = PCX_ENV_INT("PCX_MIXED_ROUNDS", 0);   // (diagnostic library: groups per workgroup instead of equal shares, A/B)
+    const unsigned grid = mixed_rounds > 0 ? rounds_grid(ngroups, 256 * per_cu, (unsigned)mixed_rounds) : persistent_grid(ngroups, 256 * per_cu);
     hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, st, (const G *)in, (G *)out, (int)nbins, nframes, (const G *)tw,
                        (const uint16_t *)iperm, plan);
     PCX_LAUNCH_CHECK();

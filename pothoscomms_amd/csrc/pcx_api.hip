@@ -5,6 +5,7 @@
 #include <complex>
 #include <new>
 #include <string>
+#include <thread>
 
 #include <dlfcn.h>
 
@@ -346,10 +347,36 @@ void PinBuf::release()
 // previous one (measured, 128 MiB each way: 23.1 ms in one piece; tools/host_path.py)
 static size_t stage_piece(size_t bytes)
 {
-    constexpr size_t kMin = (size_t)1 << 20, kMaxPieces = 32;
+    constexpr size_t kMin = (size_t)1 << 20, kMaxPieces = 16;
     size_t piece = (bytes + kMaxPieces - 1) / kMaxPieces;
     piece = (piece + 4095) & ~(size_t)4095;
     return piece < kMin ? kMin : piece;
+}
+// The CPU side of a large staged transfer: one core copies 10-14 GB/s, the DMA engine moves 50.  Pieces of 4 MiB and more
+// are split over up to four short-lived helper threads (the caller copies the first share itself); smaller copies, i.e.
+// every call below 64 MiB, stay on the calling thread.
+static void stage_copy(void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t kParallelFrom = (size_t)4 << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = bytes >= kParallelFrom ? std::min(4u, hw > 1 ? hw / 2 : 1u) : 1u;
+    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+    const size_t share = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::thread helpers[3];
+    unsigned started = 0;
+    for (unsigned t = 1; t < nt; t++) {
+        const size_t off = (size_t)t * share;
+        if (off >= bytes) break;
+        const size_t c = bytes - off < share ? bytes - off : share;
+        try {
+            helpers[started] = std::thread([=] { std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, c); });
+            started++;
+        } catch (...) {      // no thread to be had: the caller copies this share as well
+            std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, c);
+        }
+    }
+    std::memcpy(dst, src, share < bytes ? share : bytes);
+    for (unsigned t = 0; t < started; t++) helpers[t].join();
 }
 void StageBuf::release()
 {
@@ -364,7 +391,7 @@ static int stage_in(const void *host, size_t bytes, StageBuf &ws, hipStream_t st
     const size_t piece = stage_piece(bytes);
     for (size_t off = 0; off < bytes; off += piece) {
         const size_t c = bytes - off < piece ? bytes - off : piece;
-        std::memcpy(static_cast<char *>(ws.pin.p) + off, static_cast<const char *>(host) + off, c);
+        stage_copy(static_cast<char *>(ws.pin.p) + off, static_cast<const char *>(host) + off, c);
         PCX_HIP(hipMemcpyAsync(static_cast<char *>(ws.dev.p) + off, static_cast<const char *>(ws.pin.p) + off, c, hipMemcpyHostToDevice, st));
     }
     *dev = ws.dev.p;
@@ -400,7 +427,7 @@ static int stage_out_rest(void *host, StageBuf &ws, size_t bytes, bool staged, h
             const size_t cn = bytes - nxt < piece ? bytes - nxt : piece;
             PCX_HIP(hipMemcpyAsync(static_cast<char *>(ws.pin.p) + nxt, static_cast<const char *>(ws.dev.p) + nxt, cn, hipMemcpyDeviceToHost, st));
         }
-        std::memcpy(static_cast<char *>(host) + off, static_cast<const char *>(ws.pin.p) + off, c);
+        stage_copy(static_cast<char *>(host) + off, static_cast<const char *>(ws.pin.p) + off, c);
     }
     return PCX_OK;
 }

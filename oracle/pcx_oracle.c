@@ -228,11 +228,29 @@ ORC_EXPORT void orc_fir_activate(orc_fir *f) { f->waitTapsArmed = f->waitTapsMod
 ORC_EXPORT size_t orc_fir_K(const orc_fir *f) { return f->K; }
 ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequire; }
 
+/* std::complex<float/double> operator* as GCC compiles it (FIRFilter.cpp:298, Rotate.cpp:20): the plain formula, every product
+ * and sum rounded separately, and -- only when BOTH parts come out NaN -- libgcc's __mulsc3 / __muldc3, which recovers the
+ * infinities of C99 Annex G.  The libgcc functions are called directly so that the slow path is the reference's own. */
+extern float _Complex __mulsc3(float a, float b, float c, float d);
+extern double _Complex __muldc3(double a, double b, double c, double d);
+static inline void orc_cmul_f32(float a, float b, float c, float d, float *x, float *y)
+{
+    const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    *x = ac - bd; *y = ad + bc;
+    if (*x != *x && *y != *y) { const float _Complex z = __mulsc3(a, b, c, d); *x = __real__ z; *y = __imag__ z; }
+}
+static inline void orc_cmul_f64(double a, double b, double c, double d, double *x, double *y)
+{
+    const double ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    *x = ac - bd; *y = ad + bc;
+    if (*x != *x && *y != *y) { const double _Complex z = __muldc3(a, b, c, d); *x = __real__ z; *y = __imag__ z; }
+}
+
 /* the convolution loop FIRFilter.cpp:286-302, floating point element types.
  * Accumulation is sequential in k in the Q type (== element type for floats);
- * complex*complex follows libgcc __mulsc3's finite path: (ac-bd, ad+bc), every
- * product and sum rounded separately. */
-#define ORC_FIR_FLOAT(NAME, T, ROWS)                                                               \
+ * complex*complex is orc_cmul_* above: (ac-bd, ad+bc), every product and sum rounded
+ * separately, with libgcc's slow path when both parts are NaN. */
+#define ORC_FIR_FLOAT(NAME, T, ROWS, CMUL)                                                             \
     static size_t NAME(const orc_fir *f, const T *x, T *y, size_t N)                            \
     {                                                                                           \
         const size_t L = f->L, M = f->M, K = f->K;                                              \
@@ -263,9 +281,8 @@ ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequi
                     T ar = 0, ai = 0;                                                           \
                     for (size_t k = 0; k < len; k++) {                                          \
                         const T *xp = x + 2 * ((ptrdiff_t)n - (ptrdiff_t)k);                    \
-                        const T a = tp[2 * k], b = tp[2 * k + 1], c = xp[0], d = xp[1];         \
-                        const T ac = a * c, bd = b * d, ad = a * d, bc = b * c;                 \
-                        const T pr = ac - bd, pi = ad + bc;                                     \
+                        T pr, pi;                                                               \
+                        CMUL(tp[2 * k], tp[2 * k + 1], xp[0], xp[1], &pr, &pi);                 \
                         ar = ar + pr; ai = ai + pi;                                             \
                     }                                                                           \
                     y[2 * nout] = ar; y[2 * nout + 1] = ai; nout++;                             \
@@ -274,8 +291,8 @@ ORC_EXPORT size_t orc_fir_input_require(const orc_fir *f) { return f->inputRequi
         }                                                                                       \
         return nout;                                                                            \
     }
-ORC_FIR_FLOAT(fir_loop_f32, float, rowTapsF32)
-ORC_FIR_FLOAT(fir_loop_f64, double, rowTapsF)
+ORC_FIR_FLOAT(fir_loop_f32, float, rowTapsF32, orc_cmul_f32)
+ORC_FIR_FLOAT(fir_loop_f64, double, rowTapsF, orc_cmul_f64)
 
 /* same loop for the integer element types: all operations are ring operations
  * modulo 2^qbits (std::complex<intN> products/sums wrap), so the result is the
@@ -908,16 +925,12 @@ ORC_EXPORT int orc_rotate(int st, double phase, const void *in, void *out, size_
         const float pr = (float)c, pi = (float)s;
         const float *x = (const float *)in; float *y = (float *)out;
         for (size_t i = 0; i < n; i++) {
-            const float a = pr, b = pi, cc = x[2 * i], d = x[2 * i + 1];
-            const float ac = a * cc, bd = b * d, ad = a * d, bc = b * cc;
-            y[2 * i] = ac - bd; y[2 * i + 1] = ad + bc;
+            orc_cmul_f32(pr, pi, x[2 * i], x[2 * i + 1], &y[2 * i], &y[2 * i + 1]);
         }
     } else if (st == ORC_F64) {
         const double *x = (const double *)in; double *y = (double *)out;
         for (size_t i = 0; i < n; i++) {
-            const double a = c, b = s, cc = x[2 * i], d = x[2 * i + 1];
-            const double ac = a * cc, bd = b * d, ad = a * d, bc = b * cc;
-            y[2 * i] = ac - bd; y[2 * i + 1] = ad + bc;
+            orc_cmul_f64(c, s, x[2 * i], x[2 * i + 1], &y[2 * i], &y[2 * i + 1]);
         }
     } else {
         const int qb = q_bits(st);

@@ -14,6 +14,7 @@
 //     complex<double> /: Smith's ratio form (__divdc3's path for operands in the normal range).
 // Float results are bit-identical to the reference for finite, normal-range operands; the parity bar
 // is 1e-5 relative.
+#include "pcx_cplx.hpp"
 #include "pcx_internal.hpp"
 #include "vec_io.hpp"
 
@@ -92,12 +93,16 @@ struct CplxOp<float, OP, true> {
         else if (OP == PCX_ARITH_SUB) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; }
         else if (OP == PCX_ARITH_MUL) {
             const float ac = a[0] * b[0], bd = a[1] * b[1], ad = a[0] * b[1], bc = a[1] * b[0];
-            o[0] = ac - bd; o[1] = ad + bc;
+            float x = ac - bd, y = ad + bc;
+            if (both_nan(x, y)) cmul_annex_g(a[0], a[1], b[0], b[1], x, y);   // __mulsc3's slow path
+            o[0] = x; o[1] = y;
         } else {
             const double aa = a[0], bb = a[1], cc = b[0], dd = b[1];
             const double den = (cc * cc) + (dd * dd);
-            o[0] = (float)(((aa * cc) + (bb * dd)) / den);
-            o[1] = (float)(((bb * cc) - (aa * dd)) / den);
+            float x = (float)(((aa * cc) + (bb * dd)) / den);
+            float y = (float)(((bb * cc) - (aa * dd)) / den);
+            if (both_nan(x, y)) cdiv_annex_g(a[0], a[1], b[0], b[1], x, y);   // __divsc3's
+            o[0] = x; o[1] = y;
         }
     }
 };
@@ -105,20 +110,42 @@ template <int OP>
 struct CplxOp<double, OP, true> {
     __device__ void operator()(const double *x, const double *y, double *o) const
     {
-        const double a = x[0], b = x[1], c = y[0], d = y[1];
+        double a = x[0], b = x[1], c = y[0], d = y[1];
         if (OP == PCX_ARITH_ADD) { o[0] = a + c; o[1] = b + d; }
         else if (OP == PCX_ARITH_SUB) { o[0] = a - c; o[1] = b - d; }
         else if (OP == PCX_ARITH_MUL) {
             const double ac = a * c, bd = b * d, ad = a * d, bc = b * c;
-            o[0] = ac - bd; o[1] = ad + bc;
-        } else if (fabs(c) < fabs(d)) {
-            const double ratio = c / d, den = (c * ratio) + d;
-            o[0] = ((a * ratio) + b) / den;
-            o[1] = ((b * ratio) - a) / den;
+            double x = ac - bd, y = ad + bc;
+            if (both_nan(x, y)) cmul_annex_g(a, b, c, d, x, y);   // __muldc3's slow path
+            o[0] = x; o[1] = y;
         } else {
-            const double ratio = d / c, den = (d * ratio) + c;
-            o[0] = ((b * ratio) + a) / den;
-            o[1] = (b - (a * ratio)) / den;
+            // libgcc's __divdc3 as shipped since GCC 12 (what the reference's operator/ calls; restated here and checked
+            // bit for bit against this box's libgcc on 4 M wide-range and special operands): Smith's division with the
+            // operands rescaled when the denominator is huge or tiny or a numerator part would underflow, and the other
+            // order of operations when the ratio itself is subnormal
+            constexpr double kBig = 1.7976931348623157e308 / 2, kMin = 2.2250738585072014e-308, kMin2 = 2.220446049250313e-16,
+                             kScale = 1.0 / 2.220446049250313e-16, kMax2 = kBig * kMin2;
+            double aa = a, bb = b, cc = c, dd = d;
+            const bool first = fabs(cc) < fabs(dd);
+            const double m = first ? fabs(dd) : fabs(cc);
+            double f = 1.0;
+            if (m >= kBig) f = 0.5;
+            else if (m < kMin2) f = kScale;
+            else if ((fabs(aa) < kMin && fabs(bb) < kMax2 && m < kMax2) || (fabs(bb) < kMin && fabs(aa) < kMax2 && m < kMax2)) f = kScale;
+            aa *= f; bb *= f; cc *= f; dd *= f;
+            double x, y;
+            if (first) {
+                const double ratio = cc / dd, den = (cc * ratio) + dd;
+                if (fabs(ratio) > kMin) { x = ((aa * ratio) + bb) / den; y = ((bb * ratio) - aa) / den; }
+                else { x = ((cc * (aa / dd)) + bb) / den; y = ((cc * (bb / dd)) - aa) / den; }
+            } else {
+                const double ratio = dd / cc, den = (dd * ratio) + cc;
+                if (fabs(ratio) > kMin) { x = ((bb * ratio) + aa) / den; y = (bb - (aa * ratio)) / den; }
+                else { x = ((dd * (bb / cc)) + aa) / den; y = (bb - (dd * (aa / cc))) / den; }
+            }
+            a = aa; b = bb; c = cc; d = dd;     // the slow path below sees the rescaled operands, as libgcc's does
+            if (both_nan(x, y)) cdiv_annex_g(a, b, c, d, x, y);   // __divdc3's
+            o[0] = x; o[1] = y;
         }
     }
 };

@@ -9,6 +9,7 @@
 // (a*c - b*d, a*d + b*c) with every product and sum rounded separately
 // (std::complex operator* on baseline x86-64), and keeping the same unfused
 // sequence makes Rotate/Scale/Conjugate/Abs(float) BIT-IDENTICAL to it.
+#include "pcx_cplx.hpp"
 #include "pcx_internal.hpp"
 #include "vec_io.hpp"
 
@@ -23,6 +24,25 @@ constexpr int kUnroll = 4;
 // No __restrict__: pcx.h documents out == in for the same-size maps (rotate, scale, conj), and Arithmetic's buffer
 // inlining relies on it.  Every lane loads the vectors it is about to overwrite before it stores them, and no lane
 // touches another lane's elements, so the in-place call is well defined as written.
+template <typename Op, typename = void>
+struct HasFix : std::false_type {};
+template <typename Op>
+struct HasFix<Op, std::enable_if_t<Op::kHasFix>> : std::true_type {};
+// the rare second look at a lane's vector of results (an Op with kHasFix: Rotate's complex multiply)
+template <int IN_PER, int OUT_PER, int ITEMS, typename Op, typename In, typename Out>
+__device__ __forceinline__ void map_fix(const Op &op, const In *a, Out *b)
+{
+    if constexpr (HasFix<Op>::value) {
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) bad |= op.suspect(&b[k * OUT_PER]);
+        if (__builtin_expect(bad, 0)) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) op.fix(&a[k * IN_PER], &b[k * OUT_PER]);
+        }
+    }
+}
+
 template <typename In, typename Out, int IN_PER, int OUT_PER, int ITEMS, typename Op>
 __global__ __launch_bounds__(kBlock) void map_kernel(const In *in, Out *out, size_t nitems, Op op)
 {
@@ -43,6 +63,7 @@ __global__ __launch_bounds__(kBlock) void map_kernel(const In *in, Out *out, siz
             VOut b;
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) op(&a[u].v[k * IN_PER], &b.v[k * OUT_PER]);
+            map_fix<IN_PER, OUT_PER, ITEMS>(op, a[u].v, b.v);
             nt_store(&vout[base + (size_t)u * kBlock], b);
         }
     }
@@ -53,9 +74,19 @@ __global__ __launch_bounds__(kBlock) void map_kernel(const In *in, Out *out, siz
         VOut b;
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) op(&a.v[k * IN_PER], &b.v[k * OUT_PER]);
+        map_fix<IN_PER, OUT_PER, ITEMS>(op, a.v, b.v);
         vout[i] = b;
     }
-    for (size_t i = nvec * ITEMS + gtid; i < nitems; i += gstride) op(in + i * IN_PER, out + i * OUT_PER);
+    for (size_t i = nvec * ITEMS + gtid; i < nitems; i += gstride) {
+        Out y[OUT_PER];
+        In x[IN_PER];
+#pragma unroll
+        for (int k = 0; k < IN_PER; k++) x[k] = in[i * IN_PER + k];     // (out may be in: read the element before writing it)
+        op(x, y);
+        map_fix<IN_PER, OUT_PER, 1>(op, x, y);
+#pragma unroll
+        for (int k = 0; k < OUT_PER; k++) out[i * OUT_PER + k] = y[k];
+    }
 }
 
 template <typename In, typename Out, int IN_PER, int OUT_PER, typename Op>
@@ -100,6 +131,14 @@ struct RotateF {
         const T ac = pr * x[0], bd = pi * x[1], ad = pr * x[1], bc = pi * x[0];
         y[0] = ac - bd;
         y[1] = ad + bc;
+    }
+    // std::complex operator*'s slow path (pcx_cplx.hpp): map_kernel asks `suspect` for every result of a lane's vector and
+    // runs `fix` on the vector only when one of them says yes
+    static constexpr bool kHasFix = true;
+    __device__ bool suspect(const T *y) const { return both_nan(y[0], y[1]); }
+    __device__ void fix(const T *x, T *y) const
+    {
+        if (both_nan(y[0], y[1])) cmul_annex_g(pr, pi, x[0], x[1], y[0], y[1]);
     }
 };
 template <typename S, typename Q>

@@ -12,6 +12,7 @@
 //   * float types, EXACT=false: same order, fused multiply-add.
 // The LDS-tiled direct kernel (fir_direct.hip) and the frequency-domain kernel
 // (fir_ols.hip) are the performance paths for complex_float32, M=L=1.
+#include "pcx_cplx.hpp"
 #include "pcx_internal.hpp"
 
 #include <cstdlib>
@@ -26,6 +27,28 @@ template <typename Q>
 struct QComp {
     using type = typename std::conditional<(sizeof(Q) < 4), uint32_t, typename std::make_unsigned<Q>::type>::type;
 };
+
+// One output of a complex-taps float filter once more, in the reference's order, with every product going through the
+// reference's complex multiply INCLUDING its slow path (pcx_cplx.hpp): what the EXACT kernels run for an output whose two
+// parts both came out NaN -- the only outputs in which a product can have taken that path (a NaN + i NaN product makes the
+// running sum NaN + i NaN for good).  xp -> x[n] (the newest sample of the window), taps in the stored row order.
+// (inlined into a cold branch and returning by value: a call, or accumulators passed by reference, put the hot loop's
+// registers into scratch -- measured -38 % at 15 taps)
+template <typename S>
+struct CPair { S re, im; };
+template <typename S>
+__device__ __forceinline__ CPair<S> fir_output_annex_g(const S *xp, const S *tp, size_t len)
+{
+    S ar = 0, ai = 0;
+    for (size_t k = 0; k < len; k++) {
+        const S a = tp[2 * k], b = tp[2 * k + 1], c = xp[-(ptrdiff_t)k * 2], d = xp[-(ptrdiff_t)k * 2 + 1];
+        const S ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+        S pr = ac - bd, pi = ad + bc;
+        if (both_nan(pr, pi)) cmul_annex_g(a, b, c, d, pr, pi);
+        ar = ar + pr; ai = ai + pi;
+    }
+    return CPair<S>{ar, ai};
+}
 
 // S = element scalar, TT = stored tap scalar (float/double or Q int), CPLX/CTAPS flags
 template <typename S, typename TT, bool CPLX, bool CTAPS, bool EXACT>
@@ -64,6 +87,12 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const S *__restrict__ 
                         ar = t_fma(a, c, ar); ar = t_fma(-b, d, ar);
                         ai = t_fma(a, d, ai); ai = t_fma(b, c, ai);
                     }
+                }
+            }
+            if constexpr (EXACT && CPLX && CTAPS) {
+                if (__builtin_expect(both_nan(ar, ai), 0)) {
+                    const CPair<S> fx = fir_output_annex_g<S>(xp, reinterpret_cast<const S *>(tp), len);
+                    ar = fx.re; ai = fx.im;
                 }
             }
             out[o * EW] = ar;
@@ -205,10 +234,14 @@ __global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in
             }
         }
         // the lane's R outputs are R*EW*sizeof(S) contiguous bytes: 16-byte stores when the run is whole and aligned
+        unsigned badmask = 0;
         S res[R * EW];
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if constexpr (FLT) {
+                if constexpr (EXACT && CPLX && CTAPS) {
+                    if (both_nan(ar[r], ai[r])) badmask |= 1u << r;     // see fir_output_annex_g: looked at again behind the stores
+                }
                 res[r * EW] = ar[r];
                 if constexpr (CPLX) res[r * EW + 1] = ai[r];
             } else {
@@ -230,6 +263,20 @@ __global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in
                 if (o0 + r >= n_out) break;
 #pragma unroll
                 for (int c = 0; c < EW; c++) op[r * EW + c] = res[r * EW + c];
+            }
+        }
+        if constexpr (FLT && EXACT && CPLX && CTAPS) {
+            // outputs that came out NaN + i NaN, once more through the reference's complex multiply with its slow path
+            // (fir_output_annex_g), one at a time and straight to memory over what was just stored: nothing of the hot
+            // loop is live here, so the cold path costs the kernel no registers
+            if (__builtin_expect(badmask != 0, 0)) {
+#pragma unroll 1
+                for (int r = 0; r < R; r++) {
+                    if (!((badmask >> r) & 1u) || o0 + r >= n_out) continue;
+                    const CPair<S> fx = fir_output_annex_g<S>(reinterpret_cast<const S *>(in) + (o0 + r + K - 1) * 2, reinterpret_cast<const S *>(taps), K);
+                    out[(o0 + r) * 2] = fx.re;
+                    out[(o0 + r) * 2 + 1] = fx.im;
+                }
             }
         }
     }

@@ -876,8 +876,8 @@ ORC_EXPORT int orc_freqdemod_work(orc_freqdemod *h, const void *in, void *out, s
         float pr = (float)h->pr, pi = (float)h->pi;
         for (size_t i = 0; i < N; i++) {
             const float a = x[2 * i], b = x[2 * i + 1];
-            const float ac = a * pr, bd = b * pi, ad = a * pi, bc = b * pr;   /* in_i * _prev  :63 */
-            const float dr = ac - bd, di = ad + bc;
+            float dr, di;
+            orc_cmul_f32(a, b, pr, pi, &dr, &di);                             /* in_i * _prev  :63 */
             y[i] = atan2f(di, dr);                                            /* std::arg FxptHelpers.hpp:18 */
             pr = a; pi = -b;                                                  /* _prev = conj(in_i) :65 */
         }
@@ -887,8 +887,8 @@ ORC_EXPORT int orc_freqdemod_work(orc_freqdemod *h, const void *in, void *out, s
         double pr = h->pr, pi = h->pi;
         for (size_t i = 0; i < N; i++) {
             const double a = x[2 * i], b = x[2 * i + 1];
-            const double ac = a * pr, bd = b * pi, ad = a * pi, bc = b * pr;
-            const double dr = ac - bd, di = ad + bc;
+            double dr, di;
+            orc_cmul_f64(a, b, pr, pi, &dr, &di);
             y[i] = atan2(di, dr);
             pr = a; pi = -b;
         }

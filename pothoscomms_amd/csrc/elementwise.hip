@@ -356,13 +356,17 @@ __device__ inline float demod_one<float>(float a, float b, float c, float d)
 {
     // in_i * _prev, unfused: re = a*c - b*d, im = a*d + b*c
     const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
-    return atan2f(ad + bc, ac - bd);
+    float re = ac - bd, im = ad + bc;
+    if (__builtin_expect(both_nan(re, im), 0)) cmul_annex_g(a, b, c, d, re, im);   // operator*'s slow path (pcx_cplx.hpp)
+    return atan2f(im, re);
 }
 template <>
 __device__ inline double demod_one<double>(double a, double b, double c, double d)
 {
     const double ac = a * c, bd = b * d, ad = a * d, bc = b * c;
-    return atan2(ad + bc, ac - bd);
+    double re = ac - bd, im = ad + bc;
+    if (__builtin_expect(both_nan(re, im), 0)) cmul_annex_g(a, b, c, d, re, im);
+    return atan2(im, re);
 }
 template <typename T>
 __device__ inline T conj_im(T d)

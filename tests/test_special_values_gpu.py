@@ -76,8 +76,8 @@ def test_angle_and_freq_demod_on_special_values(oracle, dev):
     assert np.all(d <= TOL * np.pi), (x[~wn][d > TOL * np.pi][:6], got[~wn][d > TOL * np.pi][:6], want[~wn][d > TOL * np.pi][:6])
     zero_in = ~wn & (want == 0)
     assert np.array_equal(np.signbit(got[zero_in]), np.signbit(want[zero_in]))       # +0 and -0 as the reference
-    # FreqDemod: finite samples only (a product of two infinities is NaN on both sides; checked for NaN agreement)
-    fin = x[np.isfinite(x).all(1)]
+    # FreqDemod: in[i] * conj(in[i-1]) through the reference's complex multiply (slow path included), then atan2f
+    fin = np.concatenate([x, x[::-1], np.roll(x, 5, axis=0)])
     want, got = oracle.FreqDemod(oracle.F32).work(fin), dev.FreqDemod("complex_float32").process(fin)
     gn, wn = np.isnan(got), np.isnan(want)
     assert np.array_equal(gn, wn)

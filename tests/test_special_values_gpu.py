@@ -99,3 +99,22 @@ def test_reference_order_fir_on_special_values(oracle, dev):
         got, _, gp = f.process(x, n)
         assert gp == p == n
         _same(got, want, ("fir exact", len(taps)))
+
+
+def test_double_precision_abs_and_angle_on_special_values(oracle, dev):
+    """hypot and atan2 in double: the device's are not bit-identical to glibc's (bars 4e-15 / 1e-5 of pi), but every special case must
+    be the reference's -- +inf next to a NaN, NaN propagation, 0 / +-pi on signed zeros, multiples of pi/4 on infinities"""
+    x = _grid(np.float64)
+    for name, got, want, tol in (("abs", dev.abs_(x, True), oracle.abs_(x, True), 4e-15), ("angle", dev.angle(x), oracle.angle(x), None)):
+        gn, wn = np.isnan(got), np.isnan(want)
+        assert np.array_equal(gn, wn), (name, np.flatnonzero(gn != wn)[:8])
+        inf = ~wn & np.isinf(want)
+        assert np.array_equal(got[inf], want[inf]), name
+        zero = ~wn & (want == 0)
+        assert np.array_equal(got[zero], want[zero]) and np.array_equal(np.signbit(got[zero]), np.signbit(want[zero])), name
+        fin = ~wn & ~inf & ~zero
+        if tol is not None:
+            # subnormal magnitudes: a few ulps of the smallest subnormal are allowed on top of the relative bar
+            assert np.all(np.abs(got[fin] - want[fin]) <= tol * np.abs(want[fin]) + 4 * np.finfo(np.float64).smallest_subnormal), name
+        else:
+            assert np.all(np.abs(got[fin] - want[fin]) <= TOL * np.pi), name

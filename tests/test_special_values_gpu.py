@@ -99,6 +99,16 @@ def test_reference_order_fir_on_special_values(oracle, dev):
         got, _, gp = f.process(x, n)
         assert gp == p == n
         _same(got, want, ("fir exact", len(taps)))
+    # the resampling kernel's reference-order mode (one output per lane) has the same second look
+    taps = rng.normal(size=23) + 1j * rng.normal(size=23)
+    for L, M in ((2, 1), (1, 3), (3, 2)):
+        f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(taps); f.set_interpolation(L); f.set_decimation(M); f.set_algo(_lib.FIR_EXACT)
+        ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(taps); ref.set_interpolation(L); ref.set_decimation(M); ref.activate()
+        cap = len(x) * L // M + 8
+        want, rc, rp, _ = ref.work(x, cap)
+        got, gc, gp = f.process(x, cap)
+        assert (gc, gp) == (rc, rp) and rp > 0
+        _same(got, want, ("fir exact resampling", L, M))
 
 
 def test_double_precision_abs_and_angle_on_special_values(oracle, dev):

@@ -196,3 +196,38 @@ def test_scatter_and_gather_on_page_locked_and_pageable_memory_agree(oracle):
         ns.sync()
         del ns
         _lib.check(L.pcx_host_free(pin)); _lib.check(L.pcx_host_free(pout))
+
+
+def test_call_order_and_argument_errors():
+    """every misuse of include/pcx.h's call order (create -> set_taps -> configure -> scatter/step/gather) and every bad argument is
+    refused with PCX_ERR_ARG and a message; nothing is launched and the handle stays usable"""
+    from pothoscomms_amd import _lib, device, taps as tp
+    L = _lib.load()
+    h = C.c_void_p()
+    for n, devs, tr, frag in ((0, None, 1, "0 shards"), (65, None, 1, "65 shards"), (1, [0], 7, "unknown transport"), (1, [99], 1, "on device 99")):
+        arr = (C.c_int * len(devs))(*devs) if devs else None
+        assert L.pcx_shard_create(n, arr, tr, C.byref(h)) == _lib.ERR_ARG
+        assert frag in L.pcx_last_error().decode(), (frag, L.pcx_last_error())
+    ns = device.NodeStream([0, 0], device.NodeStream.PEER_COPY)
+    x = np.zeros((1000, 2), np.float32)
+    with pytest.raises(_lib.PcxError, match="set the taps first"):
+        ns.configure(100)
+    with pytest.raises(_lib.PcxError, match="configure first"):
+        ns.step()
+    with pytest.raises(_lib.PcxError, match="configure first"):
+        ns.scatter(x)
+    ns.set_taps(tp.c1_taps())
+    with pytest.raises(_lib.PcxError, match="empty shard"):
+        ns.configure(0)
+    with pytest.raises(_lib.PcxError, match="shorter than the 254-sample halo"):
+        ns.configure(100)
+    ns.configure(400)
+    with pytest.raises(_lib.PcxError, match="expected K-1 \\+ shards\\*C = 1054"):
+        ns.scatter(x)
+    y = np.zeros((801, 2), np.float32)
+    assert L.pcx_shard_gather(ns._h, y.ctypes.data_as(C.c_void_p), 801) == _lib.ERR_ARG
+    assert L.pcx_shard_step(None) == _lib.ERR_ARG and L.pcx_shard_destroy(None) == 0
+    # ... and the handle still works
+    xs = np.random.default_rng(0).standard_normal((254 + 800, 2)).astype(np.float32)
+    ns.scatter(xs); ns.step()
+    assert ns.gather().shape == (800, 2)

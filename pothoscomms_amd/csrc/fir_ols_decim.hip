@@ -27,7 +27,9 @@ namespace pcx {
 namespace {
 using namespace fft4k;
 
-template <int LOG2M, bool DYN = false>
+// NOINV (diagnostic library, TIMING ONLY, wrong outputs): the block without its N/M-point inverse stage -- what batching that stage
+// over several blocks could save at most
+template <int LOG2M, bool DYN = false, bool NOINV = false>
 __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                         size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                         const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
@@ -134,12 +136,17 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
             }
         }
         __syncthreads();                                  // every lane is done with the forward image (pass 3 reads)
+        if (NOINV) {
+#pragma unroll
+            for (int k1 = 0; k1 < P; k1++) { const int n = j + 256 * k1; lds[OIMG + n + (n >> 4)] = z[k1]; }
+        }
 #pragma unroll
         for (int k1 = 0; k1 < P; k1++) lds[k1 * FRAME + j + (j >> 4)] = z[k1];
         __syncthreads();
         // P independent 256-point transforms, 16 lanes each: radix 16 x 16 (Ns = 1, Ns = 16)
         cf w[16];
         cf *fr = lds + fi * FRAME;
+        if (!NOINV) {
         if (sub) {
 #pragma unroll
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
             }
         }
         __syncthreads();
+        }
         // decimated sample n' of the block is output b*Sd + n' - Kov/M; n' < Kov/M wraps past num_records and is dropped
         if (M2 > 1) {
             const size_t B0 = (b * Sd) / M2;
@@ -202,6 +210,175 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
     walk.finish(j);
 }
 
+// --------------------------------------------------------------------------------- //
+// The same filter with the N/M-point inverse stage BATCHED over G consecutive blocks.
+//
+// In the kernel above the inverse stage of a block keeps only 16 P of the 256 lanes busy (P = 16/M sub-transforms of 256
+// points, 16 lanes each) through six barriers: a quarter of the block's time at M = 8 (0.192 -> 0.144 ms per 64 Mi samples
+// without it, timing-only build PCX_DECIM_NOINV).  Here a workgroup takes G blocks at a time: forward passes, H and the fold
+// for each of them, the P folded and twiddled values per lane parked in registers (G P <= 16 of them), then ONE inverse stage
+// over all G P sub-transforms -- 16 G P lanes busy, the same six barriers once per group -- and the G blocks' outputs, which
+// are contiguous in the output stream, stored together.  Plain decimation factors only (no cofactor M2: those calls keep the
+// kernel above).  In practice the parked values cost registers the forward passes need: the product uses it at M = 8 with
+// G = 2 only (launch_decim below has the measurements).
+// --------------------------------------------------------------------------------- //
+template <int LOG2M, int LOG2G, bool TW3_REG>
+__global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_batched_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+                                                                                size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
+                                                                                const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
+                                                                                size_t nblocks)
+{
+    constexpr int M = 1 << LOG2M, P = 16 / M, G = 1 << LOG2G, T = G * P;
+    static_assert(T <= 16, "at most 16 sub-transforms of 256 points fill the workgroup");
+    constexpr int FRAME = 272;
+    __shared__ cf lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    const size_t S = (size_t)(N - Kov), Sd = S >> LOG2M;
+    const size_t ngroups = (nblocks + G - 1) / G;
+    LaneTw tw3r;
+    if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
+    cf td1;
+    {
+        float sn, cs;
+        sincospif(-2.0f * (float)j / (float)(256 * P), &sn, &cs);
+        td1 = cf{cs, sn};
+    }
+    const int fi = j >> 4, l = j & 15;               // sub-transform t = fi (block fi / P of the group, k1 = fi % P) and lane inside it
+    const bool sub = j < 16 * T;
+
+    for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        cf zz[T];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const size_t b = grp * G + g;
+            if (b >= nblocks) {                       // (workgroup-uniform) the launch's last group may be short
+#pragma unroll
+                for (int k1 = 0; k1 < P; k1++) zz[g * P + k1] = cf{0.f, 0.f};
+                continue;
+            }
+            cf v[16];
+            if (b >= first_full && b < nfull) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + b * S - pad, N * 8);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const u32x2 t = (r == 0 || r == 15) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 0)
+                                                        : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 2);
+                    v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+                }
+            } else {
+                const size_t shift = b * S >= (size_t)pad ? 0 : (size_t)pad - b * S;
+                const size_t first = b * S + shift - pad;
+                const size_t left = in_elems > first ? in_elems - first : 0;
+                const size_t want = (size_t)N - shift;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first, (unsigned)((left < want ? left : want) * 8));
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * r - (int)shift) * 8, 0, 0);
+                    v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+                }
+            }
+            pass1(v, lds, j);
+            pass2(v, lds, j);
+            if (TW3_REG) {
+                pass3(v, lds, j, tw3r);
+            } else {
+                const float2 *tp = twtab;
+                asm volatile("" : "+v"(tp));
+                LaneTw tw3;
+                load_pass3_twiddles(tw3, tp, j);
+                pass3(v, lds, j, tw3);
+            }
+            const cf *Hb = Hg;
+            asm volatile("" : "+v"(Hb));
+            cf u[16];
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const int k0 = bin_of(q), k1 = bin_of(q + 1);
+                u[k0] = v[q];
+                u[k1] = v[q + 1];
+                cmul2_conj(u[k0], u[k1], Hb[256 * k0], Hb[256 * k1]);
+            }
+            cf z[P];
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                z[r] = u[r];
+#pragma unroll
+                for (int m = 1; m < M; m++) z[r] = z[r] + u[r + P * m];
+            }
+            if constexpr (P == 8) fft8(z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+            else if constexpr (P == 4) fft4(z[0], z[1], z[2], z[3]);
+            else if constexpr (P == 2) { const cf a = z[0], c = z[1]; z[0] = a + c; z[1] = a - c; }
+            {
+                cf t = td1;
+#pragma unroll
+                for (int k1 = 1; k1 < P; k1++) {
+                    z[k1] = cmul1(z[k1], t);
+                    if (k1 + 1 < P) t = cmul1(t, td1);
+                }
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < P; k1++) zz[g * P + k1] = z[k1];
+        }
+        // ---- one inverse stage for the whole group: T sub-transforms of 256 points, 16 lanes each ----
+        __syncthreads();                                  // the last block's pass-3 reads of the image are done
+#pragma unroll
+        for (int t = 0; t < T; t++) lds[t * FRAME + j + (j >> 4)] = zz[t];
+        __syncthreads();
+        cf w[16];
+        cf *fr = lds + fi * FRAME;
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            fft16_plain(w);
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            LaneTw tl;
+            const cf *t2 = lds + LDS_DATA + l;
+#pragma unroll
+            for (int p = 0; p < 3; p++) tl.a[p] = t2[p * 16];
+#pragma unroll
+            for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
+            fft16_tw(w, tl);
+        }
+        __syncthreads();                                  // every frame has been read: the image is rewritten in output order
+        if (sub) {
+            // w[q] = bin k2 = l + 16 bin_of(q) of sub-transform (g, k1) = (fi / P, fi % P): decimated sample n' = k1 + P k2 of block g
+            const int g = fi / P, k1 = fi % P;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int n = g * (256 * P) + k1 + P * (l + 16 * bin_of(q));
+                lds[n + (n >> 4)] = w[q];
+            }
+        }
+        __syncthreads();
+        // decimated sample n' of block b is output b*Sd + n' - Kov/M; n' < Kov/M wraps past num_records and is dropped
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const size_t b = grp * G + g;
+            if (b >= nblocks) break;
+            const size_t room = n_out - b * Sd;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * Sd, (unsigned)((room < Sd ? room : Sd) * 8));
+            const unsigned vbase = (unsigned)(j - (Kov >> LOG2M)) * 8u;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const int n = g * (256 * P) + j + 256 * i;
+                const cf y = lds[n + (n >> 4)];
+                store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, cf{y.x, -y.y});
+            }
+        }
+    }
+}
+
 template <int LOG2M>
 int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, size_t M2,
                  void *sched, hipStream_t st)
@@ -222,6 +399,40 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     const bool dyn = sched && nblocks > 2 * 1024 && PCX_ENV_SET("PCX_SCHED_RESAMPLERS");
     const unsigned grid = dyn ? 1024u : persistent_grid(nblocks, 1024);
     const unsigned magic2 = M2 > 1 ? (unsigned)(((1ull << 32) + M2 - 1) / M2) : 0u;
+    // Measured (tools/ab_decim.sh, profiles/r02/ab_decim.txt): two blocks per group pay at M = 8 (330-344 -> 359-367 Gsamples/s) and
+    // nowhere else -- M = 4 +3 %, M = 2 +1 %, M = 16 -5 % -- and four or eight blocks per group lose everywhere: the parked values
+    // push the forward passes over 128 VGPRs and into scratch.  So M = 8 takes the batched kernel, the rest the one above;
+    // PCX_DECIM_BATCHED / PCX_DECIM_UNBATCHED (diagnostic library) force either for A/B.
+    const bool batched = M2 == 1 && ((LOG2M == 3 && !PCX_ENV_SET("PCX_DECIM_UNBATCHED")) || PCX_ENV_SET("PCX_DECIM_BATCHED"));
+    if (batched) {
+        // blocks per group / pass-3 constants in registers: PCX_DECIM_G, PCX_DECIM_TW3 (diagnostic library) for A/B
+        constexpr int LGMAX = LOG2M == 1 ? 1 : LOG2M == 2 ? 2 : 3;      // G P <= 16, eight blocks at most
+        int lg = (int)PCX_ENV_INT("PCX_DECIM_G", 1);
+        if (lg > LGMAX) lg = LGMAX;
+        if (lg < 1) lg = 1;
+        const bool tw3 = PCX_ENV_INT("PCX_DECIM_TW3", LOG2M >= 3 ? 1 : 0) != 0;
+        const size_t ngroups = (nblocks + ((size_t)1 << lg) - 1) >> lg;
+        const unsigned bgrid = persistent_grid(ngroups, 1024, (unsigned)PCX_ENV_INT("PCX_DECIM_OVERSUB", 1));
+#define PCX_DECIM_LAUNCH(LG, TW)                                                                                                                     \
+        hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, TW>), dim3(bgrid), dim3(256), 0, st, (const float2 *)in, in_elems,          \
+                           (float2 *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks)
+        if (lg == 1) { if (tw3) PCX_DECIM_LAUNCH(1, true); else PCX_DECIM_LAUNCH(1, false); }
+        else if (lg == 2 && LGMAX >= 2) { if (tw3) PCX_DECIM_LAUNCH((LGMAX >= 2 ? 2 : 1), true); else PCX_DECIM_LAUNCH((LGMAX >= 2 ? 2 : 1), false); }
+        else if (lg == 3 && LGMAX >= 3) { if (tw3) PCX_DECIM_LAUNCH((LGMAX >= 3 ? 3 : 1), true); else PCX_DECIM_LAUNCH((LGMAX >= 3 ? 3 : 1), false); }
+        else { set_error("decim: %d blocks per group", 1 << lg); return PCX_ERR_STATE; }
+#undef PCX_DECIM_LAUNCH
+        PCX_LAUNCH_CHECK();
+        return PCX_OK;
+    }
+#ifdef PCX_DIAG
+    if (PCX_ENV_SET("PCX_DECIM_NOINV")) {
+        hipLaunchKernelGGL((fir_cf32_ols4096_decim_kernel<LOG2M, false, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
+                           (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks, (unsigned)M2, magic2,
+                           n_out / M2, (pcx::SchedState *)nullptr);
+        PCX_LAUNCH_CHECK();
+        return PCX_OK;
+    }
+#endif
     if (dyn)
         hipLaunchKernelGGL((fir_cf32_ols4096_decim_kernel<LOG2M, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
                            (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks, (unsigned)M2, magic2,

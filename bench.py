@@ -382,7 +382,7 @@ def main():
         device.fill_uniform_f32_dev(x, seed=7, offset=0)
         units = n if wl == "decim8" else n * L            # decimator: input samples; interpolator: output samples
         roof_bytes = 8.0 * n + 8.0 * (n * L // M)
-        kernel_name = "fir_cf32_ols4096_decim_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_kernel"
+        kernel_name = "fir_cf32_ols4096_decim_batched_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_kernel"
 
         def step():
             f.process_dev(x, y)

@@ -219,11 +219,11 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const fl
 // for each of them, the P folded and twiddled values per lane parked in registers (G P <= 16 of them), then ONE inverse stage
 // over all G P sub-transforms -- 16 G P lanes busy, the same six barriers once per group -- and the G blocks' outputs, which
 // are contiguous in the output stream, stored together.  Plain decimation factors only (no cofactor M2: those calls keep the
-// kernel above).  In practice the parked values cost registers the forward passes need: the product uses it at M = 8 with
-// G = 2 only (launch_decim below has the measurements).
+// kernel above).  The parked values cost registers the forward passes need: the product runs it at THREE workgroups per CU
+// (OCC = 3, 170 VGPRs; launch_decim below has the measurements), with H held in registers as well (HREG) where that fits.
 // --------------------------------------------------------------------------------- //
-template <int LOG2M, int LOG2G, bool TW3_REG>
-__global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_batched_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+template <int LOG2M, int LOG2G, bool TW3_REG, int OCC = 4, bool HREG = false>
+__global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                                 size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                                 const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
                                                                                 size_t nblocks)
@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_batched_kernel(
     if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
     const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
+    cf Hr[16];
+    if (HREG) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) Hr[k] = Hg[256 * k];
+    }
     cf td1;
     {
         float sn, cs;
@@ -298,7 +303,8 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_batched_kernel(
                 const int k0 = bin_of(q), k1 = bin_of(q + 1);
                 u[k0] = v[q];
                 u[k1] = v[q + 1];
-                cmul2_conj(u[k0], u[k1], Hb[256 * k0], Hb[256 * k1]);
+                if (HREG) cmul2_conj(u[k0], u[k1], Hr[k0], Hr[k1]);
+                else cmul2_conj(u[k0], u[k1], Hb[256 * k0], Hb[256 * k1]);
             }
             cf z[P];
 #pragma unroll
@@ -399,28 +405,37 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     const bool dyn = sched && nblocks > 2 * 1024 && PCX_ENV_SET("PCX_SCHED_RESAMPLERS");
     const unsigned grid = dyn ? 1024u : persistent_grid(nblocks, 1024);
     const unsigned magic2 = M2 > 1 ? (unsigned)(((1ull << 32) + M2 - 1) / M2) : 0u;
-    // Measured (tools/ab_decim.sh, profiles/r02/ab_decim.txt): two blocks per group pay at M = 8 (330-344 -> 359-367 Gsamples/s) and
-    // nowhere else -- M = 4 +3 %, M = 2 +1 %, M = 16 -5 % -- and four or eight blocks per group lose everywhere: the parked values
-    // push the forward passes over 128 VGPRs and into scratch.  So M = 8 takes the batched kernel, the rest the one above;
-    // PCX_DECIM_BATCHED / PCX_DECIM_UNBATCHED (diagnostic library) force either for A/B.
-    const bool batched = M2 == 1 && ((LOG2M == 3 && !PCX_ENV_SET("PCX_DECIM_UNBATCHED")) || PCX_ENV_SET("PCX_DECIM_BATCHED"));
-    if (batched) {
-        // blocks per group / pass-3 constants in registers: PCX_DECIM_G, PCX_DECIM_TW3 (diagnostic library) for A/B
+    // Measured (tools/ab_decim.sh, tools/ab_decim_occ.sh; profiles/r02/ab_decim.txt, ab_decim_occ.txt).  At four workgroups per CU (128
+    // VGPRs) the parked values push the forward passes into scratch and batching pays at M = 8 with two blocks only (+6-8 %).  At
+    // THREE workgroups per CU (170 VGPRs) it pays everywhere -- the registers are worth more than the fourth workgroup:
+    //   M = 2: 236 -> 274-276 Gsamples/s of input (two blocks per group);   M = 4: 302 -> 353 (two blocks);
+    //   M = 8: 359 -> 403 (four blocks, H held in registers);                M = 16: 391 -> 445 (four blocks, H in registers).
+    // That is the product path for plain factors (M2 == 1); PCX_DECIM_UNBATCHED (diagnostic library) keeps the one-block kernel,
+    // PCX_DECIM_G / PCX_DECIM_HREG / PCX_DECIM_OCC=4 the other configurations, for A/B.
+    if (M2 == 1 && !PCX_ENV_SET("PCX_DECIM_UNBATCHED")) {
         constexpr int LGMAX = LOG2M == 1 ? 1 : LOG2M == 2 ? 2 : 3;      // G P <= 16, eight blocks at most
-        int lg = (int)PCX_ENV_INT("PCX_DECIM_G", 1);
+        int lg = (int)PCX_ENV_INT("PCX_DECIM_G", LOG2M >= 3 ? 2 : 1);
         if (lg > LGMAX) lg = LGMAX;
         if (lg < 1) lg = 1;
-        const bool tw3 = PCX_ENV_INT("PCX_DECIM_TW3", LOG2M >= 3 ? 1 : 0) != 0;
+        const bool hreg = PCX_ENV_INT("PCX_DECIM_HREG", LOG2M >= 3 ? 1 : 0) != 0;
+        const bool occ4 = PCX_ENV_INT("PCX_DECIM_OCC", 3) == 4;
+        const bool tw3 = PCX_ENV_INT("PCX_DECIM_TW3", LOG2M >= 3 ? 1 : 0) != 0;     // (four-per-CU builds only: pass-3 constants in registers)
         const size_t ngroups = (nblocks + ((size_t)1 << lg) - 1) >> lg;
-        const unsigned bgrid = persistent_grid(ngroups, 1024, (unsigned)PCX_ENV_INT("PCX_DECIM_OVERSUB", 1));
-#define PCX_DECIM_LAUNCH(LG, TW)                                                                                                                     \
-        hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, TW>), dim3(bgrid), dim3(256), 0, st, (const float2 *)in, in_elems,          \
-                           (float2 *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks)
-        if (lg == 1) { if (tw3) PCX_DECIM_LAUNCH(1, true); else PCX_DECIM_LAUNCH(1, false); }
-        else if (lg == 2 && LGMAX >= 2) { if (tw3) PCX_DECIM_LAUNCH((LGMAX >= 2 ? 2 : 1), true); else PCX_DECIM_LAUNCH((LGMAX >= 2 ? 2 : 1), false); }
-        else if (lg == 3 && LGMAX >= 3) { if (tw3) PCX_DECIM_LAUNCH((LGMAX >= 3 ? 3 : 1), true); else PCX_DECIM_LAUNCH((LGMAX >= 3 ? 3 : 1), false); }
-        else { set_error("decim: %d blocks per group", 1 << lg); return PCX_ERR_STATE; }
+        const unsigned bgrid = persistent_grid(ngroups, occ4 ? 1024 : 768);
+#define PCX_DECIM_ARGS dim3(bgrid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, \
+                       (const float2 *)tw4096, first_full, nfull, nblocks
+#define PCX_DECIM_LAUNCH(LG)                                                                                                      \
+        do {                                                                                                                      \
+            if (occ4 && tw3) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, true, 4, false>), PCX_DECIM_ARGS);     \
+            else if (occ4) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, false, 4, false>), PCX_DECIM_ARGS);      \
+            else if (hreg) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, true, 3, true>), PCX_DECIM_ARGS);        \
+            else hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, true, 3, false>), PCX_DECIM_ARGS);                 \
+        } while (0)
+        if (lg == 1) PCX_DECIM_LAUNCH(1);
+        else if (lg == 2) PCX_DECIM_LAUNCH((LGMAX >= 2 ? 2 : 1));
+        else PCX_DECIM_LAUNCH((LGMAX >= 3 ? 3 : 1));
 #undef PCX_DECIM_LAUNCH
+#undef PCX_DECIM_ARGS
         PCX_LAUNCH_CHECK();
         return PCX_OK;
     }

@@ -472,8 +472,10 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
 // input samples = S_in*L outputs per block; output i of a block is valid from i >= Kov_in*L on (the wrapped positions a
 // valid output still touches are zero-stuffing zeros).
 // --------------------------------------------------------------------------------- //
-template <int LOG2L, bool DYN = false>
-__global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+// OCC = workgroups per CU the register budget is cut for (4: 128 VGPRs, 3: 170); HREG: the lane's 16 bins of H held in registers
+// instead of re-read from L2 in every block (needs the 170)
+template <int LOG2L, bool DYN = false, int OCC = 4, bool HREG = false>
+__global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                          size_t n_out, const float2 *__restrict__ Hspec, int Kov_in, int pad_in,
                                                                          const float2 *__restrict__ twtab, size_t nblocks,
                                                                          pcx::SchedState *__restrict__ sched)
@@ -491,6 +493,11 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const f
     load_pass3_twiddles(tw3, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
     const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
+    cf Hr[16];
+    if (HREG) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) Hr[k] = Hg[256 * k];
+    }
     cf td1;
     {
         float sn, cs;
@@ -581,7 +588,8 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_interp_kernel(const f
         for (int r = 0; r < 16; r += 2) {
             u[r] = g[r & (P - 1)];
             u[r + 1] = g[(r + 1) & (P - 1)];
-            cmul2_conj(u[r], u[r + 1], Hb[256 * r], Hb[256 * (r + 1)]);
+            if (HREG) cmul2_conj(u[r], u[r + 1], Hr[r], Hr[r + 1]);
+            else cmul2_conj(u[r], u[r + 1], Hb[256 * r], Hb[256 * (r + 1)]);
         }
         walk.publish(j);                                  // the inverse passes' barriers follow
         pass1(u, lds, j);
@@ -611,6 +619,21 @@ int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, con
     const size_t nblocks = (n_iter + S_in - 1) / S_in;
     const bool dyn = sched && nblocks > 2 * 1024 && PCX_ENV_SET("PCX_SCHED_RESAMPLERS");   // measured +-0 (0.1960 vs 0.1950 ms at L = 4): stride kept
     const unsigned grid = dyn ? 1024u : persistent_grid(nblocks, 1024);
+    // Three workgroups per CU (170 VGPRs) instead of four: the kernel spills at 128 (12-52 bytes per lane), and the registers are worth more
+    // than the fourth workgroup, as for the decimator -- L = 2 / 4 / 8 / 16: 268 / 309 / 227 / 263 -> 309 / 329 / 250 / 277 Gsamples/s of
+    // output, with H held in registers too at L >= 8 (tools/ab_interp.sh, profiles/r02/ab_interp.txt).  PCX_INTERP_OCC=4 (diagnostic
+    // library) brings the four-per-CU build back for A/B, PCX_INTERP_HREG overrides the H choice.
+    if (!dyn && PCX_ENV_INT("PCX_INTERP_OCC", 3) == 3) {
+        const unsigned g3 = persistent_grid(nblocks, 768);
+        if (PCX_ENV_INT("PCX_INTERP_HREG", LOG2L >= 3 ? 1 : 0) != 0)
+            hipLaunchKernelGGL((fir_cf32_ols4096_interp_kernel<LOG2L, false, 3, true>), dim3(g3), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                               n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks, (pcx::SchedState *)nullptr);
+        else
+            hipLaunchKernelGGL((fir_cf32_ols4096_interp_kernel<LOG2L, false, 3, false>), dim3(g3), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
+                               n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks, (pcx::SchedState *)nullptr);
+        PCX_LAUNCH_CHECK();
+        return PCX_OK;
+    }
     if (dyn)
         hipLaunchKernelGGL((fir_cf32_ols4096_interp_kernel<LOG2L, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
                            n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks, (pcx::SchedState *)sched);

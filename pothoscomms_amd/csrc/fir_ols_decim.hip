@@ -29,8 +29,8 @@ using namespace fft4k;
 
 // NOINV (diagnostic library, TIMING ONLY, wrong outputs): the block without its N/M-point inverse stage -- what batching that stage
 // over several blocks could save at most
-template <int LOG2M, bool DYN = false, bool NOINV = false>
-__global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_decim_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+template <int LOG2M, bool DYN = false, bool NOINV = false, int OCC = 4>
+__global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                         size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                         const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
                                                                         size_t nblocks, unsigned M2, unsigned magic2, size_t n_dec2,
@@ -448,6 +448,14 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
         return PCX_OK;
     }
 #endif
+    // (the factors with a cofactor M2 stay on this kernel) three workgroups per CU as above: PCX_DECIM_OCC=4 (diagnostic library) for A/B
+    if (!dyn && PCX_ENV_INT("PCX_DECIM_OCC", 3) == 3) {
+        hipLaunchKernelGGL((fir_cf32_ols4096_decim_kernel<LOG2M, false, false, 3>), dim3(persistent_grid(nblocks, 768)), dim3(256), 0, st, (const float2 *)in,
+                           in_elems, (float2 *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks,
+                           (unsigned)M2, magic2, n_out / M2, (pcx::SchedState *)nullptr);
+        PCX_LAUNCH_CHECK();
+        return PCX_OK;
+    }
     if (dyn)
         hipLaunchKernelGGL((fir_cf32_ols4096_decim_kernel<LOG2M, true>), dim3(grid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out,
                            (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096, first_full, nfull, nblocks, (unsigned)M2, magic2,

@@ -1014,7 +1014,7 @@ struct pcx_fft {
     int log2n = 0;
     DevBuf tw, perm;
     StageBuf wsIn, wsOut;
-    DevBuf sched;            // dynamic frame assignment of fft4096_kernel (pcx_sched.hpp), zeroed at create
+    DevBuf sched;            // dynamic frame assignment of fft4096_kernel (pcx_sched.hpp; diagnostic A/B only since the family kernel took over), zeroed at create
     std::vector<int> radix;  // kf_factor order (kissfft.hh:38-55 / kiss_fft.c:309-328 give the same list)
     // FOURSTEP (fft_large.hip): numBins = n1 * n2, both within the single-workgroup plans
     size_t n1 = 0, n2 = 0;

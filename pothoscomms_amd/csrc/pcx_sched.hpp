@@ -96,7 +96,8 @@ struct BlockWalk<false> {
     __device__ __forceinline__ void finish(int) {}
 };
 
-// The same dealing for a kernel that prefetches the NEXT block's input while it works on the current one (fft4096_kernel):
+// The same dealing for a kernel that prefetches the NEXT block's input while it works on the current one (fft4096_kernel, which
+// the product no longer runs -- fft.hip: the plain family kernel measured faster -- and the diagnostic library keeps for that A/B):
 // the next block's index must be known at the START of a block, so the draw for chunk c+1 is issued during the FIRST
 // block of chunk c, published in front of one of that block's barriers and read at the start of the chunk's second block.
 // (Only the launch's last chunk can be a single block, and nothing follows it.)

@@ -617,6 +617,155 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
     walk.finish(j);
 }
 
+// --------------------------------------------------------------------------------- //
+// The interpolating filter with its SHORT FORWARD stage batched over G consecutive blocks -- the mirror of
+// fir_cf32_ols4096_decim_batched_kernel.  The N/L-point forward transform of a block keeps 16 P of the 256 lanes busy (P = 16/L
+// sub-transforms of 256 points); here the input windows of G blocks are loaded together (G P values per lane in flight), all
+// G P sub-transforms run side by side on 16 lanes each, the lane's values of every block are parked in registers, and the
+// blocks then go through twiddle, radix-P stage, H and the full inverse one after the other.  Three workgroups per CU.
+// --------------------------------------------------------------------------------- //
+template <int LOG2L, int LOG2G, bool HREG>
+__global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+                                                                                 size_t n_out, const float2 *__restrict__ Hspec, int Kov_in, int pad_in,
+                                                                                 const float2 *__restrict__ twtab, size_t nblocks)
+{
+    constexpr int L = 1 << LOG2L, P = 16 / L, LOG2P = 4 - LOG2L, ND = 256 * P, G = 1 << LOG2G, T = G * P;
+    static_assert(T <= 16, "at most 16 sub-transforms of 256 points fill the workgroup");
+    constexpr int FRAME = 272;
+    __shared__ cf lds[LDS_ELEMS];
+    const int j = threadIdx.x;
+    const size_t S_in = (size_t)(ND - Kov_in), S_out = S_in << LOG2L;
+    const int Kov_out = Kov_in << LOG2L;
+    const size_t ngroups = (nblocks + G - 1) / G;
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
+    cf Hr[16];
+    if (HREG) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) Hr[k] = Hg[256 * k];
+    }
+    cf td1;
+    {
+        float sn, cs;
+        sincospif(-2.0f * (float)j / (float)ND, &sn, &cs);
+        td1 = cf{cs, sn};
+    }
+    const int fi = j >> 4, l = j & 15;
+    const bool sub = j < 16 * T;
+
+    for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        // the G input windows (ND samples each, from input index b*S_in - pad_in; what lies before the buffer or behind it reads 0)
+        cf xx[T];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const size_t b = grp * G + g;
+            const size_t start = b * S_in;
+            const size_t shift = start >= (size_t)pad_in ? 0 : (size_t)pad_in - start;
+            const size_t first = start + shift - pad_in;
+            const size_t left = (b < nblocks && in_elems > first) ? in_elems - first : 0;     // a block past the end loads nothing
+            const size_t want = (size_t)ND - shift;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + (b < nblocks ? first : 0), (unsigned)((left < want ? left : want) * 8));
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (j + 256 * i - (int)shift) * 8, 0, 0);
+                xx[g * P + i] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+            }
+        }
+        __syncthreads();                                  // the previous group's last inverse is done with the image
+        // polyphase component n1 = n mod P of block g's window goes to sub-frame g P + n1 at position n / P  (n = j + 256 i)
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const int n2 = (j >> LOG2P) + (256 >> LOG2P) * i;
+                lds[(g * P + (j & (P - 1))) * FRAME + n2 + (n2 >> 4)] = xx[g * P + i];
+            }
+        }
+        __syncthreads();
+        cf w[16];
+        cf *fr = lds + fi * FRAME;
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            fft16_plain(w);
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
+        }
+        __syncthreads();
+        if (sub) {
+#pragma unroll
+            for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
+            LaneTw tl;
+            const cf *t2 = lds + LDS_DATA + l;
+#pragma unroll
+            for (int p = 0; p < 3; p++) tl.a[p] = t2[p * 16];
+#pragma unroll
+            for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
+            fft16_tw(w, tl);
+        }
+        __syncthreads();                                  // every lane of a frame has read its inputs
+        if (sub) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int k2 = l + 16 * bin_of(q);
+                fr[k2 + (k2 >> 4)] = w[q];
+            }
+        }
+        __syncthreads();
+        // park the lane's values of every block: the inverse passes below reuse the image
+        cf gg[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) gg[t] = lds[t * FRAME + j + (j >> 4)];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const size_t b = grp * G + g;
+            if (b >= nblocks) break;                      // (workgroup-uniform)
+            // lane j: Xs[j + 256 r'] = sum_n1 W_P^(n1 r') W_ND^(n1 j) G_n1[j]
+            cf gv[P];
+#pragma unroll
+            for (int n1 = 0; n1 < P; n1++) gv[n1] = gg[g * P + n1];
+            {
+                cf t = td1;
+#pragma unroll
+                for (int n1 = 1; n1 < P; n1++) {
+                    gv[n1] = cmul1(gv[n1], t);
+                    if (n1 + 1 < P) t = cmul1(t, td1);
+                }
+            }
+            if constexpr (P == 8) fft8(gv[0], gv[1], gv[2], gv[3], gv[4], gv[5], gv[6], gv[7]);
+            else if constexpr (P == 4) fft4(gv[0], gv[1], gv[2], gv[3]);
+            else if constexpr (P == 2) { const cf a = gv[0], c = gv[1]; gv[0] = a + c; gv[1] = a - c; }
+            const cf *Hb = Hg;
+            asm volatile("" : "+v"(Hb));
+            cf u[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                u[r] = gv[r & (P - 1)];
+                u[r + 1] = gv[(r + 1) & (P - 1)];
+                if (HREG) cmul2_conj(u[r], u[r + 1], Hr[r], Hr[r + 1]);
+                else cmul2_conj(u[r], u[r + 1], Hb[256 * r], Hb[256 * (r + 1)]);
+            }
+            pass1(u, lds, j);                             // (opens with a barrier: every lane has parked its values by now)
+            pass2(u, lds, j);
+            pass3(u, lds, j, tw3);
+            const size_t room = n_out - b * S_out;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S_out, (unsigned)((room < S_out ? room : S_out) * 8));
+            const unsigned vbase = (unsigned)(j - Kov_out) * 8u;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int row = 256 * bin_of(q);
+                if (row + 255 < Kov_out) continue;
+                store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
+            }
+        }
+    }
+}
+
 template <int LOG2L>
 int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, const void *tw4096, void *sched, hipStream_t st)
 {
@@ -631,6 +780,32 @@ int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, con
     // than the fourth workgroup, as for the decimator -- L = 2 / 4 / 8 / 16: 268 / 309 / 227 / 263 -> 309 / 329 / 250 / 277 Gsamples/s of
     // output, with H held in registers too at L >= 8 (tools/ab_interp.sh, profiles/r02/ab_interp.txt).  PCX_INTERP_OCC=4 (diagnostic
     // library) brings the four-per-CU build back for A/B, PCX_INTERP_HREG overrides the H choice.
+    // The short forward stage batched over 2^lgi blocks (fir_cf32_ols4096_interp_batched_kernel) where it measured faster, three interleaved
+    // repeats on one box (tools/ab_interp.sh, profiles/r02/ab_interp.txt): L = 8 two blocks 240-243 -> 250-255 Gsamples/s of output, L = 16
+    // four blocks 277-280 -> 300-305; L = 2 loses 10 % and L = 4 is inside the noise, so they keep the one-block kernel.
+    // PCX_INTERP_G (diagnostic library) overrides: 0 = one block, 1 / 2 / 3 = two / four / eight.
+    const int lgi = (int)PCX_ENV_INT("PCX_INTERP_G", LOG2L == 3 ? 1 : LOG2L == 4 ? 2 : 0);
+    if (!dyn && lgi > 0) {
+        constexpr int LGMAX = LOG2L == 1 ? 1 : LOG2L == 2 ? 2 : 3;
+        const int lg = lgi > LGMAX ? LGMAX : lgi;
+        const bool hreg = PCX_ENV_INT("PCX_INTERP_HREG", LOG2L >= 3 ? 1 : 0) != 0;
+        const size_t ngroups = (nblocks + ((size_t)1 << lg) - 1) >> lg;
+        const unsigned gb = persistent_grid(ngroups, 768);
+#define PCX_INTERP_ARGS dim3(gb), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_iter * L, (const float2 *)Hspec, (int)Kov_in, \
+                        (int)pad_in, (const float2 *)tw4096, nblocks
+#define PCX_INTERP_LAUNCH(LG)                                                                                                   \
+        do {                                                                                                                    \
+            if (hreg) hipLaunchKernelGGL((fir_cf32_ols4096_interp_batched_kernel<LOG2L, LG, true>), PCX_INTERP_ARGS);              \
+            else hipLaunchKernelGGL((fir_cf32_ols4096_interp_batched_kernel<LOG2L, LG, false>), PCX_INTERP_ARGS);                  \
+        } while (0)
+        if (lg == 1) PCX_INTERP_LAUNCH(1);
+        else if (lg == 2) PCX_INTERP_LAUNCH((LGMAX >= 2 ? 2 : 1));
+        else PCX_INTERP_LAUNCH((LGMAX >= 3 ? 3 : 1));
+#undef PCX_INTERP_LAUNCH
+#undef PCX_INTERP_ARGS
+        PCX_LAUNCH_CHECK();
+        return PCX_OK;
+    }
     if (!dyn && PCX_ENV_INT("PCX_INTERP_OCC", 3) == 3) {
         const unsigned g3 = persistent_grid(nblocks, 768);
         if (PCX_ENV_INT("PCX_INTERP_HREG", LOG2L >= 3 ? 1 : 0) != 0)

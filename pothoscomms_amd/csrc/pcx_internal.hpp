@@ -84,13 +84,14 @@ struct PinBuf {
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
 };
-// ROCTx range around a C-ABI entry point while pcx_trace(1) is in force (pcx_api.hip); one relaxed load otherwise
+// ROCTx range around a C-ABI entry point while pcx_trace(1) is in force (pcx_api.hip); one acquire load otherwise (it pairs with the
+// store that publishes the function pointers)
 extern std::atomic<int> g_trace_on;
 extern int (*g_roctx_push)(const char *);
 extern int (*g_roctx_pop)();
 struct TraceRange {
     bool on;
-    explicit TraceRange(const char *name) : on(g_trace_on.load(std::memory_order_relaxed) != 0) { if (on) (void)g_roctx_push(name); }
+    explicit TraceRange(const char *name) : on(g_trace_on.load(std::memory_order_acquire) != 0) { if (on) (void)g_roctx_push(name); }
     ~TraceRange() { if (on) (void)g_roctx_pop(); }
     TraceRange(const TraceRange &) = delete;
     TraceRange &operator=(const TraceRange &) = delete;

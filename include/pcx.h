@@ -40,9 +40,14 @@
  *     call is ordered behind it (an event), carried state and all; setters
  *     that rewrite device tables first wait for the handle's outstanding
  *     work; reset() is enqueued behind the previous call and ahead of the
- *     next.  Setters cannot be captured into a hipGraph; *_dev calls can,
- *     once the handle's tables are uploaded (its first call after a setter)
- *     and on the stream of the handle's previous call.
+ *     next.  Setters cannot be captured into a hipGraph; *_dev calls and
+ *     reset() can, once the handle's tables are uploaded (its first call
+ *     after a setter) and on the stream of the handle's previous call.
+ *     A handle with carried state (pcx_freqdemod, pcx_fmchain) keeps it in
+ *     two device slots it alternates between, and a captured call replays
+ *     with the slots it was captured with: capture reset() in front of the
+ *     calls (every replay starts a new stream), or an EVEN number of calls
+ *     per handle (every replay continues where the previous one ended).
  *   - the library reads no environment variable.
  *   - input and output buffers of one call must not overlap, with two exceptions the reference
  *     relies on or that cost nothing: the same-size element-wise maps (rotate, scale, conj, arith)

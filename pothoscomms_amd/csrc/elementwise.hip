@@ -461,6 +461,22 @@ static int launch_freqdemod_t(const void *in, void *out, size_t n, const void *p
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
+// Zeroing a handle's carried state as a KERNEL, not as hipMemsetAsync: a reset captured into a hipGraph then replays correctly.  (With
+// the memset node the first replay was right and later ones started from non-zero state once other work had run in between --
+// torch's allocator and kernels in the same process; tools/graph_probe*.py.  A kernel node carries its own copy of its arguments.)
+__global__ void zero_words_kernel(unsigned *p, unsigned nwords)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nwords) p[i] = 0u;
+}
+int launch_zero_words(void *p, size_t nwords, hipStream_t st)
+{
+    if (nwords == 0) return PCX_OK;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((nwords + 63) / 64)), dim3(64), 0, st, static_cast<unsigned *>(p), (unsigned)nwords);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 int launch_freqdemod(int scalar, const void *in, void *out, size_t n, const void *prev_in, void *prev_out, hipStream_t st)
 {
     switch (scalar) {

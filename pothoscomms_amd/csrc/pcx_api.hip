@@ -1410,10 +1410,21 @@ int pcx_freqdemod_reset(pcx_freqdemod *h)
     hipStream_t st = h->cx.have_last ? h->cx.last : nullptr;
     if (!h->cx.have_last) PCX_TRY(ctx_own_stream(h->cx, &st));
     PCX_TRY(ctx_enter(h->cx, st));
-    PCX_HIP(hipMemsetAsync(h->prev.p, 0, 64, st));
+    PCX_TRY(launch_zero_words(h->prev.p, 16, st));   // (a kernel, not hipMemsetAsync: see launch_zero_words)
     h->cur = 0;
     return PCX_OK;
 }
+#ifdef PCX_DIAG
+// (diagnostic library only) the 64 bytes of carried state and the slot the next call reads, after a device synchronise
+extern "C" __attribute__((visibility("default"))) int pcx_diag_freqdemod_state(pcx_freqdemod *h, void *out64, int *cur)
+{
+    if (!h || !out64 || !cur) return PCX_ERR_ARG;
+    PCX_HIP(hipDeviceSynchronize());
+    PCX_HIP(hipMemcpy(out64, h->prev.p, 64, hipMemcpyDeviceToHost));
+    *cur = h->cur;
+    return PCX_OK;
+}
+#endif
 int pcx_freqdemod_process_dev(pcx_freqdemod *h, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
     PCX_TRACE();
@@ -1712,7 +1723,7 @@ int pcx_fmchain_reset(pcx_fmchain *h)
     hipStream_t st = h->cx.have_last ? h->cx.last : nullptr;
     if (!h->cx.have_last) PCX_TRY(ctx_own_stream(h->cx, &st));
     PCX_TRY(ctx_enter(h->cx, st));
-    PCX_HIP(hipMemsetAsync(h->prev.p, 0, 64, st));
+    PCX_TRY(launch_zero_words(h->prev.p, 16, st));   // (a kernel, not hipMemsetAsync: see launch_zero_words)
     h->cur = 0;
     return PCX_OK;
 }

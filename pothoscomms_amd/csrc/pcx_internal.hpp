@@ -174,6 +174,7 @@ inline unsigned rounds_grid(size_t units, unsigned slots, unsigned rounds)
 }
 
 // ---- kernel launchers implemented in the .hip files ----
+int launch_zero_words(void *p, size_t nwords, hipStream_t st);   // (elementwise.hip) a kernel, so that a captured reset replays
 int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n, hipStream_t st);
 int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st);
 int launch_abs(int scalar, int is_complex, const void *in, void *out, size_t n, hipStream_t st);

@@ -186,6 +186,39 @@ def test_process_dev_can_be_captured_into_a_graph(oracle, dev):
     ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h); ref.activate()
     xw = x[:60000 + K - 1].cpu().numpy()
     assert nerr(y[:60000].cpu().numpy(), ref.work(xw, 60000)[0]) <= TOL
+    # the other launch shapes: decimating and interpolating filters (batched stages), the FFT, the fused chain with its carried state
+    fd = dev.FirFilter("complex_float32", "COMPLEX"); fd.set_taps(h); fd.set_decimation(8)
+    fi = dev.FirFilter("complex_float32", "COMPLEX"); fi.set_taps(tp.complex_bandpass(255 * 8, 0.05 / 8, 0.05 / 8) * 8); fi.set_interpolation(8)
+    t = dev.Fft("complex_float32", 4096, False)
+    ch = dev.FmChain(); ch.set_phase(0.3); ch.set_taps(tp.c4_taps(), False)
+    nd = (n // 8) * 8
+    yd = torch.empty((nd // 8, 2), dtype=torch.float32, device=d)
+    ni = n // 8
+    yi = torch.empty((ni * 8, 2), dtype=torch.float32, device=d)
+    yf = torch.empty((n, 2), dtype=torch.float32, device=d)
+    yc = torch.empty(n, dtype=torch.float32, device=d)
+    Ki, Kc = fi.K, len(tp.c4_taps())
+
+    def run():
+        fd.process_dev(x, yd, nd + K - 1, nd // 8)
+        fi.process_dev(x, yi, ni + Ki - 1, ni * 8)
+        t.transform_dev(x, yf, n // 4096)
+        ch.reset()
+        ch.process_dev(x, yc, n + Kc - 1, n)
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.synchronize()
+    wants = [v.clone() for v in (yd, yi, yf, yc)]
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        run()
+    for _ in range(3):
+        for v in (yd, yi, yf, yc):
+            v.fill_(float("nan"))
+        g2.replay()
+        torch.cuda.synchronize()
+        for v, w in zip((yd, yi, yf, yc), wants):
+            assert torch.equal(v, w)
 
 
 def test_a_new_handle_is_ready_when_create_returns(oracle, dev):
@@ -229,3 +262,46 @@ def test_a_new_handle_is_ready_when_create_returns(oracle, dev):
         if want is None:
             want = y
         assert np.array_equal(y, want), rep
+
+
+def test_captured_stateful_calls_reset_or_pairs(oracle, dev):
+    """include/pcx.h: a captured reset() + call starts every replay from zero state; a captured PAIR of calls carries the state from
+    one replay into the next (the handle alternates between two device slots, and a graph replays the slots it was captured with)"""
+    import torch
+    d = torch.device("cuda", 0)
+    n = 1 << 16
+    rng = np.random.default_rng(3)
+    ph = np.cumsum(rng.uniform(-1.0, 1.0, 2 * n))
+    xh = np.stack([np.cos(ph), np.sin(ph)], 1).astype(np.float32)
+    x = torch.from_numpy(xh).to(d)
+    y = torch.empty(2 * n, dtype=torch.float32, device=d)
+    s = torch.cuda.Stream(d)
+    # reset + one call: every replay is the stream from its start
+    dm = dev.FreqDemod("complex_float32")
+    with torch.cuda.stream(s):
+        dm.reset(); dm.process_dev(x[:n], y[:n], n, stream=s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        dm.reset(); dm.process_dev(x[:n], y[:n], n, stream=s)
+    want = oracle.FreqDemod(oracle.F32).work(xh[:n])
+    for _ in range(4):
+        y.fill_(float("nan"))
+        junk = (x * 2).sum()                      # other work in between (a captured hipMemsetAsync did not survive this)
+        g.replay(); torch.cuda.synchronize()
+        assert ang_err(y[:n].cpu().numpy(), want) <= TOL
+    # a pair of calls: replay r continues from replay r-1
+    dm2 = dev.FreqDemod("complex_float32")
+    with torch.cuda.stream(s):
+        dm2.process_dev(x[:n], y[:n], n, stream=s); dm2.process_dev(x[n:], y[n:], n, stream=s)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        dm2.process_dev(x[:n], y[:n], n, stream=s); dm2.process_dev(x[n:], y[n:], n, stream=s)
+    ref = oracle.FreqDemod(oracle.F32)
+    ref.work(xh)                                    # the eager pass above
+    for _ in range(3):
+        want2 = ref.work(xh)                        # the reference keeps streaming: xh again, state carried
+        y.fill_(float("nan"))
+        g2.replay(); torch.cuda.synchronize()
+        assert ang_err(y.cpu().numpy(), want2) <= TOL

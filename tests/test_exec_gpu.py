@@ -305,3 +305,31 @@ def test_captured_stateful_calls_reset_or_pairs(oracle, dev):
         y.fill_(float("nan"))
         g2.replay(); torch.cuda.synchronize()
         assert ang_err(y.cpu().numpy(), want2) <= TOL
+
+
+def test_a_handle_can_be_destroyed_with_its_work_still_in_flight(oracle, dev):
+    """*_dev calls only enqueue; destroying the handle right behind them must not pull the tables from under the running kernel
+    (hipFree waits for the device) -- a Pothos topology tears blocks down without draining the device first"""
+    import torch
+    from pothoscomms_amd import taps as tp
+    d = torch.device("cuda", 0)
+    h = tp.c1_taps()
+    K, n = len(h), 32 << 20
+    x = torch.empty((n + K - 1, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(x, seed=8)
+    y = torch.full((n, 2), float("nan"), dtype=torch.float32, device=d)
+    yc = torch.full((n,), float("nan"), dtype=torch.float32, device=d)
+    s = torch.cuda.Stream(d)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h)
+        ch = dev.FmChain(); ch.set_phase(0.2); ch.set_taps(tp.c4_taps(), False)
+        f.process_dev(x, y, n + K - 1, n, stream=s)
+        ch.process_dev(x, yc, n + len(tp.c4_taps()) - 1, n, stream=s)
+        del f, ch                                   # destroy with both kernels queued or running
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(yc).all())
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h); ref.activate()
+    for start in (0, n - 50000):
+        xw = x[start:start + 50000 + K - 1].cpu().numpy()
+        assert nerr(y[start:start + 50000].cpu().numpy(), ref.work(xw, 50000)[0]) <= TOL

@@ -49,15 +49,52 @@ int DevBuf::ensure(size_t bytes)
     cap = want;
     return PCX_OK;
 }
-// hipMemset on device memory returns before the fill has run (it is queued on the null stream), and the handles' own streams
-// are non-blocking: the fill must be COMPLETE before a handle is handed out, or its first kernel races it (found by the
-// fuzz soak, eight processes on one GPU: FreqDemod's first output read the previous owner's _prev, or the late fill wiped
-// the state the first call had written)
+// Control-plane transfers (tables at set_taps / create, zeroed state) must be COMPLETE on the device when the call returns: the kernels
+// that use them run on non-blocking streams, which wait for nothing.  What proved reliable for that, under every runtime mode tried
+// (eight processes on the GPU; AMD_DIRECT_DISPATCH=0; GPU_MAX_HW_QUEUES=1/8; HSA_ENABLE_SDMA=0), is ONE recipe: a page-locked source
+// of the library's own, hipMemcpyAsync / a kernel on a non-blocking stream of the library's own, hipStreamSynchronize on that stream.
+// What did not: hipMemset (returns before the fill has run) and hipMemcpy from pageable memory followed by a null-stream
+// synchronise (under AMD_DIRECT_DISPATCH=0 the first kernel of a new handle still read an empty table five times out of six:
+// tools/shard_dd_probe.py; in the default mode about one first call in 10^5 under load).
+namespace {
+struct ControlLane {           // per host thread: a stream and a staging buffer for the device that is current
+    int device = -1;
+    hipStream_t st = nullptr;
+    PinBuf pin;
+    void drop()
+    {
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+        pin.release();
+        device = -1;
+    }
+    ~ControlLane() { drop(); }
+};
+thread_local ControlLane g_lane;
+int control_lane(ControlLane **out)
+{
+    int cur = -1;
+    PCX_HIP(hipGetDevice(&cur));
+    if (g_lane.device != cur) {
+        if (g_lane.device >= 0) {
+            (void)hipSetDevice(g_lane.device);
+            g_lane.drop();
+            PCX_HIP(hipSetDevice(cur));
+        }
+        g_lane.device = cur;
+    }
+    if (!g_lane.st) PCX_HIP(hipStreamCreateWithFlags(&g_lane.st, hipStreamNonBlocking));
+    *out = &g_lane;
+    return PCX_OK;
+}
+}  // namespace
 int DevBuf::ensure_zeroed(size_t bytes)
 {
     PCX_TRY(ensure(bytes));
-    PCX_HIP(hipMemsetAsync(p, 0, bytes, nullptr));
-    PCX_HIP(hipStreamSynchronize(nullptr));
+    ControlLane *lane;
+    PCX_TRY(control_lane(&lane));
+    PCX_TRY(launch_zero_words(p, (bytes + 3) / 4, lane->st));     // (ensure() rounds the allocation up to 4 KiB: whole words exist)
+    PCX_HIP(hipStreamSynchronize(lane->st));
     return PCX_OK;
 }
 void DevBuf::release()
@@ -67,16 +104,19 @@ void DevBuf::release()
     cap = 0;
 }
 
-// upload a host vector into a DevBuf (control plane: COMPLETE on return).  hipMemcpy from pageable memory may return once
-// the source has been staged, with the transfer to the device still queued on the null stream -- which the handles' own
-// non-blocking streams do not wait for -- so the null stream is drained before the table counts as uploaded (the fuzz soak,
-// eight processes on one GPU: about one first call in 10^5 ran on a table that had not landed yet)
+// upload a host vector into a DevBuf (control plane: COMPLETE on return; the recipe above)
 template <typename T>
 static int upload(DevBuf &b, const std::vector<T> &v)
 {
-    PCX_TRY(b.ensure(v.size() * sizeof(T)));
-    PCX_HIP(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    PCX_HIP(hipStreamSynchronize(nullptr));
+    const size_t bytes = v.size() * sizeof(T);
+    PCX_TRY(b.ensure(bytes));
+    if (bytes == 0) return PCX_OK;
+    ControlLane *lane;
+    PCX_TRY(control_lane(&lane));
+    PCX_TRY(lane->pin.ensure(bytes));
+    std::memcpy(lane->pin.p, v.data(), bytes);
+    PCX_HIP(hipMemcpyAsync(b.p, lane->pin.p, bytes, hipMemcpyHostToDevice, lane->st));
+    PCX_HIP(hipStreamSynchronize(lane->st));
     return PCX_OK;
 }
 
@@ -793,6 +833,15 @@ static int fir_sync_tables(pcx_fir *h)
     h->dirty = false;
     return PCX_OK;
 }
+
+// (internal, pcx_shard.hip) upload the handle's tables now -- every allocation and transfer of the control plane -- instead of at its next call
+namespace pcx {
+int fir_prepare(pcx_fir *h)
+{
+    DeviceScope dev_scope(h->cx.device);
+    return fir_sync_tables(h);
+}
+}  // namespace pcx
 
 int pcx_fir_create(int scalar, int is_complex, int complex_taps, pcx_fir **out)
 {

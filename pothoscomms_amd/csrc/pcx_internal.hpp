@@ -98,6 +98,8 @@ struct TraceRange {
 };
 #define PCX_TRACE() ::pcx::TraceRange pcx_trace_range_(__func__)
 
+// (pcx_api.hip, for pcx_shard.hip) upload a FIR handle's tables now instead of at its next call
+int fir_prepare(struct ::pcx_fir *h);
 // device-visible alias of a host pointer when it is page-locked (pcx_api.hip), else nullptr
 void *device_alias(const void *p);
 // staging pair of one direction of a host-pointer call (pcx_api.hip stage_in / stage_out_*)

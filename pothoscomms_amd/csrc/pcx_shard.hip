@@ -310,6 +310,15 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
     DeviceGuard guard;
     const float2 *x = static_cast<const float2 *>(host_stream);
     const bool locked = device_alias(host_stream) != nullptr;
+    if (!locked) {
+        // every bounce buffer is in place BEFORE the first transfer is queued: a page-locked allocation made while another shard's
+        // copy was pending left that copy's destination zero (first pass only, AMD_DIRECT_DISPATCH=0: tools/shard_dd_probe.py)
+        for (int g = 0; g < s->G; g++) {
+            PCX_HIP(hipSetDevice(s->dev[g]));
+            PCX_HIP(hipStreamSynchronize(s->st[g]));      // the bounce buffer's previous transfer
+            PCX_TRY(s->bounce_in[g]->ensure((s->K - 1 + s->C) * sizeof(float2)));
+        }
+    }
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         // shard 0 also takes the stream's own K-1 history; every other halo slot is filled by the exchange of each pass
@@ -318,8 +327,6 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
         const float2 *src = x + (size_t)g * s->C + skip;
         if (!locked) {
             PinBuf &b = *s->bounce_in[g];
-            PCX_HIP(hipStreamSynchronize(s->st[g]));      // the bounce buffer's previous transfer
-            PCX_TRY(b.ensure(bytes));
             constexpr size_t kPiece = (size_t)4 << 20;     // the CPU copies piece i+1 while piece i is on the wire
             for (size_t off = 0; off < bytes; off += kPiece) {
                 const size_t c = bytes - off < kPiece ? bytes - off : kPiece;
@@ -343,13 +350,14 @@ int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
     float2 *y = static_cast<float2 *>(host_out);
     const bool locked = device_alias(host_out) != nullptr;
     const size_t bytes = s->C * sizeof(float2);
+    if (!locked)
+        for (int g = 0; g < s->G; g++) {                  // (allocations first, transfers afterwards: see pcx_shard_scatter)
+            PCX_HIP(hipSetDevice(s->dev[g]));
+            PCX_TRY(s->bounce_out[g]->ensure(bytes));
+        }
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
-        void *dst = y + (size_t)g * s->C;
-        if (!locked) {
-            PCX_TRY(s->bounce_out[g]->ensure(bytes));
-            dst = s->bounce_out[g]->p;
-        }
+        void *dst = locked ? static_cast<void *>(y + (size_t)g * s->C) : s->bounce_out[g]->p;
         PCX_HIP(hipMemcpyAsync(dst, s->out[g], bytes, hipMemcpyDeviceToHost, s->st[g]));
     }
     for (int g = 0; g < s->G; g++) {
@@ -390,6 +398,13 @@ int pcx_shard_step(pcx_shard *s)
     DeviceGuard guard;
     const int G = s->G;
     const size_t halo = s->K - 1, hbytes = halo * sizeof(float2);
+    // every shard's tables are on its device BEFORE anything of the pass is queued: uploading them lazily -- allocations and
+    // transfers of the control plane -- between other shards' queued work lost one shard's pass (AMD_DIRECT_DISPATCH=0,
+    // tests/test_shard_gpu.py retap test; the rule of pcx_shard_scatter)
+    for (int g = 0; g < G; g++) {
+        PCX_HIP(hipSetDevice(s->dev[g]));
+        PCX_TRY(fir_prepare(s->fir[g]));
+    }
     if (G == 1 || halo == 0) {
         // nothing to exchange: each shard is one plain call (with one device, exactly pcx_fir_process_dev on the whole stream)
         for (int g = 0; g < G; g++) {

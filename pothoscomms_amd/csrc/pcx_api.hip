@@ -423,6 +423,15 @@ void StageBuf::release()
     dev.release();
     pin.release();
 }
+// Every staging buffer of a call is in place BEFORE its first transfer is queued (no allocation between queuing a transfer and its
+// completion: profiles/r02/contention.md section 4).  The host entry points reserve all their directions first.
+static int stage_reserve(const void *host, size_t bytes, StageBuf &ws)
+{
+    if (device_alias(host)) return PCX_OK;
+    PCX_TRY(ws.dev.ensure(bytes));
+    PCX_TRY(ws.pin.ensure(bytes));
+    return PCX_OK;
+}
 static int stage_in(const void *host, size_t bytes, StageBuf &ws, hipStream_t st, const void **dev)
 {
     if (void *a = device_alias(host)) { *dev = a; return PCX_OK; }
@@ -1044,7 +1053,9 @@ int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size
     // Everything goes through the handle's own stream.
     hipStream_t st;
     PCX_TRY(ctx_own_stream(h->cx, &st));
+    PCX_TRY(fir_sync_tables(h));        // (tables first: nothing of the control plane between the transfers queued below)
     const void *din; void *dout; bool staged;
+    PCX_TRY(stage_reserve(out, n_out * esz, h->wsOut));
     PCX_TRY(stage_in(in, used_in * esz, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, n_out * esz, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_fir_process_dev(h, din, used_in, dout, n_out, consumed, produced, st));
@@ -1420,6 +1431,7 @@ int pcx_fft_transform(pcx_fft *h, const void *in, void *out, size_t nframes)
     hipStream_t st;
     PCX_TRY(ctx_own_stream(h->cx, &st));
     const void *din; void *dout; bool staged;
+    PCX_TRY(stage_reserve(out, bytes, h->wsOut));
     PCX_TRY(stage_in(in, bytes, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, bytes, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_fft_transform_dev(h, din, dout, nframes, st));
@@ -1500,6 +1512,7 @@ int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
     hipStream_t st;
     PCX_TRY(ctx_own_stream(h->cx, &st));
     const void *din; void *dout; bool staged;
+    PCX_TRY(stage_reserve(out, n * sb, h->wsOut));
     PCX_TRY(stage_in(in, n * 2 * sb, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, n * sb, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_freqdemod_process_dev(h, din, dout, n, st));
@@ -1552,6 +1565,7 @@ static int run_host_map(const void *in, void *out, size_t in_bytes, size_t out_b
     MapWs *ws;
     PCX_TRY(map_ws(&ws));
     const void *din; void *dout; bool staged;
+    PCX_TRY(stage_reserve(out, out_bytes, ws->out));
     PCX_TRY(stage_in(in, in_bytes, ws->in, ws->st, &din));
     PCX_TRY(stage_out_begin(out, out_bytes, ws->out, &dout, &staged));
     PCX_TRY(launch(din, dout, ws->st));
@@ -1656,6 +1670,8 @@ int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *i
     MapWs *ws;
     PCX_TRY(map_ws(&ws));
     const void *d0, *d1; void *dout; bool staged;
+    PCX_TRY(stage_reserve(in1, b, ws->in2));
+    PCX_TRY(stage_reserve(out, b, ws->out));
     PCX_TRY(stage_in(in0, b, ws->in, ws->st, &d0));
     PCX_TRY(stage_in(in1, b, ws->in2, ws->st, &d1));
     PCX_TRY(stage_out_begin(out, b, ws->out, &dout, &staged));
@@ -1680,6 +1696,8 @@ int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n)
     MapWs *ws;
     PCX_TRY(map_ws(&ws));
     const void *din; void *dre, *dim; bool sre, sim;
+    PCX_TRY(stage_reserve(re, b, ws->out));
+    PCX_TRY(stage_reserve(im, b, ws->out2));
     PCX_TRY(stage_in(in, 2 * b, ws->in, ws->st, &din));
     PCX_TRY(stage_out_begin(re, b, ws->out, &dre, &sre));
     PCX_TRY(stage_out_begin(im, b, ws->out2, &dim, &sim));
@@ -1705,6 +1723,8 @@ int pcx_combine_complex(int scalar, const void *re, const void *im, void *out, s
     MapWs *ws;
     PCX_TRY(map_ws(&ws));
     const void *dre, *dim; void *dout; bool staged;
+    PCX_TRY(stage_reserve(im, b, ws->in2));
+    PCX_TRY(stage_reserve(out, 2 * b, ws->out));
     PCX_TRY(stage_in(re, b, ws->in, ws->st, &dre));
     PCX_TRY(stage_in(im, b, ws->in2, ws->st, &dim));
     PCX_TRY(stage_out_begin(out, 2 * b, ws->out, &dout, &staged));
@@ -1887,6 +1907,7 @@ int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *o
     hipStream_t st;
     PCX_TRY(ctx_own_stream(h->cx, &st));
     const void *din; void *dout; bool staged;
+    PCX_TRY(stage_reserve(out, N * 4, h->wsOut));
     PCX_TRY(stage_in(in, used * 8, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, N * 4, h->wsOut, &dout, &staged));
     PCX_TRY(pcx_fmchain_process_dev(h, din, used, dout, N, consumed, produced, st));

@@ -12,6 +12,7 @@ for n in (1 << 16, 1 << 20, 1 << 24):
     for _ in range(reps): y, c, p = f.process(x, n)
     dt = (time.perf_counter() - t0) / reps
     print("fir host path  n=%9d  %.3f ms  %.2f Gsamples/s  (%.1f GB/s each way)" % (n, dt * 1e3, n / dt / 1e9, 8 * n / dt / 1e9))
+    device.conj(x)                      # (warm-up: the thread's map workspace and its buffers)
     t0 = time.perf_counter()
     for _ in range(reps): device.conj(x)
     dt = (time.perf_counter() - t0) / reps

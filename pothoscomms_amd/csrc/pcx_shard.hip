@@ -313,9 +313,14 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
     if (!locked) {
         // every bounce buffer is in place BEFORE the first transfer is queued: a page-locked allocation made while another shard's
         // copy was pending left that copy's destination zero (first pass only, AMD_DIRECT_DISPATCH=0: tools/shard_dd_probe.py)
+        // -- and nothing of an earlier pass is still running on ANY shard while they are allocated
         for (int g = 0; g < s->G; g++) {
             PCX_HIP(hipSetDevice(s->dev[g]));
             PCX_HIP(hipStreamSynchronize(s->st[g]));      // the bounce buffer's previous transfer
+            PCX_HIP(hipStreamSynchronize(s->hst[g]));
+        }
+        for (int g = 0; g < s->G; g++) {
+            PCX_HIP(hipSetDevice(s->dev[g]));
             PCX_TRY(s->bounce_in[g]->ensure((s->K - 1 + s->C) * sizeof(float2)));
         }
     }
@@ -350,11 +355,18 @@ int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
     float2 *y = static_cast<float2 *>(host_out);
     const bool locked = device_alias(host_out) != nullptr;
     const size_t bytes = s->C * sizeof(float2);
-    if (!locked)
-        for (int g = 0; g < s->G; g++) {                  // (allocations first, transfers afterwards: see pcx_shard_scatter)
+    if (!locked) {
+        // allocations first, transfers afterwards (see pcx_shard_scatter) -- and not while the pass is still running: gather waits
+        // for it in any case, so it waits BEFORE the first page-locked allocation (the halo copies of a pass came out zero when
+        // the first gather allocated behind them; AMD_DIRECT_DISPATCH=0 with eight processes on the device)
+        bool grow = false;
+        for (int g = 0; g < s->G; g++) grow = grow || s->bounce_out[g]->cap < bytes;
+        if (grow) PCX_TRY(pcx_shard_sync(s));
+        for (int g = 0; g < s->G; g++) {
             PCX_HIP(hipSetDevice(s->dev[g]));
             PCX_TRY(s->bounce_out[g]->ensure(bytes));
         }
+    }
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         void *dst = locked ? static_cast<void *>(y + (size_t)g * s->C) : s->bounce_out[g]->p;

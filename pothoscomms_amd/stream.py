@@ -40,6 +40,10 @@ class HaloRing:
         """Post the exchange; returns the requests to pass to finish()."""
         if self.world == 1 or self.halo == 0:
             return []
+        if buf.is_cuda and dist.get_backend(self.group) != "nccl":
+            # RCCL orders its send behind the current stream's earlier work; a host-driven backend (the one-GPU gloo rehearsal)
+            # reads the tail of buf whenever it gets to it, so whatever filled the shard has to be complete first
+            torch.cuda.current_stream(buf.device).synchronize()
         ops = []
         if self.rank + 1 < self.world:
             ops.append(dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], self.rank + 1, self.group))

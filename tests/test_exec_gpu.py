@@ -251,14 +251,19 @@ def test_a_new_handle_is_ready_when_create_returns(oracle, dev):
     xd = torch.from_numpy(xs).to(d)
     want = None
     for rep in range(4):
+        # the output is poisoned and that fill drained BEFORE the null stream is made busy: the handle's stream does not wait for
+        # the null stream, so a fill of yd queued behind the busy work would land on top of the filter's output
+        yd = torch.full((n, 2), float("nan"), dtype=torch.float32, device=d)
+        torch.cuda.synchronize()
         for _ in range(8):
             busy.fill_(1.0)
         f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(t)
-        yd = torch.zeros((n, 2), dtype=torch.float32, device=d)
         s = torch.cuda.Stream(device=d)
-        f.process_dev(xd, yd, n, n, stream=s)
+        c, p = f.process_dev(xd, yd, n, n, stream=s)
         s.synchronize()
-        y = yd.cpu().numpy()
+        assert p == n - 254, (c, p)
+        y = yd[:p].cpu().numpy()
+        assert not np.isnan(y).any(), rep
         if want is None:
             want = y
         assert np.array_equal(y, want), rep

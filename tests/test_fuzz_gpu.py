@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import TOL, ang_err, diff_note, nerr, rand_stream
+from tests.util import TOL, ang_err, d2h, diff_note, h2d, nerr, rand_stream
 
 pytestmark = pytest.mark.gpu
 SEEDS = range(int(os.environ.get("PCX_FUZZ_SEEDS", "12")))
@@ -26,31 +26,31 @@ def test_maps_on_offset_device_buffers(oracle, dev, seed):
     oi, oo = int(rng.integers(0, 5)), int(rng.integers(0, 5))
     x = rand_stream(rng, scalar, n, True)
     xin = torch.zeros((n + 8, 2), dtype=TD, device=d)
-    xin[oi:oi + n] = torch.from_numpy(x).to(d)
+    xin[oi:oi + n] = h2d(x, d)
     xv = xin[oi:oi + n]
     outc = torch.zeros((n + 8, 2), dtype=TD, device=d)
     outr = torch.zeros((n + 8,), dtype=TD, device=d)
     oc, orr = outc[oo:oo + n], outr[oo:oo + n]
     phase = float(rng.uniform(-3, 3))
     dev.rotate(xv, phase, scalar=scalar, out=oc, n=n)
-    assert np.array_equal(oc.cpu().numpy(), oracle.rotate(x, phase))
+    assert np.array_equal(d2h(oc), oracle.rotate(x, phase))
     dev.scale(xv, 0.37, True, scalar=scalar, out=oc, n=n)
-    assert np.array_equal(oc.cpu().numpy(), oracle.scale(x, 0.37, True))
+    assert np.array_equal(d2h(oc), oracle.scale(x, 0.37, True))
     dev.conj(xv, scalar=scalar, out=oc, n=n)
-    assert np.array_equal(oc.cpu().numpy(), oracle.conj(x))
+    assert np.array_equal(d2h(oc), oracle.conj(x))
     dev.abs_(xv, True, scalar=scalar, out=orr, n=n)
     ref = oracle.abs_(x, True)
-    got = orr.cpu().numpy()
+    got = d2h(orr)
     assert (nerr(got, ref) <= 1e-15 * 4) if scalar == oracle.F64 else np.array_equal(got, ref)
     dev.angle(xv, scalar=scalar, out=orr, n=n)
-    ref, got = oracle.angle(x), orr.cpu().numpy()
+    ref, got = oracle.angle(x), d2h(orr)
     assert (ang_err(got, ref) <= TOL) if scalar in (oracle.F32, oracle.F64) else np.array_equal(got, ref)
     y = rand_stream(rng, scalar, n, True)
     yin = torch.zeros((n + 8, 2), dtype=TD, device=d)
-    yin[oo:oo + n] = torch.from_numpy(y).to(d)
+    yin[oo:oo + n] = h2d(y, d)
     for op in ("ADD", "SUB", "MUL"):
         dev.arith(op, xv, yin[oo:oo + n], True, scalar=scalar, out=oc, n=n)
-        assert np.array_equal(oc.cpu().numpy().view(np.uint8), oracle.arith(getattr(oracle, op), x, y, True).view(np.uint8)), op
+        assert np.array_equal(d2h(oc).view(np.uint8), oracle.arith(getattr(oracle, op), x, y, True).view(np.uint8)), op
     # nothing outside the output windows was written
     assert not bool(outc[:oo].any()) and not bool(outc[oo + n:].any())
     assert not bool(outr[:oo].any()) and not bool(outr[oo + n:].any())

@@ -48,3 +48,27 @@ def diff_note(got, want):
     runs = np.split(bad, np.flatnonzero(np.diff(bad) > 1) + 1)
     return "%d rows of %d differ (%d of them zero) in %d runs: %s" % (
         bad.size, g.shape[0], zero, len(runs), ", ".join("%d..%d" % (r[0], r[-1]) for r in runs[:8]))
+
+
+def h2d(a, d):
+    """numpy -> device tensor.  With PCX_TEST_PINNED=1 through page-locked memory, so that under a runtime-mode variation
+    (profiles/r02/contention.md section 4) the test's own transfers stay off the runtime's pageable copy path and a difference the
+    test reports is the library's; the plain path otherwise (page-locking every case makes the soak five times longer)."""
+    import os
+
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.pin_memory() if os.environ.get("PCX_TEST_PINNED") else t).to(d)
+
+
+def d2h(t):
+    """device tensor -> numpy (page-locked bounce under PCX_TEST_PINNED=1)"""
+    import os
+
+    import torch
+    if not os.environ.get("PCX_TEST_PINNED"):
+        return t.cpu().numpy()
+    out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    out.copy_(t)
+    torch.cuda.current_stream(t.device).synchronize()
+    return out.numpy().copy()

@@ -339,3 +339,38 @@ def test_sinc_response_meets_the_reference_test_points(band, window):
         assert np.allclose(taps, taps[::-1], rtol=0, atol=1e-15)
     else:
         assert np.allclose(taps, np.conj(taps[::-1]), rtol=0, atol=1e-15)
+
+
+_SHARP = ["SINC", "RAISED_COSINE", "ROOT_RAISED_COSINE", "MAXFLAT", "REMEZ"]
+
+
+@pytest.mark.parametrize("band", ["LOW_PASS", "HIGH_PASS", "BAND_PASS", "BAND_STOP", "COMPLEX_BAND_PASS", "COMPLEX_BAND_STOP"])
+@pytest.mark.parametrize("ftype", _SHARP + ["GAUSSIAN"])
+def test_every_filter_type_designs_every_band_type(ftype, band):
+    """FIRDesigner.cpp:204-330: each prototype goes through every band transform (MAXFLAT refuses the two stop bands, :263-266).
+    Probe points well inside a band must sit on the side of one half the band type names."""
+    cplx = band.startswith("COMPLEX")
+    des, flt = _designer_and_filter(band)
+    des.call("setFilterType", ftype); des.call("setBandType", band)
+    des.call("setSampleRate", 1e6); des.call("setFrequencyLower", 1e5); des.call("setFrequencyUpper", 2e5)
+    des.call("setNumTaps", 51)
+    des.call("setAlpha", 0.1)     # (at the default 0.5 a raised-cosine HIGH_PASS prototype at 0.4 rolls off across Nyquist and leaks into DC)
+    if ftype == "MAXFLAT" and band.endswith("STOP"):
+        with pytest.raises(Exception, match="MAXFLAT"):
+            des.activate()
+        return
+    des.activate()
+    t = np.asarray(_taps(flt, cplx))
+    if cplx and t.dtype != np.complex128:
+        t = t.reshape(-1, 2) @ np.array([1, 1j])
+    assert len(t) == 51 and np.isfinite(t).all()
+    H = np.abs(np.fft.fft(t, 1000))                      # bin k = k kHz
+    dc, mid, far, neg = H[0], H[150], H[400], H[850]     # 0, +150 kHz (between the edges), +400 kHz, -150 kHz
+    if ftype == "GAUSSIAN":
+        return                                           # a pulse shape (Lower Freq is the time-bandwidth product): designs, no band claim
+    want = {"LOW_PASS": (1, None, 0, None), "HIGH_PASS": (0, None, 1, None), "BAND_PASS": (0, 1, 0, 1), "BAND_STOP": (1, 0, 1, 0),
+            "COMPLEX_BAND_PASS": (0, 1, 0, 0), "COMPLEX_BAND_STOP": (1, 0, 1, 1)}[band]
+    for name, got, w in zip(("dc", "mid", "far", "neg"), (dc, mid, far, neg), want):
+        if w is None:
+            continue
+        assert (got > 0.7) if w else (got < 0.3), (ftype, band, name, got)

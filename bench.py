@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SHARD = 64 * 1024 * 1024       # samples per GPU (configs[1])
-PREWARM = 100                  # untimed setup passes before the W warm-up steps (clock settling)
+PREWARM = 400                  # untimed setup passes before the W warm-up steps (clock settling: tools/transient_probe.py)
 
 
 def parse():
@@ -244,8 +244,20 @@ def spawn_ranks(args):
     print(line, flush=True)
 
 
-def load_traffic(workload):
-    """PMC-measured HBM bytes per launch for this workload, if a measurement is committed."""
+def source_hashes(files):
+    """sha256 (first 16 hex digits) of kernel source files, paths relative to the repository root."""
+    import hashlib
+    out = {}
+    for rel in files:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            out[rel] = hashlib.sha256(f.read()).hexdigest()[:16]
+    return out
+
+
+def load_traffic(workload, kernel_name):
+    """PMC-measured HBM bytes per launch for this workload -- only when the committed measurement was taken on THIS kernel:
+    the entry of profiles/traffic.json names the kernel symbol and carries the hashes of the source files the kernel is
+    built from (tools/collect_profiles.py stamps them when it files the PMC summary); any mismatch, and the line says null."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(p):
         return None
@@ -253,8 +265,14 @@ def load_traffic(workload):
         with open(p) as f:
             t = json.load(f)
         e = t.get(workload)
-        return e.get("hbm_bytes_per_launch") if e else None
-    except (OSError, ValueError):
+        if not e or not e.get("kernel") or not e.get("sources"):
+            return None
+        if e["kernel"] not in kernel_name and kernel_name not in e["kernel"]:
+            return None
+        if source_hashes(sorted(e["sources"])) != e["sources"]:
+            return None
+        return e.get("hbm_bytes_per_launch")
+    except (OSError, ValueError, KeyError):
         return None
 
 
@@ -316,6 +334,7 @@ def main():
         device.fill_uniform_f32_dev(sf.buf, seed=2, offset=2 * rank * C)
         units = C
         roof_bytes = 16.0 * C
+        read_bytes = 8.0 * C
         kernel_name = "fir_cf32_ols4096_kernel" if wl == "fir255" else "fir_cf32_direct_kernel"
 
         def step():
@@ -333,6 +352,7 @@ def main():
         fft = device.Fft("complex_float32", 4096, False)
         units = nframes * 4096
         roof_bytes = 16.0 * units
+        read_bytes = 8.0 * units
         kernel_name = "fft_r16_kernel<12>"
 
         def step():
@@ -352,6 +372,7 @@ def main():
         device.fill_uniform_f32_dev(x, seed=5, offset=0)
         units = n
         roof_bytes = 12.0 * n
+        read_bytes = 8.0 * n
         kernel_name = "fmchain_cf32_ols4096_kernel"
 
         def step():
@@ -382,6 +403,7 @@ def main():
         device.fill_uniform_f32_dev(x, seed=7, offset=0)
         units = n if wl == "decim8" else n * L            # decimator: input samples; interpolator: output samples
         roof_bytes = 8.0 * n + 8.0 * (n * L // M)
+        read_bytes = 8.0 * n
         kernel_name = "fir_cf32_ols4096_decim_batched_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_kernel"
 
         def step():
@@ -402,6 +424,7 @@ def main():
         y = torch.empty((n, 2), dtype=torch.int16, device=dev)
         units = n
         roof_bytes = 8.0 * n
+        read_bytes = 4.0 * n
         kernel_name = "fir_cf64_ols_kernel"
 
         def step():
@@ -415,6 +438,7 @@ def main():
         device.fill_uniform_f32_dev(x, seed=6, offset=0)
         units = n
         roof_bytes = 16.0 * n
+        read_bytes = 8.0 * n
         kernel_name = "map_kernel<rotate>"
 
         def step():
@@ -427,9 +451,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # setup: let the clocks settle.  The first ~50 back-to-back launches after an idle period run
-    # through a DVFS transient on this part (230 us -> 320 us -> 245 us per launch, profiles/r01);
-    # these untimed passes are part of setup, not of the W warm-up steps or the timed region.
+    # setup: let the clocks settle.  The launches behind an idle period run through a DVFS transient on this part: after
+    # 5 ms of idle the headline kernel takes 209-229 us per launch for the first 80, 200-206 for the next 100 and reaches
+    # its settled 196-199 only after ~200 launches (tools/transient_probe.py, profiles/r03/transient_probe.txt); a
+    # synchronisation WITHOUT idle time (the barrier below) costs nothing.  These untimed passes are part of setup, not
+    # of the W warm-up steps or the timed region; their number is reported as config.setup_passes.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(args.settle):
         step()
     for _ in range(args.warmup):
@@ -438,7 +465,6 @@ def main():
     # HIP events on the launch stream (torch's current stream is the stream every pcx_*_dev call
     # gets): ONE pair around the K timed steps, so no event packet sits between two launches
     # (a pair per step costs ~12 us of gap per step on this stack); avg launch = span / K.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for k in range(args.steps):
@@ -466,10 +492,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if wl == "fir255_i16" else "f32",
             "data": "synthetic", "config": desc,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(wl),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "read_only_frac": round(read_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": load_traffic(wl, kernel_name),
                          "kernel": kernel_name, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": roof_bytes,
-                         "bytes_counted": "algorithmic read + write (SURVEY 8d); the read stream alone is the smaller share"},
+                         "bytes_counted": "frac: algorithmic read + write (SURVEY 8d); read_only_frac: the read stream alone "
+                                          "(north_star words its target on reads: a kernel that writes every sample back "
+                                          "cannot put more than its read share of the pins into reads)"},
         }
         if world == 1 and not args.no_cpu:
             cpu_n = min(C, 16 * 1024 * 1024)          # bounded sample: 10-30 s of CPU work for the whole leg

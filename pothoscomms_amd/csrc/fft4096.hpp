@@ -13,8 +13,15 @@
 // Global loads/stores are stride-256 across r and unit-stride across lanes: every
 // wave-instruction moves one contiguous 512-byte row (measured: this pattern streams at the
 // same 5.5 TB/s as a float4 copy, tools/ubench.hip).  The LDS image is padded by one
-// element per 16 (pad(i) = i + i/16) so pass-1/2 scatter writes (16-lane groups) and the
-// stride-1 gathers are bank-conflict free.
+// element per 16 (pad(i) = i + i/16): the pass-1/2 scatter writes (ds_write_b64: 16-lane groups
+// over 32 banks) are conflict-free; the stride-1 gathers are NOT quite -- ds_read_b64 serves
+// 32-lane groups over 64 banks, the pad puts 33 elements under 32 lanes, lane 31 lands on lane
+// 0's banks and each group takes two LDS cycles instead of one (SQ_LDS_BANK_CONFLICT = 20 % of
+// SQ_LDS_IDX_ACTIVE).  A layout that is conflict-free for both, s(e) = (e & ~15) | ((e ^ (e >> 4)) & 15)
+// in exactly 32 KiB, was built and measured (tools/ols_lab3.hip SWZ, profiles/r03/ols_lab3.md):
+// its scatter addresses are no longer affine in the register index -- one v_xor per store,
+// 64 VALU instructions per block on a kernel that is short of VALU issue slots, not of LDS
+// cycles -- and it ran 0.7-1.2 % SLOWER.  The padded image stays.
 //
 // Twiddles.  The radix-16 butterfly is two layers of DFT4 (n = 4 n1 + n2, k = k1 + 4 k2).
 // A lane's external twiddle w^n (w = W256^(j&15) in pass 2, W4096^j in pass 3) factors as
@@ -304,23 +311,45 @@ __device__ __forceinline__ void fft8(cf &a0, cf &a1, cf &a2, cf &a3, cf &a4, cf 
     a3 = e3 + w3; a7 = e3 - w3;
 }
 
+// The passes' barriers order LDS accesses only (the exchange image, the pass-2 table, a kernel's own LDS words): a release /
+// acquire pair on the LOCAL address space around s_barrier = `s_waitcnt lgkmcnt(0); s_barrier`.  __syncthreads() also drains
+// vmcnt -- every outstanding global load, store and atomic of the wave -- which made the first barrier of a block wait for the
+// block dealer's atomic (pcx_sched.hpp) and would make any barrier wait for stores still in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // PART (timing-only builds of the energy split, wrong outputs): 0 = the real pass, 1 = butterflies only
 // (no LDS exchange, no barriers), 2 = exchange only (no butterfly arithmetic)
-// pass 1: v[r] = x[j + 256 r] on entry; leaves the pass-1 result in LDS
+// pass 1: v[r] = x[j + 256 r] on entry; leaves the pass-1 result in LDS.  pass1 = pass1_math + pass1_exchange: a kernel that
+// deals its blocks dynamically issues the draw between the two (every load of the block has been consumed by then).
+template <int PART = 0>
+__device__ __forceinline__ void pass1_math(cf (&v)[16])
+{
+    if (PART != 2) fft16_plain(v);
+}
+template <int PART = 0>
+__device__ __forceinline__ void pass1_exchange(cf (&v)[16], cf *lds, int j)
+{
+    if (PART == 1) return;
+    lds_barrier();  // previous readers of this LDS image are done
+#pragma unroll
+    for (int q = 0; q < 16; q++) lds[17 * j + bin_of(q)] = v[q];  // pad(16 j + k) = 17 j + k
+}
 template <int PART = 0>
 __device__ __forceinline__ void pass1(cf (&v)[16], cf *lds, int j)
 {
-    if (PART != 2) fft16_plain(v);
-    if (PART == 1) return;
-    __syncthreads();  // previous readers of this LDS image are done
-#pragma unroll
-    for (int q = 0; q < 16; q++) lds[17 * j + bin_of(q)] = v[q];  // pad(16 j + k) = 17 j + k
+    pass1_math<PART>(v);
+    pass1_exchange<PART>(v, lds, j);
 }
 template <int PART = 0>
 __device__ __forceinline__ void pass2(cf (&v)[16], cf *lds, int j)
 {
     if (PART != 1) {
-        __syncthreads();
+        lds_barrier();
         const int rb = j + (j >> 4);  // pad(j + 256 r) = rb + 272 r
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
@@ -334,7 +363,7 @@ __device__ __forceinline__ void pass2(cf (&v)[16], cf *lds, int j)
     if (PART != 2) fft16_tw(v, tw);
     else v[0] = v[0] + tw.a[0] + tw.c[0];   // keep the table reads alive
     if (PART == 1) return;
-    __syncthreads();
+    lds_barrier();
     const int wb = (j >> 4) * 272 + (j & 15);  // pad((j>>4)*256 + kk + 16 k) = wb + 17 k
 #pragma unroll
     for (int q = 0; q < 16; q++) lds[wb + 17 * bin_of(q)] = v[q];
@@ -344,7 +373,7 @@ template <int PART = 0>
 __device__ __forceinline__ void pass3(cf (&v)[16], const cf *lds, int j, const LaneTw &tw3)
 {
     if (PART != 1) {
-        __syncthreads();
+        lds_barrier();
         const int rb = j + (j >> 4);
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];

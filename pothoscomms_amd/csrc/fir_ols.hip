@@ -15,8 +15,7 @@
 //   so the spectrum never leaves registers
 //   store time samples i >= Kov (the first K-1 are circularly aliased) to y[b*S + i-Kov]
 // HBM traffic per block: 32 KiB read + 8*S bytes written; LDS: one padded 34 KiB image.
-// The kernel runs at the package power cap: what remains above the load+store
-// floor is clock, not scheduling.
+// What bounds it: DESIGN.md 4.1 (profiles/r03/ols_lab3.md).
 #include "fft4096.hpp"
 #include "pcx_sched.hpp"
 #include <cstdio>
@@ -61,8 +60,8 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
     // instead of a grid stride, so the K-1 samples block b+1 shares with block b were fetched
     // by the same CU a moment ago (L2/L1 hit instead of a second trip to the memory side).
     size_t b, bend, bstep;
-    // CHUNKED == 3 (the product default): blocks dealt dynamically, two per draw (pcx_sched.hpp) -- the CUs do not all run
-    // at one rate, and a fixed share per workgroup made every launch wait for the slowest
+    // CHUNKED == 3 (the product default): blocks dealt dynamically, one per draw from sixteen counters (pcx_sched.hpp) -- the CUs
+    // do not all run at one rate, and a fixed share per workgroup made every launch wait for the slowest
     __shared__ unsigned sched_slot;
     BlockDealer deal;
     if (CHUNKED == 3) {
@@ -143,10 +142,11 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         } else {
             fetch(v, b);
         }
-        if (CHUNKED == 3) deal.draw(j);     // behind the loads in the in-order vmcnt queue: they can be waited for without it
         constexpr int PART = DIAG == 3 ? 1 : DIAG == 4 ? 2 : 0;
+        if (DIAG != 2) pass1_math<PART>(v);
+        if (CHUNKED == 3) deal.draw(j);     // behind the first butterflies: no load of this block is outstanding any more (pcx_sched.hpp)
         if (DIAG != 2) {
-        pass1<PART>(v, lds, j);
+        pass1_exchange<PART>(v, lds, j);
         pass2<PART>(v, lds, j);
         pass3<PART>(v, lds, j, tw3);
         }
@@ -352,8 +352,9 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
                 v[r] = cf{__uint_as_float(a), __uint_as_float(b)};
             }
         }
-        walk.draw(j);
-        pass1(v, lds, j);
+        pass1_math(v);
+        walk.draw(j);                       // behind the first butterflies (pcx_sched.hpp)
+        pass1_exchange(v, lds, j);
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
         cf u[16];
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - K);
     size_t b = blockIdx.x;
-    BlockDealer deal;        // DYN: blocks dealt dynamically, two per draw (pcx_sched.hpp)
+    BlockDealer deal;        // DYN: blocks dealt dynamically (pcx_sched.hpp)
     if (DYN) {
         if (!deal.begin(sched, &sched_slot, nblocks, j)) { deal.finish(j); return; }
         b = deal.block();
@@ -619,8 +620,9 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
     for (; b < nblocks; b += DYN ? 0 : gridDim.x) {
         cf v[16];
         fetch(v, b);
-        if (DYN) deal.draw(j);
-        pass1(v, lds, j);
+        pass1_math(v);
+        if (DYN) deal.draw(j);              // behind the first butterflies (pcx_sched.hpp)
+        pass1_exchange(v, lds, j);
         pass2(v, lds, j);
         pass3(v, lds, j, tw3);
         cf u[16];

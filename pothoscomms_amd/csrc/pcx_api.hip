@@ -500,7 +500,7 @@ struct pcx_fir {
     bool dirty = true;
     DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096;
     StageBuf wsIn, wsOut;
-    DevBuf sched;             // {draws, finished}: dynamic block assignment of the overlap-save kernels (pcx_sched.hpp), zeroed once
+    DevBuf sched;             // SchedState: dynamic block assignment of the overlap-save kernels (pcx_sched.hpp), zeroed once
     size_t Kp = 8;
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
@@ -643,7 +643,7 @@ static int fir_sync_tables(pcx_fir *h)
     }
     h->have_ols = false;
     if (!h->sched.p) {
-        PCX_TRY(h->sched.ensure_zeroed(64));
+        PCX_TRY(h->sched.ensure_zeroed(kSchedBytes));
     }
     if (fir_fast_applicable(h)) {
         const size_t K = h->K;
@@ -1210,7 +1210,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
     } else if (scalar == PCX_F32 && num_bins == 4096) {
         h->kind = pcx_fft::R16_4096;
         rc = upload(h->tw, make_tw4096());
-        if (rc == PCX_OK) rc = h->sched.ensure_zeroed(64);
+        if (rc == PCX_OK) rc = h->sched.ensure_zeroed(kSchedBytes);
     } else if (scalar == PCX_F32 && pow2 && num_bins >= 16 && num_bins <= 16384) {
         h->kind = pcx_fft::R16;
         while (((size_t)1 << h->log2n) < num_bins) h->log2n++;
@@ -1764,7 +1764,7 @@ int pcx_fmchain_create(pcx_fmchain **out)
     h->taps.assign(1, 1.0);
     DeviceScope dev_scope(h->cx.device);
     int rc = h->prev.ensure_zeroed(64);
-    if (rc == PCX_OK) rc = h->sched.ensure_zeroed(64);
+    if (rc == PCX_OK) rc = h->sched.ensure_zeroed(kSchedBytes);
     if (rc != PCX_OK) { delete h; return rc; }
     *out = h;
     return PCX_OK;

@@ -115,6 +115,9 @@ struct StageBuf {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// bytes of a handle's block-dealer state (pcx_sched.hpp SchedState: sixteen counters a cache line apart + the exit count)
+constexpr size_t kSchedBytes = 4096;
+
 // A/B and diagnostic switches.  The PRODUCT library (libpcx_hip.so) ignores the process environment
 // entirely: every switch is its measured-best default, compiled in.  Only the diagnostic build
 // (make diag -> libpcx_hip_diag.so, -DPCX_DIAG, loaded by tools/ through PCX_HIP_LIBRARY) reads the

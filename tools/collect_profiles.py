@@ -2,8 +2,22 @@
 profiles/traffic.json from the PMC summaries (tools/refresh_profiles.sh produces <run> on the GPU box).
     python tools/collect_profiles.py gpurun_out/r01b profiles/r01
 """
-import glob, json, os, re, shutil, sys
+import glob, hashlib, json, os, re, shutil, sys
 src, dst = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+C = "pothoscomms_amd/csrc/"
+# the kernel each workload's PMC run measured and the source files it is built from: bench.py reports `traffic` only while
+# these files still hash to what they did when the measurement was filed (run this script on the tree the GPU run used)
+KERNELS = {
+    "fir255": ("fir_cf32_ols4096_kernel", [C + "fir_ols.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
+    "fmchain": ("fmchain_cf32_ols4096_kernel", [C + "fir_ols.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
+    "fft4096": ("fft_r16_kernel", [C + "fft_r16.hip", C + "fft4096.hpp"]),
+    "direct255": ("fir_cf32_direct_kernel", [C + "fir_direct.hip"]),
+    "decim8": ("fir_cf32_ols4096_decim_batched_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
+    "interp4": ("fir_cf32_ols4096_interp_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
+}
+def hashes(files):
+    return {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] for f in files}
 os.makedirs(dst, exist_ok=True)
 
 def newest(pattern):
@@ -20,7 +34,7 @@ f = newest(os.path.join(src, "bench_kt", "**", "*_kernel_stats.csv"))
 if f:
     shutil.copy(f, os.path.join(dst, "bench_fir255_kernel_stats.csv"))
 traffic = {}
-for wl in ("fir255", "fft4096", "fmchain", "direct255"):
+for wl in ("fir255", "fft4096", "fmchain", "direct255", "decim8", "interp4"):
     summ = os.path.join(src, wl, "summary.txt")
     if not os.path.exists(summ):
         continue
@@ -34,6 +48,8 @@ for wl in ("fir255", "fft4096", "fmchain", "direct255"):
     if fetch and write:
         fk, wk = float(fetch.group(1)), float(write.group(1))
         traffic[wl] = {
+            "kernel": KERNELS[wl][0],
+            "sources": hashes(KERNELS[wl][1]),
             "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
             "FETCH_SIZE_KiB_raw": fk,
             "WRITE_SIZE_KiB": wk,

@@ -29,5 +29,19 @@ elif wl == "fmchain":
     device.fill_uniform_f32_dev(x, seed=5)
     for _ in range(n):
         ch.process_dev(x, y, C + 126, C)
+elif wl in ("decim8", "interp4"):
+    # the same configurations as bench.py --workload decim8 / interp4
+    n = C if wl == "decim8" else C // 4
+    M, L = (8, 1) if wl == "decim8" else (1, 4)
+    h = tp.complex_bandpass(255 * L, 0.05 / max(L, M), 0.05 / max(L, M)) * L
+    f = device.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h); f.set_decimation(M); f.set_interpolation(L)
+    K = f.K
+    lead = (-(K - 1)) % 16
+    xa = torch.empty((lead + n + K - 1, 2), dtype=torch.float32, device=dev); x = xa[lead:]
+    y = torch.empty((n * L // M + 8, 2), dtype=torch.float32, device=dev)
+    device.fill_uniform_f32_dev(x, seed=7, offset=0)
+    for _ in range(n_launch := n and int(sys.argv[2]) if len(sys.argv) > 2 else 5):
+        f.process_dev(x, y)
 torch.cuda.synchronize()
 print("done", wl)

@@ -600,8 +600,10 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + blk * S - lead, N * 8);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const u32x2 t = (r < NOV || r >= 16 - NOV) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 0)
-                                                           : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, 2048 * r, 2);
+                // row r at byte 2048 r: the odd rows' 2048 goes into the instruction's 12-bit offset field, so eight scalar
+                // offsets serve sixteen rows
+                const u32x2 t = (r < NOV || r >= 16 - NOV) ? __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8 + 2048 * (r & 1), 4096 * (r >> 1), 0)
+                                                           : __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8 + 2048 * (r & 1), 4096 * (r >> 1), 2);
                 dst[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
             }
             return;
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
 #pragma unroll
             for (int q = 0; q < 16; q++) bnd[(j >> 6) * 16 + bin_of(q)] = u[q];
         }
-        __syncthreads();
+        lds_barrier();                      // orders bnd[] only: no global access is waited for (fft4096.hpp)
         const size_t room = n_out - b * S;
         const size_t cnt = room < S ? room : S;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)(cnt * 4));
@@ -661,12 +663,19 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         // lane 0 of wave w > 0 continues lane 63 of wave w-1 in the same row; lane 0 of wave 0 continues
         // lane 255 of row k-1 (bnd[47 + k]; for k = 0 that is time index -1: never a valid output)
         const cf *edge_row = bnd + ((j >> 6) > 0 ? ((j >> 6) - 1) * 16 : 47);
-        // two rows at a time so the demodulator's arithmetic runs on packed pairs (fast_atan2f_x2)
+        // Two rows at a time so that the demodulator's polynomial and reflections run on packed pairs.  Rows whose outputs are all
+        // dropped (time index < K) for every K this instantiation serves are skipped at compile time (NDEAD); the others are
+        // computed whole and the descriptor's range check drops what must not be stored -- no run-time row tests, no branches.
+        // The atan2 constants ride in four scalar register PAIRS, either half picked with op_sel: (c5,c4) (c3,c2) (c1,c0) (pi/2,pi).
+        // atan(t) = t (c0 + c1 s + ... + c5 s^5), s = t^2, t in [0,1]: minimax, 1.8e-6 rad in float32 -- 18x inside the
+        // 1e-5*pi parity bar (the seven-term fit it replaces: 3e-7 rad, 100x).
+        constexpr int NDEAD = NOV / 2;      // Kov in (256 NOV/2, 256 NOV] (NOV = 1: Kov <= 256): rows 0 .. NDEAD-1 are dead whatever K
+        const cf K54 = {-0.01171913556754589f, 0.05264735221862793f}, K32 = {-0.116426482796669f, 0.19354037940502167f};
+        const cf K10 = {-0.33262282609939575f, 0.9999772310256958f}, KPI = {1.57079632679489661923f, 3.14159265358979323846f};
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
             const int k0 = bin_of(q), k1 = bin_of(q + 1);
-            const bool live0 = 256 * k0 + 255 >= K, live1 = 256 * k1 + 255 >= K;   // any valid output in the row? (uniform)
-            if (!live0 && !live1) continue;
+            if (k0 < NDEAD && k1 < NDEAD) continue;
             // conj(y[m-1]) for both rows; edge_row[k]: wave-uniform address, broadcast read
             auto prev = [&](cf a, cf edge) {
                 cf p;
@@ -676,12 +685,40 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             };
             const cf a0 = u[q], a1 = u[q + 1];
             const cf p0 = prev(a0, edge_row[k0]), p1 = prev(a1, edge_row[k1]);
-            // y[m] * conj(y[m-1]) = conj(a) * p
-            const cf re = {a0.x * p0.x + a0.y * p0.y, a1.x * p1.x + a1.y * p1.y};
-            const cf im = {a0.x * p0.y - a0.y * p0.x, a1.x * p1.y - a1.y * p1.x};
-            const cf d = fast_atan2f_x2(im, re);
-            if (live0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d.x), ws, (int)(vbase + (unsigned)(256 * k0) * 4u), 0, SAUX);
-            if (live1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d.y), ws, (int)(vbase + (unsigned)(256 * k1) * 4u), 0, SAUX);
+            // z = y[m] * conj(y[m-1]) = conj(a) * p = (a.x p.x + a.y p.y, a.x p.y - a.y p.x): two packed instructions per sample.
+            // (Written as plain multiply-adds the vectoriser packs them itself and then spends eight v_mov per pair building
+            // the operand pairs; this form costs two v_max x, x per sample instead -- the compiler cannot know asm results to be
+            // canonical floats in front of the min / max below -- which measured the cheaper of the two.)
+            cf z0, z1;
+            asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"     // (a.y p.y, -a.y p.x)
+                "v_pk_mul_f32 %1, %4, %5 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+                "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"       // (a.x p.x, a.x p.y) + that
+                "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+                : "=&v"(z0), "=&v"(z1)
+                : "v"(a0), "v"(p0), "v"(a1), "v"(p1));
+            const float x0 = z0.x, y0 = z0.y, x1 = z1.x, y1 = z1.y;
+            // atan2(y, x), two samples side by side.  |z| = 0 (the first output after activate(): arg of a signed zero,
+            // FreqDemod.cpp:44-47,63-64) gives t = 0 / tiny = 0 and the quadrant from the sign bits alone, as atan2f does.
+            const cf mx = {__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(y0)), 1e-37f),
+                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x1), __builtin_fabsf(y1)), 1e-37f)};
+            const cf mn = {__builtin_fminf(__builtin_fabsf(x0), __builtin_fabsf(y0)), __builtin_fminf(__builtin_fabsf(x1), __builtin_fabsf(y1))};
+            const cf rc = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+            const cf t = mn * rc;
+            const cf sq = t * t;
+            cf pl, ro, rn;
+            asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(pl) : "s"(K54), "v"(sq));            // c5 s + c4
+            asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(pl) : "v"(sq), "s"(K32));            // .. s + c3
+            asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(pl) : "v"(sq), "s"(K32));            // .. s + c2
+            asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(pl) : "v"(sq), "s"(K10));            // .. s + c1
+            asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(pl) : "v"(sq), "s"(K10));            // .. s + c0
+            cf r = t * pl;
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ro) : "s"(KPI), "v"(r));   // pi/2 - r
+            r = cf{__builtin_fabsf(y0) > __builtin_fabsf(x0) ? ro.x : r.x, __builtin_fabsf(y1) > __builtin_fabsf(x1) ? ro.y : r.y};
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rn) : "s"(KPI), "v"(r));   // pi - r
+            r = cf{__float_as_int(x0) < 0 ? rn.x : r.x, __float_as_int(x1) < 0 ? rn.y : r.y};
+            const float d0 = __builtin_copysignf(r.x, y0), d1 = __builtin_copysignf(r.y, y1);
+            if (k0 >= NDEAD) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), ws, (int)(vbase + (unsigned)(256 * k0) * 4u), 0, SAUX);
+            if (k1 >= NDEAD) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), ws, (int)(vbase + (unsigned)(256 * k1) * 4u), 0, SAUX);
         }
         if (b == nblocks - 1) {
             // the stream's last output becomes the next call's carried state (kept conjugated)

@@ -7,6 +7,7 @@ from pothoscomms_amd.stream import ShardedFir
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "fir255"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+reps = n
 dev = torch.device("cuda", 0)
 C = 64 * 1024 * 1024
 if wl in ("fir255", "direct255"):
@@ -41,7 +42,7 @@ elif wl in ("decim8", "interp4"):
     xa = torch.empty((lead + n + K - 1, 2), dtype=torch.float32, device=dev); x = xa[lead:]
     y = torch.empty((n * L // M + 8, 2), dtype=torch.float32, device=dev)
     device.fill_uniform_f32_dev(x, seed=7, offset=0)
-    for _ in range(n_launch := n and int(sys.argv[2]) if len(sys.argv) > 2 else 5):
+    for _ in range(reps):
         f.process_dev(x, y)
 torch.cuda.synchronize()
 print("done", wl)

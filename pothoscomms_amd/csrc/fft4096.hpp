@@ -115,6 +115,19 @@ __device__ __forceinline__ void fft4_mi2(cf &a0, cf &a1, cf &a2, cf &a3)
     addsub_mi(a1, a3, t1, d);
 }
 
+// forward DFT4 with CONJUGATED outputs: the negations ride on the last four additions (neg_lo / neg_hi modifiers), so a kernel
+// that wants conj(FFT(..)) -- the inverse transform computed on the forward passes -- pays nothing for the final conjugation
+__device__ __forceinline__ void fft4_conj(cf &a0, cf &a1, cf &a2, cf &a3)
+{
+    const cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
+    asm("v_pk_add_f32 %0, %4, %5 neg_hi:[1,1]\n\t"                                        // ( t0.x + t2.x, -t0.y - t2.y)
+        "v_pk_add_f32 %1, %4, %5 neg_lo:[0,1] neg_hi:[1,0]\n\t"                           // ( t0.x - t2.x, -t0.y + t2.y)
+        "v_pk_add_f32 %2, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"           // ( t1.x + d.y,  -t1.y + d.x )
+        "v_pk_add_f32 %3, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]"     // ( t1.x - d.y,  -t1.y - d.x )
+        : "=&v"(a0), "=&v"(a2), "=&v"(a1), "=&v"(a3)
+        : "v"(t0), "v"(t2), "v"(t1), "v"(d));
+}
+
 // the 15 lane-constant factors of one twiddled pass
 struct LaneTw {
     cf a[3];    // (w^4)^n1, n1 = 1..3
@@ -169,6 +182,23 @@ __device__ __forceinline__ void fft16_tw(cf (&v)[16], const LaneTw &tw)
         cmul2(v[4 * 2 + n2], v[4 * 3 + n2], tw.c[(n2 - 1) * 4 + 2], tw.c[(n2 - 1) * 4 + 3]);
     }
     fft16_outer(v);
+}
+// the same with conjugated outputs (fft4_conj in the outer layer)
+__device__ __forceinline__ void fft16_tw_conj(cf (&v)[16], const LaneTw &tw)
+{
+#pragma unroll
+    for (int n1 = 1; n1 < 4; n1++) {
+        cmul2(v[4 * n1 + 0], v[4 * n1 + 1], tw.a[n1 - 1], tw.a[n1 - 1]);
+        cmul2(v[4 * n1 + 2], v[4 * n1 + 3], tw.a[n1 - 1], tw.a[n1 - 1]);
+    }
+    fft16_inner(v);
+#pragma unroll
+    for (int n2 = 1; n2 < 4; n2++) {
+        cmul2(v[4 * 0 + n2], v[4 * 1 + n2], tw.c[(n2 - 1) * 4 + 0], tw.c[(n2 - 1) * 4 + 1]);
+        cmul2(v[4 * 2 + n2], v[4 * 3 + n2], tw.c[(n2 - 1) * 4 + 2], tw.c[(n2 - 1) * 4 + 3]);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) fft4_conj(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
 // register index q holds output bin k = bin_of(q)
 __device__ __forceinline__ constexpr int bin_of(int q) { return (q >> 2) + 4 * (q & 3); }
@@ -368,8 +398,9 @@ __device__ __forceinline__ void pass2(cf (&v)[16], cf *lds, int j)
 #pragma unroll
     for (int q = 0; q < 16; q++) lds[wb + 17 * bin_of(q)] = v[q];
 }
-// pass 3: on exit v[q] = X[j + 256 * bin_of(q)]
-template <int PART = 0>
+// pass 3: on exit v[q] = X[j + 256 * bin_of(q)]; CONJ: conj(X[..]) (the closing conjugation of an inverse transform run on the
+// forward passes, for free)
+template <int PART = 0, bool CONJ = false>
 __device__ __forceinline__ void pass3(cf (&v)[16], const cf *lds, int j, const LaneTw &tw3)
 {
     if (PART != 1) {
@@ -378,7 +409,10 @@ __device__ __forceinline__ void pass3(cf (&v)[16], const cf *lds, int j, const L
 #pragma unroll
         for (int r = 0; r < 16; r++) v[r] = lds[rb + 272 * r];
     }
-    if (PART != 2) fft16_tw(v, tw3);
+    if (PART != 2) {
+        if (CONJ) fft16_tw_conj(v, tw3);
+        else fft16_tw(v, tw3);
+    }
 }
 
 }  // namespace fft4k

@@ -89,14 +89,6 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
     // loop invariants of the persistent workgroup: the lane's pass-3 twiddles and its 16 bins
     // of H in registers, the pass-2 twiddle table in LDS.  Nothing but the stream itself is
     // loaded from global memory inside the loop.
-    LaneTw tw3;
-    load_pass3_twiddles(tw3, twtab, j);
-    stage_pass2_twiddles(lds, twtab, j);
-    cf H[16];
-    if (!HGLOBAL) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
-    }
     auto fetch = [&](cf (&dst)[16], size_t blk) {
         if (DIAG == 1) blk = first_full;
         if (blk >= first_full && blk < nfull) {
@@ -130,6 +122,17 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
             }
         }
     };
+    // (Issuing the first block's stream loads BEFORE the workgroup's 64 KB of tables are requested -- possible now that the
+    // first block is the blockIdx -- was built: the compiler then keeps the loaded samples, H and the twiddles live together
+    // through the prologue and spills 27 registers, thirteen of them re-read from scratch in every block.  Not kept.)
+    LaneTw tw3;
+    load_pass3_twiddles(tw3, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    cf H[16];
+    if (!HGLOBAL) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    }
     cf nx[16];
     if (PREFETCH) fetch(nx, b);
     for (; b < bend; b += bstep) {
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         // spectrum times H, re-ordered into natural register order for the next pass 1.
         // The inverse transform runs on the FORWARD passes: IFFT(z) = conj(FFT(conj(z))), so
         // one set of twiddles serves both directions.  u = conj(v * H); the final conj rides
-        // on the store.
+        // on the last additions of the inverse's third pass.
         cf u[16];
         if (HGLOBAL) {
             const cf *Hp = reinterpret_cast<const cf *>(Hspec);
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         if (DIAG != 2) {
         pass1<PART>(u, lds, j);
         pass2<PART>(u, lds, j);
-        pass3<PART>(u, lds, j, tw3);
+        pass3<PART, true>(u, lds, j, tw3);      // conj(FFT(u)) = the block's time samples: the conjugation rides on the last additions
         }
         // time sample i of the block is output b*S + i - (K-1).  For i < K-1 (circularly
         // aliased) the unsigned byte offset wraps far beyond num_records and the store is
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         for (int q = 0; q < 16; q++) {
             const int row = 256 * bin_of(q);
             if (row + 255 < Kov) continue;                    // whole row dropped: uniform skip
-            store_cf<SAUX>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
+            store_cf<SAUX>(ws, vbase + (unsigned)row * 8u, DIAG == 2 ? cf{u[q].x, -u[q].y} : u[q]);
         }
         __builtin_amdgcn_s_setprio(0);
         if (CHUNKED == 3) {
@@ -369,8 +372,8 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
         __builtin_amdgcn_s_setprio(1);      // as fir_cf32_ols4096_kernel: the second half of a block first
         pass1(u, lds, j);
         pass2(u, lds, j);
-        pass3(u, lds, j, tw3);
-        // y = conj(u): real part -> block A's outputs, -imag part -> block B's
+        pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
+        // real part -> block A's outputs, imaginary part -> block B's
         const size_t roomA = n_out - bA * S;
         const size_t roomB = bB < nblocks ? n_out - bB * S : 0;
         const __amdgpu_buffer_rsrc_t wa = make_rsrc(out + bA * S, (unsigned)((roomA < S ? roomA : S) * 4));
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
             const int row = 256 * bin_of(q);
             if (row + 255 < Kov) continue;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[q].x), wa, (int)(vbase + (unsigned)row * 4u), 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-u[q].y), wb, (int)(vbase + (unsigned)row * 4u), 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[q].y), wb, (int)(vbase + (unsigned)row * 4u), 0, 2);
         }
         __builtin_amdgcn_s_setprio(0);
         if (!walk.advance()) break;
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const flo
         }
         pass1(u, lds, j);
         pass2(u, lds, j);
-        pass3(u, lds, j, tw3);
+        pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
         // input index of time sample i is n = b*S + i - (K-1); flat index f = n*L + jrow
         const unsigned long long B0 = (unsigned long long)(b * S) * L + jrow + 1;   // f+1 at i' = i-(K-1) = 0 (wave-uniform)
         const unsigned long long q0 = B0 / M;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const flo
             if (ip >= nl) continue;
             const unsigned x = r0 + ip * L;
             const unsigned qq = (unsigned)(((unsigned long long)x * magic) >> 40);   // x / M
-            if (x - qq * M == 0) ob[qq] = make_float2(u[q].x, -u[q].y);
+            if (x - qq * M == 0) ob[qq] = make_float2(u[q].x, u[q].y);
         }
     }
 }
@@ -647,9 +650,11 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         if (b == 0) {
             // block 0: the slot of y[-1] (time index K-1, itself a dropped output) takes the carried state
             const cf carried = cf{prev_in[0].x, prev_in[0].y};
+            int slot_i = K - 1;
+            asm volatile("" : "+s"(slot_i));     // computed HERE, once per launch: hoisted, the sixteen lane masks below sat in 32 scalar registers for the whole loop
 #pragma unroll
             for (int q = 0; q < 16; q++)
-                if (j + 256 * bin_of(q) == K - 1) u[q] = carried;
+                if (j + 256 * bin_of(q) == slot_i) u[q] = carried;
         }
         if ((j & 63) == 63) {
 #pragma unroll
@@ -663,9 +668,11 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         // lane 0 of wave w > 0 continues lane 63 of wave w-1 in the same row; lane 0 of wave 0 continues
         // lane 255 of row k-1 (bnd[47 + k]; for k = 0 that is time index -1: never a valid output)
         const cf *edge_row = bnd + ((j >> 6) > 0 ? ((j >> 6) - 1) * 16 : 47);
-        // Two rows at a time so that the demodulator's polynomial and reflections run on packed pairs.  Rows whose outputs are all
-        // dropped (time index < K) for every K this instantiation serves are skipped at compile time (NDEAD); the others are
-        // computed whole and the descriptor's range check drops what must not be stored -- no run-time row tests, no branches.
+        // Two rows at a time so that the demodulator's polynomial and reflections run on packed pairs.  Every row is computed whole
+        // and the descriptor's range check drops what must not be stored (time index < K: the byte offset wraps past
+        // num_records) -- no run-time row tests, no branches.  (Leaving out the stores of rows that are dead for every K of
+        // an instantiation made the compiler spill 6-12 registers in the long-filter instantiations; a pair of rows is
+        // skipped only when both are dead.)
         // The atan2 constants ride in four scalar register PAIRS, either half picked with op_sel: (c5,c4) (c3,c2) (c1,c0) (pi/2,pi).
         // atan(t) = t (c0 + c1 s + ... + c5 s^5), s = t^2, t in [0,1]: minimax, 1.8e-6 rad in float32 -- 18x inside the
         // 1e-5*pi parity bar (the seven-term fit it replaces: 3e-7 rad, 100x).
@@ -717,8 +724,8 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rn) : "s"(KPI), "v"(r));   // pi - r
             r = cf{__float_as_int(x0) < 0 ? rn.x : r.x, __float_as_int(x1) < 0 ? rn.y : r.y};
             const float d0 = __builtin_copysignf(r.x, y0), d1 = __builtin_copysignf(r.y, y1);
-            if (k0 >= NDEAD) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), ws, (int)(vbase + (unsigned)(256 * k0) * 4u), 0, SAUX);
-            if (k1 >= NDEAD) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), ws, (int)(vbase + (unsigned)(256 * k1) * 4u), 0, SAUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), ws, (int)(vbase + (unsigned)(256 * k0) * 4u), 0, SAUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), ws, (int)(vbase + (unsigned)(256 * k1) * 4u), 0, SAUX);
         }
         if (b == nblocks - 1) {
             // the stream's last output becomes the next call's carried state (kept conjugated)

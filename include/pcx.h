@@ -95,6 +95,13 @@ PCX_API int pcx_dev_free(void *dptr);
 PCX_API int pcx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 PCX_API int pcx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 PCX_API int pcx_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+/* what kind of memory a buffer lives in -- a block's port buffer may be pageable host memory, one of the page-locked slabs of
+ * pcx_host_alloc, or (an edge between two blocks of this module) device memory the CPU must not touch */
+typedef enum pcx_pointer_kind_t { PCX_PTR_PAGEABLE = 0, PCX_PTR_PAGE_LOCKED = 1, PCX_PTR_DEVICE = 2 } pcx_pointer_kind_t;
+PCX_API int pcx_pointer_kind(const void *p, int *kind);
+/* bytes of `src` -- any of the three kinds -- into ordinary host memory, complete on return (FIRFilter::work's burst flush,
+ * FIRFilter.cpp:263-272, builds its zero-padded tail on the host) */
+PCX_API int pcx_memcpy_to_host(void *dst_host, const void *src, size_t bytes);
 PCX_API int pcx_stream_sync(void *stream);
 /* ROCTx ranges around every data-plane entry point (pcx_*_process[_dev], pcx_fft_transform[_dev], the maps,
  * pcx_shard_scatter/step/gather), named after the function: `rocprofv3 --marker-trace --kernel-trace` then shows which
@@ -156,6 +163,24 @@ PCX_API int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *o
                             size_t *consumed, size_t *produced);
 PCX_API int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                                 size_t *consumed, size_t *produced, void *stream);
+/*
+ * The same call over ONE SHARD of a stream that is split across devices: the first K-1 samples of `in_dev` -- the
+ * history slot, FIRFilter.cpp:281,305-307 -- are the HALO, still on its way from the left neighbour when the call is queued.
+ * ONE launch covers the whole shard: the blocks at the front, the only ones that read the halo, are computed last and not before
+ * the 32-bit word *gate_dev has reached gate_value (signed distance, so a pass counter needs no reset).  The caller queues
+ * pcx_gate_signal_dev(gate_dev, gate_value, s) on the stream that carries the halo, behind the transfer; everything else of the
+ * shard is filtered while the halo is in flight.
+  * The wait is bounded: after two seconds without the signal the held blocks run on whatever the halo slot holds and the word
+ * behind the gate word (gate_dev[1]) is set to 0xDEAD -- a gate takes two 32-bit words.
+ *   *gated = 1: queued as described.   *gated = 0: this configuration has no gated kernel (anything but complex_float32 with
+ *   M = L = 1 and K <= 2049, or a call of fewer than ~2048 blocks) and NOTHING has been queued: the caller waits for the halo on
+ *   `stream` itself (an event) and calls pcx_fir_process_dev.
+ */
+PCX_API int pcx_fir_process_dev_gated(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                      size_t *consumed, size_t *produced, const void *gate_dev, unsigned gate_value, void *stream,
+                                      int *gated);
+/* a one-thread kernel on `stream`: *gate_dev <- value (system-scope release) */
+PCX_API int pcx_gate_signal_dev(void *gate_dev, unsigned value, void *stream);
 
 /* ===================================================================== *
  *  /comms/fft             fft/FFT.cpp, fft/FFTAux.h, fft/kissfft.hh, fft/kiss_fft.c
@@ -247,6 +272,11 @@ PCX_API int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems,
                                 size_t *consumed, size_t *produced);
 PCX_API int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                                     size_t *consumed, size_t *produced, void *stream);
+/* one shard of a sharded chain in ONE launch, as pcx_fir_process_dev_gated: the halo in front of the shard is K samples here
+ * (the FIR's K-1 and the one FreqDemod's `_prev` needs, FreqDemod.cpp:63-65); gated for K <= 2048 and long calls */
+PCX_API int pcx_fmchain_process_dev_gated(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                          size_t *consumed, size_t *produced, const void *gate_dev, unsigned gate_value, void *stream,
+                                          int *gated);
 
 /* ===================================================================== *
  *  ONE complex_float32 stream over the GPUs of a node  (BASELINE.json configs[3])
@@ -256,7 +286,8 @@ PCX_API int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t i
  *  call's history (:305-307).  A stream of G*C samples is split into G contiguous shards of C samples, one per
  *  device; before every pass shard g receives the LAST K-1 samples of shard g-1 into the slot in front of its own
  *  samples (RCCL ncclSend/ncclRecv, one group per pass, (K-1)*8 bytes per boundary), shard 0 keeps the stream's
- *  own history.  The body of each shard is filtered while the halo is in flight, its first 4096 outputs after it.
+ *  own history.  Each shard is ONE kernel launch per pass: everything behind its first block is filtered while the halo is in
+ *  flight, the first block last, behind a gate word the halo stream sets (pcx_fir_process_dev_gated).
  *  One process drives all devices (ncclCommInitAll): a Pothos block that owns a pcx_shard spreads its stream over
  *  the node from inside one work() call.  M = L = 1, complex_float32 (the north-star path).
  *
@@ -275,6 +306,10 @@ PCX_API int pcx_shard_destroy(pcx_shard *s);
 /* FIRFilter::setTaps on every device's filter, FIRFilter.cpp:138-144; REAL (complex_taps = 0) or COMPLEX taps */
 PCX_API int pcx_shard_set_taps(pcx_shard *s, const double *taps, size_t ntaps, int complex_taps);
 PCX_API int pcx_shard_set_algo(pcx_shard *s, int algo);                 /* pcx_fir_algo, default PCX_FIR_AUTO */
+/* enable != 0: the shards run the fused chain Rotate(phase) -> FIR -> FreqDemod (pcx_fmchain, BASELINE configs[4]) instead of the
+ * FIR alone: float32 outputs, a halo of K samples (the FIR's K-1 and FreqDemod's one, FreqDemod.cpp:63-65), every pass from the
+ * reset state (the first output of the stream is arg of a zero, FreqDemod.cpp:44-47).  Call before pcx_shard_configure. */
+PCX_API int pcx_shard_set_chain(pcx_shard *s, int enable, double phase);
 /* allocate, on every device, [halo (K-1) | shard_elems samples] and shard_elems outputs; the halo of shard 0 (the
  * stream's history) starts as zeros, as after FIRFilter::activate */
 PCX_API int pcx_shard_configure(pcx_shard *s, size_t shard_elems);
@@ -284,7 +319,8 @@ PCX_API int pcx_shard_info(const pcx_shard *s, int *nshards, size_t *K, size_t *
 PCX_API int pcx_shard_buffers(pcx_shard *s, int g, void **in_dev, void **out_dev, void **stream, int *device);
 /* host_stream: K-1 history samples followed by nshards*shard_elems samples; only shard 0 receives a halo from here */
 PCX_API int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems);
-/* one pass over every shard: halo exchange, body, head */
+/* one pass over every shard: the halo exchange and ONE launch per shard (pcx_fir_process_dev_gated); configurations without a
+ * gated kernel run body, exchange, head as two launches */
 PCX_API int pcx_shard_step(pcx_shard *s);
 /* the nshards*shard_elems outputs in stream order (waits for the pass) */
 PCX_API int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems);

@@ -48,6 +48,8 @@ SIGNATURES = {
     "pcx_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "pcx_memcpy_d2d": (_i, [_vp, _vp, _sz, _vp]),
     "pcx_stream_sync": (_i, [_vp]),
+    "pcx_pointer_kind": (_i, [_vp, C.POINTER(_i)]),
+    "pcx_memcpy_to_host": (_i, [_vp, _vp, _sz]),
     "pcx_trace": (_i, [_i]),
     "pcx_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "pcx_host_free": (_i, [_vp]),
@@ -62,6 +64,8 @@ SIGNATURES = {
     "pcx_fir_last_algo": (_i, [_vp]),
     "pcx_fir_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz]),
     "pcx_fir_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp]),
+    "pcx_fir_process_dev_gated": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp, C.c_uint, _vp, C.POINTER(C.c_int)]),
+    "pcx_gate_signal_dev": (_i, [_vp, C.c_uint, _vp]),
     "pcx_fft_create": (_i, [_i, _sz, _i, C.POINTER(_vp)]),
     "pcx_fft_destroy": (_i, [_vp]),
     "pcx_fft_transform": (_i, [_vp, _vp, _vp, _sz]),
@@ -96,10 +100,12 @@ SIGNATURES = {
     "pcx_fmchain_last_algo": (_i, [_vp]),
     "pcx_fmchain_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz]),
     "pcx_fmchain_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp]),
+    "pcx_fmchain_process_dev_gated": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp, C.c_uint, _vp, C.POINTER(C.c_int)]),
     "pcx_shard_create": (_i, [_i, C.POINTER(C.c_int), _i, C.POINTER(_vp)]),
     "pcx_shard_destroy": (_i, [_vp]),
     "pcx_shard_set_taps": (_i, [_vp, C.POINTER(C.c_double), _sz, _i]),
     "pcx_shard_set_algo": (_i, [_vp, _i]),
+    "pcx_shard_set_chain": (_i, [_vp, _i, _d]),
     "pcx_shard_configure": (_i, [_vp, _sz]),
     "pcx_shard_info": (_i, [_vp, C.POINTER(C.c_int), _psz, _psz, C.POINTER(C.c_int)]),
     "pcx_shard_buffers": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),

@@ -251,11 +251,13 @@ class Block:
         _check(load().pcxb_link_buffer(self._h, downstream._h, nbytes, C.byref(p), C.byref(sz), C.byref(kind)))
         return p.value, kind.value
 
-    def work_raw(self, in_ptr, in_elems, out_ptr, out_elems):
+    def work_raw(self, in_ptr, in_elems, out_ptr, out_elems, labels=()):
         """One work() call on raw buffer addresses (host or device memory).  Returns (consumed, produced, reserve)."""
-        labs, posted = (PcxbLabel * 1)(), (PcxbLabel * 64)()
+        labs, posted = (PcxbLabel * max(1, len(labels)))(), (PcxbLabel * 64)()
+        for i, l in enumerate(labels):
+            l._to_c(labs[i])
         c, p, r, npost = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-        _check(load().pcxb_work(self._h, C.c_void_p(in_ptr), in_elems, labs, 0, C.c_void_p(out_ptr), out_elems, C.byref(c), C.byref(p),
+        _check(load().pcxb_work(self._h, C.c_void_p(in_ptr), in_elems, labs, len(labels), C.c_void_p(out_ptr), out_elems, C.byref(c), C.byref(p),
                                 C.byref(r), posted, 64, C.byref(npost)))
         return c.value, p.value, (None if r.value == _SIZE_MAX else r.value)
 

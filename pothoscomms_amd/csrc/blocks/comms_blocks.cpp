@@ -26,6 +26,7 @@
 #include <cmath>
 #include <complex>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -98,27 +99,55 @@ void check(int rc, const std::string &where)
  **********************************************************************/
 constexpr size_t kPortSlabBytes = 8u << 20;
 #ifdef PCX_WITH_POTHOS
-// Pothos build: the generic pool logic over page-locked slabs.  [Written against the PothosCore 0.7 headers from memory;
-// PothosCore is not installable in this image, so this branch has never been compiled -- INTEGRATION.md 2.]
-class PinnedBufferManager : public Pothos::GenericBufferManager {
+// Pothos build: a pool of page-locked slabs behind Pothos::BufferManager's PUBLIC interface (init / empty / pop / push over
+// setFrontBuffer) -- the pool logic of the framework's own "generic" manager, which lives in PothosCore's library
+// (lib/Framework/Builtin/GenericBufferManager.cpp) and is not in the installed headers, so it cannot be a base class here
+// (ADVICE r2).  Slabs come from pcx_host_alloc: the C ABI's host-pointer entry points then run their kernels on the port
+// buffers in place over PCIe instead of staging them.
+// [PothosCore is not installable in this image: this branch is parsed and type-checked against a declaration-only header set
+// (tests/pothos_decl, tests/test_pothos_syntax_cpu.py) and has never been linked or run -- INTEGRATION.md 2.]
+class PinnedBufferManager : public Pothos::BufferManager, public std::enable_shared_from_this<PinnedBufferManager> {
 public:
+    explicit PinnedBufferManager(size_t slabBytes) : _slabBytes(slabBytes) {}
     void init(const Pothos::BufferManagerArgs &args) override
     {
         Pothos::BufferManager::init(args);
+        const size_t bytes = std::max(args.bufferSize, _slabBytes);
         for (size_t i = 0; i < args.numBuffers; i++) {
             void *p = nullptr;
-            if (pcx_host_alloc(&p, args.bufferSize) != PCX_OK) throw Pothos::Exception("PinnedBufferManager::init()", pcx_last_error());
+            if (pcx_host_alloc(&p, bytes) != PCX_OK) throw Pothos::Exception("PinnedBufferManager::init()", pcx_last_error());
             auto keep = std::shared_ptr<void>(p, [](void *q) { (void)pcx_host_free(q); });
-            Pothos::SharedBuffer sb(size_t(p), args.bufferSize, keep);
+            Pothos::SharedBuffer sb(size_t(p), bytes, keep);
             Pothos::ManagedBuffer mb;
             mb.reset(this->shared_from_this(), sb, i);
             this->push(mb);
         }
     }
+    bool empty() const override { return _ready.empty(); }
+    void pop(const size_t) override
+    {
+        _ready.pop_front();     // the consumer holds the chunk; the slab comes back through push() when its last reference goes
+        if (_ready.empty()) this->setFrontBuffer(Pothos::BufferChunk::null());
+        else this->setFrontBuffer(Pothos::BufferChunk(_ready.front()));
+    }
+    void push(const Pothos::ManagedBuffer &buff) override
+    {
+        if (_ready.empty()) this->setFrontBuffer(Pothos::BufferChunk(buff));
+        _ready.push_back(buff);
+    }
+
+private:
+    size_t _slabBytes;
+    std::deque<Pothos::ManagedBuffer> _ready;
 };
-static pcxfw::BufferManager::Sptr pinnedManager(const std::string &, size_t = kPortSlabBytes)
+// "circular": the FIR's sliding window needs its K-1 history contiguous in front of new samples, which the framework's own
+// circular manager provides by mapping its memory twice (FIRFilter.cpp:196-199 asks for exactly this).  That memory is pageable:
+// the C ABI stages it through its bounce buffer.  (Page-locking it afterwards with hipHostRegister is the upgrade path,
+// INTEGRATION.md 3.)  Anything else: page-locked slabs.
+static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
 {
-    return pcxfw::BufferManager::Sptr(new PinnedBufferManager());   // the scheduler calls init() with its own args
+    if (name == "circular") return Pothos::BufferManager::make("circular");
+    return pcxfw::BufferManager::Sptr(new PinnedBufferManager(slabBytes));   // the scheduler calls init() with its own args
 }
 #else
 static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
@@ -318,7 +347,9 @@ public:
         size_t srcElems = avail;
         if (_eobSampsLeft != 0 && _eobSampsLeft < _inputRequire) {
             _flush.assign((_eobSampsLeft + K - 1) * _elemBytes, 0);
-            std::memcpy(_flush.data(), src, _eobSampsLeft * _elemBytes);
+            // the port buffer may be a DEVICE slab (the upstream block is one of this module's, getInputBufferManager): the CPU must
+            // not read it (this was a std::memcpy)
+            check(pcx_memcpy_to_host(_flush.data(), src, _eobSampsLeft * _elemBytes), "FIRFilter::work()");
             src = _flush.data();
             srcElems = _eobSampsLeft + K - 1;
         }

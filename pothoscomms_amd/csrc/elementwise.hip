@@ -469,6 +469,18 @@ __global__ void zero_words_kernel(unsigned *p, unsigned nwords)
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nwords) p[i] = 0u;
 }
+// the halo gate of a sharded stream (pcx_sched.hpp Gate): queued on the stream that carried the halo, behind the transfer
+__global__ void gate_signal_kernel(unsigned *word, unsigned value)
+{
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int launch_gate_signal(void *gate_word, unsigned value, hipStream_t st)
+{
+    hipLaunchKernelGGL(gate_signal_kernel, dim3(1), dim3(1), 0, st, (unsigned *)gate_word, value);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 int launch_zero_words(void *p, size_t nwords, hipStream_t st)
 {
     if (nwords == 0) return PCX_OK;

@@ -41,12 +41,12 @@ namespace pcx {
 // without the LDS exchanges, 4 = real stream, LDS exchanges without the butterflies (energy split)
 // HGLOBAL: fetch the lane's 16 H bins from L2 in every block instead of holding them in 32 VGPRs
 // -- room for the register prefetch at 4 workgroups per CU.
-template <bool PREFETCH, int LAUX = 0, int SAUX = 0, int CHUNKED = 0, int DIAG = 0, bool HGLOBAL = false>
+template <bool PREFETCH, int LAUX = 0, int SAUX = 0, int CHUNKED = 0, int DIAG = 0, bool HGLOBAL = false, bool GATED = false>
 __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                   const float2 *__restrict__ twtab, size_t first_full,
-                                                                  size_t nfull, size_t nblocks, SchedState *__restrict__ sched)
+                                                                  size_t nfull, size_t nblocks, SchedState *__restrict__ sched, Gate gate)
 {
     // Kov >= K-1 outputs are dropped at the head of every block and the block's input window starts
     // `pad` = Kov-(K-1) samples before sample b*S: with Kov a multiple of 16 every row this kernel
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
     if (CHUNKED == 3) {
         static_assert(CHUNKED != 3 || !PREFETCH, "the register prefetch needs the next block's index a block early");
         if (!deal.begin(sched, &sched_slot, nblocks, j)) { deal.finish(j); return; }
-        b = deal.block(); bend = nblocks; bstep = 0;
+        b = GATED ? nblocks - 1 - deal.block() : deal.block();     // GATED (a shard behind a halo): the front blocks last
+        bend = nblocks; bstep = 0;
     } else if (CHUNKED == 2) {
         // XCD-aware walk: workgroup w runs on XCD w % 8 (round-robin dispatch).  Each XCD takes one
         // contiguous eighth of the blocks and its workgroups walk it side by side, so the window rows
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
             const size_t bn = b + bstep;
             if (bn < bend) fetch(nx, bn);   // in flight during this block's math
         } else {
+            if (CHUNKED == 3 && GATED && b < gate.blocks) gate_wait(gate, j);   // this block's window reaches into the halo slot
             fetch(v, b);
         }
         constexpr int PART = DIAG == 3 ? 1 : DIAG == 4 ? 2 : 0;
@@ -197,15 +199,19 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         __builtin_amdgcn_s_setprio(0);
         if (CHUNKED == 3) {
             if (!deal.advance()) break;
-            b = deal.block();
+            b = GATED ? nblocks - 1 - deal.block() : deal.block();
         }
     }
     if (CHUNKED == 3) deal.finish(j);
 }
 
+// gate_word != nullptr: the caller wants the blocks that read in[0 .. K-2] held until *gate_word reaches gate_value.  Only the
+// dealt kernel has the gate; *gated says whether this launch honours it -- if not, NOTHING has been launched and the caller
+// orders the halo in front of the call itself.
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                            const void *tw4096, void *sched, hipStream_t st)
+                            const void *tw4096, void *sched, hipStream_t st, const void *gate_word, unsigned gate_value, int *gated)
 {
+    if (gated) *gated = 0;
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2049) { set_error("fir ols: K=%zu outside 1..2049", K); return PCX_ERR_UNSUPPORTED; }
     // PCX_OLS_VARIANT (libpcx_hip_diag.so only: the product library has no such switch): unset = default policy below;
@@ -238,7 +244,12 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     const unsigned slots = (unsigned)PCX_ENV_INT("PCX_OLS_SLOTS", 1024);
     const unsigned g4 = persistent_grid(nblocks, slots), g3 = persistent_grid(nblocks, 768);
     const unsigned gx = 8 * persistent_grid((nblocks + 7) / 8, 128);   // XCD-aware walk: equal rounds inside every XCD's eighth
-#define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks, (SchedState *)sched)
+    const bool dealt = sched && nblocks > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");   // (PCX_SCHED_STATIC, diag only: the grid stride, for A/B)
+    if (gate_word && !dealt) return PCX_OK;       // no gate in the grid-stride kernels: *gated stays 0, nothing launched
+    // the window of block b starts at sample b*S - pad: only block 0 reaches below K-1 (Kov <= 2048 <= S)
+    const Gate gate{dealt ? (const unsigned *)gate_word : nullptr, gate_value, 1u};
+    if (gated && gate.word) *gated = 1;
+#define PCX_OLS_LAUNCH(KERN, GRID) hipLaunchKernelGGL(KERN, dim3(GRID), dim3(256), 0, st, pi, in_elems, po, n_out, ph, (int)Kov, (int)pad, pt, first_full, nfull, nblocks, (SchedState *)sched, gate)
 #ifdef PCX_DIAG
     switch (variant) {
     case 0: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<true>), g3); goto launched;
@@ -267,7 +278,16 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
 #endif
     // non-temporal stores; non-temporal loads for the rows no other block reads; blocks dealt dynamically when the caller
     // brought the counter pair (every pcx_fir handle does), else the grid stride
-    if (sched && nblocks > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC")) {   // (PCX_SCHED_STATIC, diag only: the grid stride, for A/B)
+    if (dealt && gate.word) {
+        // (Leaving a few of the 1024 resident slots empty, so that the kernels the gate waits for -- the halo's receive or copy, the
+        // one-thread signal -- find room beside this launch, measured no better: 0.2196 ms at 1024 workgroups, 0.2242 at 1008,
+        // two shards on one device, profiles/r03/shard_probe.txt.  PCX_GATED_SLOTS (diag) sets the number.)
+        const unsigned gd = (unsigned)PCX_ENV_INT("PCX_GATED_SLOTS", 1024);
+        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3, 0, false, true>), gd);
+        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3, 0, false, true>), gd);
+        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3, 0, false, true>), gd);
+        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3, 0, false, true>), gd);
+    } else if (dealt) {
         const unsigned gd = 1024;   // 4 resident workgroups per CU, all of them drawing
         if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3>), gd);
         else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3>), gd);
@@ -564,13 +584,13 @@ int launch_interleave_rows_cf32(const void *rows, void *out, size_t n, size_t L,
 // sample (8 in, 4 out).  The overlap is rounded up to a multiple of 32 samples (aligned 1 KiB
 // output rows); 128 VGPRs, 4 workgroups per CU.
 // --------------------------------------------------------------------------------- //
-template <int OCC, int NOV, int SAUX, bool DYN = false>
+template <int OCC, int NOV, int SAUX, bool DYN = false, bool GATED = false>
 __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                         float *__restrict__ out, size_t n_out,
                                                                         const float2 *__restrict__ Hspec, int K, int pad,
                                                                         const float2 *__restrict__ twtab, size_t nblocks,
                                                                         const float2 *__restrict__ prev_in,
-                                                                        float2 *__restrict__ prev_out, SchedState *__restrict__ sched)
+                                                                        float2 *__restrict__ prev_out, SchedState *__restrict__ sched, Gate gate)
 {
     // K here = the block overlap: taps + pad, a multiple of 32 so that every 1 KiB row of outputs
     // this kernel stores starts on a 128-byte line (see fir_cf32_ols4096_kernel)
@@ -584,7 +604,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
     BlockDealer deal;        // DYN: blocks dealt dynamically (pcx_sched.hpp)
     if (DYN) {
         if (!deal.begin(sched, &sched_slot, nblocks, j)) { deal.finish(j); return; }
-        b = deal.block();
+        b = GATED ? nblocks - 1 - deal.block() : deal.block();     // GATED (a shard behind a halo): the front blocks last
     } else if (b >= nblocks) return;
     LaneTw tw3;
     load_pass3_twiddles(tw3, twtab, j);
@@ -624,6 +644,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
     };
     for (; b < nblocks; b += DYN ? 0 : gridDim.x) {
         cf v[16];
+        if (DYN && GATED && b < gate.blocks) gate_wait(gate, j);   // this block's window reaches into the halo slot
         fetch(v, b);
         pass1_math(v);
         if (DYN) deal.draw(j);              // behind the first butterflies (pcx_sched.hpp)
@@ -737,15 +758,18 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         __builtin_amdgcn_s_setprio(0);
         if (DYN) {
             if (!deal.advance()) break;
-            b = deal.block();
+            b = GATED ? nblocks - 1 - deal.block() : deal.block();
         }
     }
     if (DYN) deal.finish(j);
 }
 
+// gate_word / gated: as launch_fir_cf32_ols4096 (the halo of a sharded chain is K samples: the FIR's K-1 and the demodulator's one)
 int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                                const void *tw4096, const void *prev_in, void *prev_out, void *sched, hipStream_t st)
+                                const void *tw4096, const void *prev_in, void *prev_out, void *sched, hipStream_t st,
+                                const void *gate_word, unsigned gate_value, int *gated)
 {
+    if (gated) *gated = 0;
     if (n_out == 0) return PCX_OK;
     if (K < 1 || K > 2048) { set_error("fm chain ols: K=%zu outside 1..2048", K); return PCX_ERR_UNSUPPORTED; }
     // PCX_FMCHAIN_OCC (libpcx_hip_diag.so only, A/B): 3 = 3 workgroups per CU, 5 = 4 per CU with plain loads/stores; default 4 + row policy
@@ -754,16 +778,25 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
     const bool dyn = sched && nblocks > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");   // dynamic dealing when the handle brought its counter pair and the launch is long
+    if (gate_word && !dyn) return PCX_OK;         // no gate in the grid-stride kernel: *gated stays 0, nothing launched
+    // the window of block b starts at sample b*S - 1 - pad: it reaches below sample K while b*S < Kov + 1 -- block 0, and block 1
+    // too when S == Kov (2048 taps)
+    const Gate gate{dyn ? (const unsigned *)gate_word : nullptr, gate_value, S < Kov + 1 ? 2u : 1u};
+    if (gated && gate.word) *gated = 1;
 #define PCX_FM_LAUNCH(OCC, NOV, SAUX, CAP)                                                                                       \
     do {                                                                                                                         \
-        if (dyn)                                                                                                                 \
+        if (dyn && gate.word)                                                                                                    \
+            hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX, true, true>), dim3(CAP), dim3(256), 0, st, (const float2 *)in, \
+                               in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096,  \
+                               nblocks, (const float2 *)prev_in, (float2 *)prev_out, (SchedState *)sched, gate);                  \
+        else if (dyn)                                                                                                            \
             hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX, true>), dim3(CAP), dim3(256), 0, st, (const float2 *)in, \
                                in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, (const float2 *)tw4096,  \
-                               nblocks, (const float2 *)prev_in, (float2 *)prev_out, (SchedState *)sched);                        \
+                               nblocks, (const float2 *)prev_in, (float2 *)prev_out, (SchedState *)sched, gate);                  \
         else                                                                                                                     \
             hipLaunchKernelGGL((fmchain_cf32_ols4096_kernel<OCC, NOV, SAUX>), dim3(persistent_grid(nblocks, CAP)), dim3(256), 0, st, \
                                (const float2 *)in, in_elems, (float *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad,      \
-                               (const float2 *)tw4096, nblocks, (const float2 *)prev_in, (float2 *)prev_out, (SchedState *)nullptr); \
+                               (const float2 *)tw4096, nblocks, (const float2 *)prev_in, (float2 *)prev_out, (SchedState *)nullptr, gate); \
     } while (0)
 #ifdef PCX_DIAG
     if (occ == 3) PCX_FM_LAUNCH(3, 8, 0, 768);            // A/B: 3 workgroups per CU, plain loads and stores

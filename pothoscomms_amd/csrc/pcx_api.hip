@@ -279,6 +279,29 @@ int pcx_host_alloc(void **hptr, size_t bytes)
     return PCX_OK;
 }
 int pcx_host_free(void *hptr) { PCX_HIP(hipHostFree(hptr)); return PCX_OK; }
+int pcx_pointer_kind(const void *p, int *kind)
+{
+    PCX_CHECK_ARG(kind, "null kind");
+    *kind = PCX_PTR_PAGEABLE;
+    if (!p) return PCX_OK;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return PCX_OK; }   // unknown to the runtime: pageable
+    if (a.type == hipMemoryTypeDevice) *kind = PCX_PTR_DEVICE;
+    else if (a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged) *kind = PCX_PTR_PAGE_LOCKED;
+    return PCX_OK;
+}
+int pcx_memcpy_to_host(void *dst_host, const void *src, size_t bytes)
+{
+    PCX_CHECK_ARG(dst_host && src, "null buffer");
+    int kind = PCX_PTR_PAGEABLE;
+    PCX_TRY(pcx_pointer_kind(src, &kind));
+    if (kind != PCX_PTR_DEVICE) { std::memcpy(dst_host, src, bytes); return PCX_OK; }
+    // device memory: the CPU must not touch it.  A blocking copy, and the null stream drained behind it (profiles/r02/contention.md:
+    // a blocking copy is not complete on return for the purposes of a non-blocking stream)
+    PCX_HIP(hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost));
+    PCX_HIP(hipStreamSynchronize(nullptr));
+    return PCX_OK;
+}
 int pcx_stream_sync(void *st) { PCX_HIP(hipStreamSynchronize(as_stream(st))); return PCX_OK; }
 int pcx_fill_uniform_f32_dev(float *dst, size_t n, uint64_t seed, uint64_t offset, void *st)
 {
@@ -921,11 +944,34 @@ static size_t fir_iterations(const pcx_fir *h, size_t in_elems, size_t out_cap)
     return std::min(a, b) * h->M;
 }
 
+static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                size_t *consumed, size_t *produced, void *stream, const void *gate_word, unsigned gate_value, int *gated);
+
 int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                         size_t *consumed, size_t *produced, void *stream)
 {
     PCX_TRACE();
+    return fir_process_dev_impl(h, in_dev, in_elems, out_dev, out_cap, consumed, produced, stream, nullptr, 0, nullptr);
+}
+int pcx_fir_process_dev_gated(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                              size_t *consumed, size_t *produced, const void *gate_dev, unsigned gate_value, void *stream, int *gated)
+{
+    PCX_TRACE();
+    PCX_CHECK_ARG(gate_dev && gated, "null gate");
+    return fir_process_dev_impl(h, in_dev, in_elems, out_dev, out_cap, consumed, produced, stream, gate_dev, gate_value, gated);
+}
+int pcx_gate_signal_dev(void *gate_dev, unsigned value, void *stream)
+{
+    PCX_TRACE();
+    PCX_CHECK_ARG(gate_dev, "null gate");
+    return launch_gate_signal(gate_dev, value, as_stream(stream));
+}
+
+static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                size_t *consumed, size_t *produced, void *stream, const void *gate_word, unsigned gate_value, int *gated)
+{
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    if (gated) *gated = 0;
     DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
     const size_t N = fir_iterations(h, in_elems, out_cap);
@@ -965,6 +1011,19 @@ int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *o
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
+    if (gate_word) {
+        // a gated call: only the plain complex_float32 M = L = 1 plan on 4096-sample blocks has the gate (and only its dealt launch,
+        // launch_fir_cf32_ols4096 decides).  Anything else: *gated stays 0, nothing has been queued, the caller orders the halo itself.
+        const bool plain = algo == PCX_FIR_OLS_FFT && !h->have_interp_real && !h->have_interp64 && !h->have_ols_real64 && !h->have_ols64 &&
+                           !h->have_ols_int && !h->have_real_ols && !h->have_interp && !h->have_decim && !h->have_poly && h->ols_log2n == 0;
+        if (!plain) return PCX_OK;
+        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, gate_word, gate_value, gated);
+        if (rc != PCX_OK || !*gated) return rc;
+        h->last_algo = algo;
+        *consumed = N;
+        *produced = n_out;
+        return PCX_OK;
+    }
     // interpolation through polyphase ROWS: every row filtered at the input rate into a contiguous workspace row, then one
     // interleaving pass.  Long calls go in batches of iterations so that the workspace stays at kRowsWorkspaceCap bytes
     // whatever the call (it would be a second copy of the output otherwise).
@@ -1836,6 +1895,14 @@ static int fmchain_sync(pcx_fmchain *h)
     h->dirty = false;
     return PCX_OK;
 }
+// (internal, pcx_shard.hip) upload the chain's tables now instead of at its next call
+namespace pcx {
+int fmchain_prepare(pcx_fmchain *h)
+{
+    DeviceScope dev_scope(h->cx.device);
+    return fmchain_sync(h);
+}
+}  // namespace pcx
 int pcx_fmchain_set_algo(pcx_fmchain *h, int algo)
 {
     PCX_CHECK_ARG(h, "null handle");
@@ -1844,11 +1911,26 @@ int pcx_fmchain_set_algo(pcx_fmchain *h, int algo)
     return PCX_OK;
 }
 int pcx_fmchain_last_algo(const pcx_fmchain *h) { return h ? h->last_algo : PCX_ERR_ARG; }
+static int fmchain_process_dev_impl(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                    size_t *consumed, size_t *produced, void *stream, const void *gate_word, unsigned gate_value, int *gated);
 int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                             size_t *consumed, size_t *produced, void *stream)
 {
     PCX_TRACE();
+    return fmchain_process_dev_impl(h, in_dev, in_elems, out_dev, out_cap, consumed, produced, stream, nullptr, 0, nullptr);
+}
+int pcx_fmchain_process_dev_gated(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                  size_t *consumed, size_t *produced, const void *gate_dev, unsigned gate_value, void *stream, int *gated)
+{
+    PCX_TRACE();
+    PCX_CHECK_ARG(gate_dev && gated, "null gate");
+    return fmchain_process_dev_impl(h, in_dev, in_elems, out_dev, out_cap, consumed, produced, stream, gate_dev, gate_value, gated);
+}
+static int fmchain_process_dev_impl(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
+                                    size_t *consumed, size_t *produced, void *stream, const void *gate_word, unsigned gate_value, int *gated)
+{
     PCX_CHECK_ARG(h && consumed && produced, "null argument");
+    if (gated) *gated = 0;
     DeviceScope dev_scope(h->cx.device);
     *consumed = 0; *produced = 0;
     PCX_TRY(fmchain_sync(h));
@@ -1859,6 +1941,7 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     char *base = static_cast<char *>(h->prev.p);
     PCX_TRY(ctx_enter(h->cx, as_stream(stream)));
     int algo = h->algo;
+    if (gate_word && !(h->have_ols && (algo == PCX_FIR_AUTO || algo == PCX_FIR_OLS_FFT))) return PCX_OK;   // no gate but in the fused frequency-domain kernel
     if (algo == PCX_FIR_AUTO && !h->have_ols) {
         // K > 2048: two launches (FIR with the folded phasor, then FreqDemod) sharing the chain's carried state
         // (in batches: the intermediate FIR output stays at kRowsWorkspaceCap bytes whatever the call; the demodulator's state
@@ -1882,7 +1965,8 @@ int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems,
     if (algo == PCX_FIR_OLS_FFT) {
         if (!h->have_ols) { set_error("fm chain: OLS_FFT needs K <= 2048"); return PCX_ERR_UNSUPPORTED; }
         PCX_TRY(launch_fmchain_cf32_ols4096(in_dev, N + h->K - 1, out_dev, N, h->Hspec.p, h->K, h->tw4096.p, base + 32 * h->cur,
-                                            base + 32 * (h->cur ^ 1), h->sched.p, as_stream(stream)));
+                                            base + 32 * (h->cur ^ 1), h->sched.p, as_stream(stream), gate_word, gate_value, gated));
+        if (gate_word && !*gated) return PCX_OK;      // a short call: the grid-stride kernel has no gate, nothing was queued
     } else {
         PCX_TRY(launch_fmchain_cf32(in_dev, N + h->K - 1, out_dev, N, h->tapsRev.p, h->K, h->Kp, base + 32 * h->cur,
                                     base + 32 * (h->cur ^ 1), as_stream(stream)));

@@ -92,6 +92,40 @@ struct BlockDealer {
     }
 };
 
+// A gate for the blocks of a launch that read the halo slot of a sharded stream (pcx_shard.hip, stream.py): the launch covers the
+// WHOLE shard, walks its blocks in reverse order so that the blocks at the front -- the only ones whose windows reach into the halo
+// -- are dealt last, and holds those until a 32-bit word in device memory has reached `value` (signed distance: the word carries
+// the pass number, nobody resets it).  The word is written by a one-thread kernel queued behind the halo transfer on its stream
+// (pcx_gate_signal_dev).  One launch per shard and pass instead of a body launch plus a head launch behind an event: the second
+// launch's start-up, its ragged end and the kernel boundary cost 5-14 % of a pass (profiles/r02/shard_probe.txt).
+// Visibility: the halo bytes were written by another kernel or by a copy engine and are complete before the signalling kernel
+// starts (stream order); the word is polled with system-scope loads, and a system-scope acquire behind the poll drops whatever
+// this CU's L1 holds (the XCD's L2 cannot be stale for local memory: MTYPE RW lines are probed).
+struct Gate {
+    const unsigned *word;     // nullptr: no gate, natural block order
+    unsigned value, blocks;   // blocks 0 .. blocks-1 wait
+};
+// The wait is BOUNDED: a signal that never comes (a caller's bug, a failed transfer) must not hang the device.  After kGateTimeout
+// the block goes ahead on whatever the halo slot holds and leaves kGateTimedOut in the word behind the gate word, where the host
+// finds it (pcx_shard_sync reports PCX_ERR_STATE).
+constexpr unsigned long long kGateTimeoutTicks = 200000000ull;     // 2 s of s_memrealtime (100 MHz)
+constexpr unsigned kGateTimedOut = 0xDEADu;
+__device__ __forceinline__ void gate_wait(const Gate &g, int lane)
+{
+    if (lane == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - g.value) < 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kGateTimeoutTicks) {
+                __hip_atomic_store(const_cast<unsigned *>(g.word) + 1, kGateTimedOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
 // One spelling for both walks, so a kernel is written once: BlockWalk<false> is the grid stride, BlockWalk<true> the dealer.
 //     BlockWalk<DYN> walk;
 //     if (!walk.begin(sched, &slot, nblocks, lane)) { walk.finish(lane); return; }

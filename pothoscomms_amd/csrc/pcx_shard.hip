@@ -9,11 +9,23 @@
 // shard 0 keeps the stream's own history.  One process, one communicator over the devices (ncclCommInitAll), one stream
 // pair and one FIR handle per device, 2,032 bytes per boundary and pass for 255 taps, no other collective.
 //
-// Per device g and pass (pcx_shard_step):
-//     compute stream   [record in_ready] ......... body: outputs head..C-1 .......... [wait halo_ready] head: outputs 0..head-1
-//     halo stream      [wait in_ready(g, g-1)]  recv halo <- g-1 / send tail -> g+1  [record halo_ready]
-// Only the first `head` = 4096 outputs read the halo, so the exchange (pure latency for 2 KB) hides behind the body of
-// the pass.  in_ready also orders the NEXT pass's receive behind this pass's head kernel, which reads the halo slot.
+// Per device g and pass (pcx_shard_step) -- ONE kernel launch per shard:
+//     compute stream   [record in_ready] .. the whole shard, its blocks walked back to front; block 0, the only one whose window
+//                                            reaches into the halo slot, is dealt LAST and waits for the gate word
+//     halo stream      [wait in_ready(g, g-1)]  recv halo <- g-1 / send tail -> g+1  [gate word <- pass number] [record halo_done]
+// (pcx_fir_process_dev_gated / pcx_sched.hpp Gate).  The exchange -- pure latency for 2 KB -- hides behind the rest of the
+// shard, and there is no second launch with its own start-up, ragged end and kernel boundary (round 2 ran a body launch and
+// a head launch behind an event: +14 % per pass with two shards on one device, profiles/r02/shard_probe.txt).  Configurations
+// without a gated kernel (anything but the 4096-sample complex_float32 plan, or shards of fewer than ~2048 blocks) keep the two
+// launches: body = outputs head..C-1 with head >= K-1 so that it never touches the halo slot, then the head behind halo_done.
+// in_ready also orders the NEXT pass's receive behind this pass's kernel, which reads the halo slot; halo_done(g) is waited for
+// by compute stream g-1 at the end of the step, so that nothing queued on it later (the caller's next fill) can overwrite the
+// tail of shard g-1 while the exchange is still reading it.
+//
+// The fused chain Rotate -> FIR -> FreqDemod (pcx_shard_set_chain, BASELINE configs[4]) shards the same way with a halo of K
+// samples -- the FIR's K-1 and the one sample FreqDemod's `_prev` needs (FreqDemod.cpp:63-65) -- and one extra output in front
+// of every shard but the first, computed only to be that predecessor and dropped.  Every pass starts from the reset state, as
+// a single-device run of the whole stream does.
 //
 // RCCL is loaded on first use (dlopen "librccl.so.1"): a single-GPU Pothos process never maps the 570 MB library, and
 // a process that already holds a copy (PyTorch bundles one under the same SONAME) shares it instead of loading a second.
@@ -105,17 +117,26 @@ struct pcx_shard {
     const RcclApi *rccl = nullptr;
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> st, hst;             // compute / halo stream per shard
-    std::vector<hipEvent_t> in_ready, halo_ready;
+    std::vector<hipEvent_t> in_ready, halo_ready;  // halo_ready(g): the exchange that WROTE shard g's halo slot and READ shard g-1's tail is done
     std::vector<pcx_fir *> fir;
-    std::vector<void *> alloc, out;               // per shard: [lead | halo K-1 | C] and C outputs (cf32)
+    std::vector<pcx_fmchain *> chain;             // chain mode: the fused Rotate -> FIR -> FreqDemod handle of each device
+    std::vector<void *> gate;                     // per shard: the 32-bit gate word (device memory), holds the pass number
+    bool chain_mode = false;
+    double phase = 0.0;
+    std::vector<double> taps;                     // as given to set_taps (chain mode re-applies them with the phase)
+    int complex_taps = 0;
+    std::vector<void *> alloc, out;               // per shard: [lead | halo | C] (cf32) and the outputs (cf32, or float32 in chain mode: 1 + C)
     std::vector<std::unique_ptr<PinBuf>> bounce_in, bounce_out;   // scatter / gather of PAGEABLE host memory (pcx_api.hip stage_in)
-    size_t K = 1, C = 0, lead = 0, head = 0;
+    size_t K = 1, C = 0, head = 0;
+    std::vector<size_t> lead;                     // per shard: samples in front of the halo slot (alignment, pcx_shard_configure)
     bool have_taps = false;
     unsigned long long steps = 0;
-    float2 *in_ptr(int g) const { return static_cast<float2 *>(alloc[g]) + lead; }
+    size_t halo() const { return chain_mode ? K : K - 1; }      // samples in front of every shard
+    float2 *in_ptr(int g) const { return static_cast<float2 *>(alloc[g]) + lead[g]; }       // the halo slot
+    float2 *hist_ptr(int g) const { return in_ptr(g) + (halo() - (K - 1)); }                  // the K-1 history samples in front of the shard
 };
 
-static constexpr size_t kHead = 4096;   // outputs computed after the halo has landed: one overlap-save block's worth, whatever K
+static constexpr size_t kHead = 4096;   // two-launch fallback: outputs computed after the halo has landed (at least K-1: the body must not read the halo slot)
 
 #define PCX_CHECK_ARG(cond, ...)        \
     do {                                \
@@ -153,6 +174,8 @@ int pcx_shard_destroy(pcx_shard *s)
     for (int g = 0; g < s->G; g++) {
         (void)hipSetDevice(s->dev[g]);
         if (g < (int)s->fir.size() && s->fir[g]) (void)pcx_fir_destroy(s->fir[g]);
+        if (g < (int)s->chain.size() && s->chain[g]) (void)pcx_fmchain_destroy(s->chain[g]);
+        if (g < (int)s->gate.size() && s->gate[g]) (void)hipFree(s->gate[g]);
         if (g < (int)s->in_ready.size() && s->in_ready[g]) (void)hipEventDestroy(s->in_ready[g]);
         if (g < (int)s->halo_ready.size() && s->halo_ready[g]) (void)hipEventDestroy(s->halo_ready[g]);
         if (g < (int)s->st.size() && s->st[g]) (void)hipStreamDestroy(s->st[g]);
@@ -186,16 +209,24 @@ int pcx_shard_create(int nshards, const int *devices, int transport, pcx_shard *
     s->comm.assign(nshards, nullptr);
     s->st.assign(nshards, nullptr); s->hst.assign(nshards, nullptr);
     s->in_ready.assign(nshards, nullptr); s->halo_ready.assign(nshards, nullptr);
-    s->fir.assign(nshards, nullptr);
+    s->fir.assign(nshards, nullptr); s->chain.assign(nshards, nullptr); s->gate.assign(nshards, nullptr);
     s->alloc.assign(nshards, nullptr); s->out.assign(nshards, nullptr);
+    s->lead.assign(nshards, 0);
     for (int g = 0; g < nshards; g++) { s->bounce_in.emplace_back(new PinBuf()); s->bounce_out.emplace_back(new PinBuf()); }
     DeviceGuard guard;
     auto fail = [&](int rc) { (void)pcx_shard_destroy(s); return rc; };
     for (int g = 0; g < nshards; g++) {
+        // (halo streams at the device's highest stream priority were tried -- the exchange ahead of the passes' own kernels -- and
+        // made every pass SLOWER: 0.2242 -> 0.2411 ms with two shards on one device, 0.2674 -> 0.4570 with eight,
+        // profiles/r03/shard_probe.txt; PCX_SHARD_HALO_PRIO=1 in the diagnostic library repeats it)
+        int prio_lo = 0, prio_hi = 0;
+        if (PCX_ENV_INT("PCX_SHARD_HALO_PRIO", 0) != 0 && hipSetDevice(dev[g]) == hipSuccess &&
+            hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_hi = 0; }
         if (hipSetDevice(dev[g]) != hipSuccess || hipStreamCreateWithFlags(&s->st[g], hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&s->hst[g], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithPriority(&s->hst[g], hipStreamNonBlocking, prio_hi) != hipSuccess ||
             hipEventCreateWithFlags(&s->in_ready[g], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s->halo_ready[g], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s->halo_ready[g], hipEventDisableTiming) != hipSuccess ||
+            hipMalloc(&s->gate[g], 256) != hipSuccess || hipMemset(s->gate[g], 0, 256) != hipSuccess) {
             set_error("pcx_shard: stream/event setup on device %d failed: %s", dev[g], hipGetErrorString(hipGetLastError()));
             return fail(PCX_ERR_HIP);
         }
@@ -227,16 +258,36 @@ int pcx_shard_create(int nshards, const int *devices, int transport, pcx_shard *
     return PCX_OK;
 }
 
+// taps (and, in chain mode, the phase) on every device's handle
+static int shard_apply_taps(pcx_shard *s)
+{
+    const size_t ntaps = s->K;
+    if (s->chain_mode) {
+        for (int g = 0; g < s->G; g++) {
+            PCX_TRY(pcx_fmchain_set_phase(s->chain[g], s->phase));
+            PCX_TRY(pcx_fmchain_set_taps(s->chain[g], s->taps.data(), ntaps, s->complex_taps));
+        }
+        return PCX_OK;
+    }
+    // the per-device FIR handles are COMPLEX-tap filters; REAL taps are the same filter with zero imaginary parts
+    std::vector<double> t(2 * ntaps);
+    for (size_t k = 0; k < ntaps; k++) {
+        t[2 * k] = s->complex_taps ? s->taps[2 * k] : s->taps[k];
+        t[2 * k + 1] = s->complex_taps ? s->taps[2 * k + 1] : 0.0;
+    }
+    for (int g = 0; g < s->G; g++) PCX_TRY(pcx_fir_set_taps(s->fir[g], t.data(), ntaps));
+    return PCX_OK;
+}
+
 int pcx_shard_set_taps(pcx_shard *s, const double *taps, size_t ntaps, int complex_taps)
 {
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_ARG(ntaps > 0 && taps, "FIRFilter::setTaps(): taps cannot be empty");
-    // the per-device handles are COMPLEX-tap filters; REAL taps are the same filter with zero imaginary parts
-    std::vector<double> t(2 * ntaps);
-    for (size_t k = 0; k < ntaps; k++) { t[2 * k] = complex_taps ? taps[2 * k] : taps[k]; t[2 * k + 1] = complex_taps ? taps[2 * k + 1] : 0.0; }
     const size_t Kold = s->K;
-    for (int g = 0; g < s->G; g++) PCX_TRY(pcx_fir_set_taps(s->fir[g], t.data(), ntaps));
+    s->taps.assign(taps, taps + ntaps * (complex_taps ? 2 : 1));
+    s->complex_taps = complex_taps ? 1 : 0;
     s->K = ntaps;
+    PCX_TRY(shard_apply_taps(s));
     s->have_taps = true;
     if (s->C && ntaps != Kold) {   // the halo slot in front of every shard changes size: the buffers must be laid out again
         DeviceGuard guard;
@@ -245,10 +296,32 @@ int pcx_shard_set_taps(pcx_shard *s, const double *taps, size_t ntaps, int compl
     return PCX_OK;
 }
 
+int pcx_shard_set_chain(pcx_shard *s, int enable, double phase)
+{
+    PCX_CHECK_ARG(s, "null handle");
+    DeviceGuard guard;
+    const bool was = s->chain_mode;
+    if (enable) {
+        for (int g = 0; g < s->G; g++)
+            if (!s->chain[g]) {
+                PCX_HIP(hipSetDevice(s->dev[g]));
+                PCX_TRY(pcx_fmchain_create(&s->chain[g]));
+            }
+    }
+    s->chain_mode = enable != 0;
+    s->phase = phase;
+    if (s->have_taps) PCX_TRY(shard_apply_taps(s));
+    if (s->C && was != s->chain_mode) shard_free_buffers(s);   // another halo, another output type: lay the buffers out again
+    return PCX_OK;
+}
+
 int pcx_shard_set_algo(pcx_shard *s, int algo)
 {
     PCX_CHECK_ARG(s, "null handle");
-    for (int g = 0; g < s->G; g++) PCX_TRY(pcx_fir_set_algo(s->fir[g], algo));
+    for (int g = 0; g < s->G; g++) {
+        PCX_TRY(pcx_fir_set_algo(s->fir[g], algo));
+        if (s->chain[g] && (algo == PCX_FIR_AUTO || algo == PCX_FIR_DIRECT || algo == PCX_FIR_OLS_FFT)) PCX_TRY(pcx_fmchain_set_algo(s->chain[g], algo));
+    }
     return PCX_OK;
 }
 
@@ -257,22 +330,34 @@ int pcx_shard_configure(pcx_shard *s, size_t shard_elems)
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_ARG(s->have_taps, "pcx_shard_configure: set the taps first (the halo is K-1 samples)");
     PCX_CHECK_ARG(shard_elems >= 1, "pcx_shard_configure: empty shard");
-    PCX_CHECK_ARG(s->G == 1 || shard_elems >= s->K - 1, "pcx_shard_configure: a shard of %zu samples is shorter than the %zu-sample halo its neighbour needs",
-                  shard_elems, s->K - 1);
+    const size_t halo = s->halo();
+    PCX_CHECK_ARG(s->G == 1 || shard_elems >= halo, "pcx_shard_configure: a shard of %zu samples is shorter than the %zu-sample halo its neighbour needs",
+                  shard_elems, halo);
     DeviceGuard guard;
     shard_free_buffers(s);
-    // [lead | halo (K-1) | shard (C)] with the SHARD on a 128-byte line: the overlap-save kernel rounds its block overlap
-    // up to 16 samples, so with this placement every 2 KiB row it loads and every row it stores starts on a line
-    // (measured 0.2245 -> 0.2187 ms per 64 Mi samples against a line-aligned halo)
-    s->lead = (16 - (s->K - 1) % 16) % 16;
+    // [lead | halo | shard (C)], placed so that every 2 KiB row the overlap-save kernels load and every row they store starts on a
+    // 128-byte line (measured 0.2245 -> 0.2187 ms per 64 Mi samples against a line-aligned halo).  FIR: the kernel rounds its block
+    // overlap K-1 up to 16 samples and starts its windows `pad` samples before the history, so the history goes pad samples behind
+    // a line -- which puts the SHARD on a line.  Chain: the overlap is K rounded up to 32 and a window starts 1 + pad samples
+    // before the call's first sample: shard 0 is called on [K-1 history | C] (reset state, as a single-device run), every other
+    // shard on [K halo | C] (one extra output in front, dropped), so their slots differ by one sample.
+    for (int g = 0; g < s->G; g++) {
+        if (!s->chain_mode) s->lead[g] = (16 - (s->K - 1) % 16) % 16;
+        else {
+            const size_t pad = (s->K + 31) / 32 * 32 - s->K;
+            s->lead[g] = (pad + (g == 0 ? 0 : 1)) % 16;
+        }
+    }
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_HIP(hipMalloc(&s->alloc[g], (s->lead + s->K - 1 + shard_elems) * sizeof(float2)));
-        PCX_HIP(hipMalloc(&s->out[g], shard_elems * sizeof(float2)));
-        PCX_HIP(hipMemsetAsync(s->alloc[g], 0, (s->lead + s->K - 1) * sizeof(float2), s->st[g]));   // stream start: zero history
+        PCX_HIP(hipMalloc(&s->alloc[g], (s->lead[g] + halo + shard_elems) * sizeof(float2)));
+        PCX_HIP(hipMalloc(&s->out[g], s->chain_mode ? (shard_elems + 1) * sizeof(float) : shard_elems * sizeof(float2)));
+        PCX_HIP(hipMemsetAsync(s->alloc[g], 0, (s->lead[g] + halo) * sizeof(float2), s->st[g]));   // stream start: zero history
     }
     s->C = shard_elems;
-    s->head = std::min(kHead, shard_elems);
+    // the two-launch fallback's split: the body (outputs head .. C-1) reads in[head ..], which must lie behind the halo slot
+    // in[0 .. K-2] whatever K -- a fixed 4096 let filters of more than 4097 taps read a halo that had not arrived yet
+    s->head = std::min(shard_elems, std::max(kHead, (halo + kHead - 1) / kHead * kHead));
     return PCX_OK;
 }
 
@@ -291,8 +376,8 @@ int pcx_shard_buffers(pcx_shard *s, int g, void **in_dev, void **out_dev, void *
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_ARG(g >= 0 && g < s->G, "pcx_shard_buffers: shard %d of %d", g, s->G);
     PCX_CHECK_ARG(s->C, "pcx_shard_buffers: call pcx_shard_configure first");
-    if (in_dev) *in_dev = s->in_ptr(g);
-    if (out_dev) *out_dev = s->out[g];
+    if (in_dev) *in_dev = s->hist_ptr(g);
+    if (out_dev) *out_dev = s->chain_mode ? static_cast<void *>(static_cast<float *>(s->out[g]) + 1) : s->out[g];
     if (stream) *stream = s->st[g];
     if (device) *device = s->dev[g];
     return PCX_OK;
@@ -330,17 +415,17 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
         const size_t skip = g == 0 ? 0 : s->K - 1;
         const size_t bytes = (s->K - 1 - skip + s->C) * sizeof(float2);
         const float2 *src = x + (size_t)g * s->C + skip;
+        float2 *dst = s->hist_ptr(g) + skip;
         if (!locked) {
             PinBuf &b = *s->bounce_in[g];
             constexpr size_t kPiece = (size_t)4 << 20;     // the CPU copies piece i+1 while piece i is on the wire
             for (size_t off = 0; off < bytes; off += kPiece) {
                 const size_t c = bytes - off < kPiece ? bytes - off : kPiece;
                 std::memcpy(static_cast<char *>(b.p) + off, reinterpret_cast<const char *>(src) + off, c);
-                PCX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(s->in_ptr(g) + skip) + off, static_cast<const char *>(b.p) + off, c,
-                                       hipMemcpyHostToDevice, s->st[g]));
+                PCX_HIP(hipMemcpyAsync(reinterpret_cast<char *>(dst) + off, static_cast<const char *>(b.p) + off, c, hipMemcpyHostToDevice, s->st[g]));
             }
         } else {
-            PCX_HIP(hipMemcpyAsync(s->in_ptr(g) + skip, src, bytes, hipMemcpyHostToDevice, s->st[g]));
+            PCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->st[g]));
         }
     }
     return PCX_OK;
@@ -352,9 +437,10 @@ int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
     PCX_CHECK_ARG(s && host_out, "null argument");
     PCX_CHECK_ARG(s->C && elems == (size_t)s->G * s->C, "pcx_shard_gather: %zu elements, expected shards*C = %zu", elems, (size_t)s->G * s->C);
     DeviceGuard guard;
-    float2 *y = static_cast<float2 *>(host_out);
+    const size_t esz = s->chain_mode ? sizeof(float) : sizeof(float2);
+    char *y = static_cast<char *>(host_out);
     const bool locked = device_alias(host_out) != nullptr;
-    const size_t bytes = s->C * sizeof(float2);
+    const size_t bytes = s->C * esz;
     if (!locked) {
         // allocations first, transfers afterwards (see pcx_shard_scatter) -- and not while the pass is still running: gather waits
         // for it in any case, so it waits BEFORE the first page-locked allocation (the halo copies of a pass came out zero when
@@ -369,13 +455,14 @@ int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
     }
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
-        void *dst = locked ? static_cast<void *>(y + (size_t)g * s->C) : s->bounce_out[g]->p;
-        PCX_HIP(hipMemcpyAsync(dst, s->out[g], bytes, hipMemcpyDeviceToHost, s->st[g]));
+        void *dst = locked ? static_cast<void *>(y + (size_t)g * bytes) : s->bounce_out[g]->p;
+        const void *src = s->chain_mode ? static_cast<const void *>(static_cast<const float *>(s->out[g]) + 1) : s->out[g];
+        PCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->st[g]));
     }
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         PCX_HIP(hipStreamSynchronize(s->st[g]));
-        if (!locked) std::memcpy(y + (size_t)g * s->C, s->bounce_out[g]->p, bytes);
+        if (!locked) std::memcpy(y + (size_t)g * bytes, s->bounce_out[g]->p, bytes);
     }
     return PCX_OK;
 }
@@ -389,16 +476,51 @@ int pcx_shard_sync(pcx_shard *s)
         PCX_HIP(hipStreamSynchronize(s->st[g]));
         PCX_HIP(hipStreamSynchronize(s->hst[g]));
     }
+    // a gated launch that gave up waiting for its halo (pcx_sched.hpp gate_wait: two seconds) says so in the word behind its gate
+    for (int g = 1; g < s->G && s->steps; g++) {
+        unsigned words[2] = {0, 0};
+        PCX_HIP(hipSetDevice(s->dev[g]));
+        PCX_HIP(hipMemcpy(words, s->gate[g], sizeof words, hipMemcpyDeviceToHost));
+        if (words[1] == 0xDEADu) {
+            set_error("pcx_shard: shard %d did not receive its halo within two seconds of a pass (gate word %u, pass %llu)", g, words[0], s->steps);
+            return PCX_ERR_STATE;
+        }
+    }
     return PCX_OK;
 }
 
-static int shard_run(pcx_shard *s, int g, size_t first_out, size_t n_out)
+// FIR mode: outputs [first_out, first_out + n_out) of shard g, which read in[first_out : first_out + n_out + K - 1].
+// gate != nullptr: through the gated entry point; *gated = 0 means nothing was queued.
+static int shard_run_fir(pcx_shard *s, int g, size_t first_out, size_t n_out, const void *gate, unsigned value, int *gated)
 {
-    // outputs [first_out, first_out + n_out) read in[first_out : first_out + n_out + K - 1]
     size_t c = 0, p = 0;
-    PCX_TRY(pcx_fir_process_dev(s->fir[g], s->in_ptr(g) + first_out, n_out + s->K - 1, static_cast<float2 *>(s->out[g]) + first_out, n_out, &c, &p,
-                                s->st[g]));
+    const float2 *in = s->in_ptr(g) + first_out;
+    float2 *out = static_cast<float2 *>(s->out[g]) + first_out;
+    if (gate) {
+        PCX_TRY(pcx_fir_process_dev_gated(s->fir[g], in, n_out + s->K - 1, out, n_out, &c, &p, gate, value, s->st[g], gated));
+        if (!*gated) return PCX_OK;
+    } else {
+        PCX_TRY(pcx_fir_process_dev(s->fir[g], in, n_out + s->K - 1, out, n_out, &c, &p, s->st[g]));
+    }
     if (c != n_out || p != n_out) { set_error("pcx_shard: shard %d produced %zu of %zu outputs", g, p, n_out); return PCX_ERR_STATE; }
+    return PCX_OK;
+}
+// chain mode: the whole shard from the reset state.  Shard 0: [K-1 history | C] -> C outputs at out + 1; every other shard:
+// [K halo | C] -> 1 + C outputs at out (the first exists only to be the demodulator's predecessor of the second).
+static int shard_run_chain(pcx_shard *s, int g, const void *gate, unsigned value, int *gated)
+{
+    size_t c = 0, p = 0;
+    const size_t extra = g == 0 ? 0 : 1, n_out = s->C + extra;
+    const float2 *in = s->in_ptr(g) + (1 - extra);
+    float *out = static_cast<float *>(s->out[g]) + (1 - extra);
+    PCX_TRY(pcx_fmchain_reset(s->chain[g]));
+    if (gate) {
+        PCX_TRY(pcx_fmchain_process_dev_gated(s->chain[g], in, n_out + s->K - 1, out, n_out, &c, &p, gate, value, s->st[g], gated));
+        if (!*gated) return PCX_OK;
+    } else {
+        PCX_TRY(pcx_fmchain_process_dev(s->chain[g], in, n_out + s->K - 1, out, n_out, &c, &p, s->st[g]));
+    }
+    if (c != n_out || p != n_out) { set_error("pcx_shard: chain shard %d produced %zu of %zu outputs", g, p, n_out); return PCX_ERR_STATE; }
     return PCX_OK;
 }
 
@@ -409,30 +531,35 @@ int pcx_shard_step(pcx_shard *s)
     PCX_CHECK_ARG(s->C, "pcx_shard_step: call pcx_shard_configure first");
     DeviceGuard guard;
     const int G = s->G;
-    const size_t halo = s->K - 1, hbytes = halo * sizeof(float2);
+    const size_t halo = s->halo(), hbytes = halo * sizeof(float2);
     // every shard's tables are on its device BEFORE anything of the pass is queued: uploading them lazily -- allocations and
     // transfers of the control plane -- between other shards' queued work lost one shard's pass (AMD_DIRECT_DISPATCH=0,
     // tests/test_shard_gpu.py retap test; the rule of pcx_shard_scatter)
     for (int g = 0; g < G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_TRY(fir_prepare(s->fir[g]));
+        if (s->chain_mode) PCX_TRY(fmchain_prepare(s->chain[g]));
+        else PCX_TRY(fir_prepare(s->fir[g]));
     }
+    auto whole = [&](int g) -> int {   // the whole shard in one plain call
+        return s->chain_mode ? shard_run_chain(s, g, nullptr, 0, nullptr) : shard_run_fir(s, g, 0, s->C, nullptr, 0, nullptr);
+    };
     if (G == 1 || halo == 0) {
         // nothing to exchange: each shard is one plain call (with one device, exactly pcx_fir_process_dev on the whole stream)
         for (int g = 0; g < G; g++) {
             PCX_HIP(hipSetDevice(s->dev[g]));
-            PCX_TRY(shard_run(s, g, 0, s->C));
+            PCX_TRY(whole(g));
         }
         s->steps++;
         return PCX_OK;
     }
+    const unsigned pass = (unsigned)(s->steps + 1);      // the value the gate words take in this pass (compared by signed distance)
     // 1. inputs of this pass are in place once everything queued on the compute streams so far has run (the caller's
-    //    fill / scatter, and the previous pass's head kernel, which READ the halo slot this pass overwrites)
+    //    fill / scatter, and the previous pass's kernel, which READ the halo slot this pass overwrites)
     for (int g = 0; g < G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         PCX_HIP(hipEventRecord(s->in_ready[g], s->st[g]));
     }
-    // 2. the exchange, on the halo streams: tail of shard g -> halo slot of shard g+1, in place
+    // 2. the exchange, on the halo streams: tail of shard g -> halo slot of shard g+1, in place; behind it the gate word
     for (int g = 0; g < G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         PCX_HIP(hipStreamWaitEvent(s->hst[g], s->in_ready[g], 0));
@@ -441,7 +568,7 @@ int pcx_shard_step(pcx_shard *s)
     if (s->transport == PCX_SHARD_RCCL) {
         PCX_RCCL(s->rccl, s->rccl->GroupStart());
         for (int g = 0; g < G; g++) {
-            if (g + 1 < G) PCX_RCCL(s->rccl, s->rccl->Send(s->in_ptr(g) + s->C, hbytes, ncclChar, g + 1, s->comm[g], s->hst[g]));   // last K-1 samples
+            if (g + 1 < G) PCX_RCCL(s->rccl, s->rccl->Send(s->in_ptr(g) + s->C, hbytes, ncclChar, g + 1, s->comm[g], s->hst[g]));   // the last `halo` samples
             if (g > 0) PCX_RCCL(s->rccl, s->rccl->Recv(s->in_ptr(g), hbytes, ncclChar, g - 1, s->comm[g], s->hst[g]));
         }
         PCX_RCCL(s->rccl, s->rccl->GroupEnd());
@@ -451,21 +578,33 @@ int pcx_shard_step(pcx_shard *s)
             PCX_HIP(hipMemcpyPeerAsync(s->in_ptr(g), s->dev[g], s->in_ptr(g - 1) + s->C, s->dev[g - 1], hbytes, s->hst[g]));
         }
     }
-    for (int g = 1; g < G; g++) {
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_HIP(hipEventRecord(s->halo_ready[g], s->hst[g]));
-    }
-    // 3. the body of every shard while the halos are in flight (it does not touch the halo slot) ...
-    if (s->C > s->head)
-        for (int g = 0; g < G; g++) {
-            PCX_HIP(hipSetDevice(s->dev[g]));
-            PCX_TRY(shard_run(s, g, s->head, s->C - s->head));
-        }
-    // 4. ... then the head, behind the halo
     for (int g = 0; g < G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
-        if (g > 0) PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[g], 0));
-        PCX_TRY(shard_run(s, g, 0, s->head));
+        if (g > 0) PCX_TRY(pcx_gate_signal_dev(s->gate[g], pass, s->hst[g]));
+        // halo_ready(g): RCCL -- the send that reads shard g's tail and the receive into its halo slot are done;
+        // peer copies -- the copy that reads shard g-1's tail and writes shard g's halo slot is done
+        if (g > 0 || s->transport == PCX_SHARD_RCCL) PCX_HIP(hipEventRecord(s->halo_ready[g], s->hst[g]));
+    }
+    // 3. every shard in ONE launch: shard 0 has no halo to wait for; the others hold their first block behind the gate
+    for (int g = 0; g < G; g++) {
+        PCX_HIP(hipSetDevice(s->dev[g]));
+        if (g == 0) { PCX_TRY(whole(0)); continue; }
+        int gated = 0;
+        if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, s->gate[g], pass, &gated));
+        else PCX_TRY(shard_run_fir(s, g, 0, s->C, s->gate[g], pass, &gated));
+        if (gated) continue;
+        // no gated kernel for this configuration: the round-2 scheme.  FIR: the body while the halo is in flight, then the head
+        // behind it; chain (long filters, short shards): the halo first, then the shard
+        if (!s->chain_mode && s->C > s->head) PCX_TRY(shard_run_fir(s, g, s->head, s->C - s->head, nullptr, 0, nullptr));
+        PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[g], 0));
+        if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, nullptr, 0, nullptr));
+        else PCX_TRY(shard_run_fir(s, g, 0, s->head, nullptr, 0, nullptr));
+    }
+    // 4. whatever is queued on a compute stream after this step -- the caller's next fill, the next scatter -- must not overwrite
+    //    the tail of its shard while the exchange is still reading it
+    for (int g = 0; g + 1 < G; g++) {
+        PCX_HIP(hipSetDevice(s->dev[g]));
+        PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[s->transport == PCX_SHARD_RCCL ? g : g + 1], 0));
     }
     s->steps++;
     return PCX_OK;

@@ -75,7 +75,7 @@ def _dev_ptr(t):
 def _stream_ptr(stream=None):
     import torch
     s = torch.cuda.current_stream() if stream is None else stream
-    return C.c_void_p(s.cuda_stream)
+    return C.c_void_p(s if isinstance(s, int) else s.cuda_stream)      # a torch stream, or a raw hipStream_t
 
 
 class _Handle:
@@ -161,6 +161,25 @@ class FirFilter(_Handle):
         _lib.check(_lib.load().pcx_fir_process_dev(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap,
                                                    C.byref(c), C.byref(p), _stream_ptr(stream)))
         return c.value, p.value
+
+    def process_dev_gated(self, x, y, gate, value, in_elems=None, out_cap=None, stream=None):
+        """pcx_fir_process_dev_gated: one launch over a shard whose first K-1 samples (the halo) are still on their way; the blocks
+        that read them wait until the 32-bit word `gate` (a device tensor) has reached `value`.  Returns (consumed, produced, gated);
+        gated == False: nothing was queued (no gated kernel for this configuration)."""
+        w = 2 if self.is_complex else 1
+        if in_elems is None:
+            in_elems = x.numel() // w
+        if out_cap is None:
+            out_cap = y.numel() // w
+        c, p, g = C.c_size_t(), C.c_size_t(), C.c_int()
+        _lib.check(_lib.load().pcx_fir_process_dev_gated(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap, C.byref(c), C.byref(p),
+                                                         _dev_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream), C.byref(g)))
+        return c.value, p.value, bool(g.value)
+
+
+def gate_signal(gate, value, stream=None):
+    """pcx_gate_signal_dev: a one-thread kernel on `stream` (default: torch's current one) that sets the gate word to `value`."""
+    _lib.check(_lib.load().pcx_gate_signal_dev(_dev_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream)))
 
 
 class Fft(_Handle):
@@ -255,6 +274,13 @@ class FmChain(_Handle):
         _lib.check(_lib.load().pcx_fmchain_process_dev(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap,
                                                        C.byref(c), C.byref(p), _stream_ptr(stream)))
         return c.value, p.value
+
+    def process_dev_gated(self, x, y, gate, value, in_elems, out_cap, stream=None):
+        """pcx_fmchain_process_dev_gated (see FirFilter.process_dev_gated; the halo is K samples).  Returns (consumed, produced, gated)."""
+        c, p, g = C.c_size_t(), C.c_size_t(), C.c_int()
+        _lib.check(_lib.load().pcx_fmchain_process_dev_gated(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap, C.byref(c), C.byref(p),
+                                                             _dev_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream), C.byref(g)))
+        return c.value, p.value, bool(g.value)
 
 
 # ---- stateless maps ------------------------------------------------------------------
@@ -402,6 +428,11 @@ class NodeStream(_Handle):
     def set_algo(self, algo):
         _lib.check(_lib.load().pcx_shard_set_algo(self._h, algo))
 
+    def set_chain(self, enable, phase=0.0):
+        """pcx_shard_set_chain: the shards run Rotate(phase) -> FIR -> FreqDemod (float32 outputs, halo of K samples)."""
+        _lib.check(_lib.load().pcx_shard_set_chain(self._h, int(bool(enable)), float(phase)))
+        self.chain = bool(enable)
+
     def configure(self, shard_elems):
         _lib.check(_lib.load().pcx_shard_configure(self._h, shard_elems))
         self.C = shard_elems
@@ -423,6 +454,7 @@ class NodeStream(_Handle):
         _lib.check(_lib.load().pcx_shard_sync(self._h))
 
     def gather(self, out=None):
-        y = np.empty((self.nshards * self.C, 2), np.float32) if out is None else out
+        shape = (self.nshards * self.C,) if getattr(self, "chain", False) else (self.nshards * self.C, 2)
+        y = np.empty(shape, np.float32) if out is None else out
         _lib.check(_lib.load().pcx_shard_gather(self._h, _np_ptr(y), y.shape[0]))
         return y

@@ -14,10 +14,14 @@ in front of the shard so the kernel sees the same "history at the front" buffer 
 call (pcx_fir_process_dev), and the received bytes land in place (no staging copy).  The shard,
 not the halo, is placed on a 128-byte line (see ShardedFir.__init__).
 
-Latency hiding: a 2 KB message is pure latency (tens of microseconds against a ~0.25 ms pass).
-Only the first `head` outputs of a shard read the halo, so a pass (a) posts the exchange,
-(b) filters everything behind the head while the message is in flight, (c) waits, (d) filters
-the head.  The wait then costs nothing unless the link is slower than the body of the pass.
+Latency hiding: a 2 KB message is pure latency (tens of microseconds against a ~0.2 ms pass).
+Only the first block of a shard reads the halo, so a pass is ONE kernel launch over the whole
+shard that walks its blocks back to front and holds the first one behind a gate word
+(pcx_fir_process_dev_gated, include/pcx.h): the exchange is posted on a side stream, a one-thread
+kernel behind it sets the gate, and everything else of the shard is filtered meanwhile.  (Round 2
+ran a body launch, waited, and ran a head launch: the second launch's start-up, ragged end and
+kernel boundary cost 5.6 % of a pass.)  Configurations without a gated kernel, and host-driven
+backends (the gloo rehearsal), keep the two launches.
 """
 import torch
 import torch.distributed as dist
@@ -86,7 +90,8 @@ class ShardedFir:
         self._alloc = torch.zeros((lead + self.K - 1 + self.C, 2), dtype=torch.float32, device=device)
         self.buf = self._alloc[lead:]
         self.out = torch.empty((self.C, 2), dtype=torch.float32, device=device)
-        self.head = min(self.HEAD, self.C)
+        # the two-launch fallback's split: the body (outputs head .. C-1) must not read the halo slot buf[0 : K-1]
+        self.head = min(self.C, max(self.HEAD, -(-(self.K - 1) // self.HEAD) * self.HEAD))
 
     @property
     def shard(self):
@@ -98,16 +103,53 @@ class ShardedFir:
         c, p = self.fir.process_dev(self.buf[first_out:], self.out[first_out:], n_out + self.K - 1, n_out)
         assert c == n_out and p == n_out, (c, p, n_out)
 
+    def _gate_setup(self):
+        # the gate word (holds the pass number) and the side stream the exchange is posted on
+        if getattr(self, "_gate", None) is None:
+            self._gate = torch.zeros((64,), dtype=torch.int32, device=self.buf.device)
+            self._side = torch.cuda.Stream(device=self.buf.device)
+            self._pass = 0
+            self._sent = None
+
     def step(self):
-        """One pass: halo from the left neighbour overlapped with the body, then the head -> C outputs."""
+        """One pass: the halo from the left neighbour in flight while the shard is filtered -> C outputs."""
         if self.ring.world == 1:
             self._run(0, self.C)
             return self.out
+        if self.buf.is_cuda and dist.is_initialized() and dist.get_backend(self.ring.group) == "nccl":
+            return self._step_gated()
         reqs = self.ring.start(self.buf)
         if self.C > self.head:
             self._run(self.head, self.C - self.head)      # does not touch the halo
         self.ring.finish(reqs)
         self._run(0, self.head)
+        return self.out
+
+    def _step_gated(self):
+        """RCCL: exchange + gate signal on a side stream, ONE gated launch on the current stream (rank 0 has no halo to wait for)."""
+        from . import device as dv
+        self._gate_setup()
+        self._pass += 1
+        cur = torch.cuda.current_stream(self.buf.device)
+        self._side.wait_stream(cur)                       # the shard's samples are in place; the previous pass has read its halo
+        with torch.cuda.stream(self._side):
+            self.ring.finish(self.ring.start(self.buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
+            if self.ring.rank > 0:
+                dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
+        if self.ring.rank == 0:
+            self._run(0, self.C)
+        else:
+            c, p, gated = self.fir.process_dev_gated(self.buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C)
+            if gated:
+                assert c == self.C and p == self.C, (c, p)
+            else:
+                # no gated kernel for this configuration (long filters, short shards): body, wait, head
+                if self.C > self.head:
+                    self._run(self.head, self.C - self.head)
+                cur.wait_stream(self._side)
+                self._run(0, self.head)
+        # nothing queued on this stream later (the next fill of the shard) may overwrite the tail the send is still reading
+        cur.wait_stream(self._side)
         return self.out
 
 
@@ -158,6 +200,8 @@ class ShardedFmChain:
 
     def step(self):
         first = self.ring.rank == 0
+        if self.ring.world > 1 and self.buf.is_cuda and dist.is_initialized() and dist.get_backend(self.ring.group) == "nccl":
+            return self._step_gated()
         reqs = self.ring.start(self.buf)
         if self.C > self.head:
             # body: FIR outputs head-1 .. C-1; the first one only seeds the demodulator and lands on
@@ -168,4 +212,32 @@ class ShardedFmChain:
             self._run(self._chains[0], 1, self.head, 1)             # stream start: reset state, no extra output
         else:
             self._run(self._chains[0], 0, self.head + 1, 0)         # extra output -1 from the halo, dropped
+        return self.out
+
+    def _step_gated(self):
+        """RCCL: the exchange and the gate signal on a side stream, ONE launch over the shard on the current stream (ShardedFir)."""
+        from . import device as dv
+        if getattr(self, "_gate", None) is None:
+            self._gate = torch.zeros((64,), dtype=torch.int32, device=self.buf.device)
+            self._side = torch.cuda.Stream(device=self.buf.device)
+            self._pass = 0
+        self._pass += 1
+        cur = torch.cuda.current_stream(self.buf.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self.ring.finish(self.ring.start(self.buf))
+            if self.ring.rank > 0:
+                dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
+        ch = self._chains[0]
+        if self.ring.rank == 0:
+            self._run(ch, 1, self.C, 1)                             # stream start: reset state, no extra output
+        else:
+            ch.reset()
+            c, p, gated = ch.process_dev_gated(self.buf, self._out, self._gate, self._pass, self.C + 1 + self.K - 1, self.C + 1)
+            if not gated:                                           # long filters, short shards: the halo first, then the shard
+                cur.wait_stream(self._side)
+                self._run(ch, 0, self.C + 1, 0)
+            else:
+                assert c == self.C + 1 and p == self.C + 1, (c, p)
+        cur.wait_stream(self._side)
         return self.out

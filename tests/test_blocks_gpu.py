@@ -566,3 +566,37 @@ def test_edge_to_a_host_block_gets_host_memory():
     arr, pinned = rot.port_buffer(1, (1024, 2), np.float32)
     assert pinned and isinstance(arr, np.ndarray)
     arr[:] = 1.0          # host-addressable
+
+
+def test_burst_flush_on_a_device_resident_edge(oracle):
+    """Rotate -> FIRFilter with setFrameStartId on an edge whose buffer is a DEVICE slab.  A burst shorter than
+    M+K-1 takes FIRFilter::work's flush path (FIRFilter.cpp:263-272), which builds its zero-padded tail on the host: it must fetch
+    the samples with a device copy, not with the CPU.  Equals the oracle block fed the same rotated samples and label."""
+    import ctypes as C
+
+    from pothoscomms_amd import _lib
+    from pothoscomms_amd.blocks import Label
+    L = _lib.load()
+    rng = np.random.default_rng(44)
+    taps = rng.normal(size=31) / 4
+    K, burst = 31, 20                      # burst < K: the whole frame is shorter than the window
+    x = rand_stream(rng, oracle.F32, burst, True)
+    rot = B.make("/comms/rotate", "complex_float32"); rot.call("setPhase", 0.3)
+    fir = B.make("/comms/fir_filter", "complex_float32", "REAL"); fir.call("setTaps", taps); fir.call("setFrameStartId", "S")
+    for b in (rot, fir):
+        b.activate()
+    xin, _ = rot.port_buffer(0, (burst, 2), np.float32)
+    e1, kind = rot.link_buffer(fir, 4096 * 8)
+    assert kind == 2                       # device memory
+    k = C.c_int(-1)
+    _lib.check(L.pcx_pointer_kind(C.c_void_p(e1), C.byref(k)))
+    assert k.value == 2
+    yout, _ = fir.port_buffer(1, (4096, 2), np.float32)
+    xin[:] = x
+    assert rot.work_raw(xin.ctypes.data, burst, e1, burst)[:2] == (burst, burst)
+    c, p, r = fir.work_raw(e1, burst, yout.ctypes.data, 4096, labels=[Label("S", 0, burst)])
+    ref = oracle.Fir(oracle.F32, True, False)
+    ref.set_taps(taps); ref.set_frame_ids(True, False); ref.activate()
+    want, rc, rp, _ = ref.work(oracle.rotate(x, 0.3), 4096, [("S", 0, 1, burst)])      # (id, index, width, length)
+    assert (c, p) == (rc, rp) and p == burst
+    assert nerr(yout[:p], want) <= TOL

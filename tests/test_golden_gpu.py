@@ -96,3 +96,45 @@ def test_reference_test_points_angle_abs(dev, name):
         assert nerr(gc, want) <= 4e-15          # device hypot vs glibc hypot: <= 2 ulp
     else:
         assert np.array_equal(gc, want)         # getAbs compiled from the reference: float32 and the integers bit for bit
+
+
+# ---- Rotate / Scale / Conjugate: the DEVICE against the reference tests' own known answers, with their own tolerances ----
+def _close(got, exp, name):
+    """POTHOS_TEST_CLOSE(out, expected, 1); the int8 expectation is std::complex<int8>(double), whose cast wraps"""
+    got = np.asarray(got, np.float64)
+    if name == "int8":
+        exp = exp.astype(np.int64).astype(np.int8).astype(np.float64)
+        d = np.abs(got - exp)
+        return np.minimum(d, 256 - d)
+    return np.abs(got - exp)
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_rotate_reference_test_points_on_the_device(dev, name):
+    """math/TestRotate.cpp:28-32 (inputs), :50-53 (POTHOS_TEST_CLOSE(out, expected, 1) at phases 0, pi/2, pi, 3pi/2)"""
+    x = GOLD["rotate_in_" + name]
+    for k, phase in enumerate([0.0, np.pi / 2, np.pi, 3 * np.pi / 2]):
+        d = _close(dev.rotate(x, phase), GOLD["rotate_exp_%s_%d" % (name, k)], name)
+        assert np.max(d) <= 1.0, (name, phase)
+        if name.startswith("float"):
+            assert np.max(d) <= 1e-4 * 240          # what float arithmetic owes the exact rotation of +-240
+
+
+@pytest.mark.parametrize("name", TYPES)
+def test_scale_reference_test_points_on_the_device(dev, name):
+    """math/TestScale.cpp:28-31 (inputs), :49-52 (POTHOS_TEST_CLOSE(out, expected, 1) at factors -1, -0.5, 0, 0.5, 1)"""
+    x = GOLD["scale_in_" + name]
+    for k, factor in enumerate([-1.0, -0.5, 0.0, 0.5, 1.0]):
+        d = _close(dev.scale(x, factor, False), GOLD["scale_exp_%s_%d" % (name, k)], name)
+        assert np.max(d) <= 1.0, (name, factor)
+
+
+def test_conjugate_reference_test_points_on_the_device(dev):
+    """math/TestConjugate.cpp:30-34 (inputs), :64-66: exact equality with std::conj, float and integer"""
+    x = GOLD["conj_in"]
+    got = dev.conj(x)
+    assert np.array_equal(got[:, 0], x[:, 0]) and np.array_equal(got[:, 1], -x[:, 1])
+    for dt in (np.int8, np.int16, np.int32, np.int64, np.float64):
+        xi = x.astype(dt)
+        gi = dev.conj(xi)
+        assert np.array_equal(gi[:, 0], xi[:, 0]) and np.array_equal(gi[:, 1], (-xi[:, 1].astype(np.int64)).astype(dt) if dt != np.float64 else -xi[:, 1])

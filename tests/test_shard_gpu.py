@@ -231,3 +231,208 @@ def test_call_order_and_argument_errors():
     xs = np.random.default_rng(0).standard_normal((254 + 800, 2)).astype(np.float32)
     ns.scatter(xs); ns.step()
     assert ns.gather().shape == (800, 2)
+
+
+# ---- round 3: one launch per shard and pass (the gate), long filters, the fused chain ----
+
+def test_the_gate_holds_the_first_block_until_it_is_signalled(oracle):
+    """pcx_fir_process_dev_gated: ONE launch over a shard whose halo has not arrived.  The launch is queued with NaN in the
+    halo slot and the gate closed; 50 ms later another stream writes the halo and signals.  Had block 0 run ahead of the gate the
+    first outputs would be NaN; the result must be bit-identical to the plain call on the completed buffer."""
+    import time
+
+    import torch
+
+    from pothoscomms_amd import device, taps as tp
+    h = tp.c1_taps()
+    K = len(h)
+    n = 2100 * 3840                       # > 2048 blocks: the dealt kernel, which is the one that has the gate
+    dev = torch.device("cuda", 0)
+    lead = (-(K - 1)) % 16
+    xa = torch.empty((lead + K - 1 + n, 2), dtype=torch.float32, device=dev)
+    x = xa[lead:]
+    device.fill_uniform_f32_dev(x, seed=9, offset=0)
+    halo = x[:K - 1].clone()
+    f = device.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h)
+    want = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    assert f.process_dev(x, want) == (n, n)
+    torch.cuda.synchronize()
+    gate = torch.zeros((64,), dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    for value in (1, 2, 0x7FFFFFFF + 3):               # a pass counter, also across the sign bit (signed distance)
+        if value > 2:
+            gate.fill_((value - 1) - (1 << 32) if value - 1 >= (1 << 31) else value - 1)     # the word as int32
+        x[:K - 1] = float("nan")
+        got = torch.full((n, 2), float("nan"), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        c, p, gated = f.process_dev_gated(x, got, gate, value)
+        assert gated and (c, p) == (n, n)
+        time.sleep(0.05)                                # the launch is running (or done, all but block 0) by now
+        with torch.cuda.stream(side):
+            x[:K - 1] = halo
+            device.gate_signal(gate, value, side.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, want)
+    # a short call has no gated kernel: nothing is queued, the caller is told
+    c, p, gated = f.process_dev_gated(x[:K - 1 + 50000], got, gate, 5, out_cap=50000)
+    assert not gated and (c, p) == (0, 0)
+    ref = _oracle_fir(oracle, h, x[:K - 1 + 8192].cpu().numpy(), 8192)
+    assert nerr(want[:8192].cpu().numpy(), ref) <= TOL
+
+
+@pytest.mark.parametrize("G", [2, 3])
+def test_long_shards_take_one_gated_launch_each_and_have_no_seam(oracle, G):
+    """shards of more than 2048 blocks: pcx_shard_step queues ONE launch per shard; poisoned halos, two passes; every shard's output
+    is bit-identical to a plain call on its completed buffer, and the seams agree with the oracle"""
+    import torch
+
+    from pothoscomms_amd import _lib, device, taps as tp
+    L = _lib.load()
+    h = tp.c1_taps()
+    K, Cs = len(h), 2080 * 3840
+    ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+    ns.set_taps(h)
+    ns.configure(Cs)
+    for g in range(G):
+        i, o, s, d = ns.buffers(g)
+        _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (K - 1 + Cs), 4, 2 * g * Cs, C.c_void_p(s)))
+    f = device.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h)
+    for rep in range(2):
+        _poison_halos(ns)
+        ns.step()
+        ns.sync()
+        for g in range(G):
+            i, o, s, d = ns.buffers(g)
+            xin = np.empty((K - 1 + Cs, 2), np.float32)
+            yout = np.empty((Cs, 2), np.float32)
+            _lib.check(L.pcx_memcpy_d2h(xin.ctypes.data_as(C.c_void_p), C.c_void_p(i), xin.nbytes, None))
+            _lib.check(L.pcx_memcpy_d2h(yout.ctypes.data_as(C.c_void_p), C.c_void_p(o), yout.nbytes, None))
+            assert np.isfinite(yout).all(), "shard %d pass %d" % (g, rep)
+            # the seam against the oracle, and the whole shard against a plain call on the same (completed) buffer
+            assert nerr(yout[:6000], _oracle_fir(oracle, h, xin[:K - 1 + 6000], 6000)) <= TOL
+            lead = (-(K - 1)) % 16
+            xa = torch.zeros((lead + K - 1 + Cs, 2), dtype=torch.float32, device="cuda:0")
+            xa[lead:] = torch.from_numpy(xin).cuda()
+            y = torch.empty((Cs, 2), dtype=torch.float32, device="cuda:0")
+            assert f.process_dev(xa[lead:], y) == (Cs, Cs)
+            assert np.array_equal(yout, y.cpu().numpy()), "shard %d pass %d" % (g, rep)
+            if g > 0:      # the halo really is the left neighbour's tail
+                ip, _, _, _ = ns.buffers(g - 1)
+                tail = np.empty((K - 1, 2), np.float32)
+                _lib.check(L.pcx_memcpy_d2h(tail.ctypes.data_as(C.c_void_p), C.c_void_p(ip + 8 * Cs), tail.nbytes, None))
+                assert np.array_equal(xin[:K - 1], tail)
+
+
+@pytest.mark.parametrize("K", [5000, 9000])
+def test_filters_longer_than_the_old_head_split(oracle, K):
+    """the two-launch split used a head of 4096 outputs whatever K, so with K-1 > 4096 the body launch read
+    halo samples that had not arrived.  Two shards, two passes with DIFFERENT data (a stale halo of pass 1 must show in pass 2)."""
+    from pothoscomms_amd import device, taps as tp
+    rng = np.random.default_rng(K)
+    h = (rng.standard_normal(K) + 1j * rng.standard_normal(K)) / K
+    G, Cs = 2, 20000
+    ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+    ns.set_taps(h)
+    ns.configure(Cs)
+    for seed in (11, 12):
+        x = oracle.fill_uniform_f32(2 * (K - 1 + G * Cs), seed, 0).reshape(-1, 2)
+        ns.scatter(x)
+        _poison_halos(ns)
+        ns.step()
+        got = ns.gather()
+        assert np.isfinite(got).all()
+        ref = _oracle_fir(oracle, h, x, G * Cs)
+        # K = 9000 runs the sliding-window kernel in the reference's own order: bit-identical; K = 5000 the 16384-sample plan
+        assert nerr(got, ref) <= (TOL if K <= 8193 else 0.0) + 0.0, nerr(got, ref)
+
+
+def _oracle_chain(o, taps, phase, x, n):
+    r = o.rotate(x, phase)
+    blk = o.Fir(o.F32, True, False)
+    blk.set_taps(taps)
+    blk.activate()
+    y, c, p, _ = blk.work(r, n)
+    assert p == n
+    return o.FreqDemod(o.F32).work(y)
+
+
+@pytest.mark.parametrize("G,Cs", [(2, 30000), (3, 7000), (2, 2080 * 3968)])
+def test_the_fused_chain_shards_behind_the_c_abi(oracle, G, Cs):
+    """pcx_shard_set_chain: Rotate -> FIR(127 real taps) -> FreqDemod over G shards (halo of K samples, one extra output in front of
+    every shard but the first, dropped).  Small shards run the ungated path, the long ones ONE gated launch per shard; the seams
+    (windows around every shard boundary) and the stream start agree with the oracle's three blocks, the whole stream with the
+    single-device fused kernel."""
+    import torch
+
+    from pothoscomms_amd import _lib, device, taps as tp
+    from tests.util import ang_err
+    L = _lib.load()
+    h = tp.c4_taps()
+    K = len(h)
+    n = G * Cs
+    ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+    ns.set_chain(True, tp.C4_PHASE)
+    ns.set_taps(h, complex_taps=False)
+    ns.configure(Cs)
+    for g in range(G):
+        i, o, s, d = ns.buffers(g)
+        # shard g: its K-1 history and its samples, straight from the node-wide stream (the exchange must overwrite the history)
+        _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (K - 1 + Cs), 5, 2 * g * Cs, C.c_void_p(s)))
+    for rep in range(2):
+        for g in range(1, G):     # NaN into every halo slot: K-1 history samples + the demodulator's predecessor in front of them
+            i, _, s, _ = ns.buffers(g)
+            nan = np.full((K, 2), np.nan, np.float32)
+            _lib.check(L.pcx_memcpy_h2d(C.c_void_p(i - 8), nan.ctypes.data_as(C.c_void_p), nan.nbytes, C.c_void_p(s)))
+            _lib.check(L.pcx_stream_sync(C.c_void_p(s)))
+        ns.step()
+        got = ns.gather()
+        assert got.shape == (n,) and np.isfinite(got).all()
+        # the whole stream through ONE fused call on one device
+        ch = device.FmChain(); ch.set_phase(tp.C4_PHASE); ch.set_taps(h, False)
+        xa = torch.empty((2 + n + K - 1, 2), dtype=torch.float32, device="cuda:0")
+        device.fill_uniform_f32_dev(xa[2:], seed=5, offset=0)
+        y = torch.empty((n,), dtype=torch.float32, device="cuda:0")
+        assert ch.process_dev(xa[2:], y, n + K - 1, n) == (n, n)
+        # Two device results with different block boundaries, each carrying the transform's ~3e-7 max|y| of rounding in y: the angle
+        # of a sample whose |y| is a thousandth of the largest moves by a thousand times that, and a stream of millions of random
+        # samples holds such samples.  So: twice the bar on all but one sample in 1e5, and no sample off by more than 1e-2 rad
+        # (a seam error is an error of order one); the seams themselves are held to the bar against the oracle below.
+        dd = np.abs((got.astype(np.float64) - y.cpu().numpy() + np.pi) % (2 * np.pi) - np.pi)
+        assert np.quantile(dd, 1 - 1e-5) / np.pi <= 2 * TOL and dd.max() < 1e-2, (np.quantile(dd, 1 - 1e-5), dd.max())
+        # stream start and every seam against the oracle's three blocks
+        xs = xa[2:].cpu().numpy()
+        W = 3000
+        ref0 = _oracle_chain(oracle, h, tp.C4_PHASE, xs[:K - 1 + W], W)
+        assert ang_err(got[:W], ref0) <= TOL
+        for g in range(1, G):
+            a = g * Cs - W                      # outputs a .. a + 2W - 1 straddle the boundary; one more in front seeds the demodulator
+            ref = _oracle_chain(oracle, h, tp.C4_PHASE, xs[a - 1:a - 1 + K - 1 + 2 * W + 1], 2 * W + 1)[1:]
+            assert ang_err(got[a:a + 2 * W], ref) <= TOL, "seam %d" % g
+
+
+def test_a_gate_that_is_never_signalled_times_out_instead_of_hanging():
+    """the wait is bounded (two seconds): the held block then runs on whatever the halo slot holds and says so in gate[1]"""
+    import time
+
+    import torch
+
+    from pothoscomms_amd import device, taps as tp
+    h = tp.c1_taps()
+    K, n = len(h), 2100 * 3840
+    dev = torch.device("cuda", 0)
+    x = torch.zeros((K - 1 + n, 2), dtype=torch.float32, device=dev)
+    y = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    gate = torch.zeros((64,), dtype=torch.int32, device=dev)
+    f = device.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    c, p, gated = f.process_dev_gated(x, y, gate, 1)
+    assert gated
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert 1.5 < dt < 10.0, dt
+    assert int(gate[1].item()) == 0xDEAD and int(gate[0].item()) == 0

@@ -23,8 +23,9 @@ for G in (1, 2, 4, 8):
     n = 200
     for _ in range(n):
         ns.step()
+    host = (time.perf_counter() - t0) / n        # what the host spends queueing one pass
     ns.sync()
     dt = (time.perf_counter() - t0) / n
-    print("G=%d shards on device 0 (%s): %.4f ms per pass over %d samples = %.1f Gsamples/s" %
-          (G, "rccl comm of one" if G == 1 else "peer copies", dt * 1e3, total, total / dt / 1e9))
+    print("G=%d shards on device 0 (%s): %.4f ms per pass over %d samples = %.1f Gsamples/s  (host: %.4f ms to queue a pass)" %
+          (G, "rccl comm of one" if G == 1 else "peer copies", dt * 1e3, total, total / dt / 1e9, host * 1e3))
     ns.close()

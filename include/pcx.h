@@ -150,6 +150,11 @@ PCX_API int pcx_fir_set_algo(pcx_fir *h, int algo);
 PCX_API int pcx_fir_get_geometry(const pcx_fir *h, size_t *K, size_t *input_require);
 /* which algorithm the last process call ran (pcx_fir_algo) */
 PCX_API int pcx_fir_last_algo(const pcx_fir *h);
+/* How many of the device's 1024 resident workgroup slots the handle's persistent launches may take (a multiple of 128; default
+ * 1024 = the whole device).  For handles that run SIDE BY SIDE on one device -- several shards of a stream on one GPU, two filter
+ * blocks of one topology -- so that their launches share the device instead of queueing behind one another's workgroups
+ * (two 32 Mi-sample launches: 0.2196 ms with 1024 each, 0.1988 with 512 each; one 64 Mi launch 0.1971). */
+PCX_API int pcx_fir_set_slots(pcx_fir *h, unsigned slots);
 /*
  * The filter loop, FIRFilter.cpp:278-308.  `in` points at the front of the input
  * buffer: in_elems elements of which the first K-1 are history (the reference's
@@ -266,6 +271,7 @@ PCX_API int pcx_fmchain_reset(pcx_fmchain *h);
 /* PCX_FIR_AUTO (default), PCX_FIR_DIRECT (LDS-tiled time domain) or PCX_FIR_OLS_FFT (K <= 2048) */
 PCX_API int pcx_fmchain_set_algo(pcx_fmchain *h, int algo);
 PCX_API int pcx_fmchain_last_algo(const pcx_fmchain *h);
+PCX_API int pcx_fmchain_set_slots(pcx_fmchain *h, unsigned slots);      /* as pcx_fir_set_slots */
 /* in_elems input samples with K-1 history in front -> in_elems-(K-1) demodulated
  * outputs; FreqDemod's prev is carried in the handle */
 PCX_API int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *out, size_t out_cap,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pcx_fir_set_algo": (_i, [_vp, _i]),
     "pcx_fir_get_geometry": (_i, [_vp, _psz, _psz]),
     "pcx_fir_last_algo": (_i, [_vp]),
+    "pcx_fir_set_slots": (_i, [_vp, C.c_uint]),
     "pcx_fir_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz]),
     "pcx_fir_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp]),
     "pcx_fir_process_dev_gated": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp, C.c_uint, _vp, C.POINTER(C.c_int)]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "pcx_fmchain_reset": (_i, [_vp]),
     "pcx_fmchain_set_algo": (_i, [_vp, _i]),
     "pcx_fmchain_last_algo": (_i, [_vp]),
+    "pcx_fmchain_set_slots": (_i, [_vp, C.c_uint]),
     "pcx_fmchain_process": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz]),
     "pcx_fmchain_process_dev": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp]),
     "pcx_fmchain_process_dev_gated": (_i, [_vp, _vp, _sz, _vp, _sz, _psz, _psz, _vp, C.c_uint, _vp, C.POINTER(C.c_int)]),

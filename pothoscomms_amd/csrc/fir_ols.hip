@@ -208,8 +208,11 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
 // gate_word != nullptr: the caller wants the blocks that read in[0 .. K-2] held until *gate_word reaches gate_value.  Only the
 // dealt kernel has the gate; *gated says whether this launch honours it -- if not, NOTHING has been launched and the caller
 // orders the halo in front of the call itself.
+// slots: resident workgroups this launch may take (1024 = the whole device; a device that carries several shards of a stream
+// gives each its share, pcx_shard.hip) -- a multiple of 128, so that the dealer's sixteen groups hold the same number of workgroups
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
-                            const void *tw4096, void *sched, hipStream_t st, const void *gate_word, unsigned gate_value, int *gated)
+                            const void *tw4096, void *sched, hipStream_t st, const void *gate_word, unsigned gate_value, int *gated,
+                            unsigned slots)
 {
     if (gated) *gated = 0;
     if (n_out == 0) return PCX_OK;
@@ -241,10 +244,12 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     const float2 *pi = (const float2 *)in, *ph = (const float2 *)Hspec, *pt = (const float2 *)tw4096;
     float2 *po = (float2 *)out;
     // PCX_OLS_SLOTS (diagnostic): resident workgroups to use chip-wide (default 1024 = 4 per CU)
-    const unsigned slots = (unsigned)PCX_ENV_INT("PCX_OLS_SLOTS", 1024);
-    const unsigned g4 = persistent_grid(nblocks, slots), g3 = persistent_grid(nblocks, 768);
+    if (slots < 128 || slots > 1024 || slots % 128) slots = 1024;
+    const long env_static = PCX_ENV_INT("PCX_OLS_SLOTS", 0);
+    const unsigned static_slots = env_static > 0 ? (unsigned)env_static : slots;
+    const unsigned g4 = persistent_grid(nblocks, static_slots), g3 = persistent_grid(nblocks, 768);
     const unsigned gx = 8 * persistent_grid((nblocks + 7) / 8, 128);   // XCD-aware walk: equal rounds inside every XCD's eighth
-    const bool dealt = sched && nblocks > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");   // (PCX_SCHED_STATIC, diag only: the grid stride, for A/B)
+    const bool dealt = sched && nblocks > 2 * (size_t)slots && !PCX_ENV_SET("PCX_SCHED_STATIC");   // (PCX_SCHED_STATIC, diag only: the grid stride, for A/B)
     if (gate_word && !dealt) return PCX_OK;       // no gate in the grid-stride kernels: *gated stays 0, nothing launched
     // the window of block b starts at sample b*S - pad: only block 0 reaches below K-1 (Kov <= 2048 <= S)
     const Gate gate{dealt ? (const unsigned *)gate_word : nullptr, gate_value, 1u};
@@ -282,13 +287,15 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
         // (Leaving a few of the 1024 resident slots empty, so that the kernels the gate waits for -- the halo's receive or copy, the
         // one-thread signal -- find room beside this launch, measured no better: 0.2196 ms at 1024 workgroups, 0.2242 at 1008,
         // two shards on one device, profiles/r03/shard_probe.txt.  PCX_GATED_SLOTS (diag) sets the number.)
-        const unsigned gd = (unsigned)PCX_ENV_INT("PCX_GATED_SLOTS", 1024);
+        const long env_gd = PCX_ENV_INT("PCX_GATED_SLOTS", 0);
+        const unsigned gd = env_gd > 0 ? (unsigned)env_gd : slots;
         if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3, 0, false, true>), gd);
         else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3, 0, false, true>), gd);
         else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3, 0, false, true>), gd);
         else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3, 0, false, true>), gd);
     } else if (dealt) {
-        const unsigned gd = 1024;   // 4 resident workgroups per CU, all of them drawing
+        const long env_gd = PCX_ENV_INT("PCX_DEALT_SLOTS", 0);
+        const unsigned gd = env_gd > 0 ? (unsigned)env_gd : slots;   // 4 resident workgroups per CU, all of them drawing
         if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3>), gd);
         else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3>), gd);
         else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3>), gd);
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
 // gate_word / gated: as launch_fir_cf32_ols4096 (the halo of a sharded chain is K samples: the FIR's K-1 and the demodulator's one)
 int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                                 const void *tw4096, const void *prev_in, void *prev_out, void *sched, hipStream_t st,
-                                const void *gate_word, unsigned gate_value, int *gated)
+                                const void *gate_word, unsigned gate_value, int *gated, unsigned slots)
 {
     if (gated) *gated = 0;
     if (n_out == 0) return PCX_OK;
@@ -777,7 +784,8 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
     const size_t Kov = (K + 31) / 32 * 32, pad = Kov - K;    // <= 2048
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
-    const bool dyn = sched && nblocks > 2 * 1024 && !PCX_ENV_SET("PCX_SCHED_STATIC");   // dynamic dealing when the handle brought its counter pair and the launch is long
+    if (slots < 128 || slots > 1024 || slots % 128) slots = 1024;
+    const bool dyn = sched && nblocks > 2 * (size_t)slots && !PCX_ENV_SET("PCX_SCHED_STATIC");   // dynamic dealing when the handle brought its counter pair and the launch is long
     if (gate_word && !dyn) return PCX_OK;         // no gate in the grid-stride kernel: *gated stays 0, nothing launched
     // the window of block b starts at sample b*S - 1 - pad: it reaches below sample K while b*S < Kov + 1 -- block 0, and block 1
     // too when S == Kov (2048 taps)
@@ -805,10 +813,10 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
 #else
     (void)occ;
 #endif
-    if (Kov <= 256) PCX_FM_LAUNCH(4, 1, 2, 1024);
-    else if (Kov <= 512) PCX_FM_LAUNCH(4, 2, 2, 1024);
-    else if (Kov <= 1024) PCX_FM_LAUNCH(4, 4, 2, 1024);
-    else PCX_FM_LAUNCH(4, 8, 2, 1024);
+    if (Kov <= 256) PCX_FM_LAUNCH(4, 1, 2, slots);
+    else if (Kov <= 512) PCX_FM_LAUNCH(4, 2, 2, slots);
+    else if (Kov <= 1024) PCX_FM_LAUNCH(4, 4, 2, slots);
+    else PCX_FM_LAUNCH(4, 8, 2, slots);
 #undef PCX_FM_LAUNCH
     PCX_LAUNCH_CHECK();
     return PCX_OK;

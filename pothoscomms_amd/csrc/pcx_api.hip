@@ -524,6 +524,7 @@ struct pcx_fir {
     DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096;
     StageBuf wsIn, wsOut;
     DevBuf sched;             // SchedState: dynamic block assignment of the overlap-save kernels (pcx_sched.hpp), zeroed once
+    unsigned slots = 1024;    // resident workgroups a persistent launch may take (pcx_shard: several shards on one device share it)
     size_t Kp = 8;
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
@@ -873,6 +874,7 @@ int fir_prepare(pcx_fir *h)
     DeviceScope dev_scope(h->cx.device);
     return fir_sync_tables(h);
 }
+void fir_set_slots(pcx_fir *h, unsigned slots) { h->slots = slots; }
 }  // namespace pcx
 
 int pcx_fir_create(int scalar, int is_complex, int complex_taps, pcx_fir **out)
@@ -933,6 +935,13 @@ int pcx_fir_get_geometry(const pcx_fir *h, size_t *K, size_t *input_require)
     return PCX_OK;
 }
 int pcx_fir_last_algo(const pcx_fir *h) { return h ? h->last_algo : PCX_ERR_ARG; }
+int pcx_fir_set_slots(pcx_fir *h, unsigned slots)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(slots >= 128 && slots <= 1024 && slots % 128 == 0, "pcx_fir_set_slots: %u is not a multiple of 128 in 128..1024", slots);
+    h->slots = slots;
+    return PCX_OK;
+}
 
 static size_t fir_elem_bytes(const pcx_fir *h) { return (size_t)scalar_bytes(h->scalar) * (h->cplx ? 2 : 1); }
 
@@ -1017,7 +1026,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         const bool plain = algo == PCX_FIR_OLS_FFT && !h->have_interp_real && !h->have_interp64 && !h->have_ols_real64 && !h->have_ols64 &&
                            !h->have_ols_int && !h->have_real_ols && !h->have_interp && !h->have_decim && !h->have_poly && h->ols_log2n == 0;
         if (!plain) return PCX_OK;
-        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, gate_word, gate_value, gated);
+        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, gate_word, gate_value, gated, h->slots);
         if (rc != PCX_OK || !*gated) return rc;
         h->last_algo = algo;
         *consumed = N;
@@ -1073,7 +1082,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {
         rc = launch_fir_cf32_ols_r16(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {
-        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st);
+        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, nullptr, 0, nullptr, h->slots);
     } else if (algo == PCX_FIR_DIRECT && fast && (2048 + h->Kp + 8) * 9 / 8 * 8 + 64 <= 64 * 1024) {
         // the LDS-tiled time-domain kernel while its tile (2048 outputs + taps) fits; longer filters than every
         // fast plan (K > 8193) take the sliding-window kernel below
@@ -1806,6 +1815,7 @@ struct pcx_fmchain {
     DevBuf tapsRev, Hspec, tw4096, prev;
     StageBuf wsIn, wsOut;
     DevBuf sched;   // dynamic block assignment of the fused kernel (pcx_sched.hpp), zeroed at create
+    unsigned slots = 1024;
     int cur = 0;
     int algo = PCX_FIR_AUTO, last_algo = 0;
     bool have_ols = false;
@@ -1902,6 +1912,7 @@ int fmchain_prepare(pcx_fmchain *h)
     DeviceScope dev_scope(h->cx.device);
     return fmchain_sync(h);
 }
+void fmchain_set_slots(pcx_fmchain *h, unsigned slots) { h->slots = slots; }
 }  // namespace pcx
 int pcx_fmchain_set_algo(pcx_fmchain *h, int algo)
 {
@@ -1911,6 +1922,13 @@ int pcx_fmchain_set_algo(pcx_fmchain *h, int algo)
     return PCX_OK;
 }
 int pcx_fmchain_last_algo(const pcx_fmchain *h) { return h ? h->last_algo : PCX_ERR_ARG; }
+int pcx_fmchain_set_slots(pcx_fmchain *h, unsigned slots)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    PCX_CHECK_ARG(slots >= 128 && slots <= 1024 && slots % 128 == 0, "pcx_fmchain_set_slots: %u is not a multiple of 128 in 128..1024", slots);
+    h->slots = slots;
+    return PCX_OK;
+}
 static int fmchain_process_dev_impl(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                                     size_t *consumed, size_t *produced, void *stream, const void *gate_word, unsigned gate_value, int *gated);
 int pcx_fmchain_process_dev(pcx_fmchain *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
@@ -1965,7 +1983,7 @@ static int fmchain_process_dev_impl(pcx_fmchain *h, const void *in_dev, size_t i
     if (algo == PCX_FIR_OLS_FFT) {
         if (!h->have_ols) { set_error("fm chain: OLS_FFT needs K <= 2048"); return PCX_ERR_UNSUPPORTED; }
         PCX_TRY(launch_fmchain_cf32_ols4096(in_dev, N + h->K - 1, out_dev, N, h->Hspec.p, h->K, h->tw4096.p, base + 32 * h->cur,
-                                            base + 32 * (h->cur ^ 1), h->sched.p, as_stream(stream), gate_word, gate_value, gated));
+                                            base + 32 * (h->cur ^ 1), h->sched.p, as_stream(stream), gate_word, gate_value, gated, h->slots));
         if (gate_word && !*gated) return PCX_OK;      // a short call: the grid-stride kernel has no gate, nothing was queued
     } else {
         PCX_TRY(launch_fmchain_cf32(in_dev, N + h->K - 1, out_dev, N, h->tapsRev.p, h->K, h->Kp, base + 32 * h->cur,

@@ -101,6 +101,9 @@ struct TraceRange {
 // (pcx_api.hip, for pcx_shard.hip) upload a FIR handle's tables now instead of at its next call
 int fir_prepare(struct ::pcx_fir *h);
 int fmchain_prepare(struct ::pcx_fmchain *h);
+// (pcx_shard.hip) resident workgroups a handle's persistent launches may take: 1024 / the number of shards that share the device
+void fir_set_slots(struct ::pcx_fir *h, unsigned slots);
+void fmchain_set_slots(struct ::pcx_fmchain *h, unsigned slots);
 // device-visible alias of a host pointer when it is page-locked (pcx_api.hip), else nullptr
 void *device_alias(const void *p);
 // staging pair of one direction of a host-pointer call (pcx_api.hip stage_in / stage_out_*)
@@ -215,7 +218,7 @@ int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_
 // sched: the handle's SchedState pair (pcx_sched.hpp: dynamic block assignment) or nullptr for the static grid stride
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                             const void *tw4096, void *sched, hipStream_t st, const void *gate_word = nullptr, unsigned gate_value = 0,
-                            int *gated = nullptr);
+                            int *gated = nullptr, unsigned slots = 1024);
 int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
                                    const void *tw4096, void *sched, hipStream_t st);
 size_t fir_decim_fold_factor(size_t M);
@@ -275,7 +278,7 @@ int launch_bluestein_post(int scalar, const void *z, void *X, const void *w, siz
 // fused Rotate -> FIR -> FreqDemod, frequency domain (Hspec already carries the phasor)
 int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                                 const void *tw4096, const void *prev_in, void *prev_out, void *sched, hipStream_t st,
-                                const void *gate_word = nullptr, unsigned gate_value = 0, int *gated = nullptr);
+                                const void *gate_word = nullptr, unsigned gate_value = 0, int *gated = nullptr, unsigned slots = 1024);
 int launch_gate_signal(void *gate_word, unsigned value, hipStream_t st);   // (elementwise.hip) one thread: the word <- value, system-scope release
 // fused Rotate -> FIR -> FreqDemod, time domain
 int launch_fmchain_cf32(const void *in, size_t in_elems, void *out, size_t n_out, const void *taps_rev, size_t K,

@@ -355,6 +355,18 @@ int pcx_shard_configure(pcx_shard *s, size_t shard_elems)
         PCX_HIP(hipMemsetAsync(s->alloc[g], 0, (s->lead[g] + halo) * sizeof(float2), s->st[g]));   // stream start: zero history
     }
     s->C = shard_elems;
+    // Several shards on ONE device (the one-GPU rehearsal; a node with fewer devices than shards) share its 1024 resident
+    // workgroup slots: each shard's persistent launch takes its share, so that all of them run side by side and end together.
+    // With 1024 each the launches queue behind one another's workgroups: two shards 0.2196 ms per 64 Mi samples against
+    // 0.1988 with 512 each (one 64 Mi launch: 0.1971; tools/ab_gated_slots.sh, profiles/r03/shard_probe.txt).
+    for (int g = 0; g < s->G; g++) {
+        unsigned same = 0;
+        for (int k = 0; k < s->G; k++) same += s->dev[k] == s->dev[g];
+        unsigned slots = 1024 / same / 128 * 128;
+        if (slots < 128) slots = 128;
+        fir_set_slots(s->fir[g], slots);
+        if (s->chain[g]) fmchain_set_slots(s->chain[g], slots);
+    }
     // the two-launch fallback's split: the body (outputs head .. C-1) reads in[head ..], which must lie behind the halo slot
     // in[0 .. K-2] whatever K -- a fixed 4096 let filters of more than 4097 taps read a halo that had not arrived yet
     s->head = std::min(shard_elems, std::max(kHead, (halo + kHead - 1) / kHead * kHead));

@@ -131,6 +131,10 @@ class FirFilter(_Handle):
     def last_algo(self):
         return _lib.load().pcx_fir_last_algo(self._h)
 
+    def set_slots(self, slots):
+        """pcx_fir_set_slots: the share of the device's 1024 resident workgroup slots this handle's launches take"""
+        _lib.check(_lib.load().pcx_fir_set_slots(self._h, int(slots)))
+
     def geometry(self):
         k, r = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.load().pcx_fir_get_geometry(self._h, C.byref(k), C.byref(r)))
@@ -261,6 +265,9 @@ class FmChain(_Handle):
     @property
     def last_algo(self):
         return _lib.load().pcx_fmchain_last_algo(self._h)
+
+    def set_slots(self, slots):
+        _lib.check(_lib.load().pcx_fmchain_set_slots(self._h, int(slots)))
 
     def process(self, x, out_cap):
         xp = as_pairs(x)

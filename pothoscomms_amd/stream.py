@@ -72,11 +72,14 @@ class ShardedFir:
     # outputs computed after the halo has arrived: one overlap-save block's worth is the
     # minimum (outputs 0 .. 4096-K); rounding up to 4096 keeps the split independent of K
     HEAD = 4096
+    gate_host_driven = False     # tests set it: the gated launch with a host-driven exchange (gloo)
 
-    def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None):
+    def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None, slots=None):
         from . import device as dv   # the HIP path; raises if libpcx_hip.so is missing
         self.fir = dv.FirFilter("complex_float32", taps_type)
         self.fir.set_taps(taps)
+        if slots is not None:        # several ranks on ONE device (a rehearsal): each takes its share of the resident slots
+            self.fir.set_slots(slots)
         if algo is not None:
             self.fir.set_algo(algo)
         self.K = self.fir.K
@@ -116,8 +119,11 @@ class ShardedFir:
         if self.ring.world == 1:
             self._run(0, self.C)
             return self.out
-        if self.buf.is_cuda and dist.is_initialized() and dist.get_backend(self.ring.group) == "nccl":
+        if self.buf.is_cuda and dist.is_initialized() and (dist.get_backend(self.ring.group) == "nccl" or self.gate_host_driven):
             return self._step_gated()
+        # host tensors (the CPU tests of the exchange logic) and host-driven backends on device tensors (the gloo rehearsal of the
+        # multi-rank control flow on one GPU: two PROCESSES time-share the device and the exchange is a host round trip, so the
+        # one-launch scheme has nothing to hide behind -- measured 0.25-0.27 ms per step against 0.22 for this one): body, wait, head
         reqs = self.ring.start(self.buf)
         if self.C > self.head:
             self._run(self.head, self.C - self.head)      # does not touch the halo
@@ -126,28 +132,39 @@ class ShardedFir:
         return self.out
 
     def _step_gated(self):
-        """RCCL: exchange + gate signal on a side stream, ONE gated launch on the current stream (rank 0 has no halo to wait for)."""
+        """ONE launch over the shard; the exchange beside it, a one-thread kernel behind it opens the gate.
+        RCCL: the exchange and the signal are queued on a side stream.  A host-driven backend (the gloo rehearsal on one GPU): the
+        exchange is started, the launch queued, and the host waits for the halo before it queues the signal."""
         from . import device as dv
         self._gate_setup()
         self._pass += 1
+        nccl = dist.get_backend(self.ring.group) == "nccl"
         cur = torch.cuda.current_stream(self.buf.device)
-        self._side.wait_stream(cur)                       # the shard's samples are in place; the previous pass has read its halo
-        with torch.cuda.stream(self._side):
-            self.ring.finish(self.ring.start(self.buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
-            if self.ring.rank > 0:
-                dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
+        if nccl:
+            self._side.wait_stream(cur)                   # the shard's samples are in place; the previous pass has read its halo
+            with torch.cuda.stream(self._side):
+                self.ring.finish(self.ring.start(self.buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
+                if self.ring.rank > 0:
+                    dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
+            reqs = []
+        else:
+            reqs = self.ring.start(self.buf)              # (drains the current stream first: HaloRing.start)
+        gated = True
         if self.ring.rank == 0:
             self._run(0, self.C)
         else:
             c, p, gated = self.fir.process_dev_gated(self.buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C)
             if gated:
                 assert c == self.C and p == self.C, (c, p)
-            else:
-                # no gated kernel for this configuration (long filters, short shards): body, wait, head
-                if self.C > self.head:
-                    self._run(self.head, self.C - self.head)
-                cur.wait_stream(self._side)
-                self._run(0, self.head)
+            elif self.C > self.head:
+                self._run(self.head, self.C - self.head)  # no gated kernel for this configuration: the body now, the head below
+        if not nccl:
+            self.ring.finish(reqs)                        # the host waits for the halo ...
+            if self.ring.rank > 0:
+                dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)      # ... and opens the gate
+        if not gated:
+            cur.wait_stream(self._side)
+            self._run(0, self.head)
         # nothing queued on this stream later (the next fill of the shard) may overwrite the tail the send is still reading
         cur.wait_stream(self._side)
         return self.out

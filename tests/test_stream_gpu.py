@@ -68,6 +68,67 @@ def test_two_ranks_real_kernels_no_seam(oracle):
     assert nerr(got, ref) <= TOL
 
 
+def _gated_worker(rank, world, port, C, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pothoscomms_amd import device, taps as tp
+    from pothoscomms_amd.stream import ShardedFir
+    torch.cuda.set_device(0)
+    ShardedFir.gate_host_driven = True            # the one-launch step (what the RCCL backend runs) with gloo carrying the halo
+    sf = ShardedFir(tp.c1_taps(), C, torch.device("cuda", 0))
+    K = sf.K
+    device.fill_uniform_f32_dev(sf.buf, seed=2, offset=2 * rank * C)
+    seam = []
+    for rep in range(2):
+        if rank > 0:
+            sf.buf[:K - 1] = float("nan")
+        out = sf.step()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        if rank > 0:
+            assert int(sf._gate[0].item()) == rep + 1 and int(sf._gate[1].item()) == 0      # signalled, never timed out
+        seam.append(out[:6000].cpu().numpy())
+    # the shard against a plain call on the completed buffer: bit for bit
+    want = torch.empty_like(sf.out)
+    f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.c1_taps())
+    assert f.process_dev(sf.buf, want) == (C, C)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(sf.out, want))
+    q.put((rank, seam[1], same, sf.buf[:K - 1 + 6000].cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gated_launch_per_pass(oracle):
+    """ShardedFir's one-launch step -- the halo exchange beside ONE gated launch over the shard, pcx_fir_process_dev_gated -- on
+    shards long enough for the dealt kernel (> 2048 blocks), two processes on this box's one GPU, gloo carrying the halo: poisoned
+    halos, two passes, the seam against the oracle and the whole shard bit-identical to a plain call"""
+    from pothoscomms_amd import taps as tp
+    world, C = 2, 2080 * 3840
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gated_worker, args=(r, world, port, C, q)) for r in range(world)]
+    [p.start() for p in procs]
+    parts = {}
+    for _ in range(world):
+        rank, seam, same, xin = q.get(timeout=300)
+        parts[rank] = (seam, same, xin)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    h = tp.c1_taps()
+    for rank in range(world):
+        seam, same, xin = parts[rank]
+        assert same, "rank %d" % rank
+        ref_blk = oracle.Fir(oracle.F32, True, True); ref_blk.set_taps(h); ref_blk.activate()
+        ref, _, p, _ = ref_blk.work(xin, 6000)
+        assert p == 6000 and nerr(seam, ref) <= TOL
+
+
 def _chain_worker(rank, world, port, C, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

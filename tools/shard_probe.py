@@ -6,26 +6,36 @@ import ctypes as C
 import numpy as np
 from pothoscomms_amd import _lib, device, taps as tp
 
+if len(sys.argv) < 2:
+    # one FRESH process per shard count: a process that has created and destroyed streams maps its next streams onto the device's
+    # four hardware queues differently, and two shards whose streams share a queue run one after the other
+    # (same G = 2, same library: 0.1994 ms in a fresh process, 0.2457 behind a G = 1 run in the same process)
+    import subprocess
+    for G in (1, 2, 4, 8):
+        subprocess.run([sys.executable, os.path.abspath(__file__), str(G)], check=False)
+    sys.exit(0)
 L = _lib.load()
 total = 64 * 1024 * 1024
 h = tp.c1_taps()
-for G in (1, 2, 4, 8):
+for G in [int(a) for a in sys.argv[1:]]:
     ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY if G > 1 else device.NodeStream.RCCL)
     ns.set_taps(h)
     ns.configure(total // G)
     for g in range(G):
         i, o, s, d = ns.buffers(g)
         _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (len(h) - 1 + total // G), 2, 2 * g * (total // G), C.c_void_p(s)))
-    for _ in range(150):
+    import os as _os
+    short = bool(_os.environ.get("PCX_PROBE_SHORT"))
+    for _ in range(20 if short else 400):
         ns.step()
     ns.sync()
     t0 = time.perf_counter()
-    n = 200
+    n = 10 if short else 300
     for _ in range(n):
         ns.step()
     host = (time.perf_counter() - t0) / n        # what the host spends queueing one pass
     ns.sync()
     dt = (time.perf_counter() - t0) / n
     print("G=%d shards on device 0 (%s): %.4f ms per pass over %d samples = %.1f Gsamples/s  (host: %.4f ms to queue a pass)" %
-          (G, "rccl comm of one" if G == 1 else "peer copies", dt * 1e3, total, total / dt / 1e9, host * 1e3))
+          (G, "rccl comm of one" if G == 1 else "peer copies", dt * 1e3, total, total / dt / 1e9, host * 1e3), flush=True)
     ns.close()

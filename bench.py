@@ -51,6 +51,13 @@ def parse():
     ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "decim8", "interp4", "fir255_i16"])
     ap.add_argument("--shard", type=int, default=SHARD, help="samples per GPU (default 64 Mi)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--driver", default="ranks", choices=["ranks", "native"],
+                    help="ranks: one process per GPU over torch.distributed (the bench contract); native: ONE process driving every GPU "
+                         "through the C ABI's pcx_shard_* (RCCL send/recv loaded by the library itself) -- what a Pothos block that owns "
+                         "a pcx_shard does")
+    ap.add_argument("--native-devices", default="",
+                    help="native driver only: comma-separated device ordinals, one per shard (default 0..N-1).  Repeating an ordinal "
+                         "puts several shards on one device over peer copies -- the one-GPU rehearsal; the line then says so")
     ap.add_argument("--settle", type=int, default=PREWARM,
                     help="untimed setup passes before the W warm-up steps (clock settling after idle; reported as config.setup_passes)")
     return ap.parse_args()
@@ -276,10 +283,87 @@ def load_traffic(workload, kernel_name):
         return None
 
 
+def run_native(args):
+    """One process, every GPU: pcx_shard_* behind the C ABI (include/pcx.h).  Same workload, same JSON line; `n_gpus` and
+    `world_size_observed` are the number of DISTINCT devices that carry a shard, and the run refuses fewer GPUs than shards unless
+    --native-devices names the rehearsal layout explicitly."""
+    import ctypes as Cc
+
+    import numpy as np
+    import torch
+
+    from pothoscomms_amd import _lib, device, taps as tp
+    if args.workload not in ("fir255", "fmchain"):
+        raise SystemExit("--driver native runs the sharded workloads: fir255, fmchain")
+    L = _lib.load()
+    ndev = torch.cuda.device_count()
+    G = args.gpus
+    if args.native_devices:
+        devs = [int(d) for d in args.native_devices.split(",")]
+        if len(devs) != G:
+            raise SystemExit("--native-devices names %d shards, --gpus %d" % (len(devs), G))
+    else:
+        if ndev < G:
+            raise SystemExit("--gpus %d needs %d GPUs on this node, %d visible (--native-devices 0,0,... rehearses on fewer)" % (G, G, ndev))
+        devs = list(range(G))
+    distinct = len(set(devs))
+    transport = device.NodeStream.RCCL if distinct == G else device.NodeStream.PEER_COPY
+    C = args.shard
+    chain = args.workload == "fmchain"
+    h = tp.c4_taps() if chain else tp.c1_taps()
+    K = len(h)
+    ns = device.NodeStream(devs, transport)
+    if chain:
+        ns.set_chain(True, tp.C4_PHASE)
+    ns.set_taps(h, complex_taps=not chain)
+    ns.configure(C)
+    for g in range(G):
+        i, o, st, d = ns.buffers(g)
+        _lib.check(L.pcx_fill_uniform_f32_dev(Cc.c_void_p(i), 2 * (K - 1 + C), 5 if chain else 2, 2 * g * C, Cc.c_void_p(st)))
+    for _ in range(args.settle + args.warmup):
+        ns.step()
+    ns.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ns.step()
+    ns.sync()
+    elapsed = time.perf_counter() - t0
+    per = elapsed / args.steps
+    bytes_per = (12.0 if chain else 16.0) * C           # per shard and pass
+    value = G * C * args.steps / elapsed / 1e6
+    # per-DEVICE roofline: each device streams its shards' bytes in the time of one pass
+    achieved = bytes_per * (G / distinct) / per / 1e9
+    out = {
+        "metric": "Msamples/s fused FM-demod chain" if chain else "Msamples/s complex_float32 255-tap FIR",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": distinct, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(per * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": ("fused Rotate->FIR(127 real taps)->FreqDemod" if chain else "255-tap complex_float32 FIR (/comms/fir_filter, COMPLEX taps, M=L=1)")
+                               + ", %d-sample shard x %d, one process, pcx_shard_* behind the C ABI" % (C, G),
+                   "taps": K, "shard_samples": C, "halo_samples": K if chain else K - 1, "setup_passes": args.settle,
+                   "driver": "native", "shards": G, "shard_devices": devs, "world_size_observed": distinct,
+                   "halo_transport": "rccl send/recv (ncclCommInitAll, one process)" if transport == device.NodeStream.RCCL
+                                     else "peer copies (REHEARSAL: %d shards on %d device(s))" % (G, distinct),
+                   "parallelism": "overlap-save shards x%d, one gated launch per shard and pass" % G},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "fmchain_cf32_ols4096_kernel" if chain else "fir_cf32_ols4096_kernel", "avg_launch_ms": round(per * 1e3, 4),
+                     "algorithmic_bytes_per_launch": bytes_per,
+                     "bytes_counted": "per device: its shards' algorithmic read + write bytes over the wall time of a pass (host clock "
+                                      "around the K steps, all streams synchronised on both sides)"},
+    }
+    print(json.dumps(out), flush=True)
+    ns.close()
+
+
 def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.driver == "native":
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--driver native is ONE process: do not start it under torch.distributed.run")
+        return run_native(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)      # before torch is imported or the GPU touched
     rank = int(os.environ.get("RANK", "0"))

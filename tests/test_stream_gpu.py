@@ -262,3 +262,26 @@ def test_bench_refuses_more_rccl_ranks_than_gpus():
     r = _run_bench({}, "--gpus", str(n), "--shard", "1048576", "--steps", "1", "--warmup", "0", "--no-cpu")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_native_driver_rehearsed_on_one_gpu_and_refused_without_enough_gpus():
+    """`bench.py --driver native`: ONE process, pcx_shard_* behind the C ABI.  On this one-GPU box the layout has to be named
+    (--native-devices 0,0: two shards on device 0 over peer copies) and the line says it is a rehearsal and counts ONE gpu;
+    without the override two shards on one GPU are refused."""
+    import json
+    import torch
+    r = _run_bench({}, "--driver", "native", "--gpus", "2", "--native-devices", "0,0", "--shard", str(2080 * 3840), "--steps", "5", "--warmup", "2",
+                   "--settle", "5")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["world_size_observed"] == 1 and line["config"]["shards"] == 2
+    assert line["config"]["driver"] == "native" and "REHEARSAL" in line["config"]["halo_transport"]
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0.1
+    if torch.cuda.device_count() < 2:
+        r = _run_bench({}, "--driver", "native", "--gpus", "2", "--steps", "2", "--warmup", "1", "--settle", "1")
+        assert r.returncode != 0 and "needs 2 GPUs" in r.stderr
+    r = _run_bench({}, "--driver", "native", "--gpus", "2", "--native-devices", "0,0", "--workload", "fmchain", "--shard", str(2080 * 3968),
+                   "--steps", "3", "--warmup", "1", "--settle", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["metric"].startswith("Msamples/s fused FM-demod chain") and line["config"]["halo_samples"] == 127

@@ -55,8 +55,10 @@
  *     the FFT accepts out == in.  abs/angle (narrower output), FIR, FreqDemod and the fused chain
  *     read what another lane may already have overwritten: no aliasing.
  *   - there is NO CPU fallback: a type/size the device path does not implement
- *     returns PCX_ERR_UNSUPPORTED (after round 2: complex_int16 FFTs beyond
- *     32768 bins; every float numBins has a plan).
+ *     returns PCX_ERR_UNSUPPORTED.  After round 3 nothing of the path does: every numBins the reference
+ *     constructs has a plan for every type FFTFactory accepts (complex_int16 beyond one workgroup's LDS runs
+ *     kf_work's stages one launch each, bit-exact; transforms beyond 2^26 bins are refused), the FIR's
+ *     PCX_FIR_OLS_FFT request is refused only for geometries it does not cover (PCX_FIR_AUTO always runs).
  */
 #ifndef PCX_H
 #define PCX_H

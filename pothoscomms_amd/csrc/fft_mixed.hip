@@ -90,6 +90,72 @@ struct Q15Arith {
 
 // TWLDS: the twiddle table (N entries, gathered per lane at k * fstride * j) sits in LDS behind the frame images,
 // copied once per persistent workgroup; otherwise it is read through L1/L2
+// kf_bfly2 / kf_bfly3 / kf_bfly4 / kf_bfly5 (kiss_fft.c:21-185, kissfft.hh:163-262) on the p elements F[0], F[m] .. F[(p-1) m] with the
+// twiddles W^(k q) = tw[kf q], kf = k * fstride: every C_FIXDIV / sround of the Q15 build in the reference's own order (Q15Arith), plain
+// arithmetic for floats.  Shared by the LDS kernel below and the stage-per-launch plan for frames beyond one workgroup's LDS.
+template <typename A>
+__device__ __forceinline__ void kf_bfly(int p, typename A::cpx *F, int m, const typename A::cpx *tw, int kf, int fstride, int inverse)
+{
+    typedef typename A::cpx cpx;
+    if (p == 2) {  // kf_bfly2
+        const cpx f0 = A::fixdiv(F[0], 2), f1 = A::fixdiv(F[m], 2);
+        const cpx t = A::mul(f1, tw[kf]);
+        F[m] = A::sub(f0, t);
+        F[0] = A::add(f0, t);
+    } else if (p == 4) {  // kf_bfly4
+        cpx f0 = A::fixdiv(F[0], 4);
+        const cpx f1 = A::fixdiv(F[m], 4), f2 = A::fixdiv(F[2 * m], 4), f3 = A::fixdiv(F[3 * m], 4);
+        const cpx s0 = A::mul(f1, tw[kf]), s1 = A::mul(f2, tw[kf * 2]), s2 = A::mul(f3, tw[kf * 3]);
+        const cpx s5 = A::sub(f0, s1);
+        f0 = A::add(f0, s1);
+        const cpx s3 = A::add(s0, s2), s4 = A::sub(s0, s2);
+        F[2 * m] = A::sub(f0, s3);
+        F[0] = A::add(f0, s3);
+        if (inverse) {
+            F[m] = {A::ssub(s5.r, s4.i), A::sadd(s5.i, s4.r)};
+            F[3 * m] = {A::sadd(s5.r, s4.i), A::ssub(s5.i, s4.r)};
+        } else {
+            F[m] = {A::sadd(s5.r, s4.i), A::ssub(s5.i, s4.r)};
+            F[3 * m] = {A::ssub(s5.r, s4.i), A::sadd(s5.i, s4.r)};
+        }
+    } else if (p == 3) {  // kf_bfly3
+        const cpx epi3 = tw[fstride * m];
+        const cpx f0 = A::fixdiv(F[0], 3), f1 = A::fixdiv(F[m], 3), f2 = A::fixdiv(F[2 * m], 3);
+        const cpx s1 = A::mul(f1, tw[kf]), s2 = A::mul(f2, tw[kf * 2]);
+        const cpx s3 = A::add(s1, s2);
+        cpx s0 = A::sub(s1, s2);
+        cpx fm = {A::ssub(f0.r, A::half(s3.r)), A::ssub(f0.i, A::half(s3.i))};
+        s0 = {A::smul(s0.r, epi3.i), A::smul(s0.i, epi3.i)};
+        F[0] = A::add(f0, s3);
+        F[2 * m] = {A::sadd(fm.r, s0.i), A::ssub(fm.i, s0.r)};
+        F[m] = {A::ssub(fm.r, s0.i), A::sadd(fm.i, s0.r)};
+    } else {  // kf_bfly5
+        const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
+        cpx f0 = A::fixdiv(F[0], 5);
+        const cpx f1 = A::fixdiv(F[m], 5), f2 = A::fixdiv(F[2 * m], 5), f3 = A::fixdiv(F[3 * m], 5), f4 = A::fixdiv(F[4 * m], 5);
+        const cpx s0 = f0;
+        const cpx s1 = A::mul(f1, tw[kf]), s2 = A::mul(f2, tw[kf * 2]);
+        const cpx s3 = A::mul(f3, tw[kf * 3]), s4 = A::mul(f4, tw[kf * 4]);
+        const cpx s7 = A::add(s1, s4), s10 = A::sub(s1, s4), s8 = A::add(s2, s3), s9 = A::sub(s2, s3);
+        // Fout0 += s7 + s8 (kiss_fft.c:174-175 adds the sum; kissfft.hh:228-229 adds twice: same for floats up to rounding)
+        f0 = {A::sadd(f0.r, A::sadd(s7.r, s8.r)), A::sadd(f0.i, A::sadd(s7.i, s8.i))};
+        F[0] = f0;
+        const cpx s5 = {A::sadd(A::sadd(s0.r, A::smul(s7.r, ya.r)), A::smul(s8.r, yb.r)),
+                        A::sadd(A::sadd(s0.i, A::smul(s7.i, ya.r)), A::smul(s8.i, yb.r))};
+        const cpx s6 = {A::sadd(A::smul(s10.i, ya.i), A::smul(s9.i, yb.i)),
+                        A::ssub(A::neg(A::smul(s10.r, ya.i)), A::smul(s9.r, yb.i))};
+        F[m] = A::sub(s5, s6);
+        F[4 * m] = A::add(s5, s6);
+        const cpx s11 = {A::sadd(A::sadd(s0.r, A::smul(s7.r, yb.r)), A::smul(s8.r, ya.r)),
+                         A::sadd(A::sadd(s0.i, A::smul(s7.i, yb.r)), A::smul(s8.i, ya.r))};
+        const cpx s12 = {A::sadd(A::neg(A::smul(s10.i, yb.i)), A::smul(s9.i, ya.i)),
+                         A::ssub(A::smul(s10.r, yb.i), A::smul(s9.r, ya.i))};
+        F[2 * m] = A::add(s11, s12);
+        F[3 * m] = A::sub(s11, s12);
+    }
+
+}
+
 template <typename A, bool TWLDS>
 __global__ __launch_bounds__(1024) void fft_mixed_kernel(const typename A::cpx *__restrict__ in, typename A::cpx *__restrict__ out,
                                                          int N, size_t nframes, const typename A::cpx *__restrict__ tw_global,
@@ -128,62 +194,7 @@ __global__ __launch_bounds__(1024) void fft_mixed_kernel(const typename A::cpx *
                     const int g = fdiv(b, plan.inv_m[s]), k = b - mul24(g, m);
                     cpx *F = cur + mul24(fi, N) + mul24(g, mul24(p, m)) + k;
                     const int kf = mul24(k, fstride);   // twiddle index of W^k; its multiples are below radix * N < 2^24
-                    if (p == 2) {  // kf_bfly2
-                        const cpx f0 = A::fixdiv(F[0], 2), f1 = A::fixdiv(F[m], 2);
-                        const cpx t = A::mul(f1, tw[kf]);
-                        F[m] = A::sub(f0, t);
-                        F[0] = A::add(f0, t);
-                    } else if (p == 4) {  // kf_bfly4
-                        cpx f0 = A::fixdiv(F[0], 4);
-                        const cpx f1 = A::fixdiv(F[m], 4), f2 = A::fixdiv(F[2 * m], 4), f3 = A::fixdiv(F[3 * m], 4);
-                        const cpx s0 = A::mul(f1, tw[kf]), s1 = A::mul(f2, tw[kf * 2]), s2 = A::mul(f3, tw[kf * 3]);
-                        const cpx s5 = A::sub(f0, s1);
-                        f0 = A::add(f0, s1);
-                        const cpx s3 = A::add(s0, s2), s4 = A::sub(s0, s2);
-                        F[2 * m] = A::sub(f0, s3);
-                        F[0] = A::add(f0, s3);
-                        if (inverse) {
-                            F[m] = {A::ssub(s5.r, s4.i), A::sadd(s5.i, s4.r)};
-                            F[3 * m] = {A::sadd(s5.r, s4.i), A::ssub(s5.i, s4.r)};
-                        } else {
-                            F[m] = {A::sadd(s5.r, s4.i), A::ssub(s5.i, s4.r)};
-                            F[3 * m] = {A::ssub(s5.r, s4.i), A::sadd(s5.i, s4.r)};
-                        }
-                    } else if (p == 3) {  // kf_bfly3
-                        const cpx epi3 = tw[fstride * m];
-                        const cpx f0 = A::fixdiv(F[0], 3), f1 = A::fixdiv(F[m], 3), f2 = A::fixdiv(F[2 * m], 3);
-                        const cpx s1 = A::mul(f1, tw[kf]), s2 = A::mul(f2, tw[kf * 2]);
-                        const cpx s3 = A::add(s1, s2);
-                        cpx s0 = A::sub(s1, s2);
-                        cpx fm = {A::ssub(f0.r, A::half(s3.r)), A::ssub(f0.i, A::half(s3.i))};
-                        s0 = {A::smul(s0.r, epi3.i), A::smul(s0.i, epi3.i)};
-                        F[0] = A::add(f0, s3);
-                        F[2 * m] = {A::sadd(fm.r, s0.i), A::ssub(fm.i, s0.r)};
-                        F[m] = {A::ssub(fm.r, s0.i), A::sadd(fm.i, s0.r)};
-                    } else {  // kf_bfly5
-                        const cpx ya = tw[fstride * m], yb = tw[fstride * 2 * m];
-                        cpx f0 = A::fixdiv(F[0], 5);
-                        const cpx f1 = A::fixdiv(F[m], 5), f2 = A::fixdiv(F[2 * m], 5), f3 = A::fixdiv(F[3 * m], 5), f4 = A::fixdiv(F[4 * m], 5);
-                        const cpx s0 = f0;
-                        const cpx s1 = A::mul(f1, tw[kf]), s2 = A::mul(f2, tw[kf * 2]);
-                        const cpx s3 = A::mul(f3, tw[kf * 3]), s4 = A::mul(f4, tw[kf * 4]);
-                        const cpx s7 = A::add(s1, s4), s10 = A::sub(s1, s4), s8 = A::add(s2, s3), s9 = A::sub(s2, s3);
-                        // Fout0 += s7 + s8 (kiss_fft.c:174-175 adds the sum; kissfft.hh:228-229 adds twice: same for floats up to rounding)
-                        f0 = {A::sadd(f0.r, A::sadd(s7.r, s8.r)), A::sadd(f0.i, A::sadd(s7.i, s8.i))};
-                        F[0] = f0;
-                        const cpx s5 = {A::sadd(A::sadd(s0.r, A::smul(s7.r, ya.r)), A::smul(s8.r, yb.r)),
-                                        A::sadd(A::sadd(s0.i, A::smul(s7.i, ya.r)), A::smul(s8.i, yb.r))};
-                        const cpx s6 = {A::sadd(A::smul(s10.i, ya.i), A::smul(s9.i, yb.i)),
-                                        A::ssub(A::neg(A::smul(s10.r, ya.i)), A::smul(s9.r, yb.i))};
-                        F[m] = A::sub(s5, s6);
-                        F[4 * m] = A::add(s5, s6);
-                        const cpx s11 = {A::sadd(A::sadd(s0.r, A::smul(s7.r, yb.r)), A::smul(s8.r, ya.r)),
-                                         A::sadd(A::sadd(s0.i, A::smul(s7.i, yb.r)), A::smul(s8.i, ya.r))};
-                        const cpx s12 = {A::sadd(A::neg(A::smul(s10.i, yb.i)), A::smul(s9.i, ya.i)),
-                                         A::ssub(A::smul(s10.r, yb.i), A::smul(s9.r, ya.i))};
-                        F[2 * m] = A::add(s11, s12);
-                        F[3 * m] = A::sub(s11, s12);
-                    }
+                    kf_bfly<A>(p, F, m, tw, kf, fstride, inverse);
                 }
                 __syncthreads();
             } else {
@@ -554,6 +565,114 @@ int launch_smooth(const void *in, void *out, size_t nbins, size_t nframes, bool 
 }
 
 }  // namespace
+
+// --------------------------------------------------------------------------------- //
+// complex_int16 frames beyond one workgroup's LDS (power-of-two sizes above 32,768 bins, other sizes above ~20,000): kf_work's
+// recursion (kiss_fft.c:237-302) unrolled over GLOBAL memory, one launch per stage.  The reference takes any numBins
+// (FFT.cpp:83-93, kiss_fft.c:339-368); a four-step split would round in another order, but the recursion itself is a leaf gather
+// followed by the butterfly passes bottom-up, the butterflies of one pass touch disjoint elements, and every one of them is
+// kf_bfly (above) with its C_FIXDIV per stage -- so running a pass as one launch over all frames leaves every rounding where the
+// reference has it: bit-exact, whatever the size.  Generic radices (primes above 5) go cur -> alt as in the LDS kernel.
+// 2 + 2 bytes per element read and written per pass: a correctness path for sizes no DSP block normally asks of a Q15 transform.
+// --------------------------------------------------------------------------------- //
+struct GlobalPlan {
+    int nstages;
+    int radix[kMaxStagesMixed], m[kMaxStagesMixed], fstride[kMaxStagesMixed];
+};
+template <typename A>
+__global__ __launch_bounds__(256) void fft_global_gather_kernel(const typename A::cpx *__restrict__ in, typename A::cpx *__restrict__ out, unsigned N,
+                                                                size_t total, GlobalPlan plan)
+{
+    // position sum_s q_s m_s  <-  input index sum_s q_s fstride_s  (the m == 1 leaves, kiss_fft.c:276-280)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / N;
+        unsigned rem = (unsigned)(i - f * N), idx = 0;
+        for (int s = 0; s < plan.nstages; s++) {
+            const unsigned q = rem / (unsigned)plan.m[s];
+            rem -= q * (unsigned)plan.m[s];
+            idx += q * (unsigned)plan.fstride[s];
+        }
+        out[i] = in[f * N + idx];
+    }
+}
+template <typename A>
+__global__ __launch_bounds__(256) void fft_global_stage_kernel(typename A::cpx *__restrict__ buf, unsigned N, size_t total_bfly, int p, int m, int fstride,
+                                                               const typename A::cpx *__restrict__ tw, int inverse)
+{
+    const unsigned nb = N / (unsigned)p;
+    for (size_t bb = (size_t)blockIdx.x * blockDim.x + threadIdx.x; bb < total_bfly; bb += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = bb / nb;
+        const unsigned b = (unsigned)(bb - f * nb);
+        const unsigned g = b / (unsigned)m, k = b - g * (unsigned)m;
+        kf_bfly<A>(p, buf + f * N + (size_t)g * (unsigned)(p * m) + k, m, tw, (int)(k * (unsigned)fstride), fstride, inverse);
+    }
+}
+template <typename A>
+__global__ __launch_bounds__(256) void fft_global_generic_kernel(const typename A::cpx *__restrict__ cur, typename A::cpx *__restrict__ alt, unsigned N,
+                                                                 size_t total, int p, int m, int fstride, const typename A::cpx *__restrict__ tw)
+{
+    typedef typename A::cpx cpx;
+    const unsigned span = (unsigned)(p * m);
+    for (size_t ee = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ee < total; ee += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = ee / N;
+        const unsigned e = (unsigned)(ee - f * N);
+        const unsigned g = e / span, within = e - g * span, u = within % (unsigned)m;
+        const cpx *S = cur + f * N + (size_t)g * span + u;
+        cpx acc = A::fixdiv(S[0], p);
+        const unsigned step = (unsigned)(((unsigned long long)fstride * within) % N);    // kf_bfly_generic: twidx += fstride*k, reduced modulo Norig
+        unsigned twidx = 0;
+        for (int q = 1; q < p; q++) {
+            twidx += step;
+            if (twidx >= N) twidx -= N;
+            S += m;
+            acc = A::add(acc, A::mul(A::fixdiv(S[0], p), tw[twidx]));
+        }
+        alt[ee] = acc;
+    }
+}
+
+int launch_fft_q15_global(const void *in, void *out, void *ws, size_t nbins, size_t nframes, bool inverse, const void *tw, const int *radix,
+                          int nstages, hipStream_t st)
+{
+    typedef Q15Arith A;
+    if (nframes == 0) return PCX_OK;
+    if (nstages > kMaxStagesMixed || nbins >= ((size_t)1 << 27)) { set_error("fft (Q15, global plan): %zu bins", nbins); return PCX_ERR_UNSUPPORTED; }
+    GlobalPlan plan;
+    plan.nstages = nstages;
+    size_t m = nbins, fs = 1;
+    for (int s = 0; s < nstages; s++) {
+        plan.radix[s] = radix[s];
+        m /= (size_t)radix[s];
+        plan.m[s] = (int)m;
+        plan.fstride[s] = (int)fs;
+        fs *= (size_t)radix[s];
+    }
+    const size_t total = nframes * nbins;
+    const unsigned N = (unsigned)nbins;
+    A::cpx *cur = (A::cpx *)out, *alt = (A::cpx *)ws;
+    if (in == out) {            // a transform in place: the gather needs another destination
+        if (!ws) { set_error("fft (Q15, global plan): in-place needs the workspace"); return PCX_ERR_STATE; }
+        cur = (A::cpx *)ws; alt = (A::cpx *)out;
+    }
+    hipLaunchKernelGGL(fft_global_gather_kernel<A>, dim3(stream_grid(total, 256)), dim3(256), 0, st, (const A::cpx *)in, cur, N, total, plan);
+    PCX_LAUNCH_CHECK();
+    for (int s = nstages - 1; s >= 0; s--) {
+        const int p = plan.radix[s];
+        if (p <= 5) {
+            const size_t nbfly = total / (size_t)p;
+            hipLaunchKernelGGL(fft_global_stage_kernel<A>, dim3(stream_grid(nbfly, 256)), dim3(256), 0, st, cur, N, nbfly, p, plan.m[s], plan.fstride[s],
+                               (const A::cpx *)tw, inverse ? 1 : 0);
+        } else {
+            if (!alt) { set_error("fft (Q15, global plan): radix %d needs the workspace", p); return PCX_ERR_STATE; }
+            hipLaunchKernelGGL(fft_global_generic_kernel<A>, dim3(stream_grid(total, 256)), dim3(256), 0, st, (const A::cpx *)cur, alt, N, total, p,
+                               plan.m[s], plan.fstride[s], (const A::cpx *)tw);
+            A::cpx *t = cur; cur = alt; alt = t;
+        }
+        PCX_LAUNCH_CHECK();
+    }
+    if (cur != (A::cpx *)out) PCX_HIP(hipMemcpyAsync(out, cur, total * sizeof(A::cpx), hipMemcpyDeviceToDevice, st));
+    return PCX_OK;
+}
 
 int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
                      const int *radix_host, int nstages, hipStream_t st)

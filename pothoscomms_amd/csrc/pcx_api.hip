@@ -1138,7 +1138,7 @@ struct pcx_fft {
     int scalar = PCX_F32;
     size_t nbins = 0;
     int inverse = 0;
-    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, MIXED, SMOOTH, FOURSTEP, FOURSTEP_SHORT, BLUESTEIN } kind = MIXED;
+    enum Kind { IDENTITY, R16_4096, R16, POW2, Q15_POW2, Q15_GLOBAL, MIXED, SMOOTH, FOURSTEP, FOURSTEP_SHORT, BLUESTEIN } kind = MIXED;
     int log2n = 0;
     DevBuf tw, perm;
     StageBuf wsIn, wsOut;
@@ -1187,14 +1187,17 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         for (size_t d = (size_t)std::floor(std::sqrt((double)num_bins)); d >= 2; d--)
             if (num_bins % d == 0) { if (num_bins / d <= lds_limit) mixed_n1 = d; break; }
     }
-    bool bluestein = false;
+    bool bluestein = false, q15_global = false;
     if (num_bins > 1 && !r16 && !four_step && !mixed_n1 && num_bins * esz * ((scalar == PCX_I16 && pow2) ? 1 : 2) > 160 * 1024) {
-        if (scalar == PCX_I16 || num_bins > ((size_t)1 << 26)) {
-            set_error("FFT: numBins=%zu (%s) does not fit the single-workgroup LDS plan; not implemented on the device", num_bins,
-                      scalar == PCX_I16 ? "complex_int16: the Q15 rounding sequence of kiss_fft cannot be kept beyond it" : "beyond the chirp-z plan");
+        if (num_bins > ((size_t)1 << 26)) {
+            set_error("FFT: numBins=%zu is beyond every device plan (2^26 bins)", num_bins);
             return PCX_ERR_UNSUPPORTED;
         }
-        bluestein = true;   // float sizes with no other plan (e.g. 2 x a prime beyond one workgroup): chirp-z on the power-of-two plans
+        // complex_int16 frames that no workgroup's LDS holds: kf_work's stages one launch each over global memory -- the Q15
+        // rounding sequence of kiss_fft is kept whatever the size (fft_mixed.hip launch_fft_q15_global); a four-step split
+        // would not keep it
+        if (scalar == PCX_I16) q15_global = true;
+        else bluestein = true;   // float sizes with no other plan (e.g. 2 x a prime beyond one workgroup): chirp-z on the power-of-two plans
     }
     pcx_fft *h = new (std::nothrow) pcx_fft();
     if (!h) { set_error("out of memory"); return PCX_ERR_STATE; }
@@ -1343,7 +1346,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
         }
     } else {
         // kiss_fft_alloc, kiss_fft.c:339-368: Q15 twiddles floor(.5 + 32767*cos/sin(phase))
-        h->kind = pow2 ? pcx_fft::Q15_POW2 : pcx_fft::MIXED;
+        h->kind = q15_global ? pcx_fft::Q15_GLOBAL : pow2 ? pcx_fft::Q15_POW2 : pcx_fft::MIXED;
         std::vector<int16_t> t(2 * num_bins);
         for (size_t i = 0; i < num_bins; i++) {
             const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
@@ -1353,7 +1356,7 @@ int pcx_fft_create(int scalar, size_t num_bins, int inverse, pcx_fft **out)
             t[2 * i + 1] = (int16_t)std::floor(.5 + 32767 * std::sin(phase));
         }
         rc = upload(h->tw, t);
-        if (rc == PCX_OK && pow2 && num_bins <= 65536) {
+        if (rc == PCX_OK && pow2 && num_bins <= 65536 && !q15_global) {
             // the leaf gather of kf_work (kiss_fft.c:276-280): position sum q_s*m_s <- input index sum q_s*fstride_s
             std::vector<uint16_t> perm(num_bins);
             for (size_t pos = 0; pos < num_bins; pos++) {
@@ -1409,7 +1412,7 @@ int pcx_fft_transform_dev(pcx_fft *h, const void *in_dev, void *out_dev, size_t 
     if (nframes == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
     PCX_TRY(ctx_enter(h->cx, as_stream(stream)));
-    if (h->kind == pcx_fft::FOURSTEP_SHORT || h->kind == pcx_fft::FOURSTEP || h->kind == pcx_fft::BLUESTEIN) {
+    if (h->kind == pcx_fft::FOURSTEP_SHORT || h->kind == pcx_fft::FOURSTEP || h->kind == pcx_fft::BLUESTEIN || h->kind == pcx_fft::Q15_GLOBAL) {
         const size_t esz = 2 * (size_t)scalar_bytes(h->scalar);
         const size_t ws_frame = (h->kind == pcx_fft::BLUESTEIN ? h->n2 : h->nbins) * esz;   // workspace bytes per frame
         size_t batch = kFftWorkspaceCap / ws_frame;
@@ -1443,6 +1446,9 @@ static int fft_transform_batch(pcx_fft *h, const void *in_dev, void *out_dev, si
     case pcx_fft::POW2:
         return h->scalar == PCX_F32 ? launch_fft_pow2_cf32(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st)
                                     : launch_fft_pow2_cf64(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, st);
+    case pcx_fft::Q15_GLOBAL:
+        PCX_TRY(h->ws1.ensure(nframes * h->nbins * 4));
+        return launch_fft_q15_global(in_dev, out_dev, h->ws1.p, h->nbins, nframes, h->inverse != 0, h->tw.p, h->radix.data(), (int)h->radix.size(), st);
     case pcx_fft::Q15_POW2:
         return launch_fft_q15(in_dev, out_dev, h->nbins, nframes, h->inverse != 0, h->tw.p, h->perm.p, h->radix.data(), (int)h->radix.size(), st);
     case pcx_fft::FOURSTEP_SHORT: {

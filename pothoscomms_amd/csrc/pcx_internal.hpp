@@ -255,6 +255,8 @@ int launch_fft_pow2_cf32(const void *in, void *out, size_t nbins, size_t nframes
 int launch_fft_pow2_cf64(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw,
                          hipStream_t st);
 // kiss_fft Q15 (bit-exact): nbins = product of radix 4/2 stages; tw = int16 pairs
+int launch_fft_q15_global(const void *in, void *out, void *ws, size_t nbins, size_t nframes, bool inverse, const void *tw, const int *radix,
+                          int nstages, hipStream_t st);   // (fft_mixed.hip) Q15 frames beyond one workgroup's LDS: one launch per stage
 int launch_fft_q15_one(const void *in, void *out, size_t nframes, hipStream_t st);   // numBins = 1, Q15: x * 32767/32768 rounded
 int launch_fft_q15(const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *perm,
                    const int *radix_host, int nstages, hipStream_t st);

@@ -88,7 +88,8 @@ def test_factory_and_setter_argument_errors(pcx):
     f = C.c_void_p()
     assert L.pcx_fft_create(pcx.I32, 64, 0, C.byref(f)) == pcx._lib.ERR_ARG      # FFTFactory: unsupported type
     # (2 x a prime beyond one workgroup's LDS used to be rejected here; it now takes the chirp-z plan, whose tables need the device)
-    assert L.pcx_fft_create(pcx.I16, 1 << 16, 0, C.byref(f)) == pcx._lib.ERR_UNSUPPORTED
+    # (complex_int16 beyond 32768 bins used to be PCX_ERR_UNSUPPORTED; it now takes the stage-per-launch plan, whose tables need the device)
+    assert L.pcx_fft_create(pcx.F32, (1 << 26) * 3, 0, C.byref(f)) == pcx._lib.ERR_UNSUPPORTED      # beyond every plan
     assert L.pcx_fft_create(pcx.F32, 0, 0, C.byref(f)) == pcx._lib.ERR_ARG
     assert L.pcx_rotate_dev(42, 1.0, 0.0, None, None, 0, None) == pcx._lib.ERR_ARG
 

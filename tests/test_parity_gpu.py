@@ -322,7 +322,7 @@ def test_fft_errors(dev):
     with pytest.raises(ValueError):
         dev.Fft("complex_int32", 64)       # FFTFactory: unsupported type
     with pytest.raises(NotImplementedError):
-        dev.Fft("complex_int16", 1 << 16)     # the Q15 rounding order cannot be kept across a four-step split
+        dev.Fft("complex_float32", 3 << 26)   # beyond every plan (2^26 bins); complex_int16 at 65,536 bins was the last size refused
 
 
 @pytest.mark.parametrize("inverse", [False, True])
@@ -915,3 +915,32 @@ def test_documented_in_place_calls(oracle, dev):
     ti = torch.from_numpy(xi).to(d)
     dev.Fft("complex_int16", 1024, False).transform_dev(ti, ti, 7)
     assert np.array_equal(ti.cpu().numpy(), oracle.fft(xi, 1024, False))
+
+
+@pytest.mark.parametrize("nbins", [65536, 131072, 98304, 40000, 57344, 2 * 32771])
+@pytest.mark.parametrize("inv", [False, True])
+def test_q15_fft_beyond_one_workgroup_is_bit_exact(oracle, dev, nbins, inv):
+    """complex_int16 frames that no workgroup's LDS holds (the last PCX_ERR_UNSUPPORTED): kf_work's stages one launch
+    each over global memory (kiss_fft.c:237-302), every C_FIXDIV where the reference has it.  Powers of two (65,536 = 4^8,
+    131,072 = 4^8 * 2), 3 * 2^15, 2^6 * 5^4, 7 * 2^13 (a generic-radix stage) and 2 * a prime beyond 2^15 (kf_bfly_generic over
+    32,771 terms): bit for bit against the oracle and, where the compiled reference is present, against fft/kiss_fft.c itself."""
+    rng = np.random.default_rng(nbins + int(inv))
+    nframes = 2 if nbins < 100000 and nbins != 2 * 32771 else 1
+    x = rng.integers(-32768, 32768, (nframes * nbins, 2)).astype(np.int16)
+    got = dev.Fft("complex_int16", nbins, inv).transform(x)
+    want = oracle.fft(x, nbins, inv)
+    assert np.array_equal(got, want)
+    if oracle.ref() is not None:
+        assert np.array_equal(got, oracle.ref_fft(x, nbins, inv))
+
+
+def test_q15_fft_beyond_one_workgroup_in_place_and_batched(oracle, dev):
+    """the same plan with input and output in ONE device buffer (the gather needs the workspace as its destination)"""
+    import torch
+    nbins, nframes = 65536, 3
+    rng = np.random.default_rng(5)
+    x = rng.integers(-20000, 20000, (nframes * nbins, 2)).astype(np.int16)
+    t = torch.from_numpy(x).cuda()
+    dev.Fft("complex_int16", nbins, False).transform_dev(t, t, nframes)
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), oracle.fft(x, nbins, False))

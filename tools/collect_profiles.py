@@ -27,7 +27,8 @@ def newest(pattern):
 for name in ("bench_default.json", "bench_other_workloads.jsonl", "bench_driver_flags.json", "bench_two_ranks_one_gpu_gloo.json",
              "ab_sched.txt", "ab_oversub.txt", "ab_fft4096_family.txt", "ab_fft_family_rounds.txt", "shard_probe.txt", "host_path.txt", "two_blocks.txt", "chain_path.txt", "pcie_lab.txt", "ubench_roofs.txt",
              "ols_lab_summary.txt", "sweep_fir_taps.txt", "sweep_elementwise.txt", "sweep_fft_sizes.txt", "sweep_fft_f64.txt",
-             "sweep_fft_mixed.txt", "sweep_fir_f64.txt", "real_f32_fir.txt"):
+             "sweep_fft_mixed.txt", "sweep_fir_f64.txt", "real_f32_fir.txt", "ols_lab3_summary.txt", "transient_probe.txt", "shard4_trace.txt",
+             "sweep_fft_q15_large.txt", "bench_native_two_shards_one_gpu.json", "bench_native_two_shards_one_gpu_fmchain.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 f = newest(os.path.join(src, "bench_kt", "**", "*_kernel_stats.csv"))

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
             for (int p = 0; p < 3; p++) tl.a[p] = t2[p * 16];
 #pragma unroll
             for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
-            fft16_tw(w, tl);
+            fft16_tw_conj(w, tl);      // conjugated on its last additions: w = the decimated time samples (fft4096.hpp fft4_conj)
             // w[q] = bin k2 = l + 16 bin_of(q) of sub-transform k1 = fi: decimated time sample n' = k1 + P k2
 #pragma unroll
             for (int q = 0; q < 16; q++) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
                 const unsigned qt = __umulhi(t, magic2);
                 if (g >= 0 && (size_t)g < left && qt * M2 == t) {
                     const cf y = lds[OIMG + n + (n >> 4)];
-                    store_cf<2>(ws, (qt - 1u) * 8u, cf{y.x, -y.y});
+                    store_cf<2>(ws, (qt - 1u) * 8u, y);
                 }
             }
         } else {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
         for (int i = 0; i < P; i++) {
             const int n = j + 256 * i;
             const cf y = lds[OIMG + n + (n >> 4)];
-            store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, cf{y.x, -y.y});
+            store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, y);
         }
         }
         if (!walk.advance()) break;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
             for (int p = 0; p < 3; p++) tl.a[p] = t2[p * 16];
 #pragma unroll
             for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
-            fft16_tw(w, tl);
+            fft16_tw_conj(w, tl);      // conjugated on its last additions (fft4_conj)
         }
         __syncthreads();                                  // every frame has been read: the image is rewritten in output order
         if (sub) {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
             for (int i = 0; i < P; i++) {
                 const int n = g * (256 * P) + j + 256 * i;
                 const cf y = lds[n + (n >> 4)];
-                store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, cf{y.x, -y.y});
+                store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, y);
             }
         }
     }
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
         walk.publish(j);                                  // the inverse passes' barriers follow
         pass1(u, lds, j);
         pass2(u, lds, j);
-        pass3(u, lds, j, tw3);
+        pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
         const size_t room = n_out - b * S_out;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S_out, (unsigned)((room < S_out ? room : S_out) * 8));
         const unsigned vbase = (unsigned)(j - Kov_out) * 8u;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
         for (int q = 0; q < 16; q++) {
             const int row = 256 * bin_of(q);
             if (row + 255 < Kov_out) continue;                // whole row dropped: uniform skip
-            store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
+            store_cf<2>(ws, vbase + (unsigned)row * 8u, u[q]);
         }
         if (!walk.advance()) break;
     }
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
             }
             pass1(u, lds, j);                             // (opens with a barrier: every lane has parked its values by now)
             pass2(u, lds, j);
-            pass3(u, lds, j, tw3);
+            pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
             const size_t room = n_out - b * S_out;
             const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S_out, (unsigned)((room < S_out ? room : S_out) * 8));
             const unsigned vbase = (unsigned)(j - Kov_out) * 8u;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
             for (int q = 0; q < 16; q++) {
                 const int row = 256 * bin_of(q);
                 if (row + 255 < Kov_out) continue;
-                store_cf<2>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
+                store_cf<2>(ws, vbase + (unsigned)row * 8u, u[q]);
             }
         }
     }

@@ -185,15 +185,15 @@ class Block:
             buf, cnt = np.zeros(64, np.float64), C.c_size_t()
             _check(L.pcxb_get_taps(self._h, n, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(cnt), 0))
             return buf[:cnt.value].copy()
-        if name == "setPreload":
+        if name in ("setPreload", "setDevices"):
             v = (C.c_size_t * max(1, len(args[0])))(*[int(a) for a in args[0]])
             return _check(L.pcxb_call_sizes(self._h, n, v, len(args[0])))
-        if name == "preload":
+        if name in ("preload", "getDevices"):
             v, cnt = (C.c_size_t * 64)(), C.c_size_t()
             _check(L.pcxb_get_sizes(self._h, n, v, 64, C.byref(cnt)))
             return [int(v[k]) for k in range(cnt.value)]
         if not args:   # getter
-            if name in ("getDecimation", "getInterpolation", "getNumInlineBuffers", "numTaps"):
+            if name in ("getDecimation", "getInterpolation", "getNumInlineBuffers", "numTaps", "getShardPasses"):
                 v = C.c_size_t()
                 _check(L.pcxb_get_size(self._h, n, C.byref(v)))
                 return v.value

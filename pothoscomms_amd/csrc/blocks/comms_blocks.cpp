@@ -232,11 +232,15 @@ public:
         // extension (not in the reference): which device kernel family serves the filter
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setKernel));
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getKernel));
+        // extension: the block's stream spread over several devices of the node from inside work() (pcx_shard_*, pcx.h)
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setDevices));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getDevices));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getShardPasses));
         // initial update: a single unit tap (reference ctor)
         _taps.assign(1, std::complex<double>(1.0, 0.0));
         this->pushTaps();
     }
-    ~FIRFilter() { pcx_fir_destroy(_h); }
+    ~FIRFilter() { if (_sh) pcx_shard_destroy(_sh); pcx_fir_destroy(_h); }
 
     void setTapsReal(const std::vector<double> &taps)
     {
@@ -293,6 +297,29 @@ public:
     std::string getFrameStartId() const { return _frameStartId; }
     void setFrameEndId(std::string id) { _frameEndId = id; }
     std::string getFrameEndId() const { return _frameEndId; }
+
+    // EXTENSION (not in the reference): one stream over several GPUs from this one block.  devices = the ordinals that carry a
+    // shard each, in stream order; an empty list (the default) is the single-device filter.  Each work() call then splits what
+    // the port holds into devices.size() contiguous shards, moves the K-1-sample halo between neighbouring devices (RCCL send/recv;
+    // peer copies when an ordinal repeats, i.e. several shards on one device -- a rehearsal) and filters every shard in ONE gated
+    // launch (pcx_shard_step).  complex_float32 with M = L = 1 outside burst mode; anything else, and calls that bring less
+    // than a shard's worth per device, run on the single-device handle: the totals of consume / produce are the reference's either way.
+    void setDevices(const std::vector<size_t> &devices)
+    {
+        if (_sh) { check(pcx_shard_destroy(_sh), "FIRFilter::setDevices()"); _sh = nullptr; }
+        _devices = devices;
+        _shardC = 0;
+        if (devices.size() < 2) return;
+        if (!(_dtype == DType("complex_float32"))) throw InvalidArgumentException("FIRFilter::setDevices()", "a sharded stream is complex_float32");
+        std::vector<int> d(devices.begin(), devices.end());
+        std::vector<int> sorted(d);
+        std::sort(sorted.begin(), sorted.end());
+        const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+        check(pcx_shard_create((int)d.size(), d.data(), distinct ? PCX_SHARD_RCCL : PCX_SHARD_PEER_COPY, &_sh), "FIRFilter::setDevices()");
+        this->pushTaps();
+    }
+    std::vector<size_t> getDevices() const { return _devices; }
+    size_t getShardPasses() const { return _shardPasses; }
 
     // the sliding window needs its K-1 history contiguous in front of new samples -- in HBM when the upstream block is one of
     // this module's (kDomain), in page-locked host memory otherwise
@@ -354,6 +381,25 @@ public:
             srcElems = _eobSampsLeft + K - 1;
         }
         size_t consumed = 0, produced = 0;
+        if (_sh && M == 1 && L == 1 && _eobSampsLeft == 0 && srcElems >= K) {
+            // the sharded pass: G shards of C samples each out of what the port holds; the first call fixes C (the port slabs are of
+            // one size: later calls bring the same amount, a shorter tail goes to the single-device handle below)
+            const size_t G = _devices.size();
+            const size_t N = std::min(srcElems - (K - 1), outPort->elements());
+            if (_shardC == 0 && N / G >= K) {
+                _shardC = N / G;
+                check(pcx_shard_configure(_sh, _shardC), "FIRFilter::work()");
+            }
+            if (_shardC != 0 && N >= G * _shardC) {
+                check(pcx_shard_scatter(_sh, src, K - 1 + G * _shardC), "FIRFilter::work()");
+                check(pcx_shard_step(_sh), "FIRFilter::work()");
+                check(pcx_shard_gather(_sh, outPort->buffer().template as<void *>(), G * _shardC), "FIRFilter::work()");
+                _shardPasses++;
+                inPort->consume(G * _shardC);
+                outPort->produce(G * _shardC);
+                return;
+            }
+        }
         check(pcx_fir_process(_h, src, srcElems, outPort->buffer().template as<void *>(), outPort->elements(), &consumed, &produced),
               "FIRFilter::work()");
 
@@ -387,6 +433,7 @@ private:
             for (size_t i = 0; i < _taps.size(); i++) flat[i] = _taps[i].real();
         }
         check(pcx_fir_set_taps(_h, flat.data(), _taps.size()), "FIRFilter::setTaps()");
+        if (_sh) { check(pcx_shard_set_taps(_sh, flat.data(), _taps.size(), _complexTaps ? 1 : 0), "FIRFilter::setTaps()"); _shardC = 0; }
         this->refreshGeometry();
     }
     void refreshGeometry() { check(pcx_fir_get_geometry(_h, &K, &_inputRequire), "FIRFilter::updateInternals()"); }
@@ -398,6 +445,9 @@ private:
     bool _waitTapsMode, _waitTapsArmed;
     std::string _frameStartId, _frameEndId;
     std::string _kernel = "AUTO";
+    pcx_shard *_sh = nullptr;              // setDevices(): the stream over several devices
+    std::vector<size_t> _devices;
+    size_t _shardC = 0, _shardPasses = 0;
     size_t _eobSampsLeft;
     DType _dtype;
     pcx_fir *_h;

@@ -600,3 +600,43 @@ def test_burst_flush_on_a_device_resident_edge(oracle):
     want, rc, rp, _ = ref.work(oracle.rotate(x, 0.3), 4096, [("S", 0, 1, burst)])      # (id, index, width, length)
     assert (c, p) == (rc, rp) and p == burst
     assert nerr(yout[:p], want) <= TOL
+
+
+def test_fir_block_that_owns_a_sharded_stream(oracle):
+    """/comms/fir_filter.setDevices([0, 0]) (an extension): every work() call spreads what the port holds over the listed devices --
+    here two shards on device 0 over peer copies, the rehearsal of two GPUs -- through pcx_shard_* and equals the reference block's
+    stream; consume / produce totals are the reference's, tails shorter than a shard set run on the single-device handle."""
+    from pothoscomms_amd import taps as tp
+    h = tp.c1_taps()
+    K = len(h)
+    rng = np.random.default_rng(77)
+    n = 700000
+    x = rand_stream(rng, oracle.F32, n, True)
+    blk = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    blk.call("setTaps", h)
+    blk.call("setDevices", [0, 0])
+    assert blk.call("getDevices") == [0, 0]
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h)
+    blk.activate(); ref.activate()
+    CH = 200000                       # what a port slab holds per call; the last call brings less
+    got, want, pos = [], [], 0
+    while pos + K - 1 < n:
+        avail = min(CH + K - 1, n - pos)
+        win = x[pos:pos + avail]
+        y, c, p, r, _ = blk.work(win, CH)
+        ry, rc, rp, _ = ref.work(win, CH)
+        assert c == p and c > 0
+        got.append(y); want.append(ry[:p] if p <= rp else ry)
+        # the sharded call may consume a few samples less than the reference (2 shards of floor(N/2)); what matters is the stream
+        pos += c
+        if rp != p:                   # re-align the reference on what the block consumed
+            ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h); ref.activate()
+    got = np.concatenate(got)
+    ref2 = oracle.Fir(oracle.F32, True, True); ref2.set_taps(h); ref2.activate()
+    full, _, pf, _ = ref2.work(x, n)
+    assert got.shape[0] == pf == n - (K - 1)
+    assert nerr(got, full) <= TOL
+    assert blk.call("getShardPasses") >= 3
+    blk.call("setDevices", [])        # back to one device
+    y, c, p, r, _ = blk.work(x[:50000], 50000)
+    assert (c, p) == (50000 - (K - 1),) * 2 and nerr(y, full[:p]) <= TOL

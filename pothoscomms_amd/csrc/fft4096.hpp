@@ -262,6 +262,20 @@ __device__ __forceinline__ void store_cf(__amdgpu_buffer_rsrc_t rs, unsigned vof
     __builtin_amdgcn_raw_buffer_store_b64(t, rs, (int)voff, 0, AUX);
 }
 
+// the workgroup's tables through a descriptor as well: one lane offset and scalar row offsets, no 64-bit address pair per load
+__device__ __forceinline__ cf load_cf(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return cf{__uint_as_float(t.x), __uint_as_float(t.y)};
+}
+__device__ __forceinline__ void load_pass3_twiddles(LaneTw &t, __amdgpu_buffer_rsrc_t tab, int j)
+{
+#pragma unroll
+    for (int p = 0; p < 3; p++) t.a[p] = load_cf(tab, j * 8, (LDS_TW2 + p * 256) * 8);
+#pragma unroll
+    for (int p = 0; p < 12; p++) t.c[p] = load_cf(tab, j * 8, (LDS_TW2 + (3 + p) * 256) * 8);
+}
+
 // atan2 for the fused demodulator: min/max ratio through v_rcp_f32 and a degree-6 minimax
 // polynomial in t^2 (max error 2.5e-7 rad on [0,1], fitted offline) -- ~22 VALU instructions
 // against ~46 for the library atan2f, with an error two orders below the 1e-5*pi parity bar.
@@ -413,6 +427,142 @@ __device__ __forceinline__ void pass3(cf (&v)[16], const cf *lds, int j, const L
         if (CONJ) fft16_tw_conj(v, tw3);
         else fft16_tw(v, tw3);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------- //
+// The transform PAIR of an overlap-save block with its second exchange kept inside sixteen lanes.
+//
+// A convolution does not care in which order the spectrum sits in the registers, only that H sits in the same order.  So the
+// forward transform runs decimation in FREQUENCY (butterfly, then twiddle: `fft16_post`) and the inverse is its transpose,
+// decimation in time (the passes above), and the two meet on a spectrum that is digit-reversed ACROSS LANES:
+//   lane j = 16 ka + kb, register q:  X[ka + 16 kb + 256 bin_of(q)]                     (H is loaded once, in that order)
+// Index algebra, n = j + 256 r on the way in, k = ka + 16 kb + 256 kc:
+//   A   lane j:            DFT16 over r, times W4096^(j ka)            -> a[ka][j]             exchange 1 (whole workgroup)
+//   B   lane (ka, j1):     DFT16 over j2 (j = j1 + 16 j2), W256^(j1 kb) -> b[ka][kb][j1]        exchange 2 (the 16 lanes of ka)
+//   C   lane (ka, kb):     DFT16 over j1                               -> X[ka + 16 kb + 256 kc]
+//   C^T, exchange 2^T, B^T (= pass 2 above: twiddle, DFT16), exchange 1^T, A^T (= pass 3 above) bring conj(IFFT) back in
+//   natural order: lane j holds y[j + 256 bin_of(q)], as the stores want it.
+// Image: sixteen rows of 272 elements (the same 34,816 B).  Row ka is written by everyone in exchange 1 and from then on touched
+// only by the sixteen lanes of ka -- one quarter of one wave -- until exchange 1^T has been read: exchange 2 and 2^T need no
+// s_barrier at all (LDS executes one wave's instructions in order), exchange 1^T needs none in front of its writes.  Three
+// barriers per block instead of eight.  Inside a row exchange 1 uses element 16 j2 + j1, exchange 2 uses 17 kb + j1: every
+// access below is conflict-free for ds_*_b64 (32 lanes over 64 banks) -- rows are 2,176 B = 8.5 bank rows apart, so the two
+// rows under one half-wave fall on opposite halves of the banks, and a lane stride of 17 elements walks all 64 banks.
+// The LDS instruction count drops as well: 16 + 8 + 8 + 8 per transform instead of 8 + 16 + 8 + 16.
+// ---------------------------------------------------------------------------------------------------------------------------- //
+// 16-point forward DFT of x[n], outputs X[k] * w^k: the transpose of fft16_tw, same fifteen factors (c'[n2][k1] = c[k1][n2])
+__device__ __forceinline__ void fft16_post(cf (&v)[16], const LaneTw &tw)
+{
+    fft16_inner(v);                                  // y[n2][k1] at v[4 k1 + n2]
+#pragma unroll
+    for (int k1 = 1; k1 < 4; k1++) {                 // times w^k1 * W16^(n2 k1)
+        cmul2(v[4 * k1 + 0], v[4 * k1 + 1], tw.c[(k1 - 1) * 4 + 0], tw.c[(k1 - 1) * 4 + 1]);
+        cmul2(v[4 * k1 + 2], v[4 * k1 + 3], tw.c[(k1 - 1) * 4 + 2], tw.c[(k1 - 1) * 4 + 3]);
+    }
+    fft16_outer(v);                                  // X[k1 + 4 k2] * w^k1 at v[4 k1 + k2]
+#pragma unroll
+    for (int k2 = 1; k2 < 4; k2++) {                 // times (w^4)^k2
+        cmul2(v[4 * 0 + k2], v[4 * 1 + k2], tw.a[k2 - 1], tw.a[k2 - 1]);
+        cmul2(v[4 * 2 + k2], v[4 * 3 + k2], tw.a[k2 - 1], tw.a[k2 - 1]);
+    }
+}
+// one wave's LDS writes before its LDS reads: ordering for the compiler only, the hardware keeps a wave's LDS traffic in order
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+// the lane that holds spectrum bin (j' + 256 kc) of the natural order is lane j with j' = spec_lane(j)
+__device__ __forceinline__ int spec_lane(int j) { return (j >> 4) + 16 * (j & 15); }
+// H[k] = spec[spec_lane(j) + 256 k], once per workgroup: fetched in natural order (whole 512-byte rows per wave) and turned
+// across the lanes through the block image -- as a gather straight from memory every lane would touch sixteen lines of its own
+// (4 Mi requests per launch of 1024 workgroups: measured 0.6 % of the headline launch)
+// in two halves, so that a kernel can put the requests FIRST in its prologue and the turn behind everything else it requests:
+// the memory counter retires in order, and whatever is waited for drags every older request with it
+struct SpectrumLoad {
+    cf row[16];
+    cf tw2;
+};
+__device__ __forceinline__ void spectrum_request(SpectrumLoad &t, const float2 *__restrict__ spec, const float2 *__restrict__ twtab, int j)
+{
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(spec, N * 8);
+#pragma unroll
+    for (int k = 0; k < 16; k++) t.row[k] = load_cf(rs, j * 8, 2048 * k);
+    t.tw2 = load_cf(make_rsrc(twtab, LDS_TW2 * 8), j * 8, 0);        // lanes >= 240: out of range, reads 0, not stored
+}
+// also stages the pass-2 twiddle table (stage_pass2_twiddles)
+__device__ __forceinline__ void spectrum_turn(cf (&H)[16], const SpectrumLoad &t, cf *lds, int j)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[j + 272 * k] = t.row[k];
+    if (j < LDS_TW2) lds[LDS_DATA + j] = t.tw2;
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; k++) H[k] = lds[spec_lane(j) + 272 * k];
+    // (the next writer of the image is exchange 1, behind its own barrier)
+}
+__device__ __forceinline__ void load_spectrum_lanes(cf (&H)[16], const float2 *__restrict__ spec, const float2 *__restrict__ twtab, cf *lds, int j)
+{
+    SpectrumLoad t;
+    spectrum_request(t, spec, twtab, j);
+    spectrum_turn(H, t, lds, j);
+}
+__device__ __forceinline__ void load_pass2_twiddles(LaneTw &tw, const cf *lds, int j)
+{
+    const cf *t2 = lds + LDS_DATA + (j & 15);
+#pragma unroll
+    for (int p = 0; p < 3; p++) tw.a[p] = t2[p * 16];
+#pragma unroll
+    for (int p = 0; p < 12; p++) tw.c[p] = t2[(3 + p) * 16];
+}
+// forward, part 1: v[r] = x[j + 256 r] -> butterflies of A (a dealt kernel issues its draw behind this)
+__device__ __forceinline__ void dif_a_math(cf (&v)[16], const LaneTw &tw3) { fft16_post(v, tw3); }
+// forward, the rest: on exit v[q] = X[spec_lane(j) + 256 bin_of(q)]
+__device__ __forceinline__ void dif_rest(cf (&v)[16], cf *lds, int j)
+{
+    const int row = 272 * (j >> 4), l = j & 15;
+    lds_barrier();                                   // the readers of the previous exchange 1^T are done
+#pragma unroll
+    for (int q = 0; q < 16; q++) lds[j + 272 * bin_of(q)] = v[q];
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = lds[row + l + 16 * r];
+    LaneTw tw2;
+    load_pass2_twiddles(tw2, lds, j);
+    fft16_post(v, tw2);
+    wave_lds_order();
+#pragma unroll
+    for (int q = 0; q < 16; q++) lds[row + l + 17 * bin_of(q)] = v[q];
+    wave_lds_order();
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = lds[row + 17 * l + r];
+    fft16_plain(v);
+}
+// inverse on conjugated input: u[r] = conj(Y)[spec_lane(j) + 256 r] on entry, u[q] = IFFT(Y)[j + 256 bin_of(q)] on exit
+// (CONJ = false: conj(IFFT(Y)), for a kernel that wants the conjugate anyway)
+template <bool CONJ = true>
+__device__ __forceinline__ void dit_back(cf (&u)[16], cf *lds, int j, const LaneTw &tw3)
+{
+    const int row = 272 * (j >> 4), l = j & 15;
+    fft16_plain(u);
+    wave_lds_order();
+#pragma unroll
+    for (int q = 0; q < 16; q++) lds[row + 17 * l + bin_of(q)] = u[q];
+    wave_lds_order();
+#pragma unroll
+    for (int r = 0; r < 16; r++) u[r] = lds[row + l + 17 * r];
+    LaneTw tw2;
+    load_pass2_twiddles(tw2, lds, j);
+    fft16_tw(u, tw2);
+    wave_lds_order();
+#pragma unroll
+    for (int q = 0; q < 16; q++) lds[row + l + 16 * bin_of(q)] = u[q];
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; r++) u[r] = lds[j + 272 * r];
+    if (CONJ) fft16_tw_conj(u, tw3);
+    else fft16_tw(u, tw3);
 }
 
 }  // namespace fft4k

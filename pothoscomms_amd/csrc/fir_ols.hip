@@ -41,7 +41,9 @@ namespace pcx {
 // without the LDS exchanges, 4 = real stream, LDS exchanges without the butterflies (energy split)
 // HGLOBAL: fetch the lane's 16 H bins from L2 in every block instead of holding them in 32 VGPRs
 // -- room for the register prefetch at 4 workgroups per CU.
-template <bool PREFETCH, int LAUX = 0, int SAUX = 0, int CHUNKED = 0, int DIAG = 0, bool HGLOBAL = false, bool GATED = false>
+// XCH: 1 = the transform pair with its second exchange inside sixteen lanes (fft4096.hpp: three barriers per block), 0 = the
+// Stockham passes both ways (eight)
+template <bool PREFETCH, int LAUX = 0, int SAUX = 0, int CHUNKED = 0, int DIAG = 0, bool HGLOBAL = false, bool GATED = false, int XCH = 0>
 __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_ols4096_kernel(const float2 *__restrict__ in, size_t in_elems,
                                                                   float2 *__restrict__ out, size_t n_out,
                                                                   const float2 *__restrict__ Hspec, int Kov, int pad,
@@ -126,31 +128,54 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
     // (Issuing the first block's stream loads BEFORE the workgroup's 64 KB of tables are requested -- possible now that the
     // first block is the blockIdx -- was built: the compiler then keeps the loaded samples, H and the twiddles live together
     // through the prologue and spills 27 registers, thirteen of them re-read from scratch in every block.  Not kept.)
+    // XCH: the first block's samples are requested AHEAD of the workgroup's 64 KB of tables (all of them through descriptors: no
+    // address registers live across the prologue)
+    // requests of the prologue, oldest first: H and the pass-2 table (they pass through LDS, so they are waited for first), the first
+    // block's samples, the pass-3 twiddles
+    cf v[16];
     LaneTw tw3;
-    load_pass3_twiddles(tw3, twtab, j);
-    stage_pass2_twiddles(lds, twtab, j);
     cf H[16];
-    if (!HGLOBAL) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    if (XCH) {
+        SpectrumLoad sl;
+        spectrum_request(sl, Hspec, twtab, j);
+        if (!PREFETCH) {
+            if (CHUNKED == 3 && GATED && b < gate.blocks) gate_wait(gate, j);
+            fetch(v, b);
+        }
+        load_pass3_twiddles(tw3, make_rsrc(twtab, TW_TABLE_ELEMS * 8), j);
+        spectrum_turn(H, sl, lds, j);
+    } else {
+        load_pass3_twiddles(tw3, twtab, j);
+        stage_pass2_twiddles(lds, twtab, j);
     }
+    if (!HGLOBAL) {
+        if (XCH) {}
+        else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+        }
+    }
+    static_assert(!XCH || (DIAG == 0 && !HGLOBAL), "the sixteen-lane exchange is built for the product configuration only");
     cf nx[16];
     if (PREFETCH) fetch(nx, b);
     for (; b < bend; b += bstep) {
-        cf v[16];
         if (PREFETCH) {
 #pragma unroll
             for (int r = 0; r < 16; r++) v[r] = nx[r];
             const size_t bn = b + bstep;
             if (bn < bend) fetch(nx, bn);   // in flight during this block's math
+        } else if (XCH) {
+            // (requested at the foot of the previous trip -- or ahead of the tables)
         } else {
             if (CHUNKED == 3 && GATED && b < gate.blocks) gate_wait(gate, j);   // this block's window reaches into the halo slot
             fetch(v, b);
         }
         constexpr int PART = DIAG == 3 ? 1 : DIAG == 4 ? 2 : 0;
-        if (DIAG != 2) pass1_math<PART>(v);
+        if (XCH) dif_a_math(v, tw3);
+        else if (DIAG != 2) pass1_math<PART>(v);
         if (CHUNKED == 3) deal.draw(j);     // behind the first butterflies: no load of this block is outstanding any more (pcx_sched.hpp)
-        if (DIAG != 2) {
+        if (XCH) dif_rest(v, lds, j);
+        else if (DIAG != 2) {
         pass1_exchange<PART>(v, lds, j);
         pass2<PART>(v, lds, j);
         pass3<PART>(v, lds, j, tw3);
@@ -178,7 +203,8 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         // waves of a SIMD): blocks already half done retire -- and free their loads' successors -- sooner.  Measured +1.7 %
         // (tools/ols_lab.hip "prio 1 on inverse + stores": 0.2060 -> 0.2023 ms); graded or higher levels measured the same.
         __builtin_amdgcn_s_setprio(1);
-        if (DIAG != 2) {
+        if (XCH) dit_back(u, lds, j, tw3);
+        else if (DIAG != 2) {
         pass1<PART>(u, lds, j);
         pass2<PART>(u, lds, j);
         pass3<PART, true>(u, lds, j, tw3);      // conj(FFT(u)) = the block's time samples: the conjugation rides on the last additions
@@ -200,6 +226,13 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         if (CHUNKED == 3) {
             if (!deal.advance()) break;
             b = GATED ? nblocks - 1 - deal.block() : deal.block();
+        }
+        if (XCH && !PREFETCH) {
+            const size_t bn = CHUNKED == 3 ? b : b + bstep;
+            if (bn < bend) {
+                if (CHUNKED == 3 && GATED && bn < gate.blocks) gate_wait(gate, j);   // this block's window reaches into the halo slot
+                fetch(v, bn);
+            }
         }
     }
     if (CHUNKED == 3) deal.finish(j);
@@ -289,22 +322,28 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
         // two shards on one device, profiles/r03/shard_probe.txt.  PCX_GATED_SLOTS (diag) sets the number.)
         const long env_gd = PCX_ENV_INT("PCX_GATED_SLOTS", 0);
         const unsigned gd = env_gd > 0 ? (unsigned)env_gd : slots;
-        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3, 0, false, true>), gd);
-        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3, 0, false, true>), gd);
-        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3, 0, false, true>), gd);
-        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3, 0, false, true>), gd);
+        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3, 0, false, true, 1>), gd);
+        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3, 0, false, true, 1>), gd);
+        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3, 0, false, true, 1>), gd);
+        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3, 0, false, true, 1>), gd);
     } else if (dealt) {
         const long env_gd = PCX_ENV_INT("PCX_DEALT_SLOTS", 0);
         const unsigned gd = env_gd > 0 ? (unsigned)env_gd : slots;   // 4 resident workgroups per CU, all of them drawing
-        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3>), gd);
-        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3>), gd);
-        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3>), gd);
-        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3>), gd);
+#ifdef PCX_DIAG
+        if (PCX_ENV_INT("PCX_OLS_XCH", 1) == 0) {       // the eight-barrier Stockham pair, for A/B
+            if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3>), gd);
+            else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3>), gd);
+        } else
+#endif
+        if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 3, 0, false, false, 1>), gd);
+        else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 3, 0, false, false, 1>), gd);
+        else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 3, 0, false, false, 1>), gd);
+        else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 3, 0, false, false, 1>), gd);
     }
-    else if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2>), g4);
-    else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2>), g4);
-    else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2>), g4);
-    else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2>), g4);
+    else if (Kov <= 256) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 0, false, false, 1>), g4);
+    else if (Kov <= 512) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 5, 2, 0, 0, false, false, 1>), g4);
+    else if (Kov <= 1024) PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 6, 2, 0, 0, false, false, 1>), g4);
+    else PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 2, 0, 0, false, false, 1>), g4);
 #ifdef PCX_DIAG
 launched:
 #endif
@@ -337,11 +376,9 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
     BlockWalk<DYN> walk;     // the unit dealt is a PAIR of real blocks (one complex transform)
     if (!walk.begin(sched, &sched_slot, npairs, j)) { walk.finish(j); return; }
     LaneTw tw3;
-    load_pass3_twiddles(tw3, twtab, j);
-    stage_pass2_twiddles(lds, twtab, j);
+    load_pass3_twiddles(tw3, make_rsrc(twtab, TW_TABLE_ELEMS * 8), j);
     cf H[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    load_spectrum_lanes(H, Hspec, twtab, lds, j);
     for (;;) {
         const size_t p = walk.block();
         const size_t bA = 2 * p, bB = 2 * p + 1;
@@ -382,11 +419,9 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
                 v[r] = cf{__uint_as_float(a), __uint_as_float(b)};
             }
         }
-        pass1_math(v);
+        dif_a_math(v, tw3);
         walk.draw(j);                       // behind the first butterflies (pcx_sched.hpp)
-        pass1_exchange(v, lds, j);
-        pass2(v, lds, j);
-        pass3(v, lds, j, tw3);
+        dif_rest(v, lds, j);
         cf u[16];
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
@@ -397,9 +432,7 @@ __global__ __launch_bounds__(256, 4) void fir_f32_ols4096_kernel(const float *__
         }
         walk.publish(j);
         __builtin_amdgcn_s_setprio(1);      // as fir_cf32_ols4096_kernel: the second half of a block first
-        pass1(u, lds, j);
-        pass2(u, lds, j);
-        pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
+        dit_back(u, lds, j, tw3);           // conjugated on the last additions: u = the time samples
         // real part -> block A's outputs, imaginary part -> block B's
         const size_t roomA = n_out - bA * S;
         const size_t roomB = bB < nblocks ? n_out - bB * S : 0;
@@ -471,11 +504,9 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const flo
     size_t b = blockIdx.x;
     if (b >= nblocks) return;
     LaneTw tw3;
-    load_pass3_twiddles(tw3, twtab, j);
-    stage_pass2_twiddles(lds, twtab, j);
+    load_pass3_twiddles(tw3, make_rsrc(twtab, TW_TABLE_ELEMS * 8), j);
     cf H[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    load_spectrum_lanes(H, Hspec, twtab, lds, j);
     for (; b < nblocks; b += gridDim.x) {
         cf v[16];
         {
@@ -483,9 +514,8 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const flo
             if (left >= (size_t)N) load_frame<false, 0>(v, make_rsrc(in + b * S, N * 8), j);   // row offsets in soffset
             else load_frame<true, 0>(v, make_rsrc(in + b * S, (unsigned)(left * 8)), j);      // ragged tail: range-checked
         }
-        pass1(v, lds, j);
-        pass2(v, lds, j);
-        pass3(v, lds, j, tw3);
+        dif_a_math(v, tw3);
+        dif_rest(v, lds, j);
         cf u[16];
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
@@ -494,9 +524,7 @@ __global__ __launch_bounds__(256, 4) void fir_cf32_ols4096_poly_kernel(const flo
             u[k1] = v[q + 1];
             cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
-        pass1(u, lds, j);
-        pass2(u, lds, j);
-        pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
+        dit_back(u, lds, j, tw3);           // conjugated on the last additions: u = the time samples
         // input index of time sample i is n = b*S + i - (K-1); flat index f = n*L + jrow
         const unsigned long long B0 = (unsigned long long)(b * S) * L + jrow + 1;   // f+1 at i' = i-(K-1) = 0 (wave-uniform)
         const unsigned long long q0 = B0 / M;
@@ -614,11 +642,9 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         b = GATED ? nblocks - 1 - deal.block() : deal.block();     // GATED (a shard behind a halo): the front blocks last
     } else if (b >= nblocks) return;
     LaneTw tw3;
-    load_pass3_twiddles(tw3, twtab, j);
-    stage_pass2_twiddles(lds, twtab, j);
+    load_pass3_twiddles(tw3, make_rsrc(twtab, TW_TABLE_ELEMS * 8), j);
     cf H[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    load_spectrum_lanes(H, Hspec, twtab, lds, j);
     // element i of block blk is xh[blk*S - 1 - pad + i].  Block 0 has no xh[-1-pad .. -1]: its
     // descriptor sits at xh[0] and the byte offsets of those elements wrap past num_records and
     // read 0 (they only feed dropped outputs and y[-1], which is replaced by the carried state).
@@ -653,11 +679,9 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         cf v[16];
         if (DYN && GATED && b < gate.blocks) gate_wait(gate, j);   // this block's window reaches into the halo slot
         fetch(v, b);
-        pass1_math(v);
+        dif_a_math(v, tw3);
         if (DYN) deal.draw(j);              // behind the first butterflies (pcx_sched.hpp)
-        pass1_exchange(v, lds, j);
-        pass2(v, lds, j);
-        pass3(v, lds, j, tw3);
+        dif_rest(v, lds, j);
         cf u[16];
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
@@ -668,9 +692,7 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         }
         if (DYN) deal.publish(j);
         __builtin_amdgcn_s_setprio(1);      // as fir_cf32_ols4096_kernel: the second half of a block first
-        pass1(u, lds, j);
-        pass2(u, lds, j);
-        pass3(u, lds, j, tw3);
+        dit_back<false>(u, lds, j, tw3);
         // u[q] = conj(y) at time index i = j + 256*bin_of(q).  conj(y[i-1]) sits in lane j-1 of the
         // same register: a wave-shift DPP move brings it over, and only the first lane of each wave
         // needs the last lane of the wave before it (row k-1 for lane 0) -- 64 values through LDS

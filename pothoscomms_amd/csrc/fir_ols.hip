@@ -307,6 +307,13 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     case 16: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 4>), g4); goto launched;
     case 12: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 1>), g4); goto launched;
     case 13: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 2, 0, 2>), g4); goto launched;
+    // 30..34: the product kernel with other cache-policy bits on its stores (sc0 = 1, nt = 2, sc1 = 16)
+    case 30: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 0, 3, 0, false, false, 1>), g4); goto launched;
+    case 31: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 3, 3, 0, false, false, 1>), g4); goto launched;
+    case 32: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 18, 3, 0, false, false, 1>), g4); goto launched;
+    case 33: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 19, 3, 0, false, false, 1>), g4); goto launched;
+    case 34: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 16, 3, 0, false, false, 1>), g4); goto launched;
+    case 35: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 4, 17, 3, 0, false, false, 1>), g4); goto launched;
     case 10: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 1>), g4); goto launched;
     case 11: PCX_OLS_LAUNCH((fir_cf32_ols4096_kernel<false, 0, 0, 0, 2>), g4); goto launched;
     default: break;

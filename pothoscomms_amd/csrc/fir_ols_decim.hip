@@ -235,19 +235,26 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - Kov), Sd = S >> LOG2M;
     const size_t ngroups = (nblocks + G - 1) / G;
+    // XCH (H and the pass-3 constants both in registers): the forward transform runs decimation in frequency with its second
+    // exchange inside sixteen lanes (fft4096.hpp) and leaves lane j with the bins js + 256 r, js = spec_lane(j) -- the fold is the
+    // same sum over the lane's own registers, and the inverse stage takes its 256-point frames in natural order through js
+    constexpr bool XCH = TW3_REG && HREG;
+    const int js = XCH ? spec_lane(j) : j;
     LaneTw tw3r;
-    if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
-    stage_pass2_twiddles(lds, twtab, j);
+    if (XCH) load_pass3_twiddles(tw3r, make_rsrc(twtab, TW_TABLE_ELEMS * 8), j);
+    else if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
+    if (!XCH) stage_pass2_twiddles(lds, twtab, j);
     const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
     cf Hr[16];
-    if (HREG) {
+    if (XCH) load_spectrum_lanes(Hr, Hspec, twtab, lds, j);     // (stages the pass-2 table as well)
+    else if (HREG) {
 #pragma unroll
         for (int k = 0; k < 16; k++) Hr[k] = Hg[256 * k];
     }
     cf td1;
     {
         float sn, cs;
-        sincospif(-2.0f * (float)j / (float)(256 * P), &sn, &cs);
+        sincospif(-2.0f * (float)js / (float)(256 * P), &sn, &cs);
         td1 = cf{cs, sn};
     }
     const int fi = j >> 4, l = j & 15;               // sub-transform t = fi (block fi / P of the group, k1 = fi % P) and lane inside it
@@ -284,9 +291,15 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
                     v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
                 }
             }
+            if (XCH) {
+                dif_a_math(v, tw3r);
+                dif_rest(v, lds, j);
+            } else {
             pass1(v, lds, j);
             pass2(v, lds, j);
-            if (TW3_REG) {
+            }
+            if (XCH) {
+            } else if (TW3_REG) {
                 pass3(v, lds, j, tw3r);
             } else {
                 const float2 *tp = twtab;
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
         // ---- one inverse stage for the whole group: T sub-transforms of 256 points, 16 lanes each ----
         __syncthreads();                                  // the last block's pass-3 reads of the image are done
 #pragma unroll
-        for (int t = 0; t < T; t++) lds[t * FRAME + j + (j >> 4)] = zz[t];
+        for (int t = 0; t < T; t++) lds[t * FRAME + js + (js >> 4)] = zz[t];
         __syncthreads();
         cf w[16];
         cf *fr = lds + fi * FRAME;

@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
     cf td1;
     {
         float sn, cs;
-        sincospif(-2.0f * (float)j / (float)(256 * P), &sn, &cs);
+        sincospif(-2.0f * (float)spec_lane(j) / (float)(256 * P), &sn, &cs);    // the lane's bins are js + 256 r (file header)
         td1 = cf{cs, sn};
     }
+    const int js = spec_lane(j);
     const int fi = j >> 4, l = j & 15;               // sub-frame and lane inside it (lanes j < 16 P run the 256-point stage)
     const bool sub = j < 16 * P;
 
@@ -92,18 +93,17 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
             }
         }
         walk.draw(j);
-        pass1(v, lds, j);
-        walk.publish(j);      // pass 2 opens with a barrier, and more follow before the block ends
-        pass2(v, lds, j);
         if (TW3_REG) {
-            pass3(v, lds, j, tw3r);
+            dif_a_math(v, tw3r);
         } else {
             const float2 *tp = twtab;
             asm volatile("" : "+v"(tp));
             LaneTw tw3;
             load_pass3_twiddles(tw3, tp, j);
-            pass3(v, lds, j, tw3);
+            dif_a_math(v, tw3);
         }
+        walk.publish(j);      // the first exchange opens with a barrier, and more follow before the block ends
+        dif_rest(v, lds, j);
         // u[r] = conj(X[j + 256 r] * H'[j + 256 r]), natural r
         const cf *Hb = Hg;
         asm volatile("" : "+v"(Hb));   // loop-invariant: without this the loads are hoisted back into registers
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
             for (int k1 = 0; k1 < P; k1++) { const int n = j + 256 * k1; lds[OIMG + n + (n >> 4)] = z[k1]; }
         }
 #pragma unroll
-        for (int k1 = 0; k1 < P; k1++) lds[k1 * FRAME + j + (j >> 4)] = z[k1];
+        for (int k1 = 0; k1 < P; k1++) lds[k1 * FRAME + js + (js >> 4)] = z[k1];
         __syncthreads();
         // P independent 256-point transforms, 16 lanes each: radix 16 x 16 (Ns = 1, Ns = 16)
         cf w[16];
@@ -235,19 +235,13 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
     const int j = threadIdx.x;
     const size_t S = (size_t)(N - Kov), Sd = S >> LOG2M;
     const size_t ngroups = (nblocks + G - 1) / G;
-    // XCH (H and the pass-3 constants both in registers): the forward transform runs decimation in frequency with its second
-    // exchange inside sixteen lanes (fft4096.hpp) and leaves lane j with the bins js + 256 r, js = spec_lane(j) -- the fold is the
-    // same sum over the lane's own registers, and the inverse stage takes its 256-point frames in natural order through js
-    constexpr bool XCH = TW3_REG && HREG;
-    const int js = XCH ? spec_lane(j) : j;
+    const int js = spec_lane(j);       // the lane's bins are js + 256 r (file header)
     LaneTw tw3r;
-    if (XCH) load_pass3_twiddles(tw3r, make_rsrc(twtab, TW_TABLE_ELEMS * 8), j);
-    else if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
-    if (!XCH) stage_pass2_twiddles(lds, twtab, j);
-    const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;
+    if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
+    stage_pass2_twiddles(lds, twtab, j);
+    const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;      // (turned on the host: lane j finds H[js + 256 r] at j + 256 r)
     cf Hr[16];
-    if (XCH) load_spectrum_lanes(Hr, Hspec, twtab, lds, j);     // (stages the pass-2 table as well)
-    else if (HREG) {
+    if (HREG) {
 #pragma unroll
         for (int k = 0; k < 16; k++) Hr[k] = Hg[256 * k];
     }
@@ -291,23 +285,16 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
                     v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
                 }
             }
-            if (XCH) {
+            if (TW3_REG) {
                 dif_a_math(v, tw3r);
-                dif_rest(v, lds, j);
-            } else {
-            pass1(v, lds, j);
-            pass2(v, lds, j);
-            }
-            if (XCH) {
-            } else if (TW3_REG) {
-                pass3(v, lds, j, tw3r);
             } else {
                 const float2 *tp = twtab;
                 asm volatile("" : "+v"(tp));
                 LaneTw tw3;
                 load_pass3_twiddles(tw3, tp, j);
-                pass3(v, lds, j, tw3);
+                dif_a_math(v, tw3);
             }
+            dif_rest(v, lds, j);
             const cf *Hb = Hg;
             asm volatile("" : "+v"(Hb));
             cf u[16];
@@ -423,6 +410,8 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     // THREE workgroups per CU (170 VGPRs) it pays everywhere -- the registers are worth more than the fourth workgroup:
     //   M = 2: 236 -> 274-276 Gsamples/s of input (two blocks per group);   M = 4: 302 -> 353 (two blocks);
     //   M = 8: 359 -> 403 (four blocks, H held in registers);                M = 16: 391 -> 445 (four blocks, H in registers).
+    // Round 3, forward transform on the sixteen-lane exchange (profiles/r03/ab_decim.txt): M = 2 / 4 / 8 / 16 = 279 / 356 / 410-434 / 459, same
+    // configuration (H in registers at M = 4 measured 372 once and 356 the next time: left as it was).
     // That is the product path for plain factors (M2 == 1); PCX_DECIM_UNBATCHED (diagnostic library) keeps the one-block kernel,
     // PCX_DECIM_G / PCX_DECIM_HREG / PCX_DECIM_OCC=4 the other configurations, for A/B.
     if (M2 == 1 && !PCX_ENV_SET("PCX_DECIM_UNBATCHED")) {
@@ -522,9 +511,10 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
     cf td1;
     {
         float sn, cs;
-        sincospif(-2.0f * (float)j / (float)ND, &sn, &cs);
+        sincospif(-2.0f * (float)spec_lane(j) / (float)ND, &sn, &cs);     // the lane takes the bins js + 256 r (decimator above)
         td1 = cf{cs, sn};
     }
+    const int js = spec_lane(j);
     const int fi = j >> 4, l = j & 15;
     const bool sub = j < 16 * P;
 
@@ -589,7 +579,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
         // lane j: Xs[j + 256 r'] = sum_n1 W_P^(n1 r') W_ND^(n1 j) G_n1[j]
         cf g[P];
 #pragma unroll
-        for (int n1 = 0; n1 < P; n1++) g[n1] = lds[n1 * FRAME + j + (j >> 4)];
+        for (int n1 = 0; n1 < P; n1++) g[n1] = lds[n1 * FRAME + js + (js >> 4)];
         {
             cf t = td1;
 #pragma unroll
@@ -612,10 +602,9 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
             if (HREG) cmul2_conj(u[r], u[r + 1], Hr[r], Hr[r + 1]);
             else cmul2_conj(u[r], u[r + 1], Hb[256 * r], Hb[256 * (r + 1)]);
         }
-        walk.publish(j);                                  // the inverse passes' barriers follow
-        pass1(u, lds, j);
-        pass2(u, lds, j);
-        pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
+        walk.publish(j);                                  // two barriers follow
+        lds_barrier();                                    // every lane has read its frame values: the inverse below reuses the image
+        dit_back(u, lds, j, tw3);           // conjugated on the last additions: u = the time samples
         const size_t room = n_out - b * S_out;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S_out, (unsigned)((room < S_out ? room : S_out) * 8));
         const unsigned vbase = (unsigned)(j - Kov_out) * 8u;
@@ -662,9 +651,10 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
     cf td1;
     {
         float sn, cs;
-        sincospif(-2.0f * (float)j / (float)ND, &sn, &cs);
+        sincospif(-2.0f * (float)spec_lane(j) / (float)ND, &sn, &cs);     // the lane takes the bins js + 256 r (decimator above)
         td1 = cf{cs, sn};
     }
+    const int js = spec_lane(j);
     const int fi = j >> 4, l = j & 15;
     const bool sub = j < 16 * T;
 
@@ -733,7 +723,7 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
         // park the lane's values of every block: the inverse passes below reuse the image
         cf gg[T];
 #pragma unroll
-        for (int t = 0; t < T; t++) gg[t] = lds[t * FRAME + j + (j >> 4)];
+        for (int t = 0; t < T; t++) gg[t] = lds[t * FRAME + js + (js >> 4)];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const size_t b = grp * G + g;
@@ -763,9 +753,8 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
                 if (HREG) cmul2_conj(u[r], u[r + 1], Hr[r], Hr[r + 1]);
                 else cmul2_conj(u[r], u[r + 1], Hb[256 * r], Hb[256 * (r + 1)]);
             }
-            pass1(u, lds, j);                             // (opens with a barrier: every lane has parked its values by now)
-            pass2(u, lds, j);
-            pass3<0, true>(u, lds, j, tw3);     // conjugated on the last additions: u = the time samples
+            lds_barrier();                                // every lane has parked its values / read the previous block's samples: the image is reused
+            dit_back(u, lds, j, tw3);           // conjugated on the last additions: u = the time samples
             const size_t room = n_out - b * S_out;
             const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S_out, (unsigned)((room < S_out ? room : S_out) * 8));
             const unsigned vbase = (unsigned)(j - Kov_out) * 8u;
@@ -797,11 +786,13 @@ int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, con
     // repeats on one box (tools/ab_interp.sh, profiles/r02/ab_interp.txt): L = 8 two blocks 240-243 -> 250-255 Gsamples/s of output, L = 16
     // four blocks 277-280 -> 300-305; L = 2 loses 10 % and L = 4 is inside the noise, so they keep the one-block kernel.
     // PCX_INTERP_G (diagnostic library) overrides: 0 = one block, 1 / 2 / 3 = two / four / eight.
-    const int lgi = (int)PCX_ENV_INT("PCX_INTERP_G", LOG2L == 3 ? 1 : LOG2L == 4 ? 2 : 0);
+    // (round 3, with the inverse on the sixteen-lane exchange: L = 4 two blocks with H in registers 320 -> 344 Gsamples/s at 1020 taps,
+    // bench.py --workload interp4 0.471 -> 0.503 of HBM; profiles/r03/ab_interp.txt)
+    const int lgi = (int)PCX_ENV_INT("PCX_INTERP_G", LOG2L == 2 || LOG2L == 3 ? 1 : LOG2L == 4 ? 2 : 0);
     if (!dyn && lgi > 0) {
         constexpr int LGMAX = LOG2L == 1 ? 1 : LOG2L == 2 ? 2 : 3;
         const int lg = lgi > LGMAX ? LGMAX : lgi;
-        const bool hreg = PCX_ENV_INT("PCX_INTERP_HREG", LOG2L >= 3 ? 1 : 0) != 0;
+        const bool hreg = PCX_ENV_INT("PCX_INTERP_HREG", LOG2L >= 2 ? 1 : 0) != 0;
         const size_t ngroups = (nblocks + ((size_t)1 << lg) - 1) >> lg;
         const unsigned gb = persistent_grid(ngroups, 768);
 #define PCX_INTERP_ARGS dim3(gb), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_iter * L, (const float2 *)Hspec, (int)Kov_in, \

@@ -213,6 +213,19 @@ static std::vector<T> make_hspec(const std::vector<std::complex<double>> &h, siz
     return H;
 }
 static std::vector<float> make_hspec4096(const std::vector<std::complex<double>> &h) { return make_hspec(h, 4096); }
+// The resampling kernels (fir_ols_decim.hip) re-read H from L2 in every block, so their copy is stored the way their lanes hold the
+// spectrum (fft4096.hpp, spec_lane): entry j + 256 r is bin (j >> 4) + 16 (j & 15) + 256 r, and a wave still reads whole 512-byte rows
+static std::vector<float> turn_spectrum_lanes(const std::vector<float> &H)
+{
+    std::vector<float> T(H.size());
+    for (size_t r = 0; r < 16; r++)
+        for (size_t j = 0; j < 256; j++) {
+            const size_t src = ((j >> 4) + 16 * (j & 15)) + 256 * r, dst = j + 256 * r;
+            T[2 * dst] = H[2 * src];
+            T[2 * dst + 1] = H[2 * src + 1];
+        }
+    return T;
+}
 
 }  // namespace pcx
 
@@ -847,7 +860,7 @@ static int fir_sync_tables(pcx_fir *h)
         for (size_t k = 0; k < h->K; k++)
             hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]), h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
         // even M = M1 * M2: M1 = 16 / 8 / 4 / 2 folded into the spectrum, the cofactor kept one in M2 on the store
-        PCX_TRY(upload(h->Hdecim, make_hspec(hq, 4096, fir_decim_fold_factor(h->M) - 1)));
+        PCX_TRY(upload(h->Hdecim, turn_spectrum_lanes(make_hspec(hq, 4096, fir_decim_fold_factor(h->M) - 1))));
         h->have_decim = true;
     }
     h->have_interp = false;
@@ -859,7 +872,7 @@ static int fir_sync_tables(pcx_fir *h)
             std::vector<std::complex<double>> hq(h->ntaps);
             for (size_t k = 0; k < h->ntaps; k++)
                 hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]), h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
-            PCX_TRY(upload(h->Hdecim, make_hspec(hq, 4096)));
+            PCX_TRY(upload(h->Hdecim, turn_spectrum_lanes(make_hspec(hq, 4096))));
             h->have_interp = true;
         }
     }

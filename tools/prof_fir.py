@@ -44,5 +44,14 @@ elif wl in ("decim8", "interp4"):
     device.fill_uniform_f32_dev(x, seed=7, offset=0)
     for _ in range(reps):
         f.process_dev(x, y)
+elif wl == "fir255_i16":
+    # as bench.py --workload fir255_i16
+    f = device.FirFilter("complex_int16", "COMPLEX")
+    f.set_taps(tp.c1_taps() * 0.9)
+    K = f.K
+    x = torch.randint(-20000, 20000, (C + K - 1, 2), device=dev).to(torch.int16)
+    y = torch.empty((C, 2), dtype=torch.int16, device=dev)
+    for _ in range(reps):
+        f.process_dev(x, y)
 torch.cuda.synchronize()
 print("done", wl)

@@ -179,6 +179,12 @@ PCX_API int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems,
  * shard is filtered while the halo is in flight.
   * The wait is bounded: after two seconds without the signal the held blocks run on whatever the halo slot holds and the word
  * behind the gate word (gate_dev[1]) is set to 0xDEAD -- a gate takes two 32-bit words.
+ * ORDER OF QUEUEING.  Queue the transfer and the signal BEFORE this call (pcx_shard_step and the RCCL driver do): then nothing the
+ * gate waits for can sit behind the gated launch.  A signal queued AFTER it must not share the launch's HARDWARE queue -- HIP
+ * maps a process's streams onto four of them, round robin, and a packet waits for every earlier packet of its queue whatever
+ * stream it came from: a signal behind the launch in the same queue waits for the launch, which waits for the signal (measured:
+ * every fourth stream a process creates times out, tools/gate_queue_probe.py).  A stream of ANOTHER PRIORITY
+ * (hipStreamCreateWithPriority) has queues of its own: use one for a signal that has to be queued late.
  *   *gated = 1: queued as described.   *gated = 0: this configuration has no gated kernel (anything but complex_float32 with
  *   M = L = 1 and K <= 2049, or a call of fewer than ~2048 blocks) and NOTHING has been queued: the caller waits for the halo on
  *   `stream` itself (an event) and calls pcx_fir_process_dev.

@@ -110,7 +110,11 @@ class ShardedFir:
         # the gate word (holds the pass number) and the side stream the exchange is posted on
         if getattr(self, "_gate", None) is None:
             self._gate = torch.zeros((64,), dtype=torch.int32, device=self.buf.device)
-            self._side = torch.cuda.Stream(device=self.buf.device)
+            # A host-driven backend queues the signal BEHIND the gated launch: its stream must not share the launch's hardware queue
+            # (HIP maps streams onto four of them, and a packet waits for every earlier packet of its queue: include/pcx.h, the gate's
+            # contract) -- a stream of another priority has queues of its own.  RCCL queues exchange and signal before the launch.
+            host_driven = not (dist.is_initialized() and dist.get_backend(self.ring.group) == "nccl")
+            self._side = torch.cuda.Stream(device=self.buf.device, priority=-1 if host_driven else 0)
             self._pass = 0
             self._sent = None
 

@@ -259,7 +259,9 @@ def test_the_gate_holds_the_first_block_until_it_is_signalled(oracle):
     assert f.process_dev(x, want) == (n, n)
     torch.cuda.synchronize()
     gate = torch.zeros((64,), dtype=torch.int32, device=dev)
-    side = torch.cuda.Stream(device=dev)
+    # the signal is queued BEHIND the launch here (that is the point of the test): its stream must not share the launch's hardware
+    # queue, and a stream of another priority never does (include/pcx.h, the gate's contract; tools/gate_queue_probe.py)
+    side = torch.cuda.Stream(device=dev, priority=-1)
     for value in (1, 2, 0x7FFFFFFF + 3):               # a pass counter, also across the sign bit (signed distance)
         if value > 2:
             gate.fill_((value - 1) - (1 << 32) if value - 1 >= (1 << 31) else value - 1)     # the word as int32

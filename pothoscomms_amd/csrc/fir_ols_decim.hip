@@ -410,6 +410,9 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     // THREE workgroups per CU (170 VGPRs) it pays everywhere -- the registers are worth more than the fourth workgroup:
     //   M = 2: 236 -> 274-276 Gsamples/s of input (two blocks per group);   M = 4: 302 -> 353 (two blocks);
     //   M = 8: 359 -> 403 (four blocks, H held in registers);                M = 16: 391 -> 445 (four blocks, H in registers).
+    // (Also round 3: the NEXT block's samples prefetched into registers while this block is transformed -- 32 VGPRs, so H has to be
+    // re-read per block instead of held -- 0.1686 ms at M = 8 against 0.1697-0.1709 for the same build without the prefetch and 0.1458
+    // with H in registers: the load latency is not what this kernel waits for.  Not kept.)
     // Round 3, forward transform on the sixteen-lane exchange (profiles/r03/ab_decim.txt): M = 2 / 4 / 8 / 16 = 279 / 356 / 410-434 / 459, same
     // configuration (H in registers at M = 4 measured 372 once and 356 the next time: left as it was).
     // That is the product path for plain factors (M2 == 1); PCX_DECIM_UNBATCHED (diagnostic library) keeps the one-block kernel,

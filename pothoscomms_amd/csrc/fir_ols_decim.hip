@@ -413,16 +413,19 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
     // (Also round 3: the NEXT block's samples prefetched into registers while this block is transformed -- 32 VGPRs, so H has to be
     // re-read per block instead of held -- 0.1686 ms at M = 8 against 0.1697-0.1709 for the same build without the prefetch and 0.1458
     // with H in registers: the load latency is not what this kernel waits for.  Not kept.)
-    // Round 3, forward transform on the sixteen-lane exchange (profiles/r03/ab_decim.txt): M = 2 / 4 / 8 / 16 = 279 / 356 / 410-434 / 459, same
-    // configuration (H in registers at M = 4 measured 372 once and 356 the next time: left as it was).
+    // Round 3, forward transform on the sixteen-lane exchange, every configuration re-timed in a process of its own behind 300 settling
+    // launches (tools/resampler_sweep.py, profiles/r03/resampler_sweep.txt; ms per 64 Mi input samples, two runs each):
+    //   M = 2: two blocks, H re-read 0.2021-0.2030 (H in registers 0.2274-0.2281)      M = 4: two blocks, H in registers 0.1650 (re-read 0.1726-0.1731)
+    //   M = 8: two blocks, H in registers 0.1456-0.1460 (four blocks 0.1479-0.1500)    M = 16: four blocks, H in registers 0.1357-0.1375
+    // -- the defaults below.
     // That is the product path for plain factors (M2 == 1); PCX_DECIM_UNBATCHED (diagnostic library) keeps the one-block kernel,
     // PCX_DECIM_G / PCX_DECIM_HREG / PCX_DECIM_OCC=4 the other configurations, for A/B.
     if (M2 == 1 && !PCX_ENV_SET("PCX_DECIM_UNBATCHED")) {
         constexpr int LGMAX = LOG2M == 1 ? 1 : LOG2M == 2 ? 2 : 3;      // G P <= 16, eight blocks at most
-        int lg = (int)PCX_ENV_INT("PCX_DECIM_G", LOG2M >= 3 ? 2 : 1);
+        int lg = (int)PCX_ENV_INT("PCX_DECIM_G", LOG2M >= 4 ? 2 : 1);
         if (lg > LGMAX) lg = LGMAX;
         if (lg < 1) lg = 1;
-        const bool hreg = PCX_ENV_INT("PCX_DECIM_HREG", LOG2M >= 3 ? 1 : 0) != 0;
+        const bool hreg = PCX_ENV_INT("PCX_DECIM_HREG", LOG2M >= 2 ? 1 : 0) != 0;
         const bool occ4 = PCX_ENV_INT("PCX_DECIM_OCC", 3) == 4;
         const bool tw3 = PCX_ENV_INT("PCX_DECIM_TW3", LOG2M >= 3 ? 1 : 0) != 0;     // (four-per-CU builds only: pass-3 constants in registers)
         const size_t ngroups = (nblocks + ((size_t)1 << lg) - 1) >> lg;
@@ -791,7 +794,9 @@ int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, con
     // PCX_INTERP_G (diagnostic library) overrides: 0 = one block, 1 / 2 / 3 = two / four / eight.
     // (round 3, with the inverse on the sixteen-lane exchange: L = 4 two blocks with H in registers 320 -> 344 Gsamples/s at 1020 taps,
     // bench.py --workload interp4 0.471 -> 0.503 of HBM; profiles/r03/ab_interp.txt)
-    const int lgi = (int)PCX_ENV_INT("PCX_INTERP_G", LOG2L == 2 || LOG2L == 3 ? 1 : LOG2L == 4 ? 2 : 0);
+    // (the same sweep: L = 2 one block, H in registers 0.1841-0.1846 ms per 32 Mi inputs against 0.1898-0.1902 re-read; L = 4 two blocks, H in
+    // registers 0.1679-0.1687; L = 8 four blocks, H in registers 0.2014-0.2017 against 0.2063-0.2076 for two)
+    const int lgi = (int)PCX_ENV_INT("PCX_INTERP_G", LOG2L == 2 ? 1 : LOG2L >= 3 ? 2 : 0);
     if (!dyn && lgi > 0) {
         constexpr int LGMAX = LOG2L == 1 ? 1 : LOG2L == 2 ? 2 : 3;
         const int lg = lgi > LGMAX ? LGMAX : lgi;
@@ -815,7 +820,7 @@ int launch_interp(const void *in, size_t in_elems, void *out, size_t n_iter, con
     }
     if (!dyn && PCX_ENV_INT("PCX_INTERP_OCC", 3) == 3) {
         const unsigned g3 = persistent_grid(nblocks, 768);
-        if (PCX_ENV_INT("PCX_INTERP_HREG", LOG2L >= 3 ? 1 : 0) != 0)
+        if (PCX_ENV_INT("PCX_INTERP_HREG", 1) != 0)
             hipLaunchKernelGGL((fir_cf32_ols4096_interp_kernel<LOG2L, false, 3, true>), dim3(g3), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out,
                                n_iter * L, (const float2 *)Hspec, (int)Kov_in, (int)pad_in, (const float2 *)tw4096, nblocks, (pcx::SchedState *)nullptr);
         else

@@ -30,6 +30,9 @@
 //           One steal from the neighbouring counter when the own one runs dry (NOSTEAL: none).
 //   DMA     the next block's input goes global -> LDS by LDS-DMA, issued BEFORE this block's stores (in-order vmcnt: the loads
 //           no longer wait for the stores' acknowledgements, and their latency overlaps the last butterflies + store issue)
+//   XCH     the transform pair of the product since late round 3 (fft4096.hpp dif_a_math / dif_rest / dit_back): forward decimation in
+//           frequency, inverse its transpose, the second exchange of each inside sixteen lanes -- three barriers per block, no conflicts,
+//           H turned across the lanes through LDS once per workgroup.  (The product also requests its first block ahead of the tables.)
 //
 // Build: make -C tools ols_lab3      Run: tools/ols_lab3 [seconds-per-config] [first-config] [last-config]
 #include <hip/hip_runtime.h>
@@ -49,7 +52,7 @@
 
 using namespace pcx::fft4k;
 
-enum { F_SWZ = 1, F_FIRST = 2, F_STAMP = 4, F_MEM = 8, F_DOSE = 16, F_DMA = 32, F_NOPRIO = 64, F_STATIC = 128, F_SINGLES = 256, F_LBAR = 512, F_ADRAW = 1024, F_SHARD = 2048, F_NOSTEAL = 4096 };
+enum { F_SWZ = 1, F_FIRST = 2, F_STAMP = 4, F_MEM = 8, F_DOSE = 16, F_DMA = 32, F_NOPRIO = 64, F_STATIC = 128, F_SINGLES = 256, F_LBAR = 512, F_ADRAW = 1024, F_SHARD = 2048, F_NOSTEAL = 4096, F_XCH = 8192 };
 
 struct WgStat {   // per workgroup, written once at exit
     unsigned long long t_start, t_first, t_end;      // s_memrealtime (100 MHz)
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(256, 4) void lab3_kernel(const float2 *__restrict__
     constexpr bool LBAR = (FLAGS & F_LBAR) != 0 || DMA, ADRAW = (FLAGS & F_ADRAW) != 0;
     constexpr unsigned NSH = (FLAGS & F_SHARD) ? 16u : 1u;
     constexpr bool STEAL = NSH > 1 && (FLAGS & F_NOSTEAL) == 0;
+    constexpr bool XCH = (FLAGS & F_XCH) != 0;
+    static_assert(!XCH || (!SWZ && !DMA && LBAR && ADRAW), "XCH: on the padded image, the product's barriers and draw");
     __shared__ cf lds[(SWZ ? N : LDS_DATA) + LDS_TW2];
     __shared__ unsigned slots[2];
     const int j = threadIdx.x;
@@ -203,8 +208,12 @@ __global__ __launch_bounds__(256, 4) void lab3_kernel(const float2 *__restrict__
     load_pass3_twiddles(tw3, twtab, j);
     if (j < LDS_TW2) lds[(SWZ ? N : LDS_DATA) + j] = reinterpret_cast<const cf *>(twtab)[j];
     cf H[16];
+    if (XCH) {
+        load_spectrum_lanes(H, Hspec, twtab, lds, j);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+        for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
+    }
     cf acc[16];
     if (DOSE) {
 #pragma unroll
@@ -282,7 +291,8 @@ __global__ __launch_bounds__(256, 4) void lab3_kernel(const float2 *__restrict__
             if (!STATIC && j == 0 && last_of_chunk()) *slot = chunk_of_draw(pending, shard);
             wg_barrier<LBAR>();
         } else {
-            if (ADRAW) transform<SWZ, LBAR>(v, lds, j, tw3, draw);
+            if (XCH) { dif_a_math(v, tw3); draw(); dif_rest(v, lds, j); }
+            else if (ADRAW) transform<SWZ, LBAR>(v, lds, j, tw3, draw);
             else transform<SWZ, LBAR>(v, lds, j, tw3);
 #pragma unroll
             for (int q = 0; q < 16; q += 2) {
@@ -294,7 +304,9 @@ __global__ __launch_bounds__(256, 4) void lab3_kernel(const float2 *__restrict__
             if (!STATIC && j == 0 && last_of_chunk()) *slot = chunk_of_draw(pending, shard);
             if (STAMP) p2 = STAMP_NOW();
             if (PRIO) __builtin_amdgcn_s_setprio(1);
-            if (!DMA) {
+            if (XCH) {
+                dit_back<false>(u, lds, j, tw3);
+            } else if (!DMA) {
                 transform<SWZ, LBAR>(u, lds, j, tw3);
             } else {
                 // the same transform with the next block's DMA slipped in between the last gather and the last butterflies
@@ -462,6 +474,11 @@ int main(int argc, char **argv)
         /* 16 */ {"static first chunk only (again)", lab3_kernel<B>, 1024, true, false, false},
         /* 17 */ {"singles, 16 counters (again)", lab3_kernel<A | F_SHARD | F_SINGLES>, 1024, true, false, false},
         /* 18 */ {"singles, 16 counters, all-zero input", lab3_kernel<A | F_SHARD | F_SINGLES>, 1024, true, false, true},
+        /* 19 */ {"singles, no stealing, SIXTEEN-LANE EXCHANGE", lab3_kernel<A | F_SHARD | F_SINGLES | F_NOSTEAL | F_XCH>, 1024, true, false, false},
+        /* 20 */ {"STAMPED sixteen-lane exchange", lab3_kernel<A | F_SHARD | F_SINGLES | F_NOSTEAL | F_XCH | F_STAMP>, 1024, true, true, false},
+        /* 21 */ {"singles, no stealing (again)", lab3_kernel<A | F_SHARD | F_SINGLES | F_NOSTEAL>, 1024, true, false, false},
+        /* 22 */ {"sixteen-lane exchange (again)", lab3_kernel<A | F_SHARD | F_SINGLES | F_NOSTEAL | F_XCH>, 1024, true, false, false},
+        /* 23 */ {"sixteen-lane exchange, all-zero input", lab3_kernel<A | F_SHARD | F_SINGLES | F_NOSTEAL | F_XCH>, 1024, true, false, true},
     };
     // reference output: the r01 static-stride pipeline
     hipLaunchKernelGGL(lab3_kernel<F_STATIC>, dim3(g971), dim3(256), 0, 0, x, yref, n, Hs, Kov, tw, nblocks, sched, st);

@@ -98,8 +98,18 @@ class ShardedFir:
 
     @property
     def shard(self):
-        """The C samples this rank owns (a view behind the halo)."""
+        """The C samples this rank owns (a view behind the halo).  Taking the view fences the input (fence_input): whoever asks for it is
+        about to write samples."""
+        self.fence_input()
         return self.buf[self.K - 1:]
+
+    def fence_input(self):
+        """Make the current stream wait until the last pass's exchange has READ the shard's tail (the send to the right neighbour runs on
+        a side stream).  Only a WRITER of the shard needs that -- the next pass only reads it -- so step() does not pay for the
+        cross-stream wait (13 us of a 190 us pass, tools/host_step_probe.py); call this, or take `shard` again, before anything queued on
+        the current stream overwrites samples."""
+        if getattr(self, "_side", None) is not None and self.buf.is_cuda:
+            torch.cuda.current_stream(self.buf.device).wait_stream(self._side)
 
     def _run(self, first_out, n_out):
         # outputs [first_out, first_out + n_out) read buf[first_out : first_out + n_out + K - 1]
@@ -169,8 +179,7 @@ class ShardedFir:
         if not gated:
             cur.wait_stream(self._side)
             self._run(0, self.head)
-        # nothing queued on this stream later (the next fill of the shard) may overwrite the tail the send is still reading
-        cur.wait_stream(self._side)
+        # (a later WRITER of the shard has to wait for the send that is still reading its tail: fence_input)
         return self.out
 
 
@@ -207,7 +216,13 @@ class ShardedFmChain:
 
     @property
     def shard(self):
+        """The C samples this rank owns; taking the view fences the input (ShardedFir.fence_input)."""
+        self.fence_input()
         return self.buf[self.K:]
+
+    def fence_input(self):
+        if getattr(self, "_side", None) is not None and self.buf.is_cuda:
+            torch.cuda.current_stream(self.buf.device).wait_stream(self._side)
 
     @property
     def out(self):
@@ -260,5 +275,4 @@ class ShardedFmChain:
                 self._run(ch, 0, self.C + 1, 0)
             else:
                 assert c == self.C + 1 and p == self.C + 1, (c, p)
-        cur.wait_stream(self._side)
         return self.out

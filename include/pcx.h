@@ -184,7 +184,9 @@ PCX_API int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems,
  * maps a process's streams onto four of them, round robin, and a packet waits for every earlier packet of its queue whatever
  * stream it came from: a signal behind the launch in the same queue waits for the launch, which waits for the signal (measured:
  * every fourth stream a process creates times out, tools/gate_queue_probe.py).  A stream of ANOTHER PRIORITY
- * (hipStreamCreateWithPriority) has queues of its own: use one for a signal that has to be queued late.
+ * (hipStreamCreateWithPriority) has queues of its own: use one for a signal that has to be queued late -- or put the gate words
+ * in page-locked host memory (hipHostMalloc; the waiting workgroup reads them in place with system-scope loads) and open the gate
+ * from the host with a plain 32-bit store, as the host-driven driver of pothoscomms_amd/stream.py does.
  *   *gated = 1: queued as described.   *gated = 0: this configuration has no gated kernel (anything but complex_float32 with
  *   M = L = 1 and K <= 2049, or a call of fewer than ~2048 blocks) and NOTHING has been queued: the caller waits for the halo on
  *   `stream` itself (an event) and calls pcx_fir_process_dev.

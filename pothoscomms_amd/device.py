@@ -72,6 +72,13 @@ def _dev_ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _gate_ptr(t):
+    """a gate word: device memory, or page-locked host memory (the device reads it in place; the host opens it with a plain store)"""
+    if not t.is_cuda and t.is_pinned():
+        return C.c_void_p(t.data_ptr())
+    return _dev_ptr(t)
+
+
 def _stream_ptr(stream=None):
     import torch
     s = torch.cuda.current_stream() if stream is None else stream
@@ -177,13 +184,21 @@ class FirFilter(_Handle):
             out_cap = y.numel() // w
         c, p, g = C.c_size_t(), C.c_size_t(), C.c_int()
         _lib.check(_lib.load().pcx_fir_process_dev_gated(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap, C.byref(c), C.byref(p),
-                                                         _dev_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream), C.byref(g)))
+                                                         _gate_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream), C.byref(g)))
         return c.value, p.value, bool(g.value)
 
 
 def gate_signal(gate, value, stream=None):
     """pcx_gate_signal_dev: a one-thread kernel on `stream` (default: torch's current one) that sets the gate word to `value`."""
     _lib.check(_lib.load().pcx_gate_signal_dev(_dev_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream)))
+
+
+def gate_signal_host(gate, value):
+    """Open a gate that lives in page-locked HOST memory: a plain 32-bit store, no stream and no hardware queue behind it -- the way
+    to signal LATE (behind the gated launch), where a stream's signal kernel could sit in the launch's own queue (include/pcx.h)."""
+    if gate.is_cuda or not gate.is_pinned():
+        raise ValueError("gate_signal_host needs a page-locked host tensor")
+    C.c_uint32.from_address(gate.data_ptr()).value = value & 0xFFFFFFFF
 
 
 class Fft(_Handle):
@@ -286,7 +301,7 @@ class FmChain(_Handle):
         """pcx_fmchain_process_dev_gated (see FirFilter.process_dev_gated; the halo is K samples).  Returns (consumed, produced, gated)."""
         c, p, g = C.c_size_t(), C.c_size_t(), C.c_int()
         _lib.check(_lib.load().pcx_fmchain_process_dev_gated(self._h, _dev_ptr(x), in_elems, _dev_ptr(y), out_cap, C.byref(c), C.byref(p),
-                                                             _dev_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream), C.byref(g)))
+                                                             _gate_ptr(gate), value & 0xFFFFFFFF, _stream_ptr(stream), C.byref(g)))
         return c.value, p.value, bool(g.value)
 
 

@@ -119,12 +119,15 @@ class ShardedFir:
     def _gate_setup(self):
         # the gate word (holds the pass number) and the side stream the exchange is posted on
         if getattr(self, "_gate", None) is None:
-            self._gate = torch.zeros((64,), dtype=torch.int32, device=self.buf.device)
-            # A host-driven backend queues the signal BEHIND the gated launch: its stream must not share the launch's hardware queue
-            # (HIP maps streams onto four of them, and a packet waits for every earlier packet of its queue: include/pcx.h, the gate's
-            # contract) -- a stream of another priority has queues of its own.  RCCL queues exchange and signal before the launch.
+            # A host-driven backend opens the gate BEHIND the gated launch.  A signal kernel queued that late can land in the launch's own
+            # hardware queue and wait for it (include/pcx.h, the gate's contract), so the word lives in page-locked host memory and the
+            # host stores to it.  RCCL queues exchange and signal before the launch: device word, side stream.
             host_driven = not (dist.is_initialized() and dist.get_backend(self.ring.group) == "nccl")
-            self._side = torch.cuda.Stream(device=self.buf.device, priority=-1 if host_driven else 0)
+            if host_driven:
+                self._gate = torch.zeros((64,), dtype=torch.int32).pin_memory()
+            else:
+                self._gate = torch.zeros((64,), dtype=torch.int32, device=self.buf.device)
+            self._side = torch.cuda.Stream(device=self.buf.device)
             self._pass = 0
             self._sent = None
 
@@ -175,7 +178,7 @@ class ShardedFir:
         if not nccl:
             self.ring.finish(reqs)                        # the host waits for the halo ...
             if self.ring.rank > 0:
-                dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)      # ... and opens the gate
+                dv.gate_signal_host(self._gate, self._pass)                         # ... and opens the gate (a store to the host word)
         if not gated:
             cur.wait_stream(self._side)
             self._run(0, self.head)

@@ -125,13 +125,12 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
             }
         }
     };
-    // (Issuing the first block's stream loads BEFORE the workgroup's 64 KB of tables are requested -- possible now that the
-    // first block is the blockIdx -- was built: the compiler then keeps the loaded samples, H and the twiddles live together
-    // through the prologue and spills 27 registers, thirteen of them re-read from scratch in every block.  Not kept.)
-    // XCH: the first block's samples are requested AHEAD of the workgroup's 64 KB of tables (all of them through descriptors: no
-    // address registers live across the prologue)
-    // requests of the prologue, oldest first: H and the pass-2 table (they pass through LDS, so they are waited for first), the first
-    // block's samples, the pass-3 twiddles
+    // XCH: the first block's samples are requested together with the workgroup's 64 KB of tables, not behind them (possible since the
+    // first block is the blockIdx).  Oldest request first: H and the pass-2 table (they pass through LDS, so they are waited for
+    // first), the samples, the pass-3 twiddles -- every one of them through a descriptor, so that no address registers live across
+    // the prologue, and with the block loop rotated (the next block's fetch at the foot of this one).  Built the plain way -- the
+    // fetch at the top of the loop, selected on the first trip -- the same idea spilled 27-29 registers, thirteen of them re-read
+    // from scratch in every block.
     cf v[16];
     LaneTw tw3;
     cf H[16];
@@ -148,12 +147,9 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
         load_pass3_twiddles(tw3, twtab, j);
         stage_pass2_twiddles(lds, twtab, j);
     }
-    if (!HGLOBAL) {
-        if (XCH) {}
-        else {
+    if (!HGLOBAL && !XCH) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
-        }
+        for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cf *>(Hspec)[j + 256 * k];
     }
     static_assert(!XCH || (DIAG == 0 && !HGLOBAL), "the sixteen-lane exchange is built for the product configuration only");
     cf nx[16];

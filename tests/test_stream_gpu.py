@@ -285,3 +285,95 @@ def test_bench_native_driver_rehearsed_on_one_gpu_and_refused_without_enough_gpu
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["metric"].startswith("Msamples/s fused FM-demod chain") and line["config"]["halo_samples"] == 127
+
+
+# ---- the RCCL branch of the rank driver, for real, on ONE GPU: a group of one rank whose ring sends the halo to the rank itself ----
+
+def _rccl_self_worker(port, C, chain, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from pothoscomms_amd import device, taps as tp
+    from pothoscomms_amd.stream import HaloRing, ShardedFir, ShardedFmChain
+
+    class SelfRing(HaloRing):
+        """a MIDDLE rank of three whose neighbours are both itself: one RCCL group with a send and a receive, like any interior rank"""
+        def __init__(self, halo):
+            self.halo = halo; self.group = None; self.rank = 1; self.world = 3
+
+        def start(self, buf):
+            return dist.batch_isend_irecv([dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], 0),
+                                           dist.P2POp(dist.irecv, buf[:self.halo], 0)])
+
+    dev = torch.device("cuda", 0)
+    res = []
+    if chain:
+        sc = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, C, dev)
+        sc.ring = SelfRing(sc.K)
+        import numpy as np
+        x = torch.from_numpy(np.ascontiguousarray(tp.fm_test_signal(C + sc.K)).view(np.float32).reshape(-1, 2)).to(dev)
+        for p in range(2):
+            sc.buf.copy_(torch.roll(x, 1000 * p, 0))
+            tail = sc.buf[sc.buf.shape[0] - sc.K:].clone()
+            sc.buf[:sc.K] = float("nan")               # only the exchange can make the front of the shard right
+            out = sc.step()
+            torch.cuda.synchronize()
+            assert torch.equal(sc.buf[:sc.K], tail)
+            res.append((sc.buf.cpu().numpy(), out.cpu().numpy()))
+    else:
+        sf = ShardedFir(tp.c1_taps(), C, dev)
+        sf.ring = SelfRing(sf.K - 1)
+        K = sf.K
+        f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.c1_taps())
+        want = torch.empty((C, 2), dtype=torch.float32, device=dev)
+        for p in range(2):
+            device.fill_uniform_f32_dev(sf.buf, seed=3 + p, offset=0)
+            tail = sf.buf[sf.buf.shape[0] - (K - 1):].clone()
+            sf.buf[:K - 1] = float("nan")
+            out = sf.step()
+            torch.cuda.synchronize()
+            assert torch.equal(sf.buf[:K - 1], tail)                     # the halo arrived, in place
+            assert f.process_dev(sf.buf, want) == (C, C)                 # a plain call on the completed buffer
+            torch.cuda.synchronize()
+            res.append((bool(torch.equal(out, want)), int(sf._gate[1].item()), sf.buf[:K - 1 + 8192].cpu().numpy(), out[:8192].cpu().numpy()))
+    q.put(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_the_rccl_pass_of_a_middle_rank_on_one_gpu(oracle, chain):
+    """ShardedFir / ShardedFmChain._step_gated over the RCCL backend -- side stream, grouped isend / irecv, the gate signal behind them,
+    ONE gated launch -- had only ever run in its host-driven variant (gloo).  One GPU is enough to run it for real: a group of one rank
+    whose ring sends the halo to the rank itself.  Poisoned halo slot, two passes with different data: bit-identical to a plain call on
+    the completed buffer (FIR), the chain against the oracle chain; no gate time-out."""
+    from pothoscomms_amd import taps as tp
+    C = 2100 * 3840 if not chain else 2100 * 3968
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_self_worker, args=(_free_port(), C, chain, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    if not chain:
+        h = tp.c1_taps()
+        for same, timed_out, xin, got in res:
+            assert same and timed_out == 0
+            ref_blk = oracle.Fir(oracle.F32, True, True); ref_blk.set_taps(h); ref_blk.activate()
+            ref, _, _, _ = ref_blk.work(xin, 8192)
+            assert nerr(got, ref) <= TOL
+    else:
+        from tests.util import ang_err
+        h = tp.c4_taps()
+        for xbuf, got in res:
+            n = 20000                                      # the front of the shard: what the halo feeds
+            xr = oracle.rotate(xbuf[:n + len(h)], tp.C4_PHASE)
+            fir = oracle.Fir(oracle.F32, True, False); fir.set_taps(h); fir.activate()
+            y, _, _, _ = fir.work(xr, n + 1)
+            ref = oracle.FreqDemod(oracle.F32).work(y)[1:n + 1]
+            assert not np.isnan(got).any()
+            assert ang_err(got[:n], ref) <= TOL

@@ -424,7 +424,7 @@ def main():
         def step():
             sf.step()
         desc = {"workload": "255-tap complex_float32 FIR (/comms/fir_filter, COMPLEX taps, M=L=1), %d-sample shard per GPU, "
-                            "%s" % (C, "frequency-domain overlap-save (4096-pt Stockham)" if wl == "fir255" else "LDS-tiled direct form"),
+                            "%s" % (C, "frequency-domain overlap-save (4096-pt radix-16 passes)" if wl == "fir255" else "LDS-tiled direct form"),
                 "taps": 255, "shard_samples": C, "halo_samples": K - 1, "setup_passes": args.settle,
                 "parallelism": "overlap-save shards x%d, RCCL send/recv halo" % world if world > 1 else "single GPU"}
         metric = "Msamples/s complex_float32 255-tap FIR"

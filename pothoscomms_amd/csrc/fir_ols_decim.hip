@@ -152,12 +152,12 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
             fft16_plain(w);
         }
-        __syncthreads();
-        if (sub) {
+        wave_lds_order();                                 // a frame belongs to sixteen lanes of ONE wave from here to the stage's last read:
+        if (sub) {                                        // no workgroup barrier between its passes (fft4096.hpp)
 #pragma unroll
             for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
         }
-        __syncthreads();
+        wave_lds_order();
         if (sub) {
 #pragma unroll
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
@@ -339,12 +339,12 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
             fft16_plain(w);
         }
-        __syncthreads();
-        if (sub) {
+        wave_lds_order();                                 // a frame belongs to sixteen lanes of ONE wave from here to the stage's last read:
+        if (sub) {                                        // no workgroup barrier between its passes (fft4096.hpp)
 #pragma unroll
             for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
         }
-        __syncthreads();
+        wave_lds_order();
         if (sub) {
 #pragma unroll
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
@@ -555,12 +555,12 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
             fft16_plain(w);
         }
-        __syncthreads();
-        if (sub) {
+        wave_lds_order();                                 // a frame belongs to sixteen lanes of ONE wave from here to the stage's last read:
+        if (sub) {                                        // no workgroup barrier between its passes (fft4096.hpp)
 #pragma unroll
             for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
         }
-        __syncthreads();
+        wave_lds_order();
         if (sub) {
 #pragma unroll
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_interp_kernel(const
             for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
             fft16_tw(w, tl);
         }
-        __syncthreads();                                  // every lane of the frame has read its inputs
+        wave_lds_order();                                 // every lane of the frame has read its inputs (the frame's own sixteen lanes)
         if (sub) {
             // G_n1[k2], k2 = l + 16 bin_of(q), back into the frame in natural order
 #pragma unroll
@@ -700,12 +700,12 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
             fft16_plain(w);
         }
-        __syncthreads();
-        if (sub) {
+        wave_lds_order();                                 // a frame belongs to sixteen lanes of ONE wave from here to the stage's last read:
+        if (sub) {                                        // no workgroup barrier between its passes (fft4096.hpp)
 #pragma unroll
             for (int q = 0; q < 16; q++) fr[17 * l + bin_of(q)] = w[q];
         }
-        __syncthreads();
+        wave_lds_order();
         if (sub) {
 #pragma unroll
             for (int s = 0; s < 16; s++) w[s] = fr[l + 17 * s];
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
             for (int p = 0; p < 12; p++) tl.c[p] = t2[(3 + p) * 16];
             fft16_tw(w, tl);
         }
-        __syncthreads();                                  // every lane of a frame has read its inputs
+        wave_lds_order();                                 // every lane of a frame has read its inputs (the frame's own sixteen lanes)
         if (sub) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {

@@ -488,7 +488,7 @@ def main():
         units = n if wl == "decim8" else n * L            # decimator: input samples; interpolator: output samples
         roof_bytes = 8.0 * n + 8.0 * (n * L // M)
         read_bytes = 8.0 * n
-        kernel_name = "fir_cf32_ols4096_decim_batched_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_kernel"
+        kernel_name = "fir_cf32_ols4096_decim_batched_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_batched_kernel"
 
         def step():
             f.process_dev(x, y)

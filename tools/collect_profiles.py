@@ -14,7 +14,7 @@ KERNELS = {
     "fft4096": ("fft_r16_kernel", [C + "fft_r16.hip", C + "fft4096.hpp"]),
     "direct255": ("fir_cf32_direct_kernel", [C + "fir_direct.hip"]),
     "decim8": ("fir_cf32_ols4096_decim_batched_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
-    "interp4": ("fir_cf32_ols4096_interp_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
+    "interp4": ("fir_cf32_ols4096_interp_batched_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
 }
 def hashes(files):
     return {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] for f in files}

@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--native-devices", default="",
                     help="native driver only: comma-separated device ordinals, one per shard (default 0..N-1).  Repeating an ordinal "
                          "puts several shards on one device over peer copies -- the one-GPU rehearsal; the line then says so")
+    ap.add_argument("--sustain", type=float, default=1.0,
+                    help="seconds of extra launches behind the timed region whose last half is reported as roofline.sustained (0: off)")
     ap.add_argument("--settle", type=int, default=PREWARM,
                     help="untimed setup passes before the W warm-up steps (clock settling after idle; reported as config.setup_passes)")
     return ap.parse_args()
@@ -557,6 +559,20 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = [ev0.elapsed_time(ev1) / args.steps]
+    # Behind the timed region, outside `value`: the same launches kept up for about a second, the LAST half of them timed.  The
+    # package power cap lets the clock sag over the first seconds of a run (profiles/r03/README.md: a 3 s loop reads 3-4 % below a
+    # 0.13 s one on the same box), so the line carries both numbers; single GPU only.
+    sustained = None
+    if world == 1 and args.sustain > 0:
+        n_s = max(200, int(args.sustain / max(kern_ms[0] * 1e-3, 1e-6)))
+        es0, es1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(n_s):
+            if k == n_s // 2:
+                es0.record()
+            step()
+        es1.record()
+        torch.cuda.synchronize()
+        sustained = (es0.elapsed_time(es1) / (n_s - n_s // 2), n_s)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -585,6 +601,12 @@ def main():
                                           "(north_star words its target on reads: a kernel that writes every sample back "
                                           "cannot put more than its read share of the pins into reads)"},
         }
+        if sustained is not None:
+            out["roofline"]["sustained"] = {"avg_launch_ms": round(sustained[0], 4),
+                                            "frac": round(roof_bytes / (sustained[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "launches": sustained[1],
+                                            "note": "the same launches kept up for ~%.1f s behind the timed region, the last half timed: "
+                                                    "the clock sags under the package power cap" % args.sustain}
         if world == 1 and not args.no_cpu:
             cpu_n = min(C, 16 * 1024 * 1024)          # bounded sample: 10-30 s of CPU work for the whole leg
             if wl in ("fir255", "direct255"):

@@ -228,15 +228,23 @@ def spawn_ranks(args):
     import socket
     import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for attempt in range(4):
+        # a port that is free NOW; another process may take it before the rendezvous binds it (eight test workers at once did):
+        # that failure is recognised and the launch repeated on another port
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+        if proc.returncode != 0 and "EADDRINUSE" in proc.stderr and attempt < 3:
+            print("bench.py: port %d was taken before the rendezvous could bind it, starting the ranks again" % port, file=sys.stderr)
+            continue
+        sys.stderr.write(proc.stderr)
+        break
     line = None
     for ln in proc.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:

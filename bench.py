@@ -224,9 +224,10 @@ def spawn_ranks(args):
 
     This parent never imports torch and never touches the GPU; the children are fresh interpreters
     started by torch.distributed.run.  Their stdout is captured so the one JSON line can be checked
-    (n_gpus must equal --gpus) before it is relayed; stderr passes through."""
+    (n_gpus must equal --gpus) before it is relayed; stderr passes through as it is written."""
     import socket
     import subprocess
+    import threading
 
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -239,14 +240,28 @@ def spawn_ranks(args):
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
-        if proc.returncode != 0 and "EADDRINUSE" in proc.stderr and attempt < 3:
+        # the ranks' stderr is passed on as it comes (a hung run must not be silent) and kept for the port check
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+        err_lines = []
+
+        def relay(pipe=proc.stderr, keep=err_lines):
+            for ln in pipe:
+                keep.append(ln)
+                sys.stderr.write(ln)
+                sys.stderr.flush()
+        t = threading.Thread(target=relay, daemon=True)
+        t.start()
+        stdout = proc.stdout.read()
+        proc.wait()
+        t.join()
+        err = "".join(err_lines)
+        taken = any(m in err for m in ("EADDRINUSE", "Address already in use", "errno: 98", "address already in use"))
+        if proc.returncode != 0 and taken and attempt < 3:
             print("bench.py: port %d was taken before the rendezvous could bind it, starting the ranks again" % port, file=sys.stderr)
             continue
-        sys.stderr.write(proc.stderr)
         break
     line = None
-    for ln in proc.stdout.splitlines():
+    for ln in stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
         else:

@@ -338,8 +338,11 @@ PCX_API int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elem
 /* one pass over every shard: the halo exchange and ONE launch per shard (pcx_fir_process_dev_gated); configurations without a
  * gated kernel run body, exchange, head as two launches */
 PCX_API int pcx_shard_step(pcx_shard *s);
-/* the nshards*shard_elems outputs in stream order (waits for the pass) */
+/* the nshards*shard_elems outputs in stream order (waits for the pass).  PCX_ERR_STATE when a shard's gated launch gave up
+ * waiting for its halo during the passes since the last gather / sync (the two-second bound of pcx_fir_process_dev_gated): the
+ * outputs are copied all the same, the seam's are wrong, and the condition is cleared by being reported. */
 PCX_API int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems);
+/* waits for everything queued on the shards' streams; reports (and clears) a gate timeout like pcx_shard_gather */
 PCX_API int pcx_shard_sync(pcx_shard *s);
 
 #ifdef __cplusplus

@@ -306,17 +306,23 @@ public:
     // than a shard's worth per device, run on the single-device handle: the totals of consume / produce are the reference's either way.
     void setDevices(const std::vector<size_t> &devices)
     {
-        if (_sh) { check(pcx_shard_destroy(_sh), "FIRFilter::setDevices()"); _sh = nullptr; }
+        // validate first: getDevices() reports the layout that is IN EFFECT, also after a call that threw
+        if (devices.size() >= 2 && !(_dtype == DType("complex_float32")))
+            throw InvalidArgumentException("FIRFilter::setDevices()", "a sharded stream is complex_float32");
+        pcx_shard *sh = nullptr;
+        if (devices.size() >= 2) {
+            std::vector<int> d(devices.begin(), devices.end());
+            std::vector<int> sorted(d);
+            std::sort(sorted.begin(), sorted.end());
+            const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+            check(pcx_shard_create((int)d.size(), d.data(), distinct ? PCX_SHARD_RCCL : PCX_SHARD_PEER_COPY, &sh), "FIRFilter::setDevices()");
+        }
+        if (_sh) { const int rc = pcx_shard_destroy(_sh); _sh = nullptr; if (rc != PCX_OK) { (void)pcx_shard_destroy(sh); check(rc, "FIRFilter::setDevices()"); } }
+        _sh = sh;
         _devices = devices;
         _shardC = 0;
-        if (devices.size() < 2) return;
-        if (!(_dtype == DType("complex_float32"))) throw InvalidArgumentException("FIRFilter::setDevices()", "a sharded stream is complex_float32");
-        std::vector<int> d(devices.begin(), devices.end());
-        std::vector<int> sorted(d);
-        std::sort(sorted.begin(), sorted.end());
-        const bool distinct = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
-        check(pcx_shard_create((int)d.size(), d.data(), distinct ? PCX_SHARD_RCCL : PCX_SHARD_PEER_COPY, &_sh), "FIRFilter::setDevices()");
-        this->pushTaps();
+        _shardShort = 0;
+        if (_sh) this->pushTaps();
     }
     std::vector<size_t> getDevices() const { return _devices; }
     size_t getShardPasses() const { return _shardPasses; }
@@ -382,12 +388,19 @@ public:
         }
         size_t consumed = 0, produced = 0;
         if (_sh && M == 1 && L == 1 && _eobSampsLeft == 0 && srcElems >= K) {
-            // the sharded pass: G shards of C samples each out of what the port holds; the first call fixes C (the port slabs are of
-            // one size: later calls bring the same amount, a shorter tail goes to the single-device handle below)
+            // the sharded pass: G shards of C samples each out of what the port holds.  C follows what the calls bring: it is laid out
+            // by the first call that brings a shard set worth the G launches and the exchange (kMinShard samples per device), laid
+            // out again when a call brings twice as much (a small first call must not pin tiny shards for good) or when two calls in
+            // a row bring less than one set (the port slabs shrank); a single shorter call -- the tail of a stream -- and anything
+            // below kMinShard per device go to the single-device handle below
             const size_t G = _devices.size();
             const size_t N = std::min(srcElems - (K - 1), outPort->elements());
-            if (_shardC == 0 && N / G >= K) {
-                _shardC = N / G;
+            const size_t want = N / G;
+            const bool worth = want >= std::max(K, kMinShard);
+            if (_shardC != 0 && N < G * _shardC) _shardShort++; else _shardShort = 0;
+            if (worth && (_shardC == 0 || want >= 2 * _shardC || _shardShort >= 2)) {
+                _shardC = want;
+                _shardShort = 0;
                 check(pcx_shard_configure(_sh, _shardC), "FIRFilter::work()");
             }
             if (_shardC != 0 && N >= G * _shardC) {
@@ -447,7 +460,8 @@ private:
     std::string _kernel = "AUTO";
     pcx_shard *_sh = nullptr;              // setDevices(): the stream over several devices
     std::vector<size_t> _devices;
-    size_t _shardC = 0, _shardPasses = 0;
+    size_t _shardC = 0, _shardPasses = 0, _shardShort = 0;
+    static constexpr size_t kMinShard = 32768;   // samples per device below which a sharded pass is not worth its G launches
     size_t _eobSampsLeft;
     DType _dtype;
     pcx_fir *_h;

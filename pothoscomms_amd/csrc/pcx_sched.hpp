@@ -107,7 +107,7 @@ struct Gate {
 };
 // The wait is BOUNDED: a signal that never comes (a caller's bug, a failed transfer) must not hang the device.  After kGateTimeout
 // the block goes ahead on whatever the halo slot holds and leaves kGateTimedOut in the word behind the gate word, where the host
-// finds it (pcx_shard_sync reports PCX_ERR_STATE).
+// finds it (pcx_shard_sync and pcx_shard_gather report PCX_ERR_STATE and clear it; stream.py check_gate()).
 constexpr unsigned long long kGateTimeoutTicks = 200000000ull;     // 2 s of s_memrealtime (100 MHz)
 constexpr unsigned kGateTimedOut = 0xDEADu;
 __device__ __forceinline__ void gate_wait(const Gate &g, int lane)

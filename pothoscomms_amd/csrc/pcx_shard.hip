@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "pcx_internal.hpp"
+#include "pcx_sched.hpp"
 
 namespace {
 
@@ -121,6 +122,7 @@ struct pcx_shard {
     std::vector<pcx_fir *> fir;
     std::vector<pcx_fmchain *> chain;             // chain mode: the fused Rotate -> FIR -> FreqDemod handle of each device
     std::vector<void *> gate;                     // per shard: the 32-bit gate word (device memory), holds the pass number
+    unsigned *gate_seen = nullptr;                // page-locked, two words per shard: what shard_check_gates last read of gate[g]
     bool chain_mode = false;
     double phase = 0.0;
     std::vector<double> taps;                     // as given to set_taps (chain mode re-applies them with the phase)
@@ -171,6 +173,7 @@ int pcx_shard_destroy(pcx_shard *s)
         for (ncclComm_t c : s->comm)
             if (c) (void)s->rccl->CommDestroy(c);
     shard_free_buffers(s);
+    if (s->gate_seen) (void)hipHostFree(s->gate_seen);
     for (int g = 0; g < s->G; g++) {
         (void)hipSetDevice(s->dev[g]);
         if (g < (int)s->fir.size() && s->fir[g]) (void)pcx_fir_destroy(s->fir[g]);
@@ -215,6 +218,12 @@ int pcx_shard_create(int nshards, const int *devices, int transport, pcx_shard *
     for (int g = 0; g < nshards; g++) { s->bounce_in.emplace_back(new PinBuf()); s->bounce_out.emplace_back(new PinBuf()); }
     DeviceGuard guard;
     auto fail = [&](int rc) { (void)pcx_shard_destroy(s); return rc; };
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->gate_seen), 2 * sizeof(unsigned) * nshards, hipHostMallocDefault) != hipSuccess) {
+        s->gate_seen = nullptr;
+        set_error("pcx_shard: page-locked allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(PCX_ERR_HIP);
+    }
+    std::memset(s->gate_seen, 0, 2 * sizeof(unsigned) * nshards);
     for (int g = 0; g < nshards; g++) {
         // (halo streams at the device's highest stream priority were tried -- the exchange ahead of the passes' own kernels -- and
         // made every pass SLOWER: 0.2242 -> 0.2411 ms with two shards on one device, 0.2674 -> 0.4570 with eight,
@@ -443,6 +452,39 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
     return PCX_OK;
 }
 
+// A gated launch that gave up waiting for its halo (pcx_sched.hpp gate_wait: two seconds) went ahead on whatever the halo slot held
+// and said so in the word behind its gate word.  Every call that hands results to the caller ends here: queue_gate_reads() puts the
+// read of each shard's two words BEHIND the pass on its compute stream, check_gate_reads() looks at them once those streams have
+// been waited for.  A reported timeout is cleared (the next pass starts clean) and the call fails: the seam outputs of that pass
+// are not the stream's.
+static int queue_gate_reads(pcx_shard *s)
+{
+    for (int g = 1; g < s->G && s->steps; g++) {
+        PCX_HIP(hipSetDevice(s->dev[g]));
+        PCX_HIP(hipMemcpyAsync(s->gate_seen + 2 * g, s->gate[g], 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s->st[g]));
+    }
+    return PCX_OK;
+}
+static int check_gate_reads(pcx_shard *s)
+{
+    int bad = -1;
+    unsigned word = 0;
+    for (int g = 1; g < s->G && s->steps; g++)
+        if (s->gate_seen[2 * g + 1] == kGateTimedOut) {
+            if (bad < 0) { bad = g; word = s->gate_seen[2 * g]; }
+            s->gate_seen[2 * g + 1] = 0;
+            PCX_HIP(hipSetDevice(s->dev[g]));
+            PCX_HIP(hipMemsetAsync(static_cast<unsigned *>(s->gate[g]) + 1, 0, sizeof(unsigned), s->st[g]));
+            PCX_HIP(hipStreamSynchronize(s->st[g]));
+        }
+    if (bad >= 0) {
+        set_error("pcx_shard: shard %d did not receive its halo within two seconds of a pass (gate word %u, pass %llu): "
+                  "the outputs at that seam were computed on a stale halo", bad, word, s->steps);
+        return PCX_ERR_STATE;
+    }
+    return PCX_OK;
+}
+
 int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
 {
     PCX_TRACE();
@@ -471,34 +513,26 @@ int pcx_shard_gather(pcx_shard *s, void *host_out, size_t elems)
         const void *src = s->chain_mode ? static_cast<const void *>(static_cast<const float *>(s->out[g]) + 1) : s->out[g];
         PCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->st[g]));
     }
+    PCX_TRY(queue_gate_reads(s));
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         PCX_HIP(hipStreamSynchronize(s->st[g]));
         if (!locked) std::memcpy(y + (size_t)g * bytes, s->bounce_out[g]->p, bytes);
     }
-    return PCX_OK;
+    return check_gate_reads(s);      // the outputs are copied either way; the caller learns that a seam is wrong
 }
 
 int pcx_shard_sync(pcx_shard *s)
 {
     PCX_CHECK_ARG(s, "null handle");
     DeviceGuard guard;
+    PCX_TRY(queue_gate_reads(s));
     for (int g = 0; g < s->G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
         PCX_HIP(hipStreamSynchronize(s->st[g]));
         PCX_HIP(hipStreamSynchronize(s->hst[g]));
     }
-    // a gated launch that gave up waiting for its halo (pcx_sched.hpp gate_wait: two seconds) says so in the word behind its gate
-    for (int g = 1; g < s->G && s->steps; g++) {
-        unsigned words[2] = {0, 0};
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_HIP(hipMemcpy(words, s->gate[g], sizeof words, hipMemcpyDeviceToHost));
-        if (words[1] == 0xDEADu) {
-            set_error("pcx_shard: shard %d did not receive its halo within two seconds of a pass (gate word %u, pass %llu)", g, words[0], s->steps);
-            return PCX_ERR_STATE;
-        }
-    }
-    return PCX_OK;
+    return check_gate_reads(s);
 }
 
 // FIR mode: outputs [first_out, first_out + n_out) of shard g, which read in[first_out : first_out + n_out + K - 1].
@@ -564,7 +598,9 @@ int pcx_shard_step(pcx_shard *s)
         s->steps++;
         return PCX_OK;
     }
-    const unsigned pass = (unsigned)(s->steps + 1);      // the value the gate words take in this pass (compared by signed distance)
+    // the value the gate words take in this pass (compared by signed distance).  Taken BEFORE anything is queued: a step that fails
+    // half-way has used its number up -- the next one must not find its gate already open
+    const unsigned pass = (unsigned)++s->steps;
     // 1. inputs of this pass are in place once everything queued on the compute streams so far has run (the caller's
     //    fill / scatter, and the previous pass's kernel, which READ the halo slot this pass overwrites)
     for (int g = 0; g < G; g++) {
@@ -590,9 +626,10 @@ int pcx_shard_step(pcx_shard *s)
             PCX_HIP(hipMemcpyPeerAsync(s->in_ptr(g), s->dev[g], s->in_ptr(g - 1) + s->C, s->dev[g - 1], hbytes, s->hst[g]));
         }
     }
+    const long drop = PCX_ENV_INT("PCX_SHARD_DROP_SIGNAL", 0);   // (diagnostic library only) the pass whose gate signals are left out: the timeout path's test
     for (int g = 0; g < G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
-        if (g > 0) PCX_TRY(pcx_gate_signal_dev(s->gate[g], pass, s->hst[g]));
+        if (g > 0 && !(drop > 0 && (long)pass == drop)) PCX_TRY(pcx_gate_signal_dev(s->gate[g], pass, s->hst[g]));
         // halo_ready(g): RCCL -- the send that reads shard g's tail and the receive into its halo slot are done;
         // peer copies -- the copy that reads shard g-1's tail and writes shard g's halo slot is done
         if (g > 0 || s->transport == PCX_SHARD_RCCL) PCX_HIP(hipEventRecord(s->halo_ready[g], s->hst[g]));
@@ -618,6 +655,5 @@ int pcx_shard_step(pcx_shard *s)
         PCX_HIP(hipSetDevice(s->dev[g]));
         PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[s->transport == PCX_SHARD_RCCL ? g : g + 1], 0));
     }
-    s->steps++;
     return PCX_OK;
 }

@@ -23,8 +23,40 @@ ran a body launch, waited, and ran a head launch: the second launch's start-up, 
 kernel boundary cost 5.6 % of a pass.)  Configurations without a gated kernel, and host-driven
 backends (the gloo rehearsal), keep the two launches.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+GATE_TIMED_OUT = 0xDEAD      # pcx_sched.hpp kGateTimedOut: what a gated launch leaves in gate[1] when its halo never came
+
+
+class GateTimeout(RuntimeError):
+    """A pass's gated launch gave up waiting for its halo (two seconds) and ran its first block on a stale halo slot."""
+
+
+def _check_gate(owner):
+    """Wait for the owner's pass, then read the word behind its gate word; raise (once) if a launch timed out."""
+    gate = getattr(owner, "_gate", None)
+    if gate is None:
+        return
+    if gate.is_cuda:
+        torch.cuda.current_stream(gate.device).synchronize()
+        owner._side.synchronize()
+    if int(gate[1].item()) == GATE_TIMED_OUT:
+        gate[1] = 0
+        raise GateTimeout("rank %d: the halo did not arrive within two seconds of pass %d (or an earlier one since the last check); "
+                          "the outputs at the front of the shard were computed on a stale halo" % (owner.ring.rank, owner._pass))
+
+
+def _two_launch_forced(arg):
+    """The RCCL path takes ONE gated launch per pass by default; two_launch=True (or PCX_STREAM_TWO_LAUNCH=1) forces the round-2
+    scheme -- body launch, wait for the halo, head launch -- so that the two can be compared, and the gated one bypassed, on a node
+    where it misbehaves (it rests on a peer's halo bytes being visible behind a system-scope acquire and on RCCL's receive kernel
+    finding room beside a persistent launch: rehearsed on one GPU only so far)."""
+    if arg is not None:
+        return bool(arg)
+    return os.environ.get("PCX_STREAM_TWO_LAUNCH", "0") not in ("", "0")
 
 
 class HaloRing:
@@ -74,8 +106,9 @@ class ShardedFir:
     HEAD = 4096
     gate_host_driven = False     # tests set it: the gated launch with a host-driven exchange (gloo)
 
-    def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None, slots=None):
+    def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None, slots=None, two_launch=None):
         from . import device as dv   # the HIP path; raises if libpcx_hip.so is missing
+        self.two_launch = _two_launch_forced(two_launch)
         self.fir = dv.FirFilter("complex_float32", taps_type)
         self.fir.set_taps(taps)
         if slots is not None:        # several ranks on ONE device (a rehearsal): each takes its share of the resident slots
@@ -91,29 +124,45 @@ class ShardedFir:
         # (measured on MI355X: 0.2245 -> 0.2187 ms per 64 Mi samples against a line-aligned halo).
         lead = (-(self.K - 1)) % 16
         self._alloc = torch.zeros((lead + self.K - 1 + self.C, 2), dtype=torch.float32, device=device)
-        self.buf = self._alloc[lead:]
+        self._buf = self._alloc[lead:]
         self.out = torch.empty((self.C, 2), dtype=torch.float32, device=device)
         # the two-launch fallback's split: the body (outputs head .. C-1) must not read the halo slot buf[0 : K-1]
         self.head = min(self.C, max(self.HEAD, -(-(self.K - 1) // self.HEAD) * self.HEAD))
+
+    # WRITING THE INPUT.  `buf` ([halo | C samples]) and `shard` (the C samples) are handed out as views, and taking either one fences
+    # the input (fence_input): whoever asks is about to write.  Do NOT keep a view across step(): a view taken before a pass and
+    # written after it is not ordered behind that pass's send of the shard's tail, which runs on a side stream (the C driver orders
+    # every later writer itself, pcx_shard_step part 4; this one leaves the 13 us cross-stream wait out of the pass and puts it
+    # here, where a writer pays it).  Take the view again for every refill.
+    @property
+    def buf(self):
+        """[halo (K-1) | C samples], a view; fences the input like `shard`."""
+        self.fence_input()
+        return self._buf
 
     @property
     def shard(self):
         """The C samples this rank owns (a view behind the halo).  Taking the view fences the input (fence_input): whoever asks for it is
         about to write samples."""
         self.fence_input()
-        return self.buf[self.K - 1:]
+        return self._buf[self.K - 1:]
 
     def fence_input(self):
         """Make the current stream wait until the last pass's exchange has READ the shard's tail (the send to the right neighbour runs on
         a side stream).  Only a WRITER of the shard needs that -- the next pass only reads it -- so step() does not pay for the
-        cross-stream wait (13 us of a 190 us pass, tools/host_step_probe.py); call this, or take `shard` again, before anything queued on
-        the current stream overwrites samples."""
-        if getattr(self, "_side", None) is not None and self.buf.is_cuda:
-            torch.cuda.current_stream(self.buf.device).wait_stream(self._side)
+        cross-stream wait (13 us of a 190 us pass, tools/host_step_probe.py); call this, or take `shard` / `buf` again, before anything
+        queued on the current stream overwrites samples."""
+        if getattr(self, "_side", None) is not None and self._buf.is_cuda:
+            torch.cuda.current_stream(self._buf.device).wait_stream(self._side)
+
+    def check_gate(self):
+        """Synchronise, then raise GateTimeout if a pass since the last check ran its first block without its halo (the gated launch's
+        wait is bounded, pcx.h): call it wherever results leave the device.  bench.py and the tests do, after the timed region."""
+        _check_gate(self)
 
     def _run(self, first_out, n_out):
         # outputs [first_out, first_out + n_out) read buf[first_out : first_out + n_out + K - 1]
-        c, p = self.fir.process_dev(self.buf[first_out:], self.out[first_out:], n_out + self.K - 1, n_out)
+        c, p = self.fir.process_dev(self._buf[first_out:], self.out[first_out:], n_out + self.K - 1, n_out)
         assert c == n_out and p == n_out, (c, p, n_out)
 
     def _gate_setup(self):
@@ -126,8 +175,8 @@ class ShardedFir:
             if host_driven:
                 self._gate = torch.zeros((64,), dtype=torch.int32).pin_memory()
             else:
-                self._gate = torch.zeros((64,), dtype=torch.int32, device=self.buf.device)
-            self._side = torch.cuda.Stream(device=self.buf.device)
+                self._gate = torch.zeros((64,), dtype=torch.int32, device=self._buf.device)
+            self._side = torch.cuda.Stream(device=self._buf.device)
             self._pass = 0
             self._sent = None
 
@@ -136,12 +185,13 @@ class ShardedFir:
         if self.ring.world == 1:
             self._run(0, self.C)
             return self.out
-        if self.buf.is_cuda and dist.is_initialized() and (dist.get_backend(self.ring.group) == "nccl" or self.gate_host_driven):
+        gated_ok = dist.is_initialized() and ((dist.get_backend(self.ring.group) == "nccl" and not self.two_launch) or self.gate_host_driven)
+        if self._buf.is_cuda and gated_ok:
             return self._step_gated()
         # host tensors (the CPU tests of the exchange logic) and host-driven backends on device tensors (the gloo rehearsal of the
         # multi-rank control flow on one GPU: two PROCESSES time-share the device and the exchange is a host round trip, so the
         # one-launch scheme has nothing to hide behind -- measured 0.25-0.27 ms per step against 0.22 for this one): body, wait, head
-        reqs = self.ring.start(self.buf)
+        reqs = self.ring.start(self._buf)
         if self.C > self.head:
             self._run(self.head, self.C - self.head)      # does not touch the halo
         self.ring.finish(reqs)
@@ -156,23 +206,23 @@ class ShardedFir:
         self._gate_setup()
         self._pass += 1
         nccl = dist.get_backend(self.ring.group) == "nccl"
-        cur = torch.cuda.current_stream(self.buf.device)
+        cur = torch.cuda.current_stream(self._buf.device)
         if nccl:
             self._side.wait_stream(cur)                   # the shard's samples are in place; the previous pass has read its halo
             with torch.cuda.stream(self._side):
                 # (posting the exchange from the CURRENT stream instead -- RCCL's stream then waits for it directly, one cross-stream hop
                 # in front of the exchange instead of two -- measured slower, 212 against 205 us per pass, tools/host_step_probe.py)
-                self.ring.finish(self.ring.start(self.buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
+                self.ring.finish(self.ring.start(self._buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
                 if self.ring.rank > 0:
                     dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
             reqs = []
         else:
-            reqs = self.ring.start(self.buf)              # (drains the current stream first: HaloRing.start)
+            reqs = self.ring.start(self._buf)              # (drains the current stream first: HaloRing.start)
         gated = True
         if self.ring.rank == 0:
             self._run(0, self.C)
         else:
-            c, p, gated = self.fir.process_dev_gated(self.buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C)
+            c, p, gated = self.fir.process_dev_gated(self._buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C)
             if gated:
                 assert c == self.C and p == self.C, (c, p)
             elif self.C > self.head:
@@ -200,8 +250,9 @@ class ShardedFmChain:
     """
     HEAD = 4096
 
-    def __init__(self, taps, phase, shard_len, device, complex_taps=False, algo=None, group=None):
+    def __init__(self, taps, phase, shard_len, device, complex_taps=False, algo=None, group=None, two_launch=None):
         from . import device as dv   # the HIP path; raises if libpcx_hip.so is missing
+        self.two_launch = _two_launch_forced(two_launch)
         self._chains = []
         for _ in range(2):           # head and body calls each start from the reset state
             ch = dv.FmChain()
@@ -215,19 +266,29 @@ class ShardedFmChain:
         self.ring = HaloRing(self.K, group)
         lead = (-(self.K - 1)) % 16      # the sample behind the FIR history of the head call on a 128-byte line
         self._alloc = torch.zeros((lead + self.K + self.C, 2), dtype=torch.float32, device=device)
-        self.buf = self._alloc[lead:]
+        self._buf = self._alloc[lead:]
         self._out = torch.empty((self.C + 1,), dtype=torch.float32, device=device)
         self.head = min(self.HEAD, self.C)
+
+    @property
+    def buf(self):
+        """[K halo | C samples], a view; fences the input.  Views must not be kept across step() (ShardedFir)."""
+        self.fence_input()
+        return self._buf
 
     @property
     def shard(self):
         """The C samples this rank owns; taking the view fences the input (ShardedFir.fence_input)."""
         self.fence_input()
-        return self.buf[self.K:]
+        return self._buf[self.K:]
 
     def fence_input(self):
-        if getattr(self, "_side", None) is not None and self.buf.is_cuda:
-            torch.cuda.current_stream(self.buf.device).wait_stream(self._side)
+        if getattr(self, "_side", None) is not None and self._buf.is_cuda:
+            torch.cuda.current_stream(self._buf.device).wait_stream(self._side)
+
+    def check_gate(self):
+        """ShardedFir.check_gate"""
+        _check_gate(self)
 
     @property
     def out(self):
@@ -236,14 +297,14 @@ class ShardedFmChain:
 
     def _run(self, ch, first_in, n_out, out_at):
         ch.reset()
-        c, p = ch.process_dev(self.buf[first_in:], self._out[out_at:], n_out + self.K - 1, n_out)
+        c, p = ch.process_dev(self._buf[first_in:], self._out[out_at:], n_out + self.K - 1, n_out)
         assert c == n_out and p == n_out, (c, p, n_out)
 
     def step(self):
         first = self.ring.rank == 0
-        if self.ring.world > 1 and self.buf.is_cuda and dist.is_initialized() and dist.get_backend(self.ring.group) == "nccl":
+        if self.ring.world > 1 and self._buf.is_cuda and dist.is_initialized() and dist.get_backend(self.ring.group) == "nccl" and not self.two_launch:
             return self._step_gated()
-        reqs = self.ring.start(self.buf)
+        reqs = self.ring.start(self._buf)
         if self.C > self.head:
             # body: FIR outputs head-1 .. C-1; the first one only seeds the demodulator and lands on
             # _out[head], which the head call overwrites
@@ -259,14 +320,14 @@ class ShardedFmChain:
         """RCCL: the exchange and the gate signal on a side stream, ONE launch over the shard on the current stream (ShardedFir)."""
         from . import device as dv
         if getattr(self, "_gate", None) is None:
-            self._gate = torch.zeros((64,), dtype=torch.int32, device=self.buf.device)
-            self._side = torch.cuda.Stream(device=self.buf.device)
+            self._gate = torch.zeros((64,), dtype=torch.int32, device=self._buf.device)
+            self._side = torch.cuda.Stream(device=self._buf.device)
             self._pass = 0
         self._pass += 1
-        cur = torch.cuda.current_stream(self.buf.device)
+        cur = torch.cuda.current_stream(self._buf.device)
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
-            self.ring.finish(self.ring.start(self.buf))
+            self.ring.finish(self.ring.start(self._buf))
             if self.ring.rank > 0:
                 dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
         ch = self._chains[0]
@@ -274,7 +335,7 @@ class ShardedFmChain:
             self._run(ch, 1, self.C, 1)                             # stream start: reset state, no extra output
         else:
             ch.reset()
-            c, p, gated = ch.process_dev_gated(self.buf, self._out, self._gate, self._pass, self.C + 1 + self.K - 1, self.C + 1)
+            c, p, gated = ch.process_dev_gated(self._buf, self._out, self._gate, self._pass, self.C + 1 + self.K - 1, self.C + 1)
             if not gated:                                           # long filters, short shards: the halo first, then the shard
                 cur.wait_stream(self._side)
                 self._run(ch, 0, self.C + 1, 0)

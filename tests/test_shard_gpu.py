@@ -438,3 +438,53 @@ def test_a_gate_that_is_never_signalled_times_out_instead_of_hanging():
     dt = time.perf_counter() - t0
     assert 1.5 < dt < 10.0, dt
     assert int(gate[1].item()) == 0xDEAD and int(gate[0].item()) == 0
+
+
+_DROP_SCRIPT = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from pothoscomms_amd import _lib, device, taps as tp
+L = _lib.load()
+h = tp.c1_taps()
+K, Cs, G = len(h), 2080 * 3840, 2
+ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+ns.set_taps(h); ns.configure(Cs)
+for g in range(G):
+    i, o, s, d = ns.buffers(g)
+    _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (K - 1 + Cs), 4, 2 * g * Cs, C.c_void_p(s)))
+out = np.empty((G * Cs, 2), np.float32)
+res = []
+for p in (1, 2, 3):
+    ns.step()
+    try:
+        ns.gather(out) if p != 3 else ns.sync()
+        res.append("ok")
+    except _lib.PcxError as e:
+        res.append("state" if e.status == _lib.ERR_STATE and "halo" in str(e) else "other: %%s" %% e)
+    try:
+        ns.sync()
+        res.append("ok")
+    except _lib.PcxError as e:
+        res.append("again")
+print("RESULT " + ",".join(res))
+"""
+
+
+def test_a_dropped_gate_signal_is_reported_by_gather_and_cleared():
+    """a gated launch that gives up waiting for its halo (two seconds) ran its first block on stale data and only
+    left 0xDEAD behind the gate word -- which pcx_shard_gather, the call FIRFilter::work() makes, never read.  The diagnostic library
+    leaves out the signals of pass 2 (PCX_SHARD_DROP_SIGNAL): gather of pass 2 must fail with PCX_ERR_STATE, the condition must be
+    cleared by having been reported (the sync behind it is clean), and pass 3 -- whose gate value is one further -- must be clean."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "pothoscomms_amd", "libpcx_hip_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("diagnostic library not built (make -C pothoscomms_amd/csrc diag)")
+    env = dict(os.environ, PCX_HIP_LIBRARY=diag, PCX_SHARD_DROP_SIGNAL="2")
+    r = subprocess.run([sys.executable, "-c", _DROP_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    assert line == "RESULT ok,ok,state,ok,ok,ok", line

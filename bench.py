@@ -600,6 +600,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # a pass whose gated launch ran without its halo (the bounded wait of pcx_fir_process_dev_gated) is not a measurement
+        for owner in (locals().get("sf"), locals().get("sc")):
+            if owner is not None:
+                owner.check_gate()
 
     if rank == 0:
         value = world * units * args.steps / elapsed / 1e6

@@ -22,6 +22,14 @@ Two kinds of vectors, all plain data (inputs + expected outputs):
     fxpt_atan2.cpp, FxptHelpers.hpp built from /root/reference where they lie) on seeded
     random inputs -- these pin the oracle bit-for-bit on the GPU box, where the reference
     sources do not exist.
+ 3. /comms/freq_demod: demod/FreqDemod.cpp itself needs <Pothos/Framework.hpp> and cannot be compiled here, but its loop
+    (:60-67) is nothing but three operations the compiled reference DOES export --
+        diff = in[i] * _prev      std::complex<T> operator*            (ref_std_arith, MUL, the toolchain's <complex>/libgcc)
+        angle = getAngle(diff)    functions/FxptHelpers.hpp:14-29      (ref_angle_*, compiled from the reference header)
+        _prev = std::conj(in[i])  sign flip of the imaginary part
+    -- with _prev = 0 at activate() (:44-47).  `freqdemod_out_*` = ref_angle(ref_std_arith(MUL, x[i], conj(x[i-1]))), x[-1] = 0:
+    the compiled pieces composed, no restatement of either in between.  The integer inputs cover the wrap of the product in
+    complex<intN> followed by getAngle's truncation to int16.
 """
 import os
 import sys
@@ -167,6 +175,32 @@ def main():
             for opname, op in (("ADD", o.ADD), ("SUB", o.SUB), ("MUL", o.MUL)):
                 g["arith_rand_%s_%d_%s" % (name, cplx, opname)] = o.ref_arith(op, a, b, bool(cplx))
             g["arith_rand_%s_%d_DIV" % (name, cplx)] = o.ref_arith(o.DIV, ad, bd, bool(cplx))
+
+    # ---- 4. /comms/freq_demod = compiled std::complex multiply + compiled getAngle (docstring, 3.) -----------------
+    rng4 = np.random.default_rng(20240404)
+    for name, dt in ALL_TYPES.items():
+        if name.startswith("int"):
+            info = np.iinfo(dt)
+            x = rng4.integers(info.min, info.max + 1, (3072, 2), dtype=dt)           # products wrap in complex<intN>
+            x[:512] = rng4.integers(-90, 91, (512, 2))                                 # products that do not
+            x[512:520] = [[info.min, info.min], [info.max, info.max], [info.min, info.max], [0, info.min], [info.min, 0], [0, 0], [1, 0], [0, 0]]
+            amp = min(info.max, 20000)
+            ph = np.cumsum(2 * np.pi * (0.02 + 0.01 * np.sin(2 * np.pi * np.arange(1024) / 100)))
+            x[1024:2048] = np.trunc(np.stack([amp * np.cos(ph), amp * np.sin(ph)], 1)).astype(np.int64).astype(dt)   # an FM signal
+        else:
+            # SURVEY 8d's C4 signal (FM, small noise), then random samples over forty orders of magnitude, then zeros, signed zero and axis points
+            n = np.arange(2048)
+            ph = np.cumsum(2 * np.pi * (0.02 + 0.01 * np.sin(2 * np.pi * n / 1000)))
+            fm = np.stack([np.cos(ph), np.sin(ph)], 1) + 1e-3 * rng4.uniform(-1, 1, (2048, 2))
+            wide = rng4.normal(size=(1016, 2)) * np.exp(rng4.uniform(-20, 20, (1016, 1)))
+            corner = np.array([[0, 0], [0, 0], [1, 0], [0, -1], [-1, 0], [-0.0, 0.0], [1e-30, -1e-30], [3, 4]], np.float64)
+            x = np.concatenate([fm, wide, corner]).astype(dt)
+        prev = np.concatenate([np.zeros((1, 2), dt), x[:-1]])                          # _prev = 0 at activate(), FreqDemod.cpp:44-47
+        with np.errstate(over="ignore"):
+            prev[:, 1] = (-prev[:, 1].astype(np.int64)).astype(dt) if name.startswith("int") else -prev[:, 1]   # std::conj; -MIN wraps to MIN
+        diff = o.ref_arith(o.MUL, np.ascontiguousarray(x), np.ascontiguousarray(prev), True)
+        g["freqdemod_in_" + name] = x
+        g["freqdemod_out_" + name] = o.ref_angle(diff)
 
     np.savez_compressed(OUT, **g)
     print("wrote %s: %d arrays, %d bytes" % (OUT, len(g), os.path.getsize(OUT)))

@@ -98,6 +98,26 @@ def test_reference_test_points_angle_abs(dev, name):
         assert np.array_equal(gc, want)         # getAbs compiled from the reference: float32 and the integers bit for bit
 
 
+@pytest.mark.parametrize("name", TYPES)
+def test_freqdemod_against_the_compiled_reference_pieces(dev, name):
+    """demod/FreqDemod.cpp:60-67 as the compiled std::complex<T> operator* and the compiled getAngle (FxptHelpers.hpp:14-29) composed
+    (tests/golden/make_golden.py section 4): the HIP kernel against that fixture directly -- integers bit for bit (the product wraps
+    in complex<intN>, getAngle truncates it to int16), floats within 1e-5 of pi; in one call, and with _prev carried over three"""
+    x, want = GOLD["freqdemod_in_" + name], GOLD["freqdemod_out_" + name]
+
+    def close(got, ref):
+        if name.startswith("int"):
+            return np.array_equal(got, ref)
+        return ang_err(got, ref) <= TOL
+    assert close(dev.FreqDemod("complex_" + name).process(x), want)
+    blk = dev.FreqDemod("complex_" + name)
+    parts = np.concatenate([blk.process(x[:1]), blk.process(x[1:777]), blk.process(x[777:])])
+    assert close(parts, want)
+    assert parts[0] == 0                      # the first sample meets _prev = 0 (FreqDemod.cpp:44-47)
+    blk.reset()
+    assert close(blk.process(x[:100]), want[:100])
+
+
 # ---- Rotate / Scale / Conjugate: the DEVICE against the reference tests' own known answers, with their own tolerances ----
 def _close(got, exp, name):
     """POTHOS_TEST_CLOSE(out, expected, 1); the int8 expectation is std::complex<int8>(double), whose cast wraps"""

@@ -311,6 +311,21 @@ def test_freqdemod_state_carries_and_resets(oracle):
     assert np.array_equal(blk.work(x[:10]), whole[:10])
 
 
+@pytest.mark.parametrize("name", list(TYPES))
+def test_freqdemod_against_the_compiled_reference_pieces(oracle, name):
+    """demod/FreqDemod.cpp:60-67 = std::complex<T> operator* + getAngle (FxptHelpers.hpp:14-29) + std::conj, _prev = 0 at activate():
+    the fixture composes the COMPILED pieces (tests/golden/make_golden.py section 4); the oracle's loop must reproduce it bit for bit,
+    in one call and with the state carried over calls -- the first sample against _prev = 0, the integer products wrapping in
+    complex<intN> before getAngle truncates them to int16."""
+    x, want = GOLD["freqdemod_in_" + name], GOLD["freqdemod_out_" + name]
+    sc = oracle.scalar_code(x)
+    assert np.array_equal(oracle.FreqDemod(sc).work(x), want)
+    blk = oracle.FreqDemod(sc)
+    parts = np.concatenate([blk.work(x[:1]), blk.work(x[1:777]), blk.work(x[777:])])
+    assert np.array_equal(parts, want)
+    assert want[0] == 0                       # anything times _prev = 0 has angle 0 (getAngle(0) = 0 for every type)
+
+
 def test_fft_work_is_one_frame_per_call(oracle):
     """FFT.cpp:61-72: consume/produce exactly numBins whatever is queued."""
     import ctypes as C

@@ -164,3 +164,33 @@ def test_bench_parent_fails_loudly_when_its_ranks_fail():
         pytest.skip("a GPU is present: the ranks would run")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_check_gate_raises_once_on_a_timed_out_gate():
+    """stream.py check_gate: the word behind the gate word says a gated launch gave up waiting; reported once, then cleared"""
+    import types
+
+    import torch
+
+    from pothoscomms_amd import stream
+    owner = types.SimpleNamespace(_gate=torch.zeros((64,), dtype=torch.int32), _pass=7, ring=types.SimpleNamespace(rank=3), _side=None)
+    stream._check_gate(owner)                       # clean
+    owner._gate[1] = stream.GATE_TIMED_OUT
+    with pytest.raises(stream.GateTimeout, match="rank 3.*pass 7"):
+        stream._check_gate(owner)
+    stream._check_gate(owner)                       # cleared by having been reported
+    stream._check_gate(types.SimpleNamespace())     # no gate yet: nothing to check
+
+
+def test_two_launch_switch():
+    from pothoscomms_amd import stream
+    assert stream._two_launch_forced(True) and not stream._two_launch_forced(False)
+    old = os.environ.pop("PCX_STREAM_TWO_LAUNCH", None)
+    try:
+        assert not stream._two_launch_forced(None)
+        os.environ["PCX_STREAM_TWO_LAUNCH"] = "1"
+        assert stream._two_launch_forced(None)
+    finally:
+        os.environ.pop("PCX_STREAM_TWO_LAUNCH", None)
+        if old is not None:
+            os.environ["PCX_STREAM_TWO_LAUNCH"] = old

@@ -60,6 +60,9 @@ def parse():
                          "puts several shards on one device over peer copies -- the one-GPU rehearsal; the line then says so")
     ap.add_argument("--sustain", type=float, default=1.0,
                     help="seconds of extra launches behind the timed region whose last half is reported as roofline.sustained (0: off)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default workload only: skip the `secondary` object (configs[2] 4096-pt FFT and configs[4] fused chain, ~1 s of GPU each)")
+    ap.add_argument("--no-cold", action="store_true", help="skip roofline.cold (three bursts of 20 launches behind 5 ms of idle)")
     ap.add_argument("--settle", type=int, default=PREWARM,
                     help="untimed setup passes before the W warm-up steps (clock settling after idle; reported as config.setup_passes)")
     return ap.parse_args()
@@ -286,8 +289,9 @@ def source_hashes(files):
     return out
 
 
-def load_traffic(workload, kernel_name):
-    """PMC-measured HBM bytes per launch for this workload -- only when the committed measurement was taken on THIS kernel:
+def load_profile(workload, kernel_name):
+    """The committed PMC measurement of this workload's kernel (profiles/traffic.json: HBM bytes per launch, VALU instruction counts)
+    -- only when it was taken on THIS kernel:
     the entry of profiles/traffic.json names the kernel symbol and carries the hashes of the source files the kernel is
     built from (tools/collect_profiles.py stamps them when it files the PMC summary); any mismatch, and the line says null."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -303,7 +307,7 @@ def load_traffic(workload, kernel_name):
             return None
         if source_hashes(sorted(e["sources"])) != e["sources"]:
             return None
-        return e.get("hbm_bytes_per_launch")
+        return e
     except (OSError, ValueError, KeyError):
         return None
 
@@ -381,6 +385,329 @@ def run_native(args):
     ns.close()
 
 
+# ---- measured ceilings next to the datasheet ones ---------------------------------------------------------------------------------
+FP32_FMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak with packed v_pk_fma_f32 (256 CUs x 4 SIMDs x 16 lanes x 2 x 2 flop x 2.4 GHz)
+N_SIMDS = 1024                 # 256 CUs x 4
+# A wave64 VALU instruction holds its SIMD (16 lanes) for four cycles (transcendentals and f64 longer: the share below is a floor).
+VALU_CYCLES_PER_INST = 4
+
+
+def measured_fma_rate():
+    """the packed-FMA rate the committed microbenchmark reached on this part (profiles/*/ubench_roofs.txt, TFLOP/s), or None"""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "ubench_roofs.txt"))):
+        for m in re.finditer(r"pk_fma[^\n]*?([0-9.]+)\s*TFLOP", open(f).read()):
+            best = (float(m.group(1)), os.path.relpath(f, ROOT))
+    return best
+
+
+class Workload:
+    """One bench workload: device buffers, the step closure and what the roofline of its dominant kernel is priced on."""
+    step = None
+    units = 0                  # samples per step and GPU (the metric's unit)
+    roof_bytes = 0.0           # algorithmic HBM bytes per launch (SURVEY 8d)
+    read_bytes = 0.0
+    kernel_name = ""
+    metric = ""
+    desc = None
+    dtype = "f32"
+    bound = "hbm"
+    flops_per_unit = None      # set where another roof than HBM binds (direct255: 8 K flop per sample)
+    limiter = None             # what the profile says holds the kernel below the HBM roof, when it is not the memory system
+    blocks = None              # overlap-save blocks per launch (for valu.per_wave_block)
+    owner = None               # the ShardedFir / ShardedFmChain, when the stream is sharded over ranks
+
+
+def build_workload(wl, C, dev, rank, world, args):
+    import torch
+
+    from pothoscomms_amd import _lib, device, taps as tp
+    from pothoscomms_amd.stream import ShardedFir
+    W = Workload()
+    W.name = wl
+    if wl in ("fir255", "direct255"):
+        h = tp.c1_taps()
+        algo = _lib.FIR_OLS_FFT if wl == "fir255" else _lib.FIR_DIRECT
+        sf = ShardedFir(h, C, dev, "COMPLEX", algo)
+        K = sf.K
+        # the node-wide stream starts K-1 samples before shard 0 (rank 0's history); every rank
+        # fills [its halo | its shard] from the same counter-hash stream, then the timed steps
+        # overwrite the halo through RCCL
+        device.fill_uniform_f32_dev(sf.buf, seed=2, offset=2 * rank * C)
+        W.owner = sf
+        W.units = C
+        W.roof_bytes = 16.0 * C
+        W.read_bytes = 8.0 * C
+        W.kernel_name = "fir_cf32_ols4096_kernel" if wl == "fir255" else "fir_cf32_direct_kernel"
+        W.step = sf.step
+        W.desc = {"workload": "255-tap complex_float32 FIR (/comms/fir_filter, COMPLEX taps, M=L=1), %d-sample shard per GPU, "
+                              "%s" % (C, "frequency-domain overlap-save (4096-pt radix-16 passes)" if wl == "fir255" else "LDS-tiled direct form"),
+                  "taps": 255, "shard_samples": C, "halo_samples": K - 1,
+                  "parallelism": "overlap-save shards x%d, RCCL send/recv halo" % world if world > 1 else "single GPU"}
+        W.metric = "Msamples/s complex_float32 255-tap FIR"
+        if wl == "direct255":
+            # SURVEY 8d: the time-domain form is NOT HBM-bound -- 8 K flop per sample against 16 B (127 flop/B, machine balance 19.7)
+            W.bound = "fp32-fma"
+            W.flops_per_unit = 8.0 * K
+        else:
+            W.blocks = -(-C // (4096 - (K - 1 + 15) // 16 * 16))
+    elif wl == "fft4096":
+        nframes = 65536
+        x = torch.empty((nframes * 4096, 2), dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        device.fill_uniform_f32_dev(x, seed=3, offset=2 * rank * nframes * 4096)
+        fft = device.Fft("complex_float32", 4096, False)
+        W.units = nframes * 4096
+        W.roof_bytes = 16.0 * W.units
+        W.read_bytes = 8.0 * W.units
+        W.kernel_name = "fft_r16_kernel<12>"
+        W.step = lambda: fft.transform_dev(x, y, nframes)
+        W.desc = {"workload": "4096-pt complex_float32 FFT (/comms/fft), 65536 frames per GPU", "frames": nframes}
+        W.metric = "Msamples/s complex_float32 4096-pt FFT"
+    elif wl == "fmchain":
+        n = C
+        K = len(tp.c4_taps())
+        if world > 1:
+            # the stream sharded over the ranks: K-sample halo from the left neighbour (stream.ShardedFmChain)
+            from pothoscomms_amd.stream import ShardedFmChain
+            sc = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
+            device.fill_uniform_f32_dev(sc.buf, seed=5, offset=2 * rank * n)
+            W.owner = sc
+            W.step = sc.step
+        else:
+            ch = device.FmChain()
+            ch.set_phase(tp.C4_PHASE)
+            ch.set_taps(tp.c4_taps(), False)
+            # [lead | 126-sample history | n samples] with the samples (not the history) on a 128-byte line,
+            # the same placement ShardedFir uses
+            xa = torch.empty((2 + n + 126, 2), dtype=torch.float32, device=dev)
+            x = xa[2:]
+            y = torch.empty((n,), dtype=torch.float32, device=dev)
+            device.fill_uniform_f32_dev(x, seed=5, offset=0)
+            W.step = lambda: ch.process_dev(x, y, n + 126, n)
+        W.units = n
+        W.roof_bytes = 12.0 * n
+        W.read_bytes = 8.0 * n
+        W.kernel_name = "fmchain_cf32_ols4096_kernel"
+        W.desc = {"workload": "fused Rotate->FIR(127 real taps)->FreqDemod in one frequency-domain kernel, complex_float32 -> float32, %d samples" % n}
+        if world > 1:
+            W.desc["parallelism"] = "overlap-save shards x%d, RCCL send/recv halo of 127 samples" % world
+        W.metric = "Msamples/s fused FM-demod chain"
+        W.limiter = "valu-issue"
+        W.blocks = -(-n // (4096 - (K + 31) // 32 * 32))
+    elif wl in ("decim8", "interp4"):
+        # resampling complex_float32 FIR, 255 taps (per polyphase row when interpolating); independent replicas per rank
+        n = C if wl == "decim8" else C // 4
+        M, L = (8, 1) if wl == "decim8" else (1, 4)
+        h = tp.complex_bandpass(255 * L, 0.05 / max(L, M), 0.05 / max(L, M)) * L
+        f = device.FirFilter("complex_float32", "COMPLEX")
+        f.set_taps(h); f.set_decimation(M); f.set_interpolation(L)
+        K = f.K
+        lead = (-(K - 1)) % 16
+        xa = torch.empty((lead + n + K - 1, 2), dtype=torch.float32, device=dev)
+        x = xa[lead:]
+        y = torch.empty((n * L // M + 8, 2), dtype=torch.float32, device=dev)
+        device.fill_uniform_f32_dev(x, seed=7, offset=0)
+        W.units = n if wl == "decim8" else n * L            # decimator: input samples; interpolator: output samples
+        W.roof_bytes = 8.0 * n + 8.0 * (n * L // M)
+        W.read_bytes = 8.0 * n
+        W.kernel_name = "fir_cf32_ols4096_decim_batched_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_batched_kernel"
+        W.step = lambda: f.process_dev(x, y)
+        W.desc = {"workload": "255-tap complex_float32 FIR, %s, %d input samples per GPU" %
+                              ("decimation 8 folded into the spectrum (input rate)" if wl == "decim8"
+                               else "interpolation 4 from the replicated spectrum, 255 taps per phase (output rate)", n),
+                  "decimation": M, "interpolation": L}
+        W.metric = "Msamples/s complex_float32 %s FIR" % ("decimating (in)" if wl == "decim8" else "interpolating (out)")
+        W.limiter = "valu-issue"
+    elif wl == "fir255_i16":
+        # complex_int16 255-tap FIR: bit-exact on the double-precision overlap-save pipeline
+        n = C
+        h = tp.c1_taps() * 0.9
+        f = device.FirFilter("complex_int16", "COMPLEX")
+        f.set_taps(h)
+        K = f.K
+        x = torch.randint(-20000, 20000, (n + K - 1, 2), device=dev).to(torch.int16)
+        y = torch.empty((n, 2), dtype=torch.int16, device=dev)
+        W.units = n
+        W.roof_bytes = 8.0 * n
+        W.read_bytes = 4.0 * n
+        W.kernel_name = "fir_cf64_ols_kernel"
+        W.step = lambda: f.process_dev(x, y)
+        W.desc = {"workload": "255-tap complex_int16 FIR (bit-exact, double-precision overlap-save), %d samples per GPU" % n, "taps": 255}
+        W.metric = "Msamples/s complex_int16 255-tap FIR"
+        W.dtype = "f64"
+        W.limiter = "valu-issue (f64 pipeline)"
+    else:
+        n = C
+        x = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        device.fill_uniform_f32_dev(x, seed=6, offset=0)
+        W.units = n
+        W.roof_bytes = 16.0 * n
+        W.read_bytes = 8.0 * n
+        W.kernel_name = "map_kernel<rotate>"
+        W.step = lambda: device.rotate(x, 0.7, scalar=device.F32, out=y, n=n)
+        W.desc = {"workload": "/comms/rotate complex_float32, %d samples" % n}
+        W.metric = "Msamples/s complex_float32 rotate"
+    W.desc["setup_passes"] = args.settle
+    return W
+
+
+def time_launches(step, n):
+    """n back-to-back steps between ONE pair of HIP events on the launch stream (torch's current stream is the stream every
+    pcx_*_dev call gets; a pair per step costs ~12 us of gap per step on this stack).  Returns ms per step."""
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def cold_launches(step, n=20, idle_ms=5.0, reps=3):
+    """What a bursty topology sees: the first n launches behind idle_ms of idle (the clocks have dropped; tools/transient_probe.py shows
+    the ramp launch by launch).  Median of `reps` bursts; ms per launch."""
+    import torch
+    out = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        time.sleep(idle_ms * 1e-3)
+        out.append(time_launches(step, n))
+    out.sort()
+    return out[len(out) // 2]
+
+
+def clock_under_load(step, launches=80, spin_us=2000):
+    """The shader clock the workload runs at: one probe wave (pcx_clock_probe_dev) on a side stream spins for spin_us beside `launches`
+    back-to-back steps that are already settled.  MHz, or None if the probe did not run."""
+    import torch
+
+    from pothoscomms_amd import device
+    out = torch.zeros((16,), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(launches):
+        if k == 8:
+            device.clock_probe(out, spin_us, side)
+        step()
+    torch.cuda.synchronize()
+    mhz = float(out[0].item())
+    return round(mhz, 1) if mhz > 0 else None
+
+
+def roofline_of(W, avg_ms, sustained=None, cold=None, sustain_s=1.0, clk=None):
+    """The roofline object of a workload's dominant kernel from its measured average launch duration."""
+    sec = avg_ms * 1e-3
+    hbm = W.roof_bytes / sec / 1e9
+    entry = load_profile(W.name, W.kernel_name)
+    traffic = entry.get("hbm_bytes_per_launch") if entry else None
+    bytes_note = ("frac: algorithmic read + write (SURVEY 8d); read_only_frac: the read stream alone (north_star words its target "
+                  "on reads: a kernel that writes every sample back cannot put more than its read share of the pins into reads)")
+    if W.bound == "fp32-fma":
+        tf = W.flops_per_unit * W.units / sec / 1e12
+        r = {"bound": "fp32-fma", "achieved": round(tf, 2), "peak": FP32_FMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(tf / FP32_FMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": W.kernel_name, "avg_launch_ms": round(avg_ms, 4),
+             "algorithmic_flops_per_launch": W.flops_per_unit * W.units,
+             "flops_counted": "8 K = %d flop per output sample (K complex multiply-adds, SURVEY 8d) x %d samples; peak = the datasheet "
+                              "packed-FP32 vector rate" % (int(W.flops_per_unit), W.units),
+             "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_launch": W.roof_bytes,
+                     "note": "the other ceiling: 127 flop per byte puts this kernel on the FMA roof, not here"}}
+        m = measured_fma_rate()
+        if m:
+            r["frac_of_measured_fma_rate"] = round(tf / m[0], 4)
+            r["measured_fma_rate"] = {"TFLOP/s": m[0], "source": m[1]}
+    else:
+        r = {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
+             "read_only_frac": round(W.read_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+             "kernel": W.kernel_name, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": W.roof_bytes,
+             "bytes_counted": bytes_note}
+    if W.limiter:
+        r["limiter"] = W.limiter
+    ctr = (entry or {}).get("counters") or {}
+    if ctr.get("SQ_INSTS_VALU"):
+        insts = float(ctr["SQ_INSTS_VALU"])
+        v = {"insts_per_launch": insts, "wave_insts_per_sample": round(insts / W.units, 4),
+             "source": entry.get("source"),
+             "note": "wave64 VALU instructions per launch from the PMC pass; a wave instruction holds one of the %d SIMDs for %d cycles, "
+                     "so simd_cycle_share = insts x %d / (%d x launch time x clock) is the part of all SIMD issue time the arithmetic "
+                     "alone takes at that clock" % (N_SIMDS, VALU_CYCLES_PER_INST, VALU_CYCLES_PER_INST, N_SIMDS)}
+        if ctr.get("SQ_WAVES"):
+            v["per_wave"] = round(insts / float(ctr["SQ_WAVES"]), 1)
+        if W.blocks:
+            v["per_wave_block"] = round(insts / (4.0 * W.blocks), 1)
+        if clk:
+            v["simd_cycle_share"] = round(insts * VALU_CYCLES_PER_INST / (N_SIMDS * sec * clk * 1e6), 3)
+            v["at_clock_mhz"] = clk
+        v["simd_cycle_share_at_boost_2400_MHz"] = round(insts * VALU_CYCLES_PER_INST / (N_SIMDS * sec * 2400e6), 3)
+        r["valu"] = v
+    if clk:
+        r["clock_mhz_under_load"] = clk
+    if sustained is not None:
+        r["sustained"] = {"avg_launch_ms": round(sustained[0], 4),
+                          "frac": round((hbm if W.bound == "hbm" else r["achieved"]) * avg_ms / sustained[0] / r["peak"], 4),
+                          "launches": sustained[1],
+                          "note": "the same launches kept up for ~%.1f s behind the timed region, the last half timed: "
+                                  "the clock sags under the package power cap" % sustain_s}
+    if cold is not None:
+        r["cold"] = {"avg_launch_ms": round(cold, 4), "frac": round(r["achieved"] * avg_ms / cold / r["peak"], 4), "launches": 20, "idle_ms": 5.0,
+                     "note": "the first 20 launches behind 5 ms of idle, median of 3 bursts: what a topology with gaps between work() "
+                             "calls sees (the clocks ramp over ~200 launches, tools/transient_probe.py)"}
+    return r
+
+
+def cpu_baseline_of(wl, C):
+    from pothoscomms_amd import taps as tp
+    cpu_n = min(C, 16 * 1024 * 1024)          # bounded sample: 10-30 s of CPU work for the whole leg
+    if wl in ("fir255", "direct255"):
+        cb = cpu_baseline_fir(tp.c1_taps(), 2, cpu_n)
+        cb["c0"] = cpu_baseline_c0()
+        return cb
+    if wl == "fft4096":
+        return cpu_baseline_fft(4096)
+    if wl == "fmchain":
+        return cpu_baseline_fmchain(cpu_n)
+    if wl == "rotate":
+        return cpu_baseline_rotate(cpu_n)
+    if wl == "decim8":
+        return cpu_baseline_resampler(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8), 8, 1, cpu_n)
+    if wl == "interp4":
+        return cpu_baseline_resampler(tp.complex_bandpass(255 * 4, 0.05 / 4, 0.05 / 4) * 4, 1, 4, cpu_n // 4)
+    return cpu_baseline_fir_i16(tp.c1_taps() * 0.9, cpu_n // 2)
+
+
+def measure_secondary(wl, dev, args):
+    """BASELINE configs[2] / configs[4] behind the headline's timed region, in the same process and under the same event protocol
+    (settling passes, one event pair around the timed launches); outside `value`."""
+    import gc
+
+    import torch
+    W = build_workload(wl, SHARD, dev, 0, 1, args)
+    for _ in range(args.settle // 2 + args.warmup):
+        W.step()
+    torch.cuda.synchronize()
+    probe = time_launches(W.step, 20)
+    n = max(50, min(2000, int(0.6 / max(probe * 1e-3, 1e-6))))       # about 0.6 s of launches
+    t0 = time.perf_counter()
+    avg_ms = time_launches(W.step, n)
+    wall = time.perf_counter() - t0
+    clk = clock_under_load(W.step)
+    cold = cold_launches(W.step)
+    out = {"metric": W.metric, "value": round(W.units / (avg_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s", "steps": n,
+           "ms_per_step": round(avg_ms, 4), "wall_ms_per_step": round(wall / n * 1e3, 4), "dtype": W.dtype, "config": W.desc,
+           "roofline": roofline_of(W, avg_ms, cold=cold, clk=clk)}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_fft(2048) if wl == "fft4096" else cpu_baseline_fmchain(4 * 1024 * 1024)
+    del W
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -400,9 +727,6 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-
-    from pothoscomms_amd import _lib, device, taps as tp
-    from pothoscomms_amd.stream import ShardedFir
 
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     ndev = torch.cuda.device_count()
@@ -429,131 +753,8 @@ def main():
 
     C = args.shard
     wl = args.workload
-    roof_bytes = None
-    kernel_name = None
-
-    if wl in ("fir255", "direct255"):
-        h = tp.c1_taps()
-        algo = _lib.FIR_OLS_FFT if wl == "fir255" else _lib.FIR_DIRECT
-        sf = ShardedFir(h, C, dev, "COMPLEX", algo)
-        K = sf.K
-        # the node-wide stream starts K-1 samples before shard 0 (rank 0's history); every rank
-        # fills [its halo | its shard] from the same counter-hash stream, then the timed steps
-        # overwrite the halo through RCCL
-        device.fill_uniform_f32_dev(sf.buf, seed=2, offset=2 * rank * C)
-        units = C
-        roof_bytes = 16.0 * C
-        read_bytes = 8.0 * C
-        kernel_name = "fir_cf32_ols4096_kernel" if wl == "fir255" else "fir_cf32_direct_kernel"
-
-        def step():
-            sf.step()
-        desc = {"workload": "255-tap complex_float32 FIR (/comms/fir_filter, COMPLEX taps, M=L=1), %d-sample shard per GPU, "
-                            "%s" % (C, "frequency-domain overlap-save (4096-pt radix-16 passes)" if wl == "fir255" else "LDS-tiled direct form"),
-                "taps": 255, "shard_samples": C, "halo_samples": K - 1, "setup_passes": args.settle,
-                "parallelism": "overlap-save shards x%d, RCCL send/recv halo" % world if world > 1 else "single GPU"}
-        metric = "Msamples/s complex_float32 255-tap FIR"
-    elif wl == "fft4096":
-        nframes = 65536
-        x = torch.empty((nframes * 4096, 2), dtype=torch.float32, device=dev)
-        y = torch.empty_like(x)
-        device.fill_uniform_f32_dev(x, seed=3, offset=2 * rank * nframes * 4096)
-        fft = device.Fft("complex_float32", 4096, False)
-        units = nframes * 4096
-        roof_bytes = 16.0 * units
-        read_bytes = 8.0 * units
-        kernel_name = "fft_r16_kernel<12>"
-
-        def step():
-            fft.transform_dev(x, y, nframes)
-        desc = {"workload": "4096-pt complex_float32 FFT (/comms/fft), 65536 frames per GPU", "frames": nframes}
-        metric = "Msamples/s complex_float32 4096-pt FFT"
-    elif wl == "fmchain":
-        n = C
-        ch = device.FmChain()
-        ch.set_phase(tp.C4_PHASE)
-        ch.set_taps(tp.c4_taps(), False)
-        # [lead | 126-sample history | n samples] with the samples (not the history) on a 128-byte line,
-        # the same placement ShardedFir uses
-        xa = torch.empty((2 + n + 126, 2), dtype=torch.float32, device=dev)
-        x = xa[2:]
-        y = torch.empty((n,), dtype=torch.float32, device=dev)
-        device.fill_uniform_f32_dev(x, seed=5, offset=0)
-        units = n
-        roof_bytes = 12.0 * n
-        read_bytes = 8.0 * n
-        kernel_name = "fmchain_cf32_ols4096_kernel"
-
-        def step():
-            ch.process_dev(x, y, n + 126, n)
-        if world > 1:
-            # the stream sharded over the ranks: K-sample halo from the left neighbour (stream.ShardedFmChain)
-            from pothoscomms_amd.stream import ShardedFmChain
-            sc = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
-            device.fill_uniform_f32_dev(sc.buf, seed=5, offset=2 * rank * n)
-            del xa, x, y
-            step = sc.step
-        desc = {"workload": "fused Rotate->FIR(127 real taps)->FreqDemod in one frequency-domain kernel, complex_float32 -> float32, %d samples" % n}
-        if world > 1:
-            desc["parallelism"] = "overlap-save shards x%d, RCCL send/recv halo of 127 samples" % world
-        metric = "Msamples/s fused FM-demod chain"
-    elif wl in ("decim8", "interp4"):
-        # resampling complex_float32 FIR, 255 taps (per polyphase row when interpolating); independent replicas per rank
-        n = C if wl == "decim8" else C // 4
-        M, L = (8, 1) if wl == "decim8" else (1, 4)
-        h = tp.complex_bandpass(255 * L, 0.05 / max(L, M), 0.05 / max(L, M)) * L
-        f = device.FirFilter("complex_float32", "COMPLEX")
-        f.set_taps(h); f.set_decimation(M); f.set_interpolation(L)
-        K = f.K
-        lead = (-(K - 1)) % 16
-        xa = torch.empty((lead + n + K - 1, 2), dtype=torch.float32, device=dev)
-        x = xa[lead:]
-        y = torch.empty((n * L // M + 8, 2), dtype=torch.float32, device=dev)
-        device.fill_uniform_f32_dev(x, seed=7, offset=0)
-        units = n if wl == "decim8" else n * L            # decimator: input samples; interpolator: output samples
-        roof_bytes = 8.0 * n + 8.0 * (n * L // M)
-        read_bytes = 8.0 * n
-        kernel_name = "fir_cf32_ols4096_decim_batched_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_batched_kernel"
-
-        def step():
-            f.process_dev(x, y)
-        desc = {"workload": "255-tap complex_float32 FIR, %s, %d input samples per GPU" %
-                            ("decimation 8 folded into the spectrum (input rate)" if wl == "decim8"
-                             else "interpolation 4 from the replicated spectrum, 255 taps per phase (output rate)", n),
-                "decimation": M, "interpolation": L}
-        metric = "Msamples/s complex_float32 %s FIR" % ("decimating (in)" if wl == "decim8" else "interpolating (out)")
-    elif wl == "fir255_i16":
-        # complex_int16 255-tap FIR: bit-exact on the double-precision overlap-save pipeline
-        n = C
-        h = tp.c1_taps() * 0.9
-        f = device.FirFilter("complex_int16", "COMPLEX")
-        f.set_taps(h)
-        K = f.K
-        x = torch.randint(-20000, 20000, (n + K - 1, 2), device=dev).to(torch.int16)
-        y = torch.empty((n, 2), dtype=torch.int16, device=dev)
-        units = n
-        roof_bytes = 8.0 * n
-        read_bytes = 4.0 * n
-        kernel_name = "fir_cf64_ols_kernel"
-
-        def step():
-            f.process_dev(x, y)
-        desc = {"workload": "255-tap complex_int16 FIR (bit-exact, double-precision overlap-save), %d samples per GPU" % n, "taps": 255}
-        metric = "Msamples/s complex_int16 255-tap FIR"
-    else:
-        n = C
-        x = torch.empty((n, 2), dtype=torch.float32, device=dev)
-        y = torch.empty_like(x)
-        device.fill_uniform_f32_dev(x, seed=6, offset=0)
-        units = n
-        roof_bytes = 16.0 * n
-        read_bytes = 8.0 * n
-        kernel_name = "map_kernel<rotate>"
-
-        def step():
-            device.rotate(x, 0.7, scalar=device.F32, out=y, n=n)
-        desc = {"workload": "/comms/rotate complex_float32, %d samples" % n}
-        metric = "Msamples/s complex_float32 rotate"
+    W = build_workload(wl, C, dev, rank, world, args)
+    step, desc = W.step, W.desc
 
     def barrier():
         if world > 1:
@@ -564,7 +765,8 @@ def main():
     # 5 ms of idle the headline kernel takes 209-229 us per launch for the first 80, 200-206 for the next 100 and reaches
     # its settled 196-199 only after ~200 launches (tools/transient_probe.py, profiles/r03/transient_probe.txt); a
     # synchronisation WITHOUT idle time (the barrier below) costs nothing.  These untimed passes are part of setup, not
-    # of the W warm-up steps or the timed region; their number is reported as config.setup_passes.
+    # of the W warm-up steps or the timed region; their number is reported as config.setup_passes, and what the launches
+    # behind an idle period cost is reported as roofline.cold.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(args.settle):
         step()
@@ -586,6 +788,7 @@ def main():
     # package power cap lets the clock sag over the first seconds of a run (profiles/r03/README.md: a 3 s loop reads 3-4 % below a
     # 0.13 s one on the same box), so the line carries both numbers; single GPU only.
     sustained = None
+    cold = None
     if world == 1 and args.sustain > 0:
         n_s = max(200, int(args.sustain / max(kern_ms[0] * 1e-3, 1e-6)))
         es0, es1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -596,62 +799,40 @@ def main():
         es1.record()
         torch.cuda.synchronize()
         sustained = (es0.elapsed_time(es1) / (n_s - n_s // 2), n_s)
+    clk = None
+    if world == 1 and not args.no_cold:
+        clk = clock_under_load(step)
+        cold = cold_launches(step)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # a pass whose gated launch ran without its halo (the bounded wait of pcx_fir_process_dev_gated) is not a measurement
-        for owner in (locals().get("sf"), locals().get("sc")):
-            if owner is not None:
-                owner.check_gate()
+        if W.owner is not None:
+            W.owner.check_gate()
 
     if rank == 0:
-        value = world * units * args.steps / elapsed / 1e6
+        value = world * W.units * args.steps / elapsed / 1e6
         avg_ms = float(np.mean(kern_ms))
-        achieved = roof_bytes / (avg_ms * 1e-3) / 1e9
         desc["world_size_observed"] = world
         desc["rank_devices"] = rank_devices
         if world > 1:
             desc["halo_backend"] = "rccl" if backend == "nccl" else backend + " (rehearsal: ranks may share a GPU)"
+            if getattr(W.owner, "two_launch", False):
+                desc["halo_scheme"] = "two launches per pass (body, halo, head): PCX_STREAM_TWO_LAUNCH"
         out = {
-            "metric": metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
+            "metric": W.metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if wl == "fir255_i16" else "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": W.dtype,
             "data": "synthetic", "config": desc,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "read_only_frac": round(read_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": load_traffic(wl, kernel_name),
-                         "kernel": kernel_name, "avg_launch_ms": round(avg_ms, 4),
-                         "algorithmic_bytes_per_launch": roof_bytes,
-                         "bytes_counted": "frac: algorithmic read + write (SURVEY 8d); read_only_frac: the read stream alone "
-                                          "(north_star words its target on reads: a kernel that writes every sample back "
-                                          "cannot put more than its read share of the pins into reads)"},
+            "roofline": roofline_of(W, avg_ms, sustained, cold, args.sustain, clk),
         }
-        if sustained is not None:
-            out["roofline"]["sustained"] = {"avg_launch_ms": round(sustained[0], 4),
-                                            "frac": round(roof_bytes / (sustained[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                            "launches": sustained[1],
-                                            "note": "the same launches kept up for ~%.1f s behind the timed region, the last half timed: "
-                                                    "the clock sags under the package power cap" % args.sustain}
         if world == 1 and not args.no_cpu:
-            cpu_n = min(C, 16 * 1024 * 1024)          # bounded sample: 10-30 s of CPU work for the whole leg
-            if wl in ("fir255", "direct255"):
-                cb = cpu_baseline_fir(tp.c1_taps(), 2, cpu_n)
-                cb["c0"] = cpu_baseline_c0()
-            elif wl == "fft4096":
-                cb = cpu_baseline_fft(4096)
-            elif wl == "fmchain":
-                cb = cpu_baseline_fmchain(cpu_n)
-            elif wl == "rotate":
-                cb = cpu_baseline_rotate(cpu_n)
-            elif wl == "decim8":
-                cb = cpu_baseline_resampler(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8), 8, 1, cpu_n)
-            elif wl == "interp4":
-                cb = cpu_baseline_resampler(tp.complex_bandpass(255 * 4, 0.05 / 4, 0.05 / 4) * 4, 1, 4, cpu_n // 4)
-            else:
-                cb = cpu_baseline_fir_i16(tp.c1_taps() * 0.9, cpu_n // 2)
-            out["cpu_baseline"] = cb
+            out["cpu_baseline"] = cpu_baseline_of(wl, C)
+        if world == 1 and wl == "fir255" and not args.no_secondary:
+            # BASELINE.json configs[2] and configs[4], measured by the same command so that the driver's own run covers them
+            del W, step
+            out["secondary"] = {"fft4096": measure_secondary("fft4096", dev, args), "fmchain": measure_secondary("fmchain", dev, args)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -89,6 +89,34 @@ typedef enum pcx_status {
 PCX_API const char *pcx_last_error(void);
 PCX_API const char *pcx_version(void);
 
+/* ---- Pothos::Util::floatToQ / fromQ for INTEGER element types --------------------------------------------------------------
+ * Call sites in the reference: filter/FIRFilter.cpp:300 (fromQ<OutType>(y_n)) and :348 (floatToQ<QTapsType>(taps)),
+ * math/Rotate.cpp:21,74, math/Scale.cpp:21,73.  The header that defines them, PothosCore's include/Pothos/Util/QFormat.hpp, is
+ * NOT under /root/reference (CMakeLists.txt:8 only names the package), and the reference tests that go through it
+ * (math/TestRotate.cpp:53, math/TestScale.cpp:52: multiples of 10 times 0, +-0.5, +-1, tolerance 1) leave TWELVE readings
+ * standing (profiles/r02/qformat_enumeration.txt):
+ *     fractional bits n     half the Q word (PCX_Q_FRAC_HALF_Q)    |  half the ELEMENT word (PCX_Q_FRAC_HALF_ELEM)
+ *     floatToQ<T>(x)        T(ldexp(x, n)), the cast truncating    |  rounding to nearest (ties away from zero)
+ *     fromQ<T>(q)           q >> n (floor)  |  q / 2^n (toward zero)  |  (q + 2^(n-1)) >> n (nearest, ties up)
+ * with Q the widened accumulator type of the factories (int8 -> int16, int16 -> int32, int32 -> int64, int64 -> int64:
+ * FIRFilter.cpp:377-382, Rotate.cpp:143-157, Scale.cpp:142-157).  Every integer FIR, Rotate and Scale path of this library takes
+ * the reading as a parameter; the all-zero pcx_qformat -- HALF_Q, TRUNCATE, FLOOR, the builder's recollection of the header -- is the
+ * built-in default (kDefaultQFormat, csrc/pcx_internal.hpp: the ONE line to change the day the header is read).  Products and sums
+ * wrap modulo 2^bits(Q) under every reading (std::complex<intN> arithmetic), the result of fromQ is truncated to the element
+ * width.  Floating-point element types are not affected: both functions are plain casts there. */
+typedef enum pcx_q_frac { PCX_Q_FRAC_HALF_Q = 0, PCX_Q_FRAC_HALF_ELEM = 1 } pcx_q_frac;
+typedef enum pcx_q_to { PCX_Q_TRUNCATE = 0, PCX_Q_NEAREST = 1 } pcx_q_to;
+typedef enum pcx_q_from { PCX_Q_FLOOR = 0, PCX_Q_TOWARD_ZERO = 1, PCX_Q_ROUND = 2 } pcx_q_from;
+typedef struct pcx_qformat {
+    int frac;          /* pcx_q_frac */
+    int float_to_q;    /* pcx_q_to */
+    int from_q;        /* pcx_q_from */
+} pcx_qformat;
+/* the process-wide reading: what handles created AFTERWARDS start with and what the stateless pcx_rotate* / pcx_scale* use.
+ * NULL restores the built-in default.  Not synchronised with running calls: set it before the blocks are made. */
+PCX_API int pcx_set_qformat(const pcx_qformat *q);
+PCX_API int pcx_get_qformat(pcx_qformat *q);
+
 /* ---- device plumbing (for hosts without their own HIP runtime binding) ---- */
 PCX_API int pcx_device_count(int *count);
 PCX_API int pcx_set_device(int ordinal);
@@ -119,6 +147,11 @@ PCX_API int pcx_host_free(void *hptr);
 /* synthetic stream generator on the device: the same splitmix64 counter hash as
  * the oracle's orc_fill_uniform_f32 (uniform [-1,1), bit-identical values) */
 PCX_API int pcx_fill_uniform_f32_dev(float *dst_dev, size_t n_scalars, uint64_t seed, uint64_t offset, void *stream);
+/* measurement aid (no reference counterpart): ONE wave on `stream` spins for spin_us microseconds and writes the shader clock it
+ * ran at, in MHz, to *mhz_dev (shader cycles from s_memtime over the 100 MHz s_memrealtime).  Queued on a stream of its own beside
+ * a running workload it reads the clock the workload is held at by the package power cap -- bench.py uses it to turn the profiled
+ * VALU instruction count of a kernel into a share of SIMD issue time (`roofline.valu`). */
+PCX_API int pcx_clock_probe_dev(float *mhz_dev, unsigned spin_us, void *stream);
 
 /* ===================================================================== *
  *  /comms/fir_filter      filter/FIRFilter.cpp
@@ -148,6 +181,9 @@ PCX_API int pcx_fir_set_taps(pcx_fir *h, const double *taps, size_t ntaps);
 PCX_API int pcx_fir_set_decimation(pcx_fir *h, size_t decim);
 PCX_API int pcx_fir_set_interpolation(pcx_fir *h, size_t interp);
 PCX_API int pcx_fir_set_algo(pcx_fir *h, int algo);
+/* the Q-format reading of THIS filter (integer element types; see pcx_qformat): the taps are quantised again with it and every
+ * later call shifts and rounds by it.  NULL: the process-wide reading of pcx_set_qformat. */
+PCX_API int pcx_fir_set_qformat(pcx_fir *h, const pcx_qformat *q);
 /* K = ceil(ntaps/L) (FIRFilter.cpp:335) and _inputRequire = M+K-1 (:353) */
 PCX_API int pcx_fir_get_geometry(const pcx_fir *h, size_t *K, size_t *input_require);
 /* which algorithm the last process call ran (pcx_fir_algo) */
@@ -238,6 +274,13 @@ PCX_API int pcx_rotate_dev(int scalar, double phasor_re, double phasor_im, const
 /* arrayScale, Scale.cpp:15-23 with factorScaled = floatToQ(factor) (:70-74); real factor */
 PCX_API int pcx_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n);
 PCX_API int pcx_scale_dev(int scalar, int is_complex, double factor, const void *in_dev, void *out_dev, size_t n, void *stream);
+/* the same two maps under an explicit Q-format reading (integer element types; q == NULL: the process-wide one) */
+PCX_API int pcx_rotate_q(int scalar, double phasor_re, double phasor_im, const pcx_qformat *q, const void *in, void *out, size_t n);
+PCX_API int pcx_rotate_q_dev(int scalar, double phasor_re, double phasor_im, const pcx_qformat *q, const void *in_dev, void *out_dev, size_t n,
+                             void *stream);
+PCX_API int pcx_scale_q(int scalar, int is_complex, double factor, const pcx_qformat *q, const void *in, void *out, size_t n);
+PCX_API int pcx_scale_q_dev(int scalar, int is_complex, double factor, const pcx_qformat *q, const void *in_dev, void *out_dev, size_t n,
+                            void *stream);
 /* Abs.cpp:40-43 via getAbs, FxptHelpers.hpp:36-49; out is the real scalar type */
 PCX_API int pcx_abs(int scalar, int is_complex, const void *in, void *out, size_t n);
 PCX_API int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *out_dev, size_t n, void *stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "pcx_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "pcx_host_free": (_i, [_vp]),
     "pcx_fill_uniform_f32_dev": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
+    "pcx_clock_probe_dev": (_i, [_vp, C.c_uint, _vp]),
     "pcx_fir_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "pcx_fir_destroy": (_i, [_vp]),
     "pcx_fir_set_taps": (_i, [_vp, _vp, _sz]),

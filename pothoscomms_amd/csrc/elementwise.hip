@@ -116,10 +116,10 @@ struct QCompute {
     using type = typename std::conditional<(sizeof(Q) < 4), uint32_t, typename std::make_unsigned<Q>::type>::type;
 };
 template <typename S, typename Q>
-__device__ inline S from_q_dev(typename QCompute<Q>::type v)
+__device__ inline S from_q_dev(typename QCompute<Q>::type v, QShift qs)
 {
     const Q q = (Q)v;                       // wrap to the Q width
-    return (S)(q >> (4 * sizeof(Q)));       // fromQ: arithmetic >> half the Q bits, then truncate
+    return (S)from_q_bits<Q>(q, qs);        // fromQ under the reading in force (pcx_qformat.hpp), then truncate to the element
 }
 
 // ---- Rotate  (math/Rotate.cpp:15-23) ----
@@ -145,22 +145,25 @@ template <typename S, typename Q>
 struct RotateI {
     using C = typename QCompute<Q>::type;
     C pr, pi;
+    QShift qs;
     __device__ void operator()(const S *x, S *y) const
     {
         const C c = (C)(Q)x[0], d = (C)(Q)x[1];
-        y[0] = from_q_dev<S, Q>(pr * c - pi * d);
-        y[1] = from_q_dev<S, Q>(pr * d + pi * c);
+        y[0] = from_q_dev<S, Q>(pr * c - pi * d, qs);
+        y[1] = from_q_dev<S, Q>(pr * d + pi * c, qs);
     }
 };
-int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n, hipStream_t st)
+int launch_rotate(int scalar, double pr, double pi, const QFormat &qf, const void *in, void *out, size_t n, hipStream_t st)
 {
+    // phasor = floatToQ<QType>(std::polar(1.0, phase)), Rotate.cpp:74; out = fromQ<Type>(phasor * QType(in)), :21
+    const QShift qs = q_shift(qf, scalar);
     switch (scalar) {
     case PCX_F32: return launch_map<float, float, 2, 2>(in, out, n, RotateF<float>{(float)pr, (float)pi}, st);
     case PCX_F64: return launch_map<double, double, 2, 2>(in, out, n, RotateF<double>{pr, pi}, st);
-    case PCX_I64: return launch_map<int64_t, int64_t, 2, 2>(in, out, n, RotateI<int64_t, int64_t>{(uint64_t)float_to_q(pr, 64), (uint64_t)float_to_q(pi, 64)}, st);
-    case PCX_I32: return launch_map<int32_t, int32_t, 2, 2>(in, out, n, RotateI<int32_t, int64_t>{(uint64_t)float_to_q(pr, 64), (uint64_t)float_to_q(pi, 64)}, st);
-    case PCX_I16: return launch_map<int16_t, int16_t, 2, 2>(in, out, n, RotateI<int16_t, int32_t>{(uint32_t)float_to_q(pr, 32), (uint32_t)float_to_q(pi, 32)}, st);
-    case PCX_I8: return launch_map<int8_t, int8_t, 2, 2>(in, out, n, RotateI<int8_t, int16_t>{(uint32_t)float_to_q(pr, 16), (uint32_t)float_to_q(pi, 16)}, st);
+    case PCX_I64: return launch_map<int64_t, int64_t, 2, 2>(in, out, n, RotateI<int64_t, int64_t>{(uint64_t)float_to_q(pr, scalar, qf), (uint64_t)float_to_q(pi, scalar, qf), qs}, st);
+    case PCX_I32: return launch_map<int32_t, int32_t, 2, 2>(in, out, n, RotateI<int32_t, int64_t>{(uint64_t)float_to_q(pr, scalar, qf), (uint64_t)float_to_q(pi, scalar, qf), qs}, st);
+    case PCX_I16: return launch_map<int16_t, int16_t, 2, 2>(in, out, n, RotateI<int16_t, int32_t>{(uint32_t)float_to_q(pr, scalar, qf), (uint32_t)float_to_q(pi, scalar, qf), qs}, st);
+    case PCX_I8: return launch_map<int8_t, int8_t, 2, 2>(in, out, n, RotateI<int8_t, int16_t>{(uint32_t)float_to_q(pr, scalar, qf), (uint32_t)float_to_q(pi, scalar, qf), qs}, st);
     }
     set_error("rotate: unsupported scalar type %d", scalar);
     return PCX_ERR_ARG;
@@ -176,18 +179,21 @@ template <typename S, typename Q>
 struct ScaleI {
     using C = typename QCompute<Q>::type;
     C f;
-    __device__ void operator()(const S *x, S *y) const { y[0] = from_q_dev<S, Q>(f * (C)(Q)x[0]); }
+    QShift qs;
+    __device__ void operator()(const S *x, S *y) const { y[0] = from_q_dev<S, Q>(f * (C)(Q)x[0], qs); }
 };
-int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st)
+int launch_scale(int scalar, int is_complex, double factor, const QFormat &qf, const void *in, void *out, size_t n, hipStream_t st)
 {
+    // factorScaled = floatToQ<ScaleType>(factor), Scale.cpp:73; out = fromQ<Type>(factorScaled * QType(in)), :21
     const size_t ns = n * (is_complex ? 2 : 1);
+    const QShift qs = q_shift(qf, scalar);
     switch (scalar) {
     case PCX_F32: return launch_map<float, float, 1, 1>(in, out, ns, ScaleF<float>{(float)factor}, st);
     case PCX_F64: return launch_map<double, double, 1, 1>(in, out, ns, ScaleF<double>{factor}, st);
-    case PCX_I64: return launch_map<int64_t, int64_t, 1, 1>(in, out, ns, ScaleI<int64_t, int64_t>{(uint64_t)float_to_q(factor, 64)}, st);
-    case PCX_I32: return launch_map<int32_t, int32_t, 1, 1>(in, out, ns, ScaleI<int32_t, int64_t>{(uint64_t)float_to_q(factor, 64)}, st);
-    case PCX_I16: return launch_map<int16_t, int16_t, 1, 1>(in, out, ns, ScaleI<int16_t, int32_t>{(uint32_t)float_to_q(factor, 32)}, st);
-    case PCX_I8: return launch_map<int8_t, int8_t, 1, 1>(in, out, ns, ScaleI<int8_t, int16_t>{(uint32_t)float_to_q(factor, 16)}, st);
+    case PCX_I64: return launch_map<int64_t, int64_t, 1, 1>(in, out, ns, ScaleI<int64_t, int64_t>{(uint64_t)float_to_q(factor, scalar, qf), qs}, st);
+    case PCX_I32: return launch_map<int32_t, int32_t, 1, 1>(in, out, ns, ScaleI<int32_t, int64_t>{(uint64_t)float_to_q(factor, scalar, qf), qs}, st);
+    case PCX_I16: return launch_map<int16_t, int16_t, 1, 1>(in, out, ns, ScaleI<int16_t, int32_t>{(uint32_t)float_to_q(factor, scalar, qf), qs}, st);
+    case PCX_I8: return launch_map<int8_t, int8_t, 1, 1>(in, out, ns, ScaleI<int8_t, int16_t>{(uint32_t)float_to_q(factor, scalar, qf), qs}, st);
     }
     set_error("scale: unsupported scalar type %d", scalar);
     return PCX_ERR_ARG;
@@ -523,6 +529,30 @@ int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t offset
 {
     if (n == 0) return PCX_OK;
     hipLaunchKernelGGL(fill_uniform_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, dst, n, seed, offset);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+// ---- shader clock probe ----
+// One wave spins for `spin_us` of wall time and reports how many shader cycles went by: s_memtime counts shader-clock cycles on
+// gfx950 (tools/clk_lab.hip: 2,397-2,424 per microsecond on an idle device), s_memrealtime the constant 100 MHz reference.  Queued
+// on a stream of its own BESIDE a running workload it reads the clock that workload runs at -- the package power cap holds it far
+// below the 2.4 GHz boost on real data -- which is what turns an instruction count into a share of SIMD time.
+__global__ __launch_bounds__(64) void clock_probe_kernel(float *mhz, unsigned spin_ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) *mhz = (float)(100.0 * (double)(t1 - t0) / (double)(r1 - r0));
+}
+int launch_clock_probe(float *mhz_dev, unsigned spin_us, hipStream_t st)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, mhz_dev, spin_us * 100u);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ CPair<S> fir_output_annex_g(const S *xp, const S *tp,
 template <typename S, typename TT, bool CPLX, bool CTAPS, bool EXACT>
 __global__ __launch_bounds__(256) void fir_generic_kernel(const S *__restrict__ in, S *__restrict__ out, size_t n_out,
                                                           size_t L, size_t M, size_t K,
-                                                          const uint32_t *__restrict__ rowLen, const TT *__restrict__ rowTaps)
+                                                          const uint32_t *__restrict__ rowLen, const TT *__restrict__ rowTaps, QShift qs)
 {
     constexpr bool FLT = std::is_floating_point<S>::value;
     constexpr int EW = CPLX ? 2 : 1, TW = CTAPS ? 2 : 1;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const S *__restrict__ 
                     }
                 }
             }
-            out[o * EW] = (S)(((TT)ar) >> (4 * sizeof(TT)));
-            if constexpr (CPLX) out[o * EW + 1] = (S)(((TT)ai) >> (4 * sizeof(TT)));
+            out[o * EW] = (S)from_q_bits<TT>((TT)ar, qs);        // fromQ<OutType>(y_n), FIRFilter.cpp:300, under the reading in force
+            if constexpr (CPLX) out[o * EW + 1] = (S)from_q_bits<TT>((TT)ai, qs);
         }
     }
 }
@@ -141,7 +141,7 @@ template <typename S, typename TT> struct SlideAcc<S, TT, false> { typedef typen
 // R+1 elements is conflict-free for 4-, 8- and 16-byte elements.
 template <typename S, typename TT, bool CPLX, bool CTAPS, bool EXACT, bool MAD24, int R, bool STAGE>
 __global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in, S *__restrict__ out, size_t n_out, size_t K,
-                                                        const TT *__restrict__ taps)
+                                                        const TT *__restrict__ taps, QShift qs)
 {
     constexpr bool FLT = std::is_floating_point<S>::value;
     constexpr int EW = CPLX ? 2 : 1, TW = CTAPS ? 2 : 1;
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in
                 res[r * EW] = ar[r];
                 if constexpr (CPLX) res[r * EW + 1] = ai[r];
             } else {
-                res[r * EW] = (S)(((TT)ar[r]) >> (4 * sizeof(TT)));
-                if constexpr (CPLX) res[r * EW + 1] = (S)(((TT)ai[r]) >> (4 * sizeof(TT)));
+                res[r * EW] = (S)from_q_bits<TT>((TT)ar[r], qs);
+                if constexpr (CPLX) res[r * EW + 1] = (S)from_q_bits<TT>((TT)ai[r], qs);
             }
         }
         constexpr int BYTES = R * EW * (int)sizeof(S);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void fir_slide_kernel(const S *__restrict__ in
 }
 
 template <typename S, typename TT, bool EXACT, bool MAD24>
-static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g, const void *in, void *out, size_t n_out, hipStream_t st)
+static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g, const void *in, void *out, size_t n_out, QShift qs, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     constexpr int R = sizeof(S) >= 8 ? 4 : 8;
@@ -300,8 +300,8 @@ static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g
     const bool stage = stage_on && lds <= 64 * 1024;
 #define PCX_FIR_LAUNCH(CP, CT)                                                                                                          \
     do {                                                                                                                                \
-        if (stage) hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R, true>), dim3(grid), dim3(256), lds, st, pin, pout, n_out, g.K, tp); \
-        else hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R, false>), dim3(grid), dim3(256), 0, st, pin, pout, n_out, g.K, tp);     \
+        if (stage) hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R, true>), dim3(grid), dim3(256), lds, st, pin, pout, n_out, g.K, tp, qs); \
+        else hipLaunchKernelGGL((fir_slide_kernel<S, TT, CP, CT, EXACT, MAD24, R, false>), dim3(grid), dim3(256), 0, st, pin, pout, n_out, g.K, tp, qs); \
     } while (0)
     if (!is_complex) PCX_FIR_LAUNCH(false, false);
     else if (!complex_taps) PCX_FIR_LAUNCH(true, false);
@@ -324,7 +324,7 @@ static int launch_fir_slide_t(int is_complex, int complex_taps, const FirGeom &g
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 template <bool IN8>
 __global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const void *__restrict__ in_v, void *__restrict__ out_v, size_t n_out, size_t K,
-                                                            const uint32_t *__restrict__ tapsP)
+                                                            const uint32_t *__restrict__ tapsP, QShift qs)
 {
     const uint32_t *in = static_cast<const uint32_t *>(in_v);
     uint32_t *out = static_cast<uint32_t *>(out_v);
@@ -377,11 +377,11 @@ __global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const void *__restri
             }
         }
         if (IN8) {
-            // QType int16: the accumulator is the low half of the int32 sum; fromQ = >> 8, truncated to int8
+            // QType int16: the accumulator is the low half of the int32 sum; fromQ (>> 8 by default), truncated to int8
             uint16_t res[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t re = (uint8_t)(int8_t)((int16_t)ar[r] >> 8), im = (uint8_t)(int8_t)((int16_t)ai[r] >> 8);
+                const uint32_t re = (uint8_t)(int8_t)from_q_bits<int16_t>((int16_t)ar[r], qs), im = (uint8_t)(int8_t)from_q_bits<int16_t>((int16_t)ai[r], qs);
                 res[r] = (uint16_t)(re | (im << 8));
             }
             uint16_t *op = static_cast<uint16_t *>(out_v) + o0;
@@ -395,11 +395,11 @@ __global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const void *__restri
                 for (int r = 0; r < R; r++) { if (o0 + r >= n_out) break; op[r] = res[r]; }
             }
         } else {
-            // fromQ: arithmetic >> 16 of the wrapped int32, truncated to int16 (FIRFilter.cpp:300)
+            // fromQ of the wrapped int32 (arithmetic >> 16 by default), truncated to int16 (FIRFilter.cpp:300)
             uint32_t res[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t re = (uint32_t)(uint16_t)(int16_t)(ar[r] >> 16), im = (uint32_t)(uint16_t)(int16_t)(ai[r] >> 16);
+                const uint32_t re = (uint32_t)(uint16_t)(int16_t)from_q_bits<int32_t>(ar[r], qs), im = (uint32_t)(uint16_t)(int16_t)from_q_bits<int32_t>(ai[r], qs);
                 res[r] = re | (im << 16);
             }
             uint32_t *op = out + o0;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void fir_ci16_dot2_kernel(const void *__restri
         }
     }
 }
-int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, bool in8, hipStream_t st)
+int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, bool in8, QShift qs, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     constexpr int R = 8;
@@ -423,36 +423,36 @@ int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, cons
     if (lds > 64 * 1024) { set_error("fir (int16 dot2): %zu taps exceed the LDS tile", K); return PCX_ERR_UNSUPPORTED; }
     size_t gsz = (n_out + 256 * R - 1) / (256 * R);
     if (gsz > (1u << 20)) gsz = 1u << 20;
-    if (in8) hipLaunchKernelGGL(fir_ci16_dot2_kernel<true>, dim3((unsigned)gsz), dim3(256), lds, st, in, out, n_out, K, (const uint32_t *)tapsP);
-    else hipLaunchKernelGGL(fir_ci16_dot2_kernel<false>, dim3((unsigned)gsz), dim3(256), lds, st, in, out, n_out, K, (const uint32_t *)tapsP);
+    if (in8) hipLaunchKernelGGL(fir_ci16_dot2_kernel<true>, dim3((unsigned)gsz), dim3(256), lds, st, in, out, n_out, K, (const uint32_t *)tapsP, qs);
+    else hipLaunchKernelGGL(fir_ci16_dot2_kernel<false>, dim3((unsigned)gsz), dim3(256), lds, st, in, out, n_out, K, (const uint32_t *)tapsP, qs);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
 
 // M = L = 1 entry: `taps24` = every Q tap fits 24 signed bits (int16 / int8 element types)
 int launch_fir_slide(int scalar, int is_complex, int complex_taps, bool exact, bool taps24, const FirGeom &g, const void *in,
-                     void *out, size_t n_out, hipStream_t st)
+                     void *out, size_t n_out, QShift qs, hipStream_t st)
 {
     switch (scalar) {
     case PCX_F32:
-        return exact ? launch_fir_slide_t<float, float, true, false>(is_complex, complex_taps, g, in, out, n_out, st)
-                     : launch_fir_slide_t<float, float, false, false>(is_complex, complex_taps, g, in, out, n_out, st);
+        return exact ? launch_fir_slide_t<float, float, true, false>(is_complex, complex_taps, g, in, out, n_out, qs, st)
+                     : launch_fir_slide_t<float, float, false, false>(is_complex, complex_taps, g, in, out, n_out, qs, st);
     case PCX_F64:
-        return exact ? launch_fir_slide_t<double, double, true, false>(is_complex, complex_taps, g, in, out, n_out, st)
-                     : launch_fir_slide_t<double, double, false, false>(is_complex, complex_taps, g, in, out, n_out, st);
-    case PCX_I64: return launch_fir_slide_t<int64_t, int64_t, true, false>(is_complex, complex_taps, g, in, out, n_out, st);
-    case PCX_I32: return launch_fir_slide_t<int32_t, int64_t, true, false>(is_complex, complex_taps, g, in, out, n_out, st);
+        return exact ? launch_fir_slide_t<double, double, true, false>(is_complex, complex_taps, g, in, out, n_out, qs, st)
+                     : launch_fir_slide_t<double, double, false, false>(is_complex, complex_taps, g, in, out, n_out, qs, st);
+    case PCX_I64: return launch_fir_slide_t<int64_t, int64_t, true, false>(is_complex, complex_taps, g, in, out, n_out, qs, st);
+    case PCX_I32: return launch_fir_slide_t<int32_t, int64_t, true, false>(is_complex, complex_taps, g, in, out, n_out, qs, st);
     case PCX_I16:
-        return taps24 ? launch_fir_slide_t<int16_t, int32_t, true, true>(is_complex, complex_taps, g, in, out, n_out, st)
-                      : launch_fir_slide_t<int16_t, int32_t, true, false>(is_complex, complex_taps, g, in, out, n_out, st);
-    case PCX_I8: return launch_fir_slide_t<int8_t, int16_t, true, true>(is_complex, complex_taps, g, in, out, n_out, st);
+        return taps24 ? launch_fir_slide_t<int16_t, int32_t, true, true>(is_complex, complex_taps, g, in, out, n_out, qs, st)
+                      : launch_fir_slide_t<int16_t, int32_t, true, false>(is_complex, complex_taps, g, in, out, n_out, qs, st);
+    case PCX_I8: return launch_fir_slide_t<int8_t, int16_t, true, true>(is_complex, complex_taps, g, in, out, n_out, qs, st);
     }
     set_error("fir: unsupported scalar type %d", scalar);
     return PCX_ERR_ARG;
 }
 
 template <typename S, typename TT, bool EXACT>
-static int launch_fir_generic_t(int is_complex, int complex_taps, const FirGeom &g, const void *in, void *out, size_t n_out, hipStream_t st)
+static int launch_fir_generic_t(int is_complex, int complex_taps, const FirGeom &g, const void *in, void *out, size_t n_out, QShift qs, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     size_t gsz = (n_out + 255) / 256;
@@ -463,7 +463,7 @@ static int launch_fir_generic_t(int is_complex, int complex_taps, const FirGeom 
     const TT *tp = (const TT *)g.rowTaps;
 #define PCX_FIR_LAUNCH(CP, CT)                                                                                           \
     hipLaunchKernelGGL((fir_generic_kernel<S, TT, CP, CT, EXACT>), dim3(grid), dim3(256), 0, st, pin, pout, n_out, g.L, \
-                       g.M, g.K, g.rowLen, tp)
+                       g.M, g.K, g.rowLen, tp, qs)
     if (!is_complex) PCX_FIR_LAUNCH(false, false);
     else if (!complex_taps) PCX_FIR_LAUNCH(true, false);
     else PCX_FIR_LAUNCH(true, true);
@@ -473,19 +473,19 @@ static int launch_fir_generic_t(int is_complex, int complex_taps, const FirGeom 
 }
 
 int launch_fir_generic(int scalar, int is_complex, int complex_taps, bool exact, const FirGeom &g, const void *in,
-                       void *out, size_t n_out, hipStream_t st)
+                       void *out, size_t n_out, QShift qs, hipStream_t st)
 {
     switch (scalar) {
     case PCX_F32:
-        return exact ? launch_fir_generic_t<float, float, true>(is_complex, complex_taps, g, in, out, n_out, st)
-                     : launch_fir_generic_t<float, float, false>(is_complex, complex_taps, g, in, out, n_out, st);
+        return exact ? launch_fir_generic_t<float, float, true>(is_complex, complex_taps, g, in, out, n_out, qs, st)
+                     : launch_fir_generic_t<float, float, false>(is_complex, complex_taps, g, in, out, n_out, qs, st);
     case PCX_F64:
-        return exact ? launch_fir_generic_t<double, double, true>(is_complex, complex_taps, g, in, out, n_out, st)
-                     : launch_fir_generic_t<double, double, false>(is_complex, complex_taps, g, in, out, n_out, st);
-    case PCX_I64: return launch_fir_generic_t<int64_t, int64_t, true>(is_complex, complex_taps, g, in, out, n_out, st);
-    case PCX_I32: return launch_fir_generic_t<int32_t, int64_t, true>(is_complex, complex_taps, g, in, out, n_out, st);
-    case PCX_I16: return launch_fir_generic_t<int16_t, int32_t, true>(is_complex, complex_taps, g, in, out, n_out, st);
-    case PCX_I8: return launch_fir_generic_t<int8_t, int16_t, true>(is_complex, complex_taps, g, in, out, n_out, st);
+        return exact ? launch_fir_generic_t<double, double, true>(is_complex, complex_taps, g, in, out, n_out, qs, st)
+                     : launch_fir_generic_t<double, double, false>(is_complex, complex_taps, g, in, out, n_out, qs, st);
+    case PCX_I64: return launch_fir_generic_t<int64_t, int64_t, true>(is_complex, complex_taps, g, in, out, n_out, qs, st);
+    case PCX_I32: return launch_fir_generic_t<int32_t, int64_t, true>(is_complex, complex_taps, g, in, out, n_out, qs, st);
+    case PCX_I16: return launch_fir_generic_t<int16_t, int32_t, true>(is_complex, complex_taps, g, in, out, n_out, qs, st);
+    case PCX_I8: return launch_fir_generic_t<int8_t, int16_t, true>(is_complex, complex_taps, g, in, out, n_out, qs, st);
     }
     set_error("fir: unsupported scalar type %d", scalar);
     return PCX_ERR_ARG;

@@ -109,7 +109,7 @@ struct StreamIo<0> {
     {
         return as_cd(__builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y)
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y, QShift)
     {
         __builtin_amdgcn_raw_buffer_store_b128(as_u4(y), ws, voff, 0, kAuxStream);
     }
@@ -122,14 +122,14 @@ struct StreamIo<1> {
         const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX);
         return cd{(double)(short)(t & 0xffffu), (double)(short)(t >> 16)};
     }
-    static __device__ __forceinline__ unsigned q(double d)   // wrap to the 32-bit Q accumulator, fromQ, truncate to int16
+    static __device__ __forceinline__ unsigned q(double d, QShift qs)   // wrap to the 32-bit Q accumulator, fromQ (pcx_qformat.hpp), truncate to int16
     {
         const int w = (int)(unsigned)(unsigned long long)__double2ll_rn(d);
-        return (unsigned)(w >> 16) & 0xffffu;
+        return (unsigned)from_q_bits<int>(w, qs) & 0xffffu;
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y)
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y, QShift qs)
     {
-        __builtin_amdgcn_raw_buffer_store_b32(q(y.x) | (q(y.y) << 16), ws, voff, 0, kAuxStream);
+        __builtin_amdgcn_raw_buffer_store_b32(q(y.x, qs) | (q(y.y, qs) << 16), ws, voff, 0, kAuxStream);
     }
 };
 template <>
@@ -140,14 +140,14 @@ struct StreamIo<2> {
         const unsigned t = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, AUX);
         return cd{(double)(signed char)(t & 0xffu), (double)(signed char)((t >> 8) & 0xffu)};
     }
-    static __device__ __forceinline__ unsigned q(double d)   // 16-bit Q accumulator, >> 8, truncate to int8
+    static __device__ __forceinline__ unsigned q(double d, QShift qs)   // 16-bit Q accumulator, fromQ, truncate to int8
     {
         const short w = (short)(unsigned short)(unsigned long long)__double2ll_rn(d);
-        return (unsigned)(w >> 8) & 0xffu;
+        return (unsigned)from_q_bits<short>(w, qs) & 0xffu;
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y)
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y, QShift qs)
     {
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(q(y.x) | (q(y.y) << 8)), ws, voff, 0, kAuxStream);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(q(y.x, qs) | (q(y.y, qs) << 8)), ws, voff, 0, kAuxStream);
     }
 };
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
                                                                           unsigned char *__restrict__ out, size_t n_out, size_t n_dec, unsigned M, unsigned magic,
                                                                           const double2 *__restrict__ Hspec, int Kov, int pad,
                                                                           const double2 *__restrict__ twtab, size_t first_full,
-                                                                          size_t nfull, size_t nblocks)
+                                                                          size_t nfull, size_t nblocks, QShift qs)
 {
     typedef OlsPlan<LOG2N> P;
     typedef StreamIo<IO> SIO;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
                 const unsigned t = base + (unsigned)(i - Kov) + 1u;
                 const unsigned qt = __umulhi(t, magic);
                 if (i >= Kov && (size_t)(i - Kov) < full_left && qt * M == t)
-                    SIO::store(ws, (int)((qt - 1u) * (unsigned)EB), cd{u[q].x, -u[q].y});
+                    SIO::store(ws, (int)((qt - 1u) * (unsigned)EB), cd{u[q].x, -u[q].y}, qs);
             }
         } else {
         const size_t room = n_out - b * S;
@@ -241,14 +241,14 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
         for (int q = 0; q < 16; q++) {
             const int row = LPF * (P::NATURAL ? q : bin_of(q));
             if (row + LPF - 1 < Kov) continue;                // whole row dropped: uniform skip
-            SIO::store(ws, (int)(vbase + (unsigned)row * (unsigned)EB), cd{u[q].x, -u[q].y});
+            SIO::store(ws, (int)(vbase + (unsigned)row * (unsigned)EB), cd{u[q].x, -u[q].y}, qs);
         }
         }
     }
 }
 
 template <int LOG2N, int IO>
-int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, hipStream_t st)
+int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, hipStream_t st)
 {
     typedef OlsPlan<LOG2N> P;
     const size_t Km1 = K - 1;
@@ -274,7 +274,7 @@ int launch_ols(const void *in, size_t in_elems, void *out, size_t n_out, const v
     // +5 % at 64 Mi samples (tools/ab_oversub.sh), which is this; PCX_OVERSUB (diagnostic library) brings the fixed factor back
     const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * per_cu, 1) : rounds_grid(nblocks, 256 * per_cu, 4);
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out, n_out / M,
-                       (unsigned)M, magic, (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, first_full, nfull, nblocks);
+                       (unsigned)M, magic, (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, first_full, nfull, nblocks, qs);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -296,7 +296,7 @@ struct RealIo<0> {   // float64
     {
         return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y, QShift)
     {
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, y), ws, voff, 0, kAuxStream);
@@ -309,9 +309,9 @@ struct RealIo<1> {   // int16: 32-bit Q accumulator, >> 16
     {
         return (double)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, 0, 0);
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y, QShift qs)
     {
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)StreamIo<1>::q(y), ws, voff, 0, kAuxStream);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)StreamIo<1>::q(y, qs), ws, voff, 0, kAuxStream);
     }
 };
 template <>
@@ -321,9 +321,9 @@ struct RealIo<2> {   // int8: 16-bit Q accumulator, >> 8
     {
         return (double)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, 0, 0);
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y, QShift qs)
     {
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)StreamIo<2>::q(y), ws, voff, 0, kAuxStream);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)StreamIo<2>::q(y, qs), ws, voff, 0, kAuxStream);
     }
 };
 
@@ -334,7 +334,7 @@ struct RealIo<3> {   // float32 (decimating real float32 filters: the undecimate
     {
         return (double)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
     }
-    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y)
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, double y, QShift)
     {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)y), ws, voff, 0, kAuxStream);
     }
@@ -344,7 +344,7 @@ struct RealIo<3> {   // float32 (decimating real float32 filters: the undecimate
 template <int LOG2N, int IO, bool DECIM>
 __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_per_eu(2))) void fir_real_ols_kernel(
     const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, const double2 *__restrict__ Hspec,
-    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real, size_t n_dec, unsigned M, unsigned magic)
+    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real, size_t n_dec, unsigned M, unsigned magic, QShift qs)
 {
     typedef OlsPlan<LOG2N> P;
     typedef RealIo<IO> RIO;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
                     const unsigned t = base + (unsigned)(i - Kov) + 1u;
                     const unsigned qt = __umulhi(t, magic);
                     if (i >= Kov && (size_t)(i - Kov) < full_left && qt * M == t)
-                        RIO::store(wd, (int)((qt - 1u) * (unsigned)EB), h == 0 ? u[q].x : -u[q].y);
+                        RIO::store(wd, (int)((qt - 1u) * (unsigned)EB), h == 0 ? u[q].x : -u[q].y, qs);
                 }
             }
         } else {
@@ -436,15 +436,15 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
             const int row = LPF * (P::NATURAL ? q : bin_of(q));
             if (row + LPF - 1 < Kov) continue;                // whole row dropped: uniform skip
             // y = conj(u): block 2b is its real part, block 2b+1 its imaginary part
-            RIO::store(ws[0], (int)(vbase + (unsigned)row * (unsigned)EB), u[q].x);
-            RIO::store(ws[1], (int)(vbase + (unsigned)row * (unsigned)EB), -u[q].y);
+            RIO::store(ws[0], (int)(vbase + (unsigned)row * (unsigned)EB), u[q].x, qs);
+            RIO::store(ws[1], (int)(vbase + (unsigned)row * (unsigned)EB), -u[q].y, qs);
         }
         }
     }
 }
 
 template <int LOG2N, int IO>
-int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, hipStream_t st)
+int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, hipStream_t st)
 {
     typedef OlsPlan<LOG2N> P;
     const size_t Km1 = K - 1;
@@ -464,7 +464,7 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
     if (per_cu < 1) per_cu = 1;
     const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * per_cu, 1) : rounds_grid(nblocks, 256 * per_cu, 4);   // as fir_cf64_ols
     hipLaunchKernelGGL(k, dim3(grid), dim3(P::LPF), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out,
-                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks_real, n_out / M, (unsigned)M, magic);
+                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks_real, n_out / M, (unsigned)M, magic, qs);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -474,15 +474,15 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
 // log2n in {10 .. 13}; Hspec = FFT_N(h)/N in double, tw = make_tw_r16<double>(log2n) (pcx_api.hip).  io: 0 complex_float64,
 // 1 complex_int16, 2 complex_int8 (h = the Q-format integer taps; see StreamIo).  n_out = full-rate outputs; M > 1 keeps one in M
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
-                        const void *tw, int io, size_t M, hipStream_t st)
+                        const void *tw, int io, size_t M, QShift qs, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     if (M < 1 || M > 65535) { set_error("fir ols f64: decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
 #define PCX_OLS64_CASE(L2)                                                                                    \
     case L2:                                                                                                  \
-        return io == 0   ? launch_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, st)                  \
-               : io == 1 ? launch_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, st)                  \
-                         : launch_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, st);
+        return io == 0   ? launch_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)                  \
+               : io == 1 ? launch_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)                  \
+                         : launch_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
     switch (log2n) {
         PCX_OLS64_CASE(10)
         PCX_OLS64_CASE(11)
@@ -500,16 +500,16 @@ namespace pcx {
 // REAL streams on the same pipeline (real taps): io 0 float64, 1 int16, 2 int8, 3 float32; log2n 12 (K <= 2049) or 13 (K <= 4097);
 // n_out = full-rate outputs, M > 1 keeps one in M
 int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n, const void *tw,
-                        int io, size_t M, hipStream_t st)
+                        int io, size_t M, QShift qs, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     if (M < 1 || M > 65535) { set_error("fir ols (real): decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
 #define PCX_REAL_CASE(L2)                                                                                   \
     if (log2n == L2)                                                                                        \
-        return io == 0   ? launch_real_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, st)            \
-               : io == 1 ? launch_real_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, st)            \
-               : io == 2 ? launch_real_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, st)            \
-                         : launch_real_ols<L2, 3>(in, in_elems, out, n_out, Hspec, K, tw, M, st);
+        return io == 0   ? launch_real_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)            \
+               : io == 1 ? launch_real_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)            \
+               : io == 2 ? launch_real_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)            \
+                         : launch_real_ols<L2, 3>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
     PCX_REAL_CASE(12)
     PCX_REAL_CASE(13)
 #undef PCX_REAL_CASE

@@ -320,6 +320,12 @@ int pcx_fill_uniform_f32_dev(float *dst, size_t n, uint64_t seed, uint64_t offse
 {
     return launch_fill_uniform_f32(dst, n, seed, offset, as_stream(st));
 }
+int pcx_clock_probe_dev(float *mhz_dev, unsigned spin_us, void *st)
+{
+    PCX_CHECK_ARG(mhz_dev, "null output");
+    PCX_CHECK_ARG(spin_us >= 1 && spin_us <= 100000, "pcx_clock_probe_dev: spin of %u us (1 .. 100000)", spin_us);
+    return launch_clock_probe(mhz_dev, spin_us, as_stream(st));
+}
 
 
 // A handle belongs to ONE device: the one current on the calling thread at the first call that

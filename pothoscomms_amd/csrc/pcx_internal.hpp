@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "pcx.h"
+#include "pcx_qformat.hpp"
 
 namespace pcx {
 
@@ -57,8 +58,15 @@ inline int q_bits(int s)
     }
     return 0;
 }
-// Pothos::Util::floatToQ<T>(x) for integer T: T(std::ldexp(x, 4*sizeof(T)))
-int64_t float_to_q(double x, int qbits);
+// fractional bits of an integer element type's Q format under a reading: half the Q word, or half the element word
+inline int q_frac_bits(const QFormat &f, int scalar) { return f.frac == PCX_Q_FRAC_HALF_ELEM ? 4 * scalar_bytes(scalar) : q_bits(scalar) / 2; }
+inline QShift q_shift(const QFormat &f, int scalar) { return QShift{q_frac_bits(f, scalar), f.from}; }
+// Pothos::Util::floatToQ<T>(x) for integer T of qbits bits: T(std::ldexp(x, frac_bits)), the value truncated by the cast
+// (PCX_Q_TRUNCATE) or rounded to nearest first (PCX_Q_NEAREST)
+int64_t float_to_q(double x, int qbits, int frac_bits, int rounding);
+inline int64_t float_to_q(double x, int scalar, const QFormat &f) { return float_to_q(x, q_bits(scalar), q_frac_bits(f, scalar), f.to); }
+QFormat process_qformat();                                   // pcx_set_qformat's current value
+int qformat_from_api(const pcx_qformat *q, QFormat *out);    // validates; NULL -> the process-wide reading
 
 // growable device workspace owned by a handle
 struct DevBuf {
@@ -184,8 +192,8 @@ inline unsigned rounds_grid(size_t units, unsigned slots, unsigned rounds)
 
 // ---- kernel launchers implemented in the .hip files ----
 int launch_zero_words(void *p, size_t nwords, hipStream_t st);   // (elementwise.hip) a kernel, so that a captured reset replays
-int launch_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n, hipStream_t st);
-int launch_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n, hipStream_t st);
+int launch_rotate(int scalar, double pr, double pi, const QFormat &qf, const void *in, void *out, size_t n, hipStream_t st);
+int launch_scale(int scalar, int is_complex, double factor, const QFormat &qf, const void *in, void *out, size_t n, hipStream_t st);
 int launch_abs(int scalar, int is_complex, const void *in, void *out, size_t n, hipStream_t st);
 int launch_conj(int scalar, const void *in, void *out, size_t n, hipStream_t st);
 int launch_angle(int scalar, const void *in, void *out, size_t n, hipStream_t st);
@@ -195,6 +203,7 @@ int launch_combine_complex(int scalar, const void *re, const void *im, void *out
 // out[i] = angle(in[i]*_prev); _prev(i=0) := *prev_in (already conjugated); *prev_out := conj(in[n-1])
 int launch_freqdemod(int scalar, const void *in, void *out, size_t n, const void *prev_in, void *prev_out, hipStream_t st);
 int launch_fill_uniform_f32(float *dst, size_t n, uint64_t seed, uint64_t offset, hipStream_t st);
+int launch_clock_probe(float *mhz_dev, unsigned spin_us, hipStream_t st);
 
 // FIR: generic polyphase kernel (all types; EXACT = reference order, unfused)
 struct FirGeom {
@@ -202,13 +211,14 @@ struct FirGeom {
     const uint32_t *rowLen;  // device, L entries
     const void *rowTaps;     // device, L*K entries of the tap type (Q precision), row-major
 };
+// (qs: the integer types' fromQ -- shift and rounding, pcx_qformat.hpp; ignored by the float types)
 int launch_fir_generic(int scalar, int is_complex, int complex_taps, bool exact, const FirGeom &g, const void *in,
-                       void *out, size_t n_out, hipStream_t st);
+                       void *out, size_t n_out, QShift qs, hipStream_t st);
 // complex_int16 stream, complex taps within int16 after floatToQ, M = L = 1: packed dot-product kernel; tapsP = 2K dwords
-int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, bool in8, hipStream_t st);
+int launch_fir_ci16_dot2(const void *in, void *out, size_t n_out, size_t K, const void *tapsP, bool in8, QShift qs, hipStream_t st);
 // M = L = 1, every type: register sliding window (fir_generic.hip); taps24 = all Q taps fit 24 signed bits
 int launch_fir_slide(int scalar, int is_complex, int complex_taps, bool exact, bool taps24, const FirGeom &g, const void *in,
-                     void *out, size_t n_out, hipStream_t st);
+                     void *out, size_t n_out, QShift qs, hipStream_t st);
 // FIR: fast LDS-tiled direct form, complex_float32, M=L=1.  taps_rev: device array of
 // Kp (K rounded up to 8) cf32 taps in reversed order g[m] = h[K-1-m], zero padded
 int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_out, const void *taps_rev, size_t K,
@@ -227,9 +237,9 @@ int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, si
 int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
                             const void *tw, hipStream_t st);
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
-                        const void *tw, int io, size_t M, hipStream_t st);
+                        const void *tw, int io, size_t M, QShift qs, hipStream_t st);
 int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n, const void *tw,
-                        int io, size_t M, hipStream_t st);
+                        int io, size_t M, QShift qs, hipStream_t st);
 
 // real float32 stream, real taps, M=L=1: two real blocks per complex transform
 int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,

@@ -365,14 +365,17 @@ int pcx_shard_configure(pcx_shard *s, size_t shard_elems)
     }
     s->C = shard_elems;
     // Several shards on ONE device (the one-GPU rehearsal; a node with fewer devices than shards) share its 1024 resident
-    // workgroup slots: each shard's persistent launch takes its share, so that all of them run side by side and end together.
-    // With 1024 each the launches queue behind one another's workgroups: two shards 0.2196 ms per 64 Mi samples against
-    // 0.1988 with 512 each (one 64 Mi launch: 0.1971; tools/ab_gated_slots.sh, profiles/r03/shard_probe.txt).
+    // workgroup slots.  TWO shards side by side want half each, so that both launches are resident at once and end together
+    // (two 32 Mi-sample shards: 0.2196 ms with 1024 each, 0.1988 with 512 each; one 64 Mi launch 0.1971; tools/ab_gated_slots.sh,
+    // profiles/r03/shard_probe.txt).  MORE shards must NOT go on dividing: the runtime maps a process's streams onto four hardware
+    // queues, so no more than four of the launches run side by side whatever their size, and eight launches of 128 workgroups leave
+    // half the device idle -- configs[3]'s eight 64 Mi-sample shards on one device: 3.00 ms per pass at 128 slots each, 1.82 at 256,
+    // 1.57 at 512, 1.55 at 1024 (one 512 Mi launch: 1.50); 512 is within 1.5 % of the best for every shard count from 2 to 8
+    // (profiles/r04/shard_probe_c3.txt, shard_probe_c3_slots.txt).  A device that carries ONE shard gives it all 1024.
     for (int g = 0; g < s->G; g++) {
         unsigned same = 0;
         for (int k = 0; k < s->G; k++) same += s->dev[k] == s->dev[g];
-        unsigned slots = 1024 / same / 128 * 128;
-        if (slots < 128) slots = 128;
+        const unsigned slots = same >= 2 ? 512 : 1024;
         fir_set_slots(s->fir[g], slots);
         if (s->chain[g]) fmchain_set_slots(s->chain[g], slots);
     }

@@ -424,6 +424,12 @@ def fill_uniform_f32_dev(t, seed, offset=0, stream=None):
     return t
 
 
+def clock_probe(out, spin_us, stream):
+    """pcx_clock_probe_dev: one wave on `stream` (a raw stream pointer or torch stream) spins for spin_us and writes the shader clock in
+    MHz to the float32 CUDA tensor `out`."""
+    _lib.check(_lib.load().pcx_clock_probe_dev(_dev_ptr(out), int(spin_us), _stream_ptr(stream)))
+
+
 class NodeStream(_Handle):
     """pcx_shard_*: ONE complex_float32 stream over several devices from ONE process -- per-device FIR handles and
     streams, the tap-length halo exchanged natively by RCCL send/recv (or peer copies), include/pcx.h."""

@@ -35,15 +35,28 @@ def _d2h(L, ptr, rows, cols, dtype=np.float32):
     return a
 
 
-def _fill(L, ns, K, seed):
-    """every shard's [K-1 history | C samples] straight from the node-wide counter-hash stream (shard g starts at sample g*C), then
-    NaN over every halo slot but shard 0's: only the exchange of the pass can make the seams right"""
+def _fill(L, ns, K, seed, fm=None):
+    """every shard's [K-1 history | C samples] straight from the node-wide stream (shard g starts at sample g*C) -- the counter-hash
+    stream of the bench, or (fm: a device tensor of K-1+C samples) the FM test signal at a different amplitude in every shard --
+    then NaN over every halo slot but shard 0's: only the exchange of the pass can make the seams right"""
+    import torch
+
     from pothoscomms_amd import _lib
     halo = K if getattr(ns, "chain", False) else K - 1
     nan = np.full((halo, 2), np.nan, np.float32)
     for g in range(ns.nshards):
         i, _, s, _ = ns.buffers(g)
-        _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (K - 1 + ns.C), seed, 2 * g * ns.C, C.c_void_p(s)))
+        if fm is None:
+            _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (K - 1 + ns.C), seed, 2 * g * ns.C, C.c_void_p(s)))
+        else:
+            # the tile of the test signal divides the shard length, so every shard would hold the SAME samples and a halo taken from
+            # the wrong shard would go unnoticed: each shard (and each pass) gets its own amplitude -- not its own phase: a phase jump
+            # at the seam could bring the filter output close to zero there, where its angle is ill-conditioned
+            xg = fm * (1.0 + 0.05 * g + 0.001 * seed)
+            torch.cuda.synchronize()
+            _lib.check(L.pcx_memcpy_d2d(C.c_void_p(i), C.c_void_p(xg.data_ptr()), 8 * (K - 1 + ns.C), C.c_void_p(s)))
+            _lib.check(L.pcx_stream_sync(C.c_void_p(s)))
+            del xg
         if g > 0:
             _lib.check(L.pcx_memcpy_h2d(C.c_void_p(i - 8 * (halo - (K - 1))), nan.ctypes.data_as(C.c_void_p), nan.nbytes, C.c_void_p(s)))
         _lib.check(L.pcx_stream_sync(C.c_void_p(s)))
@@ -138,8 +151,14 @@ def test_c3_split_of_the_fused_chain_eight_shards_of_64Mi(oracle):
     xa = torch.zeros((16 + K + Cs, 2), dtype=torch.float32, device="cuda:0")
     y = torch.empty((Cs + 1,), dtype=torch.float32, device="cuda:0")
     y_shard = torch.empty_like(y)
-    for rep, seed in enumerate((5, 51)):      # C4 is seed 5
-        _fill(L, ns, K, seed)
+    # SURVEY 8d's C4 signal (FM, small noise: the envelope never vanishes, so the 1e-5 bar on the ANGLE is meaningful -- on a stream of
+    # uniform noise the filter output comes arbitrarily close to zero and its angle is ill-conditioned there): 1 Mi samples from
+    # taps.fm_test_signal, tiled on the device; the phase jumps at tile and shard seams are part of the stream both sides see
+    tile = torch.from_numpy(tp.fm_test_signal(1 << 20).view(np.float32).reshape(-1, 2)).to("cuda:0")
+    fm = tile.repeat((K - 1 + Cs + (1 << 20) - 1) // (1 << 20), 1)[:K - 1 + Cs].contiguous()
+    del tile
+    for rep, seed in enumerate((5, 51)):
+        _fill(L, ns, K, seed, fm)
         ns.step()
         ns.sync()
         bufs = [ns.buffers(g) for g in range(G)]
@@ -153,6 +172,8 @@ def test_c3_split_of_the_fused_chain_eight_shards_of_64Mi(oracle):
             got = np.concatenate([_d2h(L, bufs[g - 1][1] + 4 * (Cs - W), W, 0), _d2h(L, bufs[g][1], W, 0)])
             assert np.isfinite(got).all(), "seam %d pass %d" % (g, rep)
             assert ang_err(got, ref) <= TOL, "seam %d pass %d: %g" % (g, rep, ang_err(got, ref))
+            # the halo slot (K samples, one in front of the history) holds exactly the left neighbour's tail
+            assert np.array_equal(_d2h(L, bufs[g][0] - 8, K, 2), left[W:]), "halo %d pass %d" % (g, rep)
         for g in range(G):
             i, o, s, d = bufs[g]
             extra = 0 if g == 0 else 1        # shard 0: [K-1 history | C] -> C outputs; the others: [K halo | C] -> 1 + C, the first dropped

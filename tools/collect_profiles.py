@@ -15,6 +15,8 @@ KERNELS = {
     "direct255": ("fir_cf32_direct_kernel", [C + "fir_direct.hip"]),
     "decim8": ("fir_cf32_ols4096_decim_batched_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
     "interp4": ("fir_cf32_ols4096_interp_batched_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
+    "fir255_i16": ("fir_cf64_ols_kernel", [C + "fir_ols_f64.hip", C + "fft_f64.hpp"]),
+    "rotate": ("map_kernel", [C + "elementwise.hip", C + "vec_io.hpp"]),
 }
 def hashes(files):
     return {f: hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] for f in files}
@@ -28,14 +30,16 @@ for name in ("bench_default.json", "bench_other_workloads.jsonl", "bench_driver_
              "ab_sched.txt", "ab_oversub.txt", "ab_fft4096_family.txt", "ab_fft_family_rounds.txt", "shard_probe.txt", "host_path.txt", "two_blocks.txt", "chain_path.txt", "pcie_lab.txt", "ubench_roofs.txt",
              "ols_lab_summary.txt", "sweep_fir_taps.txt", "sweep_elementwise.txt", "sweep_fft_sizes.txt", "sweep_fft_f64.txt",
              "sweep_fft_mixed.txt", "sweep_fir_f64.txt", "real_f32_fir.txt", "ols_lab3_summary.txt", "transient_probe.txt", "shard4_trace.txt",
-             "sweep_fft_q15_large.txt", "bench_native_two_shards_one_gpu.json", "bench_native_two_shards_one_gpu_fmchain.json"):
+             "sweep_fft_q15_large.txt", "bench_native_two_shards_one_gpu.json", "bench_native_two_shards_one_gpu_fmchain.json",
+             "bench_native_c3_eight_shards_one_gpu.json", "bench_native_c3_eight_shards_one_gpu_fmchain.json", "bench_eight_ranks_one_gpu_gloo.json",
+             "clk_lab.txt", "shard_probe_c3.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 f = newest(os.path.join(src, "bench_kt", "**", "*_kernel_stats.csv"))
 if f:
     shutil.copy(f, os.path.join(dst, "bench_fir255_kernel_stats.csv"))
 traffic = {}
-for wl in ("fir255", "fft4096", "fmchain", "direct255", "decim8", "interp4"):
+for wl in KERNELS:
     summ = os.path.join(src, wl, "summary.txt")
     if not os.path.exists(summ):
         continue
@@ -46,9 +50,13 @@ for wl in ("fir255", "fft4096", "fmchain", "direct255", "decim8", "interp4"):
     txt = open(summ).read()
     fetch = re.search(r"FETCH_SIZE\s+([0-9.e+]+)", txt)
     write = re.search(r"WRITE_SIZE\s+([0-9.e+]+)", txt)
+    counters = {m.group(1): float(m.group(2)) for m in re.finditer(r"^pmc\s+(\S+)\s+([0-9.e+]+)", txt, re.M)
+                if m.group(1) in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS", "SQ_INSTS_SALU",
+                                  "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE")}
     if fetch and write:
         fk, wk = float(fetch.group(1)), float(write.group(1))
         traffic[wl] = {
+            "counters": counters,
             "kernel": KERNELS[wl][0],
             "sources": hashes(KERNELS[wl][1]),
             "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),

@@ -1,21 +1,29 @@
 # The judged evidence set, produced on the GPU box:  gpurun -- bash tools/refresh_profiles.sh [outdir]
 # then, here:  python tools/collect_profiles.py <outdir> profiles/<round>
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=${1:-gpurun_out/r03b}; rm -rf $O; mkdir -p $O
+O=${1:-gpurun_out/r04b}; rm -rf $O; mkdir -p $O
 ulimit -c 0
-make -s -C tools ubench ols_lab3 > /dev/null 2>&1
+make -s -C tools ubench ols_lab3 clk_lab > /dev/null 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> /dev/null
 for w in fft4096 fmchain rotate direct255 decim8 interp4 fir255_i16; do python bench.py --workload $w 2>/dev/null | tail -1 >> $O/bench_other_workloads.jsonl; done
 PCX_BENCH_BACKEND=gloo python bench.py --gpus 2 --shard 33554432 --steps 50 --warmup 10 --no-cpu > $O/bench_two_ranks_one_gpu_gloo.json 2> /dev/null
 python bench.py --driver native --gpus 2 --native-devices 0,0 --shard 33554432 --no-cpu > $O/bench_native_two_shards_one_gpu.json 2> /dev/null
 python bench.py --driver native --gpus 2 --native-devices 0,0 --shard 33554432 --workload fmchain --no-cpu > $O/bench_native_two_shards_one_gpu_fmchain.json 2> /dev/null
+# configs[3] rehearsed on this one GPU: eight shards of 64 Mi samples each behind the C ABI, and eight RANKS (gloo, reduced shard)
+python bench.py --driver native --gpus 8 --native-devices 0,0,0,0,0,0,0,0 --no-cpu > $O/bench_native_c3_eight_shards_one_gpu.json 2> /dev/null
+python bench.py --driver native --gpus 8 --native-devices 0,0,0,0,0,0,0,0 --workload fmchain --no-cpu > $O/bench_native_c3_eight_shards_one_gpu_fmchain.json 2> /dev/null
+PCX_BENCH_BACKEND=gloo python bench.py --gpus 8 --shard 8388608 --steps 50 --warmup 10 --no-cpu > $O/bench_eight_ranks_one_gpu_gloo.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -- python3 bench.py --steps 2000 --warmup 50 --no-cpu > $O/bench_kt.log 2>&1
 bash tools/prof.sh fir255 $O/fir255 ols4096 > /dev/null 2>&1
 bash tools/prof.sh fft4096 $O/fft4096 fft_r16 > /dev/null 2>&1
 bash tools/prof.sh fmchain $O/fmchain fmchain > /dev/null 2>&1
 bash tools/prof.sh decim8 $O/decim8 decim > /dev/null 2>&1
 bash tools/prof.sh interp4 $O/interp4 interp > /dev/null 2>&1
+bash tools/prof.sh fir255_i16 $O/fir255_i16 fir_cf64_ols > /dev/null 2>&1
+bash tools/prof.sh direct255 $O/direct255 fir_cf32_direct > /dev/null 2>&1
+bash tools/prof.sh rotate $O/rotate map_kernel > /dev/null 2>&1
+timeout 60 tools/clk_lab > $O/clk_lab.txt 2>&1
 timeout 300 tools/ols_lab3 3 > $O/ols_lab3_summary.txt 2>&1
 python tools/transient_probe.py 20 24 0 2>/dev/null > $O/transient_probe.txt
 python tools/transient_probe.py 20 24 5 2>/dev/null >> $O/transient_probe.txt

@@ -15,7 +15,7 @@ if len(sys.argv) < 2:
         subprocess.run([sys.executable, os.path.abspath(__file__), str(G)], check=False)
     sys.exit(0)
 L = _lib.load()
-total = 64 * 1024 * 1024
+total = int(os.environ.get("PCX_PROBE_TOTAL", 64 * 1024 * 1024))     # PCX_PROBE_TOTAL=536870912 with G = 8: configs[3]'s shards on one device
 h = tp.c1_taps()
 for G in [int(a) for a in sys.argv[1:]]:
     ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY if G > 1 else device.NodeStream.RCCL)
@@ -26,11 +26,11 @@ for G in [int(a) for a in sys.argv[1:]]:
         _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (len(h) - 1 + total // G), 2, 2 * g * (total // G), C.c_void_p(s)))
     import os as _os
     short = bool(_os.environ.get("PCX_PROBE_SHORT"))
-    for _ in range(20 if short else 400):
+    for _ in range(20 if short else max(40, 400 * (64 << 20) // total)):
         ns.step()
     ns.sync()
     t0 = time.perf_counter()
-    n = 10 if short else 300
+    n = 10 if short else max(30, 300 * (64 << 20) // total)
     for _ in range(n):
         ns.step()
     host = (time.perf_counter() - t0) / n        # what the host spends queueing one pass

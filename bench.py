@@ -418,6 +418,7 @@ class Workload:
     limiter = None             # what the profile says holds the kernel below the HBM roof, when it is not the memory system
     blocks = None              # overlap-save blocks per launch (for valu.per_wave_block)
     owner = None               # the ShardedFir / ShardedFmChain, when the stream is sharded over ranks
+    inputs = ()                # the device tensors the step reads (tools/floor_table.py zeroes them for the "kernel on zeros" row)
 
 
 def build_workload(wl, C, dev, rank, world, args):
@@ -437,6 +438,7 @@ def build_workload(wl, C, dev, rank, world, args):
         # overwrite the halo through RCCL
         device.fill_uniform_f32_dev(sf.buf, seed=2, offset=2 * rank * C)
         W.owner = sf
+        W.inputs = (sf.buf,)
         W.units = C
         W.roof_bytes = 16.0 * C
         W.read_bytes = 8.0 * C
@@ -464,6 +466,7 @@ def build_workload(wl, C, dev, rank, world, args):
         W.read_bytes = 8.0 * W.units
         W.kernel_name = "fft_r16_kernel<12>"
         W.step = lambda: fft.transform_dev(x, y, nframes)
+        W.inputs = (x,)
         W.desc = {"workload": "4096-pt complex_float32 FFT (/comms/fft), 65536 frames per GPU", "frames": nframes}
         W.metric = "Msamples/s complex_float32 4096-pt FFT"
     elif wl == "fmchain":
@@ -475,6 +478,7 @@ def build_workload(wl, C, dev, rank, world, args):
             sc = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
             device.fill_uniform_f32_dev(sc.buf, seed=5, offset=2 * rank * n)
             W.owner = sc
+            W.inputs = (sc.buf,)
             W.step = sc.step
         else:
             ch = device.FmChain()
@@ -487,6 +491,7 @@ def build_workload(wl, C, dev, rank, world, args):
             y = torch.empty((n,), dtype=torch.float32, device=dev)
             device.fill_uniform_f32_dev(x, seed=5, offset=0)
             W.step = lambda: ch.process_dev(x, y, n + 126, n)
+            W.inputs = (x,)
         W.units = n
         W.roof_bytes = 12.0 * n
         W.read_bytes = 8.0 * n
@@ -515,6 +520,7 @@ def build_workload(wl, C, dev, rank, world, args):
         W.read_bytes = 8.0 * n
         W.kernel_name = "fir_cf32_ols4096_decim_batched_kernel" if wl == "decim8" else "fir_cf32_ols4096_interp_batched_kernel"
         W.step = lambda: f.process_dev(x, y)
+        W.inputs = (x,)
         W.desc = {"workload": "255-tap complex_float32 FIR, %s, %d input samples per GPU" %
                               ("decimation 8 folded into the spectrum (input rate)" if wl == "decim8"
                                else "interpolation 4 from the replicated spectrum, 255 taps per phase (output rate)", n),
@@ -535,6 +541,7 @@ def build_workload(wl, C, dev, rank, world, args):
         W.read_bytes = 4.0 * n
         W.kernel_name = "fir_cf64_ols_kernel"
         W.step = lambda: f.process_dev(x, y)
+        W.inputs = (x,)
         W.desc = {"workload": "255-tap complex_int16 FIR (bit-exact, double-precision overlap-save), %d samples per GPU" % n, "taps": 255}
         W.metric = "Msamples/s complex_int16 255-tap FIR"
         W.dtype = "f64"
@@ -549,6 +556,7 @@ def build_workload(wl, C, dev, rank, world, args):
         W.read_bytes = 8.0 * n
         W.kernel_name = "map_kernel<rotate>"
         W.step = lambda: device.rotate(x, 0.7, scalar=device.F32, out=y, n=n)
+        W.inputs = (x,)
         W.desc = {"workload": "/comms/rotate complex_float32, %d samples" % n}
         W.metric = "Msamples/s complex_float32 rotate"
     W.desc["setup_passes"] = args.settle

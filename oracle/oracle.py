@@ -335,6 +335,18 @@ def coeff_label_scan(elems, label_index, label_match, have_label_id=True):
     return n, idx.value
 
 
+Q_HALF_Q, Q_HALF_ELEM = 0, 1            # pcx_q_frac
+Q_TRUNCATE, Q_NEAREST = 0, 1            # pcx_q_to
+Q_FLOOR, Q_TOWARD_ZERO, Q_ROUND = 0, 1, 2   # pcx_q_from
+QFORMATS = [(f, t, r) for f in (0, 1) for t in (0, 1) for r in (0, 1, 2)]   # the twelve readings (profiles/r02/qformat_enumeration.txt)
+
+
+def set_qformat(frac=0, float_to_q=0, from_q=0):
+    """The Q-format reading of the integer Fir / rotate / scale restatements (orc_set_qformat; process-wide).  Set it BEFORE creating
+    a Fir or setting its taps: taps are quantised when they are set.  set_qformat() restores the default."""
+    lib().orc_set_qformat(int(frac), int(float_to_q), int(from_q))
+
+
 def fill_uniform_f32(n_scalars, seed, offset=0):
     a = np.empty(n_scalars, dtype=np.float32)
     lib().orc_fill_uniform_f32(_ptr(a), n_scalars, seed, offset)

@@ -28,8 +28,9 @@
  *     survive (tools/qformat_enumeration.py) -- the fractional
  *     bit count is half the Q word or half the element word, the same in both
  *     directions; rounding is not pinned at all.  This restatement is one of
- *     the 12.  Integer FIR/Rotate/Scale are bit-exact against it, not against
- *     the (absent) header.
+ *     the 12 by default and takes ANY of the 12 as a parameter (orc_set_qformat,
+ *     mirroring pcx_qformat of include/pcx.h): integer FIR/Rotate/Scale are
+ *     bit-exact against it under every reading, not against the (absent) header.
  *   - The pinning tests run on BOTH boxes (tests/test_oracle_cpu.py under
  *     -m "not gpu" and under -m gpu): this library binds the glibc / libgcc_s
  *     of the machine it is loaded on.
@@ -104,11 +105,25 @@ static int64_t wrap_bits(uint64_t v, int bits)
     if (v >> (bits - 1)) v |= ~m;
     return (int64_t)v;
 }
-/* Pothos::Util::floatToQ<T>(x), integer T: T(std::ldexp(x, 4*sizeof(T)))
- * (PothosCore QFormat.hpp; call sites FIRFilter.cpp:348, Rotate.cpp:74, Scale.cpp:73) */
-static int64_t float_to_q(double x, int qbits)
+/* The Q-format READING in force (include/pcx.h, pcx_qformat): QFormat.hpp is not in the reference tree and the reference's
+ * tests leave twelve readings standing, so the restatement takes the reading as a parameter exactly as the product does --
+ * fractional bits n = half the Q word (0) or half the ELEMENT word (1); floatToQ truncating (0) or to nearest, ties away (1);
+ * fromQ floor (0), toward zero (1) or to nearest, ties up (2).  All zero = the default.  Process-wide (this is a test library):
+ * set it BEFORE creating a filter or setting its taps -- they are quantised when they are set. */
+static int g_q_frac = 0, g_q_to = 0, g_q_from = 0;
+ORC_EXPORT void orc_set_qformat(int frac, int float_to_q_mode, int from_q_mode)
 {
-    const double v = ldexp(x, qbits / 2);
+    g_q_frac = frac; g_q_to = float_to_q_mode; g_q_from = from_q_mode;
+}
+static int elem_bits(int st) { return st == ORC_I64 ? 64 : st == ORC_I32 ? 32 : st == ORC_I16 ? 16 : 8; }
+static int q_frac_bits(int st) { return g_q_frac ? elem_bits(st) / 2 : q_bits(st) / 2; }
+/* Pothos::Util::floatToQ<T>(x), integer T of q_bits(st) bits: T(std::ldexp(x, n))
+ * (PothosCore QFormat.hpp; call sites FIRFilter.cpp:348, Rotate.cpp:74, Scale.cpp:73) */
+static int64_t float_to_q(double x, int st)
+{
+    const int qbits = q_bits(st);
+    double v = ldexp(x, q_frac_bits(st));
+    if (g_q_to) v = round(v);
     /* double -> integer conversion as x86-64 cvttsd2si does (out of range -> MIN) */
     if (qbits == 64) {
         if (!(v >= -9223372036854775808.0 && v < 9223372036854775808.0)) return INT64_MIN;
@@ -122,8 +137,18 @@ static int64_t float_to_q(double x, int qbits)
     if (!(v >= -2147483648.0 && v < 2147483648.0)) return 0;
     return (int16_t)(uint16_t)(uint32_t)(int32_t)v;
 }
-/* Pothos::Util::fromQ<T>(q), integer Q: T(q >> 4*sizeof(Q)) (arithmetic shift) */
-static int64_t from_q(int64_t q, int qbits) { return q >> (qbits / 2); }
+/* Pothos::Util::fromQ<T>(q), q already wrapped to the Q width: the quotient by 2^n under the reading's rounding, in 128-bit
+ * arithmetic so that no intermediate can overflow (the device does the same with shifts and masks: an independent formulation) */
+static int64_t from_q(int64_t q, int st)
+{
+    const int n = q_frac_bits(st);
+    const __int128 d = (__int128)1 << n, v = q;
+    if (g_q_from == 1) return (int64_t)(v / d);                             /* toward zero: C division */
+    const __int128 num = g_q_from == 2 ? v + (d >> 1) : v;                  /* nearest: add half first */
+    __int128 fl = num / d;
+    if (num % d != 0 && num < 0) fl -= 1;                                   /* floor */
+    return (int64_t)fl;
+}
 
 /* ===================================================================== *
  *  FIR  (filter/FIRFilter.cpp)
@@ -175,7 +200,7 @@ static void fir_update_internals(orc_fir *f)
                 /* floatToQ<QTapsType>: float Q -> plain narrowing cast */
                 f->rowTapsF[(j * K + len) * w + c] = (f->st == ORC_F32) ? (double)(float)t : t;
                 f->rowTapsF32[(j * K + len) * w + c] = (float)t;
-                if (!is_float_type(f->st)) f->rowTapsQ[(j * K + len) * w + c] = float_to_q(t, q_bits(f->st));
+                if (!is_float_type(f->st)) f->rowTapsQ[(j * K + len) * w + c] = float_to_q(t, f->st);
             }
             len++;
         }
@@ -325,10 +350,10 @@ static size_t fir_loop_int(const orc_fir *f, const void *xbase, ptrdiff_t x0, vo
                     }
                 }
             }
-            if (!f->cplx) store_int(y, nout, st, from_q(wrap_bits(ar, qb), qb));
+            if (!f->cplx) store_int(y, nout, st, from_q(wrap_bits(ar, qb), st));
             else {
-                store_int(y, 2 * nout, st, from_q(wrap_bits(ar, qb), qb));
-                store_int(y, 2 * nout + 1, st, from_q(wrap_bits(ai, qb), qb));
+                store_int(y, 2 * nout, st, from_q(wrap_bits(ar, qb), st));
+                store_int(y, 2 * nout + 1, st, from_q(wrap_bits(ai, qb), st));
             }
             nout++;
         }
@@ -934,11 +959,11 @@ ORC_EXPORT int orc_rotate(int st, double phase, const void *in, void *out, size_
         }
     } else {
         const int qb = q_bits(st);
-        const uint64_t a = (uint64_t)float_to_q(c, qb), b = (uint64_t)float_to_q(s, qb);
+        const uint64_t a = (uint64_t)float_to_q(c, st), b = (uint64_t)float_to_q(s, st);
         for (size_t i = 0; i < n; i++) {
             const uint64_t cc = (uint64_t)load_int(in, 2 * i, st), d = (uint64_t)load_int(in, 2 * i + 1, st);
-            store_int(out, 2 * i, st, from_q(wrap_bits(a * cc - b * d, qb), qb));
-            store_int(out, 2 * i + 1, st, from_q(wrap_bits(a * d + b * cc, qb), qb));
+            store_int(out, 2 * i, st, from_q(wrap_bits(a * cc - b * d, qb), st));
+            store_int(out, 2 * i + 1, st, from_q(wrap_bits(a * d + b * cc, qb), st));
         }
     }
     return 0;
@@ -964,9 +989,9 @@ ORC_EXPORT int orc_scale(int st, int is_complex, double factor, const void *in, 
         for (size_t i = 0; i < ns; i++) y[i] = x[i] * factor;
     } else {
         const int qb = q_bits(st);
-        const uint64_t f = (uint64_t)float_to_q(factor, qb);
+        const uint64_t f = (uint64_t)float_to_q(factor, st);
         for (size_t i = 0; i < ns; i++)
-            store_int(out, i, st, from_q(wrap_bits(f * (uint64_t)load_int(in, i, st), qb), qb));
+            store_int(out, i, st, from_q(wrap_bits(f * (uint64_t)load_int(in, i, st), qb), st));
     }
     return 0;
 }

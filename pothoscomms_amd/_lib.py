@@ -33,6 +33,26 @@ class Unsupported(PcxError, NotImplementedError):
     """Valid in the reference, not implemented on the device path."""
 
 
+# pcx_q_frac / pcx_q_to / pcx_q_from
+Q_FRAC_HALF_Q, Q_FRAC_HALF_ELEM = 0, 1
+Q_TRUNCATE, Q_NEAREST = 0, 1
+Q_FLOOR, Q_TOWARD_ZERO, Q_ROUND = 0, 1, 2
+
+
+class QFormat(C.Structure):
+    """pcx_qformat: the floatToQ / fromQ reading of the integer element types (include/pcx.h)."""
+    _fields_ = [("frac", C.c_int), ("float_to_q", C.c_int), ("from_q", C.c_int)]
+
+
+def qformat_ptr(q):
+    """None -> NULL (the process-wide reading); a QFormat or a (frac, float_to_q, from_q) triple -> pointer to a pcx_qformat"""
+    if q is None:
+        return None
+    if not isinstance(q, QFormat):
+        q = QFormat(*[int(v) for v in q])
+    return C.byref(q)
+
+
 _vp, _sz, _i, _d = C.c_void_p, C.c_size_t, C.c_int, C.c_double
 _psz = C.POINTER(C.c_size_t)
 
@@ -61,6 +81,9 @@ SIGNATURES = {
     "pcx_fir_set_decimation": (_i, [_vp, _sz]),
     "pcx_fir_set_interpolation": (_i, [_vp, _sz]),
     "pcx_fir_set_algo": (_i, [_vp, _i]),
+    "pcx_fir_set_qformat": (_i, [_vp, _vp]),
+    "pcx_set_qformat": (_i, [_vp]),
+    "pcx_get_qformat": (_i, [_vp]),
     "pcx_fir_get_geometry": (_i, [_vp, _psz, _psz]),
     "pcx_fir_last_algo": (_i, [_vp]),
     "pcx_fir_set_slots": (_i, [_vp, C.c_uint]),
@@ -81,6 +104,10 @@ SIGNATURES = {
     "pcx_rotate_dev": (_i, [_i, _d, _d, _vp, _vp, _sz, _vp]),
     "pcx_scale": (_i, [_i, _i, _d, _vp, _vp, _sz]),
     "pcx_scale_dev": (_i, [_i, _i, _d, _vp, _vp, _sz, _vp]),
+    "pcx_rotate_q": (_i, [_i, _d, _d, _vp, _vp, _vp, _sz]),
+    "pcx_rotate_q_dev": (_i, [_i, _d, _d, _vp, _vp, _vp, _sz, _vp]),
+    "pcx_scale_q": (_i, [_i, _i, _d, _vp, _vp, _vp, _sz]),
+    "pcx_scale_q_dev": (_i, [_i, _i, _d, _vp, _vp, _vp, _sz, _vp]),
     "pcx_abs": (_i, [_i, _i, _vp, _vp, _sz]),
     "pcx_abs_dev": (_i, [_i, _i, _vp, _vp, _sz, _vp]),
     "pcx_conj": (_i, [_i, _vp, _vp, _sz]),

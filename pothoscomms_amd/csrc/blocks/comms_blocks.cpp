@@ -88,6 +88,43 @@ void check(int rc, const std::string &where)
     throw pcxfw::Exception(where, msg);
 }
 
+// EXTENSION (not in the reference) of the integer FIR / Rotate / Scale blocks: setQFormat("HALF_Q,TRUNCATE,FLOOR") names the reading of
+// Pothos::Util::floatToQ / fromQ the block computes with (include/pcx.h, pcx_qformat: PothosCore's QFormat.hpp is not part of the
+// reference tree and the reference's tests leave twelve readings standing).  Three comma-separated words -- fractional bits HALF_Q |
+// HALF_ELEM; floatToQ TRUNCATE | NEAREST; fromQ FLOOR | TOWARD_ZERO | ROUND -- or "DEFAULT" for the process-wide reading.
+struct BlockQFormat {
+    bool set = false;          // false: the process-wide reading (a NULL pcx_qformat)
+    pcx_qformat q{0, 0, 0};
+    std::string spec = "DEFAULT";
+    const pcx_qformat *ptr() const { return set ? &q : nullptr; }
+    void parse(const std::string &text, const std::string &where)
+    {
+        if (text == "DEFAULT" || text.empty()) { set = false; spec = "DEFAULT"; return; }
+        std::vector<std::string> w;
+        size_t a = 0;
+        for (;;) {
+            const size_t b = text.find(',', a);
+            std::string t = text.substr(a, b == std::string::npos ? std::string::npos : b - a);
+            while (!t.empty() && t.front() == ' ') t.erase(t.begin());
+            while (!t.empty() && t.back() == ' ') t.pop_back();
+            w.push_back(t);
+            if (b == std::string::npos) break;
+            a = b + 1;
+        }
+        pcx_qformat v{0, 0, 0};
+        bool ok = w.size() == 3;
+        if (ok) {
+            if (w[0] == "HALF_Q") v.frac = PCX_Q_FRAC_HALF_Q; else if (w[0] == "HALF_ELEM") v.frac = PCX_Q_FRAC_HALF_ELEM; else ok = false;
+            if (w[1] == "TRUNCATE") v.float_to_q = PCX_Q_TRUNCATE; else if (w[1] == "NEAREST") v.float_to_q = PCX_Q_NEAREST; else ok = false;
+            if (w[2] == "FLOOR") v.from_q = PCX_Q_FLOOR; else if (w[2] == "TOWARD_ZERO") v.from_q = PCX_Q_TOWARD_ZERO;
+            else if (w[2] == "ROUND") v.from_q = PCX_Q_ROUND; else ok = false;
+        }
+        if (!ok) throw InvalidArgumentException(where + "(" + text + ")", "expected HALF_Q|HALF_ELEM,TRUNCATE|NEAREST,FLOOR|TOWARD_ZERO|ROUND or DEFAULT");
+        q = v; set = true;
+        spec = w[0] + "," + w[1] + "," + w[2];
+    }
+};
+
 /***********************************************************************
  * Port buffers of a device-backed block: page-locked slabs
  *
@@ -232,6 +269,8 @@ public:
         // extension (not in the reference): which device kernel family serves the filter
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setKernel));
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getKernel));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setQFormat));
+        this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getQFormat));
         // extension: the block's stream spread over several devices of the node from inside work() (pcx_shard_*, pcx.h)
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, setDevices));
         this->registerCall(this, PCX_FCN_TUPLE(FIRFilter, getDevices));
@@ -291,6 +330,13 @@ public:
         _kernel = name;
     }
     std::string getKernel() const { return _kernel; }
+    // the floatToQ<QTapsType> / fromQ<OutType> reading of an integer filter (FIRFilter.cpp:300,348; BlockQFormat above)
+    void setQFormat(const std::string &spec)
+    {
+        _qformat.parse(spec, "FIRFilter::setQFormat");
+        check(pcx_fir_set_qformat(_h, _qformat.ptr()), "FIRFilter::setQFormat(" + spec + ")");
+    }
+    std::string getQFormat() const { return _qformat.spec; }
     void setWaitTaps(const bool waitTaps) { _waitTapsMode = waitTaps; }
     bool getWaitTaps() const { return _waitTapsMode; }
     void setFrameStartId(std::string id) { _frameStartId = id; }
@@ -458,6 +504,7 @@ private:
     bool _waitTapsMode, _waitTapsArmed;
     std::string _frameStartId, _frameEndId;
     std::string _kernel = "AUTO";
+    BlockQFormat _qformat;
     pcx_shard *_sh = nullptr;              // setDevices(): the stream over several devices
     std::vector<size_t> _devices;
     size_t _shardC = 0, _shardPasses = 0, _shardShort = 0;
@@ -730,6 +777,8 @@ public:
         this->registerCall(this, PCX_FCN_TUPLE(Rotate, getPhase));
         this->registerCall(this, PCX_FCN_TUPLE(Rotate, setLabelId));
         this->registerCall(this, PCX_FCN_TUPLE(Rotate, getLabelId));
+        this->registerCall(this, PCX_FCN_TUPLE(Rotate, setQFormat));
+        this->registerCall(this, PCX_FCN_TUPLE(Rotate, getQFormat));
         this->setupInput(0, dtype);
         this->setupOutput(0, dtype);
         // NB: like the reference, the phasor stays zero until setPhase() is called
@@ -744,6 +793,8 @@ public:
     double getPhase() const { return _phase; }
     void setLabelId(const std::string &id) { _labelId = id; }
     std::string getLabelId() const { return _labelId; }
+    void setQFormat(const std::string &spec) { _qformat.parse(spec, "Rotate::setQFormat"); }   // Rotate.cpp:21,74 (BlockQFormat above)
+    std::string getQFormat() const { return _qformat.spec; }
     void applyLabel(double v) { this->setPhase(v); }
     void work()
     {
@@ -753,7 +804,8 @@ public:
         auto outPort = this->output(0);
         elems = this->scanLabels(elems);
         const size_t N = elems * inPort->dtype().dimension();
-        check(pcx_rotate(_scalar, _pr, _pi, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
+        check(pcx_rotate_q(_scalar, _pr, _pi, _qformat.ptr(), inPort->buffer().template as<const void *>(),
+                           outPort->buffer().template as<void *>(), N),
               "Rotate::work()");
         inPort->consume(elems);
         outPort->produce(elems);
@@ -762,6 +814,7 @@ public:
 private:
     int _scalar;
     double _phase, _pr, _pi;
+    BlockQFormat _qformat;
 };
 Block *rotateFactory(const DType &dtype)
 {
@@ -783,6 +836,8 @@ public:
         this->registerCall(this, PCX_FCN_TUPLE(Scale, getFactor));
         this->registerCall(this, PCX_FCN_TUPLE(Scale, setLabelId));
         this->registerCall(this, PCX_FCN_TUPLE(Scale, getLabelId));
+        this->registerCall(this, PCX_FCN_TUPLE(Scale, setQFormat));
+        this->registerCall(this, PCX_FCN_TUPLE(Scale, getQFormat));
         this->setupInput(0, dtype);
         this->setupOutput(0, dtype);
     }
@@ -790,6 +845,8 @@ public:
     double getFactor() const { return _factor; }
     void setLabelId(const std::string &id) { _labelId = id; }
     std::string getLabelId() const { return _labelId; }
+    void setQFormat(const std::string &spec) { _qformat.parse(spec, "Scale::setQFormat"); }   // Scale.cpp:21,73 (BlockQFormat above)
+    std::string getQFormat() const { return _qformat.spec; }
     void applyLabel(double v) { this->setFactor(v); }
     void work()
     {
@@ -799,8 +856,8 @@ public:
         auto outPort = this->output(0);
         elems = this->scanLabels(elems);
         const size_t N = elems * inPort->dtype().dimension();
-        check(pcx_scale(_scalar, _cplx ? 1 : 0, _factor, inPort->buffer().template as<const void *>(),
-                        outPort->buffer().template as<void *>(), N),
+        check(pcx_scale_q(_scalar, _cplx ? 1 : 0, _factor, _qformat.ptr(), inPort->buffer().template as<const void *>(),
+                          outPort->buffer().template as<void *>(), N),
               "Scale::work()");
         inPort->consume(elems);
         outPort->produce(elems);
@@ -810,6 +867,7 @@ private:
     int _scalar;
     bool _cplx;
     double _factor;
+    BlockQFormat _qformat;
 };
 Block *scaleFactory(const DType &dtype)
 {

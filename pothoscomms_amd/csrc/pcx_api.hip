@@ -25,9 +25,10 @@ void set_error(const char *fmt, ...)
     g_err = buf;
 }
 
-int64_t float_to_q(double x, int qbits)
+int64_t float_to_q(double x, int qbits, int frac_bits, int rounding)
 {
-    const double v = std::ldexp(x, qbits / 2);
+    double v = std::ldexp(x, frac_bits);
+    if (rounding == PCX_Q_NEAREST) v = std::round(v);      // ties away from zero; PCX_Q_TRUNCATE leaves the truncation to the casts below
     if (qbits == 64) {
         if (!(v >= -9223372036854775808.0 && v < 9223372036854775808.0)) return INT64_MIN;
         return (int64_t)v;
@@ -38,6 +39,25 @@ int64_t float_to_q(double x, int qbits)
     }
     if (!(v >= -2147483648.0 && v < 2147483648.0)) return 0;
     return (int16_t)(uint16_t)(uint32_t)(int32_t)v;
+}
+
+// the process-wide Q-format reading (pcx_set_qformat): three ints, read whole by the control plane of a call
+static std::atomic<int> g_qf_frac{kDefaultQFormat.frac}, g_qf_to{kDefaultQFormat.to}, g_qf_from{kDefaultQFormat.from};
+QFormat process_qformat() { return QFormat{g_qf_frac.load(), g_qf_to.load(), g_qf_from.load()}; }
+static bool qformat_valid(const pcx_qformat &q)
+{
+    return (q.frac == PCX_Q_FRAC_HALF_Q || q.frac == PCX_Q_FRAC_HALF_ELEM) && (q.float_to_q == PCX_Q_TRUNCATE || q.float_to_q == PCX_Q_NEAREST) &&
+           (q.from_q == PCX_Q_FLOOR || q.from_q == PCX_Q_TOWARD_ZERO || q.from_q == PCX_Q_ROUND);
+}
+int qformat_from_api(const pcx_qformat *q, QFormat *out)
+{
+    if (!q) { *out = process_qformat(); return PCX_OK; }
+    if (!qformat_valid(*q)) {
+        set_error("pcx_qformat {frac %d, float_to_q %d, from_q %d}: unknown reading (pcx_q_frac / pcx_q_to / pcx_q_from)", q->frac, q->float_to_q, q->from_q);
+        return PCX_ERR_ARG;
+    }
+    *out = QFormat{q->frac, q->float_to_q, q->from_q};
+    return PCX_OK;
 }
 
 int DevBuf::ensure(size_t bytes)
@@ -320,6 +340,20 @@ int pcx_fill_uniform_f32_dev(float *dst, size_t n, uint64_t seed, uint64_t offse
 {
     return launch_fill_uniform_f32(dst, n, seed, offset, as_stream(st));
 }
+int pcx_set_qformat(const pcx_qformat *q)
+{
+    QFormat f = kDefaultQFormat;
+    if (q) PCX_TRY(qformat_from_api(q, &f));
+    g_qf_frac.store(f.frac); g_qf_to.store(f.to); g_qf_from.store(f.from);
+    return PCX_OK;
+}
+int pcx_get_qformat(pcx_qformat *q)
+{
+    PCX_CHECK_ARG(q, "null output");
+    const QFormat f = process_qformat();
+    q->frac = f.frac; q->float_to_q = f.to; q->from_q = f.from;
+    return PCX_OK;
+}
 int pcx_clock_probe_dev(float *mhz_dev, unsigned spin_us, void *st)
 {
     PCX_CHECK_ARG(mhz_dev, "null output");
@@ -539,6 +573,7 @@ struct pcx_fir {
     std::vector<double> taps;  // ntaps * (ctaps ? 2 : 1)
     size_t ntaps = 1, M = 1, L = 1, K = 1, inputRequire = 1;
     int algo = PCX_FIR_AUTO, last_algo = 0;
+    QFormat qf = kDefaultQFormat;   // integer element types: the floatToQ / fromQ reading (pcx_fir_set_qformat; the process-wide one at creation)
     bool dirty = true;
     DevBuf rowLen, rowTaps, tapsRev, Hspec, tw4096;
     StageBuf wsIn, wsOut;
@@ -631,7 +666,6 @@ static int fir_upload_rows(pcx_fir *h, bool integer)
     const size_t L = h->L, K = h->K, w = h->ctaps ? 2 : 1;
     std::vector<uint32_t> rowLen(L, 0);
     std::vector<TT> rows(L * K * w, TT(0));
-    const int qb = q_bits(h->scalar);
     for (size_t j = 0; j < L; j++) {
         size_t len = 0;
         for (size_t k = 0; k < K; k++) {
@@ -639,7 +673,7 @@ static int fir_upload_rows(pcx_fir *h, bool integer)
             if (i >= h->ntaps) continue;
             for (size_t c = 0; c < w; c++) {
                 const double t = h->taps[i * w + c];
-                rows[(j * K + len) * w + c] = integer ? (TT)float_to_q(t, qb) : (TT)t;  // floatToQ<QTapsType>, :348
+                rows[(j * K + len) * w + c] = integer ? (TT)float_to_q(t, h->scalar, h->qf) : (TT)t;  // floatToQ<QTapsType>, :348
             }
             len++;
         }
@@ -729,8 +763,7 @@ static int fir_sync_tables(pcx_fir *h)
     if ((h->scalar == PCX_I16 || h->scalar == PCX_I8) && h->cplx && h->M <= 65535 && h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
         // the Q-format taps exactly as the time-domain kernels use them (floatToQ<QTapsType>, FIRFilter.cpp:348), as doubles;
         // the double transform reproduces the integer convolution bit for bit while ||h_q||_2 < 2^22 (fir_ols_f64.hip)
-        const int qb = q_bits(h->scalar);
-        auto tq = [&](double t) { return h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb); };
+            auto tq = [&](double t) { return h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, h->scalar, h->qf) : (double)(int16_t)float_to_q(t, h->scalar, h->qf); };
         std::vector<std::complex<double>> hq(h->K);
         double norm2 = 0;
         for (size_t k = 0; k < h->K; k++) {
@@ -749,9 +782,8 @@ static int fir_sync_tables(pcx_fir *h)
         h->K <= 2049) {   // M > 1: rational resampling, the interleaving pass keeps one position in M
         // interpolating filters of these types: every polyphase row h_j[k] = taps[j + k L] (FIRFilter.cpp:341-350) through the
         // double-precision pipeline into a contiguous workspace row, then one interleaving pass; integers stay exact row by row
-        const int qb = q_bits(h->scalar);
-        auto tq = [&](double t) {
-            return h->scalar == PCX_F64 ? t : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb);
+            auto tq = [&](double t) {
+            return h->scalar == PCX_F64 ? t : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, h->scalar, h->qf) : (double)(int16_t)float_to_q(t, h->scalar, h->qf);
         };
         std::vector<double> rows(h->L * 2 * 4096);
         bool ok = true;
@@ -779,10 +811,9 @@ static int fir_sync_tables(pcx_fir *h)
     h->have_interp_real = false;
     if ((h->scalar == PCX_F64 || h->scalar == PCX_F32 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M <= 65535 && h->L > 1 &&
         h->L <= 64 && h->K >= 2 && h->K <= 2049) {
-        const int qb = q_bits(h->scalar);
-        auto tq = [&](double t) {
+            auto tq = [&](double t) {
             return h->scalar == PCX_F64 ? t : h->scalar == PCX_F32 ? (double)(float)t
-                 : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb);
+                 : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, h->scalar, h->qf) : (double)(int16_t)float_to_q(t, h->scalar, h->qf);
         };
         const bool integer = h->scalar == PCX_I16 || h->scalar == PCX_I8;
         std::vector<double> rows(h->L * 2 * 4096);
@@ -812,13 +843,12 @@ static int fir_sync_tables(pcx_fir *h)
     // (real float32 joins for decimating filters only: its undecimated stream has the float kernel below)
     if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8 || (h->scalar == PCX_F32 && h->M > 1)) && !h->cplx && h->M <= 65535 &&
         h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
-        const int qb = q_bits(h->scalar);
-        std::vector<std::complex<double>> hq(h->K);
+            std::vector<std::complex<double>> hq(h->K);
         double norm2 = 0;
         for (size_t k = 0; k < h->K; k++) {
             const double t = h->taps[k];
             hq[k] = h->scalar == PCX_F64 ? t : h->scalar == PCX_F32 ? (double)(float)t
-                    : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, qb) : (double)(int16_t)float_to_q(t, qb);
+                    : h->scalar == PCX_I16 ? (double)(int32_t)float_to_q(t, h->scalar, h->qf) : (double)(int16_t)float_to_q(t, h->scalar, h->qf);
             norm2 += std::norm(hq[k]);
         }
         if (h->scalar == PCX_F64 || h->scalar == PCX_F32 || norm2 < 17592186044416.0) {   // integers: ||h_q||_2 < 2^22 keeps the rounded sums exact
@@ -908,6 +938,7 @@ int pcx_fir_create(int scalar, int is_complex, int complex_taps, pcx_fir **out)
     h->taps.assign(h->ctaps ? 2 : 1, 0.0);
     h->taps[0] = 1.0;  // ctor: setTaps({1}), FIRFilter.cpp:125
     h->ntaps = 1;
+    h->qf = process_qformat();
     fir_update_internals(h);
     { DeviceScope bind(h->cx.device); }   // the handle belongs to the device current on the creating thread
     *out = h;
@@ -944,6 +975,15 @@ int pcx_fir_set_algo(pcx_fir *h, int algo)
     PCX_CHECK_ARG(h, "null handle");
     PCX_CHECK_ARG(algo >= PCX_FIR_AUTO && algo <= PCX_FIR_EXACT, "unknown FIR algorithm %d", algo);
     h->algo = algo;
+    return PCX_OK;
+}
+int pcx_fir_set_qformat(pcx_fir *h, const pcx_qformat *q)
+{
+    PCX_CHECK_ARG(h, "null handle");
+    QFormat f;
+    PCX_TRY(qformat_from_api(q, &f));
+    h->qf = f;
+    h->dirty = true;      // the Q-format taps are quantised again before the next call
     return PCX_OK;
 }
 int pcx_fir_get_geometry(const pcx_fir *h, size_t *K, size_t *input_require)
@@ -1039,6 +1079,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     int rc;
     // only the samples the N iterations touch: N + K-1
     const size_t used_in = N + h->K - 1;
+    const QShift qs = q_shift(h->qf, h->scalar);      // integer element types: fromQ<OutType> of FIRFilter.cpp:300 under the handle's reading
     if (gate_word) {
         // a gated call: only the plain complex_float32 M = L = 1 plan on 4096-sample blocks has the gate (and only its dealt launch,
         // launch_fir_cf32_ols4096 decides).  Anything else: *gated stays 0, nothing has been queued, the caller orders the halo itself.
@@ -1070,19 +1111,19 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     if (algo == PCX_FIR_OLS_FFT && h->have_interp_real) {
         rc = rows_path(fir_elem_bytes(h), h->M, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
             return launch_fir_real_ols(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12,
-                                       h->tw4096.p, h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, 1, st);
+                                       h->tw4096.p, h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, 1, qs, st);
         });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_interp64) {
         rc = rows_path(fir_elem_bytes(h), h->M, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
             return launch_fir_cf64_ols(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12,
-                                       h->tw4096.p, h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, 1, st);
+                                       h->tw4096.p, h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, 1, qs, st);
         });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_ols_real64) {
         rc = launch_fir_real_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
-                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, h->M, st);
+                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, h->M, qs, st);
     } else if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
         rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
-                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, h->M, st);
+                                 h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, h->M, qs, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_interp) {
@@ -1113,11 +1154,11 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         // PCX_FIR_DOT2=0 keeps complex_int16 on the 24-bit multiply path (A/B)
         const int dot2 = (int)PCX_ENV_INT("PCX_FIR_DOT2", 1);
         if (slide && dot2 && h->taps16 && h->L == 1 && h->M == 1 && h->K <= 12000)
-            rc = launch_fir_ci16_dot2(in_dev, out_dev, n_out, h->K, h->tapsP.p, h->scalar == PCX_I8, st);
+            rc = launch_fir_ci16_dot2(in_dev, out_dev, n_out, h->K, h->tapsP.p, h->scalar == PCX_I8, qs, st);
         else if (slide && h->L == 1 && h->M == 1)
-            rc = launch_fir_slide(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, h->taps24, g, in_dev, out_dev, n_out, st);
+            rc = launch_fir_slide(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, h->taps24, g, in_dev, out_dev, n_out, qs, st);
         else
-            rc = launch_fir_generic(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, g, in_dev, out_dev, n_out, st);
+            rc = launch_fir_generic(h->scalar, h->cplx, h->ctaps, algo == PCX_FIR_EXACT, g, in_dev, out_dev, n_out, qs, st);
     }
     if (rc != PCX_OK) return rc;
     h->last_algo = algo;
@@ -1665,36 +1706,54 @@ static int run_host_map(const void *in, void *out, size_t in_bytes, size_t out_b
     return stage_out_end(out, out_bytes, ws->out, staged, ws->st);
 }
 
-int pcx_rotate_dev(int scalar, double pr, double pi, const void *in_dev, void *out_dev, size_t n, void *stream)
+int pcx_rotate_q_dev(int scalar, double pr, double pi, const pcx_qformat *q, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
     PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "rotateFactory: unsupported type (scalar %d)", scalar);
+    QFormat qf;
+    PCX_TRY(qformat_from_api(q, &qf));
     if (n == 0) return PCX_OK;
     PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
-    return launch_rotate(scalar, pr, pi, in_dev, out_dev, n, as_stream(stream));
+    return launch_rotate(scalar, pr, pi, qf, in_dev, out_dev, n, as_stream(stream));
 }
-int pcx_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n)
+int pcx_rotate_q(int scalar, double pr, double pi, const pcx_qformat *q, const void *in, void *out, size_t n)
 {
     PCX_TRACE();
     PCX_CHECK_ARG(valid_scalar(scalar), "rotateFactory: unsupported type (scalar %d)", scalar);
+    QFormat qf;
+    PCX_TRY(qformat_from_api(q, &qf));
     const size_t b = n * 2 * (size_t)scalar_bytes(scalar);
-    return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_rotate(scalar, pr, pi, di, dout, n, st); });
+    return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_rotate(scalar, pr, pi, qf, di, dout, n, st); });
+}
+int pcx_rotate_dev(int scalar, double pr, double pi, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    return pcx_rotate_q_dev(scalar, pr, pi, nullptr, in_dev, out_dev, n, stream);
+}
+int pcx_rotate(int scalar, double pr, double pi, const void *in, void *out, size_t n) { return pcx_rotate_q(scalar, pr, pi, nullptr, in, out, n); }
+int pcx_scale_q_dev(int scalar, int is_complex, double factor, const pcx_qformat *q, const void *in_dev, void *out_dev, size_t n, void *stream)
+{
+    PCX_TRACE();
+    PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
+    QFormat qf;
+    PCX_TRY(qformat_from_api(q, &qf));
+    if (n == 0) return PCX_OK;
+    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
+    return launch_scale(scalar, is_complex, factor, qf, in_dev, out_dev, n, as_stream(stream));
+}
+int pcx_scale_q(int scalar, int is_complex, double factor, const pcx_qformat *q, const void *in, void *out, size_t n)
+{
+    PCX_TRACE();
+    PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
+    QFormat qf;
+    PCX_TRY(qformat_from_api(q, &qf));
+    const size_t b = n * (is_complex ? 2 : 1) * (size_t)scalar_bytes(scalar);
+    return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_scale(scalar, is_complex, factor, qf, di, dout, n, st); });
 }
 int pcx_scale_dev(int scalar, int is_complex, double factor, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
-    PCX_TRACE();
-    PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
-    if (n == 0) return PCX_OK;
-    PCX_CHECK_ARG(in_dev && out_dev, "null buffer");
-    return launch_scale(scalar, is_complex, factor, in_dev, out_dev, n, as_stream(stream));
+    return pcx_scale_q_dev(scalar, is_complex, factor, nullptr, in_dev, out_dev, n, stream);
 }
-int pcx_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n)
-{
-    PCX_TRACE();
-    PCX_CHECK_ARG(valid_scalar(scalar), "scaleFactory: unsupported type (scalar %d)", scalar);
-    const size_t b = n * (is_complex ? 2 : 1) * (size_t)scalar_bytes(scalar);
-    return run_host_map(in, out, b, b, [&](const void *di, void *dout, hipStream_t st) { return launch_scale(scalar, is_complex, factor, di, dout, n, st); });
-}
+int pcx_scale(int scalar, int is_complex, double factor, const void *in, void *out, size_t n) { return pcx_scale_q(scalar, is_complex, factor, nullptr, in, out, n); }
 int pcx_abs_dev(int scalar, int is_complex, const void *in_dev, void *out_dev, size_t n, void *stream)
 {
     PCX_TRACE();

@@ -134,6 +134,11 @@ class FirFilter(_Handle):
     def set_algo(self, algo):
         _lib.check(_lib.load().pcx_fir_set_algo(self._h, algo))
 
+    def set_qformat(self, q):
+        """pcx_fir_set_qformat: the floatToQ / fromQ reading of an integer filter -- a (frac, float_to_q, from_q) triple of the
+        _lib.Q_* constants, or None for the process-wide reading"""
+        _lib.check(_lib.load().pcx_fir_set_qformat(self._h, _lib.qformat_ptr(q)))
+
     @property
     def last_algo(self):
         return _lib.load().pcx_fir_last_algo(self._h)
@@ -339,19 +344,34 @@ def _polar(phase):
     return c.value, s.value
 
 
-def rotate(x, phase, scalar=None, out=None, n=None, stream=None):
-    """arrayRotate (math/Rotate.cpp:15-23).  phase=None: block whose setPhase was never called."""
+def set_qformat(q=None):
+    """pcx_set_qformat: the process-wide floatToQ / fromQ reading (a (frac, float_to_q, from_q) triple; None: the built-in default)"""
+    _lib.check(_lib.load().pcx_set_qformat(_lib.qformat_ptr(q)))
+
+
+def get_qformat():
+    q = _lib.QFormat()
+    _lib.check(_lib.load().pcx_get_qformat(C.byref(q)))
+    return (q.frac, q.float_to_q, q.from_q)
+
+
+def rotate(x, phase, scalar=None, out=None, n=None, stream=None, qformat=None):
+    """arrayRotate (math/Rotate.cpp:15-23).  phase=None: block whose setPhase was never called.  qformat: pcx_rotate_q's reading."""
     pr, pi = (0.0, 0.0) if phase is None else _polar(float(phase))
     if not _is_torch(x):
         x = as_pairs(x)
         scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
+    if qformat is not None:
+        return _map("pcx_rotate_q", "pcx_rotate_q_dev", (scalar, pr, pi, _lib.qformat_ptr(qformat)), x, lambda a: a.shape, n, out, stream)
     return _map("pcx_rotate", "pcx_rotate_dev", (scalar, pr, pi), x, lambda a: a.shape, n, out, stream)
 
 
-def scale(x, factor, is_complex, scalar=None, out=None, n=None, stream=None):
+def scale(x, factor, is_complex, scalar=None, out=None, n=None, stream=None, qformat=None):
     if not _is_torch(x):
         x = as_pairs(x)
         scalar, n = SCALAR_OF_NP[x.dtype], x.shape[0]
+    if qformat is not None:
+        return _map("pcx_scale_q", "pcx_scale_q_dev", (scalar, int(is_complex), float(factor), _lib.qformat_ptr(qformat)), x, lambda a: a.shape, n, out, stream)
     return _map("pcx_scale", "pcx_scale_dev", (scalar, int(is_complex), float(factor)), x, lambda a: a.shape, n, out, stream)
 
 

@@ -290,6 +290,91 @@ def test_fir_integer_matches_exact_integer_convolution(oracle, scalar):
         assert int(y[n, 1]) == wrap(wrap(ai, qb) >> (qb // 2), ebits)
 
 
+# ---- the Q-format reading as a parameter (include/pcx.h pcx_qformat, oracle.set_qformat) ------------------
+def _py_scale(x, factor, q, ebits, qbits):
+    """arrayScale under a reading, in Python integers: an independent model of orc_scale (no shifts of negative numbers, no C)"""
+    import math
+    from fractions import Fraction
+    n = ebits // 2 if q[0] else qbits // 2
+    v = math.ldexp(factor, n)
+    fq = int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1) if q[1] else int(v)      # nearest, ties away | truncation
+
+    def wrap(v, bits):
+        v &= (1 << bits) - 1
+        return v - (1 << bits) if v >> (bits - 1) else v
+    out = []
+    for xi in x.tolist():
+        acc = wrap(wrap(fq, qbits) * xi, qbits)
+        r = Fraction(acc, 1 << n)
+        if q[2] == 0:
+            y = math.floor(r)
+        elif q[2] == 1:
+            y = math.trunc(r)
+        else:
+            y = math.floor(r + Fraction(1, 2))
+        out.append(wrap(y, ebits))
+    return out
+
+
+@pytest.mark.parametrize("q", [(f, t, r) for f in (0, 1) for t in (0, 1) for r in (0, 1, 2)], ids=str)
+def test_qformat_readings_against_a_python_integer_model(oracle, q):
+    rng = np.random.default_rng(sum(q) * 7 + q[0])
+    oracle.set_qformat(*q)
+    try:
+        for dt, ebits, qbits in ((np.int8, 8, 16), (np.int16, 16, 32), (np.int32, 32, 64), (np.int64, 64, 64)):
+            info = np.iinfo(dt)
+            x = rng.integers(info.min, info.max + 1, 300, dtype=dt)
+            x[:6] = [info.min, info.max, 5, -5, 1000 % (info.max + 1), -1]
+            for factor in (0.5, -0.5, 0.3, -0.3337, 1.0, -1.0, 0.0, 77.77):
+                assert oracle.scale(x, factor, False).tolist() == _py_scale(x, factor, q, ebits, qbits), (dt, factor)
+    finally:
+        oracle.set_qformat()
+
+
+@pytest.mark.parametrize("q", [(f, t, r) for f in (0, 1) for t in (0, 1) for r in (0, 1, 2)], ids=str)
+def test_reference_rotate_scale_points_hold_under_every_reading(oracle, q):
+    """math/TestRotate.cpp:50-53, math/TestScale.cpp:49-52 (tolerance 1) cannot tell the twelve readings apart: every one passes"""
+    oracle.set_qformat(*q)
+    try:
+        for name in ("int8", "int16", "int32", "int64"):
+            x = GOLD["rotate_in_" + name]
+            for k, phase in enumerate([0.0, np.pi / 2, np.pi, 3 * np.pi / 2]):
+                exp = GOLD["rotate_exp_%s_%d" % (name, k)]
+                got = oracle.rotate(x, phase).astype(np.float64)
+                if name == "int8":
+                    exp = exp.astype(np.int64).astype(np.int8).astype(np.float64)
+                    d = np.abs(got - exp)
+                    d = np.minimum(d, 256 - d)
+                else:
+                    d = np.abs(got - exp)
+                assert d.max() <= 1.0, (name, phase)
+            xs = GOLD["scale_in_" + name]
+            for k, factor in enumerate([-1.0, -0.5, 0.0, 0.5, 1.0]):
+                exp = GOLD["scale_exp_%s_%d" % (name, k)]
+                got = oracle.scale(xs, factor, False).astype(np.float64)
+                if name == "int8":
+                    exp = exp.astype(np.int64).astype(np.int8).astype(np.float64)
+                    d = np.abs(got - exp)
+                    d = np.minimum(d, 256 - d)
+                else:
+                    d = np.abs(got - exp)
+                assert d.max() <= 1.0, (name, factor)
+    finally:
+        oracle.set_qformat()
+
+
+def test_qformat_hand_computed_cases(oracle):
+    """int16 scale: 0.5 x +-5 = +-2.5 -> floor 2/-3, toward zero 2/-2, nearest 3/-2; 0.3 x 1000 under the four tap quantisations"""
+    cases = [((0, 0, 0), 0.5, [5, -5], [2, -3]), ((0, 0, 1), 0.5, [5, -5], [2, -2]), ((0, 0, 2), 0.5, [5, -5], [3, -2]),
+             ((0, 0, 0), 0.3, [1000], [299]), ((0, 1, 0), 0.3, [1000], [300]), ((1, 0, 0), 0.3, [1000], [296]), ((1, 1, 0), 0.3, [1000], [300])]
+    try:
+        for q, factor, xin, want in cases:
+            oracle.set_qformat(*q)
+            assert oracle.scale(np.array(xin, np.int16), factor, False).tolist() == want, (q, factor)
+    finally:
+        oracle.set_qformat()
+
+
 # ---- FreqDemod -----------------------------------------------------------------------------
 def test_freqdemod_anchor(oracle):
     """polar(1, 0.3 i^2) -> 0, 0.3, 0.9, 1.5, 2.1, 2.7, -2.983185, -2.383185."""

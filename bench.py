@@ -500,7 +500,9 @@ def build_workload(wl, C, dev, rank, world, args):
         if world > 1:
             W.desc["parallelism"] = "overlap-save shards x%d, RCCL send/recv halo of 127 samples" % world
         W.metric = "Msamples/s fused FM-demod chain"
-        W.limiter = "valu-issue"
+        # 998 VALU instructions per wave and block (661 of them the two transforms) fill ~0.7 of all SIMD issue time at the ~1.95 GHz the
+        # power cap leaves on real data; on all-zero input (2.37 GHz) the same kernel reads 0.62 (profiles/r04/floor_table.txt)
+        W.limiter = "valu issue at the power-capped clock"
         W.blocks = -(-n // (4096 - (K + 31) // 32 * 32))
     elif wl in ("decim8", "interp4"):
         # resampling complex_float32 FIR, 255 taps (per polyphase row when interpolating); independent replicas per rank
@@ -526,7 +528,10 @@ def build_workload(wl, C, dev, rank, world, args):
                                else "interpolation 4 from the replicated spectrum, 255 taps per phase (output rate)", n),
                   "decimation": M, "interpolation": L}
         W.metric = "Msamples/s complex_float32 %s FIR" % ("decimating (in)" if wl == "decim8" else "interpolating (out)")
-        W.limiter = "valu-issue"
+        # not VALU (0.36 / 0.44 of SIMD issue time): the blocks' LDS exchanges at THREE workgroups per CU -- the registers hold H and the
+        # pass-3 constants, a fourth workgroup would have to re-read both per block and measures slower (profiles/r04/floor_table.txt,
+        # floor_lab_sweep.txt, decim8_occupancy_variants.txt)
+        W.limiter = "LDS exchanges exposed at three workgroups per CU"
     elif wl == "fir255_i16":
         # complex_int16 255-tap FIR: bit-exact on the double-precision overlap-save pipeline
         n = C
@@ -545,7 +550,7 @@ def build_workload(wl, C, dev, rank, world, args):
         W.desc = {"workload": "255-tap complex_int16 FIR (bit-exact, double-precision overlap-save), %d samples per GPU" % n, "taps": 255}
         W.metric = "Msamples/s complex_int16 255-tap FIR"
         W.dtype = "f64"
-        W.limiter = "valu-issue (f64 pipeline)"
+        W.limiter = "f64 issue (the double-precision pipeline that keeps the integer convolution exact)"
     else:
         n = C
         x = torch.empty((n, 2), dtype=torch.float32, device=dev)

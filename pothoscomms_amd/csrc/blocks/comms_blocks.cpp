@@ -211,6 +211,14 @@ static pcxfw::BufferManager::Sptr deviceManager(const std::string &name, size_t 
 // buffer in HBM -- and the host-pointer entry points of the C ABI run in place on them (they recognise device pointers exactly
 // as they recognise page-locked ones).  A Rotate -> FIR -> FreqDemod topology of three separate blocks then crosses PCIe
 // once in and once out instead of three times each way.  Any other domain ("" = a host block) gets page-locked host slabs.
+// BUNDLED RUNTIME ONLY.  Under -DPCX_WITH_POTHOS every port gets page-locked HOST slabs, whatever the domain at the other end: a
+// Pothos::BufferChunk that points into HBM would be dereferenced on the CPU by the framework itself -- the input port's accumulator
+// memcpy's queued chunks together whenever a reserve exceeds the front buffer (the FIR's M + K - 1, the FFT's frame), the topology
+// inserts a copier block where both ends of an edge bring a manager (any output meeting the FIR's circular input), and any foreign
+// block connected to the same output reads the bytes -- and nothing short of changing PothosCore can tell those "this is device
+// memory".  An unchanged three-block chain therefore pays PCIe per edge inside Pothos (1.1-1.6 Gsamples/s against 3.8-5.7 for the
+// fused /comms/fm_demod_chain block, tools/chain_path.py): the fused block is the remedy, not device pointers in
+// the framework's hands.
 static const char *const kDomain = "pcx-hip";
 class DeviceBlock : public Block {
 public:

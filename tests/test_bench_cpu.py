@@ -1,0 +1,77 @@
+"""CPU suite: the arithmetic of bench.py's result line (no GPU): which roof a workload is priced on, what the `valu`, `cold` and
+`sustained` objects are computed from, and that a committed PMC measurement is only used for the kernel it was taken on."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _workload(**kw):
+    W = bench.Workload()
+    W.name, W.kernel_name, W.units = "none", "no_such_kernel", 64 << 20
+    W.roof_bytes, W.read_bytes = 16.0 * W.units, 8.0 * W.units
+    for k, v in kw.items():
+        setattr(W, k, v)
+    return W
+
+
+def test_hbm_roofline_object():
+    r = bench.roofline_of(_workload(), 0.2, sustained=(0.21, 5000), cold=0.25, clk=2000.0)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["achieved"] == pytest.approx(16.0 * (64 << 20) / 0.2e-3 / 1e9, rel=1e-4)
+    assert r["frac"] == pytest.approx(r["achieved"] / 8000.0, abs=1e-4)
+    assert r["read_only_frac"] == pytest.approx(r["frac"] / 2, abs=1e-4)
+    assert r["traffic"] is None and "valu" not in r                  # no committed measurement of "no_such_kernel"
+    assert r["sustained"]["frac"] == pytest.approx(r["frac"] * 0.2 / 0.21, abs=2e-4)
+    assert r["cold"]["frac"] == pytest.approx(r["frac"] * 0.2 / 0.25, abs=2e-4) and r["cold"]["launches"] == 20
+    assert r["clock_mhz_under_load"] == 2000.0
+
+
+def test_the_direct_form_is_priced_on_the_fma_roof():
+    """8 K flop per sample against 16 bytes -- 127 flop per byte, machine balance 19.7: not an HBM-bound kernel"""
+    W = _workload(bound="fp32-fma", flops_per_unit=8.0 * 255)
+    r = bench.roofline_of(W, 1.34)
+    tf = 2040.0 * (64 << 20) / 1.34e-3 / 1e12
+    assert r["bound"] == "fp32-fma" and r["unit"] == "TFLOP/s" and r["peak"] == bench.FP32_FMA_PEAK_TFLOPS
+    assert r["achieved"] == pytest.approx(tf, rel=1e-3) and r["frac"] == pytest.approx(tf / 157.3, abs=1e-3)
+    assert r["hbm"]["frac"] == pytest.approx(16.0 * (64 << 20) / 1.34e-3 / 1e9 / 8000.0, abs=1e-3)
+    m = bench.measured_fma_rate()
+    if m:                                                             # profiles/*/ubench_roofs.txt is committed
+        assert 100.0 < m[0] < 160.0 and r["frac_of_measured_fma_rate"] == pytest.approx(tf / m[0], abs=1e-3)
+
+
+def test_valu_block_from_a_committed_measurement(tmp_path, monkeypatch):
+    """the share of SIMD issue time = wave instructions x 4 cycles / (1024 SIMDs x launch time x clock)"""
+    src = "bench.py"
+    prof = {"wl": {"kernel": "k_kernel", "sources": bench.source_hashes([src]), "hbm_bytes_per_launch": 123,
+                   "counters": {"SQ_INSTS_VALU": 6.75e7, "SQ_WAVES": 4096}, "source": "profiles/rXX/wl_rocprofv3_summary.txt"}}
+    os.makedirs(tmp_path / "profiles")
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps(prof))
+    (tmp_path / src).write_bytes(open(os.path.join(ROOT, src), "rb").read())
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    W = _workload(name="wl", kernel_name="k_kernel<4>", blocks=16913, limiter="valu-issue")
+    r = bench.roofline_of(W, 0.2, clk=2000.0)
+    assert r["traffic"] == 123 and r["limiter"] == "valu-issue"
+    v = r["valu"]
+    assert v["insts_per_launch"] == 6.75e7 and v["per_wave"] == pytest.approx(6.75e7 / 4096, abs=0.1)
+    assert v["per_wave_block"] == pytest.approx(6.75e7 / (4 * 16913), abs=0.1)
+    assert v["simd_cycle_share"] == pytest.approx(6.75e7 * 4 / (1024 * 0.2e-3 * 2000e6), abs=1e-3) and v["at_clock_mhz"] == 2000.0
+    # a measurement taken on another kernel, or on other sources, is not used
+    assert bench.load_profile("wl", "other_kernel") is None
+    (tmp_path / src).write_text("changed")
+    assert bench.load_profile("wl", "k_kernel<4>") is None
+
+
+def test_default_line_documents_itself():
+    """the flags the driver uses and the ones that switch the extra measurements off exist"""
+    sys_argv, sys.argv = sys.argv, ["bench.py", "--steps", "20", "--warmup", "5", "--no-secondary", "--no-cold"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = sys_argv
+    assert (a.gpus, a.steps, a.warmup, a.no_secondary, a.no_cold, a.workload) == (1, 20, 5, True, True, "fir255")

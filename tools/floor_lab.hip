@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -166,6 +167,31 @@ int main(int argc, char **argv)
         fflush(stdout);
     };
     const char *names[3] = {"mem", "dose", "dose+x"};
+    if (argc > 2 && std::string(argv[2]) == "sweep") {
+        // what an LDS exchange costs the decimator's shape, and what a fourth workgroup per CU would buy: exchanges per block 0..3 at
+        // three and at four workgroups per CU (the product kernel: three exchanges' worth at three per CU, 170 VGPRs)
+        for (int occ = 3; occ <= 4; occ++)
+            for (int x = 0; x <= 3; x++) {
+                Shape t = dc;
+                t.occ = occ; t.grid = occ == 3 ? 729 : 1024; t.exchanges = x;
+                char what[32];
+                snprintf(what, sizeof what, "occ%d x%d", occ, x);
+                const double ms = x == 0 ? (occ == 3 ? run<3, 16>(t, 1, in, C + 4096, out, seconds, 1e-3f) : run<4, 16>(t, 1, in, C + 4096, out, seconds, 1e-3f))
+                                         : (occ == 3 ? run<3, 16>(t, 2, in, C + 4096, out, seconds, 1e-3f) : run<4, 16>(t, 2, in, C + 4096, out, seconds, 1e-3f));
+                row(t, what, ms);
+            }
+        for (int occ = 3; occ <= 4; occ++)
+            for (int x = 0; x <= 3; x++) {
+                Shape t = ip;
+                t.occ = occ; t.grid = occ == 3 ? 729 : 1024; t.exchanges = x;
+                char what[32];
+                snprintf(what, sizeof what, "occ%d x%d", occ, x);
+                const double ms = x == 0 ? (occ == 3 ? run<3, 4>(t, 1, in, C / 4 + 4096, out, seconds, 1e-3f) : run<4, 4>(t, 1, in, C / 4 + 4096, out, seconds, 1e-3f))
+                                         : (occ == 3 ? run<3, 4>(t, 2, in, C / 4 + 4096, out, seconds, 1e-3f) : run<4, 4>(t, 2, in, C / 4 + 4096, out, seconds, 1e-3f));
+                row(t, what, ms);
+            }
+        return 0;
+    }
     for (int m = 0; m < 3; m++) row(fr, names[m], run<4, 16>(fr, m, in, C + 4096, out, seconds, 1e-3f));
     for (int m = 0; m < 3; m++) row(fm, names[m], run<4, 16>(fm, m, in, C + 4096, out, seconds, 1e-3f));
     for (int m = 0; m < 3; m++) row(dc, names[m], run<3, 16>(dc, m, in, C + 4096, out, seconds, 1e-3f));

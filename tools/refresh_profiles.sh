@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/r04b}; rm -rf $O; mkdir -p $O
 ulimit -c 0
-make -s -C tools ubench ols_lab3 clk_lab > /dev/null 2>&1
+make -s -C tools ubench ols_lab3 clk_lab floor_lab > /dev/null 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> /dev/null
 for w in fft4096 fmchain rotate direct255 decim8 interp4 fir255_i16; do python bench.py --workload $w 2>/dev/null | tail -1 >> $O/bench_other_workloads.jsonl; done
@@ -32,6 +32,9 @@ python tools/two_streams_probe.py 2>/dev/null | grep launches >> $O/shard_probe.
 bash tools/ab_gated_slots.sh >> $O/shard_probe.txt 2>/dev/null
 ( export PCX_PROBE_SHORT=1; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/kt_shard4 -- python3 tools/shard_probe.py 4 > /dev/null 2>&1; python tools/trace_pass.py $O/kt_shard4 40 > $O/shard4_trace.txt; rm -rf $O/kt_shard4 )
 tools/ubench > $O/ubench_roofs.txt 2>&1
+timeout 600 python tools/floor_table.py 1.0 > $O/floor_table.txt 2>/dev/null
+timeout 300 python tools/chain_path.py > $O/chain_path.txt 2>/dev/null
+( export PCX_PROBE_TOTAL=536870912; for G in 1 2 4 8; do timeout 120 python tools/shard_probe.py $G 2>/dev/null | grep shards; done ) > $O/shard_probe_c3.txt
 python tools/sweep_fir.py > $O/sweep_fir_taps.txt 2>/dev/null
 python tools/sweep_fft.py 16 64 256 1024 2048 4096 8192 16384 > $O/sweep_fft_sizes.txt 2>/dev/null
 python tools/sweep_fft_q15_large.py > $O/sweep_fft_q15_large.txt 2>/dev/null

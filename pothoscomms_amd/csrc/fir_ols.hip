@@ -21,6 +21,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "pcx_internal.hpp"
 
 namespace pcx {
@@ -732,6 +734,16 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         constexpr int NDEAD = NOV / 2;      // Kov in (256 NOV/2, 256 NOV] (NOV = 1: Kov <= 256): rows 0 .. NDEAD-1 are dead whatever K
         const cf K54 = {-0.01171913556754589f, 0.05264735221862793f}, K32 = {-0.116426482796669f, 0.19354037940502167f};
         const cf K10 = {-0.33262282609939575f, 0.9999772310256958f}, KPI = {1.57079632679489661923f, 3.14159265358979323846f};
+        // The stores of a FULL block of the short-filter instantiation (NOV = 1: K <= 256, so every row but row 0 is valid whole and
+        // nothing lies beyond the block's S outputs): row k >= 1 goes out at voffset 4 j -- one loop-invariant register -- with the
+        // row's displacement 1024 k - 4 K in the instruction's SCALAR offset; only row 0 keeps the wrapping lane offset that lets the
+        // range check drop its time indices below K.  The general form (any K, the stream's last, partial block) adds the row's
+        // displacement to the wrapping lane offset in a vector register: fifteen v_add per block, which this saves.  Two copies
+        // of the loop, chosen by a workgroup-uniform branch.
+        const bool full_block = NOV == 1 && cnt == S;
+        const unsigned j4 = (unsigned)j * 4u;
+        auto demod_rows = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
             const int k0 = bin_of(q), k1 = bin_of(q + 1);
@@ -761,7 +773,12 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             // FreqDemod.cpp:44-47,63-64) gives t = 0 / tiny = 0 and the quadrant from the sign bits alone, as atan2f does.
             const cf mx = {__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(y0)), 1e-37f),
                            __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x1), __builtin_fabsf(y1)), 1e-37f)};
-            const cf mn = {__builtin_fminf(__builtin_fabsf(x0), __builtin_fabsf(y0)), __builtin_fminf(__builtin_fabsf(x1), __builtin_fabsf(y1))};
+            // min(|x|, |y|) spelt as the instruction it is: through __builtin_fminf the compiler puts a canonicalising v_max x, x in
+            // front of either operand (it cannot know the asm results above to be quiet) -- four instructions per pair of samples,
+            // 32 of the tail's ~337 per wave and block
+            cf mn;
+            asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn.x) : "v"(x0), "v"(y0));
+            asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn.y) : "v"(x1), "v"(y1));
             const cf rc = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
             const cf t = mn * rc;
             const cf sq = t * t;
@@ -777,9 +794,16 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rn) : "s"(KPI), "v"(r));   // pi - r
             r = cf{__float_as_int(x0) < 0 ? rn.x : r.x, __float_as_int(x1) < 0 ? rn.y : r.y};
             const float d0 = __builtin_copysignf(r.x, y0), d1 = __builtin_copysignf(r.y, y1);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), ws, (int)(vbase + (unsigned)(256 * k0) * 4u), 0, SAUX);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), ws, (int)(vbase + (unsigned)(256 * k1) * 4u), 0, SAUX);
+            auto put = [&](int k, float d) {
+                if (FULL && k > 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)j4, 1024 * k - 4 * K, SAUX);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)(256 * k) * 4u), 0, SAUX);
+            };
+            put(k0, d0);
+            put(k1, d1);
         }
+        };
+        if (full_block) demod_rows(std::true_type{});
+        else demod_rows(std::false_type{});
         if (b == nblocks - 1) {
             // the stream's last output becomes the next call's carried state (kept conjugated)
             const int i_last = K + (int)cnt - 1;

@@ -132,6 +132,7 @@ struct pcx_shard {
     size_t K = 1, C = 0, head = 0;
     std::vector<size_t> lead;                     // per shard: samples in front of the halo slot (alignment, pcx_shard_configure)
     bool have_taps = false;
+    bool exchanged_once = false;                  // the first exchange has completed (RCCL sets its connections up lazily: pcx_shard_step)
     unsigned long long steps = 0;
     size_t halo() const { return chain_mode ? K : K - 1; }      // samples in front of every shard
     float2 *in_ptr(int g) const { return static_cast<float2 *>(alloc[g]) + lead[g]; }       // the halo slot
@@ -636,6 +637,16 @@ int pcx_shard_step(pcx_shard *s)
         // halo_ready(g): RCCL -- the send that reads shard g's tail and the receive into its halo slot are done;
         // peer copies -- the copy that reads shard g-1's tail and writes shard g's halo slot is done
         if (g > 0 || s->transport == PCX_SHARD_RCCL) PCX_HIP(hipEventRecord(s->halo_ready[g], s->hst[g]));
+    }
+    // The FIRST exchange of a handle is waited for on the host before any launch is queued that depends on it: RCCL sets its
+    // point-to-point connections up lazily, inside the first send / receive, and that can take longer than the two seconds a gated
+    // launch waits for its halo -- the first pass of a run must not be the one that reports a timeout.
+    if (!s->exchanged_once) {
+        for (int g = 0; g < G; g++) {
+            PCX_HIP(hipSetDevice(s->dev[g]));
+            PCX_HIP(hipStreamSynchronize(s->hst[g]));
+        }
+        s->exchanged_once = true;
     }
     // 3. every shard in ONE launch: shard 0 has no halo to wait for; the others hold their first block behind the gate
     for (int g = 0; g < G; g++) {

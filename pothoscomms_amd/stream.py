@@ -49,6 +49,15 @@ def _check_gate(owner):
                           "the outputs at the front of the shard were computed on a stale halo" % (owner.ring.rank, owner._pass))
 
 
+def _first_exchange(owner):
+    """The FIRST exchange of a driver is waited for on the host before the gated launch that depends on it is queued: RCCL sets its
+    point-to-point connections up lazily, inside the first send / receive, and that can take longer than the two seconds a gated launch
+    waits for its halo -- the first pass of a run must not be the one that times out.  Every rank passes here in its first step."""
+    if not getattr(owner, "_exchanged_once", False):
+        owner._side.synchronize()
+        owner._exchanged_once = True
+
+
 def _two_launch_forced(arg):
     """The RCCL path takes ONE gated launch per pass by default; two_launch=True (or PCX_STREAM_TWO_LAUNCH=1) forces the round-2
     scheme -- body launch, wait for the halo, head launch -- so that the two can be compared, and the gated one bypassed, on a node
@@ -215,6 +224,7 @@ class ShardedFir:
                 self.ring.finish(self.ring.start(self._buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
                 if self.ring.rank > 0:
                     dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
+            _first_exchange(self)
             reqs = []
         else:
             reqs = self.ring.start(self._buf)              # (drains the current stream first: HaloRing.start)
@@ -330,6 +340,7 @@ class ShardedFmChain:
             self.ring.finish(self.ring.start(self._buf))
             if self.ring.rank > 0:
                 dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
+        _first_exchange(self)
         ch = self._chains[0]
         if self.ring.rank == 0:
             self._run(ch, 1, self.C, 1)                             # stream start: reset state, no extra output

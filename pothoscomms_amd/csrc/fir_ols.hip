@@ -719,7 +719,6 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         const size_t room = n_out - b * S;
         const size_t cnt = room < S ? room : S;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S, (unsigned)(cnt * 4));
-        const unsigned vbase = (unsigned)(j - K) * 4u;
         // lane 0 of wave w > 0 continues lane 63 of wave w-1 in the same row; lane 0 of wave 0 continues
         // lane 255 of row k-1 (bnd[47 + k]; for k = 0 that is time index -1: never a valid output)
         const cf *edge_row = bnd + ((j >> 6) > 0 ? ((j >> 6) - 1) * 16 : 47);
@@ -734,16 +733,15 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
         constexpr int NDEAD = NOV / 2;      // Kov in (256 NOV/2, 256 NOV] (NOV = 1: Kov <= 256): rows 0 .. NDEAD-1 are dead whatever K
         const cf K54 = {-0.01171913556754589f, 0.05264735221862793f}, K32 = {-0.116426482796669f, 0.19354037940502167f};
         const cf K10 = {-0.33262282609939575f, 0.9999772310256958f}, KPI = {1.57079632679489661923f, 3.14159265358979323846f};
-        // The stores of a FULL block of the short-filter instantiation (NOV = 1: K <= 256, so every row but row 0 is valid whole and
-        // nothing lies beyond the block's S outputs): row k >= 1 goes out at voffset 4 j -- one loop-invariant register -- with the
-        // row's displacement 1024 k - 4 K in the instruction's SCALAR offset; only row 0 keeps the wrapping lane offset that lets the
-        // range check drop its time indices below K.  The general form (any K, the stream's last, partial block) adds the row's
-        // displacement to the wrapping lane offset in a vector register: fifteen v_add per block, which this saves.  Two copies
-        // of the loop, chosen by a workgroup-uniform branch.
-        const bool full_block = NOV == 1 && cnt == S;
+        // Where a row goes.  Rows k >= NOV are valid whole whatever K (Kov <= 256 NOV): lane offset 4 j -- one loop-invariant register --
+        // and the row's displacement 1024 k - 4 K in the instruction's SCALAR offset.  The range check covers voffset + soffset as one
+        // wide unsigned sum on gfx950 (tools/soffset_lab.hip: 1024 records, soffset 2048 -> nothing written; a wrapped voffset
+        // stays out of range whatever soffset is added), so the stream's last, partial block is clipped exactly as before.  Rows
+        // below NOV keep the wrapping lane offset (j - K) * 4 + 1024 k in a vector register, which is what drops their time indices
+        // below K.  For the short-filter instantiation (NOV = 1) that is row 0 alone: fifteen v_add per block fewer.
         const unsigned j4 = (unsigned)j * 4u;
-        auto demod_rows = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
+        int k4 = 4 * K;
+        asm volatile("" : "+s"(k4));        // HERE, per block: hoisted out of the block loop the fifteen displacements sit in scalar registers the loop does not have (10-16 spilled)
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
             const int k0 = bin_of(q), k1 = bin_of(q + 1);
@@ -795,15 +793,12 @@ __global__ __launch_bounds__(256, OCC) void fmchain_cf32_ols4096_kernel(const fl
             r = cf{__float_as_int(x0) < 0 ? rn.x : r.x, __float_as_int(x1) < 0 ? rn.y : r.y};
             const float d0 = __builtin_copysignf(r.x, y0), d1 = __builtin_copysignf(r.y, y1);
             auto put = [&](int k, float d) {
-                if (FULL && k > 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)j4, 1024 * k - 4 * K, SAUX);
-                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(vbase + (unsigned)(256 * k) * 4u), 0, SAUX);
+                if (k >= NOV) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)j4, 1024 * k - k4, SAUX);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), ws, (int)(j4 + (unsigned)(1024 * k - k4)), 0, SAUX);   // = ((j - K) * 4 + 1024 k) mod 2^32
             };
             put(k0, d0);
             put(k1, d1);
         }
-        };
-        if (full_block) demod_rows(std::true_type{});
-        else demod_rows(std::false_type{});
         if (b == nblocks - 1) {
             // the stream's last output becomes the next call's carried state (kept conjugated)
             const int i_last = K + (int)cnt - 1;

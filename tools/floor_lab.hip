@@ -157,7 +157,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     }
     // shapes: block geometry from the launchers (fir_ols.hip, fir_ols_decim.hip), VALU per wave and block from profiles/r03/*_rocprofv3_summary.txt
-    const Shape fm{"fmchain (127 taps, 64 Mi)", 4, 1024, 16, 3968, 4, 3968, 1, 998, 3, (C + 3967) / 3968, 12.0 * C};
+    const Shape fm{"fmchain (127 taps, 64 Mi)", 4, 1024, 16, 3968, 4, 3968, 1, 952, 3, (C + 3967) / 3968, 12.0 * C};
     const Shape dc{"decim8 (255 taps, 64 Mi in)", 3, 729, 16, 3840, 8, 480, 4, 402, 3, (C + 3839) / 3840, 9.0 * C};
     const Shape ip{"interp4 (255 taps/phase, 16 Mi in)", 3, 729, 4, 768, 8, 3072, 4, 447, 3, (C / 4 + 767) / 768, 8.0 * (C / 4) + 8.0 * C};
     const Shape fr{"fir255 (255 taps, 64 Mi) for scale", 4, 1024, 16, 3840, 8, 3840, 1, 661, 3, (C + 3839) / 3840, 16.0 * C};

@@ -23,7 +23,7 @@ int main()
     unsigned *d;
     std::vector<unsigned> h(4096);
     hipMalloc(&d, 16384);
-    for (int soff : {0, 512, 2048, 8192}) {
+    for (int soff : {0, 512, 900, 1020, 2048, 8192}) {   // 900: lanes 0..30 fit (900 + 4*30 + 4 = 1024), 31.. do not; 1020: lane 0 alone
         hipMemset(d, 0xEE, 16384);
         probe<<<1, 64>>>(d, soff, 0x1000u);
         hipMemcpy(h.data(), d, 16384, hipMemcpyDeviceToHost);

@@ -222,7 +222,46 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_kernel(const 
 // kernel above).  The parked values cost registers the forward passes need: the product runs it at THREE workgroups per CU
 // (OCC = 3, 170 VGPRs; launch_decim below has the measurements), with H held in registers as well (HREG) where that fits.
 // --------------------------------------------------------------------------------- //
-template <int LOG2M, int LOG2G, bool TW3_REG, int OCC = 4, bool HREG = false>
+// The pass-3 factors of a lane DERIVED instead of held or re-read (TWM = 2): four of the fifteen -- w, w^2, w^3 (= c[n2][0]) and w^4
+// (= a[0]), eight registers instead of thirty -- stay in registers; per block a[1] = w^8, a[2] = w^12 take one product each and the nine
+// c[n2][k1] = w^n2 W16^(n2 k1), k1 = 1..3, one product with a constant (W16^4 = -i: none): every factor is one multiplication away
+// from a table value, ~1e-7 relative.  What it buys is the register budget of a FOURTH workgroup per CU without the 60 KB per block
+// of table re-reads the TWM = 0 builds pay (the exchanges of these kernels are exposed at three per CU).
+struct LaneTwSeed {
+    cf w1, w2, w3, w4;
+};
+__device__ __forceinline__ void load_tw3_seed(LaneTwSeed &s, const float2 *__restrict__ tab, int j)
+{
+    const cf *tb = reinterpret_cast<const cf *>(tab) + LDS_TW2;
+    s.w4 = tb[j];
+    s.w1 = tb[(3 + 0) * 256 + j];
+    s.w2 = tb[(3 + 4) * 256 + j];
+    s.w3 = tb[(3 + 8) * 256 + j];
+}
+// a * w, w a compile-time constant riding in a scalar register pair
+__device__ __forceinline__ cf cmul1k(cf a, cf w)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+        : "=&v"(t), "=&v"(r)
+        : "v"(a), "s"(w));
+    return r;
+}
+__device__ __forceinline__ void expand_tw3(LaneTw &t, const LaneTwSeed &s)
+{
+    // W16^m = exp(-j 2 pi m / 16), m = n2 k1
+    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508977173f, R2 = 0.70710678118654752440f;
+    const cf W1 = {C1, -S1}, W2 = {R2, -R2}, W3 = {S1, -C1}, W6 = {-R2, -R2}, W9 = {-C1, S1};
+    t.a[0] = s.w4;
+    t.a[1] = cmul1(s.w4, s.w4);
+    t.a[2] = cmul1(t.a[1], s.w4);
+    t.c[0] = s.w1; t.c[1] = cmul1k(s.w1, W1); t.c[2] = cmul1k(s.w1, W2); t.c[3] = cmul1k(s.w1, W3);
+    t.c[4] = s.w2; t.c[5] = cmul1k(s.w2, W2); t.c[6] = cf{s.w2.y, -s.w2.x}; t.c[7] = cmul1k(s.w2, W6);     // W16^4 = -i
+    t.c[8] = s.w3; t.c[9] = cmul1k(s.w3, W3); t.c[10] = cmul1k(s.w3, W6); t.c[11] = cmul1k(s.w3, W9);
+}
+
+template <int LOG2M, int LOG2G, int TWM, int OCC = 4, bool HREG = false>   // TWM: the pass-3 factors 0 re-read per block, 1 held, 2 derived from four (expand_tw3)
 __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
                                                                                 size_t n_out, const float2 *__restrict__ Hspec, int Kov, int pad,
                                                                                 const float2 *__restrict__ twtab, size_t first_full, size_t nfull,
@@ -237,7 +276,9 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
     const size_t ngroups = (nblocks + G - 1) / G;
     const int js = spec_lane(j);       // the lane's bins are js + 256 r (file header)
     LaneTw tw3r;
-    if (TW3_REG) load_pass3_twiddles(tw3r, twtab, j);
+    LaneTwSeed tw3s;
+    if (TWM == 1) load_pass3_twiddles(tw3r, twtab, j);
+    if (TWM == 2) load_tw3_seed(tw3s, twtab, j);
     stage_pass2_twiddles(lds, twtab, j);
     const cf *Hg = reinterpret_cast<const cf *>(Hspec) + j;      // (turned on the host: lane j finds H[js + 256 r] at j + 256 r)
     cf Hr[16];
@@ -285,8 +326,12 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
                     v[r] = cf{__uint_as_float(t.x), __uint_as_float(t.y)};
                 }
             }
-            if (TW3_REG) {
+            if (TWM == 1) {
                 dif_a_math(v, tw3r);
+            } else if (TWM == 2) {
+                LaneTw tw3;
+                expand_tw3(tw3, tw3s);
+                dif_a_math(v, tw3);
             } else {
                 const float2 *tp = twtab;
                 asm volatile("" : "+v"(tp));
@@ -426,23 +471,36 @@ int launch_decim(const void *in, size_t in_elems, void *out, size_t n_iter, cons
         if (lg > LGMAX) lg = LGMAX;
         if (lg < 1) lg = 1;
         const bool hreg = PCX_ENV_INT("PCX_DECIM_HREG", LOG2M >= 2 ? 1 : 0) != 0;
-        const bool occ4 = PCX_ENV_INT("PCX_DECIM_OCC", 3) == 4;
+        const bool derived = PCX_ENV_INT("PCX_DECIM_TW3", 1) == 2;     // (diagnostic library: the product library's PCX_ENV_INT is the default) factors derived per block, four workgroups per CU
+        const bool occ4 = derived || PCX_ENV_INT("PCX_DECIM_OCC", 3) == 4;
         const bool tw3 = PCX_ENV_INT("PCX_DECIM_TW3", LOG2M >= 3 ? 1 : 0) != 0;     // (four-per-CU builds only: pass-3 constants in registers)
         const size_t ngroups = (nblocks + ((size_t)1 << lg) - 1) >> lg;
         const unsigned bgrid = persistent_grid(ngroups, occ4 ? 1024 : 768);
 #define PCX_DECIM_ARGS dim3(bgrid), dim3(256), 0, st, (const float2 *)in, in_elems, (float2 *)out, n_out, (const float2 *)Hspec, (int)Kov, (int)pad, \
                        (const float2 *)tw4096, first_full, nfull, nblocks
+#ifdef PCX_DIAG
+        // (diagnostic library) PCX_DECIM_TW3=2: the pass-3 factors derived per block from four held ones, four workgroups per CU, H held
+        // (PCX_DECIM_HREG=1) or re-read -- the A/B of DESIGN.md 4.6's "a fourth workgroup would hide the exchanges"
+#define PCX_DECIM_DERIVED(LG)                                                                                                          \
+            if (derived && hreg) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, 2, 4, true>), PCX_DECIM_ARGS);    \
+            else if (derived) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, 2, 4, false>), PCX_DECIM_ARGS);      \
+            else
+#else
+#define PCX_DECIM_DERIVED(LG)
+#endif
 #define PCX_DECIM_LAUNCH(LG)                                                                                                      \
         do {                                                                                                                      \
-            if (occ4 && tw3) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, true, 4, false>), PCX_DECIM_ARGS);     \
-            else if (occ4) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, false, 4, false>), PCX_DECIM_ARGS);      \
-            else if (hreg) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, true, 3, true>), PCX_DECIM_ARGS);        \
-            else hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, true, 3, false>), PCX_DECIM_ARGS);                 \
+            PCX_DECIM_DERIVED(LG)                                                                                                 \
+            if (occ4 && tw3) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, 1, 4, false>), PCX_DECIM_ARGS);     \
+            else if (occ4) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, 0, 4, false>), PCX_DECIM_ARGS);      \
+            else if (hreg) hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, 1, 3, true>), PCX_DECIM_ARGS);        \
+            else hipLaunchKernelGGL((fir_cf32_ols4096_decim_batched_kernel<LOG2M, LG, 1, 3, false>), PCX_DECIM_ARGS);                 \
         } while (0)
         if (lg == 1) PCX_DECIM_LAUNCH(1);
         else if (lg == 2) PCX_DECIM_LAUNCH((LGMAX >= 2 ? 2 : 1));
         else PCX_DECIM_LAUNCH((LGMAX >= 3 ? 3 : 1));
 #undef PCX_DECIM_LAUNCH
+#undef PCX_DECIM_DERIVED
 #undef PCX_DECIM_ARGS
         PCX_LAUNCH_CHECK();
         return PCX_OK;

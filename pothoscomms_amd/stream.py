@@ -40,9 +40,12 @@ def _check_gate(owner):
     gate = getattr(owner, "_gate", None)
     if gate is None:
         return
-    if gate.is_cuda:
-        torch.cuda.current_stream(gate.device).synchronize()
-        owner._side.synchronize()
+    buf = getattr(owner, "_buf", None)
+    if gate.is_cuda or (buf is not None and buf.is_cuda):      # (a host-driven gate lives in page-locked HOST memory: the pass still runs on the device)
+        dev = gate.device if gate.is_cuda else buf.device
+        torch.cuda.current_stream(dev).synchronize()
+        if getattr(owner, "_side", None) is not None:
+            owner._side.synchronize()
     if int(gate[1].item()) == GATE_TIMED_OUT:
         gate[1] = 0
         raise GateTimeout("rank %d: the halo did not arrive within two seconds of pass %d (or an earlier one since the last check); "

@@ -438,6 +438,16 @@ def test_a_gate_that_is_never_signalled_times_out_instead_of_hanging():
     dt = time.perf_counter() - t0
     assert 1.5 < dt < 10.0, dt
     assert int(gate[1].item()) == 0xDEAD and int(gate[0].item()) == 0
+    # the ranks driver's check (stream.py check_gate, what bench.py calls behind its timed region) reads exactly this word: it raises
+    # once and clears it
+    import types
+
+    from pothoscomms_amd import stream
+    owner = types.SimpleNamespace(_gate=gate, _buf=x, _side=torch.cuda.Stream(device=dev), _pass=1, ring=types.SimpleNamespace(rank=1))
+    with pytest.raises(stream.GateTimeout):
+        stream._check_gate(owner)
+    stream._check_gate(owner)
+    assert int(gate[1].item()) == 0
 
 
 _DROP_SCRIPT = r"""

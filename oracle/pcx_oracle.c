@@ -19,7 +19,12 @@
  *     Conjugate}.cpp (tests/golden/).
  *   - FIR / FreqDemod: the reference tests hold no numeric vectors for them
  *     (RMS threshold only / no test); the restatement is pinned by an
- *     independent float64 convolution and the survey's observed anchors.
+ *     independent float64 convolution and the survey's observed anchors, and
+ *     -- since their loops are nothing but std::complex operator*, operator+=
+ *     and getAngle -- by fixtures composed of exactly those pieces as the
+ *     COMPILED reference toolchain evaluates them (oracle/_ref ref_std_arith,
+ *     ref_angle_*; tests/golden/make_golden.py sections 4 and 5): bit for bit,
+ *     float FIR on the BASELINE tap sets and FreqDemod for all six types.
  *   - Integer Q-format (fromQ/floatToQ live in PothosCore, which is not in
  *     the reference tree): restated as "half of the Q word is fractional,
  *     floatToQ = T(ldexp(x, n)), fromQ = T(q >> n)".  PARITY UNPINNED: of the

@@ -30,6 +30,13 @@ Two kinds of vectors, all plain data (inputs + expected outputs):
     -- with _prev = 0 at activate() (:44-47).  `freqdemod_out_*` = ref_angle(ref_std_arith(MUL, x[i], conj(x[i-1]))), x[-1] = 0:
     the compiled pieces composed, no restatement of either in between.  The integer inputs cover the wrap of the product in
     complex<intN> followed by getAngle's truncation to int16.
+ 4. /comms/fir_filter, floating point: filter/FIRFilter.cpp needs <Pothos/Framework.hpp> too, but for float element types its loop
+    (:294-300) is `y_n += _interpTaps[j][k] * QType(x[n-k])` in std::complex<float> / <double> -- the toolchain's operator* and
+    operator+= again (fromQ / floatToQ are plain casts for floating-point Q types) -- k ascending, y_n starting at 0.  `fir_*_out` =
+    that sum composed of ref_std_arith MUL and ADD, tap by tap (REAL taps: `T * complex<T>` scales both parts, two real
+    multiplies), on the BASELINE tap sets (63 complex taps of configs[0], 255 of configs[1], 127 real taps of configs[4]) narrowed
+    to the element type once, as :348 does.  Pins the ORDER and the operators of the oracle's FIR loop, and the device's EXACT kernel,
+    bit for bit; the integer element types go through the un-vendored Q-format and stay with the parametrised restatement.
 """
 import os
 import sys
@@ -201,6 +208,26 @@ def main():
         diff = o.ref_arith(o.MUL, np.ascontiguousarray(x), np.ascontiguousarray(prev), True)
         g["freqdemod_in_" + name] = x
         g["freqdemod_out_" + name] = o.ref_angle(diff)
+
+    # ---- 5. /comms/fir_filter (float types) = compiled std::complex multiply-accumulate in the loop's order (docstring, 4.) -----
+    from pothoscomms_amd import taps as tp            # tap recipes only (numpy): SURVEY 8d's windowed-sinc sets
+    rng5 = np.random.default_rng(20240505)
+    for key, taps, ctaps, dt, nout in (("c0_63c_f32", tp.c0_taps(), True, np.float32, 4096), ("c1_255c_f32", tp.c1_taps(), True, np.float32, 2048),
+                                       ("c4_127r_f32", tp.c4_taps(), False, np.float32, 2048), ("31c_f64", tp.c0_taps()[:31], True, np.float64, 1024)):
+        K = len(taps)
+        x = rng5.uniform(-1, 1, (K - 1 + nout, 2)).astype(dt)
+        x[5] = [0.0, -0.0]
+        t = np.asarray(taps)
+        tq = np.stack([t.real, t.imag], 1).astype(dt) if ctaps else np.real(t).astype(dt)       # floatToQ<QTapsType>: one narrowing cast (:348)
+        acc = np.zeros((nout, 2), dt)                                                           # QType y_n = 0
+        for k in range(K):
+            xs = np.ascontiguousarray(x[K - 1 - k:K - 1 - k + nout])                            # x[n - k], n = 0 .. nout-1 (x = in + K-1, :281)
+            if ctaps:
+                prod = o.ref_arith(o.MUL, np.ascontiguousarray(np.broadcast_to(tq[k], (nout, 2))), xs, True)
+            else:                                                                               # T * complex<T>: both parts scaled
+                prod = o.ref_arith(o.MUL, np.full(2 * nout, tq[k], dt), xs.reshape(-1), False).reshape(nout, 2)
+            acc = o.ref_arith(o.ADD, acc, prod, True)
+        g["fir_%s_in" % key], g["fir_%s_taps" % key], g["fir_%s_out" % key] = x, np.asarray(taps, np.complex128 if ctaps else np.float64), acc
 
     np.savez_compressed(OUT, **g)
     print("wrote %s: %d arrays, %d bytes" % (OUT, len(g), os.path.getsize(OUT)))

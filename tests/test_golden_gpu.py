@@ -98,6 +98,26 @@ def test_reference_test_points_angle_abs(dev, name):
         assert np.array_equal(gc, want)         # getAbs compiled from the reference: float32 and the integers bit for bit
 
 
+@pytest.mark.parametrize("key,ctaps", [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("31c_f64", True)])
+def test_fir_against_the_compiled_complex_multiply_accumulate(dev, key, ctaps):
+    """filter/FIRFilter.cpp:294-300 as the compiled std::complex operator* / operator+= composed tap by tap in the loop's order
+    (tests/golden/make_golden.py section 5; the tap sets of BASELINE configs[0], [1], [4]): the HIP path against that fixture directly --
+    the EXACT kernel bit for bit, the frequency-domain and the FMA time-domain kernels within 1e-5 (float32) / 1e-13 (float64) of the
+    largest reference sample"""
+    x, taps, want = GOLD["fir_%s_in" % key], GOLD["fir_%s_taps" % key], GOLD["fir_%s_out" % key]
+    n = want.shape[0]
+    f = dev.FirFilter("complex_" + ("float32" if x.dtype == np.float32 else "float64"), "COMPLEX" if ctaps else "REAL")
+    f.set_taps(taps)
+    f.set_algo(dev._lib.FIR_EXACT)
+    got, c, p = f.process(x, n)
+    assert (c, p) == (n, n) and np.array_equal(got, want)
+    bar = TOL if x.dtype == np.float32 else 1e-13
+    for algo in (dev._lib.FIR_AUTO, dev._lib.FIR_DIRECT):
+        f.set_algo(algo)
+        got, c, p = f.process(x, n)
+        assert (c, p) == (n, n) and nerr(got, want) <= bar, algo
+
+
 @pytest.mark.parametrize("name", TYPES)
 def test_freqdemod_against_the_compiled_reference_pieces(dev, name):
     """demod/FreqDemod.cpp:60-67 as the compiled std::complex<T> operator* and the compiled getAngle (FxptHelpers.hpp:14-29) composed

@@ -290,6 +290,31 @@ def test_fir_integer_matches_exact_integer_convolution(oracle, scalar):
         assert int(y[n, 1]) == wrap(wrap(ai, qb) >> (qb // 2), ebits)
 
 
+FIR_FIXTURES = [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("31c_f64", True)]
+
+
+@pytest.mark.parametrize("key,ctaps", FIR_FIXTURES)
+def test_fir_against_the_compiled_complex_multiply_accumulate(oracle, key, ctaps):
+    """filter/FIRFilter.cpp:294-300 for float element types = std::complex operator* and operator+=, k ascending from y_n = 0, on taps
+    narrowed once (:348): the fixture composes the COMPILED operators tap by tap (tests/golden/make_golden.py section 5, the BASELINE tap
+    sets of configs[0] / [1] / [4]); the oracle's loop must give the same bits -- order, operators, narrowing -- in one call and in two"""
+    x, taps, want = GOLD["fir_%s_in" % key], GOLD["fir_%s_taps" % key], GOLD["fir_%s_out" % key]
+    sc = oracle.scalar_code(x)
+    K, n = len(taps), want.shape[0]
+    blk = oracle.Fir(sc, True, ctaps)
+    blk.set_taps(taps)
+    blk.activate()
+    got, c, p, _ = blk.work(x, n)
+    assert (c, p) == (n, n) and np.array_equal(got, want)
+    blk2 = oracle.Fir(sc, True, ctaps)
+    blk2.set_taps(taps)
+    blk2.activate()
+    n1 = n // 3
+    g1, c1, p1, _ = blk2.work(x[:K - 1 + n1], n1)
+    g2, c2, p2, _ = blk2.work(x[c1:], n - n1)           # the K-1 unconsumed samples stay in front as history (:305-307)
+    assert np.array_equal(np.concatenate([g1[:p1], g2[:p2]]), want)
+
+
 # ---- the Q-format reading as a parameter (include/pcx.h pcx_qformat, oracle.set_qformat) ------------------
 def _py_scale(x, factor, q, ebits, qbits):
     """arrayScale under a reading, in Python integers: an independent model of orc_scale (no shifts of negative numbers, no C)"""

@@ -37,6 +37,8 @@ Two kinds of vectors, all plain data (inputs + expected outputs):
     multiplies), on the BASELINE tap sets (63 complex taps of configs[0], 255 of configs[1], 127 real taps of configs[4]) narrowed
     to the element type once, as :348 does.  Pins the ORDER and the operators of the oracle's FIR loop, and the device's EXACT kernel,
     bit for bit; the integer element types go through the un-vendored Q-format and stay with the parametrised restatement.
+ 5. /comms/rotate and /comms/scale, floating point: `phasor * in` and `factor * in` through the same compiled operators, the phasor
+    from glibc's sincos as an optimised std::polar evaluates it (section 6 of main()).
 """
 import os
 import sys
@@ -228,6 +230,30 @@ def main():
                 prod = o.ref_arith(o.MUL, np.full(2 * nout, tq[k], dt), xs.reshape(-1), False).reshape(nout, 2)
             acc = o.ref_arith(o.ADD, acc, prod, True)
         g["fir_%s_in" % key], g["fir_%s_taps" % key], g["fir_%s_out" % key] = x, np.asarray(taps, np.complex128 if ctaps else np.float64), acc
+
+    # ---- 6. /comms/rotate, /comms/scale (float types) = the same compiled operators (math/Rotate.cpp:15-23,71-75, math/Scale.cpp:15-23) ----
+    # arrayRotate: out = phasor * QType(in), phasor = complex<T>(std::polar(1.0, phase)); arrayScale: out = factor * QType(in) (T * complex<T>
+    # scales both parts).  std::polar in an optimised build is one glibc sincos() call: the phasor stored here comes from that call.
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    phases = np.array([0.3, 2.747554270528532, -1.1, np.pi / 2])
+    factors = np.array([0.3337, -1.77, 100.25, 0.5])
+    ph = []
+    for p in phases:
+        sn, cs = ctypes.c_double(), ctypes.c_double()
+        libm.sincos(float(p), ctypes.byref(sn), ctypes.byref(cs))
+        ph.append([cs.value, sn.value])
+    g["rotscale_phases"], g["rotscale_phasors"], g["rotscale_factors"] = phases, np.array(ph), factors
+    rng6 = np.random.default_rng(20240606)
+    for name, dt in (("float32", np.float32), ("float64", np.float64)):
+        x = (rng6.normal(size=(512, 2)) * np.exp(rng6.uniform(-10, 10, (512, 1)))).astype(dt)
+        g["rotscale_in_" + name] = x
+        for k in range(len(phases)):
+            pz = np.ascontiguousarray(np.broadcast_to(np.array(ph[k]).astype(dt), x.shape))      # floatToQ<complex<T>>: narrowing cast
+            g["rotate_out_%s_%d" % (name, k)] = o.ref_arith(o.MUL, pz, x, True)
+            f = np.full(x.size, dt(factors[k]), dt)
+            g["scale_out_%s_%d" % (name, k)] = o.ref_arith(o.MUL, f, x.reshape(-1), False).reshape(x.shape)
 
     np.savez_compressed(OUT, **g)
     print("wrote %s: %d arrays, %d bytes" % (OUT, len(g), os.path.getsize(OUT)))

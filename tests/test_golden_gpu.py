@@ -98,6 +98,17 @@ def test_reference_test_points_angle_abs(dev, name):
         assert np.array_equal(gc, want)         # getAbs compiled from the reference: float32 and the integers bit for bit
 
 
+@pytest.mark.parametrize("name", ["float32", "float64"])
+def test_rotate_scale_against_the_compiled_operators(dev, name):
+    """math/Rotate.cpp:15-23 / math/Scale.cpp:15-23 on float types through the compiled std::complex and scalar multiplies
+    (tests/golden/make_golden.py section 6): the device bit for bit, no oracle in between"""
+    x = GOLD["rotscale_in_" + name]
+    for k, phase in enumerate(GOLD["rotscale_phases"]):
+        assert np.array_equal(dev.rotate(x, float(phase)), GOLD["rotate_out_%s_%d" % (name, k)]), phase
+    for k, factor in enumerate(GOLD["rotscale_factors"]):
+        assert np.array_equal(dev.scale(x, float(factor), True), GOLD["scale_out_%s_%d" % (name, k)]), factor
+
+
 @pytest.mark.parametrize("key,ctaps", [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("31c_f64", True)])
 def test_fir_against_the_compiled_complex_multiply_accumulate(dev, key, ctaps):
     """filter/FIRFilter.cpp:294-300 as the compiled std::complex operator* / operator+= composed tap by tap in the loop's order

@@ -290,6 +290,17 @@ def test_fir_integer_matches_exact_integer_convolution(oracle, scalar):
         assert int(y[n, 1]) == wrap(wrap(ai, qb) >> (qb // 2), ebits)
 
 
+@pytest.mark.parametrize("name", ["float32", "float64"])
+def test_rotate_scale_against_the_compiled_operators(oracle, name):
+    """math/Rotate.cpp:15-23,71-75 and math/Scale.cpp:15-23 for float types = the compiled std::complex / scalar multiplies on a phasor
+    that glibc's sincos gives (tests/golden/make_golden.py section 6): the oracle's loops AND its evaluation of std::polar, bit for bit"""
+    x = GOLD["rotscale_in_" + name]
+    for k, phase in enumerate(GOLD["rotscale_phases"]):
+        assert np.array_equal(oracle.rotate(x, float(phase)), GOLD["rotate_out_%s_%d" % (name, k)]), phase
+    for k, factor in enumerate(GOLD["rotscale_factors"]):
+        assert np.array_equal(oracle.scale(x, float(factor), True), GOLD["scale_out_%s_%d" % (name, k)]), factor
+
+
 FIR_FIXTURES = [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("31c_f64", True)]
 
 

@@ -37,6 +37,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver of this pool supports dmabuf IPC only: without this RCCL's peer setup fails with "hipIpcGetMemHandle: invalid argument".
+# Already exported on the boxes; set here as well (before torch / the HIP runtime load) so that a rank started from a bare environment works.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SHARD = 64 * 1024 * 1024       # samples per GPU (configs[1])

@@ -89,6 +89,23 @@ int main(void)
     CHECK(pcx_fft_destroy(fwd));
     CHECK(pcx_fft_destroy(inv));
     free(x); free(y); free(X); free(xb);
+
+    /* the Q-format reading of the integer element types is a parameter (pcx_qformat): int16 Scale, 0.5 x (5, -5) = +-2.5 under the three
+     * fromQ roundings the reference's own tests cannot tell apart -- floor 2 / -3, toward zero 2 / -2, nearest 3 / -2 */
+    {
+        const short in16[2] = {5, -5};
+        const short want[3][2] = {{2, -3}, {2, -2}, {3, -2}};
+        for (int m = 0; m < 3; m++) {
+            const pcx_qformat q = {PCX_Q_FRAC_HALF_Q, PCX_Q_TRUNCATE, m};
+            short out16[2] = {0, 0};
+            CHECK(pcx_scale_q(PCX_I16, 0, 0.5, &q, in16, out16, 2));
+            printf("scale int16 0.5 x (5, -5), fromQ mode %d: (%d, %d)\n", m, out16[0], out16[1]);
+            if (out16[0] != want[m][0] || out16[1] != want[m][1]) return 1;
+        }
+        pcx_qformat cur;
+        CHECK(pcx_get_qformat(&cur));
+        if (cur.frac != 0 || cur.float_to_q != 0 || cur.from_q != 0) return 1;      /* the process-wide reading is the built-in default */
+    }
     printf("ok\n");
     return 0;
 }

@@ -243,3 +243,38 @@ def test_blocks_take_the_reading_by_name(oracle):
             fir.call("setQFormat", "HALF_Q,SOMETIMES,FLOOR")
     finally:
         oracle.set_qformat()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_integer_fir_randomised_geometry_and_reading(oracle, dev, seed):
+    """random (integer type, taps kind, K, L, M, buffer sizes, output room) AND a random one of the twelve readings through AUTO --
+    whatever kernel family the geometry lands on -- against the oracle's work() under the same reading, bit for bit"""
+    rng = np.random.default_rng(7000 + seed)
+    q = oracle.QFORMATS[int(rng.integers(0, 12))]
+    scalar = [oracle.I16, oracle.I8, oracle.I32, oracle.I64][seed % 4]
+    is_complex = bool(rng.integers(0, 3) > 0)
+    ctaps = is_complex and bool(rng.integers(0, 2))
+    L, M = int(rng.integers(1, 5)), int(rng.integers(1, 6))
+    if seed % 3 == 0:
+        L = M = 1
+    ntaps = int(rng.integers(1, 400 if scalar in (oracle.I16, oracle.I8) else 80))
+    K = -(-ntaps // L)
+    n_in = int(rng.integers(K, K + 30000))
+    out_cap = int(rng.integers(1, 2 * n_in * L // M + 10))
+    taps = (rng.normal(size=ntaps) + (1j * rng.normal(size=ntaps) if ctaps else 0)) / np.sqrt(ntaps) * 0.9
+    x = rand_stream(rng, scalar, n_in, is_complex, amp=1000 if scalar != oracle.I8 else 100)
+    oracle.set_qformat(*q)
+    try:
+        ref = oracle.Fir(scalar, is_complex, ctaps)
+        f = dev.FirFilter((scalar, is_complex), "COMPLEX" if ctaps else "REAL")
+        f.set_qformat(q)
+        for b in (ref, f):
+            b.set_taps(taps); b.set_interpolation(L); b.set_decimation(M)
+        ref.activate()
+        want, rc, rp, _ = ref.work(x, out_cap)
+    finally:
+        oracle.set_qformat()
+    got, gc, gp = f.process(x, out_cap)
+    assert (gc, gp) == (rc, rp), (q, scalar, is_complex, ctaps, L, M, ntaps, n_in, out_cap)
+    if rp:
+        assert np.array_equal(got, want), (q, scalar, is_complex, ctaps, L, M, ntaps, f.last_algo)

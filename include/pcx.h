@@ -381,6 +381,15 @@ PCX_API int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elem
 /* one pass over every shard: the halo exchange and ONE launch per shard (pcx_fir_process_dev_gated); configurations without a
  * gated kernel run body, exchange, head as two launches */
 PCX_API int pcx_shard_step(pcx_shard *s);
+/* enable = 0: every shard as TWO launches per pass -- the body while the halo is in flight, the head behind an event on the halo
+ * stream -- instead of one gated launch (the default, enable = 1).  The gated launch relies on the halo transfer and its signal,
+ * which pcx_shard_step queues BEFORE the launch, reaching the device before it: that is how the runtime submits (in order, from the
+ * calling thread) in its default mode.  With AMD_DIRECT_DISPATCH=0 every stream is submitted by a thread of its own and a signal can
+ * land behind the launch it is to release, in the same hardware queue: the gate then opens on its two-second bound only and
+ * pcx_shard_gather / pcx_shard_sync report PCX_ERR_STATE (measured: intermittently, one test run in three on this stack; never in the
+ * default mode, nor with GPU_MAX_HW_QUEUES=1 / 8 or HSA_ENABLE_SDMA=0).  A process that has
+ * to run in that mode switches the gate off; the two-launch form costs 5-14 % of a pass. */
+PCX_API int pcx_shard_set_gated(pcx_shard *s, int enable);
 /* the nshards*shard_elems outputs in stream order (waits for the pass).  PCX_ERR_STATE when a shard's gated launch gave up
  * waiting for its halo during the passes since the last gather / sync (the two-second bound of pcx_fir_process_dev_gated): the
  * outputs are copied all the same, the seam's are wrong, and the condition is cleared by being reported. */

@@ -132,6 +132,7 @@ struct pcx_shard {
     size_t K = 1, C = 0, head = 0;
     std::vector<size_t> lead;                     // per shard: samples in front of the halo slot (alignment, pcx_shard_configure)
     bool have_taps = false;
+    bool use_gate = true;                         // pcx_shard_set_gated: false = body launch, halo event, head launch (two launches per shard)
     bool exchanged_once = false;                  // the first exchange has completed (RCCL sets its connections up lazily: pcx_shard_step)
     unsigned long long steps = 0;
     size_t halo() const { return chain_mode ? K : K - 1; }      // samples in front of every shard
@@ -229,11 +230,14 @@ int pcx_shard_create(int nshards, const int *devices, int transport, pcx_shard *
         // (halo streams at the device's highest stream priority were tried -- the exchange ahead of the passes' own kernels -- and
         // made every pass SLOWER: 0.2242 -> 0.2411 ms with two shards on one device, 0.2674 -> 0.4570 with eight,
         // profiles/r03/shard_probe.txt; PCX_SHARD_HALO_PRIO=1 in the diagnostic library repeats it)
-        int prio_lo = 0, prio_hi = 0;
-        if (PCX_ENV_INT("PCX_SHARD_HALO_PRIO", 0) != 0 && hipSetDevice(dev[g]) == hipSuccess &&
-            hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_hi = 0; }
+        int prio_lo = 0, prio_hi = 0, halo_prio = 0;
+        const long want_prio = PCX_ENV_INT("PCX_SHARD_HALO_PRIO", 0);      // (diagnostic library) 1: highest, -1: lowest, 0: default
+        if (want_prio != 0 && hipSetDevice(dev[g]) == hipSuccess) {
+            if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_lo = prio_hi = 0; }
+            halo_prio = want_prio > 0 ? prio_hi : prio_lo;
+        }
         if (hipSetDevice(dev[g]) != hipSuccess || hipStreamCreateWithFlags(&s->st[g], hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithPriority(&s->hst[g], hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&s->hst[g], hipStreamNonBlocking, halo_prio) != hipSuccess ||
             hipEventCreateWithFlags(&s->in_ready[g], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->halo_ready[g], hipEventDisableTiming) != hipSuccess ||
             hipMalloc(&s->gate[g], 256) != hipSuccess || hipMemset(s->gate[g], 0, 256) != hipSuccess) {
@@ -322,6 +326,13 @@ int pcx_shard_set_chain(pcx_shard *s, int enable, double phase)
     s->phase = phase;
     if (s->have_taps) PCX_TRY(shard_apply_taps(s));
     if (s->C && was != s->chain_mode) shard_free_buffers(s);   // another halo, another output type: lay the buffers out again
+    return PCX_OK;
+}
+
+int pcx_shard_set_gated(pcx_shard *s, int enable)
+{
+    PCX_CHECK_ARG(s, "null handle");
+    s->use_gate = enable != 0;
     return PCX_OK;
 }
 
@@ -653,8 +664,10 @@ int pcx_shard_step(pcx_shard *s)
         PCX_HIP(hipSetDevice(s->dev[g]));
         if (g == 0) { PCX_TRY(whole(0)); continue; }
         int gated = 0;
-        if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, s->gate[g], pass, &gated));
-        else PCX_TRY(shard_run_fir(s, g, 0, s->C, s->gate[g], pass, &gated));
+        if (s->use_gate) {
+            if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, s->gate[g], pass, &gated));
+            else PCX_TRY(shard_run_fir(s, g, 0, s->C, s->gate[g], pass, &gated));
+        }
         if (gated) continue;
         // no gated kernel for this configuration: the round-2 scheme.  FIR: the body while the halo is in flight, then the head
         // behind it; chain (long filters, short shards): the halo first, then the shard

@@ -498,3 +498,64 @@ def test_a_dropped_gate_signal_is_reported_by_gather_and_cleared():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     assert line == "RESULT ok,ok,state,ok,ok,ok", line
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_long_shards_with_the_gate_switched_off_take_two_launches_and_have_no_seam(oracle, chain):
+    """pcx_shard_set_gated(s, 0): the documented way out for a process that must run under AMD_DIRECT_DISPATCH=0 (every stream submitted
+    by a thread of its own: a signal can land behind the launch it is to release).  Shards long enough for the gated kernel, the gate
+    off: body while the halo is in flight, head behind the halo event; poisoned halos, two passes; seams against the oracle, and the
+    stream equal to the gated form's within the float bar (FIR) / the angle bar (chain)."""
+    from pothoscomms_amd import _lib, device, taps as tp
+    from tests.util import ang_err
+    L = _lib.load()
+    G = 3
+    h = tp.c4_taps() if chain else tp.c1_taps()
+    K, Cs = len(h), 2080 * (3968 if chain else 3840)
+    outs = []
+    for gated in (True, False):
+        ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+        if chain:
+            ns.set_chain(True, tp.C4_PHASE)
+        ns.set_taps(h, complex_taps=not chain)
+        ns.set_gated(gated)
+        ns.configure(Cs)
+        halo = K if chain else K - 1
+        for rep in range(2):
+            for g in range(G):
+                i, o, s, d = ns.buffers(g)
+                if chain:       # the FM signal, each shard at its own amplitude (tests/test_c3_gpu.py has the reasons)
+                    xs = (tp.fm_test_signal(K - 1 + Cs, start=0).view(np.float32).reshape(-1, 2) * np.float32(1.0 + 0.05 * g + 0.01 * rep)).astype(np.float32)
+                    _lib.check(L.pcx_memcpy_h2d(C.c_void_p(i), xs.ctypes.data_as(C.c_void_p), xs.nbytes, C.c_void_p(s)))
+                else:
+                    _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (K - 1 + Cs), 4 + rep, 2 * g * Cs, C.c_void_p(s)))
+                if g > 0:
+                    nan = np.full((halo, 2), np.nan, np.float32)
+                    _lib.check(L.pcx_memcpy_h2d(C.c_void_p(i - 8 * (halo - (K - 1))), nan.ctypes.data_as(C.c_void_p), nan.nbytes, C.c_void_p(s)))
+                _lib.check(L.pcx_stream_sync(C.c_void_p(s)))
+            ns.step()
+            got = ns.gather()
+            assert np.isfinite(got).all(), (gated, rep)
+        outs.append(got)
+        # every seam of the last pass against the oracle, inputs cut from the shards' own buffers
+        W = 3000
+        for g in range(1, G):
+            il, _, _, _ = ns.buffers(g - 1)
+            ir, _, _, _ = ns.buffers(g)
+            extra = 1 if chain else 0
+            left = np.empty((W + extra + K - 1, 2), np.float32)
+            right = np.empty((W, 2), np.float32)
+            _lib.check(L.pcx_memcpy_d2h(left.ctypes.data_as(C.c_void_p), C.c_void_p(il + 8 * (Cs - W - extra)), left.nbytes, None))
+            _lib.check(L.pcx_memcpy_d2h(right.ctypes.data_as(C.c_void_p), C.c_void_p(ir + 8 * (K - 1)), right.nbytes, None))
+            xin = np.concatenate([left, right])
+            seam = got[g * Cs - W:g * Cs + W]
+            if chain:
+                assert ang_err(seam, _oracle_chain(oracle, h, tp.C4_PHASE, xin, 2 * W + 1)[1:]) <= TOL, (gated, g)
+            else:
+                assert nerr(seam, _oracle_fir(oracle, h, xin, 2 * W)) <= TOL, (gated, g)
+        ns.close()
+    if chain:
+        dd = np.abs((outs[0].astype(np.float64) - outs[1] + np.pi) % (2 * np.pi) - np.pi)
+        assert np.quantile(dd, 1 - 1e-5) / np.pi <= 2 * TOL and dd.max() < 1e-2
+    else:
+        assert nerr(outs[1], outs[0]) <= TOL

@@ -255,6 +255,21 @@ def test_bench_spawns_its_own_ranks_and_reports_the_world_it_saw():
     assert out["value"] > 0
 
 
+def test_bench_falls_back_to_two_launches_when_a_rank_reports_a_gate_timeout_in_setup():
+    """the first real multi-GPU run will be the driver's: if ANY rank's gated launch times out waiting for its halo during the setup
+    passes, every rank switches to the two-launch pass for the timed region and the line says so (here the timeout is pretended, on
+    rank 1 of two gloo ranks; the all-reduce of the flag, the switch on BOTH ranks and the annotation are real)"""
+    import json
+    r = _run_bench({"PCX_BENCH_BACKEND": "gloo", "PCX_BENCH_TEST_GATE_TIMEOUT": "1"}, "--gpus", "2", "--shard", "1048576", "--steps", "3", "--warmup", "1",
+                   "--settle", "8", "--no-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and "FALLBACK" in out["config"]["halo_scheme"] and out["value"] > 0
+    r = _run_bench({"PCX_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--shard", "1048576", "--steps", "3", "--warmup", "1", "--settle", "8", "--no-cpu")
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "FALLBACK" not in out["config"]["halo_scheme"] and "host-driven" in out["config"]["halo_scheme"]
+
+
 def test_bench_refuses_more_rccl_ranks_than_gpus():
     """With the RCCL backend every rank needs its own GPU: asking for more than the node has must fail, not fold."""
     import torch

@@ -784,32 +784,42 @@ def main():
     # of the W warm-up steps or the timed region; their number is reported as config.setup_passes, and what the launches
     # behind an idle period cost is reported as roofline.cold.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(args.settle):
-        step()
-    for _ in range(args.warmup):
-        step()
     fell_back = False
-    if world > 1 and W.owner is not None:
-        # A gate timeout during the setup passes is reported and cleared here, so that the check behind the timed region speaks for the
-        # timed passes alone -- and it is ACTED on: the one-launch pass rests on assumptions that one GPU cannot prove (a peer's bytes
-        # visible behind the gate's acquire, RCCL's kernel finding room beside a persistent launch).  If any rank saw its
-        # gate time out, EVERY rank switches to the two-launch pass (body, halo, head: stream.py two_launch) for the timed region, the
-        # setup passes are repeated in that form, and the line says so (config.halo_scheme).
+
+    def gate_check_and_fall_back(where):
+        """A gate timeout during the setup passes is reported and cleared, so that the check behind the timed region speaks for the timed
+        passes alone -- and it is ACTED on: the one-launch pass rests on assumptions that one GPU cannot prove (a peer's bytes visible
+        behind the gate's acquire, RCCL's kernel finding room beside a persistent launch).  If ANY rank saw its gate time
+        out, EVERY rank switches to the two-launch pass (body, halo, head: stream.py two_launch) from here on, and the line says so
+        (config.halo_scheme).  Every rank calls this at the same points."""
+        nonlocal fell_back
+        if world == 1 or W.owner is None:
+            return
         timed_out = 0
         try:
             W.owner.check_gate()
         except RuntimeError as e:
             timed_out = 1
-            print("bench.py: rank %d, during the setup passes (cleared): %s" % (rank, e), file=sys.stderr, flush=True)
+            print("bench.py: rank %d, %s (cleared): %s" % (rank, where, e), file=sys.stderr, flush=True)
         if os.environ.get("PCX_BENCH_TEST_GATE_TIMEOUT") == str(rank):      # tests only: this rank reports a timeout it did not have
             timed_out = 1
-        flag = torch.tensor([timed_out], dtype=torch.int32, device=dev)
+        flag = torch.tensor([timed_out], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) and not W.owner.two_launch:
             fell_back = True
             W.owner.two_launch = True
-            for _ in range(args.settle // 4 + args.warmup):
-                step()
+
+    for k in range(args.settle):
+        step()
+        if k == 2:
+            gate_check_and_fall_back("after the first three setup passes")     # early: 400 passes of two-second timeouts would be a quarter of an hour
+    for _ in range(args.warmup):
+        step()
+    before = fell_back
+    gate_check_and_fall_back("during the setup passes")
+    if fell_back and not before:
+        for _ in range(args.settle // 4 + args.warmup):      # the setup once more, in the form the timed region will run
+            step()
     barrier()
     # HIP events on the launch stream (torch's current stream is the stream every pcx_*_dev call
     # gets): ONE pair around the K timed steps, so no event packet sits between two launches

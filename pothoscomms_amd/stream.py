@@ -52,6 +52,19 @@ def _check_gate(owner):
                           "the outputs at the front of the shard were computed on a stale halo" % (owner.ring.rank, owner._pass))
 
 
+# Resident workgroup slots of a rank's launches when RCCL carries the halo.  RCCL's send / receive is a protocol KERNEL -- one workgroup
+# of 256 lanes, 132 VGPRs, 20 KB of LDS, resident for ~150 us of every pass -- and beside a launch that fills all 1024 slots it shares a
+# CU with four FIR workgroups and a saturated memory system.  One GPU, the halo sent to the rank itself (tools/host_step_probe.py, the
+# pass of a middle rank; the single-GPU launch on the same box: 191.5 us):  1024 slots 206 us per pass, 896: 198, 768: 194, 640: 206,
+# 512: 232 (profiles/r04/rccl_pass_slots.txt).  With 768 -- three workgroups on every CU, the dealer spreads the blocks -- the protocol
+# kernel costs 1.4 % of a pass instead of 7.8 %.
+RCCL_SLOTS = 768
+
+
+def _rccl_world(ring):
+    return ring.world > 1 and dist.is_initialized() and dist.get_backend(ring.group) == "nccl"
+
+
 def _first_exchange(owner):
     """The FIRST exchange of a driver is waited for on the host before the gated launch that depends on it is queued: RCCL sets its
     point-to-point connections up lazily, inside the first send / receive, and that can take longer than the two seconds a gated launch
@@ -123,13 +136,16 @@ class ShardedFir:
         self.two_launch = _two_launch_forced(two_launch)
         self.fir = dv.FirFilter("complex_float32", taps_type)
         self.fir.set_taps(taps)
-        if slots is not None:        # several ranks on ONE device (a rehearsal): each takes its share of the resident slots
-            self.fir.set_slots(slots)
         if algo is not None:
             self.fir.set_algo(algo)
         self.K = self.fir.K
         self.C = int(shard_len)
         self.ring = HaloRing(self.K - 1, group)
+        if slots is None and _rccl_world(self.ring):
+            slots = RCCL_SLOTS       # room for RCCL's protocol kernel beside the launch (above)
+        if slots is not None:        # (also: several ranks on ONE device, a rehearsal -- each takes its share of the resident slots)
+            self.fir.set_slots(slots)
+        self.slots = slots
         # layout in HBM: [lead | halo (K-1) | shard (C)] with the SHARD on a 128-byte line (the halo is
         # right-aligned against it).  The overlap-save kernel rounds its block overlap up to 16 samples,
         # so with this placement every 2 KiB row it loads AND every row it stores starts on a line
@@ -263,7 +279,7 @@ class ShardedFmChain:
     """
     HEAD = 4096
 
-    def __init__(self, taps, phase, shard_len, device, complex_taps=False, algo=None, group=None, two_launch=None):
+    def __init__(self, taps, phase, shard_len, device, complex_taps=False, algo=None, group=None, two_launch=None, slots=None):
         from . import device as dv   # the HIP path; raises if libpcx_hip.so is missing
         self.two_launch = _two_launch_forced(two_launch)
         self._chains = []
@@ -277,6 +293,12 @@ class ShardedFmChain:
         self.K = len(taps)
         self.C = int(shard_len)
         self.ring = HaloRing(self.K, group)
+        # (no RCCL_SLOTS here: the fused kernel is bound by its arithmetic and needs every slot -- the same probe with the chain: 1024 slots
+        # 207-209 us per pass against 201 for the single-GPU launch, 896: 217, 768: 223-231)
+        if slots is not None:
+            for ch in self._chains:
+                ch.set_slots(slots)
+        self.slots = slots
         lead = (-(self.K - 1)) % 16      # the sample behind the FIR history of the head call on a 128-byte line
         self._alloc = torch.zeros((lead + self.K + self.C, 2), dtype=torch.float32, device=device)
         self._buf = self._alloc[lead:]

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
 from pothoscomms_amd import taps as tp
-from pothoscomms_amd.stream import ShardedFir, HaloRing
+from pothoscomms_amd.stream import ShardedFir, ShardedFmChain, HaloRing
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 dev = torch.device("cuda", 0)
@@ -30,8 +30,13 @@ class SelfRing(HaloRing):
 
 C = 64 * 1024 * 1024
 slots = int(sys.argv[1]) if len(sys.argv) > 1 else None      # resident workgroups the gated launch takes (default: all 1024)
-sf = ShardedFir(tp.c1_taps(), C, dev, slots=slots)
-sf.ring = SelfRing(sf.K - 1)
+chain = "chain" in sys.argv[2:]                            # the fused chain's pass instead of the FIR's (halo of K samples)
+if chain:
+    sf = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, C, dev, slots=slots)
+    sf.ring = SelfRing(sf.K)
+else:
+    sf = ShardedFir(tp.c1_taps(), C, dev, slots=slots)
+    sf.ring = SelfRing(sf.K - 1)
 for _ in range(50):
     sf.step()
 torch.cuda.synchronize()
@@ -42,5 +47,5 @@ for _ in range(n):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(("high-priority RCCL streams, " if hp else "") + "slots %s  host: %.1f us to queue a pass; device: %.1f us per pass (queue + drain of %d passes)" % (slots, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6, n))
+print(("high-priority RCCL streams, " if hp else "") + ("fused chain, " if chain else "") + "slots %s  host: %.1f us to queue a pass; device: %.1f us per pass (queue + drain of %d passes)" % (slots, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6, n))
 dist.destroy_process_group()

@@ -340,7 +340,8 @@ def _rccl_self_worker(port, C, chain, q, two_launch=False):
             assert torch.equal(sc.buf[:sc.K], tail)
             res.append((sc.buf.cpu().numpy(), out.cpu().numpy()))
     else:
-        sf = ShardedFir(tp.c1_taps(), C, dev, two_launch=two_launch)
+        from pothoscomms_amd import stream
+        sf = ShardedFir(tp.c1_taps(), C, dev, two_launch=two_launch, slots=stream.RCCL_SLOTS)      # what a rank of an RCCL world takes by default
         sf.ring = SelfRing(sf.K - 1)
         K = sf.K
         f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.c1_taps())

@@ -99,6 +99,9 @@ def test_c3_fir_eight_shards_of_64Mi_on_one_device(oracle):
         # stream start: shard 0 filters from the stream's own K-1 history
         x0 = _d2h(L, bufs[0][0], K - 1 + W, 2)
         assert nerr(_d2h(L, bufs[0][1], W, 2), _oracle_fir(oracle, h, x0, W)) <= TOL
+        # and the stream's end: the last W outputs of the last shard (first / last samples and every shard boundary)
+        xe = _d2h(L, bufs[G - 1][0] + 8 * (Cs - W), W + K - 1, 2)
+        assert nerr(_d2h(L, bufs[G - 1][1] + 8 * (Cs - W), W, 2), _oracle_fir(oracle, h, xe, W)) <= TOL
         for g in range(1, G):
             # outputs g*C - W .. g*C + W - 1 of the stream: their inputs, cut from shard g-1's and shard g's OWN samples
             left = _d2h(L, bufs[g - 1][0] + 8 * (Cs - W), W + K - 1, 2)              # in_{g-1}[C-W : C+K-1]
@@ -164,6 +167,8 @@ def test_c3_split_of_the_fused_chain_eight_shards_of_64Mi(oracle):
         bufs = [ns.buffers(g) for g in range(G)]
         x0 = _d2h(L, bufs[0][0], K - 1 + W, 2)
         assert ang_err(_d2h(L, bufs[0][1], W, 0), _oracle_chain(oracle, h, tp.C4_PHASE, x0, W)) <= TOL
+        xe = _d2h(L, bufs[G - 1][0] + 8 * (Cs - W - 1), W + 1 + K - 1, 2)          # the stream's end (one output in front seeds the demodulator)
+        assert ang_err(_d2h(L, bufs[G - 1][1] + 4 * (Cs - W), W, 0), _oracle_chain(oracle, h, tp.C4_PHASE, xe, W + 1)[1:]) <= TOL
         for g in range(1, G):
             # outputs g*C - W .. g*C + W - 1 and the one before them (the demodulator's predecessor), inputs from the shards' own samples
             left = _d2h(L, bufs[g - 1][0] + 8 * (Cs - W - 1), W + 1 + K - 1, 2)      # in_{g-1}[C-W-1 : C+K-1]

@@ -338,3 +338,19 @@ def test_a_handle_can_be_destroyed_with_its_work_still_in_flight(oracle, dev):
     for start in (0, n - 50000):
         xw = x[start:start + 50000 + K - 1].cpu().numpy()
         assert nerr(y[start:start + 50000].cpu().numpy(), ref.work(xw, 50000)[0]) <= TOL
+
+
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """pcx_clock_probe_dev (a measurement aid of the C ABI): one wave spins for spin_us and reports shader cycles per 100 MHz tick in
+    MHz -- on an idle device the boost clock, beside a running workload the clock the power cap leaves it (bench.py roofline.valu)"""
+    import torch
+
+    from pothoscomms_amd import _lib, device
+    out = torch.zeros((4,), dtype=torch.float32, device="cuda:0")
+    side = torch.cuda.Stream()
+    device.clock_probe(out, 200, side)
+    torch.cuda.synchronize()
+    mhz = float(out[0].item())
+    assert 500.0 < mhz < 3500.0, mhz
+    with pytest.raises(_lib.InvalidArgument):
+        device.clock_probe(out, 0, side)

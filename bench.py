@@ -65,10 +65,26 @@ def parse():
                     help="seconds of extra launches behind the timed region whose last half is reported as roofline.sustained (0: off)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default workload only: skip the `secondary` object (configs[2] 4096-pt FFT and configs[4] fused chain, ~1 s of GPU each)")
+    ap.add_argument("--rehearse-rccl-rank", action="store_true",
+                    help="N = 1 only, fir255 / fmchain: time the pass a MIDDLE rank of an RCCL world runs -- side stream, one grouped RCCL send + receive "
+                         "of the halo (to the rank itself: one GPU is enough), gate signal, ONE gated launch on the slots such a rank takes -- instead "
+                         "of the plain single-GPU launch; the line says it is a rehearsal")
+    ap.add_argument("--rehearse-slots", type=int, default=0,
+                    help="with --rehearse-rccl-rank: resident workgroups of the gated launch (a multiple of 128; default: what a rank of an RCCL world takes)")
     ap.add_argument("--no-cold", action="store_true", help="skip roofline.cold (three bursts of 20 launches behind 5 ms of idle)")
     ap.add_argument("--settle", type=int, default=PREWARM,
                     help="untimed setup passes before the W warm-up steps (clock settling after idle; reported as config.setup_passes)")
     return ap.parse_args()
+
+
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio when its first communicator comes up; flushed only at exit it would land BEHIND the
+    JSON line this program prints with Python's own (unbuffered-on-flush) stdout.  The result line must be the last thing on stdout."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
 
 
 def _median_time(fn, reps=3):
@@ -384,8 +400,9 @@ def run_native(args):
                      "bytes_counted": "per device: its shards' algorithmic read + write bytes over the wall time of a pass (host clock "
                                       "around the K steps, all streams synchronised on both sides)"},
     }
-    print(json.dumps(out), flush=True)
     ns.close()
+    _flush_c_stdio()
+    print(json.dumps(out), flush=True)
 
 
 # ---- measured ceilings next to the datasheet ones ---------------------------------------------------------------------------------
@@ -757,24 +774,65 @@ def main():
     rank_devices = [dev_index]
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # NO device_id: with it torch creates the communicator eagerly and binds it to the device, and on this stack the ranks' pass --
+            # grouped isend / irecv on a side stream beside the gated launch -- then takes 225 us instead of 194 (tools/host_step_probe.py
+            # 768 devid, profiles/r04/rccl_pass_slots.txt).  The device is the current one (set above); barriers name it.
+            dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
         gathered = [None] * world
         dist.all_gather_object(gathered, (rank, dev_index, torch.cuda.get_device_properties(dev).name))
+        _flush_c_stdio()
         rank_devices = [g[1] for g in sorted(gathered)]
         world = dist.get_world_size()      # what the line reports is what the collective layer formed
 
     C = args.shard
     wl = args.workload
-    W = build_workload(wl, C, dev, rank, world, args)
+    rehearsal = False
+    if args.rehearse_rccl_rank:
+        if world != 1 or wl not in ("fir255", "fmchain"):
+            raise SystemExit("--rehearse-rccl-rank: one process, --workload fir255 or fmchain")
+        # a process group of ONE over RCCL; the workload is then built as a rank of an RCCL world would build it (its slots), and its ring
+        # is replaced by one whose neighbours are both the rank itself: a send AND a receive in one RCCL group, like any interior rank
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1)          # (no device_id: as the ranks of a real world, above)
+        rehearsal = True
+    W = build_workload(wl, C, dev, rank, 2 if rehearsal else world, args)
+    if rehearsal:
+        from pothoscomms_amd import stream as _stream
+
+        class SelfRing(_stream.HaloRing):
+            def __init__(self, halo):
+                self.halo, self.group, self.rank, self.world = halo, None, 1, 3
+
+            def start(self, buf):
+                return dist.batch_isend_irecv([dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], 0), dist.P2POp(dist.irecv, buf[:self.halo], 0)])
+        W.owner.ring = SelfRing(W.owner.ring.halo)
+        want_slots = args.rehearse_slots or ((_stream.RCCL_SLOTS or 0) if wl == "fir255" else 0)
+        if want_slots:                                     # (the world of one it was built in did not ask for them)
+            if wl == "fir255":
+                W.owner.fir.set_slots(want_slots)
+            else:
+                for ch in W.owner._chains:
+                    ch.set_slots(want_slots)
+            W.owner.slots = want_slots
+        W.desc["parallelism"] = ("REHEARSAL on one GPU: the pass of a MIDDLE rank of an RCCL world -- grouped RCCL send + receive of the halo (to the rank "
+                                 "itself), gate signal, one gated launch on %s resident workgroups" % (W.owner.slots or 1024))
     step, desc = W.step, W.desc
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # setup: let the clocks settle.  The launches behind an idle period run through a DVFS transient on this part: after
@@ -882,14 +940,20 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline_of(wl, C)
-        if world == 1 and wl == "fir255" and not args.no_secondary:
+        if world == 1 and wl == "fir255" and not args.no_secondary and not rehearsal:
             # BASELINE.json configs[2] and configs[4], measured by the same command so that the driver's own run covers them
             del W, step
             out["secondary"] = {"fft4096": measure_secondary("fft4096", dev, args), "fmchain": measure_secondary("fmchain", dev, args)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+        result_line = json.dumps(out)
+    if rehearsal:
+        W.owner.check_gate()
         dist.destroy_process_group()
+    if world > 1:
+        barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        _flush_c_stdio()            # whatever RCCL printed through C stdio goes out first: the result line is the last thing on stdout
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

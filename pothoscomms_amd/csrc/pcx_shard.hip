@@ -388,11 +388,9 @@ int pcx_shard_configure(pcx_shard *s, size_t shard_elems)
         unsigned same = 0;
         for (int k = 0; k < s->G; k++) same += s->dev[k] == s->dev[g];
         const unsigned slots = same >= 2 ? 512 : 1024;
-        // RCCL's send / receive is a protocol KERNEL -- one workgroup, 132 VGPRs, 20 KB of LDS, resident for ~150 us of every pass -- and
-        // beside 1024 persistent FIR workgroups it costs 7.8 % of a pass; beside 768 (three per CU) 1.4 % (206 -> 194 us against 191.5 for
-        // the plain launch: the ranks driver's pass of a middle rank on one GPU, profiles/r04/rccl_pass_slots.txt).  The fused chain, bound
-        // by its arithmetic, wants every slot (207 us at 1024, 223 at 768) and keeps them.
-        const unsigned fir_slots = (same == 1 && s->G > 1 && s->transport == PCX_SHARD_RCCL) ? 768 : slots;
+        // (Fewer slots under the RCCL transport, room for its protocol kernel, looked like 6 % on an all-zero probe and is nothing on data:
+        // profiles/r04/rccl_pass_slots.txt.  A shard alone on its device takes all 1024.)
+        const unsigned fir_slots = slots;
         fir_set_slots(s->fir[g], fir_slots);
         if (s->chain[g]) fmchain_set_slots(s->chain[g], slots);
     }

@@ -52,13 +52,11 @@ def _check_gate(owner):
                           "the outputs at the front of the shard were computed on a stale halo" % (owner.ring.rank, owner._pass))
 
 
-# Resident workgroup slots of a rank's launches when RCCL carries the halo.  RCCL's send / receive is a protocol KERNEL -- one workgroup
-# of 256 lanes, 132 VGPRs, 20 KB of LDS, resident for ~150 us of every pass -- and beside a launch that fills all 1024 slots it shares a
-# CU with four FIR workgroups and a saturated memory system.  One GPU, the halo sent to the rank itself (tools/host_step_probe.py, the
-# pass of a middle rank; the single-GPU launch on the same box: 191.5 us):  1024 slots 206 us per pass, 896: 198, 768: 194, 640: 206,
-# 512: 232 (profiles/r04/rccl_pass_slots.txt).  With 768 -- three workgroups on every CU, the dealer spreads the blocks -- the protocol
-# kernel costs 1.4 % of a pass instead of 7.8 %.
-RCCL_SLOTS = 768
+# (Round 4 first gave a rank of an RCCL world 768 of the 1024 resident slots, on a probe whose input was all ZERO -- without the power cap's
+# grip the pass read 206 us at 1024 slots and 194 at 768.  On DATA the slots do not matter: 212-215 us at 1024, 210-211 at 896, 214 at 768,
+# 224 at 640 against 193 for the single-GPU launch (bench.py --rehearse-rccl-rank --rehearse-slots N, profiles/r04/rccl_pass_slots.txt).
+# RCCL's protocol kernel costs 9-11 % of a pass whatever room it is given; the default stays 1024.)
+RCCL_SLOTS = None
 
 
 def _rccl_world(ring):
@@ -141,9 +139,9 @@ class ShardedFir:
         self.K = self.fir.K
         self.C = int(shard_len)
         self.ring = HaloRing(self.K - 1, group)
-        if slots is None and _rccl_world(self.ring):
-            slots = RCCL_SLOTS       # room for RCCL's protocol kernel beside the launch (above)
-        if slots is not None:        # (also: several ranks on ONE device, a rehearsal -- each takes its share of the resident slots)
+        if slots is None and RCCL_SLOTS and _rccl_world(self.ring):
+            slots = RCCL_SLOTS       # (off: see RCCL_SLOTS above)
+        if slots is not None:        # several ranks on ONE device (a rehearsal): each takes its share of the resident slots
             self.fir.set_slots(slots)
         self.slots = slots
         # layout in HBM: [lead | halo (K-1) | shard (C)] with the SHARD on a 128-byte line (the halo is
@@ -293,8 +291,6 @@ class ShardedFmChain:
         self.K = len(taps)
         self.C = int(shard_len)
         self.ring = HaloRing(self.K, group)
-        # (no RCCL_SLOTS here: the fused kernel is bound by its arithmetic and needs every slot -- the same probe with the chain: 1024 slots
-        # 207-209 us per pass against 201 for the single-GPU launch, 896: 217, 768: 223-231)
         if slots is not None:
             for ch in self._chains:
                 ch.set_slots(slots)

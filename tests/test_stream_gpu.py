@@ -194,24 +194,24 @@ def _rccl_worker(port, q):
     import torch.distributed as dist
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # "nccl" is RCCL on ROCm: what bench.py opens
+    dist.init_process_group("nccl", rank=0, world_size=1)     # "nccl" is RCCL on ROCm: what bench.py opens (no device_id: bench.py says why)
     from pothoscomms_amd import device, taps as tp
     from pothoscomms_amd.stream import ShardedFir
     sf = ShardedFir(tp.c1_taps(), 1 << 16, dev)
     device.fill_uniform_f32_dev(sf.buf, seed=2, offset=0)
-    dist.barrier()
+    dist.barrier(device_ids=[0])
     torch.cuda.synchronize()
     out = sf.step()
     torch.cuda.synchronize()
     t = torch.tensor([3.5], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                                 # bench.py's max-over-ranks timing reduction
-    dist.barrier()
+    dist.barrier(device_ids=[0])
     q.put((float(t.item()), sf.buf.cpu().numpy(), out.cpu().numpy()))
     dist.destroy_process_group()
 
 
 def test_rccl_group_of_one_runs_the_bench_control_flow(oracle):
-    """The 8-GPU run opens an RCCL group (bench.py: init_process_group("nccl", device_id=...), barrier, all_reduce MAX
+    """The 8-GPU run opens an RCCL group (bench.py: init_process_group("nccl"), barrier(device_ids), all_reduce MAX
     around the sharded step).  One GPU cannot host two RCCL ranks, so the seam itself is covered over gloo above;
     this holds the RCCL side of the control flow -- the library loads, the communicator comes up on this image,
     barrier / all_reduce run on the device, and the sharded step works inside an initialised nccl group."""
@@ -340,8 +340,7 @@ def _rccl_self_worker(port, C, chain, q, two_launch=False):
             assert torch.equal(sc.buf[:sc.K], tail)
             res.append((sc.buf.cpu().numpy(), out.cpu().numpy()))
     else:
-        from pothoscomms_amd import stream
-        sf = ShardedFir(tp.c1_taps(), C, dev, two_launch=two_launch, slots=stream.RCCL_SLOTS)      # what a rank of an RCCL world takes by default
+        sf = ShardedFir(tp.c1_taps(), C, dev, two_launch=two_launch, slots=768 if two_launch else None)      # (also on fewer resident workgroups than all)
         sf.ring = SelfRing(sf.K - 1)
         K = sf.K
         f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.c1_taps())

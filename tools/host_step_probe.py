@@ -15,6 +15,8 @@ hp = len(sys.argv) > 2 and sys.argv[2] == "hp"          # RCCL's own streams at 
 if hp:
     opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
     dist.init_process_group("nccl", rank=0, world_size=1, pg_options=opts)
+elif "devid" in sys.argv[2:]:                             # eager communicator bound to the device, as bench.py's ranks create it
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 else:
     dist.init_process_group("nccl", rank=0, world_size=1)
 
@@ -37,6 +39,8 @@ if chain:
 else:
     sf = ShardedFir(tp.c1_taps(), C, dev, slots=slots)
     sf.ring = SelfRing(sf.K - 1)
+from pothoscomms_amd import device
+device.fill_uniform_f32_dev(sf.buf, seed=2, offset=0)     # DATA, not zeros: on all-zero input the power cap lets go of the clock and every pass reads ~8 % faster
 for _ in range(50):
     sf.step()
 torch.cuda.synchronize()
@@ -47,5 +51,5 @@ for _ in range(n):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(("high-priority RCCL streams, " if hp else "") + ("fused chain, " if chain else "") + "slots %s  host: %.1f us to queue a pass; device: %.1f us per pass (queue + drain of %d passes)" % (slots, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6, n))
+print(("high-priority RCCL streams, " if hp else "") + ("device_id given, " if "devid" in sys.argv[2:] else "") + ("fused chain, " if chain else "") + "slots %s  host: %.1f us to queue a pass; device: %.1f us per pass (queue + drain of %d passes)" % (slots, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6, n))
 dist.destroy_process_group()

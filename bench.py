@@ -802,7 +802,10 @@ def main():
             port = sk.getsockname()[1]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(port))
-        dist.init_process_group("nccl", rank=0, world_size=1)          # (no device_id: as the ranks of a real world, above)
+        if os.environ.get("PCX_BENCH_REHEARSE_DEVICE_ID") == "1":      # (A/B of the finding above: the communicator bound to the device)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1)      # (no device_id: as the ranks of a real world, above)
         rehearsal = True
     W = build_workload(wl, C, dev, rank, 2 if rehearsal else world, args)
     if rehearsal:

@@ -69,6 +69,8 @@ def parse():
                     help="N = 1 only, fir255 / fmchain: time the pass a MIDDLE rank of an RCCL world runs -- side stream, one grouped RCCL send + receive "
                          "of the halo (to the rank itself: one GPU is enough), gate signal, ONE gated launch on the slots such a rank takes -- instead "
                          "of the plain single-GPU launch; the line says it is a rehearsal")
+    ap.add_argument("--pingpong", action="store_true",
+                    help="fir255 over ranks: two input buffers, the halo of batch k+1 exchanged while batch k is filtered (stream.PingPongFir)")
     ap.add_argument("--rehearse-slots", type=int, default=0,
                     help="with --rehearse-rccl-rank: resident workgroups of the gated launch (a multiple of 128; default: what a rank of an RCCL world takes)")
     ap.add_argument("--no-cold", action="store_true", help="skip roofline.cold (three bursts of 20 launches behind 5 ms of idle)")
@@ -451,19 +453,27 @@ def build_workload(wl, C, dev, rank, world, args):
     if wl in ("fir255", "direct255"):
         h = tp.c1_taps()
         algo = _lib.FIR_OLS_FFT if wl == "fir255" else _lib.FIR_DIRECT
-        sf = ShardedFir(h, C, dev, "COMPLEX", algo)
+        pingpong = bool(getattr(args, "pingpong", False)) and world > 1 and wl == "fir255"
+        if pingpong:
+            from pothoscomms_amd.stream import PingPongFir
+            pp = PingPongFir(h, C, dev, "COMPLEX", algo)
+            sf = pp.halves[0]
+            # the second buffer holds the NEXT batch of the node-wide stream
+            device.fill_uniform_f32_dev(pp.halves[1].buf, seed=2, offset=2 * (world + rank) * C)
+        else:
+            sf = ShardedFir(h, C, dev, "COMPLEX", algo)
         K = sf.K
         # the node-wide stream starts K-1 samples before shard 0 (rank 0's history); every rank
         # fills [its halo | its shard] from the same counter-hash stream, then the timed steps
         # overwrite the halo through RCCL
         device.fill_uniform_f32_dev(sf.buf, seed=2, offset=2 * rank * C)
-        W.owner = sf
-        W.inputs = (sf.buf,)
+        W.owner = pp if pingpong else sf
+        W.inputs = (sf.buf, pp.halves[1].buf) if pingpong else (sf.buf,)
         W.units = C
         W.roof_bytes = 16.0 * C
         W.read_bytes = 8.0 * C
         W.kernel_name = "fir_cf32_ols4096_kernel" if wl == "fir255" else "fir_cf32_direct_kernel"
-        W.step = sf.step
+        W.step = pp.step if pingpong else sf.step
         W.desc = {"workload": "255-tap complex_float32 FIR (/comms/fir_filter, COMPLEX taps, M=L=1), %d-sample shard per GPU, "
                               "%s" % (C, "frequency-domain overlap-save (4096-pt radix-16 passes)" if wl == "fir255" else "LDS-tiled direct form"),
                   "taps": 255, "shard_samples": C, "halo_samples": K - 1,
@@ -494,11 +504,17 @@ def build_workload(wl, C, dev, rank, world, args):
         K = len(tp.c4_taps())
         if world > 1:
             # the stream sharded over the ranks: K-sample halo from the left neighbour (stream.ShardedFmChain)
-            from pothoscomms_amd.stream import ShardedFmChain
-            sc = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
-            device.fill_uniform_f32_dev(sc.buf, seed=5, offset=2 * rank * n)
+            from pothoscomms_amd.stream import PingPongFmChain, ShardedFmChain
+            if getattr(args, "pingpong", False):
+                sc = PingPongFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
+                for b, half in enumerate(sc.halves):       # two consecutive batches of the node-wide stream
+                    device.fill_uniform_f32_dev(half.buf, seed=5, offset=2 * (b * world + rank) * n)
+                W.inputs = tuple(half.buf for half in sc.halves)
+            else:
+                sc = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
+                device.fill_uniform_f32_dev(sc.buf, seed=5, offset=2 * rank * n)
+                W.inputs = (sc.buf,)
             W.owner = sc
-            W.inputs = (sc.buf,)
             W.step = sc.step
         else:
             ch = device.FmChain()
@@ -819,15 +835,13 @@ def main():
                 return dist.batch_isend_irecv([dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], 0), dist.P2POp(dist.irecv, buf[:self.halo], 0)])
         W.owner.ring = SelfRing(W.owner.ring.halo)
         want_slots = args.rehearse_slots or ((_stream.RCCL_SLOTS or 0) if wl == "fir255" else 0)
+        if not want_slots and args.pingpong:
+            from pothoscomms_amd.stream import PINGPONG_SLOTS as want_slots
         if want_slots:                                     # (the world of one it was built in did not ask for them)
-            if wl == "fir255":
-                W.owner.fir.set_slots(want_slots)
-            else:
-                for ch in W.owner._chains:
-                    ch.set_slots(want_slots)
-            W.owner.slots = want_slots
+            W.owner.set_slots(want_slots)
         W.desc["parallelism"] = ("REHEARSAL on one GPU: the pass of a MIDDLE rank of an RCCL world -- grouped RCCL send + receive of the halo (to the rank "
-                                 "itself), gate signal, one gated launch on %s resident workgroups" % (W.owner.slots or 1024))
+                                 "itself), gate signal, one gated launch on %s resident workgroups%s" % (W.owner.slots or 1024,
+                                 "; two input buffers, the exchange of batch k+1 posted in front of the launch of batch k" if args.pingpong else ""))
     step, desc = W.step, W.desc
 
     def barrier():

@@ -57,6 +57,11 @@ def _check_gate(owner):
 # 224 at 640 against 193 for the single-GPU launch (bench.py --rehearse-rccl-rank --rehearse-slots N, profiles/r04/rccl_pass_slots.txt).
 # RCCL's protocol kernel costs 9-11 % of a pass whatever room it is given; the default stays 1024.)
 RCCL_SLOTS = None
+# The software-pipelined pass (PingPongFir) is another matter.  Its launch never waits for RCCL, but RCCL's workgroup (20 KB of LDS) has no
+# room beside four 36 KB workgroups on any CU of a full device: at 1024 slots it is placed when the launch beside it drains and the pass
+# takes 234-240 us; at 896 slots (32 CUs carry three workgroups) 199-200 us against 195-198 for the plain launch and 206-209 for the
+# unpipelined pass (tools/rccl_cost_probe.py, profiles/r04/rccl_cost_probe.txt).
+PINGPONG_SLOTS = 896
 
 
 def _rccl_world(ring):
@@ -181,6 +186,11 @@ class ShardedFir:
         if getattr(self, "_side", None) is not None and self._buf.is_cuda:
             torch.cuda.current_stream(self._buf.device).wait_stream(self._side)
 
+    def set_slots(self, slots):
+        """resident workgroups the shard's launches take (pcx_fir_set_slots)"""
+        self.fir.set_slots(slots)
+        self.slots = slots
+
     def check_gate(self):
         """Synchronise, then raise GateTimeout if a pass since the last check ran its first block without its halo (the gated launch's
         wait is bounded, pcx.h): call it wherever results leave the device.  bench.py and the tests do, after the timed region."""
@@ -224,45 +234,145 @@ class ShardedFir:
         self._run(0, self.head)
         return self.out
 
-    def _step_gated(self):
-        """ONE launch over the shard; the exchange beside it, a one-thread kernel behind it opens the gate.
-        RCCL: the exchange and the signal are queued on a side stream.  A host-driven backend (the gloo rehearsal on one GPU): the
-        exchange is started, the launch queued, and the host waits for the halo before it queues the signal."""
+    def post_exchange(self):
+        """RCCL: the exchange of THIS buffer's halo and the gate signal behind it, on the side stream, ordered behind everything the current
+        stream holds so far (the samples are in place; the previous pass on this buffer has read its halo).  compute() runs the pass."""
         from . import device as dv
         self._gate_setup()
         self._pass += 1
-        nccl = dist.get_backend(self.ring.group) == "nccl"
         cur = torch.cuda.current_stream(self._buf.device)
-        if nccl:
-            self._side.wait_stream(cur)                   # the shard's samples are in place; the previous pass has read its halo
-            with torch.cuda.stream(self._side):
-                # (posting the exchange from the CURRENT stream instead -- RCCL's stream then waits for it directly, one cross-stream hop
-                # in front of the exchange instead of two -- measured slower, 212 against 205 us per pass, tools/host_step_probe.py)
-                self.ring.finish(self.ring.start(self._buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
-                if self.ring.rank > 0:
-                    dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
-            _first_exchange(self)
-            reqs = []
-        else:
-            reqs = self.ring.start(self._buf)              # (drains the current stream first: HaloRing.start)
-        gated = True
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            # (posting the exchange from the CURRENT stream instead -- RCCL's stream then waits for it directly, one cross-stream hop
+            # in front of the exchange instead of two -- measured slower, 212 against 205 us per pass, tools/host_step_probe.py)
+            self.ring.finish(self.ring.start(self._buf))   # RCCL orders the exchange behind the side stream and the side stream behind it
+            if self.ring.rank > 0:
+                dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
+        _first_exchange(self)
+
+    def compute(self):
+        """The pass whose exchange post_exchange() queued: ONE launch over the shard, its first block behind the gate."""
+        cur = torch.cuda.current_stream(self._buf.device)
         if self.ring.rank == 0:
             self._run(0, self.C)
-        else:
-            c, p, gated = self.fir.process_dev_gated(self._buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C)
-            if gated:
-                assert c == self.C and p == self.C, (c, p)
-            elif self.C > self.head:
-                self._run(self.head, self.C - self.head)  # no gated kernel for this configuration: the body now, the head below
-        if not nccl:
-            self.ring.finish(reqs)                        # the host waits for the halo ...
-            if self.ring.rank > 0:
-                dv.gate_signal_host(self._gate, self._pass)                         # ... and opens the gate (a store to the host word)
-        if not gated:
+            return self.out
+        c, p, gated = self.fir.process_dev_gated(self._buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C)
+        if gated:
+            assert c == self.C and p == self.C, (c, p)
+        else:                                             # no gated kernel for this configuration: the body, the halo, the head
+            if self.C > self.head:
+                self._run(self.head, self.C - self.head)
             cur.wait_stream(self._side)
+            self._run(0, self.head)
+        return self.out
+
+    def _step_gated(self):
+        """ONE launch over the shard; the exchange beside it, a one-thread kernel behind it opens the gate.
+        RCCL: the exchange and the signal are queued on a side stream (post_exchange), then the launch (compute).  A host-driven backend
+        (the gloo rehearsal on one GPU): the exchange is started, the launch queued, and the host waits for the halo before it opens the
+        gate with a store to a page-locked word."""
+        from . import device as dv
+        if dist.get_backend(self.ring.group) == "nccl":
+            self.post_exchange()
+            return self.compute()
+        self._gate_setup()
+        self._pass += 1
+        reqs = self.ring.start(self._buf)                  # (drains the current stream first: HaloRing.start)
+        gated = True
+        c, p, gated = self.fir.process_dev_gated(self._buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C) if self.ring.rank > 0 else (self.C, self.C, True)
+        if self.ring.rank == 0:
+            self._run(0, self.C)
+        elif gated:
+            assert c == self.C and p == self.C, (c, p)
+        elif self.C > self.head:
+            self._run(self.head, self.C - self.head)      # no gated kernel for this configuration: the body now, the head below
+        self.ring.finish(reqs)                            # the host waits for the halo ...
+        if self.ring.rank > 0:
+            dv.gate_signal_host(self._gate, self._pass)   # ... and opens the gate (a store to the host word)
+        if not gated:
+            torch.cuda.current_stream(self._buf.device).wait_stream(self._side)
             self._run(0, self.head)
         # (a later WRITER of the shard has to wait for the send that is still reading its tail: fence_input)
         return self.out
+
+
+class PingPongFir:
+    """Two input buffers, software-pipelined: while batch k is filtered, the halo of batch k+1 -- already in place in the OTHER buffer -- is
+    exchanged, so that RCCL's protocol kernel (resident ~150 us for 2 KB on a saturated device: it made a pass 9-11 % longer when the
+    pass had to wait for it, profiles/r04/rccl_pass_slots.txt) has a whole pass to finish in and the gate of batch k+1 is open long
+    before its first block -- the last one computed -- asks.  The streaming order of a rank:
+        fill(buffer of batch k+1)      behind the pass that last read it (batch k-1): `next_shard` fences that
+        step()                         posts batch k+1's exchange, then runs batch k's pass (whose exchange the previous step posted)
+    One exchange and one pass per step, as before; only their pairing moved.  Without an RCCL world (one rank, gloo) step() is the plain
+    ShardedFir.step() of the current buffer."""
+
+    def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None, slots=None, two_launch=None):
+        self.halves = [ShardedFir(taps, shard_len, device, taps_type, algo, group, slots, two_launch) for _ in range(2)]
+        self._default_slots(slots)
+
+    ring = property(lambda self: self.halves[0].ring)
+
+    @ring.setter
+    def ring(self, r):
+        for h in self.halves:
+            h.ring = r
+
+    slots = property(lambda self: self.halves[0].slots)
+
+    def set_slots(self, slots):
+        for h in self.halves:
+            h.set_slots(slots)
+
+    def _default_slots(self, slots):
+        self.K, self.C = self.halves[0].K, self.halves[0].C
+        self.k = 0
+        self._primed = False
+        if slots is None and _rccl_world(self.halves[0].ring):
+            self.set_slots(PINGPONG_SLOTS)
+
+    two_launch = property(lambda self: self.halves[0].two_launch)
+
+    @two_launch.setter
+    def two_launch(self, v):
+        for h in self.halves:
+            h.two_launch = bool(v)
+
+    @property
+    def current(self):
+        """the ShardedFir whose batch the next step() filters"""
+        return self.halves[self.k & 1]
+
+    @property
+    def upcoming(self):
+        """the ShardedFir the batch AFTER that goes into (fill its `shard` / `buf` before the next step())"""
+        return self.halves[(self.k + 1) & 1]
+
+    def check_gate(self):
+        for h in self.halves:
+            h.check_gate()
+
+    def _pipelined(self):
+        h = self.halves[0]
+        return _rccl_world(h.ring) and not h.two_launch and h._buf.is_cuda
+
+    def step(self):
+        cur, nxt = self.current, self.upcoming
+        self.k += 1
+        if not self._pipelined():
+            self._primed = False
+            return cur.step()
+        if not self._primed:                               # the very first batch: its exchange has not been posted by a previous step
+            # ONE side stream for both buffers: the exchanges are serial anyway, and every further stream is a further chance that HIP maps
+            # two of them onto one hardware queue (4 per process), where a wait for RCCL then holds up whatever else that queue carries --
+            # with a side stream per buffer the pass came out at 195-202 us in some processes and 213-216 in others
+            # (profiles/r04/rccl_cost_probe.txt)
+            for h in self.halves:
+                h._gate_setup()
+            nxt._side = cur._side
+            cur.post_exchange()
+            self._primed = True
+        nxt.post_exchange()                                # batch k+1: behind the pass that last read that buffer (already on the current stream)
+        return cur.compute()
 
 
 class ShardedFmChain:
@@ -317,6 +427,11 @@ class ShardedFmChain:
         if getattr(self, "_side", None) is not None and self._buf.is_cuda:
             torch.cuda.current_stream(self._buf.device).wait_stream(self._side)
 
+    def set_slots(self, slots):
+        for ch in self._chains:
+            ch.set_slots(slots)
+        self.slots = slots
+
     def check_gate(self):
         """ShardedFir.check_gate"""
         _check_gate(self)
@@ -347,13 +462,16 @@ class ShardedFmChain:
             self._run(self._chains[0], 0, self.head + 1, 0)         # extra output -1 from the halo, dropped
         return self.out
 
-    def _step_gated(self):
-        """RCCL: the exchange and the gate signal on a side stream, ONE launch over the shard on the current stream (ShardedFir)."""
-        from . import device as dv
+    def _gate_setup(self):
         if getattr(self, "_gate", None) is None:
             self._gate = torch.zeros((64,), dtype=torch.int32, device=self._buf.device)
             self._side = torch.cuda.Stream(device=self._buf.device)
             self._pass = 0
+
+    def post_exchange(self):
+        """RCCL: the exchange of THIS buffer's halo and the gate signal on the side stream (ShardedFir.post_exchange)."""
+        from . import device as dv
+        self._gate_setup()
         self._pass += 1
         cur = torch.cuda.current_stream(self._buf.device)
         self._side.wait_stream(cur)
@@ -362,6 +480,10 @@ class ShardedFmChain:
             if self.ring.rank > 0:
                 dv.gate_signal(self._gate, self._pass, self._side.cuda_stream)
         _first_exchange(self)
+
+    def compute(self):
+        """The pass whose exchange post_exchange() queued: ONE launch over the shard on the current stream."""
+        cur = torch.cuda.current_stream(self._buf.device)
         ch = self._chains[0]
         if self.ring.rank == 0:
             self._run(ch, 1, self.C, 1)                             # stream start: reset state, no extra output
@@ -374,3 +496,16 @@ class ShardedFmChain:
             else:
                 assert c == self.C + 1 and p == self.C + 1, (c, p)
         return self.out
+
+    def _step_gated(self):
+        """RCCL: the exchange and the gate signal on a side stream, ONE launch over the shard on the current stream (ShardedFir)."""
+        self.post_exchange()
+        return self.compute()
+
+
+class PingPongFmChain(PingPongFir):
+    """PingPongFir for the fused chain: two ShardedFmChain buffers."""
+
+    def __init__(self, taps, phase, shard_len, device, complex_taps=False, algo=None, group=None, two_launch=None, slots=None):
+        self.halves = [ShardedFmChain(taps, phase, shard_len, device, complex_taps, algo, group, two_launch, slots) for _ in range(2)]
+        self._default_slots(slots)

@@ -399,3 +399,67 @@ def test_the_rccl_pass_of_a_middle_rank_on_one_gpu(oracle, chain, two_launch):
             ref = oracle.FreqDemod(oracle.F32).work(y)[1:n + 1]
             assert not np.isnan(got).any()
             assert ang_err(got[:n], ref) <= TOL
+
+
+def _rccl_pingpong_worker(port, C, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from pothoscomms_amd import device, taps as tp
+    from pothoscomms_amd.stream import HaloRing, PingPongFir
+
+    class SelfRing(HaloRing):
+        def __init__(self, halo):
+            self.halo = halo; self.group = None; self.rank = 1; self.world = 3
+
+        def start(self, buf):
+            return dist.batch_isend_irecv([dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], 0),
+                                           dist.P2POp(dist.irecv, buf[:self.halo], 0)])
+
+    dev = torch.device("cuda", 0)
+    pp = PingPongFir(tp.c1_taps(), C, dev)
+    pp.ring = SelfRing(pp.K - 1)
+    K = pp.K
+    f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.c1_taps())
+    want = torch.empty((C, 2), dtype=torch.float32, device=dev)
+
+    def load(half, seed):
+        device.fill_uniform_f32_dev(half.buf, seed=seed, offset=0)
+        half.buf[:K - 1] = float("nan")                    # only the exchange can make the front of the shard right
+
+    load(pp.current, 20)
+    res = []
+    for k in range(6):
+        load(pp.upcoming, 21 + k)                          # batch k+1 into the other buffer, then the step: its exchange rides beside batch k's pass
+        cur = pp.current
+        out = pp.step()
+        torch.cuda.synchronize()
+        tail = cur.buf[cur.buf.shape[0] - (K - 1):]
+        halo_ok = bool(torch.equal(cur.buf[:K - 1], tail))
+        assert f.process_dev(cur.buf, want) == (C, C)
+        torch.cuda.synchronize()
+        res.append((halo_ok, bool(torch.equal(out, want)), int(cur._gate[1].item()), 20 + k, float(out.abs().sum().item())))
+    pp.check_gate()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_two_input_buffers_the_next_batchs_halo_exchanged_beside_this_batchs_pass(oracle):
+    """stream.PingPongFir over RCCL on one GPU (the ring sends the halo to the rank itself): six batches through two buffers, every halo
+    poisoned before its exchange; each pass bit-identical to a plain call on the completed buffer, each batch different, no gate time-out."""
+    C = 2100 * 3840
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_pingpong_worker, args=(_free_port(), C, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert len(res) == 6
+    for halo_ok, same, timed_out, _, _ in res:
+        assert halo_ok and same and timed_out == 0
+    assert len({r[4] for r in res}) == 6                   # six different batches went through

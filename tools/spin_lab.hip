@@ -1,0 +1,89 @@
+// Why does a pass get ~9 % longer when RCCL's send/recv kernel (one workgroup, resident ~150 us) runs beside it?  The headline FIR launch,
+// queued back to back on one stream, with a ONE-workgroup companion kernel per pass on a second stream that stays resident for a set time
+// and does, in turn: nothing but count (alu); relaxed polling of a host word (poll); polling with a SYSTEM-scope acquire -- the buffer
+// invalidate behind it drops the non-local lines of the L2s -- (acq); polling + a system-scope release fence per turn -- L2 write-back -- (rel);
+// both (acqrel).  Each on data.  Usage: spin_lab [us resident, default 150]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "pcx.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#define PK(x) do { int r_ = (x); if (r_ != 0) { printf("%s: %d %s\n", #x, r_, pcx_last_error()); return 1; } } while (0)
+
+enum { ALU = 0, POLL = 1, ACQ = 2, REL = 3, ACQREL = 4, NONE = 5 };
+
+template <int MODE> __global__ __launch_bounds__(256) void companion(volatile unsigned *host_word, unsigned *dev_word, long long ticks)
+{
+    __shared__ unsigned pad[5120];                        // 20 KB, as RCCL's kernel holds
+    pad[threadIdx.x] = threadIdx.x;
+    const long long t0 = __builtin_readcyclecounter();    // s_memtime: the shader clock on gfx950 (tools/clk_lab.hip)
+    unsigned acc = 0;
+    while ((long long)__builtin_readcyclecounter() - t0 < ticks) {
+        if (MODE == ALU) { acc = acc * 1664525u + 1013904223u; }
+        if (MODE == POLL) { acc += *host_word; }
+        if (MODE == ACQ || MODE == ACQREL) { acc += __hip_atomic_load((unsigned *)host_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        if (MODE == REL || MODE == ACQREL) {
+            if (MODE == REL) acc += *host_word;
+            __hip_atomic_store(dev_word + 64 + (threadIdx.x & 63), acc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (acc == 0x12345678u) dev_word[threadIdx.x] = acc + pad[(threadIdx.x + 1) & 255];
+}
+
+int main(int argc, char **argv)
+{
+    const double us = argc > 1 ? atof(argv[1]) : 150.0;
+    const size_t C = 64u << 20, K = 255;
+    float *x, *y; unsigned *dw, *hw; hipStream_t s, side;
+    CK(hipMalloc(&x, 8 * (C + K - 1) + 256)); CK(hipMalloc(&y, 8 * C)); CK(hipMalloc(&dw, 4096)); CK(hipHostMalloc(&hw, 4096, hipHostMallocMapped));
+    memset(hw, 0, 4096);
+    CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    float *xin = x + 2;                                    // the samples (not the history) on a 128-byte line, as stream.ShardedFir places them
+    PK(pcx_fill_uniform_f32_dev(xin, 2 * (C + K - 1), 2, 0, s));
+    std::vector<double> taps(2 * K);
+    for (size_t i = 0; i < K; i++) { taps[2 * i] = 0.01 * (double)((i * 37) % 17) - 0.08; taps[2 * i + 1] = 0.005 * (double)((i * 11) % 13); }
+    pcx_fir *h; PK(pcx_fir_create(PCX_F32, 1, 1, &h)); PK(pcx_fir_set_taps(h, taps.data(), K)); PK(pcx_fir_set_algo(h, PCX_FIR_OLS_FFT));
+    size_t c, p;
+    hipEvent_t e0, e1, ek; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreateWithFlags(&ek, hipEventDisableTiming));
+    const long long ticks = (long long)(us * 100.0);      // s_memtime in the companion counts the 100 MHz reference?  measured below and rescaled
+    const char *names[] = {"alu", "poll", "acq", "rel", "acqrel", "none"};
+    const int order[] = {NONE, ALU, POLL, ACQ, REL, ACQREL, NONE};
+    // how long is the companion resident?  (alone on the device)
+    double tick_scale = 1.0;
+    {
+        CK(hipEventRecord(e0, side)); companion<ALU><<<1, 256, 0, side>>>(hw, dw, ticks); CK(hipEventRecord(e1, side)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        tick_scale = us / (ms * 1000.0);
+        printf("companion with %lld ticks alone: %.1f us -> ticks scaled by %.2f\n", ticks, ms * 1000.0, tick_scale);
+    }
+    const long long tk = (long long)((double)ticks * tick_scale);
+    for (int rep = 0; rep < 2; rep++)
+        for (int oi = 0; oi < 7; oi++) {
+            const int mode = order[oi];
+            for (int phase = 0; phase < 2; phase++) {      // 0: settle, 1: timed
+                const int n = phase ? 1500 : 600;
+                if (phase) CK(hipEventRecord(e0, s));
+                for (int i = 0; i < n; i++) {
+                    if (mode != NONE) {
+                        CK(hipEventRecord(ek, s)); CK(hipStreamWaitEvent(side, ek, 0));    // behind the previous pass, as the exchange is
+                        switch (mode) {
+                        case ALU: companion<ALU><<<1, 256, 0, side>>>(hw, dw, tk); break;
+                        case POLL: companion<POLL><<<1, 256, 0, side>>>(hw, dw, tk); break;
+                        case ACQ: companion<ACQ><<<1, 256, 0, side>>>(hw, dw, tk); break;
+                        case REL: companion<REL><<<1, 256, 0, side>>>(hw, dw, tk); break;
+                        default: companion<ACQREL><<<1, 256, 0, side>>>(hw, dw, tk); break;
+                        }
+                    }
+                    PK(pcx_fir_process_dev(h, xin, C + K - 1, y, C, &c, &p, s));
+                }
+                if (phase) {
+                    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(side));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    printf("%-7s %.4f ms per pass\n", names[mode], ms / n);
+                }
+            }
+        }
+    return 0;
+}

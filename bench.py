@@ -69,8 +69,9 @@ def parse():
                     help="N = 1 only, fir255 / fmchain: time the pass a MIDDLE rank of an RCCL world runs -- side stream, one grouped RCCL send + receive "
                          "of the halo (to the rank itself: one GPU is enough), gate signal, ONE gated launch on the slots such a rank takes -- instead "
                          "of the plain single-GPU launch; the line says it is a rehearsal")
-    ap.add_argument("--pingpong", action="store_true",
-                    help="fir255 over ranks: two input buffers, the halo of batch k+1 exchanged while batch k is filtered (stream.PingPongFir)")
+    ap.add_argument("--no-pingpong", dest="pingpong", action="store_false",
+                    help="fir255 / fmchain over ranks: ONE input buffer, every pass waits for its own exchange at its tail.  Default: two input "
+                         "buffers, the halo of batch k+1 exchanged while batch k is filtered (stream.PingPongFir)")
     ap.add_argument("--rehearse-slots", type=int, default=0,
                     help="with --rehearse-rccl-rank: resident workgroups of the gated launch (a multiple of 128; default: what a rank of an RCCL world takes)")
     ap.add_argument("--no-cold", action="store_true", help="skip roofline.cold (three bursts of 20 launches behind 5 ms of idle)")
@@ -443,6 +444,10 @@ class Workload:
     inputs = ()                # the device tensors the step reads (tools/floor_table.py zeroes them for the "kernel on zeros" row)
 
 
+PIPELINED = ("; software-pipelined over two input buffers: the halo of batch k+1 is exchanged while batch k is filtered -- one exchange and one "
+             "pass per step, as without (stream.PingPongFir)")
+
+
 def build_workload(wl, C, dev, rank, world, args):
     import torch
 
@@ -453,7 +458,7 @@ def build_workload(wl, C, dev, rank, world, args):
     if wl in ("fir255", "direct255"):
         h = tp.c1_taps()
         algo = _lib.FIR_OLS_FFT if wl == "fir255" else _lib.FIR_DIRECT
-        pingpong = bool(getattr(args, "pingpong", False)) and world > 1 and wl == "fir255"
+        pingpong = bool(getattr(args, "pingpong", True)) and world > 1 and wl == "fir255"
         if pingpong:
             from pothoscomms_amd.stream import PingPongFir
             pp = PingPongFir(h, C, dev, "COMPLEX", algo)
@@ -477,7 +482,7 @@ def build_workload(wl, C, dev, rank, world, args):
         W.desc = {"workload": "255-tap complex_float32 FIR (/comms/fir_filter, COMPLEX taps, M=L=1), %d-sample shard per GPU, "
                               "%s" % (C, "frequency-domain overlap-save (4096-pt radix-16 passes)" if wl == "fir255" else "LDS-tiled direct form"),
                   "taps": 255, "shard_samples": C, "halo_samples": K - 1,
-                  "parallelism": "overlap-save shards x%d, RCCL send/recv halo" % world if world > 1 else "single GPU"}
+                  "parallelism": "overlap-save shards x%d, RCCL send/recv halo" % world + (PIPELINED if pingpong else "") if world > 1 else "single GPU"}
         W.metric = "Msamples/s complex_float32 255-tap FIR"
         if wl == "direct255":
             # the time-domain form is NOT HBM-bound -- 8 K flop per sample against 16 B (127 flop/B, machine balance 19.7)
@@ -505,7 +510,7 @@ def build_workload(wl, C, dev, rank, world, args):
         if world > 1:
             # the stream sharded over the ranks: K-sample halo from the left neighbour (stream.ShardedFmChain)
             from pothoscomms_amd.stream import PingPongFmChain, ShardedFmChain
-            if getattr(args, "pingpong", False):
+            if getattr(args, "pingpong", True):
                 sc = PingPongFmChain(tp.c4_taps(), tp.C4_PHASE, n, dev)
                 for b, half in enumerate(sc.halves):       # two consecutive batches of the node-wide stream
                     device.fill_uniform_f32_dev(half.buf, seed=5, offset=2 * (b * world + rank) * n)
@@ -534,7 +539,7 @@ def build_workload(wl, C, dev, rank, world, args):
         W.kernel_name = "fmchain_cf32_ols4096_kernel"
         W.desc = {"workload": "fused Rotate->FIR(127 real taps)->FreqDemod in one frequency-domain kernel, complex_float32 -> float32, %d samples" % n}
         if world > 1:
-            W.desc["parallelism"] = "overlap-save shards x%d, RCCL send/recv halo of 127 samples" % world
+            W.desc["parallelism"] = "overlap-save shards x%d, RCCL send/recv halo of 127 samples" % world + (PIPELINED if getattr(args, "pingpong", True) else "")
         W.metric = "Msamples/s fused FM-demod chain"
         # 998 VALU instructions per wave and block (661 of them the two transforms) fill ~0.7 of all SIMD issue time at the ~1.95 GHz the
         # power cap leaves on real data; on all-zero input (2.37 GHz) the same kernel reads 0.62 (profiles/r04/floor_table.txt)
@@ -843,6 +848,12 @@ def main():
                                  "itself), gate signal, one gated launch on %s resident workgroups%s" % (W.owner.slots or 1024,
                                  "; two input buffers, the exchange of batch k+1 posted in front of the launch of batch k" if args.pingpong else ""))
     step, desc = W.step, W.desc
+    if W.owner is not None and (rehearsal or (world > 1 and backend == "nccl")) and os.environ.get("PCX_BENCH_NO_STREAM_PICK") != "1":
+        # the passes are launched on a stream whose hardware queue the exchange does not share (stream.py, HARDWARE QUEUES): collective,
+        # every rank runs the same number of probe exchanges
+        from pothoscomms_amd.stream import pick_launch_stream
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(pick_launch_stream(W.owner))
 
     def barrier():
         if world > 1:
@@ -948,6 +959,10 @@ def main():
                 desc["halo_scheme"] = "two launches per pass (body, halo, head): a host-driven backend opens no gate"
             else:
                 desc["halo_scheme"] = "one gated launch per pass"
+        if W.owner is not None and (backend == "nccl" or rehearsal):
+            from pothoscomms_amd.stream import exchange_shares_queue
+            # (True would mean every exchange ran BEHIND the pass it should run beside: stream.py, HARDWARE QUEUES)
+            desc["rccl_stream_shares_the_launch_queue"] = exchange_shares_queue(dev_index)
         out = {
             "metric": W.metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -68,13 +68,98 @@ def _rccl_world(ring):
     return ring.world > 1 and dist.is_initialized() and dist.get_backend(ring.group) == "nccl"
 
 
+# HARDWARE QUEUES.  HIP maps a process's streams onto four hardware queues, by creation order, and two streams on one queue run in order
+# whatever the program says.  When RCCL's own stream (drawn from torch's pool when the communicator is created) or the side stream lands on
+# the queue of the stream the passes are launched on -- it did in one process out of a few, depending on how many streams the handles of
+# the process had created before -- the exchange runs BEHIND the pass it was meant to run beside: a pass of 239 us instead of 196
+# (profiles/r04/pingpong_queues.txt).  Stream priorities do not help: a high-priority side stream or RCCL stream beside a normal-priority
+# launch stream made the pass 250-530 us in one process and left it alone in another (profiles/r04/prio_matrix.txt).  So the drivers LOOK:
+# _exchange_shares_queue() below, once behind the first exchange (a warning), and pick_launch_stream() for a caller who can choose the
+# stream the passes run on (bench.py does).
+_QUEUES_CHECKED = {}
+
+
+def _exchange_shares_queue(owner, tries=2):
+    """Does the exchange (side stream, RCCL's stream) share the hardware queue of the CURRENT stream?  A one-thread sleeper (~2 ms) on the
+    current stream, an exchange beside it: if the exchange is done while the sleeper still runs, it does not.  COLLECTIVE: every rank
+    runs exactly `tries` exchanges (a late neighbour looks like a shared queue, so one free try decides; the exchange rewrites the halo
+    with the bytes it already holds)."""
+    dev = owner._buf.device
+    shared = True
+    for _ in range(tries):
+        end = torch.cuda.Event()
+        torch.cuda._sleep(4_000_000)
+        end.record()
+        with torch.cuda.stream(owner._side):
+            owner.ring.finish(owner.ring.start(owner._buf))
+            ev = torch.cuda.Event()
+            ev.record()
+        ev.synchronize()
+        shared = shared and end.query()
+        torch.cuda.current_stream(dev).synchronize()
+    return shared
+
+
+def _halves(owner):
+    return getattr(owner, "halves", [owner])
+
+
+def pick_launch_stream(owner, candidates=4):
+    """COLLECTIVE (every rank of the ring calls it, with the same arguments, before its first step): the stream to launch this driver's
+    passes on -- the current one if the exchange can run beside it, else the first of `candidates` fresh streams it can run beside.
+    Make the result current (torch.cuda.set_stream / `with torch.cuda.stream(...)`) for every step().  Every rank runs the same number
+    of exchanges whatever it finds."""
+    hs = _halves(owner)
+    if not (_rccl_world(hs[0].ring) and hs[0]._buf.is_cuda and hasattr(torch.cuda, "_sleep")):
+        return torch.cuda.current_stream()
+    dev = hs[0]._buf.device
+    for h in hs:
+        h._gate_setup()
+        h._side = hs[0]._side
+    h = hs[0]
+    with torch.cuda.stream(h._side):                       # the communicator and its connections come up in the first exchange
+        h.ring.finish(h.ring.start(h._buf))
+    h._side.synchronize()
+    for x in hs:
+        x._exchanged_once = True
+    torch.cuda.current_stream(dev).synchronize()
+    first = torch.cuda.current_stream(dev)
+    chosen = None
+    for cand in [first] + [torch.cuda.Stream(device=dev) for _ in range(candidates)]:
+        with torch.cuda.stream(cand):
+            shared = _exchange_shares_queue(h)
+        if chosen is None and not shared:
+            chosen = cand
+    _QUEUES_CHECKED[dev.index] = chosen is None
+    if chosen is None:
+        import warnings
+        warnings.warn("pothoscomms_amd.stream: no stream found whose hardware queue the exchange does not share; every exchange will run behind the pass it should run beside")
+        chosen = first
+    return chosen
+
+
 def _first_exchange(owner):
     """The FIRST exchange of a driver is waited for on the host before the gated launch that depends on it is queued: RCCL sets its
     point-to-point connections up lazily, inside the first send / receive, and that can take longer than the two seconds a gated launch
-    waits for its halo -- the first pass of a run must not be the one that times out.  Every rank passes here in its first step."""
+    waits for its halo -- the first pass of a run must not be the one that times out.  Every rank passes here in its first step.
+    Once per process and device it is also checked that the exchange can run BESIDE a launch on the current stream (HARDWARE QUEUES above)."""
     if not getattr(owner, "_exchanged_once", False):
         owner._side.synchronize()
         owner._exchanged_once = True
+        key = owner._buf.device.index
+        if key not in _QUEUES_CHECKED and hasattr(torch.cuda, "_sleep") and _rccl_world(owner.ring):
+            torch.cuda.current_stream(owner._buf.device).synchronize()
+            _QUEUES_CHECKED[key] = _exchange_shares_queue(owner)
+            if _QUEUES_CHECKED[key]:
+                import warnings
+                warnings.warn("pothoscomms_amd.stream: the halo exchange (side stream, RCCL's stream) shares the hardware queue of the stream the passes "
+                              "are launched on -- every exchange will run behind the pass it should run beside.  Launch the passes on the stream "
+                              "pothoscomms_amd.stream.pick_launch_stream(driver) returns.")
+
+
+def exchange_shares_queue(device_index=0):
+    """What the first step (or pick_launch_stream) found (None before): True if the exchange shares the launch stream's hardware queue."""
+    return _QUEUES_CHECKED.get(device_index)
 
 
 def _two_launch_forced(arg):

@@ -194,3 +194,60 @@ def test_two_launch_switch():
         os.environ.pop("PCX_STREAM_TWO_LAUNCH", None)
         if old is not None:
             os.environ["PCX_STREAM_TWO_LAUNCH"] = old
+
+
+def test_ping_pong_posts_the_next_batchs_exchange_in_front_of_this_batchs_pass(monkeypatch):
+    """stream.PingPongFir.step: which half's exchange and which half's pass a step queues, with stand-ins for the two buffers (no GPU):
+    batch k's pass always follows batch k's exchange by one step, every step posts exactly one exchange except the first (two), the two
+    halves share ONE side stream, and with two_launch set (bench.py's fall-back) the step is the plain step of the current half."""
+    import types
+
+    from pothoscomms_amd import stream
+    log = []
+
+    class Half:
+        def __init__(self, name):
+            self.name, self.two_launch, self.slots = name, False, None
+            self.ring = types.SimpleNamespace(world=3, rank=1, group=None)
+            self._buf = types.SimpleNamespace(is_cuda=True)
+            self._side = None
+
+        def _gate_setup(self):
+            if self._side is None:
+                self._side = object()
+
+        def post_exchange(self):
+            log.append(("x", self.name))
+
+        def compute(self):
+            log.append(("c", self.name))
+            return self.name
+
+        def step(self):
+            log.append(("s", self.name))
+            return self.name
+
+        def check_gate(self):
+            log.append(("g", self.name))
+
+    monkeypatch.setattr(stream, "_rccl_world", lambda ring: True)
+    pp = object.__new__(stream.PingPongFir)
+    pp.halves, pp.k, pp._primed = [Half("A"), Half("B")], 0, False
+    assert pp.current.name == "A" and pp.upcoming.name == "B"
+    assert [pp.step() for _ in range(4)] == ["A", "B", "A", "B"]
+    assert log == [("x", "A"), ("x", "B"), ("c", "A"), ("x", "A"), ("c", "B"), ("x", "B"), ("c", "A"), ("x", "A"), ("c", "B")]
+    assert pp.halves[0]._side is pp.halves[1]._side and pp.halves[0]._side is not None
+    # every pass ran behind its own half's latest exchange
+    for i, (what, name) in enumerate(log):
+        if what == "c":
+            assert ("x", name) in log[:i] and ("c", name) not in log[max(j for j in range(i) if log[j] == ("x", name)):i]
+    del log[:]
+    pp.two_launch = True
+    assert all(h.two_launch for h in pp.halves)
+    assert [pp.step() for _ in range(2)] == ["A", "B"] and log == [("s", "A"), ("s", "B")]
+    pp.two_launch = False                                  # back: the pipeline is primed again from the current half
+    del log[:]
+    pp.step()
+    assert log == [("x", "A"), ("x", "B"), ("c", "A")]
+    pp.check_gate()
+    assert log[-2:] == [("g", "A"), ("g", "B")]

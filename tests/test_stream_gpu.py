@@ -402,6 +402,15 @@ def test_the_rccl_pass_of_a_middle_rank_on_one_gpu(oracle, chain, two_launch):
 
 
 def _rccl_pingpong_worker(port, C, q):
+    try:
+        _rccl_pingpong_body(port, C, q)
+    except BaseException:                                  # (the parent must not wait ten minutes for a worker that died on an assert)
+        import traceback
+        q.put(("error", traceback.format_exc()))
+        raise
+
+
+def _rccl_pingpong_body(port, C, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -424,6 +433,13 @@ def _rccl_pingpong_worker(port, C, q):
     pp = PingPongFir(tp.c1_taps(), C, dev)
     pp.ring = SelfRing(pp.K - 1)
     K = pp.K
+    # the passes on a stream whose hardware queue the exchange does not share (stream.py, HARDWARE QUEUES)
+    from pothoscomms_amd.stream import exchange_shares_queue, pick_launch_stream
+    torch.cuda.set_stream(pick_launch_stream(pp))
+    assert exchange_shares_queue(0) is False
+    from pothoscomms_amd.stream import PINGPONG_SLOTS
+    pp.set_slots(PINGPONG_SLOTS)                           # room for RCCL's workgroup beside the persistent launch (what a rank of a real world gets)
+    assert pp.slots == 896 and all(h.slots == 896 for h in pp.halves)
     f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.c1_taps())
     want = torch.empty((C, 2), dtype=torch.float32, device=dev)
 
@@ -458,6 +474,7 @@ def test_two_input_buffers_the_next_batchs_halo_exchanged_beside_this_batchs_pas
     p.start()
     res = q.get(timeout=600)
     p.join(120)
+    assert not (len(res) == 2 and res[0] == "error"), res[1]
     assert p.exitcode == 0
     assert len(res) == 6
     for halo_ok, same, timed_out, _, _ in res:

@@ -16,7 +16,16 @@ from pothoscomms_amd.stream import ShardedFir, ShardedFmChain, PingPongFir, Ping
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-dist.init_process_group("nccl", rank=0, world_size=1)
+from pothoscomms_amd import stream as _st
+HP_RCCL, HP_SIDE = os.environ.get("PROBE_HP_RCCL") == "1", os.environ.get("PROBE_HP_SIDE") == "1"      # A/B: stream priorities (profiles/r04/prio_matrix.txt)
+dist.init_process_group("nccl", rank=0, world_size=1, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True) if HP_RCCL else None)
+
+
+def hp_side(owner):
+    if HP_SIDE:
+        for h in getattr(owner, "halves", [owner]):
+            h._gate_setup()
+            h._side = torch.cuda.Stream(device=dev, priority=-1)
 
 
 class SelfRing(HaloRing):
@@ -49,13 +58,14 @@ def timed(step, n_settle=600, n=1500):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for rep in range(2):
+for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
     for slots in slot_list:
         sf = ShardedFmChain(tp.c4_taps(), tp.C4_PHASE, C, dev, slots=slots) if chain else ShardedFir(tp.c1_taps(), C, dev, slots=slots)
         device.fill_uniform_f32_dev(sf.buf, seed=2, offset=0)
         K = sf.K + 1 if chain else sf.K                    # (the chain's halo is K samples)
         row = {}
         sf.ring = SelfRing(K - 1)
+        hp_side(sf)
         plain = (lambda: sf._run(sf._chains[0], 1, C, 1)) if chain else (lambda: sf._run(0, C))
         sf._run0 = plain
         row["plain"] = timed(plain)
@@ -78,8 +88,10 @@ for rep in range(2):
             device.fill_uniform_f32_dev(h.buf, seed=2, offset=0)
         pp.set_slots(slots or 1024)
         pp.ring = SelfRing(K - 1)
+        hp_side(pp)
         row["pingpong"] = timed(pp.step)
         pp.check_gate()
         del pp
         print("slots %-5s " % (slots or 1024) + "  ".join("%s %.1f us" % kv for kv in row.items()), flush=True)
+print("RCCL stream %s, side stream %s priority; exchange shares the launch queue: %s" % ("high" if HP_RCCL else "normal", "high" if HP_SIDE else "normal", _st._QUEUES_CHECKED))
 dist.destroy_process_group()

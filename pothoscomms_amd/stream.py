@@ -319,14 +319,18 @@ class ShardedFir:
         self._run(0, self.head)
         return self.out
 
-    def post_exchange(self):
+    def post_exchange(self, after=None):
         """RCCL: the exchange of THIS buffer's halo and the gate signal behind it, on the side stream, ordered behind everything the current
-        stream holds so far (the samples are in place; the previous pass on this buffer has read its halo).  compute() runs the pass."""
+        stream holds so far (the samples are in place; the previous pass on this buffer has read its halo) -- or behind the event
+        `after`, recorded where that was true.  compute() runs the pass."""
         from . import device as dv
         self._gate_setup()
         self._pass += 1
         cur = torch.cuda.current_stream(self._buf.device)
-        self._side.wait_stream(cur)
+        if after is None:
+            self._side.wait_stream(cur)
+        else:
+            self._side.wait_event(after)
         with torch.cuda.stream(self._side):
             # (posting the exchange from the CURRENT stream instead -- RCCL's stream then waits for it directly, one cross-stream hop
             # in front of the exchange instead of two -- measured slower, 212 against 205 us per pass, tools/host_step_probe.py)
@@ -387,7 +391,7 @@ class PingPongFir:
     pass had to wait for it, profiles/r04/rccl_pass_slots.txt) has a whole pass to finish in and the gate of batch k+1 is open long
     before its first block -- the last one computed -- asks.  The streaming order of a rank:
         fill(buffer of batch k+1)      behind the pass that last read it (batch k-1): `next_shard` fences that
-        step()                         posts batch k+1's exchange, then runs batch k's pass (whose exchange the previous step posted)
+        step()                         runs batch k's pass (whose exchange the previous step posted) and posts batch k+1's exchange
     One exchange and one pass per step, as before; only their pairing moved.  Without an RCCL world (one rank, gloo) step() is the plain
     ShardedFir.step() of the current buffer."""
 
@@ -456,8 +460,21 @@ class PingPongFir:
             nxt._side = cur._side
             cur.post_exchange()
             self._primed = True
-        nxt.post_exchange()                                # batch k+1: behind the pass that last read that buffer (already on the current stream)
-        return cur.compute()
+        # batch k+1's exchange waits for what the current stream holds NOW (its samples are in place, the pass that last read that buffer is
+        # queued), but the HOST queues batch k's pass first: RCCL's enqueue is ~90 us of host time, and behind a synchronisation point
+        # (the first step of a timed region) the device would sit idle for it
+        ev = self._mark(cur)
+        out = cur.compute()
+        nxt.post_exchange(after=ev)
+        return out
+
+    def _mark(self, half):
+        """an event on the current stream, here"""
+        if getattr(self, "_events", None) is None:
+            self._events = [torch.cuda.Event(), torch.cuda.Event()]
+        ev = self._events[self.k & 1]
+        ev.record(torch.cuda.current_stream(half._buf.device))
+        return ev
 
 
 class ShardedFmChain:
@@ -553,13 +570,16 @@ class ShardedFmChain:
             self._side = torch.cuda.Stream(device=self._buf.device)
             self._pass = 0
 
-    def post_exchange(self):
+    def post_exchange(self, after=None):
         """RCCL: the exchange of THIS buffer's halo and the gate signal on the side stream (ShardedFir.post_exchange)."""
         from . import device as dv
         self._gate_setup()
         self._pass += 1
         cur = torch.cuda.current_stream(self._buf.device)
-        self._side.wait_stream(cur)
+        if after is None:
+            self._side.wait_stream(cur)
+        else:
+            self._side.wait_event(after)
         with torch.cuda.stream(self._side):
             self.ring.finish(self.ring.start(self._buf))
             if self.ring.rank > 0:

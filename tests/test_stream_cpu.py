@@ -203,7 +203,7 @@ def test_ping_pong_posts_the_next_batchs_exchange_in_front_of_this_batchs_pass(m
     import types
 
     from pothoscomms_amd import stream
-    log = []
+    log, afters = [], []
 
     class Half:
         def __init__(self, name):
@@ -216,8 +216,9 @@ def test_ping_pong_posts_the_next_batchs_exchange_in_front_of_this_batchs_pass(m
             if self._side is None:
                 self._side = object()
 
-        def post_exchange(self):
+        def post_exchange(self, after=None):
             log.append(("x", self.name))
+            afters.append(after)
 
         def compute(self):
             log.append(("c", self.name))
@@ -233,9 +234,12 @@ def test_ping_pong_posts_the_next_batchs_exchange_in_front_of_this_batchs_pass(m
     monkeypatch.setattr(stream, "_rccl_world", lambda ring: True)
     pp = object.__new__(stream.PingPongFir)
     pp.halves, pp.k, pp._primed = [Half("A"), Half("B")], 0, False
+    pp._mark = lambda half: "mark in front of %s's pass" % half.name
     assert pp.current.name == "A" and pp.upcoming.name == "B"
     assert [pp.step() for _ in range(4)] == ["A", "B", "A", "B"]
-    assert log == [("x", "A"), ("x", "B"), ("c", "A"), ("x", "A"), ("c", "B"), ("x", "B"), ("c", "A"), ("x", "A"), ("c", "B")]
+    # the host queues the pass first; the exchange of the next batch is ordered behind a mark taken IN FRONT of that pass
+    assert log == [("x", "A"), ("c", "A"), ("x", "B"), ("c", "B"), ("x", "A"), ("c", "A"), ("x", "B"), ("c", "B"), ("x", "A")]
+    assert afters == [None, "mark in front of A's pass", "mark in front of B's pass", "mark in front of A's pass", "mark in front of B's pass"]
     assert pp.halves[0]._side is pp.halves[1]._side and pp.halves[0]._side is not None
     # every pass ran behind its own half's latest exchange
     for i, (what, name) in enumerate(log):
@@ -248,6 +252,6 @@ def test_ping_pong_posts_the_next_batchs_exchange_in_front_of_this_batchs_pass(m
     pp.two_launch = False                                  # back: the pipeline is primed again from the current half
     del log[:]
     pp.step()
-    assert log == [("x", "A"), ("x", "B"), ("c", "A")]
+    assert log == [("x", "A"), ("c", "A"), ("x", "B")]
     pp.check_gate()
     assert log[-2:] == [("g", "A"), ("g", "B")]

@@ -609,6 +609,47 @@ def build_workload(wl, C, dev, rank, world, args):
     return W
 
 
+_BREAK_EXCHANGE = [False]
+
+
+def seam_check(owner, rank_has_halo):
+    """Behind the timed region, on every rank (the exchanges are a collective step of the ring): does a pass still see its halo?  The
+    bench's buffers are static -- every exchange delivers the bytes the slot already holds -- so a halo that arrived late, or bytes of a
+    peer not yet visible behind the gate, would go unnoticed in the timed passes.  Here the halo slot of the buffer whose exchange has
+    not been posted yet is POISONED (NaN), the driver stepped until that buffer has been exchanged and filtered, and the outputs at the
+    front of the shard compared with a plain head call on the completed buffer (no NaN; equal within 1e-3 of the largest output: the two
+    walk different block boundaries, and the check is for a missing halo, not for float parity -- tests/ do that).  Returns "" or what
+    is wrong."""
+    import torch
+    halves = getattr(owner, "halves", None)
+    pipelined = bool(halves) and owner._pipelined()
+    # (pipelined: the current buffer's exchange is already on its way, the upcoming one's is posted by the next step)
+    target = owner.upcoming if pipelined else owner.current if halves else owner
+    halo = target.ring.halo
+    if rank_has_halo:
+        target.buf[:halo] = float("nan")                   # (`buf` fences the input: behind the send that may still read the tail)
+    out = None
+    for _ in range(2 if pipelined else 1):
+        out = owner.step()
+    torch.cuda.synchronize()
+    n = min(target.head, 4 * halo + 64)
+    got = out[:n].clone()
+    if not rank_has_halo:
+        return ""
+    if bool(torch.isnan(target._buf[:halo]).any()):
+        return "the halo slot still holds the poison: the exchange did not deliver"
+    if bool(torch.isnan(got).any()):
+        return "outputs at the front of the shard were computed on the poisoned halo (the pass did not wait for its exchange)"
+    if hasattr(target, "_chains"):
+        target._run(target._chains[0], 0, target.head + 1, 0)
+    else:
+        target._run(0, target.head)
+    torch.cuda.synchronize()
+    ref = target.out[:n]
+    err = float((got - ref).abs().max() / ref.abs().max())
+    return "" if err <= 1e-3 else "outputs at the front of the shard differ from a plain head call by %.3g of the largest" % err
+
+
 def time_launches(step, n):
     """n back-to-back steps between ONE pair of HIP events on the launch stream (torch's current stream is the stream every
     pcx_*_dev call gets; a pair per step costs ~12 us of gap per step on this stack).  Returns ms per step."""
@@ -837,6 +878,8 @@ def main():
                 self.halo, self.group, self.rank, self.world = halo, None, 1, 3
 
             def start(self, buf):
+                if _BREAK_EXCHANGE[0]:                     # (tests only: the seam check must notice an exchange that delivers nothing)
+                    return []
                 return dist.batch_isend_irecv([dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], 0), dist.P2POp(dist.irecv, buf[:self.halo], 0)])
         W.owner.ring = SelfRing(W.owner.ring.halo)
         want_slots = args.rehearse_slots or ((_stream.RCCL_SLOTS or 0) if wl == "fir255" else 0)
@@ -944,6 +987,19 @@ def main():
         # a pass whose gated launch ran without its halo (the bounded wait of pcx_fir_process_dev_gated) is not a measurement
         if W.owner is not None:
             W.owner.check_gate()
+    seams = None
+    if W.owner is not None and (world > 1 or rehearsal) and hasattr(W.owner, "ring"):
+        _BREAK_EXCHANGE[0] = rehearsal and os.environ.get("PCX_BENCH_TEST_BREAK_SEAM") == "1"
+        wrong = seam_check(W.owner, W.owner.ring.rank > 0)
+        W.owner.check_gate()
+        bad = torch.tensor([1 if wrong else 0], dtype=torch.int32, device=dev if backend == "nccl" or rehearsal else "cpu")
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if wrong:
+            print("bench.py: rank %d, seam check: %s" % (rank, wrong), file=sys.stderr, flush=True)
+        if int(bad.item()):
+            raise SystemExit("bench.py: the seam check behind the timed region failed on some rank: not a measurement")
+        seams = "halo slots poisoned behind the timed region, one more pass per buffer: every rank's outputs at the shard front match a plain call on the completed buffer"
 
     if rank == 0:
         value = world * W.units * args.steps / elapsed / 1e6
@@ -963,6 +1019,8 @@ def main():
             from pothoscomms_amd.stream import exchange_shares_queue
             # (True would mean every exchange ran BEHIND the pass it should run beside: stream.py, HARDWARE QUEUES)
             desc["rccl_stream_shares_the_launch_queue"] = exchange_shares_queue(dev_index)
+        if seams:
+            desc["seam_check"] = seams
         out = {
             "metric": W.metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -480,3 +480,22 @@ def test_two_input_buffers_the_next_batchs_halo_exchanged_beside_this_batchs_pas
     for halo_ok, same, timed_out, _, _ in res:
         assert halo_ok and same and timed_out == 0
     assert len({r[4] for r in res}) == 6                   # six different batches went through
+
+
+@pytest.mark.parametrize("flags", [(), ("--no-pingpong",)], ids=["pipelined", "unpipelined"])
+def test_bench_poisons_the_halo_behind_the_timed_region_and_refuses_a_line_whose_seam_is_wrong(flags):
+    """bench.py's seam check (its buffers are static, so the timed passes cannot tell a late halo from a timely one): the middle-rank
+    rehearsal on one GPU carries config.seam_check, and with the exchange made to deliver nothing for the check pass the run ends
+    without a result line."""
+    import json
+    common = ("--rehearse-rccl-rank", "--shard", str(2100 * 3840), "--steps", "5", "--warmup", "2", "--settle", "5", "--no-cpu", "--no-cold",
+              "--no-secondary", "--sustain", "0") + tuple(flags)
+    r = _run_bench({}, *common)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "match a plain call" in line["config"]["seam_check"]
+    assert line["config"]["rccl_stream_shares_the_launch_queue"] is False
+    r = _run_bench({"PCX_BENCH_TEST_BREAK_SEAM": "1"}, *common)
+    assert r.returncode != 0
+    assert "seam check" in r.stderr and "poison" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

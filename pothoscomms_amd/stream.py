@@ -22,6 +22,12 @@ kernel behind it sets the gate, and everything else of the shard is filtered mea
 ran a body launch, waited, and ran a head launch: the second launch's start-up, ragged end and
 kernel boundary cost 5.6 % of a pass.)  Configurations without a gated kernel, and host-driven
 backends (the gloo rehearsal), keep the two launches.
+
+RCCL's send/recv kernel needs ~150 us for those 2 KB beside a launch that saturates the device, so a
+pass that waits for its OWN exchange ends late (+9-11 %).  Streaming use is therefore double-buffered
+(PingPongFir / PingPongFmChain): the halo of batch k+1 is exchanged while batch k is filtered.  Two
+things that needs are in this file too: room for RCCL's workgroup (PINGPONG_SLOTS) and a hardware
+queue of its own for the exchange (HARDWARE QUEUES, pick_launch_stream).
 """
 import os
 
@@ -390,7 +396,7 @@ class PingPongFir:
     exchanged, so that RCCL's protocol kernel (resident ~150 us for 2 KB on a saturated device: it made a pass 9-11 % longer when the
     pass had to wait for it, profiles/r04/rccl_pass_slots.txt) has a whole pass to finish in and the gate of batch k+1 is open long
     before its first block -- the last one computed -- asks.  The streaming order of a rank:
-        fill(buffer of batch k+1)      behind the pass that last read it (batch k-1): `next_shard` fences that
+        fill(`upcoming.shard`)         batch k+1; behind the pass that last read that buffer (batch k-1): taking the view fences that
         step()                         runs batch k's pass (whose exchange the previous step posted) and posts batch k+1's exchange
     One exchange and one pass per step, as before; only their pairing moved.  Without an RCCL world (one rank, gloo) step() is the plain
     ShardedFir.step() of the current buffer."""

@@ -32,6 +32,19 @@ template <int MODE> __global__ __launch_bounds__(256) void companion(volatile un
     if (acc == 0x12345678u) dev_word[threadIdx.x] = acc + pad[(threadIdx.x + 1) & 255];
 }
 
+// dependent loads, one lane: what a protocol kernel's chain of look-ups (arguments -> communicator -> channel -> connection -> flags) pays per hop.
+// kind 0: plain loads of device memory (L2 hits after the first round); 1: system-scope acquire loads of device memory; 2: of page-locked host memory
+__global__ void chase(const unsigned *table, unsigned hops, int kind, unsigned long long *ticks_out, unsigned *sink)
+{
+    unsigned i = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+    for (unsigned h = 0; h < hops; h++)
+        i = kind == 0 ? __builtin_nontemporal_load(table + i) : __hip_atomic_load(table + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    *ticks_out = t1 - t0;
+    *sink = i;
+}
+
 int main(int argc, char **argv)
 {
     const double us = argc > 1 ? atof(argv[1]) : 150.0;
@@ -85,5 +98,29 @@ int main(int argc, char **argv)
                 }
             }
         }
+    // ---- latency of a chain of dependent loads, alone and beside the launch ----
+    {
+        const unsigned hops = 64, n = 4096;
+        std::vector<unsigned> tab(n);
+        for (unsigned i = 0; i < n; i++) tab[i] = (i * 1031u + 577u) % n;       // a walk through the table, 16 KB apart on average
+        unsigned *dt, *ht; unsigned long long *ticks;
+        CK(hipMalloc(&dt, 4 * n)); CK(hipMemcpy(dt, tab.data(), 4 * n, hipMemcpyHostToDevice));
+        CK(hipHostMalloc(&ht, 4 * n, hipHostMallocMapped)); memcpy(ht, tab.data(), 4 * n);
+        CK(hipHostMalloc(&ticks, 64, hipHostMallocMapped));
+        const char *kn[] = {"device memory, plain loads", "device memory, system-scope acquire loads", "page-locked host memory, system-scope acquire loads"};
+        for (int kind = 0; kind < 3; kind++)
+            for (int loaded = 0; loaded < 2; loaded++) {
+                double sum = 0; int cnt = 0;
+                for (int rep = 0; rep < 40; rep++) {
+                    if (loaded) for (int i = 0; i < 3; i++) PK(pcx_fir_process_dev(h, xin, C + K - 1, y, C, &c, &p, s));
+                    if (loaded) { CK(hipEventRecord(ek, s)); }       // (the chase starts beside the second of three launches: no wait)
+                    chase<<<1, 1, 0, side>>>(kind == 2 ? ht : dt, hops, kind, ticks, dw);
+                    CK(hipStreamSynchronize(side));
+                    if (rep >= 8) { sum += (double)*ticks; cnt++; }
+                    CK(hipStreamSynchronize(s));
+                }
+                printf("%-52s %s: %.2f us per dependent load\n", kn[kind], loaded ? "beside the FIR launch" : "idle device          ", sum / cnt / hops / 100.0);
+            }
+    }
     return 0;
 }

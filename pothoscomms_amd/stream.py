@@ -23,7 +23,8 @@ ran a body launch, waited, and ran a head launch: the second launch's start-up, 
 kernel boundary cost 5.6 % of a pass.)  Configurations without a gated kernel, and host-driven
 backends (the gloo rehearsal), keep the two launches.
 
-RCCL's send/recv kernel needs ~150 us for those 2 KB beside a launch that saturates the device, so a
+RCCL's send/recv kernel finds no slot beside a launch that fills the device (its waves need 136 VGPRs,
+the launch's workgroups leave 128 per SIMD) and runs when the launch's first workgroups exit, so a
 pass that waits for its OWN exchange ends late (+9-11 %).  Streaming use is therefore double-buffered
 (PingPongFir / PingPongFmChain): the halo of batch k+1 is exchanged while batch k is filtered.  Two
 things that needs are in this file too: room for RCCL's workgroup (PINGPONG_SLOTS) and a hardware
@@ -393,8 +394,8 @@ class ShardedFir:
 
 class PingPongFir:
     """Two input buffers, software-pipelined: while batch k is filtered, the halo of batch k+1 -- already in place in the OTHER buffer -- is
-    exchanged, so that RCCL's protocol kernel (resident ~150 us for 2 KB on a saturated device: it made a pass 9-11 % longer when the
-    pass had to wait for it, profiles/r04/rccl_pass_slots.txt) has a whole pass to finish in and the gate of batch k+1 is open long
+    exchanged, so that RCCL's protocol kernel (it gets a slot only when a workgroup of the launch beside it exits, ~150 us after it was queued:
+    it made a pass 9-11 % longer when the pass had to wait for it, profiles/r04/rccl_pass_slots.txt) has a whole pass to finish in and the gate of batch k+1 is open long
     before its first block -- the last one computed -- asks.  The streaming order of a rank:
         fill(`upcoming.shard`)         batch k+1; behind the pass that last read that buffer (batch k-1): taking the view fences that
         step()                         runs batch k's pass (whose exchange the previous step posted) and posts batch k+1's exchange

@@ -482,14 +482,15 @@ def test_two_input_buffers_the_next_batchs_halo_exchanged_beside_this_batchs_pas
     assert len({r[4] for r in res}) == 6                   # six different batches went through
 
 
+@pytest.mark.parametrize("workload", ["fir255", "fmchain"])
 @pytest.mark.parametrize("flags", [(), ("--no-pingpong",)], ids=["pipelined", "unpipelined"])
-def test_bench_poisons_the_halo_behind_the_timed_region_and_refuses_a_line_whose_seam_is_wrong(flags):
+def test_bench_poisons_the_halo_behind_the_timed_region_and_refuses_a_line_whose_seam_is_wrong(flags, workload):
     """bench.py's seam check (its buffers are static, so the timed passes cannot tell a late halo from a timely one): the middle-rank
     rehearsal on one GPU carries config.seam_check, and with the exchange made to deliver nothing for the check pass the run ends
     without a result line."""
     import json
-    common = ("--rehearse-rccl-rank", "--shard", str(2100 * 3840), "--steps", "5", "--warmup", "2", "--settle", "5", "--no-cpu", "--no-cold",
-              "--no-secondary", "--sustain", "0") + tuple(flags)
+    common = ("--rehearse-rccl-rank", "--workload", workload, "--shard", str(2100 * (3840 if workload == "fir255" else 3968)), "--steps", "5", "--warmup", "2",
+              "--settle", "5", "--no-cpu", "--no-cold", "--no-secondary", "--sustain", "0") + tuple(flags)
     r = _run_bench({}, *common)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

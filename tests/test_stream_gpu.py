@@ -500,3 +500,91 @@ def test_bench_poisons_the_halo_behind_the_timed_region_and_refuses_a_line_whose
     assert r.returncode != 0
     assert "seam check" in r.stderr and "poison" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _rccl_pingpong_chain_body(port, C, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from pothoscomms_amd import device, taps as tp
+    from pothoscomms_amd.stream import HaloRing, PingPongFmChain, PINGPONG_SLOTS, pick_launch_stream
+
+    class SelfRing(HaloRing):
+        def __init__(self, halo):
+            self.halo = halo; self.group = None; self.rank = 1; self.world = 3
+
+        def start(self, buf):
+            return dist.batch_isend_irecv([dist.P2POp(dist.isend, buf[buf.shape[0] - self.halo:], 0),
+                                           dist.P2POp(dist.irecv, buf[:self.halo], 0)])
+
+    dev = torch.device("cuda", 0)
+    pp = PingPongFmChain(tp.c4_taps(), tp.C4_PHASE, C, dev)
+    pp.ring = SelfRing(pp.K)
+    pp.set_slots(PINGPONG_SLOTS)
+    torch.cuda.set_stream(pick_launch_stream(pp))
+    K = pp.K
+    x = torch.from_numpy(np.ascontiguousarray(tp.fm_test_signal(C + K)).view(np.float32).reshape(-1, 2)).to(dev)
+    plain = device.FmChain(); plain.set_phase(tp.C4_PHASE); plain.set_taps(tp.c4_taps(), False)
+    want = torch.empty((C + 1,), dtype=torch.float32, device=dev)
+
+    def load(half, k):
+        half.buf.copy_(torch.roll(x, 1000 * k, 0) * (1.0 + 0.25 * k))      # (batches differ by shift and amplitude, not by phase jumps)
+        half.buf[:K] = float("nan")
+
+    load(pp.current, 0)
+    res = []
+    for k in range(4):
+        load(pp.upcoming, k + 1)
+        cur = pp.current
+        out = pp.step()
+        torch.cuda.synchronize()
+        halo_ok = bool(torch.equal(cur.buf[:K], cur.buf[cur.buf.shape[0] - K:]))
+        plain.reset()
+        assert plain.process_dev(cur.buf, want, C + 1 + K - 1, C + 1) == (C + 1, C + 1)      # one plain call over halo + shard: output -1 first
+        torch.cuda.synchronize()
+        same = bool(torch.equal(out, want[1:]))
+        res.append((halo_ok, same, int(cur._gate[1].item()), cur.buf[:20000 + K].cpu().numpy(), out[:20000].cpu().numpy()))
+    pp.check_gate()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def _rccl_pingpong_chain_worker(port, C, q):
+    try:
+        _rccl_pingpong_chain_body(port, C, q)
+    except BaseException:
+        import traceback
+        q.put(("error", traceback.format_exc()))
+        raise
+
+
+def test_two_input_buffers_fused_chain(oracle):
+    """stream.PingPongFmChain over RCCL on one GPU: four batches through two buffers, halos poisoned; every pass bit-identical to ONE plain
+    fused call over [halo | shard] (the gated launch walks the same blocks) and, at the shard front -- what the halo feeds -- within the
+    angle bar of the oracle's Rotate -> FIR -> FreqDemod."""
+    from pothoscomms_amd import taps as tp
+    from tests.util import ang_err
+    C = 2100 * 3968
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_pingpong_chain_worker, args=(_free_port(), C, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(120)
+    assert not (len(res) == 2 and res[0] == "error"), res[1]
+    assert p.exitcode == 0 and len(res) == 4
+    h = tp.c4_taps()
+    for halo_ok, same, timed_out, xbuf, got in res:
+        assert halo_ok and same and timed_out == 0
+        n = 20000
+        xr = oracle.rotate(xbuf[:n + len(h)], tp.C4_PHASE)
+        fir = oracle.Fir(oracle.F32, True, False); fir.set_taps(h); fir.activate()
+        y, _, _, _ = fir.work(xr, n + 1)
+        ref = oracle.FreqDemod(oracle.F32).work(y)[1:n + 1]
+        assert not np.isnan(got).any()
+        assert ang_err(got[:n], ref) <= TOL

@@ -1032,6 +1032,12 @@ int pcx_gate_signal_dev(void *gate_dev, unsigned value, void *stream)
 {
     PCX_TRACE();
     PCX_CHECK_ARG(gate_dev, "null gate");
+    // (diagnostic library only: the word written by the command processor instead of a one-thread kernel -- a kernel needs a slot, and beside
+    // a launch that fills the device it gets one only when a workgroup of that launch exits; profiles/r04/gate_write_value.txt)
+    if (PCX_ENV_SET("PCX_GATE_WRITE_VALUE")) {
+        PCX_HIP(hipStreamWriteValue32(as_stream(stream), gate_dev, value, 0));
+        return PCX_OK;
+    }
     return launch_gate_signal(gate_dev, value, as_stream(stream));
 }
 

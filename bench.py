@@ -622,7 +622,7 @@ def seam_check(owner, rank_has_halo):
     is wrong."""
     import torch
     halves = getattr(owner, "halves", None)
-    pipelined = bool(halves) and owner._pipelined()
+    pipelined = bool(halves) and owner.pipelined
     # (pipelined: the current buffer's exchange is already on its way, the upcoming one's is posted by the next step)
     target = owner.upcoming if pipelined else owner.current if halves else owner
     halo = target.ring.halo
@@ -636,16 +636,12 @@ def seam_check(owner, rank_has_halo):
     got = out[:n].clone()
     if not rank_has_halo:
         return ""
-    if bool(torch.isnan(target._buf[:halo]).any()):
+    if bool(torch.isnan(target.buf[:halo]).any()):
         return "the halo slot still holds the poison: the exchange did not deliver"
     if bool(torch.isnan(got).any()):
         return "outputs at the front of the shard were computed on the poisoned halo (the pass did not wait for its exchange)"
-    if hasattr(target, "_chains"):
-        target._run(target._chains[0], 0, target.head + 1, 0)
-    else:
-        target._run(0, target.head)
+    ref = target.head_reference(n)
     torch.cuda.synchronize()
-    ref = target.out[:n]
     err = float((got - ref).abs().max() / ref.abs().max())
     return "" if err <= 1e-3 else "outputs at the front of the shard differ from a plain head call by %.3g of the largest" % err
 

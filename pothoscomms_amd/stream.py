@@ -293,6 +293,12 @@ class ShardedFir:
         c, p = self.fir.process_dev(self._buf[first_out:], self.out[first_out:], n_out + self.K - 1, n_out)
         assert c == n_out and p == n_out, (c, p, n_out)
 
+    def head_reference(self, n):
+        """The first n outputs (n <= head) computed again by a PLAIN call on the buffer as it stands -- halo in place -- into `out`; what a
+        seam check compares a pass's shard front with (bench.py seam_check)."""
+        self._run(0, self.head)
+        return self.out[:n]
+
     def _gate_setup(self):
         # the gate word (holds the pass number) and the side stream the exchange is posted on
         if getattr(self, "_gate", None) is None:
@@ -451,6 +457,8 @@ class PingPongFir:
         h = self.halves[0]
         return _rccl_world(h.ring) and not h.two_launch and h._buf.is_cuda
 
+    pipelined = property(lambda self: self._pipelined(), doc="does step() pair batch k's pass with batch k+1's exchange (an RCCL world, one-launch passes)?")
+
     def step(self):
         cur, nxt = self.current, self.upcoming
         self.k += 1
@@ -570,6 +578,11 @@ class ShardedFmChain:
         else:
             self._run(self._chains[0], 0, self.head + 1, 0)         # extra output -1 from the halo, dropped
         return self.out
+
+    def head_reference(self, n):
+        """ShardedFir.head_reference (a rank behind a halo: the head call's extra output -1 is dropped by `out`)"""
+        self._run(self._chains[0], 0, self.head + 1, 0)
+        return self.out[:n]
 
     def _gate_setup(self):
         if getattr(self, "_gate", None) is None:

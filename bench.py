@@ -69,6 +69,8 @@ def parse():
                     help="N = 1 only, fir255 / fmchain: time the pass a MIDDLE rank of an RCCL world runs -- side stream, one grouped RCCL send + receive "
                          "of the halo (to the rank itself: one GPU is enough), gate signal, ONE gated launch on the slots such a rank takes -- instead "
                          "of the plain single-GPU launch; the line says it is a rehearsal")
+    ap.add_argument("--native-transport", choices=["auto", "rccl", "peer"], default="auto",
+                    help="--driver native: how the halo travels between DISTINCT devices (auto: RCCL; peer: hipMemcpyPeerAsync)")
     ap.add_argument("--no-pingpong", dest="pingpong", action="store_false",
                     help="fir255 / fmchain over ranks: ONE input buffer, every pass waits for its own exchange at its tail.  Default: two input "
                          "buffers, the halo of batch k+1 exchanged while batch k is filtered (stream.PingPongFir)")
@@ -359,6 +361,12 @@ def run_native(args):
         devs = list(range(G))
     distinct = len(set(devs))
     transport = device.NodeStream.RCCL if distinct == G else device.NodeStream.PEER_COPY
+    if args.native_transport == "peer":
+        # hipMemcpyPeerAsync between the devices instead of ncclSend / ncclRecv: a copy has no kernel that must find a slot beside the gated
+        # launch (RCCL's finds one only when that launch's first workgroups exit: DESIGN.md 6) -- for the comparison on a real node
+        transport = device.NodeStream.PEER_COPY
+    elif args.native_transport == "rccl" and distinct != G:
+        raise SystemExit("--native-transport rccl: RCCL takes one shard per device, %d shards on %d device(s)" % (G, distinct))
     C = args.shard
     chain = args.workload == "fmchain"
     h = tp.c4_taps() if chain else tp.c1_taps()
@@ -394,7 +402,8 @@ def run_native(args):
                    "taps": K, "shard_samples": C, "halo_samples": K if chain else K - 1, "setup_passes": args.settle,
                    "driver": "native", "shards": G, "shard_devices": devs, "world_size_observed": distinct,
                    "halo_transport": "rccl send/recv (ncclCommInitAll, one process)" if transport == device.NodeStream.RCCL
-                                     else "peer copies (REHEARSAL: %d shards on %d device(s))" % (G, distinct),
+                                     else "peer copies (REHEARSAL: %d shards on %d device(s))" % (G, distinct) if distinct != G
+                                     else "peer copies (hipMemcpyPeerAsync between the devices, one process)",
                    "parallelism": "overlap-save shards x%d, one gated launch per shard and pass" % G},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

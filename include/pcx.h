@@ -356,8 +356,14 @@ PCX_API int pcx_fmchain_process_dev_gated(pcx_fmchain *h, const void *in_dev, si
  * ===================================================================== */
 typedef struct pcx_shard pcx_shard;
 typedef enum pcx_shard_transport {
-    PCX_SHARD_RCCL = 0,      /* ncclSend/ncclRecv over xGMI; one distinct device per shard (RCCL is loaded on first use) */
-    PCX_SHARD_PEER_COPY = 1  /* hipMemcpyPeerAsync; several shards may share a device (how a 1-GPU box rehearses G > 1) */
+    PCX_SHARD_RCCL = 0,      /* ncclSend/ncclRecv over xGMI; one distinct device per shard (RCCL is loaded on first use).  What one GPU could
+                              * show about its cost: RCCL's send/recv kernel needs a slot on the device, and beside a gated launch that fills
+                              * it (128-VGPR workgroups, RCCL's waves are allocated 136) it gets one only when that launch's first workgroups
+                              * exit -- the pass then ends ~18 us late (+9 %; DESIGN.md 6, profiles/r04/rccl_cost_probe.txt).  The rank driver
+                              * (pothoscomms_amd/stream.py) hides that by exchanging the NEXT batch's halo; this driver does not. */
+    PCX_SHARD_PEER_COPY = 1  /* hipMemcpyPeerAsync between the devices (peer access is switched on where the devices allow it): no kernel
+                              * that must find a slot -- two shards on one device cost +1.2 % over one launch.  Several shards may share a
+                              * device (how a 1-GPU box rehearses G > 1).  bench.py --driver native --native-transport peer|rccl compares. */
 } pcx_shard_transport;
 /* devices: `nshards` ordinals, or NULL for 0 .. nshards-1 */
 PCX_API int pcx_shard_create(int nshards, const int *devices, int transport, pcx_shard **out);

@@ -387,6 +387,18 @@ PCX_API int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elem
 /* one pass over every shard: the halo exchange and ONE launch per shard (pcx_fir_process_dev_gated); configurations without a
  * gated kernel run body, exchange, head as two launches */
 PCX_API int pcx_shard_step(pcx_shard *s);
+/* pcx_shard_step in its two halves -- the exchange of the halos of what the shard buffers hold NOW (+ the gate signals behind it), and
+ * the pass over it -- for DOUBLE-BUFFERED streaming over two handles A and B on the same devices:
+ *     fill B (batch k+1);  pcx_shard_compute(A)  [batch k, its exchange posted one turn earlier];  pcx_shard_post_exchange(B);  swap
+ * so that the halos of batch k+1 travel while batch k is filtered.  It matters for the RCCL transport, whose send/recv kernel finds a
+ * slot beside a gated launch only when that launch's first workgroups exit (PCX_SHARD_RCCL above): a pass that waits for its OWN exchange
+ * ends ~18 us late, a pass whose exchange was posted a turn earlier does not (measured for the rank driver, pothoscomms_amd/stream.py
+ * PingPongFir: +4 % over the plain launch instead of +9-11 %).  Each handle has its own streams, so the host may queue compute(A) first.
+ * After pcx_shard_post_exchange the shard buffers of that handle must not be written until its pcx_shard_compute has been queued (the
+ * exchange is reading their tails; compute orders later writers behind it).  compute without a posted exchange, or a second post
+ * without a compute between, is PCX_ERR_STATE. */
+PCX_API int pcx_shard_post_exchange(pcx_shard *s);
+PCX_API int pcx_shard_compute(pcx_shard *s);
 /* enable = 0: every shard as TWO launches per pass -- the body while the halo is in flight, the head behind an event on the halo
  * stream -- instead of one gated launch (the default, enable = 1).  The gated launch relies on the halo transfer and its signal,
  * which pcx_shard_step queues BEFORE the launch, reaching the device before it: that is how the runtime submits (in order, from the

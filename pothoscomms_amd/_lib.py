@@ -142,6 +142,8 @@ SIGNATURES = {
     "pcx_shard_buffers": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),
     "pcx_shard_scatter": (_i, [_vp, _vp, _sz]),
     "pcx_shard_step": (_i, [_vp]),
+    "pcx_shard_post_exchange": (_i, [_vp]),
+    "pcx_shard_compute": (_i, [_vp]),
     "pcx_shard_gather": (_i, [_vp, _vp, _sz]),
     "pcx_shard_sync": (_i, [_vp]),
 }

@@ -134,6 +134,7 @@ struct pcx_shard {
     bool have_taps = false;
     bool use_gate = true;                         // pcx_shard_set_gated: false = body launch, halo event, head launch (two launches per shard)
     bool exchanged_once = false;                  // the first exchange has completed (RCCL sets its connections up lazily: pcx_shard_step)
+    bool posted = false;                          // pcx_shard_post_exchange has queued this pass's exchange, pcx_shard_compute has not run yet
     unsigned long long steps = 0;
     size_t halo() const { return chain_mode ? K : K - 1; }      // samples in front of every shard
     float2 *in_ptr(int g) const { return static_cast<float2 *>(alloc[g]) + lead[g]; }       // the halo slot
@@ -147,6 +148,14 @@ static constexpr size_t kHead = 4096;   // two-launch fallback: outputs computed
         if (!(cond)) {                  \
             set_error(__VA_ARGS__);     \
             return PCX_ERR_ARG;         \
+        }                               \
+    } while (0)
+
+#define PCX_CHECK_STATE(cond, ...)      \
+    do {                                \
+        if (!(cond)) {                  \
+            set_error(__VA_ARGS__);     \
+            return PCX_ERR_STATE;       \
         }                               \
     } while (0)
 
@@ -588,11 +597,13 @@ static int shard_run_chain(pcx_shard *s, int g, const void *gate, unsigned value
     return PCX_OK;
 }
 
-int pcx_shard_step(pcx_shard *s)
+// pcx_shard_step in its two halves (include/pcx.h): the exchange of the halos of what the shard buffers hold NOW, and the pass over it.
+int pcx_shard_post_exchange(pcx_shard *s)
 {
     PCX_TRACE();
     PCX_CHECK_ARG(s, "null handle");
-    PCX_CHECK_ARG(s->C, "pcx_shard_step: call pcx_shard_configure first");
+    PCX_CHECK_ARG(s->C, "pcx_shard_post_exchange: call pcx_shard_configure first");
+    PCX_CHECK_STATE(!s->posted, "pcx_shard_post_exchange: the exchange of this handle is already posted; pcx_shard_compute comes next");
     DeviceGuard guard;
     const int G = s->G;
     const size_t halo = s->halo(), hbytes = halo * sizeof(float2);
@@ -604,16 +615,8 @@ int pcx_shard_step(pcx_shard *s)
         if (s->chain_mode) PCX_TRY(fmchain_prepare(s->chain[g]));
         else PCX_TRY(fir_prepare(s->fir[g]));
     }
-    auto whole = [&](int g) -> int {   // the whole shard in one plain call
-        return s->chain_mode ? shard_run_chain(s, g, nullptr, 0, nullptr) : shard_run_fir(s, g, 0, s->C, nullptr, 0, nullptr);
-    };
-    if (G == 1 || halo == 0) {
-        // nothing to exchange: each shard is one plain call (with one device, exactly pcx_fir_process_dev on the whole stream)
-        for (int g = 0; g < G; g++) {
-            PCX_HIP(hipSetDevice(s->dev[g]));
-            PCX_TRY(whole(g));
-        }
-        s->steps++;
+    if (G == 1 || halo == 0) {      // nothing to exchange
+        s->posted = true;
         return PCX_OK;
     }
     // the value the gate words take in this pass (compared by signed distance).  Taken BEFORE anything is queued: a step that fails
@@ -662,6 +665,32 @@ int pcx_shard_step(pcx_shard *s)
         }
         s->exchanged_once = true;
     }
+    s->posted = true;
+    return PCX_OK;
+}
+
+int pcx_shard_compute(pcx_shard *s)
+{
+    PCX_TRACE();
+    PCX_CHECK_ARG(s, "null handle");
+    PCX_CHECK_STATE(s->posted, "pcx_shard_compute: no exchange posted (pcx_shard_post_exchange first, or pcx_shard_step for both)");
+    s->posted = false;              // whatever happens below, this pass's exchange is used up
+    DeviceGuard guard;
+    const int G = s->G;
+    const size_t halo = s->halo();
+    auto whole = [&](int g) -> int {   // the whole shard in one plain call
+        return s->chain_mode ? shard_run_chain(s, g, nullptr, 0, nullptr) : shard_run_fir(s, g, 0, s->C, nullptr, 0, nullptr);
+    };
+    if (G == 1 || halo == 0) {
+        // nothing was exchanged: each shard is one plain call (with one device, exactly pcx_fir_process_dev on the whole stream)
+        for (int g = 0; g < G; g++) {
+            PCX_HIP(hipSetDevice(s->dev[g]));
+            PCX_TRY(whole(g));
+        }
+        s->steps++;
+        return PCX_OK;
+    }
+    const unsigned pass = (unsigned)s->steps;       // the number pcx_shard_post_exchange gave the gates
     // 3. every shard in ONE launch: shard 0 has no halo to wait for; the others hold their first block behind the gate
     for (int g = 0; g < G; g++) {
         PCX_HIP(hipSetDevice(s->dev[g]));
@@ -686,4 +715,13 @@ int pcx_shard_step(pcx_shard *s)
         PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[s->transport == PCX_SHARD_RCCL ? g : g + 1], 0));
     }
     return PCX_OK;
+}
+
+int pcx_shard_step(pcx_shard *s)
+{
+    PCX_TRACE();
+    PCX_CHECK_ARG(s, "null handle");
+    PCX_CHECK_ARG(s->C, "pcx_shard_step: call pcx_shard_configure first");
+    PCX_TRY(pcx_shard_post_exchange(s));
+    return pcx_shard_compute(s);
 }

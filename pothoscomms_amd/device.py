@@ -502,6 +502,14 @@ class NodeStream(_Handle):
     def step(self):
         _lib.check(_lib.load().pcx_shard_step(self._h))
 
+    def post_exchange(self):
+        """pcx_shard_post_exchange: the halos of what the shard buffers hold now start travelling (double-buffered streaming over two NodeStreams)"""
+        _lib.check(_lib.load().pcx_shard_post_exchange(self._h))
+
+    def compute(self):
+        """pcx_shard_compute: the pass whose exchange post_exchange() queued"""
+        _lib.check(_lib.load().pcx_shard_compute(self._h))
+
     def sync(self):
         _lib.check(_lib.load().pcx_shard_sync(self._h))
 

@@ -559,3 +559,69 @@ def test_long_shards_with_the_gate_switched_off_take_two_launches_and_have_no_se
         assert np.quantile(dd, 1 - 1e-5) / np.pi <= 2 * TOL and dd.max() < 1e-2
     else:
         assert nerr(outs[1], outs[0]) <= TOL
+
+
+def test_two_handles_double_buffered_the_next_batchs_halos_travel_beside_this_batchs_pass(oracle):
+    """pcx_shard_post_exchange / pcx_shard_compute (include/pcx.h): two handles of three long shards each on one device, five batches
+    through them alternately -- compute(batch k) queued first, then post_exchange(batch k+1) -- every halo poisoned before its exchange.
+    Every shard of every batch is bit-identical to a plain call on its completed buffer (the gated launch walks the same blocks), the
+    halos are the left neighbours' tails, no gate timed out; and the call order is enforced."""
+    import torch
+
+    from pothoscomms_amd import _lib, device, taps as tp
+    L = _lib.load()
+    h = tp.c1_taps()
+    K, Cs, G = len(h), 2080 * 3840, 3
+    pair = []
+    for _ in range(2):
+        ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+        ns.set_taps(h)
+        ns.configure(Cs)
+        pair.append(ns)
+    with pytest.raises(_lib.PcxError, match="no exchange posted"):
+        pair[0].compute()
+    f = device.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h)
+
+    def load(ns, batch):
+        for g in range(G):
+            i, o, s, d = ns.buffers(g)
+            _lib.check(L.pcx_fill_uniform_f32_dev(C.c_void_p(i), 2 * (K - 1 + Cs), 40 + batch, 2 * g * Cs, C.c_void_p(s)))
+        _poison_halos(ns)
+
+    load(pair[0], 0)
+    pair[0].post_exchange()
+    with pytest.raises(_lib.PcxError, match="already posted"):
+        pair[0].post_exchange()
+    sums = set()
+    for k in range(5):
+        cur, nxt = pair[k & 1], pair[(k + 1) & 1]
+        load(nxt, k + 1)
+        cur.compute()
+        nxt.post_exchange()
+        cur.sync()                                             # (reports a gate that timed out)
+        for g in range(G):
+            i, o, s, d = cur.buffers(g)
+            xin = np.empty((K - 1 + Cs, 2), np.float32)
+            yout = np.empty((Cs, 2), np.float32)
+            _lib.check(L.pcx_memcpy_d2h(xin.ctypes.data_as(C.c_void_p), C.c_void_p(i), xin.nbytes, None))
+            _lib.check(L.pcx_memcpy_d2h(yout.ctypes.data_as(C.c_void_p), C.c_void_p(o), yout.nbytes, None))
+            assert np.isfinite(yout).all(), "batch %d shard %d" % (k, g)
+            lead = (-(K - 1)) % 16
+            xa = torch.zeros((lead + K - 1 + Cs, 2), dtype=torch.float32, device="cuda:0")
+            xa[lead:] = torch.from_numpy(xin).cuda()
+            y = torch.empty((Cs, 2), dtype=torch.float32, device="cuda:0")
+            assert f.process_dev(xa[lead:], y) == (Cs, Cs)
+            assert np.array_equal(yout, y.cpu().numpy()), "batch %d shard %d" % (k, g)
+            if g > 0:
+                ip, _, _, _ = cur.buffers(g - 1)
+                tail = np.empty((K - 1, 2), np.float32)
+                _lib.check(L.pcx_memcpy_d2h(tail.ctypes.data_as(C.c_void_p), C.c_void_p(ip + 8 * Cs), tail.nbytes, None))
+                assert np.array_equal(xin[:K - 1], tail)
+            else:
+                assert nerr(yout[:4000], _oracle_fir(oracle, h, xin[:K - 1 + 4000], 4000)) <= TOL
+                sums.add(float(np.abs(yout[:1000]).sum()))
+    assert len(sums) == 5                                      # five different batches went through
+    pair[1 if 5 & 1 else 0].compute()                          # the exchange still posted for batch 5: use it up
+    for ns in pair:
+        ns.sync()

@@ -71,6 +71,8 @@ def parse():
                          "of the plain single-GPU launch; the line says it is a rehearsal")
     ap.add_argument("--native-transport", choices=["auto", "rccl", "peer"], default="auto",
                     help="--driver native: how the halo travels between DISTINCT devices (auto: RCCL; peer: hipMemcpyPeerAsync)")
+    ap.add_argument("--native-pingpong", action="store_true",
+                    help="--driver native: two handles driven double-buffered (pcx_shard_post_exchange / pcx_shard_compute)")
     ap.add_argument("--no-pingpong", dest="pingpong", action="store_false",
                     help="fir255 / fmchain over ranks: ONE input buffer, every pass waits for its own exchange at its tail.  Default: two input "
                          "buffers, the halo of batch k+1 exchanged while batch k is filtered (stream.PingPongFir)")
@@ -371,21 +373,42 @@ def run_native(args):
     chain = args.workload == "fmchain"
     h = tp.c4_taps() if chain else tp.c1_taps()
     K = len(h)
-    ns = device.NodeStream(devs, transport)
-    if chain:
-        ns.set_chain(True, tp.C4_PHASE)
-    ns.set_taps(h, complex_taps=not chain)
-    ns.configure(C)
-    for g in range(G):
-        i, o, st, d = ns.buffers(g)
-        _lib.check(L.pcx_fill_uniform_f32_dev(Cc.c_void_p(i), 2 * (K - 1 + C), 5 if chain else 2, 2 * g * C, Cc.c_void_p(st)))
+    # --native-pingpong: two handles, two consecutive batches of the stream; the halos of batch k+1 are exchanged while batch k is filtered
+    # (pcx_shard_post_exchange / pcx_shard_compute) -- one exchange and one pass per step, as without
+    handles = []
+    for b in range(2 if args.native_pingpong else 1):
+        ns = device.NodeStream(devs, transport)
+        if chain:
+            ns.set_chain(True, tp.C4_PHASE)
+        ns.set_taps(h, complex_taps=not chain)
+        ns.configure(C)
+        for g in range(G):
+            i, o, st, d = ns.buffers(g)
+            _lib.check(L.pcx_fill_uniform_f32_dev(Cc.c_void_p(i), 2 * (K - 1 + C), 5 if chain else 2, 2 * (b * G + g) * C, Cc.c_void_p(st)))
+        handles.append(ns)
+    ns = handles[0]
+    turn = [0]
+    if args.native_pingpong:
+        handles[0].post_exchange()
+
+        def step():
+            cur, nxt = handles[turn[0] & 1], handles[(turn[0] + 1) & 1]
+            turn[0] += 1
+            cur.compute()
+            nxt.post_exchange()
+    else:
+        step = ns.step
+
+    def sync():
+        for x in handles:
+            x.sync()
     for _ in range(args.settle + args.warmup):
-        ns.step()
-    ns.sync()
+        step()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ns.step()
-    ns.sync()
+        step()
+    sync()
     elapsed = time.perf_counter() - t0
     per = elapsed / args.steps
     bytes_per = (12.0 if chain else 16.0) * C           # per shard and pass
@@ -404,7 +427,8 @@ def run_native(args):
                    "halo_transport": "rccl send/recv (ncclCommInitAll, one process)" if transport == device.NodeStream.RCCL
                                      else "peer copies (REHEARSAL: %d shards on %d device(s))" % (G, distinct) if distinct != G
                                      else "peer copies (hipMemcpyPeerAsync between the devices, one process)",
-                   "parallelism": "overlap-save shards x%d, one gated launch per shard and pass" % G},
+                   "parallelism": "overlap-save shards x%d, one gated launch per shard and pass" % G
+                                  + ("; double-buffered over two handles: the halos of batch k+1 exchanged while batch k is filtered" if args.native_pingpong else "")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "fmchain_cf32_ols4096_kernel" if chain else "fir_cf32_ols4096_kernel", "avg_launch_ms": round(per * 1e3, 4),
@@ -412,7 +436,8 @@ def run_native(args):
                      "bytes_counted": "per device: its shards' algorithmic read + write bytes over the wall time of a pass (host clock "
                                       "around the K steps, all streams synchronised on both sides)"},
     }
-    ns.close()
+    for x in handles:
+        x.close()
     _flush_c_stdio()
     print(json.dumps(out), flush=True)
 

@@ -13,6 +13,8 @@ python bench.py --driver native --gpus 2 --native-devices 0,0 --shard 33554432 -
 # configs[3] rehearsed on this one GPU: eight shards of 64 Mi samples each behind the C ABI, and eight RANKS (gloo, reduced shard)
 python bench.py --driver native --gpus 8 --native-devices 0,0,0,0,0,0,0,0 --no-cpu > $O/bench_native_c3_eight_shards_one_gpu.json 2> /dev/null
 python bench.py --driver native --gpus 8 --native-devices 0,0,0,0,0,0,0,0 --workload fmchain --no-cpu > $O/bench_native_c3_eight_shards_one_gpu_fmchain.json 2> /dev/null
+python bench.py --driver native --gpus 8 --native-devices 0,0,0,0,0,0,0,0 --native-pingpong --no-cpu > $O/bench_native_c3_eight_shards_one_gpu_double_buffered.json 2> /dev/null
+python bench.py --driver native --gpus 2 --native-devices 0,0 --shard 33554432 --native-pingpong --no-cpu > $O/bench_native_two_shards_one_gpu_double_buffered.json 2> /dev/null
 PCX_BENCH_BACKEND=gloo python bench.py --gpus 8 --shard 8388608 --steps 50 --warmup 10 --no-cpu > $O/bench_eight_ranks_one_gpu_gloo.json 2> /dev/null
 # the pass of a MIDDLE rank of an RCCL world on this one GPU (halo sent to the rank itself): plain, pipelined (the N > 1 default), unpipelined
 for w in fir255 fmchain; do s=""; [ $w = fmchain ] && s="_fmchain"

@@ -1051,6 +1051,8 @@ def main():
             desc["rccl_stream_shares_the_launch_queue"] = exchange_shares_queue(dev_index)
         if seams:
             desc["seam_check"] = seams
+        if W.owner is not None and hasattr(W.owner, "slots"):
+            desc["resident_workgroups_per_launch"] = W.owner.slots or 1024
         out = {
             "metric": W.metric, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),

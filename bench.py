@@ -979,6 +979,10 @@ def main():
     if fell_back and not before:
         for _ in range(args.settle // 4 + args.warmup):      # the setup once more, in the form the timed region will run
             step()
+    # (torch creates the HIP event behind an Event object at its FIRST record(): created here, not between the clock reading and the first
+    # timed launch -- at the driver's --steps 20 the two creations read as 1-3 % of the region, tools/wall_vs_events.py)
+    ev0.record()
+    ev1.record()
     barrier()
     # HIP events on the launch stream (torch's current stream is the stream every pcx_*_dev call
     # gets): ONE pair around the K timed steps, so no event packet sits between two launches

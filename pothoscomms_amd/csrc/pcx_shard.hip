@@ -359,6 +359,7 @@ int pcx_shard_configure(pcx_shard *s, size_t shard_elems)
 {
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_ARG(s->have_taps, "pcx_shard_configure: set the taps first (the halo is K-1 samples)");
+    PCX_CHECK_STATE(!s->posted, "pcx_shard_configure: this handle's exchange is posted; pcx_shard_compute comes first");
     PCX_CHECK_ARG(shard_elems >= 1, "pcx_shard_configure: empty shard");
     const size_t halo = s->halo();
     PCX_CHECK_ARG(s->G == 1 || shard_elems >= halo, "pcx_shard_configure: a shard of %zu samples is shorter than the %zu-sample halo its neighbour needs",
@@ -438,6 +439,7 @@ int pcx_shard_scatter(pcx_shard *s, const void *host_stream, size_t elems)
     PCX_TRACE();
     PCX_CHECK_ARG(s && host_stream, "null argument");
     PCX_CHECK_ARG(s->C, "pcx_shard_scatter: call pcx_shard_configure first");
+    PCX_CHECK_STATE(!s->posted, "pcx_shard_scatter: this handle's exchange is posted and reading the shard buffers; pcx_shard_compute comes first");
     PCX_CHECK_ARG(elems == s->K - 1 + (size_t)s->G * s->C, "pcx_shard_scatter: %zu elements, expected K-1 + shards*C = %zu", elems,
                   s->K - 1 + (size_t)s->G * s->C);
     DeviceGuard guard;

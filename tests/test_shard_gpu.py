@@ -593,6 +593,10 @@ def test_two_handles_double_buffered_the_next_batchs_halos_travel_beside_this_ba
     pair[0].post_exchange()
     with pytest.raises(_lib.PcxError, match="already posted"):
         pair[0].post_exchange()
+    with pytest.raises(_lib.PcxError, match="exchange is posted"):      # the exchange is reading the buffers a scatter would overwrite
+        pair[0].scatter(np.zeros((K - 1 + G * Cs, 2), np.float32))
+    with pytest.raises(_lib.PcxError, match="exchange is posted"):
+        pair[0].configure(Cs)
     sums = set()
     for k in range(5):
         cur, nxt = pair[k & 1], pair[(k + 1) & 1]

@@ -64,10 +64,12 @@ def _check_gate(owner):
 # 224 at 640 against 193 for the single-GPU launch (bench.py --rehearse-rccl-rank --rehearse-slots N, profiles/r04/rccl_pass_slots.txt).
 # RCCL's protocol kernel costs 9-11 % of a pass whatever room it is given; the default stays 1024.)
 RCCL_SLOTS = None
-# The software-pipelined pass (PingPongFir) is another matter.  Its launch never waits for RCCL, but RCCL's workgroup (20 KB of LDS) has no
-# room beside four 36 KB workgroups on any CU of a full device: at 1024 slots it is placed when the launch beside it drains and the pass
-# takes 234-240 us; at 896 slots (32 CUs carry three workgroups) 199-200 us against 195-198 for the plain launch and 206-209 for the
-# unpipelined pass (tools/rccl_cost_probe.py, profiles/r04/rccl_cost_probe.txt).
+# The software-pipelined pass (PingPongFir) is another matter.  Its launch never waits for RCCL, but RCCL's workgroup (136 VGPRs per wave,
+# 20 KB of LDS) has no room beside the launch's 128-VGPR, 36 KB workgroups -- not beside four of them on a CU and not beside three: it is
+# placed when workgroups of the launch EXIT.  With three on a CU one exit is enough, with four it takes two on the same CU: at 896 slots
+# (half the CUs carry three) the exchange of batch k+1 gets in at the start of pass k's tail and the pass takes 199-200 us against 195-198
+# for the plain launch and 206-209 unpipelined; at 1024 it tends to lose the race against pass k+1's own workgroups and then waits for
+# THAT pass's tail: 234-240 us (tools/rccl_cost_probe.py, profiles/r04/rccl_cost_probe.txt).
 PINGPONG_SLOTS = 896
 
 

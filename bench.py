@@ -1055,6 +1055,9 @@ def main():
             desc["rccl_stream_shares_the_launch_queue"] = exchange_shares_queue(dev_index)
         if seams:
             desc["seam_check"] = seams
+        if PIPELINED in str(desc.get("parallelism", "")) and not getattr(W.owner, "pipelined", False):
+            # two buffers were built, but this run did not pipeline them (a host-driven backend, or the two-launch fall-back)
+            desc["parallelism"] = desc["parallelism"].replace(PIPELINED, "; two input buffers taken in turn, every pass behind its own exchange (no RCCL world or two-launch passes: nothing to pipeline)")
         if W.owner is not None and hasattr(W.owner, "slots"):
             desc["resident_workgroups_per_launch"] = W.owner.slots or 1024
         out = {

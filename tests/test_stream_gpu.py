@@ -253,6 +253,9 @@ def test_bench_spawns_its_own_ranks_and_reports_the_world_it_saw():
     assert len(out["config"]["rank_devices"]) == 2
     assert out["config"]["halo_backend"].startswith("gloo")
     assert out["value"] > 0
+    # a host-driven backend has nothing to pipeline, and the line does not claim it; the seams were checked all the same
+    assert "software-pipelined" not in out["config"]["parallelism"] and "taken in turn" in out["config"]["parallelism"]
+    assert "match a plain call" in out["config"]["seam_check"]
 
 
 def test_bench_falls_back_to_two_launches_when_a_rank_reports_a_gate_timeout_in_setup():
@@ -496,6 +499,8 @@ def test_bench_poisons_the_halo_behind_the_timed_region_and_refuses_a_line_whose
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "match a plain call" in line["config"]["seam_check"]
     assert line["config"]["rccl_stream_shares_the_launch_queue"] is False
+    assert ("two input buffers" in line["config"]["parallelism"]) == (not flags)
+    assert line["config"]["resident_workgroups_per_launch"] == (896 if not flags else 1024)
     r = _run_bench({"PCX_BENCH_TEST_BREAK_SEAM": "1"}, *common)
     assert r.returncode != 0
     assert "seam check" in r.stderr and "poison" in r.stderr

@@ -32,6 +32,23 @@ template <int MODE> __global__ __launch_bounds__(256) void companion(volatile un
     if (acc == 0x12345678u) dev_word[threadIdx.x] = acc + pad[(threadIdx.x + 1) & 255];
 }
 
+__global__ void thin_companion(unsigned *o) { if (o[0] == 0x12345678u) o[1] = 1; }
+// ~136 live VGPRs: 132 accumulators kept alive across a dependent chain
+__global__ __launch_bounds__(256) void fat_companion(unsigned *o)
+{
+    float a[132];
+#pragma unroll
+    for (int i = 0; i < 132; i++) a[i] = (float)(o[(threadIdx.x + i) & 63] + i);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int i = 0; i < 132; i++) a[i] = a[i] * 1.0001f + a[(i + 1) % 132];
+    float t = 0;
+#pragma unroll
+    for (int i = 0; i < 132; i++) t += a[i];
+    if (t == 12345.f) o[2] = 1;
+}
+
 // dependent loads, one lane: what a protocol kernel's chain of look-ups (arguments -> communicator -> channel -> connection -> flags) pays per hop.
 // kind 0: plain loads of device memory (L2 hits after the first round); 1: system-scope acquire loads of device memory; 2: of page-locked host memory
 __global__ void chase(const unsigned *table, unsigned hops, int kind, unsigned long long *ticks_out, unsigned *sink)
@@ -98,6 +115,36 @@ int main(int argc, char **argv)
                 }
             }
         }
+    // ---- when does a kernel queued BESIDE the launch get a slot?  A one-thread kernel and one whose waves hold ~136 VGPRs (what RCCL's are
+    // allocated), queued on the side stream right behind the start of a pass; events say when each was done, relative to the pass ----
+    {
+        hipEvent_t p0, p1, c1;
+        CK(hipEventCreate(&p0)); CK(hipEventCreate(&p1)); CK(hipEventCreate(&c1));
+        const unsigned slot_list[] = {1024, 896, 768, 640, 512};
+        for (int big = 0; big < 2; big++)
+            for (unsigned si = 0; si < 5; si++) {
+                PK(pcx_fir_set_slots(h, slot_list[si]));
+                for (int i = 0; i < 300; i++) PK(pcx_fir_process_dev(h, xin, C + K - 1, y, C, &c, &p, s));     // settle
+                double sum_c = 0, sum_p = 0; int cnt = 0;
+                for (int rep = 0; rep < 30; rep++) {
+                    PK(pcx_fir_process_dev(h, xin, C + K - 1, y, C, &c, &p, s));
+                    CK(hipEventRecord(p0, s));
+                    CK(hipStreamWaitEvent(side, p0, 0));
+                    PK(pcx_fir_process_dev(h, xin, C + K - 1, y, C, &c, &p, s));       // the pass the companion is queued beside
+                    CK(hipEventRecord(p1, s));
+                    if (big) fat_companion<<<1, 256, 0, side>>>(dw);
+                    else thin_companion<<<1, 1, 0, side>>>(dw);
+                    CK(hipEventRecord(c1, side));
+                    PK(pcx_fir_process_dev(h, xin, C + K - 1, y, C, &c, &p, s));
+                    CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(side));
+                    float mc, mp; CK(hipEventElapsedTime(&mc, p0, c1)); CK(hipEventElapsedTime(&mp, p0, p1));
+                    if (rep >= 5) { sum_c += mc; sum_p += mp; cnt++; }
+                }
+                printf("%s beside a pass on %4u resident workgroups: done %.0f us after the pass began; the pass took %.0f us\n",
+                       big ? "a 256-lane kernel of >128 VGPRs" : "a one-thread kernel           ", slot_list[si], sum_c / cnt * 1000.0, sum_p / cnt * 1000.0);
+            }
+        PK(pcx_fir_set_slots(h, 1024));
+    }
     // ---- latency of a chain of dependent loads, alone and beside the launch ----
     {
         const unsigned hops = 64, n = 4096;

@@ -144,6 +144,29 @@ int main(int argc, char **argv)
                        big ? "a 256-lane kernel of >128 VGPRs" : "a one-thread kernel           ", slot_list[si], sum_c / cnt * 1000.0, sum_p / cnt * 1000.0);
             }
         PK(pcx_fir_set_slots(h, 1024));
+        // the same beside GATED launches (gate word already open): pcx_fir_process_dev_gated on 1024 workgroups
+        unsigned *gw; CK(hipMalloc(&gw, 256)); CK(hipMemset(gw, 0x7f, 4)); CK(hipMemset(gw + 1, 0, 252));      // 0x7f7f7f7f >= any small pass number
+        for (int big = 0; big < 2; big++) {
+            int gated = 0;
+            for (int i = 0; i < 300; i++) PK(pcx_fir_process_dev_gated(h, xin, C + K - 1, y, C, &c, &p, gw, 5, s, &gated));
+            double sum_c = 0, sum_p = 0; int cnt = 0;
+            for (int rep = 0; rep < 30; rep++) {
+                PK(pcx_fir_process_dev_gated(h, xin, C + K - 1, y, C, &c, &p, gw, 5, s, &gated));
+                CK(hipEventRecord(p0, s));
+                CK(hipStreamWaitEvent(side, p0, 0));
+                PK(pcx_fir_process_dev_gated(h, xin, C + K - 1, y, C, &c, &p, gw, 5, s, &gated));
+                CK(hipEventRecord(p1, s));
+                if (big) fat_companion<<<1, 256, 0, side>>>(dw);
+                else thin_companion<<<1, 1, 0, side>>>(dw);
+                CK(hipEventRecord(c1, side));
+                PK(pcx_fir_process_dev_gated(h, xin, C + K - 1, y, C, &c, &p, gw, 5, s, &gated));
+                CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(side));
+                float mc, mp; CK(hipEventElapsedTime(&mc, p0, c1)); CK(hipEventElapsedTime(&mp, p0, p1));
+                if (rep >= 5) { sum_c += mc; sum_p += mp; cnt++; }
+            }
+            printf("%s beside a GATED pass on 1024 resident workgroups (gated = %d): done %.0f us after the pass began; the pass took %.0f us\n",
+                   big ? "a 256-lane kernel of >128 VGPRs" : "a one-thread kernel           ", gated, sum_c / cnt * 1000.0, sum_p / cnt * 1000.0);
+        }
     }
     // ---- latency of a chain of dependent loads, alone and beside the launch ----
     {

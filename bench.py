@@ -71,6 +71,8 @@ def parse():
                          "of the plain single-GPU launch; the line says it is a rehearsal")
     ap.add_argument("--native-transport", choices=["auto", "rccl", "peer"], default="auto",
                     help="--driver native: how the halo travels between DISTINCT devices (auto: RCCL; peer: hipMemcpyPeerAsync)")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="ranks over RCCL: do not time the pipelined against the unpipelined pass during setup, take the pipelined one")
     ap.add_argument("--native-pingpong", action="store_true",
                     help="--driver native: two handles driven double-buffered (pcx_shard_post_exchange / pcx_shard_compute)")
     ap.add_argument("--no-pingpong", dest="pingpong", action="store_false",
@@ -928,6 +930,8 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.set_stream(pick_launch_stream(W.owner))
 
+    tuned = None
+
     def barrier():
         if world > 1:
             if backend == "nccl":
@@ -972,6 +976,40 @@ def main():
         step()
         if k == 2:
             gate_check_and_fall_back("after the first three setup passes")     # early: 400 passes of two-second timeouts would be a quarter of an hour
+    if (W.owner is not None and hasattr(W.owner, "halves") and (rehearsal or (world > 1 and backend == "nccl")) and W.owner.pipelined
+            and not args.no_autotune):
+        # MEASURE, ON THE HARDWARE THIS RUNS ON, which form of the pass is faster -- pipelined on PINGPONG_SLOTS resident workgroups, or every
+        # pass behind its own exchange on all 1024 -- and take that one: the pipelined default rests on one-GPU rehearsals.
+        # Behind the settling passes (in front of them the clocks are still ramping and whichever form is timed first loses), the two forms
+        # in turn, twice, the better time of each.  Collective: every rank times both, the decision is made on the slowest rank's times.
+        from pothoscomms_amd.stream import PINGPONG_SLOTS
+        slots_p = args.rehearse_slots or W.owner.slots or PINGPONG_SLOTS
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = [[], []]
+        for rnd in range(2):
+            for which, (pipe, sl) in enumerate(((True, slots_p), (False, 1024))):
+                W.owner.pipeline = pipe
+                W.owner.set_slots(sl)
+                for _ in range(60):
+                    step()
+                e0.record()
+                for _ in range(100):
+                    step()
+                e1.record()
+                torch.cuda.synchronize()
+                times[which].append(e0.elapsed_time(e1) / 100)
+        t = torch.tensor([min(times[0]), min(times[1])], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        best = [float(v) for v in t.tolist()]
+        pipe = best[0] <= best[1]
+        W.owner.pipeline = pipe
+        W.owner.set_slots(slots_p if pipe else 1024)
+        W.owner.check_gate()
+        tuned = {"pipelined_ms": round(best[0], 4), "unpipelined_ms": round(best[1], 4), "chosen": "pipelined" if pipe else "unpipelined",
+                 "note": "100 passes of either form, twice in turn, behind the settling passes (best of each, slowest rank); --no-autotune takes the pipelined form unmeasured"}
+        for _ in range(60):
+            step()
     for _ in range(args.warmup):
         step()
     before = fell_back
@@ -1055,9 +1093,11 @@ def main():
             desc["rccl_stream_shares_the_launch_queue"] = exchange_shares_queue(dev_index)
         if seams:
             desc["seam_check"] = seams
+        if tuned:
+            desc["halo_exchange_form"] = tuned
         if PIPELINED in str(desc.get("parallelism", "")) and not getattr(W.owner, "pipelined", False):
             # two buffers were built, but this run did not pipeline them (a host-driven backend, or the two-launch fall-back)
-            desc["parallelism"] = desc["parallelism"].replace(PIPELINED, "; two input buffers taken in turn, every pass behind its own exchange (no RCCL world or two-launch passes: nothing to pipeline)")
+            desc["parallelism"] = desc["parallelism"].replace(PIPELINED, "; two input buffers taken in turn, every pass behind its own exchange (not pipelined: a host-driven backend, the two-launch fall-back, or the unpipelined form measured faster -- halo_backend / halo_scheme / halo_exchange_form)")
         if W.owner is not None and hasattr(W.owner, "slots"):
             desc["resident_workgroups_per_launch"] = W.owner.slots or 1024
         out = {

@@ -455,9 +455,12 @@ class PingPongFir:
         for h in self.halves:
             h.check_gate()
 
+    pipeline = True      # False: step() is the plain step of the current buffer (every pass behind its own exchange) -- for A/B, and for a
+                         # caller that measured the pipelined pass slower on its hardware (bench.py does measure, at N > 1)
+
     def _pipelined(self):
         h = self.halves[0]
-        return _rccl_world(h.ring) and not h.two_launch and h._buf.is_cuda
+        return self.pipeline and _rccl_world(h.ring) and not h.two_launch and h._buf.is_cuda
 
     pipelined = property(lambda self: self._pipelined(), doc="does step() pair batch k's pass with batch k+1's exchange (an RCCL world, one-launch passes)?")
 

@@ -500,7 +500,13 @@ def test_bench_poisons_the_halo_behind_the_timed_region_and_refuses_a_line_whose
     assert "match a plain call" in line["config"]["seam_check"]
     assert line["config"]["rccl_stream_shares_the_launch_queue"] is False
     assert ("two input buffers" in line["config"]["parallelism"]) == (not flags)
-    assert line["config"]["resident_workgroups_per_launch"] == (896 if not flags else 1024)
+    form = line["config"].get("halo_exchange_form")
+    if flags:                                              # --no-pingpong: one buffer, nothing to choose between
+        assert form is None and line["config"]["resident_workgroups_per_launch"] == 1024
+    else:                                                  # both forms were timed during setup and the faster one ran (one GPU: the pipelined one, by a margin)
+        assert form["chosen"] in ("pipelined", "unpipelined") and form["pipelined_ms"] > 0 and form["unpipelined_ms"] > 0
+        assert (form["chosen"] == "pipelined") == (form["pipelined_ms"] <= form["unpipelined_ms"])
+        assert line["config"]["resident_workgroups_per_launch"] == (896 if form["chosen"] == "pipelined" else 1024)
     r = _run_bench({"PCX_BENCH_TEST_BREAK_SEAM": "1"}, *common)
     assert r.returncode != 0
     assert "seam check" in r.stderr and "poison" in r.stderr

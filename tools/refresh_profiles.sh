@@ -19,7 +19,7 @@ PCX_BENCH_BACKEND=gloo python bench.py --gpus 8 --shard 8388608 --steps 50 --war
 # the pass of a MIDDLE rank of an RCCL world on this one GPU (halo sent to the rank itself): plain, pipelined (the N > 1 default), unpipelined
 for w in fir255 fmchain; do s=""; [ $w = fmchain ] && s="_fmchain"
   python bench.py --workload $w --no-cpu --no-secondary 2>/dev/null | tail -1 > $O/bench_rccl_rank_rehearsal_plain_same_box$s.json
-  python bench.py --workload $w --no-cpu --no-secondary --rehearse-rccl-rank 2>/dev/null | tail -1 > $O/bench_rccl_rank_rehearsal$s.json
+  python bench.py --workload $w --no-cpu --no-secondary --rehearse-rccl-rank --no-autotune 2>/dev/null | tail -1 > $O/bench_rccl_rank_rehearsal$s.json
   python bench.py --workload $w --no-cpu --no-secondary --rehearse-rccl-rank --no-pingpong 2>/dev/null | tail -1 > $O/bench_rccl_rank_rehearsal_unpipelined$s.json
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -- python3 bench.py --steps 2000 --warmup 50 --no-cpu > $O/bench_kt.log 2>&1

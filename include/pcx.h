@@ -396,7 +396,8 @@ PCX_API int pcx_shard_step(pcx_shard *s);
  * PingPongFir: +4 % over the plain launch instead of +9-11 %).  Each handle has its own streams, so the host may queue compute(A) first.
  * After pcx_shard_post_exchange the shard buffers of that handle must not be written until its pcx_shard_compute has been queued (the
  * exchange is reading their tails; compute orders later writers behind it).  compute without a posted exchange, a second post
- * without a compute between, and pcx_shard_scatter / pcx_shard_configure on a handle whose exchange is posted are PCX_ERR_STATE. */
+ * without a compute between, and pcx_shard_scatter / pcx_shard_configure / pcx_shard_set_taps / pcx_shard_set_chain / pcx_shard_set_algo
+ * on a handle whose exchange is posted are PCX_ERR_STATE (the setters would change, or free, what the posted pass is about to use). */
 PCX_API int pcx_shard_post_exchange(pcx_shard *s);
 PCX_API int pcx_shard_compute(pcx_shard *s);
 /* enable = 0: every shard as TWO launches per pass -- the body while the halo is in flight, the head behind an event on the halo

@@ -306,6 +306,8 @@ int pcx_shard_set_taps(pcx_shard *s, const double *taps, size_t ntaps, int compl
 {
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_ARG(ntaps > 0 && taps, "FIRFilter::setTaps(): taps cannot be empty");
+    // (new taps change the spectrum the posted pass would multiply by, a new K frees the buffers its exchange is writing into)
+    PCX_CHECK_STATE(!s->posted, "pcx_shard_set_taps: this handle's exchange is posted; pcx_shard_compute comes first");
     const size_t Kold = s->K;
     s->taps.assign(taps, taps + ntaps * (complex_taps ? 2 : 1));
     s->complex_taps = complex_taps ? 1 : 0;
@@ -322,6 +324,7 @@ int pcx_shard_set_taps(pcx_shard *s, const double *taps, size_t ntaps, int compl
 int pcx_shard_set_chain(pcx_shard *s, int enable, double phase)
 {
     PCX_CHECK_ARG(s, "null handle");
+    PCX_CHECK_STATE(!s->posted, "pcx_shard_set_chain: this handle's exchange is posted; pcx_shard_compute comes first");
     DeviceGuard guard;
     const bool was = s->chain_mode;
     if (enable) {
@@ -348,6 +351,7 @@ int pcx_shard_set_gated(pcx_shard *s, int enable)
 int pcx_shard_set_algo(pcx_shard *s, int algo)
 {
     PCX_CHECK_ARG(s, "null handle");
+    PCX_CHECK_STATE(!s->posted, "pcx_shard_set_algo: this handle's exchange is posted; pcx_shard_compute comes first");
     for (int g = 0; g < s->G; g++) {
         PCX_TRY(pcx_fir_set_algo(s->fir[g], algo));
         if (s->chain[g] && (algo == PCX_FIR_AUTO || algo == PCX_FIR_DIRECT || algo == PCX_FIR_OLS_FFT)) PCX_TRY(pcx_fmchain_set_algo(s->chain[g], algo));
@@ -677,6 +681,7 @@ int pcx_shard_compute(pcx_shard *s)
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_STATE(s->posted, "pcx_shard_compute: no exchange posted (pcx_shard_post_exchange first, or pcx_shard_step for both)");
     s->posted = false;              // whatever happens below, this pass's exchange is used up
+    PCX_CHECK_ARG(s->C, "pcx_shard_compute: the shard buffers are not laid out (pcx_shard_configure first)");   // (never launch on null + lead)
     DeviceGuard guard;
     const int G = s->G;
     const size_t halo = s->halo();

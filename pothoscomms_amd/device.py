@@ -489,6 +489,12 @@ class NodeStream(_Handle):
         _lib.check(_lib.load().pcx_shard_configure(self._h, shard_elems))
         self.C = shard_elems
 
+    def info(self):
+        """pcx_shard_info -> (nshards, K, shard_elems, transport) as the handle holds them"""
+        n, K, Ce, t = C.c_int(), C.c_size_t(), C.c_size_t(), C.c_int()
+        _lib.check(_lib.load().pcx_shard_info(self._h, C.byref(n), C.byref(K), C.byref(Ce), C.byref(t)))
+        return n.value, K.value, Ce.value, t.value
+
     def buffers(self, g):
         """(in_dev, out_dev, stream, device) of shard g as integers."""
         i, o, s, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()

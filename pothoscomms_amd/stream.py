@@ -50,6 +50,11 @@ def _check_gate(owner):
     buf = getattr(owner, "_buf", None)
     if gate.is_cuda or (buf is not None and buf.is_cuda):      # (a host-driven gate lives in page-locked HOST memory: the pass still runs on the device)
         dev = gate.device if gate.is_cuda else buf.device
+        # the stream the last gated launch went out on (compute() notes it): a caller who launches its passes on another stream than
+        # the one current HERE (pick_launch_stream's, inside a `with torch.cuda.stream(...)`) must still have the newest pass waited for
+        launched_on = getattr(owner, "_launch_stream", None)
+        if launched_on is not None:
+            launched_on.synchronize()
         torch.cuda.current_stream(dev).synchronize()
         if getattr(owner, "_side", None) is not None:
             owner._side.synchronize()
@@ -156,7 +161,14 @@ def _first_exchange(owner):
         owner._side.synchronize()
         owner._exchanged_once = True
         key = owner._buf.device.index
-        if key not in _QUEUES_CHECKED and hasattr(torch.cuda, "_sleep") and _rccl_world(owner.ring):
+        if hasattr(torch.cuda, "_sleep") and _rccl_world(owner.ring):
+            # The probe is COLLECTIVE (two ring exchanges): whether it runs must not depend on what THIS process happens to have looked at
+            # before (another driver on the device, another subgroup) or the ranks' send / receive counts stop pairing.  The ring agrees:
+            # if any rank of it has not looked yet, every rank probes.
+            need = torch.tensor([0 if key in _QUEUES_CHECKED else 1], dtype=torch.int32, device=owner._buf.device)
+            dist.all_reduce(need, op=dist.ReduceOp.MAX, group=owner.ring.group)
+            if not int(need.item()):
+                return
             torch.cuda.current_stream(owner._buf.device).synchronize()
             _QUEUES_CHECKED[key] = _exchange_shares_queue(owner)
             if _QUEUES_CHECKED[key]:
@@ -357,6 +369,7 @@ class ShardedFir:
     def compute(self):
         """The pass whose exchange post_exchange() queued: ONE launch over the shard, its first block behind the gate."""
         cur = torch.cuda.current_stream(self._buf.device)
+        self._launch_stream = cur                          # (check_gate waits for THIS stream, whatever is current where it is called)
         if self.ring.rank == 0:
             self._run(0, self.C)
             return self.out
@@ -381,6 +394,7 @@ class ShardedFir:
             return self.compute()
         self._gate_setup()
         self._pass += 1
+        self._launch_stream = torch.cuda.current_stream(self._buf.device)
         reqs = self.ring.start(self._buf)                  # (drains the current stream first: HaloRing.start)
         gated = True
         c, p, gated = self.fir.process_dev_gated(self._buf, self.out, self._gate, self._pass, self.C + self.K - 1, self.C) if self.ring.rank > 0 else (self.C, self.C, True)
@@ -408,7 +422,16 @@ class PingPongFir:
         fill(`upcoming.shard`)         batch k+1; behind the pass that last read that buffer (batch k-1): taking the view fences that
         step()                         runs batch k's pass (whose exchange the previous step posted) and posts batch k+1's exchange
     One exchange and one pass per step, as before; only their pairing moved.  Without an RCCL world (one rank, gloo) step() is the plain
-    ShardedFir.step() of the current buffer."""
+    ShardedFir.step() of the current buffer.
+
+    PRIMING AND THE END OF A STREAM (the contract of the pipelined form):
+      * the FIRST step() posts the exchange of `current` (batch 0) itself and, like every step, the exchange of `upcoming` (batch 1): BOTH
+        buffers must hold their batch before the first step, not only `upcoming`;
+      * every step posts an exchange for the batch AFTER the one it filters.  The exchange is a collective step of the ring, so all
+        ranks must call step() the same number of times; behind the last step one exchange is outstanding whose batch never comes --
+        it rewrites the halo slot of `upcoming` with the neighbour's current tail, harmlessly, and is complete once the side stream
+        has drained (check_gate() waits for it).  A rank that stops one step early leaves its right neighbour's last exchange
+        unanswered: RCCL blocks there."""
 
     def __init__(self, taps, shard_len, device, taps_type="COMPLEX", algo=None, group=None, slots=None, two_launch=None):
         self.halves = [ShardedFir(taps, shard_len, device, taps_type, algo, group, slots, two_launch) for _ in range(2)]
@@ -614,6 +637,7 @@ class ShardedFmChain:
     def compute(self):
         """The pass whose exchange post_exchange() queued: ONE launch over the shard on the current stream."""
         cur = torch.cuda.current_stream(self._buf.device)
+        self._launch_stream = cur
         ch = self._chains[0]
         if self.ring.rank == 0:
             self._run(ch, 1, self.C, 1)                             # stream start: reset state, no extra output

@@ -597,6 +597,15 @@ def test_two_handles_double_buffered_the_next_batchs_halos_travel_beside_this_ba
         pair[0].scatter(np.zeros((K - 1 + G * Cs, 2), np.float32))
     with pytest.raises(_lib.PcxError, match="exchange is posted"):
         pair[0].configure(Cs)
+    #  the setters that would change -- or, with another K / the chain switched, FREE -- what the posted pass is about to use
+    with pytest.raises(_lib.PcxError, match="exchange is posted") as e:
+        pair[0].set_taps(h[:31])
+    assert e.value.status == _lib.ERR_STATE
+    with pytest.raises(_lib.PcxError, match="exchange is posted"):
+        pair[0].set_chain(True, 0.3)
+    with pytest.raises(_lib.PcxError, match="exchange is posted"):
+        pair[0].set_algo(_lib.FIR_DIRECT)
+    assert pair[0].info()[1:3] == (K, Cs)                       # nothing was changed or freed by the refused calls
     sums = set()
     for k in range(5):
         cur, nxt = pair[k & 1], pair[(k + 1) & 1]

@@ -255,3 +255,111 @@ def test_ping_pong_posts_the_next_batchs_exchange_in_front_of_this_batchs_pass(m
     assert log == [("x", "A"), ("c", "A"), ("x", "B")]
     pp.check_gate()
     assert log[-2:] == [("g", "A"), ("g", "B")]
+
+
+# ---- bench.py --gpus N: a line comes out whatever fails (bench_supervisor.py) -------------------------------------------------------------
+# The ranks are real processes under gloo; the device and the workload are the CPU stand-in of tests/bench_standin.py (the line says so).
+# What is under test is everything else: launcher, supervisors, watchdog, fresh children in the conservative form, the in-rank re-timing.
+
+def _bench_standin(extra_env, *argv, launcher="parent", gpus=2, timeout=600):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"PCX_BENCH_TEST_STANDIN": os.path.join(ROOT, "tests", "bench_standin.py"), "PCX_BENCH_BACKEND": "gloo",
+                "PCX_BENCH_WATCHDOG_S": "15", "PCX_BENCH_RESULT_GRACE_S": "3"})
+    env.update(extra_env)
+    args = ["--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--settle", "4", "--shard", "8192", "--no-cpu"] + list(argv)
+    if launcher == "parent":                  # `python bench.py --gpus N`: bench.py starts torch.distributed.run itself
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:                                     # what the driver runs at N > 1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    import json
+    return r, [json.loads(ln) for ln in lines]
+
+
+def _is_flagged_standin_line(out, gpus):
+    assert out["n_gpus"] == gpus and out["config"]["world_size_observed"] == gpus and out["value"] > 0
+    assert "STAND-IN" in out["data"] and "TEST_STAND_IN" in out["config"]                 # never mistaken for a measurement
+    assert "match a plain call" in out["config"]["seam_check"]
+
+
+@pytest.mark.parametrize("launcher", ["parent", "torchrun"])
+def test_supervised_bench_first_attempt_clean(launcher):
+    r, lines = _bench_standin({}, launcher=launcher, gpus=2 if launcher == "parent" else 3)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    out = lines[0]
+    _is_flagged_standin_line(out, 2 if launcher == "parent" else 3)
+    assert out["config"]["attempt"] == 1 and out["config"]["attempt_mode"] == "as asked" and out["config"]["fallback_reason"] is None
+    assert "retimed" not in out["config"]
+    # both clocks stated; the wall-clock fraction reproduces from value
+    roof = out["roofline"]
+    assert "HIP events" in roof["clock"] and roof["wall_clock"]["ms_per_step"] == out["ms_per_step"]
+
+
+def test_supervised_bench_a_hung_rank_costs_an_attempt_not_the_line():
+    """rank 1 of attempt 1 stops making progress behind the process group's setup (the others wait for it in a collective): the
+    watchdog stops the attempt, FRESH children run the conservative form, and the line says so"""
+    r, lines = _bench_standin({"PCX_BENCH_TEST_HANG": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    out = lines[0]
+    _is_flagged_standin_line(out, 2)
+    assert out["config"]["attempt"] == 2 and out["config"]["attempt_mode"].startswith("conservative")
+    assert len(out["config"]["fallback_reason"]) == 1 and "silent for 15 s" in out["config"]["fallback_reason"][0]
+    assert "PCX_STREAM_TWO_LAUNCH" in out["config"]["halo_scheme"]
+    assert "starting fresh rank processes" in r.stderr
+
+
+def test_supervised_bench_a_rank_that_dies_in_setup_costs_an_attempt_not_the_line():
+    r, lines = _bench_standin({"PCX_BENCH_TEST_DIE": "1"}, launcher="torchrun")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    out = lines[0]
+    _is_flagged_standin_line(out, 2)
+    assert out["config"]["attempt"] == 2
+    why = out["config"]["fallback_reason"][0]
+    assert "rank 1: exit code 1" in why and "PCX_BENCH_TEST_DIE" in why          # the root cause is named, first-hand
+
+
+def test_supervised_bench_a_broken_exchange_in_the_one_launch_form_is_retimed_in_the_two_launch_form():
+    """PCX_BENCH_TEST_BREAK_SEAM=1: the exchange delivers nothing while the ranks run the one-launch form.  The seam check behind the
+    timed region notices (poisoned halo), every rank switches to two launches per pass, the K steps are timed again and checked again:
+    one line, from the FIRST attempt, carrying both timings and the reason"""
+    r, lines = _bench_standin({"PCX_BENCH_TEST_BREAK_SEAM": "1"}, gpus=3)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    out = lines[0]
+    _is_flagged_standin_line(out, 3)
+    c = out["config"]
+    assert c["attempt"] == 1 and "FALLBACK" in c["halo_scheme"]
+    assert c["retimed"]["first_form_ms_per_step"] > 0 and c["retimed"]["ms_per_step"] == out["ms_per_step"]
+    assert "rank 1: the halo slot still holds the poison" in c["retimed"]["first_form_seam_check"]
+    assert "rank 2" in c["retimed"]["first_form_seam_check"] and "rank 0" not in c["retimed"]["first_form_seam_check"]
+    assert any("seam check" in w for w in c["fallback_reason"])
+
+
+def test_supervised_bench_no_line_when_every_form_fails():
+    """PCX_BENCH_TEST_BREAK_SEAM=2: the exchange delivers nothing in any form -- every attempt ends in a failed seam check, the run
+    exits non-zero and prints NO line (a number with wrong seams is not a measurement)"""
+    r, lines = _bench_standin({"PCX_BENCH_TEST_BREAK_SEAM": "2"})
+    assert r.returncode != 0 and not lines
+    assert "attempt 2" in r.stderr and "every attempt failed" in r.stderr
+
+
+def test_supervised_bench_a_teardown_that_hangs_behind_the_line_does_not_cost_it():
+    r, lines = _bench_standin({"PCX_BENCH_TEST_HANG": "1:1:teardown"}, launcher="torchrun")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1 and lines[0]["config"]["attempt"] == 1
+    _is_flagged_standin_line(lines[0], 2)
+
+
+def test_bench_and_its_supervisor_never_replace_the_process():
+    """os.exec* from a process that has touched the GPU takes the box down on this pool: children are started with subprocess only"""
+    import re
+    for f in ("bench.py", "bench_supervisor.py"):
+        src = open(os.path.join(ROOT, f)).read()
+        code = "\n".join(ln.split("#")[0] for ln in src.splitlines() if not ln.lstrip().startswith(('"', "#")))
+        assert not re.search(r"\bos\.exec[lv]p?e?\s*\(|\bos\.spawn|\bexecv\s*\(", code), f

@@ -507,7 +507,18 @@ def test_bench_poisons_the_halo_behind_the_timed_region_and_refuses_a_line_whose
         assert form["chosen"] in ("pipelined", "unpipelined") and form["pipelined_ms"] > 0 and form["unpipelined_ms"] > 0
         assert (form["chosen"] == "pipelined") == (form["pipelined_ms"] <= form["unpipelined_ms"])
         assert line["config"]["resident_workgroups_per_launch"] == (896 if form["chosen"] == "pipelined" else 1024)
+    # the exchange delivers nothing in the one-launch form only: the seam check notices, the pass is switched to two launches, timed AGAIN
+    # and checked again -- one line, carrying both timings and the reason
     r = _run_bench({"PCX_BENCH_TEST_BREAK_SEAM": "1"}, *common)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "seam check" in r.stderr and "poison" in r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = line["config"]
+    assert "FALLBACK" in c["halo_scheme"] and "poison" in c["retimed"]["first_form_seam_check"]
+    assert c["retimed"]["first_form_ms_per_step"] > 0 and c["retimed"]["ms_per_step"] == line["ms_per_step"]
+    assert "match a plain call" in c["seam_check"] and any("seam check" in w for w in c["fallback_reason"])
+    # ... in either form: no line
+    r = _run_bench({"PCX_BENCH_TEST_BREAK_SEAM": "2"}, *common)
     assert r.returncode != 0
     assert "seam check" in r.stderr and "poison" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

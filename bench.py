@@ -924,7 +924,7 @@ def main():
     # RCCL does not come up (every rank on its own GPU), and the rehearsal of the multi-rank control flow on a single-GPU box (ranks then
     # share cuda:0); the line says so.
     backend = os.environ.get("PCX_BENCH_BACKEND", "nccl") if world > 1 else "none"
-    if backend == "nccl" and ndev < world:
+    if (backend == "nccl" or os.environ.get("PCX_BENCH_OWN_GPU") == "1") and ndev < world:
         raise SystemExit("--gpus %d needs %d GPUs on this node, %d visible" % (args.gpus, world, ndev))
     dev_index = local_rank % ndev          # one rank per GPU on the node the driver gives us
     torch.cuda.set_device(dev_index)

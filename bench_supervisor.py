@@ -38,7 +38,9 @@ ATTEMPTS = [
     {"mode": "conservative: two launches per pass (no gate), one input buffer (no pipelining), no autotune, no launch-stream probe",
      "env": dict(CONSERVATIVE_ENV), "args": list(CONSERVATIVE_ARGS)},
     {"mode": "halo staged through the host over gloo (RCCL not used), two launches per pass, one input buffer",
-     "env": dict(CONSERVATIVE_ENV, PCX_BENCH_BACKEND="gloo"), "args": list(CONSERVATIVE_ARGS)},
+     # (PCX_BENCH_OWN_GPU: a rank refuses to share a device -- the rehearsal a user asks for with PCX_BENCH_BACKEND=gloo may fold ranks
+     # onto one GPU, a FALLBACK must not turn "fewer GPUs than ranks" into a line that says n_gpus = N)
+     "env": dict(CONSERVATIVE_ENV, PCX_BENCH_BACKEND="gloo", PCX_BENCH_OWN_GPU="1"), "args": list(CONSERVATIVE_ARGS)},
 ]
 
 # seconds of SILENCE (no heartbeat, no other stderr line) a child is allowed, by the phase its last heartbeat named.  The first import of

@@ -144,6 +144,24 @@ PCX_API int pcx_trace(int on);
  * staging pageable memory */
 PCX_API int pcx_host_alloc(void **hptr, size_t bytes);
 PCX_API int pcx_host_free(void *hptr);
+/* Page-lock memory the FRAMEWORK owns, where it lies (hipHostRegister, portable + mapped): afterwards the host-pointer entry points
+ * treat it like a pcx_host_alloc slab (in place over PCIe, nothing staged).  The FIR's input inside Pothos is such memory: the
+ * reference asks the framework for its "circular" manager (filter/FIRFilter.cpp:196-199), whose buffer is pageable and mapped twice
+ * back to back so that a window may run across the wrap.
+ *   pcx_host_register(ptr, bytes)    [ptr, ptr + bytes), page-aligned by the caller.  Memory that is already page-locked is PCX_OK.
+ *   pcx_host_unregister(ptr)         the range registered at ptr (a range this library did not register: PCX_ERR_ARG).
+ *   pcx_host_register_mapping(p, bytes, max_bytes, &base, &len)
+ *                                    finds the mapping(s) of this process that hold [p, p + bytes) (/proc/self/maps), widens the range
+ *                                    over ADJACENT mappings of the same shared file object -- the two halves of a double-mapped
+ *                                    circular buffer are one object mapped twice -- and page-locks all of it; *base / *len say what
+ *                                    was locked (pass *base to pcx_host_unregister).  A range beyond max_bytes (0: 1 GiB), memory that
+ *                                    is not a shared mapping (a heap arena, a stack: locking one would pin whatever else lives
+ *                                    there) and memory already page-locked leave *base NULL and return PCX_OK: nothing to undo.
+ * The /comms/fir_filter block calls pcx_host_register_mapping the first time it sees a pageable port buffer and whenever the
+ * buffer's address leaves what it has locked, and unregisters in its destructor. */
+PCX_API int pcx_host_register(void *ptr, size_t bytes);
+PCX_API int pcx_host_unregister(void *ptr);
+PCX_API int pcx_host_register_mapping(const void *p, size_t bytes, size_t max_bytes, void **base, size_t *len);
 /* synthetic stream generator on the device: the same splitmix64 counter hash as
  * the oracle's orc_fill_uniform_f32 (uniform [-1,1), bit-identical values) */
 PCX_API int pcx_fill_uniform_f32_dev(float *dst_dev, size_t n_scalars, uint64_t seed, uint64_t offset, void *stream);

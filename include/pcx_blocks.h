@@ -81,6 +81,14 @@ PCXB_API int pcxb_acquire_buffer(pcxb_block *b, int is_output, size_t min_bytes,
  * host code must not touch them; 1 = page-locked host, 0 = pageable), so samples flowing between them never cross PCIe.  The
  * memory belongs to dst and lives until pcxb_destroy(dst). */
 PCXB_API int pcxb_link_buffer(pcxb_block *src, pcxb_block *dst, size_t min_bytes, void **ptr, size_t *bytes, int *kind);
+/* The FRAMEWORK's "circular" buffer (what Pothos hands a block that asks for BufferManager::make("circular"), as the reference
+ * FIR does, filter/FIRFilter.cpp:196-199): `bytes` (rounded up to whole pages, *actual) of PAGEABLE shared memory mapped twice back
+ * to back, so that base[i] and base[*actual + i] are the same byte and a window of up to *actual bytes may start anywhere in the
+ * first mapping.  The stand-in for that manager on this side of the boundary: the blocks see it exactly as they see Pothos's --
+ * ordinary host memory they did not allocate -- and /comms/fir_filter page-locks it where it lies on first sight
+ * (pcx_host_register_mapping).  Destroy it AFTER the blocks that saw it. */
+PCXB_API int pcxb_circular_create(size_t bytes, void **base, size_t *actual);
+PCXB_API int pcxb_circular_destroy(void *base);
 /* the reserve a block asked for at construction time (FFT: numBins); SIZE_MAX = none */
 PCXB_API int pcxb_initial_reserve(pcxb_block *b, size_t *reserve);
 

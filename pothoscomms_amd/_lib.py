@@ -73,6 +73,9 @@ SIGNATURES = {
     "pcx_trace": (_i, [_i]),
     "pcx_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "pcx_host_free": (_i, [_vp]),
+    "pcx_host_register": (_i, [_vp, _sz]),
+    "pcx_host_unregister": (_i, [_vp]),
+    "pcx_host_register_mapping": (_i, [_vp, _sz, _sz, C.POINTER(_vp), _psz]),
     "pcx_fill_uniform_f32_dev": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
     "pcx_clock_probe_dev": (_i, [_vp, C.c_uint, _vp]),
     "pcx_fir_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),

@@ -64,6 +64,8 @@ def load():
     L.pcxb_initial_reserve.argtypes = [vp, C.POINTER(sz)]
     L.pcxb_acquire_buffer.argtypes = [vp, i, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.pcxb_link_buffer.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+    L.pcxb_circular_create.argtypes = [sz, C.POINTER(vp), C.POINTER(sz)]
+    L.pcxb_circular_destroy.argtypes = [vp]
     L.pcxb_call_sizes.argtypes = [vp, cp, C.POINTER(sz), sz]
     L.pcxb_get_sizes.argtypes = [vp, cp, C.POINTER(sz), sz, C.POINTER(sz)]
     L.pcxb_num_ports.argtypes = [vp, i, C.POINTER(sz)]
@@ -326,6 +328,32 @@ class Block:
         reserve = None if r.value == _SIZE_MAX else r.value
         return (y[:p.value * self.out_dim], c.value, p.value, reserve,
                 [Label._from_c(posted[i]) for i in range(min(npost.value, 64))])
+
+
+class CircularBuffer:
+    """The framework's "circular" buffer (pcxb_circular_create): `size` bytes of PAGEABLE shared memory mapped twice back to back --
+    view(off, n) for any off < size and n <= size is contiguous, running across the wrap into the second mapping.  What Pothos hands a
+    block that asks for BufferManager::make("circular") (filter/FIRFilter.cpp:196-199).  close() it after the blocks that saw it."""
+
+    def __init__(self, nbytes):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(load().pcxb_circular_create(nbytes, C.byref(p), C.byref(n)))
+        self.base, self.size = p.value, n.value
+
+    def view(self, offset, nbytes, dtype=np.uint8):
+        assert 0 <= offset < self.size and 0 <= nbytes <= self.size
+        return np.ctypeslib.as_array((C.c_char * nbytes).from_address(self.base + offset)).view(dtype)
+
+    def close(self):
+        if getattr(self, "base", None):
+            _check(load().pcxb_circular_destroy(C.c_void_p(self.base)))
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def make(path, dtype=None, *args, dimension=1):

@@ -287,7 +287,12 @@ public:
         _taps.assign(1, std::complex<double>(1.0, 0.0));
         this->pushTaps();
     }
-    ~FIRFilter() { if (_sh) pcx_shard_destroy(_sh); pcx_fir_destroy(_h); }
+    ~FIRFilter()
+    {
+        if (_sh) pcx_shard_destroy(_sh);
+        pcx_fir_destroy(_h);
+        for (const auto &r : _locked) (void)pcx_host_unregister(r.first);
+    }
 
     void setTapsReal(const std::vector<double> &taps)
     {
@@ -432,6 +437,7 @@ public:
         // device call on [history | samples]; a burst tail shorter than M+K-1 is flushed with K-1 zeros
         const void *src = inPort->buffer().template as<const void *>();
         size_t srcElems = avail;
+        this->pageLock(src, avail * _elemBytes);
         if (_eobSampsLeft != 0 && _eobSampsLeft < _inputRequire) {
             _flush.assign((_eobSampsLeft + K - 1) * _elemBytes, 0);
             // the port buffer may be a DEVICE slab (the upstream block is one of this module's, getInputBufferManager): the CPU must
@@ -489,6 +495,38 @@ public:
     }
 
 private:
+    // The input buffer inside Pothos is the FRAMEWORK's circular buffer (getInputBufferManager below asks for it, as the reference
+    // does, FIRFilter.cpp:196-199): pageable memory, mapped twice back to back.  Left as it is, every call would be staged through
+    // the C ABI's bounce buffer by the CPU (0.9-1.2 Gsamples/s); page-locked where it lies, the kernel reads it in place over PCIe.
+    // So: the first time a pageable buffer shows up -- and again whenever the port's address leaves what has been locked (the
+    // framework re-allocated) -- the mapping that holds it is page-locked, both halves of the double mapping (pcx.h
+    // pcx_host_register_mapping: shared file mappings only, never a heap arena).  The destructor unlocks.  Memory that cannot be
+    // locked (not a shared mapping; the runtime refuses) is remembered and staged as before.
+    void pageLock(const void *p, size_t bytes)
+    {
+        if (bytes < kLockFrom) return;
+        const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+        for (const auto &r : _locked) if ((uintptr_t)r.first <= lo && hi <= (uintptr_t)r.first + r.second) return;
+        for (const auto &r : _unlockable) if (r.first <= lo && hi <= r.first + r.second) return;
+        int kind = PCX_PTR_PAGEABLE;
+        if (pcx_pointer_kind(p, &kind) != PCX_OK || kind != PCX_PTR_PAGEABLE) return;     // a pinned slab, a device slab
+        if (_locked.size() >= 4) {                      // the framework keeps re-allocating: drop the oldest range
+            // (the host-pointer entry points return with their result in place: no call of this block is reading the range)
+            (void)pcx_host_unregister(_locked.front().first);
+            _locked.erase(_locked.begin());
+        }
+        void *base = nullptr;
+        size_t len = 0;
+        if (pcx_host_register_mapping(p, bytes, 0, &base, &len) == PCX_OK && base) _locked.emplace_back(base, len);
+        else {
+            if (_unlockable.size() >= 16) _unlockable.erase(_unlockable.begin());
+            _unlockable.emplace_back(lo, bytes);
+        }
+    }
+    std::vector<std::pair<void *, size_t>> _locked;          // ranges this block page-locked (base, bytes)
+    std::vector<std::pair<uintptr_t, size_t>> _unlockable;   // windows that could not be locked: not asked about again
+    static constexpr size_t kLockFrom = 65536;               // bytes per call below which staging is as good
+
     void pushTaps()
     {
         std::vector<double> flat;

@@ -1,11 +1,17 @@
 // runner.cpp -- extern "C" driver over the bundled block runtime (include/pcx_blocks.h).
 // Plays the part of the Pothos scheduler for one block at a time: plants port buffers and
 // labels, sets workInfo, calls work() and propagateLabels(), reports consume/produce/reserve.
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "pcx.h"
 #include "pcx_blocks.h"
@@ -199,6 +205,43 @@ int pcxb_link_buffer(pcxb_block *src, pcxb_block *dst, size_t min_bytes, void **
     });
 }
 int pcxb_initial_reserve(pcxb_block *b, size_t *reserve) { *reserve = b->initialReserve; return PCX_OK; }
+
+// ---- the framework's circular buffer: one pageable shared-memory object mapped twice back to back ----
+static std::mutex g_circ_mutex;
+static std::map<void *, size_t> g_circ;      // base -> bytes of ONE mapping
+int pcxb_circular_create(size_t bytes, void **base, size_t *actual)
+{
+    return guarded([&] {
+        if (!base || !bytes) throw pcxfw::Exception("pcxb_circular_create()", "null argument");
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+        const size_t len = (bytes + page - 1) / page * page;
+        const int fd = memfd_create("pcx-circular", MFD_CLOEXEC);
+        if (fd < 0) throw pcxfw::Exception("pcxb_circular_create()", std::string("memfd_create: ") + std::strerror(errno));
+        if (ftruncate(fd, (off_t)len) != 0) { const int e = errno; close(fd); throw pcxfw::Exception("pcxb_circular_create()", std::string("ftruncate: ") + std::strerror(e)); }
+        // 2 x len of address space first, then the object twice on top of it
+        void *span = mmap(nullptr, 2 * len, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (span == MAP_FAILED) { const int e = errno; close(fd); throw pcxfw::Exception("pcxb_circular_create()", std::string("mmap: ") + std::strerror(e)); }
+        void *a = mmap(span, len, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0);
+        void *b = mmap(static_cast<char *>(span) + len, len, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd, 0);
+        const int e = errno;
+        close(fd);                                   // the mappings keep the object alive
+        if (a == MAP_FAILED || b == MAP_FAILED) { munmap(span, 2 * len); throw pcxfw::Exception("pcxb_circular_create()", std::string("mmap of the object: ") + std::strerror(e)); }
+        std::lock_guard<std::mutex> lk(g_circ_mutex);
+        g_circ[span] = len;
+        *base = span;
+        if (actual) *actual = len;
+    });
+}
+int pcxb_circular_destroy(void *base)
+{
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(g_circ_mutex);
+        auto it = g_circ.find(base);
+        if (it == g_circ.end()) throw pcxfw::Exception("pcxb_circular_destroy()", "not a circular buffer of this runner");
+        munmap(base, 2 * it->second);
+        g_circ.erase(it);
+    });
+}
 
 int pcxb_work(pcxb_block *b, const void *in, size_t in_elems, const pcxb_label *labels, size_t nlabels, void *out,
               size_t out_elems, size_t *consumed, size_t *produced, size_t *reserve, pcxb_label *posted, size_t cap,

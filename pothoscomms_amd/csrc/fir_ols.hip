@@ -241,9 +241,12 @@ __global__ __launch_bounds__(256, (PREFETCH && !HGLOBAL) ? 3 : 4) void fir_cf32_
 // orders the halo in front of the call itself.
 // slots: resident workgroups this launch may take (1024 = the whole device; a device that carries several shards of a stream
 // gives each its share, pcx_shard.hip) -- a multiple of 128, so that the dealer's sixteen groups hold the same number of workgroups
+// lead_valid: samples of the SAME stream readable in front of `in` (a call that is one chunk of a longer one, pcx_fir_process's
+// drained output): with at least `pad` of them block 0 is a full block like any other and every output comes out exactly as
+// the uncut call computes it
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                             const void *tw4096, void *sched, hipStream_t st, const void *gate_word, unsigned gate_value, int *gated,
-                            unsigned slots)
+                            unsigned slots, size_t lead_valid)
 {
     if (gated) *gated = 0;
     if (n_out == 0) return PCX_OK;
@@ -268,7 +271,7 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
     // full blocks: window inside the buffer and all S outputs wanted
-    const size_t first_full = pad > 0 ? 1 : 0;
+    const size_t first_full = pad > lead_valid ? 1 : 0;
     size_t nfull = n_out / S;
     while (nfull > first_full && (nfull - 1) * S - pad + 4096 > in_elems) nfull--;
     if (nfull < first_full) nfull = first_full;

@@ -3,6 +3,9 @@
 // of host buffers.  All arithmetic on stream data happens in the HIP kernels.
 #include <algorithm>
 #include <complex>
+#include <cstdio>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -312,6 +315,90 @@ int pcx_host_alloc(void **hptr, size_t bytes)
     return PCX_OK;
 }
 int pcx_host_free(void *hptr) { PCX_HIP(hipHostFree(hptr)); return PCX_OK; }
+
+// ---- page-locking memory the framework owns (include/pcx.h) ----
+namespace {
+std::mutex g_reg_mutex;
+std::map<uintptr_t, size_t> g_registered;      // base -> bytes of the ranges THIS library page-locked
+struct Vma { uintptr_t lo, hi; bool rw, shared; unsigned long long inode; std::string dev; };
+// the mappings of this process, ascending (/proc/self/maps: "lo-hi perms offset dev inode path")
+std::vector<Vma> read_maps()
+{
+    std::vector<Vma> v;
+    FILE *f = std::fopen("/proc/self/maps", "r");
+    if (!f) return v;
+    char line[1024];
+    while (std::fgets(line, sizeof line, f)) {
+        unsigned long long lo, hi, off, ino;
+        char perms[8] = {0}, dev[16] = {0};
+        if (std::sscanf(line, "%llx-%llx %7s %llx %15s %llu", &lo, &hi, perms, &off, dev, &ino) != 6) continue;
+        v.push_back({(uintptr_t)lo, (uintptr_t)hi, perms[0] == 'r' && perms[1] == 'w', perms[3] == 's', ino, dev});
+    }
+    std::fclose(f);
+    return v;
+}
+}  // namespace
+int pcx_host_register(void *ptr, size_t bytes)
+{
+    PCX_CHECK_ARG(ptr && bytes, "pcx_host_register: empty range");
+    int kind = PCX_PTR_PAGEABLE;
+    PCX_TRY(pcx_pointer_kind(ptr, &kind));
+    if (kind == PCX_PTR_PAGE_LOCKED) return PCX_OK;
+    PCX_CHECK_ARG(kind == PCX_PTR_PAGEABLE, "pcx_host_register: %p is device memory", ptr);
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return PCX_OK; }
+    PCX_HIP(e);
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    g_registered[(uintptr_t)ptr] = bytes;
+    return PCX_OK;
+}
+int pcx_host_unregister(void *ptr)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        auto it = g_registered.find((uintptr_t)ptr);
+        PCX_CHECK_ARG(it != g_registered.end(), "pcx_host_unregister: %p is not the base of a range this library page-locked", ptr);
+        g_registered.erase(it);
+    }
+    PCX_HIP(hipHostUnregister(ptr));
+    return PCX_OK;
+}
+int pcx_host_register_mapping(const void *p, size_t bytes, size_t max_bytes, void **base, size_t *len)
+{
+    PCX_CHECK_ARG(p && bytes && base && len, "pcx_host_register_mapping: null argument");
+    *base = nullptr; *len = 0;
+    int kind = PCX_PTR_PAGEABLE;
+    PCX_TRY(pcx_pointer_kind(p, &kind));
+    if (kind != PCX_PTR_PAGEABLE) return PCX_OK;            // page-locked already (or device memory): nothing to do
+    const std::vector<Vma> maps = read_maps();
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    size_t first = maps.size();
+    for (size_t i = 0; i < maps.size(); i++)
+        if (maps[i].lo <= lo && lo < maps[i].hi) { first = i; break; }
+    if (first == maps.size() || !maps[first].shared || !maps[first].rw || maps[first].inode == 0) return PCX_OK;   // not a shared file object
+    const Vma &m = maps[first];
+    auto same = [&](const Vma &o) { return o.shared && o.rw && o.inode == m.inode && o.dev == m.dev; };
+    // [p, p + bytes) must lie in consecutive mappings of that one object ...
+    size_t last = first;
+    while (maps[last].hi < hi) {
+        if (last + 1 >= maps.size() || maps[last + 1].lo != maps[last].hi || !same(maps[last + 1])) return PCX_OK;
+        last++;
+    }
+    // ... and every adjacent mapping of it comes along: the other half of a double mapping, whichever side this window is on
+    while (first > 0 && maps[first - 1].hi == maps[first].lo && same(maps[first - 1])) first--;
+    while (last + 1 < maps.size() && maps[last + 1].lo == maps[last].hi && same(maps[last + 1])) last++;
+    const uintptr_t rlo = maps[first].lo, rhi = maps[last].hi;
+    if (rhi - rlo > (max_bytes ? max_bytes : ((size_t)1 << 30))) return PCX_OK;
+    const hipError_t e = hipHostRegister((void *)rlo, rhi - rlo, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return PCX_OK; }
+    PCX_HIP(e);
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        g_registered[rlo] = rhi - rlo;
+    }
+    *base = (void *)rlo; *len = rhi - rlo;
+    return PCX_OK;
+}
 int pcx_pointer_kind(const void *p, int *kind)
 {
     PCX_CHECK_ARG(kind, "null kind");
@@ -389,12 +476,19 @@ struct ExecCtx {
     hipStream_t last = nullptr;
     bool have_last = false;
     hipEvent_t ev = nullptr;
+    // the DRAINED output of a host-pointer call (drain_* below): a second stream whose copy engine moves finished chunks of the
+    // result from a device workspace into the caller's page-locked buffer while the kernels are still reading the input over PCIe
+    static constexpr int kDrainChunks = 8;
+    hipStream_t drain = nullptr;
+    hipEvent_t drain_ev[kDrainChunks] = {};
     ExecCtx() = default;
     ExecCtx(const ExecCtx &) = delete;
     ExecCtx &operator=(const ExecCtx &) = delete;
     ~ExecCtx()
     {
         if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t e : drain_ev) if (e) (void)hipEventDestroy(e);
+        if (drain) (void)hipStreamDestroy(drain);
         if (own) (void)hipStreamDestroy(own);
     }
 };
@@ -564,6 +658,54 @@ static int stage_out_end(void *host, size_t bytes, StageBuf &ws, bool staged, hi
     return PCX_OK;
 }
 
+// ---- the DRAINED output direction -------------------------------------------------------------------------------------------
+// A kernel that reads page-locked host memory AND writes page-locked host memory moves 43 GB/s each way (36 through a whole FIR
+// call); a kernel that reads it and writes DEVICE memory reads at 55 GB/s, and a copy engine drains device memory to the host
+// at 57 (tools/pcie_lab.hip, profiles/r02/pcie_lab.txt).  So a host-pointer call whose output buffer is page-locked and large
+// enough goes in chunks: chunk c's kernel writes a device workspace, and behind an event the copy engine of a second stream
+// moves that chunk out while chunk c+1's kernel reads its input.  What stays exposed is the last chunk's copy.
+// Below kDrainFrom bytes of output the call stays in place both ways (the chunks' launches would cost more than they hide).
+static size_t drain_from() { return (size_t)PCX_ENV_INT("PCX_DRAIN_FROM", 2 << 20); }
+static size_t drain_chunk_bytes() { return (size_t)PCX_ENV_INT("PCX_DRAIN_CHUNK", 2 << 20); }
+static bool host_page_locked(const void *p)
+{
+    int kind = PCX_PTR_PAGEABLE;
+    return pcx_pointer_kind(p, &kind) == PCX_OK && kind == PCX_PTR_PAGE_LOCKED;
+}
+// how many chunks a drained output of `bytes` goes in (2 .. kDrainChunks)
+static int drain_chunks(size_t bytes)
+{
+    const size_t c = drain_chunk_bytes();
+    size_t n = (bytes + c - 1) / (c ? c : 1);
+    if (n < 2) n = 2;
+    if (n > (size_t)ExecCtx::kDrainChunks) n = ExecCtx::kDrainChunks;
+    return (int)n;
+}
+// (everything is created BEFORE the first transfer of a call is queued: profiles/r02/contention.md section 4)
+static int drain_setup(ExecCtx &c, int nchunks)
+{
+    if (!c.drain) PCX_HIP(hipStreamCreateWithFlags(&c.drain, hipStreamNonBlocking));
+    for (int i = 0; i < nchunks; i++)
+        if (!c.drain_ev[i]) PCX_HIP(hipEventCreateWithFlags(&c.drain_ev[i], hipEventDisableTiming));
+    return PCX_OK;
+}
+// chunk i's kernels are queued on `compute`: its bytes leave for the caller's (page-locked) buffer behind them
+static int drain_chunk(ExecCtx &c, int i, hipStream_t compute, void *host_dst, const void *dev_src, size_t bytes)
+{
+    if (!bytes) return PCX_OK;
+    PCX_HIP(hipEventRecord(c.drain_ev[i], compute));
+    PCX_HIP(hipStreamWaitEvent(c.drain, c.drain_ev[i], 0));
+    PCX_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c.drain));
+    return PCX_OK;
+}
+// the result is in the caller's buffer on return (the drain stream is behind every chunk's kernels)
+static int drain_finish(ExecCtx &c, hipStream_t compute)
+{
+    PCX_HIP(hipStreamSynchronize(c.drain));
+    PCX_HIP(hipStreamSynchronize(compute));
+    return PCX_OK;
+}
+
 /* ===================================================================== *
  *  FIR
  * ===================================================================== */
@@ -579,6 +721,7 @@ struct pcx_fir {
     StageBuf wsIn, wsOut;
     DevBuf sched;             // SchedState: dynamic block assignment of the overlap-save kernels (pcx_sched.hpp), zeroed once
     unsigned slots = 1024;    // resident workgroups a persistent launch may take (pcx_shard: several shards on one device share it)
+    size_t lead_valid = 0;    // set around the chunks of a drained host call: samples of the same stream in front of the chunk's first
     size_t Kp = 8;
     bool have_ols = false;
     bool have_poly = false;   // frequency-domain rows for L > 1 or M > 1
@@ -1015,6 +1158,18 @@ static size_t fir_iterations(const pcx_fir *h, size_t in_elems, size_t out_cap)
 static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                                 size_t *consumed, size_t *produced, void *stream, const void *gate_word, unsigned gate_value, int *gated);
 
+// Iterations a call may be cut at without changing any output: the block payload of the plain overlap-save plan (complex_float32,
+// M = L = 1, 4096-sample blocks: block b of a call computes outputs [b S, (b + 1) S), S = 4096 - (K - 1 rounded up to 16)) where that
+// plan serves the handle; the time-domain kernels and the exact integer pipelines compute every output by itself, any multiple of
+// M will do (a generous one: chunks stay whole tiles).  Other float plans (long taps, resamplers) are cut at multiples of M * 4096:
+// their outputs stay within the 1e-5 of the oracle either way, but are not bit-identical to an uncut call's.
+static size_t fir_chunk_quantum(const pcx_fir *h)
+{
+    const bool plain = h->scalar == PCX_F32 && h->cplx && h->M == 1 && h->L == 1 && h->have_ols && h->ols_log2n == 0 && h->K > 1;
+    if (plain) return 4096 - (h->K - 1 + 15) / 16 * 16;
+    return h->M * 4096;
+}
+
 int pcx_fir_process_dev(pcx_fir *h, const void *in_dev, size_t in_elems, void *out_dev, size_t out_cap,
                         size_t *consumed, size_t *produced, void *stream)
 {
@@ -1148,7 +1303,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {
         rc = launch_fir_cf32_ols_r16(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {
-        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, nullptr, 0, nullptr, h->slots);
+        rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, nullptr, 0, nullptr, h->slots, h->lead_valid);
     } else if (algo == PCX_FIR_DIRECT && fast && (2048 + h->Kp + 8) * 9 / 8 * 8 + 64 <= 64 * 1024) {
         // the LDS-tiled time-domain kernel while its tile (2048 outputs + taps) fits; longer filters than every
         // fast plan (K > 8193) take the sliding-window kernel below
@@ -1189,6 +1344,36 @@ int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size
     PCX_TRY(ctx_own_stream(h->cx, &st));
     PCX_TRY(fir_sync_tables(h));        // (tables first: nothing of the control plane between the transfers queued below)
     const void *din; void *dout; bool staged;
+    if (n_out * esz >= drain_from() && host_page_locked(out)) {
+        // the drained output (above): chunk by chunk into a device workspace, the copy engine behind.  A chunk is a whole number of
+        // the plan's blocks where the plan has blocks (so that every output is computed exactly as by one call over everything --
+        // the overlap-save kernels round differently at other block boundaries; lead_valid makes a chunk's first block a full
+        // one), and of M iterations always
+        const int nch = drain_chunks(n_out * esz);
+        const size_t q = fir_chunk_quantum(h);
+        size_t Nc = ((N + nch - 1) / nch + q - 1) / q * q;
+        PCX_TRY(h->wsOut.dev.ensure(n_out * esz));
+        PCX_TRY(drain_setup(h->cx, nch));
+        if (!device_alias(in)) { PCX_TRY(h->wsIn.dev.ensure(used_in * esz)); PCX_TRY(h->wsIn.pin.ensure(used_in * esz)); }
+        PCX_TRY(stage_in(in, used_in * esz, h->wsIn, st, &din));
+        size_t done = 0;
+        for (int c = 0; c < nch && done < N; c++) {
+            const size_t n = N - done < Nc ? N - done : Nc, o0 = done / h->M * h->L, no = n / h->M * h->L;
+            size_t cc = 0, pp = 0;
+            h->lead_valid = done;
+            const int rc = pcx_fir_process_dev(h, static_cast<const char *>(din) + done * esz, n + h->K - 1, static_cast<char *>(h->wsOut.dev.p) + o0 * esz, no,
+                                               &cc, &pp, st);
+            h->lead_valid = 0;
+            PCX_TRY(rc);
+            if (cc != n || pp != no) { set_error("fir: a chunk of the drained call came back short (%zu of %zu iterations)", cc, n); return PCX_ERR_STATE; }
+            PCX_TRY(drain_chunk(h->cx, c, st, static_cast<char *>(out) + o0 * esz, static_cast<const char *>(h->wsOut.dev.p) + o0 * esz, no * esz));
+            done += n;
+        }
+        PCX_TRY(drain_finish(h->cx, st));
+        *consumed = N;
+        *produced = n_out;
+        return PCX_OK;
+    }
     PCX_TRY(stage_reserve(out, n_out * esz, h->wsOut));
     PCX_TRY(stage_in(in, used_in * esz, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, n_out * esz, h->wsOut, &dout, &staged));

@@ -228,7 +228,7 @@ int launch_fir_cf32_direct(const void *in, size_t in_elems, void *out, size_t n_
 // sched: the handle's SchedState pair (pcx_sched.hpp: dynamic block assignment) or nullptr for the static grid stride
 int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,
                             const void *tw4096, void *sched, hipStream_t st, const void *gate_word = nullptr, unsigned gate_value = 0,
-                            int *gated = nullptr, unsigned slots = 1024);
+                            int *gated = nullptr, unsigned slots = 1024, size_t lead_valid = 0);
 int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t L,
                                    const void *tw4096, void *sched, hipStream_t st);
 size_t fir_decim_fold_factor(size_t M);

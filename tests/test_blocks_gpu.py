@@ -640,3 +640,81 @@ def test_fir_block_that_owns_a_sharded_stream(oracle):
     blk.call("setDevices", [])        # back to one device
     y, c, p, r, _ = blk.work(x[:50000], 50000)
     assert (c, p) == (50000 - (K - 1),) * 2 and nerr(y, full[:p]) <= TOL
+
+
+def test_fir_block_page_locks_the_frameworks_circular_buffer_where_it_lies(oracle):
+    """filter/FIRFilter.cpp:196-199: the reference FIR asks the framework for its "circular" input manager -- pageable memory mapped
+    twice back to back.  The block page-locks that mapping the first time it sees it (both halves: pcx_host_register_mapping), so the
+    kernel reads the window in place over PCIe instead of a CPU copy through the bounce buffer; results are the reference's, window
+    after window, also when a window runs ACROSS the wrap, and the destructor unlocks."""
+    import ctypes as C
+
+    from pothoscomms_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(11)
+    K = 255
+    taps = (rng.normal(size=K) + 1j * rng.normal(size=K)) / 16
+    blk = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    ref = oracle.Fir(1, True, True)
+    blk.call("setTaps", taps); ref.set_taps(taps)
+    blk.activate(); ref.activate()
+    circ = B.CircularBuffer(1 << 20)                      # 128 Ki complex_float32 samples
+    cap = circ.size // 8
+    kind = C.c_int()
+    _lib.check(L.pcx_pointer_kind(C.c_void_p(circ.base), C.byref(kind)))
+    assert kind.value == 0                                 # pageable: the framework's memory, not the module's
+    x = rand_stream(rng, 1, 600000, True)
+    rd = wr = 0                                            # sample counters of the stream; positions in the ring are modulo cap
+    outs, routs = [], []
+    for step, n_new in enumerate([40000, 90000, 70000, 100000, 100000, 100000, 100000]):
+        n_new = min(n_new, cap - (wr - rd))                # the producer fills what is free
+        ring = circ.view((wr % cap) * 8, n_new * 8, np.float32).reshape(-1, 2)
+        ring[:] = x[wr:wr + n_new]                         # (contiguous through the second mapping when it wraps)
+        wr += n_new
+        avail = wr - rd
+        win = circ.view((rd % cap) * 8, avail * 8, np.float32).reshape(-1, 2)
+        assert np.array_equal(win, x[rd:wr])
+        crosses = (rd % cap) + avail > cap
+        y, c, p, r, _ = blk.work(win, 200000)
+        ry, rc, rp, rr = ref.work(x[rd:wr], 200000)
+        assert (c, p, r) == (rc, rp, rr) and c == avail - (K - 1)
+        assert nerr(y, ry) <= TOL, (step, crosses)
+        outs.append(crosses)
+        rd += c
+        _lib.check(L.pcx_pointer_kind(C.c_void_p(circ.base + 4096), C.byref(kind)))
+        assert kind.value == 1                             # page-locked now, first half ...
+        _lib.check(L.pcx_pointer_kind(C.c_void_p(circ.base + circ.size + 4096), C.byref(kind)))
+        assert kind.value == 1                             # ... and the alias
+    assert any(outs) and not all(outs)                     # windows on both sides of the wrap and across it
+    blk.close()
+    _lib.check(L.pcx_pointer_kind(C.c_void_p(circ.base), C.byref(kind)))
+    assert kind.value == 0                                 # unlocked by the block's destructor
+    circ.close()
+
+
+def test_host_register_mapping_leaves_private_memory_alone():
+    """pcx_host_register_mapping page-locks shared file mappings only: a window inside the heap (or any private mapping) is left as it
+    is -- locking the arena would pin whatever else lives there -- and reported as 'nothing locked'."""
+    import ctypes as C
+
+    from pothoscomms_amd import _lib
+    L = _lib.load()
+    a = np.zeros(1 << 20, np.uint8)
+    base, n = C.c_void_p(), C.c_size_t()
+    _lib.check(L.pcx_host_register_mapping(C.c_void_p(a.ctypes.data), a.nbytes, 0, C.byref(base), C.byref(n)))
+    assert not base.value and n.value == 0
+    kind = C.c_int()
+    _lib.check(L.pcx_pointer_kind(C.c_void_p(a.ctypes.data), C.byref(kind)))
+    assert kind.value == 0
+    # a shared mapping beyond max_bytes is left alone as well
+    circ = B.CircularBuffer(1 << 20)
+    _lib.check(L.pcx_host_register_mapping(C.c_void_p(circ.base), 4096, 1 << 20, C.byref(base), C.byref(n)))
+    assert not base.value                                  # the two halves together are 2 MiB
+    _lib.check(L.pcx_host_register_mapping(C.c_void_p(circ.base + circ.size + 8192), 4096, 0, C.byref(base), C.byref(n)))
+    assert base.value == circ.base and n.value == 2 * circ.size       # asked about the SECOND half: both come along
+    _lib.check(L.pcx_host_register_mapping(C.c_void_p(circ.base), 4096, 0, C.byref(base), C.byref(n)))
+    assert not base.value                                  # page-locked already: nothing to do, nothing to undo
+    with pytest.raises(_lib.PcxError):
+        _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base + 4096)))      # not the base of a range this library locked
+    _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base)))
+    circ.close()

@@ -1,0 +1,122 @@
+"""GPU suite: the host-pointer entry points on PAGE-LOCKED buffers large enough for the drained output (pcx_api.hip drain_*): the call
+goes in chunks -- chunk c's kernel reads the caller's input in place over PCIe and writes a device workspace, a copy engine moves the
+chunk out on a second stream -- and must return exactly what one device-resident call over everything returns."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pothoscomms_amd import _lib, device, taps as tp
+from tests.util import TOL, nerr
+
+pytestmark = pytest.mark.gpu
+
+
+class Pinned:
+    """a numpy array over a pcx_host_alloc slab"""
+
+    def __init__(self, shape, dtype):
+        self.L = _lib.load()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.p = C.c_void_p()
+        _lib.check(self.L.pcx_host_alloc(C.byref(self.p), nbytes))
+        self.a = np.ctypeslib.as_array((C.c_char * nbytes).from_address(self.p.value)).view(dtype).reshape(shape)
+
+    def free(self):
+        if self.p:
+            self.a = None
+            _lib.check(self.L.pcx_host_free(self.p))
+            self.p = None
+
+
+def _fir_host(f, x, y, n_in, n_out_cap):
+    c, p = C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.load().pcx_fir_process(f._h, x.ctypes.data, n_in, y.ctypes.data, n_out_cap, C.byref(c), C.byref(p)))
+    return c.value, p.value
+
+
+@pytest.mark.parametrize("K", [255, 257, 63, 1000])
+def test_drained_fir_call_is_bit_identical_to_one_device_call(oracle, K):
+    """complex_float32, M = L = 1 on the plain overlap-save plan: the chunks are whole blocks and a chunk's first block reads the
+    previous chunk's samples in front of it, so every output is the uncut call's, bit for bit (K = 255: the window of a block
+    starts 2 samples before its first input, K = 257: none)"""
+    import torch
+    rng = np.random.default_rng(K)
+    h = (rng.normal(size=K) + 1j * rng.normal(size=K)) / np.sqrt(K)
+    n = (1 << 20) + 12345                                  # 8 MiB of output: four chunks
+    xin, yout = Pinned((n + K - 1, 2), np.float32), Pinned((n, 2), np.float32)
+    try:
+        xin.a[:] = rng.uniform(-1, 1, xin.a.shape).astype(np.float32)
+        yout.a[:] = np.nan
+        f = device.FirFilter("complex_float32", "COMPLEX")
+        f.set_taps(h)
+        assert _fir_host(f, xin.a, yout.a, n + K - 1, n) == (n, n)
+        xd = torch.from_numpy(xin.a).cuda()
+        yd = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+        assert f.process_dev(xd, yd) == (n, n)
+        torch.cuda.synchronize()
+        assert np.array_equal(yout.a, yd.cpu().numpy())
+        # and against the oracle, around the chunk seams (a quarter of the call each, rounded to whole blocks) and at both ends
+        S = 4096 - (K - 1 + 15) // 16 * 16
+        Nc = -(-(-(-n // 4)) // S) * S
+        ref = oracle.Fir(1, True, True)
+        ref.set_taps(h)
+        for at in (0, Nc, 2 * Nc, 3 * Nc, n - 3000):
+            lo = max(0, at - 1500)
+            m = min(3000, n - lo)
+            ref.activate()
+            want, _, p, _ = ref.work(xin.a[lo:lo + m + K - 1], m)
+            assert p == m and nerr(yout.a[lo:lo + m], want) <= TOL, at
+        # a pageable INPUT with a page-locked output: staged in, drained out -- the same bits
+        yout.a[:] = np.nan
+        assert _fir_host(f, np.array(xin.a), yout.a, n + K - 1, n) == (n, n)
+        assert np.array_equal(yout.a, yd.cpu().numpy())
+    finally:
+        xin.free(); yout.free()
+
+
+@pytest.mark.parametrize("dtype,M,L", [("complex_float32", 8, 1), ("complex_float32", 1, 4), ("complex_int16", 1, 1), ("complex_int16", 2, 1),
+                                       ("float32", 1, 1), ("complex_float64", 1, 1)])
+def test_drained_fir_call_other_plans(oracle, dtype, M, L):
+    """resampling, integer, real and double streams through the drained call: consume / produce totals are the reference's, the
+    integer results bit-exact, the float ones within the bar against the oracle across the chunk seams"""
+    from tests.util import rand_stream
+    scalar, cplx = device.parse_dtype(dtype)
+    rng = np.random.default_rng(M * 10 + L)
+    K = 127
+    h = (rng.normal(size=K * L) + (1j * rng.normal(size=K * L) if cplx else 0)) / np.sqrt(K)
+    if scalar == 4:
+        h = h * 0.2
+    n = 1 << 20
+    esz = device.NP_SCALAR[scalar]().itemsize * (2 if cplx else 1)
+    n_out_cap = n * L // M + 8
+    shape_in = (n + K - 1, 2) if cplx else (n + K - 1,)
+    shape_out = (n_out_cap, 2) if cplx else (n_out_cap,)
+    xin, yout = Pinned(shape_in, device.NP_SCALAR[scalar]), Pinned(shape_out, device.NP_SCALAR[scalar])
+    try:
+        xin.a[:] = rand_stream(rng, scalar, n + K - 1, cplx, amp=3000)
+        f = device.FirFilter(dtype, "COMPLEX" if cplx else "REAL")
+        f.set_taps(h); f.set_decimation(M); f.set_interpolation(L)
+        c, p = _fir_host(f, xin.a, yout.a, n + K - 1, n_out_cap)
+        ref = oracle.Fir(scalar, cplx, cplx)
+        ref.set_taps(h); ref.set_decimation(M); ref.set_interpolation(L); ref.activate()
+        m = 300000                                          # the oracle on the first 300k inputs: covers the first chunk seam (a quarter)
+        want, rc, rp, _ = ref.work(xin.a[:m + K - 1], m * L // M)
+        assert c == (n // M) * M and p == (n // M) * L
+        assert p * esz >= (2 << 20)                         # (large enough for the drained form)
+        got = yout.a[:rp]
+        if scalar in (4, 5):
+            assert np.array_equal(got, want)
+        else:
+            assert nerr(got, want) <= (TOL if scalar == 1 else 1e-12)
+        # the tail of the call against the oracle as well (last chunk)
+        ref.activate()
+        t0 = (n - 200000) // M * M
+        want, rc, rp, _ = ref.work(xin.a[t0:n + K - 1], 200000 * L // M + 8)
+        got = yout.a[t0 // M * L:t0 // M * L + rp]
+        if scalar in (4, 5):
+            assert np.array_equal(got, want)
+        else:
+            assert nerr(got, want) <= (TOL if scalar == 1 else 1e-12)
+    finally:
+        xin.free(); yout.free()

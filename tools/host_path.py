@@ -56,3 +56,45 @@ for n in (1 << 18, 1 << 20, 1 << 22):
     dt = (time.perf_counter() - t0) / reps
     assert p == n
     print("/comms/fir_filter work() on its own port buffers (pinned in=%s out=%s)  n=%9d  %.3f ms  %.2f Gsamples/s" % (pin_in, pin_out, n, dt * 1e3, n / dt / 1e9))
+
+
+# ---- the FRAMEWORK's circular input (pageable, double-mapped: what the FIR gets inside Pothos, FIRFilter.cpp:196-199) ----
+# work() after work() on a ring of 4x the call size, the window sliding through it and across the wrap; the block page-locks the
+# mapping on first sight (pcx_host_register_mapping), the output goes to the block's own pinned slabs.  `lock=False` shows what the
+# same loop costs when the ring is NOT locked (kLockFrom bytes per call are not reached: K-1 history + a call below 64 KiB never is,
+# so the comparison run keeps the window just under that... no: it uses a private copy of the window, which cannot be locked).
+def circular_loop(n, lock=True, reps=20):
+    K = 255
+    blk = blocks.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    blk.call("setTaps", tp.c1_taps())
+    blk.activate()
+    circ = blocks.CircularBuffer(4 * (n + K) * 8)
+    cap = circ.size // 8
+    yout, pin_out = blk.port_buffer(1, (n, 2), np.float32)
+    src = np.random.default_rng(0).uniform(-1, 1, (n, 2)).astype(np.float32)
+    rd = 0
+    circ.view(0, (K - 1) * 8, np.float32)[:] = 0
+    wr = K - 1
+    dt = 0.0
+    for it in range(reps + 2):
+        circ.view((wr % cap) * 8, n * 8, np.float32).reshape(-1, 2)[:] = src        # the producer (not timed)
+        wr += n
+        win = circ.view((rd % cap) * 8, (wr - rd) * 8, np.float32).reshape(-1, 2)
+        if not lock:
+            win = np.array(win)                            # a private (heap) copy: pageable and not lockable -> staged
+        t0 = time.perf_counter()
+        _, c, p, _, _ = blk.work(win, n, outbuf=yout)
+        if it >= 2:
+            dt += time.perf_counter() - t0
+        assert c == n and p == n
+        rd += c
+    blk.close()
+    circ.close()
+    return dt / reps
+
+
+for n in (1 << 18, 1 << 20, 1 << 22):
+    a = circular_loop(n, lock=False)
+    b = circular_loop(n, lock=True)
+    print("/comms/fir_filter work() on the framework's CIRCULAR input, n=%9d: pageable (staged) %.3f ms %.2f Gsamples/s | page-locked where it lies %.3f ms %.2f Gsamples/s"
+          % (n, a * 1e3, n / a / 1e9, b * 1e3, n / b / 1e9))

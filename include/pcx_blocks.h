@@ -103,6 +103,12 @@ PCXB_API int pcxb_work(pcxb_block *b, const void *in, size_t in_elems, const pcx
                        void *out, size_t out_elems, size_t *consumed, size_t *produced, size_t *reserve,
                        pcxb_label *posted, size_t cap, size_t *nposted);
 
+/* Measurement aid: `reps` work() calls on the SAME planted buffers back to back from native code (no labels), wall seconds of the
+ * loop in *seconds, the last call's consume / produce in *consumed / *produced -- what a C++ scheduler's loop pays per call, without
+ * the per-call cost of a scripting-language binding around pcxb_work. */
+PCXB_API int pcxb_work_loop(pcxb_block *b, const void *in, size_t in_elems, void *out, size_t out_elems, size_t reps, double *seconds,
+                            size_t *consumed, size_t *produced);
+
 /*
  * Blocks with several ports (arithmetic: N indexed inputs; split_complex: outputs "re","im";
  * combine_complex: inputs "re","im").  Ports are numbered indexed-first, then the named ones in

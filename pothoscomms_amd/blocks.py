@@ -64,6 +64,7 @@ def load():
     L.pcxb_initial_reserve.argtypes = [vp, C.POINTER(sz)]
     L.pcxb_acquire_buffer.argtypes = [vp, i, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.pcxb_link_buffer.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+    L.pcxb_work_loop.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(C.c_double), C.POINTER(sz), C.POINTER(sz)]
     L.pcxb_circular_create.argtypes = [sz, C.POINTER(vp), C.POINTER(sz)]
     L.pcxb_circular_destroy.argtypes = [vp]
     L.pcxb_call_sizes.argtypes = [vp, cp, C.POINTER(sz), sz]
@@ -262,6 +263,13 @@ class Block:
         _check(load().pcxb_work(self._h, C.c_void_p(in_ptr), in_elems, labs, len(labels), C.c_void_p(out_ptr), out_elems, C.byref(c), C.byref(p),
                                 C.byref(r), posted, 64, C.byref(npost)))
         return c.value, p.value, (None if r.value == _SIZE_MAX else r.value)
+
+    def work_loop(self, in_ptr, in_elems, out_ptr, out_elems, reps):
+        """pcxb_work_loop: `reps` work() calls on the same buffers from native code.  Returns (seconds, consumed, produced) of the loop /
+        its last call."""
+        t, c, p = C.c_double(), C.c_size_t(), C.c_size_t()
+        _check(load().pcxb_work_loop(self._h, C.c_void_p(in_ptr), in_elems, C.c_void_p(out_ptr), out_elems, reps, C.byref(t), C.byref(c), C.byref(p)))
+        return t.value, c.value, p.value
 
     def initial_reserve(self):
         r = C.c_size_t()

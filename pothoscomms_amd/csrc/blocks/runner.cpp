@@ -2,6 +2,7 @@
 // Plays the part of the Pothos scheduler for one block at a time: plants port buffers and
 // labels, sets workInfo, calls work() and propagateLabels(), reports consume/produce/reserve.
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -271,6 +272,30 @@ int pcxb_work(pcxb_block *b, const void *in, size_t in_elems, const pcxb_label *
         size_t n = 0;
         for (const auto &l : op->_posted) { if (n < cap && posted) fromLabel(l, posted[n]); n++; }
         if (nposted) *nposted = n;
+    });
+}
+
+int pcxb_work_loop(pcxb_block *b, const void *in, size_t in_elems, void *out, size_t out_elems, size_t reps, double *seconds,
+                   size_t *consumed, size_t *produced)
+{
+    return guarded([&] {
+        InputPort *ip = b->blk->input(0);
+        OutputPort *op = b->blk->output(0);
+        ip->_labels.clear();
+        WorkInfo &wi = b->blk->workInfoMutable();
+        wi.minInElements = in_elems; wi.minOutElements = out_elems;
+        wi.minElements = in_elems < out_elems ? in_elems : out_elems;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t r = 0; r < reps; r++) {
+            ip->_buffer = BufferChunk::view(const_cast<void *>(in), in_elems * ip->dtype().size(), ip->dtype());
+            op->_buffer = BufferChunk::view(out, out_elems * op->dtype().size(), op->dtype());
+            ip->_consumed = 0; ip->_reserveSet = false; ip->_reserve = 0;
+            op->_produced = 0; op->_posted.clear();
+            b->blk->work();
+        }
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (consumed) *consumed = ip->_consumed;
+        if (produced) *produced = op->_produced;
     });
 }
 

@@ -658,14 +658,18 @@ static int stage_out_end(void *host, size_t bytes, StageBuf &ws, bool staged, hi
     return PCX_OK;
 }
 
-// ---- the DRAINED output direction -------------------------------------------------------------------------------------------
-// A kernel that reads page-locked host memory AND writes page-locked host memory moves 43 GB/s each way (36 through a whole FIR
-// call); a kernel that reads it and writes DEVICE memory reads at 55 GB/s, and a copy engine drains device memory to the host
-// at 57 (tools/pcie_lab.hip, profiles/r02/pcie_lab.txt).  So a host-pointer call whose output buffer is page-locked and large
-// enough goes in chunks: chunk c's kernel writes a device workspace, and behind an event the copy engine of a second stream
-// moves that chunk out while chunk c+1's kernel reads its input.  What stays exposed is the last chunk's copy.
-// Below kDrainFrom bytes of output the call stays in place both ways (the chunks' launches would cost more than they hide).
-static size_t drain_from() { return (size_t)PCX_ENV_INT("PCX_DRAIN_FROM", 2 << 20); }
+// ---- the DRAINED output direction (diagnostic library only: measured, NOT adopted) -------------------------------------------------
+// Idea: a kernel that reads page-locked host memory AND writes page-locked host memory moves 43 GB/s each way; a kernel
+// that reads it and writes DEVICE memory reads at 55, and a copy engine drains device memory to the host at 57 (each alone).  So a
+// host-pointer call would go in chunks: chunk c's kernel writes a device workspace, and behind an event the copy engine of a second
+// stream moves that chunk out while chunk c+1's kernel reads its input.
+// Measured (tools/pcie_lab.hip, tools/drain_ab.py, profiles/r05/pcie_lab.txt, drain_ab.txt): the two do NOT overlap on this platform.
+// "kernel pinned->device || D2H copy" runs at 29.7 GB/s per direction -- the sum of the two times -- and the whole FIR call at 27.8
+// against 40.0 in place (16 Mi samples); copy engines on BOTH sides reach 48.4 unchunked but 26-41 in chunks of 1-8 MiB (15-20 us per
+// queued copy), so no chunked form beats the in-place kernel (43.3) below calls of ~100 MiB.  The in-place form stays the product's;
+// this form stays reachable in libpcx_hip_diag.so (PCX_DRAIN_FROM = bytes of output from which a call is drained, PCX_DRAIN_CHUNK)
+// so that the finding can be re-measured, and its chunks are bit-identical to the uncut call (tests/test_hostpath_gpu.py).
+static size_t drain_from() { return (size_t)PCX_ENV_INT("PCX_DRAIN_FROM", (long)1 << 62); }     // product: never
 static size_t drain_chunk_bytes() { return (size_t)PCX_ENV_INT("PCX_DRAIN_CHUNK", 2 << 20); }
 static bool host_page_locked(const void *p)
 {

@@ -1,7 +1,16 @@
-"""GPU suite: the host-pointer entry points on PAGE-LOCKED buffers large enough for the drained output (pcx_api.hip drain_*): the call
-goes in chunks -- chunk c's kernel reads the caller's input in place over PCIe and writes a device workspace, a copy engine moves the
-chunk out on a second stream -- and must return exactly what one device-resident call over everything returns."""
+"""GPU suite: the host-pointer FIR entry point on large PAGE-LOCKED buffers, in both of its forms.
+
+  * the product's: the kernel reads and writes the caller's buffers in place over PCIe;
+  * the DRAINED form of the diagnostic library (pcx_api.hip drain_*: chunk c's kernel writes a device workspace, a copy engine moves
+    the chunk out on a second stream -- measured slower on this platform, profiles/r05/drain_ab.txt, and kept for re-measuring):
+    test_the_drained_form_under_the_diagnostic_library runs this file's other tests once more under libpcx_hip_diag.so with
+    PCX_DRAIN_FROM set, where every call here goes in two to eight chunks.
+
+Either way a call must return exactly what one device-resident call over everything returns."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -36,7 +45,7 @@ def _fir_host(f, x, y, n_in, n_out_cap):
 
 
 @pytest.mark.parametrize("K", [255, 257, 63, 1000])
-def test_drained_fir_call_is_bit_identical_to_one_device_call(oracle, K):
+def test_pinned_fir_call_is_bit_identical_to_one_device_call(oracle, K):
     """complex_float32, M = L = 1 on the plain overlap-save plan: the chunks are whole blocks and a chunk's first block reads the
     previous chunk's samples in front of it, so every output is the uncut call's, bit for bit (K = 255: the window of a block
     starts 2 samples before its first input, K = 257: none)"""
@@ -77,7 +86,7 @@ def test_drained_fir_call_is_bit_identical_to_one_device_call(oracle, K):
 
 @pytest.mark.parametrize("dtype,M,L", [("complex_float32", 8, 1), ("complex_float32", 1, 4), ("complex_int16", 1, 1), ("complex_int16", 2, 1),
                                        ("float32", 1, 1), ("complex_float64", 1, 1)])
-def test_drained_fir_call_other_plans(oracle, dtype, M, L):
+def test_pinned_fir_call_other_plans(oracle, dtype, M, L):
     """resampling, integer, real and double streams through the drained call: consume / produce totals are the reference's, the
     integer results bit-exact, the float ones within the bar against the oracle across the chunk seams"""
     from tests.util import rand_stream
@@ -87,8 +96,8 @@ def test_drained_fir_call_other_plans(oracle, dtype, M, L):
     h = (rng.normal(size=K * L) + (1j * rng.normal(size=K * L) if cplx else 0)) / np.sqrt(K)
     if scalar == 4:
         h = h * 0.2
-    n = 1 << 20
     esz = device.NP_SCALAR[scalar]().itemsize * (2 if cplx else 1)
+    n = max(1 << 20, (4 << 20) // esz * M // L)            # at least 4 MiB of output: the drained form, two chunks or more
     n_out_cap = n * L // M + 8
     shape_in = (n + K - 1, 2) if cplx else (n + K - 1,)
     shape_out = (n_out_cap, 2) if cplx else (n_out_cap,)
@@ -103,7 +112,7 @@ def test_drained_fir_call_other_plans(oracle, dtype, M, L):
         m = 300000                                          # the oracle on the first 300k inputs: covers the first chunk seam (a quarter)
         want, rc, rp, _ = ref.work(xin.a[:m + K - 1], m * L // M)
         assert c == (n // M) * M and p == (n // M) * L
-        assert p * esz >= (2 << 20)                         # (large enough for the drained form)
+        assert p * esz >= (2 << 20)                         # (large enough for two chunks or more in the drained form)
         got = yout.a[:rp]
         if scalar in (4, 5):
             assert np.array_equal(got, want)
@@ -120,3 +129,17 @@ def test_drained_fir_call_other_plans(oracle, dtype, M, L):
             assert nerr(got, want) <= (TOL if scalar == 1 else 1e-12)
     finally:
         xin.free(); yout.free()
+
+
+def test_the_drained_form_under_the_diagnostic_library():
+    """the same tests, every call drained in chunks (libpcx_hip_diag.so reads PCX_DRAIN_FROM / PCX_DRAIN_CHUNK; the product never drains)"""
+    if os.environ.get("PCX_HOSTPATH_INNER"):
+        pytest.skip("this IS the inner run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "pothoscomms_amd", "libpcx_hip_diag.so")
+    assert os.path.exists(diag), "make -C pothoscomms_amd/csrc diag"
+    env = dict(os.environ, PCX_HIP_LIBRARY=diag, PCX_DRAIN_FROM=str(1 << 20), PCX_DRAIN_CHUNK=str(2 << 20), PCX_HOSTPATH_INNER="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-p", "no:xdist"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -55,5 +55,56 @@ int main()
     t("kernel reads pinned host, writes pinned host (zero-copy)", [&] { hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, s0, (const float4 *)hin, (float4 *)hout, bytes / 16); });
     t("kernel reads pinned host -> device", [&] { hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, s0, (const float4 *)hin, (float4 *)dout, bytes / 16); });
     t("kernel device -> pinned host", [&] { hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, s0, (const float4 *)din, (float4 *)hout, bytes / 16); });
+    // ---- round 5: can the two directions be split between a kernel and a copy engine? ----
+    t("kernel pinned->device (s0) || D2H copy of other data (s1)", [&] {
+        hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, s0, (const float4 *)hin, (float4 *)din, bytes / 16);
+        CK(hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, s1));
+    });
+    t("H2D copy (s0) || kernel device->pinned (s1)", [&] {
+        CK(hipMemcpyAsync(din, hin, bytes, hipMemcpyHostToDevice, s0));
+        hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, s1, (const float4 *)dout, (float4 *)hout, bytes / 16);
+    });
+    t("kernel pinned->device (s0) || kernel device->pinned (s1)", [&] {
+        hipLaunchKernelGGL(touch, dim3(1024), dim3(256), 0, s0, (const float4 *)hin, (float4 *)din, bytes / 16);
+        hipLaunchKernelGGL(touch, dim3(1024), dim3(256), 0, s1, (const float4 *)dout, (float4 *)hout, bytes / 16);
+    });
+    hipEvent_t ev[512];
+    for (auto &e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (size_t chunk : {1ull << 20, 2ull << 20, 4ull << 20, 8ull << 20, 32ull << 20}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "chunks of %zu MiB: kernel pinned->device (s0), event, D2H copy (s1)", chunk >> 20);
+        t(nm, [&] {
+            size_t k = 0;
+            for (size_t off = 0; off < bytes; off += chunk, k++) {
+                hipLaunchKernelGGL(touch, dim3(1024), dim3(256), 0, s0, (const float4 *)((char *)hin + off), (float4 *)((char *)dout + off), chunk / 16);
+                CK(hipEventRecord(ev[k], s0));
+                CK(hipStreamWaitEvent(s1, ev[k], 0));
+                CK(hipMemcpyAsync((char *)hout + off, (char *)dout + off, chunk, hipMemcpyDeviceToHost, s1));
+            }
+        });
+        snprintf(nm, sizeof nm, "chunks of %zu MiB: H2D copy (s0), event, kernel device->pinned (s1)", chunk >> 20);
+        t(nm, [&] {
+            size_t k = 0;
+            for (size_t off = 0; off < bytes; off += chunk, k++) {
+                CK(hipMemcpyAsync((char *)din + off, (char *)hin + off, chunk, hipMemcpyHostToDevice, s0));
+                CK(hipEventRecord(ev[k], s0));
+                CK(hipStreamWaitEvent(s1, ev[k], 0));
+                hipLaunchKernelGGL(touch, dim3(1024), dim3(256), 0, s1, (const float4 *)((char *)din + off), (float4 *)((char *)hout + off), chunk / 16);
+            }
+        });
+        snprintf(nm, sizeof nm, "chunks of %zu MiB: H2D copy (s0), event, kernel dev->dev (s1), event, D2H copy (s2)", chunk >> 20);
+        t(nm, [&] {
+            size_t k = 0;
+            for (size_t off = 0; off < bytes; off += chunk, k++) {
+                CK(hipMemcpyAsync((char *)din + off, (char *)hin + off, chunk, hipMemcpyHostToDevice, s0));
+                CK(hipEventRecord(ev[2 * k], s0));
+                CK(hipStreamWaitEvent(s1, ev[2 * k], 0));
+                hipLaunchKernelGGL(touch, dim3(1024), dim3(256), 0, s1, (const float4 *)((char *)din + off), (float4 *)((char *)dout + off), chunk / 16);
+                CK(hipEventRecord(ev[2 * k + 1], s1));
+                CK(hipStreamWaitEvent(s2, ev[2 * k + 1], 0));
+                CK(hipMemcpyAsync((char *)hout + off, (char *)dout + off, chunk, hipMemcpyDeviceToHost, s2));
+            }
+        });
+    }
     return 0;
 }

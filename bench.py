@@ -882,6 +882,149 @@ def _test_fault(point, rank):
             time.sleep(3600)
 
 
+def measure_c3_one_device(args, plain_ms):
+    """BASELINE configs[3] rehearsed where the driver runs: 8 shards of 64 Mi samples through pcx_shard_* (the native, one-process driver
+    behind the C ABI) on DEVICE 0, the 254-sample halos moved by peer copies, one gated launch per shard and pass.  Not a multi-GPU
+    number -- the line says so -- but the whole mechanism of a pass (exchange, gate, eight launches) under the driver's own clock:
+    ms per pass against 8 x the plain single launch, and every seam checked behind the timed passes (halos poisoned first)."""
+    import ctypes as Cc
+
+    import numpy as np
+
+    from pothoscomms_amd import _lib, device, taps as tp
+    L = _lib.load()
+    G, C = 8, SHARD
+    h = tp.c1_taps()
+    K = len(h)
+    ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+    ns.set_taps(h, complex_taps=True)
+    ns.configure(C)
+    bufs = [ns.buffers(g) for g in range(G)]
+    for g, (i, o, st, d) in enumerate(bufs):
+        _lib.check(L.pcx_fill_uniform_f32_dev(Cc.c_void_p(i), 2 * (K - 1 + C), 4, 2 * g * C, Cc.c_void_p(st)))
+    ns.sync()
+    for _ in range(40):
+        ns.step()
+    ns.sync()
+    n = 40
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ns.step()
+    ns.sync()
+    per_ms = (time.perf_counter() - t0) / n * 1e3
+    # the seams: poison every halo slot, one more pass, then shard by shard -- the slot holds the left neighbour's tail again, the first
+    # 4096 outputs are finite and equal a plain call on the completed buffer (1e-3 of the largest: a missing halo, not float parity)
+    nan = np.full((K - 1, 2), np.nan, np.float32)
+    for g in range(1, G):
+        _lib.check(L.pcx_memcpy_h2d(Cc.c_void_p(bufs[g][0]), nan.ctypes.data_as(Cc.c_void_p), nan.nbytes, Cc.c_void_p(bufs[g][2])))
+    ns.sync()
+    ns.step()
+    ns.sync()
+    f = device.FirFilter("complex_float32", "COMPLEX")
+    f.set_taps(h)
+    wrong = []
+    m = 4096
+    for g in range(1, G):
+        xin = np.empty((K - 1 + m, 2), np.float32)
+        y = np.empty((m, 2), np.float32)
+        tail = np.empty((K - 1, 2), np.float32)
+        _lib.check(L.pcx_memcpy_d2h(xin.ctypes.data_as(Cc.c_void_p), Cc.c_void_p(bufs[g][0]), xin.nbytes, None))
+        _lib.check(L.pcx_memcpy_d2h(y.ctypes.data_as(Cc.c_void_p), Cc.c_void_p(bufs[g][1]), y.nbytes, None))
+        _lib.check(L.pcx_memcpy_d2h(tail.ctypes.data_as(Cc.c_void_p), Cc.c_void_p(bufs[g - 1][0] + 8 * C), tail.nbytes, None))
+        _lib.check(L.pcx_stream_sync(None))
+        if not np.array_equal(xin[:K - 1], tail):
+            wrong.append("shard %d: the halo slot does not hold shard %d's tail" % (g, g - 1))
+            continue
+        ref, c, p = f.process(xin, m)
+        if not np.isfinite(y).all() or float(np.max(np.abs(y - ref)) / np.max(np.abs(ref))) > 1e-3:
+            wrong.append("shard %d: the outputs at its front do not match a plain call on the completed buffer" % g)
+    ns.close()
+    out = {"metric": "Msamples/s complex_float32 255-tap FIR", "value": round(G * C / (per_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+           "n_gpus": 1, "steps": n, "ms_per_pass": round(per_ms, 4),
+           "config": {"workload": "BASELINE configs[3] REHEARSED ON ONE DEVICE: 255-tap complex_float32 FIR, 8 shards x %d samples through pcx_shard_* "
+                                  "(one process, C ABI), all on device 0, halos by peer copies, one gated launch per shard and pass" % C,
+                      "shards": G, "shard_samples": C, "halo_samples": K - 1, "driver": "native"},
+           "ratio_to_8_plain_launches": round(per_ms / (8 * plain_ms), 4) if plain_ms else None,
+           "plain_launch_ms": round(plain_ms, 4) if plain_ms else None,
+           "seam_check": ("halo slots poisoned behind the timed passes, one more pass: all 7 seams hold the left neighbour's tail and the shard fronts "
+                          "match a plain call") if not wrong else "FAILED: " + "; ".join(wrong),
+           "roofline": {"bound": "hbm", "achieved": round(16.0 * G * C / (per_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(16.0 * G * C / (per_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "fir_cf32_ols4096_kernel (gated), 8 launches per pass",
+                        "clock": "wall clock around %d passes, every stream synchronised on both sides" % n}}
+    return out
+
+
+def measure_host_path(args, cpu):
+    """SURVEY 8d's "one end-to-end number including H2D/D2H": /comms/fir_filter work() -- the block a Pothos topology loads -- on host port
+    buffers, transfers INSIDE the timed region (every call returns with its result in the output buffer).  Priced on the PCIe roof of
+    THIS box, measured in this run (pcx_pcie_probe: copy engines, both directions at once).  Two inputs: the block's own page-locked
+    port slabs, and the framework's pageable double-mapped "circular" buffer (what the FIR is handed inside Pothos,
+    filter/FIRFilter.cpp:196-199), which the block page-locks where it lies -- window placed across the wrap.  Native call loop
+    (pcxb_work_loop): what a C++ scheduler pays, no Python per call."""
+    import ctypes as Cc
+
+    import numpy as np
+
+    from pothoscomms_amd import _lib, blocks, device, taps as tp
+    L = _lib.load()
+    up, down, both = Cc.c_double(), Cc.c_double(), Cc.c_double()
+    _lib.check(L.pcx_pcie_probe(128 << 20, 3, Cc.byref(up), Cc.byref(down), Cc.byref(both)))
+    roof = both.value
+    K = 255
+    calls = {}
+    for n in (1 << 20, 1 << 24):
+        for mode in ("pinned_port_buffers", "circular_input_page_locked_in_place"):
+            blk = blocks.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+            blk.call("setTaps", tp.c1_taps())
+            blk.activate()
+            yout, _ = blk.port_buffer(1, (n, 2), np.float32)
+            circ = None
+            if mode == "pinned_port_buffers":
+                xin, _ = blk.port_buffer(0, (n + K - 1, 2), np.float32)
+            else:
+                circ = blocks.CircularBuffer(2 * (n + K) * 8)
+                cap = circ.size // 8
+                xin = circ.view((cap - n // 2) * 8, (n + K - 1) * 8, np.float32).reshape(-1, 2)
+            half = xin.shape[0] // 2       # (filled on the device's generator would need a device buffer; a host fill of 128 MiB costs ~0.1 s)
+            xin[:half] = np.random.default_rng(3).uniform(-1, 1, (half, 2)).astype(np.float32)
+            xin[half:] = xin[:xin.shape[0] - half]
+            blk.work_loop(xin.ctypes.data, n + K - 1, yout.ctypes.data, n, 3)
+            reps = max(5, (1 << 25) // n)
+            best = None
+            for _ in range(3):
+                t, c, p = blk.work_loop(xin.ctypes.data, n + K - 1, yout.ctypes.data, n, reps)
+                if (c, p) != (n, n):
+                    raise SystemExit("bench.py: host_path: work() consumed %d produced %d of %d" % (c, p, n))
+                best = t / reps if best is None else min(best, t / reps)
+            gbs = 8.0 * n / best / 1e9
+            calls.setdefault("%d_samples_per_call" % n, {})[mode] = {"ms_per_call": round(best * 1e3, 4), "Msamples_per_s": round(n / best / 1e6, 1),
+                                                                     "GB_per_s_each_way": round(gbs, 2), "frac_of_pcie_roof": round(gbs / roof, 4)}
+            blk.close()
+            if circ is not None:
+                circ.close()
+    head = calls["%d_samples_per_call" % (1 << 20)]["pinned_port_buffers"]
+    out = {"metric": "Msamples/s complex_float32 255-tap FIR, host buffers in and out (PCIe inside the timed region)",
+           "value": head["Msamples_per_s"], "unit": "Msamples/s", "ms_per_step": head["ms_per_call"],
+           "config": {"workload": "/comms/fir_filter work() on host port buffers, 255 complex taps, complex_float32, %d samples per call "
+                                  "(what the block's 8 MiB port slabs carry); every call returns with its result in the output buffer" % (1 << 20),
+                      "samples_per_call": 1 << 20, "call_loop": "native (pcxb_work_loop)"},
+           "roofline": {"bound": "pcie", "achieved": head["GB_per_s_each_way"], "peak": round(roof, 2), "unit": "GB/s", "frac": head["frac_of_pcie_roof"],
+                        "traffic": None,
+                        "peak_measured": {"h2d_alone": round(up.value, 2), "d2h_alone": round(down.value, 2), "h2d_and_d2h_at_once_per_direction": round(roof, 2),
+                                          "how": "pcx_pcie_probe in this run: copy engines, 128 MiB of page-locked memory each way, two streams, best of 3"},
+                        "bytes_counted": "8 B per sample in and 8 B out over the wall time of a call; achieved = GB/s in EACH direction, peak = the box's "
+                                         "per-direction rate with both directions busy",
+                        "note": "the kernel reads and writes the host buffers in place over PCIe (zero-copy both ways); a copy-engine pipeline was measured "
+                                "and is slower below ~100 MiB per call (profiles/r05/pcie_lab.txt, drain_ab.txt)"},
+           "calls": calls}
+    if cpu:
+        out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
+        if "all_cores" in cpu:
+            out["cpu_baseline"]["all_cores"] = cpu["all_cores"]
+    return out
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -1260,7 +1403,14 @@ def main():
         if world == 1 and wl == "fir255" and not args.no_secondary and not rehearsal:
             # BASELINE.json configs[2] and configs[4], measured by the same command so that the driver's own run covers them
             del W, step
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            _hb("secondary workloads")
             out["secondary"] = {"fft4096": measure_secondary("fft4096", dev, args), "fmchain": measure_secondary("fmchain", dev, args)}
+            # ... configs[3] rehearsed on this one device through the native driver, and the end-to-end number of SURVEY 8d (PCIe inside)
+            out["secondary"]["c3_one_device"] = measure_c3_one_device(args, avg_ms)
+            out["secondary"]["host_path"] = measure_host_path(args, out.get("cpu_baseline"))
         result_line = json.dumps(out)
         if world > 1:
             # a supervised rank: the line goes out BEFORE the process group is torn down -- the measurement is complete (timed region,

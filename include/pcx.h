@@ -165,6 +165,11 @@ PCX_API int pcx_host_register_mapping(const void *p, size_t bytes, size_t max_by
 /* synthetic stream generator on the device: the same splitmix64 counter hash as
  * the oracle's orc_fill_uniform_f32 (uniform [-1,1), bit-identical values) */
 PCX_API int pcx_fill_uniform_f32_dev(float *dst_dev, size_t n_scalars, uint64_t seed, uint64_t offset, void *stream);
+/* measurement aid (no reference counterpart): the PCIe roof of this box as the copy engines see it.  `bytes` of page-locked host
+ * memory each way, `reps` times (best taken): host -> device alone, device -> host alone, and BOTH at once on two streams of the
+ * probe's own -- GB/s per direction.  bench.py prices the host-pointer path (secondary.host_path, bound "pcie") on *both_gbs,
+ * measured in the same run.  Allocates and frees 2 x bytes of host and of device memory; blocks until done. */
+PCX_API int pcx_pcie_probe(size_t bytes, int reps, double *h2d_gbs, double *d2h_gbs, double *both_gbs);
 /* measurement aid (no reference counterpart): ONE wave on `stream` spins for spin_us microseconds and writes the shader clock it
  * ran at, in MHz, to *mhz_dev (shader cycles from s_memtime over the 100 MHz s_memrealtime).  Queued on a stream of its own beside
  * a running workload it reads the clock the workload is held at by the package power cap -- bench.py uses it to turn the profiled

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pcx_trace": (_i, [_i]),
     "pcx_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "pcx_host_free": (_i, [_vp]),
+    "pcx_pcie_probe": (_i, [_sz, _i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]),
     "pcx_host_register": (_i, [_vp, _sz]),
     "pcx_host_unregister": (_i, [_vp]),
     "pcx_host_register_mapping": (_i, [_vp, _sz, _sz, C.POINTER(_vp), _psz]),

@@ -2,6 +2,7 @@
 // Host-side only: handle bookkeeping, coefficient tables, algorithm choice, staging
 // of host buffers.  All arithmetic on stream data happens in the HIP kernels.
 #include <algorithm>
+#include <chrono>
 #include <complex>
 #include <cstdio>
 #include <map>
@@ -423,6 +424,43 @@ int pcx_memcpy_to_host(void *dst_host, const void *src, size_t bytes)
     return PCX_OK;
 }
 int pcx_stream_sync(void *st) { PCX_HIP(hipStreamSynchronize(as_stream(st))); return PCX_OK; }
+int pcx_pcie_probe(size_t bytes, int reps, double *h2d_gbs, double *d2h_gbs, double *both_gbs)
+{
+    PCX_CHECK_ARG(bytes >= 4096 && reps >= 1 && h2d_gbs && d2h_gbs && both_gbs, "pcx_pcie_probe: bad argument");
+    void *hin = nullptr, *hout = nullptr, *din = nullptr, *dout = nullptr;
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    int rc = PCX_OK;
+    auto fail = [&](hipError_t e) { if (e != hipSuccess && rc == PCX_OK) { set_error("pcx_pcie_probe: %s", hipGetErrorString(e)); rc = PCX_ERR_HIP; } return e != hipSuccess; };
+    if (!fail(hipHostMalloc(&hin, bytes, hipHostMallocDefault)) && !fail(hipHostMalloc(&hout, bytes, hipHostMallocDefault)) &&
+        !fail(hipMalloc(&din, bytes)) && !fail(hipMalloc(&dout, bytes)) && !fail(hipMemset(dout, 0, bytes)) &&
+        !fail(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)) && !fail(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking))) {
+        std::memset(hin, 1, bytes);
+        std::memset(hout, 0, bytes);
+        auto timed = [&](bool up, bool down) -> double {
+            double best = 0.0;
+            for (int r = 0; r <= reps && rc == PCX_OK; r++) {       // (the first round is the warm-up)
+                const auto t0 = std::chrono::steady_clock::now();
+                if (up) fail(hipMemcpyAsync(din, hin, bytes, hipMemcpyHostToDevice, s0));
+                if (down) fail(hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, s1));
+                fail(hipStreamSynchronize(s0));
+                fail(hipStreamSynchronize(s1));
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (r > 0 && (best == 0.0 || dt < best)) best = dt;
+            }
+            return best > 0.0 ? (double)bytes / best / 1e9 : 0.0;
+        };
+        *h2d_gbs = timed(true, false);
+        *d2h_gbs = timed(false, true);
+        *both_gbs = timed(true, true);
+    }
+    if (s0) (void)hipStreamDestroy(s0);
+    if (s1) (void)hipStreamDestroy(s1);
+    if (din) (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    if (hin) (void)hipHostFree(hin);
+    if (hout) (void)hipHostFree(hout);
+    return rc;
+}
 int pcx_fill_uniform_f32_dev(float *dst, size_t n, uint64_t seed, uint64_t offset, void *st)
 {
     return launch_fill_uniform_f32(dst, n, seed, offset, as_stream(st));

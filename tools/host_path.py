@@ -41,24 +41,15 @@ def best_of(fn, reps, rounds=3):
 
 
 def pcie_roof(nbytes=128 << 20):
-    """GB/s per direction with both directions busy: copy engines, two streams"""
-    import torch
-    hin, hout = torch.empty(nbytes, dtype=torch.uint8).pin_memory(), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    din, dout = torch.empty(nbytes, dtype=torch.uint8, device="cuda"), torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
-    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
-
-    def both():
-        with torch.cuda.stream(s0):
-            din.copy_(hin, non_blocking=True)
-        with torch.cuda.stream(s1):
-            hout.copy_(dout, non_blocking=True)
-        torch.cuda.synchronize()
-    return nbytes / best_of(both, 5) / 1e9
+    """(H2D alone, D2H alone, both at once) GB/s per direction: the copy engines, two streams (pcx_pcie_probe)"""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    _lib.check(L.pcx_pcie_probe(nbytes, 5, C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 if __name__ == "__main__":
-    roof = pcie_roof()
-    print("PCIe roof of this box, H2D || D2H of 128 MiB each on two streams: %.1f GB/s per direction" % roof)
+    up, down, roof = pcie_roof()
+    print("PCIe roof of this box (copy engines, 128 MiB): H2D alone %.1f GB/s, D2H alone %.1f, H2D || D2H on two streams %.1f per direction" % (up, down, roof))
     rng = np.random.default_rng(0)
     print("-- 1. C ABI, pcx_fir_process")
     for n in (1 << 18, 1 << 20, 1 << 22, 1 << 24):

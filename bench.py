@@ -970,7 +970,12 @@ def measure_host_path(args, cpu):
     L = _lib.load()
     up, down, both = Cc.c_double(), Cc.c_double(), Cc.c_double()
     _lib.check(L.pcx_pcie_probe(128 << 20, 3, Cc.byref(up), Cc.byref(down), Cc.byref(both)))
-    roof = both.value
+    # The roof of a direction is what the link carries in that direction ALONE (PCIe is full duplex: the physical ceiling of each
+    # direction does not depend on the other being busy).  What the copy engines reach with BOTH directions busy is reported beside
+    # it: in a process on torch's bundled HIP runtime that is half of the sum (28 GB/s: the two transfers run one after the other),
+    # in a plain C process on the system runtime 48 (examples/c_pcie_probe.c, profiles/r05/pcie_lab.txt) -- the in-place kernel,
+    # which drives both directions at once itself, is above the first and below the second.
+    roof = min(up.value, down.value)
     K = 255
     calls = {}
     for n in (1 << 20, 1 << 24):
@@ -1011,10 +1016,12 @@ def measure_host_path(args, cpu):
                       "samples_per_call": 1 << 20, "call_loop": "native (pcxb_work_loop)"},
            "roofline": {"bound": "pcie", "achieved": head["GB_per_s_each_way"], "peak": round(roof, 2), "unit": "GB/s", "frac": head["frac_of_pcie_roof"],
                         "traffic": None,
-                        "peak_measured": {"h2d_alone": round(up.value, 2), "d2h_alone": round(down.value, 2), "h2d_and_d2h_at_once_per_direction": round(roof, 2),
-                                          "how": "pcx_pcie_probe in this run: copy engines, 128 MiB of page-locked memory each way, two streams, best of 3"},
-                        "bytes_counted": "8 B per sample in and 8 B out over the wall time of a call; achieved = GB/s in EACH direction, peak = the box's "
-                                         "per-direction rate with both directions busy",
+                        "peak_measured": {"h2d_alone": round(up.value, 2), "d2h_alone": round(down.value, 2),
+                                          "h2d_and_d2h_at_once_per_direction": round(both.value, 2),
+                                          "how": "pcx_pcie_probe in this run: copy engines, 128 MiB of page-locked memory each way, two streams, "
+                                                 "3 transfers back to back behind a warm-up one"},
+                        "bytes_counted": "8 B per sample in and 8 B out over the wall time of a call; achieved = GB/s in EACH direction (both are busy "
+                                         "at once); peak = the slower direction of the link measured ALONE (full duplex: each direction's ceiling)",
                         "note": "the kernel reads and writes the host buffers in place over PCIe (zero-copy both ways); a copy-engine pipeline was measured "
                                 "and is slower below ~100 MiB per call (profiles/r05/pcie_lab.txt, drain_ab.txt)"},
            "calls": calls}

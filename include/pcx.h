@@ -166,8 +166,8 @@ PCX_API int pcx_host_register_mapping(const void *p, size_t bytes, size_t max_by
  * the oracle's orc_fill_uniform_f32 (uniform [-1,1), bit-identical values) */
 PCX_API int pcx_fill_uniform_f32_dev(float *dst_dev, size_t n_scalars, uint64_t seed, uint64_t offset, void *stream);
 /* measurement aid (no reference counterpart): the PCIe roof of this box as the copy engines see it.  `bytes` of page-locked host
- * memory each way, `reps` times (best taken): host -> device alone, device -> host alone, and BOTH at once on two streams of the
- * probe's own -- GB/s per direction.  bench.py prices the host-pointer path (secondary.host_path, bound "pcie") on *both_gbs,
+ * memory each way, `reps` transfers queued back to back behind a warm-up one: host -> device alone, device -> host alone, and BOTH at
+ * once on two streams of the probe's own -- GB/s per direction.  bench.py prices the host-pointer path (secondary.host_path, bound "pcie") on *both_gbs,
  * measured in the same run.  Allocates and frees 2 x bytes of host and of device memory; blocks until done. */
 PCX_API int pcx_pcie_probe(size_t bytes, int reps, double *h2d_gbs, double *d2h_gbs, double *both_gbs);
 /* measurement aid (no reference counterpart): ONE wave on `stream` spins for spin_us microseconds and writes the shader clock it
@@ -423,6 +423,13 @@ PCX_API int pcx_shard_step(pcx_shard *s);
  * on a handle whose exchange is posted are PCX_ERR_STATE (the setters would change, or free, what the posted pass is about to use). */
 PCX_API int pcx_shard_post_exchange(pcx_shard *s);
 PCX_API int pcx_shard_compute(pcx_shard *s);
+/* enable != 0: one SUBMIT THREAD per shard.  Queueing a pass costs the host 16-20 us per shard from one thread (the cross-stream waits,
+ * the records, the gate signal, the launch): 135-165 us for eight shards against a pass of 195 us at 64 Mi samples per shard.  With
+ * submit threads every shard's share of a pass is queued by a thread of its own, bound to its shard's device; pcx_shard_step /
+ * post_exchange / compute still return when everything is queued, and everything the header says about ordering holds unchanged.  The
+ * threads spin for ~0.4 ms behind a pass (a stream of passes finds them awake) and sleep after that; they are joined by
+ * pcx_shard_destroy or by enable = 0.  Off by default.  PCX_ERR_STATE while an exchange is posted. */
+PCX_API int pcx_shard_set_submit_threads(pcx_shard *s, int enable);
 /* enable = 0: every shard as TWO launches per pass -- the body while the halo is in flight, the head behind an event on the halo
  * stream -- instead of one gated launch (the default, enable = 1).  The gated launch relies on the halo transfer and its signal,
  * which pcx_shard_step queues BEFORE the launch, reaching the device before it: that is how the runtime submits (in order, from the

@@ -139,6 +139,7 @@ SIGNATURES = {
     "pcx_shard_destroy": (_i, [_vp]),
     "pcx_shard_set_taps": (_i, [_vp, C.POINTER(C.c_double), _sz, _i]),
     "pcx_shard_set_gated": (_i, [_vp, _i]),
+    "pcx_shard_set_submit_threads": (_i, [_vp, _i]),
     "pcx_shard_set_algo": (_i, [_vp, _i]),
     "pcx_shard_set_chain": (_i, [_vp, _i, _d]),
     "pcx_shard_configure": (_i, [_vp, _sz]),

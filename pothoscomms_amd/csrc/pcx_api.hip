@@ -436,18 +436,22 @@ int pcx_pcie_probe(size_t bytes, int reps, double *h2d_gbs, double *d2h_gbs, dou
         !fail(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)) && !fail(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking))) {
         std::memset(hin, 1, bytes);
         std::memset(hout, 0, bytes);
+        // `reps` transfers per direction queued back to back, one synchronisation behind them (the steady state of a stream of calls;
+        // tools/pcie_lab.hip times the same way); a warm-up transfer first
         auto timed = [&](bool up, bool down) -> double {
-            double best = 0.0;
-            for (int r = 0; r <= reps && rc == PCX_OK; r++) {       // (the first round is the warm-up)
+            double dt = 0.0;
+            for (int round = 0; round < 2 && rc == PCX_OK; round++) {
+                const int n = round == 0 ? 1 : reps;
                 const auto t0 = std::chrono::steady_clock::now();
-                if (up) fail(hipMemcpyAsync(din, hin, bytes, hipMemcpyHostToDevice, s0));
-                if (down) fail(hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, s1));
+                for (int r = 0; r < n; r++) {
+                    if (up) fail(hipMemcpyAsync(din, hin, bytes, hipMemcpyHostToDevice, s0));
+                    if (down) fail(hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, s1));
+                }
                 fail(hipStreamSynchronize(s0));
                 fail(hipStreamSynchronize(s1));
-                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                if (r > 0 && (best == 0.0 || dt < best)) best = dt;
+                dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n;
             }
-            return best > 0.0 ? (double)bytes / best / 1e9 : 0.0;
+            return dt > 0.0 ? (double)bytes / dt / 1e9 : 0.0;
         };
         *h2d_gbs = timed(true, false);
         *d2h_gbs = timed(false, true);

@@ -38,8 +38,14 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "pcx_internal.hpp"
@@ -111,7 +117,100 @@ struct DeviceGuard {
 
 using namespace pcx;
 
+// (diagnostic library, PCX_SHARD_TIMING=1) host time per phase of a pass, printed when a handle is destroyed: tools/shard_probe.py
+#ifdef PCX_DIAG
+namespace {
+struct PhaseClock {
+    static constexpr int kPhases = 8;
+    double acc[kPhases] = {};
+    unsigned long long passes = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { t = std::chrono::steady_clock::now(); }
+    void lap(int ph) { const auto n = std::chrono::steady_clock::now(); acc[ph] += std::chrono::duration<double>(n - t).count(); t = n; }
+};
+PhaseClock g_phase;
+}
+#define PCX_PHASE_START() do { if (PCX_ENV_SET("PCX_SHARD_TIMING")) g_phase.start(); } while (0)
+#define PCX_PHASE_LAP(ph) do { if (PCX_ENV_SET("PCX_SHARD_TIMING")) g_phase.lap(ph); } while (0)
+#else
+#define PCX_PHASE_START() do { } while (0)
+#define PCX_PHASE_LAP(ph) do { } while (0)
+#endif
+
+// ---- submit threads ---------------------------------------------------------------------------------------------------------------
+// Queueing a pass costs the host 16-20 us PER SHARD from one thread (3-4 us per cross-stream wait, 7 per gated launch, the records, the
+// signal kernel: PCX_SHARD_TIMING in the diagnostic library itemises it) -- 135-165 us for eight shards against a pass of 195 us.
+// With submit threads every shard's share of a pass is queued by a thread of its own (each bound to its shard's device once), the
+// caller's thread posts the parts of the pass in turn and waits for each to be queued: what the host pays is the longest shard plus a
+// hand-over per part.  The threads spin for a while behind a part (a stream of passes finds them awake) and sleep after that.
+struct pcx_shard;
+static int shard_part(pcx_shard *s, int g, int part);
+struct ShardWorkers {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<unsigned> gen{0};
+    std::atomic<int> pending{0}, sleepers{0};
+    std::atomic<bool> stop{false};
+    int part = 0;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+    static constexpr int kSpinUs = 400;      // how long a thread stays awake behind its last part (two passes of a 64 Mi-sample stream)
+
+    void start(pcx_shard *s, int G, const std::vector<int> &dev)
+    {
+        rc.assign(G, 0);
+        err.assign(G, std::string());
+        for (int g = 0; g < G; g++) th.emplace_back([this, s, g, d = dev[g]] { run(s, g, d); });
+    }
+    void run(pcx_shard *s, int g, int device)
+    {
+        (void)hipSetDevice(device);
+        unsigned seen = 0;
+        for (;;) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_acquire)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) {
+                    std::unique_lock<std::mutex> lk(m);
+                    sleepers.fetch_add(1);
+                    cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen || stop.load(std::memory_order_acquire); });
+                    sleepers.fetch_sub(1);
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            if (stop.load(std::memory_order_acquire)) return;
+            seen = gen.load(std::memory_order_acquire);
+            rc[g] = PCX_OK;
+            for (int q = part & 0xff; q <= (part >> 8) && rc[g] == PCX_OK; q++) rc[g] = shard_part(s, g, q);    // parts [first, last] of this shard
+            if (rc[g] != PCX_OK) err[g] = pcx_last_error();
+            pending.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    // every shard's parts first .. last, each shard on its own thread; returns when all of it is queued
+    int all(int first, int last)
+    {
+        part = first | (last << 8);
+        pending.store((int)th.size(), std::memory_order_release);
+        gen.fetch_add(1, std::memory_order_acq_rel);
+        if (sleepers.load() > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
+        while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        for (size_t g = 0; g < rc.size(); g++)
+            if (rc[g] != PCX_OK) { set_error("%s", err[g].c_str()); return rc[g]; }
+        return PCX_OK;
+    }
+    ~ShardWorkers()
+    {
+        stop.store(true, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
+        for (auto &t : th) if (t.joinable()) t.join();
+    }
+};
+
 struct pcx_shard {
+    std::unique_ptr<ShardWorkers> workers;        // pcx_shard_set_submit_threads: one thread per shard queues that shard's share of a pass
+    bool tables_ready = false;                    // every shard's tables are on its device (reset by whatever changes them)
+    unsigned cur_pass = 0;                        // the pass number the parts of the pass in flight use
     int G = 0;
     int transport = PCX_SHARD_RCCL;
     std::vector<int> dev;
@@ -173,7 +272,18 @@ static void shard_free_buffers(pcx_shard *s)
 
 int pcx_shard_destroy(pcx_shard *s)
 {
+#ifdef PCX_DIAG
+    if (PCX_ENV_SET("PCX_SHARD_TIMING") && g_phase.passes) {
+        static const char *const names[] = {"tables", "in_ready records", "halo-stream waits", "exchange (copies / RCCL group)", "gate signals + halo_ready records",
+                                            "launches", "compute-stream waits"};
+        fprintf(stderr, "pcx(diag): host time per pass over %llu passes:", g_phase.passes);
+        for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.1f us;", names[i], g_phase.acc[i] / g_phase.passes * 1e6);
+        fprintf(stderr, "\n");
+        g_phase = PhaseClock();
+    }
+#endif
     if (!s) return PCX_OK;
+    s->workers.reset();             // (the submit threads first: they hold the handle)
     DeviceGuard guard;
     for (int g = 0; g < s->G; g++) {
         (void)hipSetDevice(s->dev[g]);
@@ -313,6 +423,7 @@ int pcx_shard_set_taps(pcx_shard *s, const double *taps, size_t ntaps, int compl
     s->complex_taps = complex_taps ? 1 : 0;
     s->K = ntaps;
     PCX_TRY(shard_apply_taps(s));
+    s->tables_ready = false;
     s->have_taps = true;
     if (s->C && ntaps != Kold) {   // the halo slot in front of every shard changes size: the buffers must be laid out again
         DeviceGuard guard;
@@ -336,8 +447,26 @@ int pcx_shard_set_chain(pcx_shard *s, int enable, double phase)
     }
     s->chain_mode = enable != 0;
     s->phase = phase;
+    s->tables_ready = false;
     if (s->have_taps) PCX_TRY(shard_apply_taps(s));
     if (s->C && was != s->chain_mode) shard_free_buffers(s);   // another halo, another output type: lay the buffers out again
+    return PCX_OK;
+}
+
+int pcx_shard_set_submit_threads(pcx_shard *s, int enable)
+{
+    PCX_CHECK_ARG(s, "null handle");
+    PCX_CHECK_STATE(!s->posted, "pcx_shard_set_submit_threads: this handle's exchange is posted; pcx_shard_compute comes first");
+    if (!enable) { s->workers.reset(); return PCX_OK; }
+    if (s->workers || s->G < 2) return PCX_OK;
+    try {
+        s->workers.reset(new ShardWorkers());
+        s->workers->start(s, s->G, s->dev);
+    } catch (const std::exception &e) {
+        s->workers.reset();
+        set_error("pcx_shard_set_submit_threads: %s", e.what());
+        return PCX_ERR_STATE;
+    }
     return PCX_OK;
 }
 
@@ -352,6 +481,7 @@ int pcx_shard_set_algo(pcx_shard *s, int algo)
 {
     PCX_CHECK_ARG(s, "null handle");
     PCX_CHECK_STATE(!s->posted, "pcx_shard_set_algo: this handle's exchange is posted; pcx_shard_compute comes first");
+    s->tables_ready = false;
     for (int g = 0; g < s->G; g++) {
         PCX_TRY(pcx_fir_set_algo(s->fir[g], algo));
         if (s->chain[g] && (algo == PCX_FIR_AUTO || algo == PCX_FIR_DIRECT || algo == PCX_FIR_OLS_FFT)) PCX_TRY(pcx_fmchain_set_algo(s->chain[g], algo));
@@ -370,6 +500,7 @@ int pcx_shard_configure(pcx_shard *s, size_t shard_elems)
                   shard_elems, halo);
     DeviceGuard guard;
     shard_free_buffers(s);
+    s->tables_ready = false;
     // [lead | halo | shard (C)], placed so that every 2 KiB row the overlap-save kernels load and every row they store starts on a
     // 128-byte line (measured 0.2245 -> 0.2187 ms per 64 Mi samples against a line-aligned halo).  FIR: the kernel rounds its block
     // overlap K-1 up to 16 samples and starts its windows `pad` samples before the history, so the history goes pad samples behind
@@ -603,6 +734,95 @@ static int shard_run_chain(pcx_shard *s, int g, const void *gate, unsigned value
     return PCX_OK;
 }
 
+// ---- a pass, shard by shard ------------------------------------------------------------------------------------------------
+// What shard g contributes to each part of a pass.  The parts are separated where one shard's calls depend on an event ANOTHER shard's
+// thread records (hipStreamWaitEvent takes the event as it stands when the call is made): every shard's part p is queued before any
+// shard's part p + 1.  One thread walks the shards part by part; with submit threads (pcx_shard_set_submit_threads) every shard's part is
+// queued by its own thread, all at once.
+enum ShardPart {
+    kPartTables,      // this shard's tables on its device (nothing of the pass is queued yet: the rule of pcx_shard_scatter)
+    kPartInReady,     // 1. inputs in place: everything queued on the compute stream so far (the caller's fill / scatter, and the previous
+                      //    pass's kernel, which READ the halo slot this pass overwrites)
+    kPartHaloWaits,   // 2a. the halo stream behind that -- and, peer copies, behind the SOURCE shard's inputs as well
+    kPartPeerCopy,    // 2b. peer copies: tail of shard g-1 -> halo slot of shard g, in place  [RCCL: one group call from the caller's thread]
+    kPartSignal,      // 2c. behind the exchange: the gate word, the halo_ready event
+    kPartLaunch,      // 3. the shard in ONE launch, its first block behind the gate (shard 0: a plain launch)
+    kPartFence,       // 4. later writers on the compute stream wait for the exchange that reads this shard's tail
+};
+static int shard_part(pcx_shard *s, int g, int part)
+{
+    const int G = s->G;
+    const size_t halo = s->halo(), hbytes = halo * sizeof(float2);
+    const bool rccl = s->transport == PCX_SHARD_RCCL;
+    const unsigned pass = s->cur_pass;
+    PCX_HIP(hipSetDevice(s->dev[g]));
+    switch (part) {
+    case kPartTables:
+        if (s->chain_mode) PCX_TRY(fmchain_prepare(s->chain[g]));
+        else PCX_TRY(fir_prepare(s->fir[g]));
+        return PCX_OK;
+    case kPartInReady:
+        PCX_HIP(hipEventRecord(s->in_ready[g], s->st[g]));
+        return PCX_OK;
+    case kPartHaloWaits:
+        PCX_HIP(hipStreamWaitEvent(s->hst[g], s->in_ready[g], 0));
+        if (!rccl && g > 0) PCX_HIP(hipStreamWaitEvent(s->hst[g], s->in_ready[g - 1], 0));   // the source shard's samples
+        return PCX_OK;
+    case kPartPeerCopy:
+        if (!rccl && g > 0) PCX_HIP(hipMemcpyPeerAsync(s->in_ptr(g), s->dev[g], s->in_ptr(g - 1) + s->C, s->dev[g - 1], hbytes, s->hst[g]));
+        return PCX_OK;
+    case kPartSignal: {
+        const long drop = PCX_ENV_INT("PCX_SHARD_DROP_SIGNAL", 0);   // (diagnostic library only) the pass whose gate signals are left out: the timeout path's test
+        if (g > 0 && !(drop > 0 && (long)pass == drop)) PCX_TRY(pcx_gate_signal_dev(s->gate[g], pass, s->hst[g]));
+        // halo_ready(g): RCCL -- the send that reads shard g's tail and the receive into its halo slot are done;
+        // peer copies -- the copy that reads shard g-1's tail and writes shard g's halo slot is done
+        if (g > 0 || rccl) PCX_HIP(hipEventRecord(s->halo_ready[g], s->hst[g]));
+        return PCX_OK;
+    }
+    case kPartLaunch: {
+        auto whole = [&]() -> int {   // the whole shard in one plain call
+            return s->chain_mode ? shard_run_chain(s, g, nullptr, 0, nullptr) : shard_run_fir(s, g, 0, s->C, nullptr, 0, nullptr);
+        };
+        if (g == 0 || G == 1 || halo == 0) return whole();
+        int gated = 0;
+        if (s->use_gate) {
+            if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, s->gate[g], pass, &gated));
+            else PCX_TRY(shard_run_fir(s, g, 0, s->C, s->gate[g], pass, &gated));
+        }
+        if (gated) return PCX_OK;
+        // no gated kernel for this configuration: the round-2 scheme.  FIR: the body while the halo is in flight, then the head
+        // behind it; chain (long filters, short shards): the halo first, then the shard
+        if (!s->chain_mode && s->C > s->head) PCX_TRY(shard_run_fir(s, g, s->head, s->C - s->head, nullptr, 0, nullptr));
+        PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[g], 0));
+        if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, nullptr, 0, nullptr));
+        else PCX_TRY(shard_run_fir(s, g, 0, s->head, nullptr, 0, nullptr));
+        return PCX_OK;
+    }
+    case kPartFence:
+        // whatever is queued on a compute stream after this step -- the caller's next fill, the next scatter -- must not overwrite
+        // the tail of its shard while the exchange is still reading it
+        if (g + 1 < G) PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[rccl ? g : g + 1], 0));
+        return PCX_OK;
+    }
+    return PCX_OK;
+}
+// Parts [first, last] of every shard.  The caller names ranges whose parts have no dependency ACROSS shards between them (a shard's
+// calls inside the range only concern events its own thread records, or events of an EARLIER range), so with submit threads a range
+// goes out as ONE hand-over; one thread queues it part by part, shard by shard.
+static int shard_parts(pcx_shard *s, int first, int last)
+{
+    if (s->workers) {
+        PCX_TRY(s->workers->all(first, last));
+        PCX_PHASE_LAP(last);
+        return PCX_OK;
+    }
+    for (int part = first; part <= last; part++) {
+        for (int g = 0; g < s->G; g++) PCX_TRY(shard_part(s, g, part));
+        PCX_PHASE_LAP(part);
+    }
+    return PCX_OK;
+}
+
 // pcx_shard_step in its two halves (include/pcx.h): the exchange of the halos of what the shard buffers hold NOW, and the pass over it.
 int pcx_shard_post_exchange(pcx_shard *s)
 {
@@ -613,13 +833,13 @@ int pcx_shard_post_exchange(pcx_shard *s)
     DeviceGuard guard;
     const int G = s->G;
     const size_t halo = s->halo(), hbytes = halo * sizeof(float2);
+    PCX_PHASE_START();
     // every shard's tables are on its device BEFORE anything of the pass is queued: uploading them lazily -- allocations and
     // transfers of the control plane -- between other shards' queued work lost one shard's pass (AMD_DIRECT_DISPATCH=0,
     // tests/test_shard_gpu.py retap test; the rule of pcx_shard_scatter)
-    for (int g = 0; g < G; g++) {
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        if (s->chain_mode) PCX_TRY(fmchain_prepare(s->chain[g]));
-        else PCX_TRY(fir_prepare(s->fir[g]));
+    if (!s->tables_ready) {
+        PCX_TRY(shard_parts(s, kPartTables, kPartTables));
+        s->tables_ready = true;
     }
     if (G == 1 || halo == 0) {      // nothing to exchange
         s->posted = true;
@@ -627,39 +847,20 @@ int pcx_shard_post_exchange(pcx_shard *s)
     }
     // the value the gate words take in this pass (compared by signed distance).  Taken BEFORE anything is queued: a step that fails
     // half-way has used its number up -- the next one must not find its gate already open
-    const unsigned pass = (unsigned)++s->steps;
-    // 1. inputs of this pass are in place once everything queued on the compute streams so far has run (the caller's
-    //    fill / scatter, and the previous pass's kernel, which READ the halo slot this pass overwrites)
-    for (int g = 0; g < G; g++) {
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_HIP(hipEventRecord(s->in_ready[g], s->st[g]));
-    }
-    // 2. the exchange, on the halo streams: tail of shard g -> halo slot of shard g+1, in place; behind it the gate word
-    for (int g = 0; g < G; g++) {
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_HIP(hipStreamWaitEvent(s->hst[g], s->in_ready[g], 0));
-        if (s->transport == PCX_SHARD_PEER_COPY && g > 0) PCX_HIP(hipStreamWaitEvent(s->hst[g], s->in_ready[g - 1], 0));   // the source shard's samples
-    }
+    s->cur_pass = (unsigned)++s->steps;
     if (s->transport == PCX_SHARD_RCCL) {
+        PCX_TRY(shard_parts(s, kPartInReady, kPartHaloWaits));
         PCX_RCCL(s->rccl, s->rccl->GroupStart());
         for (int g = 0; g < G; g++) {
             if (g + 1 < G) PCX_RCCL(s->rccl, s->rccl->Send(s->in_ptr(g) + s->C, hbytes, ncclChar, g + 1, s->comm[g], s->hst[g]));   // the last `halo` samples
             if (g > 0) PCX_RCCL(s->rccl, s->rccl->Recv(s->in_ptr(g), hbytes, ncclChar, g - 1, s->comm[g], s->hst[g]));
         }
         PCX_RCCL(s->rccl, s->rccl->GroupEnd());
+        PCX_PHASE_LAP(kPartPeerCopy);
+        PCX_TRY(shard_parts(s, kPartSignal, kPartSignal));
     } else {
-        for (int g = 1; g < G; g++) {
-            PCX_HIP(hipSetDevice(s->dev[g]));
-            PCX_HIP(hipMemcpyPeerAsync(s->in_ptr(g), s->dev[g], s->in_ptr(g - 1) + s->C, s->dev[g - 1], hbytes, s->hst[g]));
-        }
-    }
-    const long drop = PCX_ENV_INT("PCX_SHARD_DROP_SIGNAL", 0);   // (diagnostic library only) the pass whose gate signals are left out: the timeout path's test
-    for (int g = 0; g < G; g++) {
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        if (g > 0 && !(drop > 0 && (long)pass == drop)) PCX_TRY(pcx_gate_signal_dev(s->gate[g], pass, s->hst[g]));
-        // halo_ready(g): RCCL -- the send that reads shard g's tail and the receive into its halo slot are done;
-        // peer copies -- the copy that reads shard g-1's tail and writes shard g's halo slot is done
-        if (g > 0 || s->transport == PCX_SHARD_RCCL) PCX_HIP(hipEventRecord(s->halo_ready[g], s->hst[g]));
+        PCX_TRY(shard_parts(s, kPartInReady, kPartInReady));      // (the copy into shard g waits for shard g-1's inputs: a range of its own)
+        PCX_TRY(shard_parts(s, kPartHaloWaits, kPartSignal));
     }
     // The FIRST exchange of a handle is waited for on the host before any launch is queued that depends on it: RCCL sets its
     // point-to-point connections up lazily, inside the first send / receive, and that can take longer than the two seconds a gated
@@ -683,44 +884,17 @@ int pcx_shard_compute(pcx_shard *s)
     s->posted = false;              // whatever happens below, this pass's exchange is used up
     PCX_CHECK_ARG(s->C, "pcx_shard_compute: the shard buffers are not laid out (pcx_shard_configure first)");   // (never launch on null + lead)
     DeviceGuard guard;
-    const int G = s->G;
-    const size_t halo = s->halo();
-    auto whole = [&](int g) -> int {   // the whole shard in one plain call
-        return s->chain_mode ? shard_run_chain(s, g, nullptr, 0, nullptr) : shard_run_fir(s, g, 0, s->C, nullptr, 0, nullptr);
-    };
-    if (G == 1 || halo == 0) {
+    PCX_PHASE_START();
+    if (s->G == 1 || s->halo() == 0) {
         // nothing was exchanged: each shard is one plain call (with one device, exactly pcx_fir_process_dev on the whole stream)
-        for (int g = 0; g < G; g++) {
-            PCX_HIP(hipSetDevice(s->dev[g]));
-            PCX_TRY(whole(g));
-        }
+        PCX_TRY(shard_parts(s, kPartLaunch, kPartLaunch));
         s->steps++;
         return PCX_OK;
     }
-    const unsigned pass = (unsigned)s->steps;       // the number pcx_shard_post_exchange gave the gates
-    // 3. every shard in ONE launch: shard 0 has no halo to wait for; the others hold their first block behind the gate
-    for (int g = 0; g < G; g++) {
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        if (g == 0) { PCX_TRY(whole(0)); continue; }
-        int gated = 0;
-        if (s->use_gate) {
-            if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, s->gate[g], pass, &gated));
-            else PCX_TRY(shard_run_fir(s, g, 0, s->C, s->gate[g], pass, &gated));
-        }
-        if (gated) continue;
-        // no gated kernel for this configuration: the round-2 scheme.  FIR: the body while the halo is in flight, then the head
-        // behind it; chain (long filters, short shards): the halo first, then the shard
-        if (!s->chain_mode && s->C > s->head) PCX_TRY(shard_run_fir(s, g, s->head, s->C - s->head, nullptr, 0, nullptr));
-        PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[g], 0));
-        if (s->chain_mode) PCX_TRY(shard_run_chain(s, g, nullptr, 0, nullptr));
-        else PCX_TRY(shard_run_fir(s, g, 0, s->head, nullptr, 0, nullptr));
-    }
-    // 4. whatever is queued on a compute stream after this step -- the caller's next fill, the next scatter -- must not overwrite
-    //    the tail of its shard while the exchange is still reading it
-    for (int g = 0; g + 1 < G; g++) {
-        PCX_HIP(hipSetDevice(s->dev[g]));
-        PCX_HIP(hipStreamWaitEvent(s->st[g], s->halo_ready[s->transport == PCX_SHARD_RCCL ? g : g + 1], 0));
-    }
+    PCX_TRY(shard_parts(s, kPartLaunch, kPartFence));
+#ifdef PCX_DIAG
+    g_phase.passes++;
+#endif
     return PCX_OK;
 }
 

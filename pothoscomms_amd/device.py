@@ -480,6 +480,10 @@ class NodeStream(_Handle):
         """pcx_shard_set_gated: False = two launches per shard and pass (body, halo event, head) instead of one gated launch"""
         _lib.check(_lib.load().pcx_shard_set_gated(self._h, int(bool(enable))))
 
+    def set_submit_threads(self, enable):
+        """pcx_shard_set_submit_threads: one thread per shard queues that shard's share of a pass"""
+        _lib.check(_lib.load().pcx_shard_set_submit_threads(self._h, int(bool(enable))))
+
     def set_chain(self, enable, phase=0.0):
         """pcx_shard_set_chain: the shards run Rotate(phase) -> FIR -> FreqDemod (float32 outputs, halo of K samples)."""
         _lib.check(_lib.load().pcx_shard_set_chain(self._h, int(bool(enable)), float(phase)))

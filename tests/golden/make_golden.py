@@ -214,8 +214,14 @@ def main():
     # ---- 5. /comms/fir_filter (float types) = compiled std::complex multiply-accumulate in the loop's order (docstring, 4.) -----
     from pothoscomms_amd import taps as tp            # tap recipes only (numpy): SURVEY 8d's windowed-sinc sets
     rng5 = np.random.default_rng(20240505)
-    for key, taps, ctaps, dt, nout in (("c0_63c_f32", tp.c0_taps(), True, np.float32, 4096), ("c1_255c_f32", tp.c1_taps(), True, np.float32, 2048),
-                                       ("c4_127r_f32", tp.c4_taps(), False, np.float32, 2048), ("31c_f64", tp.c0_taps()[:31], True, np.float64, 1024)):
+    # Lengths: every float32 fixture runs across TWO seams of the frequency-domain kernel's overlap-save blocks (payload S = 4096 minus the
+    # overlap rounded up to 16: 4032 at 63 taps, 3840 at 255, 3968 at 127 real taps, 2048 at 2049 taps -- the smallest payload of the
+    # 4096-sample plan), so that tests/test_golden_gpu.py compares that kernel with reference-operator outputs ACROSS block boundaries,
+    # no oracle in between (Weak 1).
+    for key, taps, ctaps, dt, nout in (("c0_63c_f32", tp.c0_taps(), True, np.float32, 8192), ("c1_255c_f32", tp.c1_taps(), True, np.float32, 8192),
+                                       ("c4_127r_f32", tp.c4_taps(), False, np.float32, 8192),
+                                       ("2049c_f32", tp.complex_bandpass(2049, 0.02, 0.03), True, np.float32, 6144),
+                                       ("31c_f64", tp.c0_taps()[:31], True, np.float64, 1024)):
         K = len(taps)
         x = rng5.uniform(-1, 1, (K - 1 + nout, 2)).astype(dt)
         x[5] = [0.0, -0.0]

@@ -71,7 +71,9 @@ def _oracle_fir(o, taps, x, n, complex_taps=True):
     return ref
 
 
-def test_c3_fir_eight_shards_of_64Mi_on_one_device(oracle):
+@pytest.mark.parametrize("submit_threads", [False, True], ids=["one_thread", "submit_threads"])
+def test_c3_fir_eight_shards_of_64Mi_on_one_device(oracle, submit_threads):
+    """submit_threads: every shard's share of a pass queued by a thread of its own (pcx_shard_set_submit_threads) -- same seams, same bits"""
     import torch
 
     from pothoscomms_amd import _lib, device, taps as tp
@@ -80,6 +82,7 @@ def test_c3_fir_eight_shards_of_64Mi_on_one_device(oracle):
     K, Cs = len(h), SHARD
     assert K == 255
     ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+    ns.set_submit_threads(submit_threads)
     ns.set_taps(h)
     ns.configure(Cs)
     plain = device.FirFilter("complex_float32", "COMPLEX")

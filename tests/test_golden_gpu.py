@@ -109,7 +109,7 @@ def test_rotate_scale_against_the_compiled_operators(dev, name):
         assert np.array_equal(dev.scale(x, float(factor), True), GOLD["scale_out_%s_%d" % (name, k)]), factor
 
 
-@pytest.mark.parametrize("key,ctaps", [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("31c_f64", True)])
+@pytest.mark.parametrize("key,ctaps", [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("2049c_f32", True), ("31c_f64", True)])
 def test_fir_against_the_compiled_complex_multiply_accumulate(dev, key, ctaps):
     """filter/FIRFilter.cpp:294-300 as the compiled std::complex operator* / operator+= composed tap by tap in the loop's order
     (tests/golden/make_golden.py section 5; the tap sets of BASELINE configs[0], [1], [4]): the HIP path against that fixture directly --
@@ -127,6 +127,15 @@ def test_fir_against_the_compiled_complex_multiply_accumulate(dev, key, ctaps):
         f.set_algo(algo)
         got, c, p = f.process(x, n)
         assert (c, p) == (n, n) and nerr(got, want) <= bar, algo
+        if algo == dev._lib.FIR_AUTO and x.dtype == np.float32:
+            # the float32 fixtures are long enough to cross two block seams of the frequency-domain kernel (make_golden.py section 5):
+            # it IS that kernel that was just compared with the reference operators' outputs, and the seams are inside the comparison
+            assert f.last_algo == dev._lib.FIR_OLS_FFT
+            K = len(taps)
+            S = 4096 - (K - 1 + 15) // 16 * 16              # the block payload (fir_ols.hip launch_fir_cf32_ols4096)
+            assert n > 2 * S, (n, S)
+            for seam in (S, 2 * S):                          # and the samples either side of each seam, on their own (same absolute bar)
+                assert np.max(np.abs(got[seam - 64:seam + 64].astype(np.float64) - want[seam - 64:seam + 64])) <= bar * np.max(np.abs(want)), seam
 
 
 @pytest.mark.parametrize("name", TYPES)

@@ -301,7 +301,7 @@ def test_rotate_scale_against_the_compiled_operators(oracle, name):
         assert np.array_equal(oracle.scale(x, float(factor), True), GOLD["scale_out_%s_%d" % (name, k)]), factor
 
 
-FIR_FIXTURES = [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("31c_f64", True)]
+FIR_FIXTURES = [("c0_63c_f32", True), ("c1_255c_f32", True), ("c4_127r_f32", False), ("2049c_f32", True), ("31c_f64", True)]
 
 
 @pytest.mark.parametrize("key,ctaps", FIR_FIXTURES)

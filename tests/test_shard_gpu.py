@@ -638,3 +638,46 @@ def test_two_handles_double_buffered_the_next_batchs_halos_travel_beside_this_ba
     pair[1 if 5 & 1 else 0].compute()                          # the exchange still posted for batch 5: use it up
     for ns in pair:
         ns.sync()
+
+
+@pytest.mark.parametrize("chain", [False, True], ids=["fir", "chain"])
+@pytest.mark.parametrize("G,Cs", [(4, 9000), (3, 2080 * 3840), (8, 300000)])
+def test_submit_threads_queue_the_same_pass(oracle, G, Cs, chain):
+    """pcx_shard_set_submit_threads: a thread per shard queues that shard's share of every pass.  Several passes with the stream
+    scattered again in between (the threads' waits and records against the caller's own transfers), halos poisoned: the outputs are
+    bit for bit those of a handle driven from one thread, and shard 0's front matches the oracle."""
+    from pothoscomms_amd import _lib, device, taps as tp
+    h = tp.c4_taps() if chain else tp.c1_taps()
+    K = len(h)
+    outs = []
+    for threads in (False, True):
+        ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY)
+        if chain:
+            ns.set_chain(True, tp.C4_PHASE)
+        ns.set_taps(h, complex_taps=not chain)
+        ns.set_submit_threads(threads)
+        ns.configure(Cs)
+        got = []
+        for rep in range(4):
+            x = tp.fm_test_signal(K - 1 + G * Cs, seed=60 + rep) if chain else oracle.fill_uniform_f32(2 * (K - 1 + G * Cs), 70 + rep, 0).reshape(-1, 2)
+            ns.scatter(x)
+            if not chain:
+                _poison_halos(ns)
+            ns.step()
+            got.append(ns.gather().copy())
+        with pytest.raises(_lib.PcxError):                  # (a posted exchange: the switch is refused like the other setters)
+            ns.post_exchange()
+            ns.set_submit_threads(not threads)
+        ns.compute()
+        ns.sync()
+        ns.set_submit_threads(False)                        # joins the threads; the handle goes on working from the caller's thread
+        ns.step()
+        ns.sync()
+        ns.close()
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    if not chain:
+        x = oracle.fill_uniform_f32(2 * (K - 1 + G * Cs), 73, 0).reshape(-1, 2)
+        n = min(G * Cs, 30000)
+        assert nerr(outs[1][3][:n], _oracle_fir(oracle, h, x[:K - 1 + n], n)) <= TOL

@@ -37,6 +37,7 @@ int main()
     t("D2H 128 MiB pageable", [&] { CK(hipMemcpyAsync(pg, dout, bytes, hipMemcpyDeviceToHost, s0)); });
     t("H2D + D2H serial, one stream", [&] { CK(hipMemcpyAsync(din, hin, bytes, hipMemcpyHostToDevice, s0)); CK(hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, s0)); });
     t("H2D || D2H, two streams", [&] { CK(hipMemcpyAsync(din, hin, bytes, hipMemcpyHostToDevice, s0)); CK(hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, s1)); });
+    t("H2D || D2H, two streams, host waits for each pair", [&] { CK(hipMemcpyAsync(din, hin, bytes, hipMemcpyHostToDevice, s0)); CK(hipMemcpyAsync(hout, dout, bytes, hipMemcpyDeviceToHost, s1)); CK(hipStreamSynchronize(s0)); CK(hipStreamSynchronize(s1)); });
     for (size_t chunk : {1ull << 20, 4ull << 20, 16ull << 20, 32ull << 20}) {
         char nm[128];
         snprintf(nm, sizeof nm, "pipeline H2D->kernel->D2H, 3 streams, %zu MiB chunks", chunk >> 20);

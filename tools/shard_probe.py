@@ -19,6 +19,8 @@ total = int(os.environ.get("PCX_PROBE_TOTAL", 64 * 1024 * 1024))     # PCX_PROBE
 h = tp.c1_taps()
 for G in [int(a) for a in sys.argv[1:]]:
     ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY if G > 1 else device.NodeStream.RCCL)
+    threads = bool(os.environ.get("PCX_PROBE_THREADS"))     # pcx_shard_set_submit_threads: a thread per shard queues its share of a pass
+    ns.set_submit_threads(threads)
     ns.set_taps(h)
     ns.configure(total // G)
     for g in range(G):
@@ -37,5 +39,5 @@ for G in [int(a) for a in sys.argv[1:]]:
     ns.sync()
     dt = (time.perf_counter() - t0) / n
     print("G=%d shards on device 0 (%s): %.4f ms per pass over %d samples = %.1f Gsamples/s  (host: %.4f ms to queue a pass)" %
-          (G, "rccl comm of one" if G == 1 else "peer copies", dt * 1e3, total, total / dt / 1e9, host * 1e3), flush=True)
+          (G, "rccl comm of one" if G == 1 else "peer copies" + (", SUBMIT THREADS" if threads else ""), dt * 1e3, total, total / dt / 1e9, host * 1e3), flush=True)
     ns.close()

@@ -73,6 +73,8 @@ def parse():
                     help="--driver native: how the halo travels between DISTINCT devices (auto: RCCL; peer: hipMemcpyPeerAsync)")
     ap.add_argument("--no-autotune", action="store_true",
                     help="ranks over RCCL: do not time the pipelined against the unpipelined pass during setup, take the pipelined one")
+    ap.add_argument("--native-submit-threads", action="store_true",
+                    help="--driver native: one thread per shard queues that shard's share of a pass (pcx_shard_set_submit_threads)")
     ap.add_argument("--native-pingpong", action="store_true",
                     help="--driver native: two handles driven double-buffered (pcx_shard_post_exchange / pcx_shard_compute)")
     ap.add_argument("--no-pingpong", dest="pingpong", action="store_false",
@@ -405,6 +407,7 @@ def run_native(args):
     handles = []
     for b in range(2 if args.native_pingpong else 1):
         ns = device.NodeStream(devs, transport)
+        ns.set_submit_threads(args.native_submit_threads)
         if chain:
             ns.set_chain(True, tp.C4_PHASE)
         ns.set_taps(h, complex_taps=not chain)
@@ -455,7 +458,8 @@ def run_native(args):
                                      else "peer copies (REHEARSAL: %d shards on %d device(s))" % (G, distinct) if distinct != G
                                      else "peer copies (hipMemcpyPeerAsync between the devices, one process)",
                    "parallelism": "overlap-save shards x%d, one gated launch per shard and pass" % G
-                                  + ("; double-buffered over two handles: the halos of batch k+1 exchanged while batch k is filtered" if args.native_pingpong else "")},
+                                  + ("; double-buffered over two handles: the halos of batch k+1 exchanged while batch k is filtered" if args.native_pingpong else "")
+                                  + ("; a submit thread per shard" if args.native_submit_threads else "")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "fmchain_cf32_ols4096_kernel" if chain else "fir_cf32_ols4096_kernel", "avg_launch_ms": round(per * 1e3, 4),

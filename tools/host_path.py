@@ -97,3 +97,30 @@ if __name__ == "__main__":
                 circ.close()
         print("n=%9d  own pinned ports %7.3f ms %5.2f Gs/s | circular, page-locked where it lies %7.3f ms %5.2f Gs/s (%.2f of the roof) | not lockable (staged) %7.3f ms %5.2f Gs/s"
               % (n, res[0] * 1e3, n / res[0] / 1e9, res[1] * 1e3, n / res[1] / 1e9, 8 * n / res[1] / 1e9 / roof, res[2] * 1e3, n / res[2] / 1e9))
+
+    print("-- 3. /comms/fir_filter with setDevices: the call's samples split over shards (here: all on device 0, halos by peer copies), native loop")
+    print("   (one device has ONE PCIe link: the shards' transfers share it -- what this shows is the cost of scatter + pass + gather against the")
+    print("    in-place call; on a node each device brings its own link)")
+    for n in (1 << 22, 1 << 24):
+        reps = max(5, (1 << 25) // n)
+        row = []
+        for devs in ([], [0, 0], [0, 0, 0, 0]):
+            blk = blocks.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+            blk.call("setTaps", tp.c1_taps())
+            if devs:
+                blk.call("setDevices", devs)
+            blk.activate()
+            xin, _ = blk.port_buffer(0, (n + K - 1, 2), np.float32)
+            yout, _ = blk.port_buffer(1, (n, 2), np.float32)
+            xin[:] = rng.uniform(-1, 1, xin.shape).astype(np.float32)
+            blk.work_loop(xin.ctypes.data, n + K - 1, yout.ctypes.data, n, 3)
+            best = None
+            for _ in range(3):
+                t, c, p = blk.work_loop(xin.ctypes.data, n + K - 1, yout.ctypes.data, n, reps)
+                assert c == p and c >= n - len(devs), (c, p, n)
+                best = t / reps if best is None else min(best, t / reps)
+            passes = blk.call("getShardPasses") if devs else 0
+            row.append("%s %7.3f ms %5.2f Gs/s%s" % ("single device" if not devs else "%d shards" % len(devs), best * 1e3, n / best / 1e9,
+                                                    " (%d sharded passes)" % passes if devs else ""))
+            blk.close()
+        print("n=%9d  " % n + " | ".join(row))

@@ -277,13 +277,16 @@ int launch_fir_cf32_ols4096(const void *in, size_t in_elems, void *out, size_t n
     if (nfull < first_full) nfull = first_full;
     const float2 *pi = (const float2 *)in, *ph = (const float2 *)Hspec, *pt = (const float2 *)tw4096;
     float2 *po = (float2 *)out;
+    // slots below 128: a call on HOST memory over PCIe (pcx_api.hip host_grid): that many workgroups on the grid stride, several blocks each,
+    // no dealer -- block k+1's fetch at the foot of block k then runs beside block k's stores, and the link carries both directions at once
+    const bool host_grid = slots > 0 && slots < 128;
     // PCX_OLS_SLOTS (diagnostic): resident workgroups to use chip-wide (default 1024 = 4 per CU)
-    if (slots < 128 || slots > 1024 || slots % 128) slots = 1024;
+    if (!host_grid && (slots < 128 || slots > 1024 || slots % 128)) slots = 1024;
     const long env_static = PCX_ENV_INT("PCX_OLS_SLOTS", 0);
     const unsigned static_slots = env_static > 0 ? (unsigned)env_static : slots;
     const unsigned g4 = persistent_grid(nblocks, static_slots), g3 = persistent_grid(nblocks, 768);
     const unsigned gx = 8 * persistent_grid((nblocks + 7) / 8, 128);   // XCD-aware walk: equal rounds inside every XCD's eighth
-    const bool dealt = sched && nblocks > 2 * (size_t)slots && !PCX_ENV_SET("PCX_SCHED_STATIC");   // (PCX_SCHED_STATIC, diag only: the grid stride, for A/B)
+    const bool dealt = !host_grid && sched && nblocks > 2 * (size_t)slots && !PCX_ENV_SET("PCX_SCHED_STATIC");   // (PCX_SCHED_STATIC, diag only: the grid stride, for A/B)
     if (gate_word && !dealt) return PCX_OK;       // no gate in the grid-stride kernels: *gated stays 0, nothing launched
     // the window of block b starts at sample b*S - pad: only block 0 reaches below K-1 (Kov <= 2048 <= S)
     const Gate gate{dealt ? (const unsigned *)gate_word : nullptr, gate_value, 1u};
@@ -831,8 +834,9 @@ int launch_fmchain_cf32_ols4096(const void *in, size_t in_elems, void *out, size
     const size_t Kov = (K + 31) / 32 * 32, pad = Kov - K;    // <= 2048
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
-    if (slots < 128 || slots > 1024 || slots % 128) slots = 1024;
-    const bool dyn = sched && nblocks > 2 * (size_t)slots && !PCX_ENV_SET("PCX_SCHED_STATIC");   // dynamic dealing when the handle brought its counter pair and the launch is long
+    const bool host_grid = slots > 0 && slots < 128;      // a call on host memory over PCIe: few workgroups, several blocks each (launch_fir_cf32_ols4096)
+    if (!host_grid && (slots < 128 || slots > 1024 || slots % 128)) slots = 1024;
+    const bool dyn = !host_grid && sched && nblocks > 2 * (size_t)slots && !PCX_ENV_SET("PCX_SCHED_STATIC");   // dynamic dealing when the handle brought its counter pair and the launch is long
     if (gate_word && !dyn) return PCX_OK;         // no gate in the grid-stride kernel: *gated stays 0, nothing launched
     // the window of block b starts at sample b*S - 1 - pad: it reaches below sample K while b*S < Kov + 1 -- block 0, and block 1
     // too when S == Kov (2048 taps)

@@ -713,6 +713,13 @@ static int stage_out_end(void *host, size_t bytes, StageBuf &ws, bool staged, hi
 // so that the finding can be re-measured, and its chunks are bit-identical to the uncut call (tests/test_hostpath_gpu.py).
 static size_t drain_from() { return (size_t)PCX_ENV_INT("PCX_DRAIN_FROM", (long)1 << 62); }     // product: never
 static size_t drain_chunk_bytes() { return (size_t)PCX_ENV_INT("PCX_DRAIN_CHUNK", 2 << 20); }
+// A call whose input or output is HOST memory the kernel addresses over PCIe is bound by the link, not by the device -- and the link is
+// full duplex.  On the device-resident grid (1024 persistent workgroups, one or a few blocks each) a call of a Pothos slab's size
+// is a few hundred blocks that all load, then all compute, then all store: reads and writes never overlap (1 Mi samples: 0.281 ms).
+// On ~48 workgroups that walk several blocks each on the grid stride, block k+1's fetch (issued at the foot of block k) runs beside block
+// k's stores: 0.255 ms at 1 Mi samples, 0.833 against 0.947 at 4 Mi, 3.08 against 3.35 at 16 Mi = 43.6 GB/s each way, the rate
+// tools/pcie_lab.hip measures for a plain copy kernel on the same buffers (profiles/r05/host_slots_static.txt; 32 and 64 are within 2 %).
+static unsigned host_grid() { return (unsigned)PCX_ENV_INT("PCX_HOST_GRID", 48); }
 static bool host_page_locked(const void *p)
 {
     int kind = PCX_PTR_PAGEABLE;
@@ -1423,7 +1430,12 @@ int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size
     PCX_TRY(stage_reserve(out, n_out * esz, h->wsOut));
     PCX_TRY(stage_in(in, used_in * esz, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, n_out * esz, h->wsOut, &dout, &staged));
-    PCX_TRY(pcx_fir_process_dev(h, din, used_in, dout, n_out, consumed, produced, st));
+    // the kernel reads or writes the caller's page-locked memory in place: the launch shape of a link-bound call (host_grid above)
+    const unsigned keep_slots = h->slots;
+    if (host_grid() && (host_page_locked(in) || host_page_locked(out))) h->slots = host_grid();
+    const int rc = pcx_fir_process_dev(h, din, used_in, dout, n_out, consumed, produced, st);
+    h->slots = keep_slots;
+    PCX_TRY(rc);
     return stage_out_end(out, *produced * esz, h->wsOut, staged, st);
 }
 
@@ -2333,6 +2345,10 @@ int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *o
     PCX_TRY(stage_reserve(out, N * 4, h->wsOut));
     PCX_TRY(stage_in(in, used * 8, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, N * 4, h->wsOut, &dout, &staged));
-    PCX_TRY(pcx_fmchain_process_dev(h, din, used, dout, N, consumed, produced, st));
+    const unsigned keep_slots = h->slots;
+    if (host_grid() && (host_page_locked(in) || host_page_locked(out))) h->slots = host_grid();      // (pcx_fir_process: a link-bound call's launch shape)
+    const int rc = pcx_fmchain_process_dev(h, din, used, dout, N, consumed, produced, st);
+    h->slots = keep_slots;
+    PCX_TRY(rc);
     return stage_out_end(out, N * 4, h->wsOut, staged, st);
 }

@@ -194,3 +194,24 @@ def test_split_combine_factories(t):
     outs, cons, prod = sp.work_ports([np.zeros((4, 2), np.dtype(t))], [4, 0])
     assert cons == [0] and prod == [0, 0]
 
+
+
+def test_the_runners_circular_buffer_is_one_object_mapped_twice():
+    """pcxb_circular_create: the stand-in for the framework's "circular" manager (what FIRFilter.cpp:196-199 asks Pothos for) -- pageable
+    shared memory mapped twice back to back, so that a window may start anywhere in the first mapping and run across the wrap; the two
+    mappings are adjacent entries of /proc/self/maps on ONE object, which is what pcx_host_register_mapping looks for"""
+    c = B.CircularBuffer(100000)
+    assert c.size % 4096 == 0 and c.size >= 100000
+    w = c.view(c.size - 16, 64)
+    w[:] = np.arange(64, dtype=np.uint8)
+    assert np.array_equal(c.view(0, 48), np.arange(16, 64, dtype=np.uint8))           # the part behind the wrap is the buffer's start
+    assert np.array_equal(c.view(c.size - 16, 16), np.arange(16, dtype=np.uint8))
+    rows = [ln.split() for ln in open("/proc/self/maps") if "pcx-circular" in ln]
+    lo0, hi0 = (int(v, 16) for v in rows[0][0].split("-"))
+    lo1, hi1 = (int(v, 16) for v in rows[1][0].split("-"))
+    assert len(rows) == 2 and lo0 == c.base and hi0 == lo1 and hi1 - lo1 == hi0 - lo0 == c.size
+    assert rows[0][1] == rows[1][1] == "rw-s" and rows[0][4] == rows[1][4]               # shared, the same inode
+    c.close()
+    assert not [ln for ln in open("/proc/self/maps") if "pcx-circular" in ln]
+    with pytest.raises(Exception):
+        B.CircularBuffer(0)

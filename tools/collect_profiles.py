@@ -33,7 +33,8 @@ for name in ("bench_default.json", "bench_other_workloads.jsonl", "bench_driver_
              "sweep_fft_q15_large.txt", "bench_native_two_shards_one_gpu.json", "bench_native_two_shards_one_gpu_fmchain.json",
              "bench_native_c3_eight_shards_one_gpu.json", "bench_native_c3_eight_shards_one_gpu_fmchain.json", "bench_eight_ranks_one_gpu_gloo.json",
              "bench_native_c3_eight_shards_one_gpu_double_buffered.json", "bench_native_two_shards_one_gpu_double_buffered.json",
-             "clk_lab.txt", "shard_probe_c3.txt", "floor_table.txt", "chain_path.txt") + tuple(
+             "clk_lab.txt", "shard_probe_c3.txt", "floor_table.txt", "chain_path.txt", "c_pcie_probe.txt", "shard_probe_threads.txt",
+             "bench_native_c3_eight_shards_one_gpu_submit_threads.json") + tuple(
                  "bench_rccl_rank_rehearsal%s%s.json" % (a, b) for a in ("", "_unpipelined", "_plain_same_box") for b in ("", "_fmchain")):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))

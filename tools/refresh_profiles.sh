@@ -1,9 +1,9 @@
 # The judged evidence set, produced on the GPU box:  gpurun -- bash tools/refresh_profiles.sh [outdir]
 # then, here:  python tools/collect_profiles.py <outdir> profiles/<round>
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=${1:-gpurun_out/r04b}; rm -rf $O; mkdir -p $O
+O=${1:-gpurun_out/r05z}; rm -rf $O; mkdir -p $O
 ulimit -c 0
-make -s -C tools ubench ols_lab3 clk_lab floor_lab > /dev/null 2>&1
+make -s -C tools ubench ols_lab3 clk_lab floor_lab pcie_lab > /dev/null 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> /dev/null
 for w in fft4096 fmchain rotate direct255 decim8 interp4 fir255_i16; do python bench.py --workload $w 2>/dev/null | tail -1 >> $O/bench_other_workloads.jsonl; done
@@ -47,6 +47,12 @@ python tools/sweep_fir.py > $O/sweep_fir_taps.txt 2>/dev/null
 python tools/sweep_fft.py 16 64 256 1024 2048 4096 8192 16384 > $O/sweep_fft_sizes.txt 2>/dev/null
 python tools/sweep_fft_q15_large.py > $O/sweep_fft_q15_large.txt 2>/dev/null
 python tools/real_probe.py > $O/real_f32_fir.txt 2>/dev/null
+# round 5: the host path (PCIe) and the native driver's host time
+timeout 300 python tools/host_path.py 2>/dev/null > $O/host_path.txt
+timeout 120 tools/pcie_lab > $O/pcie_lab.txt 2>&1
+timeout 60 examples/c_pcie_probe > $O/c_pcie_probe.txt 2>&1
+( for t in "" 1; do PCX_PROBE_THREADS=$t PCX_PROBE_TOTAL=536870912 timeout 120 python tools/shard_probe.py 8 2>/dev/null | grep shards; PCX_PROBE_THREADS=$t timeout 120 python tools/shard_probe.py 2 2>/dev/null | grep shards; done ) > $O/shard_probe_threads.txt
+python bench.py --driver native --gpus 8 --native-devices 0,0,0,0,0,0,0,0 --native-submit-threads --no-cpu > $O/bench_native_c3_eight_shards_one_gpu_submit_threads.json 2> /dev/null
 find $O -name "*.csv" -size +2M -delete
 find $O -name "*agent_info*" -delete
 du -sh $O

@@ -242,7 +242,7 @@ def _run_attempt(a, att, rank, world, sdir, argv, reasons, script):
                 break
         time.sleep(0.1)
     _CURRENT[0] = None
-    _write_atomic("%s.rank%d" % (tag, rank), json.dumps({"ok": ok, "status": status, "phase": child.phase}))
+    _write_atomic("%s.rank%d" % (tag, rank), json.dumps({"ok": ok, "status": status, "phase": child.phase, "t": time.time()}))
     # every supervisor waits for every verdict of this attempt: they move on (or stop) together
     paths = ["%s.rank%d" % (tag, r) for r in range(world)]
     # (a peer learns of a failure within PEER_FAILED_GRACE_S and of a result at once; a peer whose supervisor is gone takes the launcher down)
@@ -254,11 +254,12 @@ def _run_attempt(a, att, rank, world, sdir, argv, reasons, script):
     if result is not None:
         # the measurement is complete (the line is written behind the timed region, the max-over-ranks clock and the seam check)
         return True, status, result.strip()
-    bad = ["rank %d: %s" % (r, v["status"]) for r, v in sorted(verdicts.items()) if not v["ok"]]
+    # the root cause first: the rank whose failure was noticed FIRST (the others' errors -- a peer's connection closed, a collective that
+    # never returned -- follow it); a rank that was stopped because another had failed is a consequence and goes last
+    failed = sorted(((v.get("t", float("inf")), r, v) for r, v in verdicts.items() if not v["ok"]), key=lambda x: ("stopped: rank" in x[2]["status"], x[0], x[1]))
+    bad = ["rank %d: %s" % (r, v["status"]) for _, r, v in failed]
     if not bad:
         bad = ["every rank ended cleanly but rank 0 printed no result line"]
-    # the root causes first: a rank that was stopped because another failed is a consequence
-    bad.sort(key=lambda s: "stopped: rank" in s)
     return False, "; ".join(bad[:3]) + (" (+%d more)" % (len(bad) - 3) if len(bad) > 3 else ""), None
 
 

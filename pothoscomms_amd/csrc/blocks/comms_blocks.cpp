@@ -519,6 +519,14 @@ private:
         size_t len = 0;
         if (pcx_host_register_mapping(p, bytes, 0, &base, &len) == PCX_OK && base) _locked.emplace_back(base, len);
         else {
+            // a window that slides through one unlockable buffer must not cost a look at /proc/self/maps per call: a window that overlaps
+            // or touches a range already known to be unlockable grows that range
+            for (auto &r : _unlockable)
+                if (lo <= r.first + r.second && r.first <= hi) {
+                    const uintptr_t nlo = std::min(lo, r.first), nhi = std::max(hi, r.first + r.second);
+                    r = std::make_pair(nlo, (size_t)(nhi - nlo));
+                    return;
+                }
             if (_unlockable.size() >= 16) _unlockable.erase(_unlockable.begin());
             _unlockable.emplace_back(lo, bytes);
         }

@@ -75,3 +75,45 @@ def test_default_line_documents_itself():
     finally:
         sys.argv = sys_argv
     assert (a.gpus, a.steps, a.warmup, a.no_secondary, a.no_cold, a.workload) == (1, 20, 5, True, True, "fir255")
+
+
+def _committed_line(name):
+    p = os.path.join(ROOT, "profiles", "r05", name)
+    if not os.path.exists(p):
+        pytest.skip(name + " is not committed")
+    return json.loads(open(p).read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["bench_default.json", "bench_driver_flags.json"])
+def test_the_committed_default_line_carries_every_single_gpu_config_and_the_host_path(name):
+    """the schema of the line the driver's own run yields (VERDICT r04 Next 3): the headline with both clocks stated, configs[2] and
+    [4], configs[3] rehearsed on one device, and SURVEY 8d's end-to-end number -- each with a roofline object whose bound, peak and
+    unit fit the workload, the CPU baseline beside the ones that have one"""
+    d = _committed_line(name)
+    assert d["metric"] == "Msamples/s complex_float32 255-tap FIR" and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.5 < r["frac"] < 0.9
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=2e-3)
+    # one line, two clocks, both stated: the wall-clock fraction reproduces from `value`
+    assert "HIP events" in r["clock"] and r["wall_clock"]["ms_per_step"] == d["ms_per_step"]
+    assert r["wall_clock"]["frac"] == pytest.approx(d["value"] * 1e6 * 16 / 8e12, rel=2e-3)
+    assert r["traffic"] and 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.15       # PMC bytes of THIS kernel (stamped sources)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    s = d["secondary"]
+    assert set(s) == {"fft4096", "fmchain", "c3_one_device", "host_path"}
+    for k in ("fft4096", "fmchain"):
+        assert s[k]["roofline"]["bound"] == "hbm" and s[k]["roofline"]["frac"] > 0.4 and "cpu_baseline" in s[k]
+    c3 = s["c3_one_device"]
+    assert c3["config"]["shards"] == 8 and c3["config"]["shard_samples"] == 64 << 20 and c3["n_gpus"] == 1
+    assert "all 7 seams" in c3["seam_check"] and not c3["seam_check"].startswith("FAILED")
+    assert 0.9 < c3["ratio_to_8_plain_launches"] < 1.15 and c3["roofline"]["frac"] > 0.55
+    hp = s["host_path"]
+    rr = hp["roofline"]
+    assert rr["bound"] == "pcie" and rr["unit"] == "GB/s" and 40 < rr["peak"] < 70               # measured in the same run
+    assert rr["peak"] == pytest.approx(min(rr["peak_measured"]["h2d_alone"], rr["peak_measured"]["d2h_alone"]), abs=0.02)
+    assert rr["frac"] == pytest.approx(rr["achieved"] / rr["peak"], abs=2e-3) and 0.3 < rr["frac"] < 1.0
+    assert hp["value"] == pytest.approx(hp["config"]["samples_per_call"] / (hp["ms_per_step"] * 1e-3) / 1e6, rel=2e-3)
+    for size in ("1048576_samples_per_call", "16777216_samples_per_call"):
+        a, b = hp["calls"][size]["pinned_port_buffers"], hp["calls"][size]["circular_input_page_locked_in_place"]
+        assert b["Msamples_per_s"] > 0.9 * a["Msamples_per_s"]             # the framework's circular buffer, locked where it lies, is as fast as the module's own slabs
+    assert hp["cpu_baseline"]["kind"] == "port"

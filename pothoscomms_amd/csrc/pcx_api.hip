@@ -720,11 +720,20 @@ static size_t drain_chunk_bytes() { return (size_t)PCX_ENV_INT("PCX_DRAIN_CHUNK"
 // k's stores: 0.255 ms at 1 Mi samples, 0.833 against 0.947 at 4 Mi, 3.08 against 3.35 at 16 Mi = 43.6 GB/s each way, the rate
 // tools/pcie_lab.hip measures for a plain copy kernel on the same buffers (profiles/r05/host_slots_static.txt; 32 and 64 are within 2 %).
 static unsigned host_grid() { return (unsigned)PCX_ENV_INT("PCX_HOST_GRID", 48); }
+// the grid-stride map kernels (pcx_internal.hpp LINK-BOUND LAUNCHES): 32 blocks for the one-to-one maps, 64 for /comms/freq_demod (two reads per sample)
+static unsigned host_map_grid(unsigned dflt = 32) { const unsigned e = (unsigned)PCX_ENV_INT("PCX_HOST_MAP_GRID", -1); return e == (unsigned)-1 ? dflt : e; }
+namespace pcx { thread_local unsigned g_link_grid = 0, g_link_map_grid = 0; }
 static bool host_page_locked(const void *p)
 {
     int kind = PCX_PTR_PAGEABLE;
     return pcx_pointer_kind(p, &kind) == PCX_OK && kind == PCX_PTR_PAGE_LOCKED;
 }
+// (grid, map grid) for a launch whose input or output is page-locked host memory the kernel addresses in place, else (0, 0)
+struct LinkBound : LinkBoundScope {
+    static bool any(const void *a, const void *b, const void *c) { return host_page_locked(a) || host_page_locked(b) || (c && host_page_locked(c)); }
+    LinkBound(const void *a, const void *b, const void *c = nullptr, unsigned map_blocks = 32)
+        : LinkBoundScope(any(a, b, c) ? host_grid() : 0, any(a, b, c) ? host_map_grid(map_blocks) : 0) {}
+};
 // how many chunks a drained output of `bytes` goes in (2 .. kDrainChunks)
 static int drain_chunks(size_t bytes)
 {
@@ -1432,8 +1441,12 @@ int pcx_fir_process(pcx_fir *h, const void *in, size_t in_elems, void *out, size
     PCX_TRY(stage_out_begin(out, n_out * esz, h->wsOut, &dout, &staged));
     // the kernel reads or writes the caller's page-locked memory in place: the launch shape of a link-bound call (host_grid above)
     const unsigned keep_slots = h->slots;
-    if (host_grid() && (host_page_locked(in) || host_page_locked(out))) h->slots = host_grid();
-    const int rc = pcx_fir_process_dev(h, din, used_in, dout, n_out, consumed, produced, st);
+    int rc;
+    {
+        LinkBound shape(in, out);                      // (every static plan: persistent_grid / stream_grid look at it)
+        if (g_link_grid) h->slots = g_link_grid;       // (the dealt plain plan: slots < 128 = that many workgroups, no dealer)
+        rc = pcx_fir_process_dev(h, din, used_in, dout, n_out, consumed, produced, st);
+    }
     h->slots = keep_slots;
     PCX_TRY(rc);
     return stage_out_end(out, *produced * esz, h->wsOut, staged, st);
@@ -1898,7 +1911,10 @@ int pcx_freqdemod_process(pcx_freqdemod *h, const void *in, void *out, size_t n)
     PCX_TRY(stage_reserve(out, n * sb, h->wsOut));
     PCX_TRY(stage_in(in, n * 2 * sb, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, n * sb, h->wsOut, &dout, &staged));
-    PCX_TRY(pcx_freqdemod_process_dev(h, din, dout, n, st));
+    {
+        LinkBound shape(in, out, nullptr, 64);
+        PCX_TRY(pcx_freqdemod_process_dev(h, din, dout, n, st));
+    }
     return stage_out_end(out, n * sb, h->wsOut, staged, st);
 }
 
@@ -1951,7 +1967,10 @@ static int run_host_map(const void *in, void *out, size_t in_bytes, size_t out_b
     PCX_TRY(stage_reserve(out, out_bytes, ws->out));
     PCX_TRY(stage_in(in, in_bytes, ws->in, ws->st, &din));
     PCX_TRY(stage_out_begin(out, out_bytes, ws->out, &dout, &staged));
-    PCX_TRY(launch(din, dout, ws->st));
+    {
+        LinkBound shape(in, out);
+        PCX_TRY(launch(din, dout, ws->st));
+    }
     return stage_out_end(out, out_bytes, ws->out, staged, ws->st);
 }
 
@@ -2076,7 +2095,10 @@ int pcx_arith(int scalar, int is_complex, int op, const void *in0, const void *i
     PCX_TRY(stage_in(in0, b, ws->in, ws->st, &d0));
     PCX_TRY(stage_in(in1, b, ws->in2, ws->st, &d1));
     PCX_TRY(stage_out_begin(out, b, ws->out, &dout, &staged));
-    PCX_TRY(launch_arith(scalar, is_complex, op, d0, d1, dout, n, ws->st));
+    {
+        LinkBound shape(in0, in1, out);
+        PCX_TRY(launch_arith(scalar, is_complex, op, d0, d1, dout, n, ws->st));
+    }
     return stage_out_end(out, b, ws->out, staged, ws->st);
 }
 int pcx_split_complex_dev(int scalar, const void *in_dev, void *re_dev, void *im_dev, size_t n, void *stream)
@@ -2102,7 +2124,10 @@ int pcx_split_complex(int scalar, const void *in, void *re, void *im, size_t n)
     PCX_TRY(stage_in(in, 2 * b, ws->in, ws->st, &din));
     PCX_TRY(stage_out_begin(re, b, ws->out, &dre, &sre));
     PCX_TRY(stage_out_begin(im, b, ws->out2, &dim, &sim));
-    PCX_TRY(launch_split_complex(scalar, din, dre, dim, n, ws->st));
+    {
+        LinkBound shape(in, re, im);
+        PCX_TRY(launch_split_complex(scalar, din, dre, dim, n, ws->st));
+    }
     PCX_TRY(stage_out_end(re, b, ws->out, sre, ws->st));
     return stage_out_end(im, b, ws->out2, sim, ws->st);
 }
@@ -2129,7 +2154,10 @@ int pcx_combine_complex(int scalar, const void *re, const void *im, void *out, s
     PCX_TRY(stage_in(re, b, ws->in, ws->st, &dre));
     PCX_TRY(stage_in(im, b, ws->in2, ws->st, &dim));
     PCX_TRY(stage_out_begin(out, 2 * b, ws->out, &dout, &staged));
-    PCX_TRY(launch_combine_complex(scalar, dre, dim, dout, n, ws->st));
+    {
+        LinkBound shape(re, im, out);
+        PCX_TRY(launch_combine_complex(scalar, dre, dim, dout, n, ws->st));
+    }
     return stage_out_end(out, 2 * b, ws->out, staged, ws->st);
 }
 
@@ -2346,8 +2374,12 @@ int pcx_fmchain_process(pcx_fmchain *h, const void *in, size_t in_elems, void *o
     PCX_TRY(stage_in(in, used * 8, h->wsIn, st, &din));
     PCX_TRY(stage_out_begin(out, N * 4, h->wsOut, &dout, &staged));
     const unsigned keep_slots = h->slots;
-    if (host_grid() && (host_page_locked(in) || host_page_locked(out))) h->slots = host_grid();      // (pcx_fir_process: a link-bound call's launch shape)
-    const int rc = pcx_fmchain_process_dev(h, din, used, dout, N, consumed, produced, st);
+    int rc;
+    {
+        LinkBound shape(in, out);                      // (pcx_fir_process: a link-bound call's launch shape)
+        if (g_link_grid) h->slots = g_link_grid;
+        rc = pcx_fmchain_process_dev(h, din, used, dout, N, consumed, produced, st);
+    }
     h->slots = keep_slots;
     PCX_TRY(rc);
     return stage_out_end(out, N * 4, h->wsOut, staged, st);

@@ -145,13 +145,30 @@ inline bool env_off(bool v) { return v; }
 #define PCX_ENV_SET(name) (::pcx::env_off(false))
 #endif
 
+// LINK-BOUND LAUNCHES.  A kernel launched by a host-pointer entry point on page-locked HOST memory is bound by the PCIe link, which is
+// full duplex: what matters is that reads and writes overlap, and they do when FEW workgroups each walk MANY pieces (a piece's loads then
+// run beside the previous piece's stores) instead of a device-filling grid whose workgroups all load, then all store.  The host entry
+// points (pcx_api.hip) set these two for the duration of their launch -- thread-local, 0 = the device-resident shape:
+//   g_link_grid      persistent block kernels (overlap-save FIR plans, the fused chain): that many workgroups on the grid stride, no dealer
+//   g_link_map_grid  grid-stride map kernels: that many blocks
+// Measured over PCIe (profiles/r05/host_grid_sweep.txt, host_other_sweep.txt): FIR 255 taps +9-14 % at 48 workgroups (decimating / interpolating /
+// real-stream plans and the fused chain +4-11 % on large calls); /comms/conjugate +15-29 % at 32 blocks, /comms/freq_demod +6-21 % at 64.
+extern thread_local unsigned g_link_grid, g_link_map_grid;
+struct LinkBoundScope {
+    unsigned keep_grid, keep_map;
+    LinkBoundScope(unsigned grid, unsigned map_grid) : keep_grid(g_link_grid), keep_map(g_link_map_grid) { g_link_grid = grid; g_link_map_grid = map_grid; }
+    ~LinkBoundScope() { g_link_grid = keep_grid; g_link_map_grid = keep_map; }
+    LinkBoundScope(const LinkBoundScope &) = delete;
+    LinkBoundScope &operator=(const LinkBoundScope &) = delete;
+};
+
 // grid size for an HBM-bound grid-stride kernel.  The cap was 256 CUs x 8 resident blocks (every block the same share of the
 // stream); with 8 queued per slot on top the dispatcher evens out the CUs' unequal rates: /comms/rotate on 64 Mi cf32 samples
 // 0.1777 -> 0.1674..0.1681 ms (0.755 -> 0.80 of the HBM peak) at caps of 4096 ... 65536 (PCX_MAP_GRID, diagnostic library: A/B)
 inline unsigned stream_grid(size_t work_items, unsigned block)
 {
     size_t g = (work_items + block - 1) / block;
-    const size_t cap = (size_t)PCX_ENV_INT("PCX_MAP_GRID", 256 * 64);
+    const size_t cap = g_link_map_grid ? (size_t)g_link_map_grid : (size_t)PCX_ENV_INT("PCX_MAP_GRID", 256 * 64);
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     return (unsigned)g;
@@ -168,7 +185,8 @@ inline unsigned stream_grid(size_t work_items, unsigned block)
 inline unsigned persistent_grid(size_t units, unsigned slots, unsigned oversub = 1)
 {
     const long forced = PCX_ENV_INT("PCX_OVERSUB", 0);
-    const size_t cap = (size_t)slots * (size_t)(forced > 0 ? (unsigned)forced : oversub);
+    // (a link-bound launch, above: at most g_link_grid workgroups, equal rounds like any other persistent grid)
+    const size_t cap = g_link_grid ? (size_t)g_link_grid : (size_t)slots * (size_t)(forced > 0 ? (unsigned)forced : oversub);
     if (units <= cap) return (unsigned)(units ? units : 1);
     const size_t rounds = (units + cap - 1) / cap;
     return (unsigned)((units + rounds - 1) / rounds);

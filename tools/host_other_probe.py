@@ -55,4 +55,14 @@ for n in (1 << 18, 1 << 20, 1 << 22, 1 << 24):
     f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8)); f.set_decimation(8)
     dt = best(lambda: _lib.check(L.pcx_fir_process(f._h, x.ctypes.data, n + 254, y.ctypes.data, n // 8, C.byref(c), C.byref(p))), n)
     row.append("fir decim 8 %.3f ms %5.2f Gs/s in (%4.1f / %4.1f)" % (dt * 1e3, n / dt / 1e9, 8 * n / dt / 1e9, n / dt / 1e9))
+    f = device.FirFilter("complex_float32", "COMPLEX"); f.set_taps(tp.complex_bandpass(255 * 4, 0.05 / 4, 0.05 / 4) * 4); f.set_interpolation(4)
+    dt = best(lambda: _lib.check(L.pcx_fir_process(f._h, x.ctypes.data, n // 4 + 254, y.ctypes.data, n, C.byref(c), C.byref(p))), n)
+    row.append("fir interp 4 %.3f ms %5.2f Gs/s out" % (dt * 1e3, n / dt / 1e9))
+    xi = x.view(np.int16); yi = y.view(np.int16)         # complex_int16: 4 bytes per sample
+    f = device.FirFilter("complex_int16", "COMPLEX"); f.set_taps(tp.c1_taps() * 0.9)
+    dt = best(lambda: _lib.check(L.pcx_fir_process(f._h, xi.ctypes.data, n + 254, yi.ctypes.data, n, C.byref(c), C.byref(p))), n)
+    row.append("fir i16 %.3f ms %5.2f Gs/s (%4.1f GB/s each way)" % (dt * 1e3, n / dt / 1e9, 4 * n / dt / 1e9))
+    f = device.FirFilter("float32", "REAL"); f.set_taps(tp.lowpass(255, 0.1))
+    dt = best(lambda: _lib.check(L.pcx_fir_process(f._h, x.ctypes.data, 2 * n + 254, y.ctypes.data, 2 * n, C.byref(c), C.byref(p))), n)
+    row.append("fir real f32 %.3f ms %5.2f Gs/s (%4.1f GB/s each way)" % (dt * 1e3, 2 * n / dt / 1e9, 8 * n / dt / 1e9))
     print("n=%9d  " % n + " | ".join(row), flush=True)

@@ -173,7 +173,9 @@ struct ShardWorkers {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinUs)) {
                     std::unique_lock<std::mutex> lk(m);
                     sleepers.fetch_add(1);
-                    cv.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen || stop.load(std::memory_order_acquire); });
+                    // (sequentially consistent on both sides: the caller bumps `gen` and THEN looks at `sleepers`, this thread bumps `sleepers` and THEN
+                    // looks at `gen` -- one of the two must see the other's write, or a wake-up is lost)
+                    cv.wait(lk, [&] { return gen.load() != seen || stop.load(); });
                     sleepers.fetch_sub(1);
                     break;
                 }
@@ -192,7 +194,7 @@ struct ShardWorkers {
     {
         part = first | (last << 8);
         pending.store((int)th.size(), std::memory_order_release);
-        gen.fetch_add(1, std::memory_order_acq_rel);
+        gen.fetch_add(1);
         if (sleepers.load() > 0) { std::lock_guard<std::mutex> lk(m); cv.notify_all(); }
         while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
         for (size_t g = 0; g < rc.size(); g++)

@@ -243,9 +243,9 @@ class FreqDemod(_Handle):
     def reset(self):
         _lib.check(_lib.load().pcx_freqdemod_reset(self._h))
 
-    def process(self, x):
+    def process(self, x, out=None):
         xp = as_pairs(x)
-        y = np.zeros(xp.shape[0], dtype=NP_SCALAR[self.scalar])
+        y = np.zeros(xp.shape[0], dtype=NP_SCALAR[self.scalar]) if out is None else out
         _lib.check(_lib.load().pcx_freqdemod_process(self._h, _np_ptr(xp), _np_ptr(y), xp.shape[0]))
         return y
 
@@ -421,7 +421,8 @@ def split_complex(x, scalar=None, re=None, im=None, n=None, stream=None):
         _lib.check(L.pcx_split_complex_dev(scalar, _dev_ptr(x), _dev_ptr(re), _dev_ptr(im), n, _stream_ptr(stream)))
         return re, im
     x = as_pairs(x)
-    re, im = np.zeros(x.shape[0], dtype=x.dtype), np.zeros(x.shape[0], dtype=x.dtype)
+    re = np.zeros(x.shape[0], dtype=x.dtype) if re is None else re
+    im = np.zeros(x.shape[0], dtype=x.dtype) if im is None else im
     _lib.check(L.pcx_split_complex(SCALAR_OF_NP[x.dtype], _np_ptr(x), _np_ptr(re), _np_ptr(im), x.shape[0]))
     return re, im
 
@@ -433,7 +434,7 @@ def combine_complex(re, im, scalar=None, out=None, n=None, stream=None):
         _lib.check(L.pcx_combine_complex_dev(scalar, _dev_ptr(re), _dev_ptr(im), _dev_ptr(out), n, _stream_ptr(stream)))
         return out
     re, im = np.ascontiguousarray(re), np.ascontiguousarray(im)
-    y = np.zeros((re.shape[0], 2), dtype=re.dtype)
+    y = np.zeros((re.shape[0], 2), dtype=re.dtype) if out is None else out
     _lib.check(L.pcx_combine_complex(SCALAR_OF_NP[re.dtype], _np_ptr(re), _np_ptr(im), _np_ptr(y), re.shape[0]))
     return y
 

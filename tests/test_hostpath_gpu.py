@@ -131,6 +131,65 @@ def test_pinned_fir_call_other_plans(oracle, dtype, M, L):
         xin.free(); yout.free()
 
 
+@pytest.mark.parametrize("scalar", [1, 4, 0])
+def test_link_bound_launch_shapes_return_the_same_bits(scalar):
+    """A host-pointer call on PAGE-LOCKED memory takes the link-bound launch shape (pcx_internal.hpp LINK-BOUND LAUNCHES: 32 / 64 blocks for
+    the grid-stride maps, 48 workgroups for the persistent block kernels); the same call on pageable memory is staged and takes the
+    device-resident shape.  Same kernels, same per-element arithmetic: every entry point must return the same bits either way -- odd
+    lengths, so that the last block of either grid is ragged."""
+    from tests.util import rand_stream
+    rng = np.random.default_rng(100 + scalar)
+    dt = device.NP_SCALAR[scalar]
+    n = (1 << 20) + 12347
+    x = rand_stream(rng, scalar, n, True, amp=20000)
+    x2 = rand_stream(rng, scalar, n, True, amp=20000)
+    px, px2 = Pinned((n, 2), dt), Pinned((n, 2), dt)
+    po, po1 = Pinned((n, 2), dt), Pinned((n,), dt)
+    pre, pim = Pinned((n,), dt), Pinned((n,), dt)
+    try:
+        px.a[:] = x
+        px2.a[:] = x2
+        for name, pinned_call, plain_call in (
+                ("rotate", lambda: device.rotate(px.a, 0.7, out=po.a), lambda: device.rotate(x, 0.7)),
+                ("scale", lambda: device.scale(px.a, 0.3337, True, out=po.a), lambda: device.scale(x, 0.3337, True)),
+                ("conj", lambda: device.conj(px.a, out=po.a), lambda: device.conj(x)),
+                ("abs", lambda: device.abs_(px.a, True, out=po1.a), lambda: device.abs_(x, True)),
+                ("angle", lambda: device.angle(px.a, out=po1.a), lambda: device.angle(x)),
+                ("arith MUL", lambda: device.arith("MUL", px.a, px2.a, True, out=po.a), lambda: device.arith("MUL", x, x2, True))):
+            got = np.array(pinned_call())
+            want = plain_call()
+            assert np.array_equal(got, want, equal_nan=True), name
+        re, im = device.split_complex(px.a, re=pre.a, im=pim.a)
+        wre, wim = device.split_complex(x)
+        assert np.array_equal(re, wre) and np.array_equal(im, wim)
+        assert np.array_equal(device.combine_complex(pre.a, pim.a, out=po.a), device.combine_complex(wre, wim))
+        # carried state across two calls each way
+        a, b = device.FreqDemod("complex_" + dt.__name__), device.FreqDemod("complex_" + dt.__name__)
+        h = n // 2
+        got = np.concatenate([np.array(a.process(px.a[:h], out=po1.a[:h])), np.array(a.process(px.a[h:], out=po1.a[h:]))])
+        want = np.concatenate([b.process(x[:h]), b.process(x[h:])])
+        assert np.array_equal(got, want), "freq_demod"
+        if scalar == 1:
+            ch = device.FmChain(); ch.set_phase(0.7); ch.set_taps(tp.c4_taps(), False)
+            c, p = C.c_size_t(), C.c_size_t()
+            L = _lib.load()
+            m = n - 126
+            _lib.check(L.pcx_fmchain_process(ch._h, px.a.ctypes.data, n, po1.a.ctypes.data, m, C.byref(c), C.byref(p)))
+            assert (c.value, p.value) == (m, m)
+            got = np.array(po1.a[:m])
+            ch.reset()
+            y = np.empty((m,), np.float32)
+            _lib.check(L.pcx_fmchain_process(ch._h, x.ctypes.data, n, y.ctypes.data, m, C.byref(c), C.byref(p)))
+            assert np.array_equal(got, y), "fm chain"
+            fft = device.Fft("complex_float32", 4096, False)
+            nf = n // 4096
+            _lib.check(L.pcx_fft_transform(fft._h, px.a.ctypes.data, po.a.ctypes.data, nf))
+            assert np.array_equal(po.a[:nf * 4096], fft.transform(x[:nf * 4096])), "fft"
+    finally:
+        for b in (px, px2, po, po1, pre, pim):
+            b.free()
+
+
 def test_the_drained_form_under_the_diagnostic_library():
     """the same tests, every call drained in chunks (libpcx_hip_diag.so reads PCX_DRAIN_FROM / PCX_DRAIN_CHUNK; the product never drains)"""
     if os.environ.get("PCX_HOSTPATH_INNER"):

@@ -240,7 +240,13 @@ public:
         return domain == kDomain ? deviceManager("generic") : pinnedManager("generic");
     }
 #else
-    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }
+    // Inside Pothos every edge is page-locked HOST memory.  An input port whose upstream block is one of this module's (its port domain
+    // is ours) ABDICATES -- a null manager: that block's output manager already hands out page-locked slabs, and two custom managers on
+    // one edge make the topology insert a copier block, a CPU memcpy per buffer [ext: Topology commit, domain / manager rectification].
+    pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
+    {
+        return domain == kDomain ? pcxfw::BufferManager::Sptr() : pinnedManager("generic");
+    }
     pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }
 #endif
 };

@@ -718,3 +718,44 @@ def test_host_register_mapping_leaves_private_memory_alone():
         _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base + 4096)))      # not the base of a range this library locked
     _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base)))
     circ.close()
+
+
+def test_fir_block_follows_a_framework_that_reallocates_its_circular_buffer(oracle):
+    """the port's address leaves what the block has page-locked (the framework re-allocated: a topology re-commit) -- the new mapping
+    is locked on first sight, the block keeps at most four ranges (the oldest is unlocked), and results stay the reference's on
+    every one of six buffers in turn, including one that is seen again after it has been evicted"""
+    import ctypes as C
+
+    from pothoscomms_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(12)
+    K = 63
+    taps = (rng.normal(size=K) + 1j * rng.normal(size=K)) / 8
+    blk = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    blk.call("setTaps", taps)
+    blk.activate()
+    n = 40000
+    circs = [B.CircularBuffer(1 << 20) for _ in range(6)]
+    kind = C.c_int()
+
+    def locked(c):
+        _lib.check(L.pcx_pointer_kind(C.c_void_p(c.base + 64), C.byref(kind)))
+        return kind.value == 1
+
+    for i in list(range(6)) + [0]:
+        c = circs[i]
+        x = rand_stream(rng, 1, n, True)
+        off = (c.size // 8 - 1000) * 8 if i % 2 else 4096 * 8           # every other window across the wrap
+        win = c.view(off, n * 8, np.float32).reshape(-1, 2)
+        win[:] = x
+        ref = oracle.Fir(1, True, True); ref.set_taps(taps); ref.activate()
+        y, cc, p, r, _ = blk.work(win, n)
+        ry, rc, rp, rr = ref.work(x, n)
+        assert (cc, p, r) == (rc, rp, rr) and nerr(y, ry) <= TOL, i
+        assert locked(c), i
+    assert sum(locked(c) for c in circs) == 4                           # never more than four ranges held
+    assert locked(circs[0]) and not locked(circs[1]) and not locked(circs[2])        # 0 came back (evicting 3's predecessor ...), the oldest went
+    blk.close()
+    assert not any(locked(c) for c in circs)
+    for c in circs:
+        c.close()

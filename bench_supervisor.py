@@ -76,7 +76,11 @@ def session_dir():
         return base
     ppid = os.getppid()
     key = "%d_%s_%s" % (ppid, _proc_start_time(ppid), os.environ.get("MASTER_PORT", "0"))
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "pcx_bench_" + key)
+    # the first of these that can be written to (the same answer on every rank of a node: they share the file system and the user)
+    for root in (os.environ.get("TMPDIR"), "/tmp", "/dev/shm", os.path.dirname(os.path.abspath(__file__))):
+        if root and os.path.isdir(root) and os.access(root, os.W_OK | os.X_OK):
+            return os.path.join(root, "pcx_bench_" + key)
+    return os.path.join("/tmp", "pcx_bench_" + key)
 
 
 def _write_atomic(path, text):

@@ -46,9 +46,11 @@ ATTEMPTS = [
 # seconds of SILENCE (no heartbeat, no other stderr line) a child is allowed, by the phase its last heartbeat named.  The first import of
 # torch on a fresh box pages the image in (1-2 minutes for one process; eight at once share the disk); RCCL brings its communicator and
 # its peer connections up inside the first collective.  PCX_BENCH_WATCHDOG_S overrides every limit (the tests use a few seconds).
-SILENCE_LIMITS = {None: 600.0, "started": 600.0, "torch imported": 300.0, "process group up": 300.0}
-SILENCE_DEFAULT = 180.0
-ATTEMPT_BUDGET_S = 1500.0           # an attempt that is still running after this long is stopped whatever it says
+# A healthy run passes every phase in seconds (the communicator of eight ranks: well under a minute); the limits are what a HUNG attempt costs
+# before the next one starts, so they are kept as short as a slow box allows: three hung attempts in a row end inside ~12 minutes.
+SILENCE_LIMITS = {None: 420.0, "started": 420.0, "torch imported": 150.0, "process group up": 150.0}
+SILENCE_DEFAULT = 90.0
+ATTEMPT_BUDGET_S = 900.0            # an attempt that is still running after this long is stopped whatever it says
 RESULT_GRACE_S = 20.0               # teardown time a child gets once rank 0's line is in hand
 PEER_FAILED_GRACE_S = 3.0           # time a child gets to finish by itself once another rank's failure is known
 

@@ -1057,6 +1057,10 @@ def main():
         import bench_supervisor
         raise SystemExit(bench_supervisor.supervise(sys.argv[1:], os.path.abspath(__file__)))
     _hb("started")
+    if os.environ.get("PCX_BENCH_TEST_RANK_ENV"):          # tests only: "rank:KEY=VALUE" -- ONE rank sees another environment than its peers
+        r_, kv = os.environ["PCX_BENCH_TEST_RANK_ENV"].split(":", 1)
+        if int(r_) == rank and int(os.environ.get("PCX_BENCH_ATTEMPT", "1")) == 1:
+            os.environ[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
 
     import numpy as np
     import torch

@@ -363,3 +363,28 @@ def test_bench_and_its_supervisor_never_replace_the_process():
         src = open(os.path.join(ROOT, f)).read()
         code = "\n".join(ln.split("#")[0] for ln in src.splitlines() if not ln.lstrip().startswith(('"', "#")))
         assert not re.search(r"\bos\.exec[lv]p?e?\s*\(|\bos\.spawn|\bexecv\s*\(", code), f
+
+
+def test_supervised_bench_ranks_that_disagree_about_the_form_of_the_pass_abort_the_attempt():
+    """part of what selects the collective branches comes from each rank's OWN environment.  Rank 1 alone sees
+    PCX_STREAM_TWO_LAUNCH=1 in attempt 1: the ranks compare the form of the pass before their first step, refuse the mismatch (instead of
+    hanging in a collective only some of them enter), and the conservative attempt -- where every rank has the same switches -- yields the line"""
+    r, lines = _bench_standin({"PCX_BENCH_TEST_RANK_ENV": "1:PCX_STREAM_TWO_LAUNCH=1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    out = lines[0]
+    _is_flagged_standin_line(out, 2)
+    assert out["config"]["attempt"] == 2
+    assert "disagree about the form of the pass" in out["config"]["fallback_reason"][0]
+
+
+def test_supervised_bench_a_gate_timeout_in_setup_switches_every_rank_to_two_launches():
+    """a gate timeout reported by ONE rank during the setup passes (pretended here: PCX_BENCH_TEST_GATE_TIMEOUT) is all-reduced and every rank
+    switches to the two-launch pass for the timed region, inside the first attempt; the line says so"""
+    r, lines = _bench_standin({"PCX_BENCH_TEST_GATE_TIMEOUT": "1"}, gpus=3, launcher="torchrun")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = lines[0]
+    _is_flagged_standin_line(out, 3)
+    c = out["config"]
+    assert c["attempt"] == 1 and "FALLBACK" in c["halo_scheme"] and "timed out" in c["halo_scheme"]
+    assert any("a gated launch timed out" in w for w in c["fallback_reason"]) and "retimed" not in c

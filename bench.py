@@ -1029,6 +1029,22 @@ def measure_host_path(args, cpu):
                         "note": "the kernel reads and writes the host buffers in place over PCIe (zero-copy both ways); a copy-engine pipeline was measured "
                                 "and is slower below ~100 MiB per call (profiles/r05/pcie_lab.txt, drain_ab.txt)"},
            "calls": calls}
+    # the same loop from a plain C process on the SYSTEM HIP runtime -- what a Pothos process is (this one runs on torch's bundled runtime):
+    # examples/c_block_path, built by __graft_entry__.build(); a child process, started and waited for
+    exe = os.path.join(ROOT, "examples", "c_block_path")
+    if os.path.exists(exe):
+        import subprocess
+        try:
+            r = subprocess.run([exe, "brief"], capture_output=True, text=True, timeout=120)
+            rows = [ln.split() for ln in r.stdout.splitlines() if len(ln.split()) == 3]
+            if r.returncode == 0 and rows:
+                out["plain_c_process"] = {
+                    "%d_samples_per_call" % int(n): {"pinned_port_buffers": {"ms_per_call": round(float(a) * 1e3, 4), "Msamples_per_s": round(int(n) / float(a) / 1e6, 1)},
+                                                     "circular_input_page_locked_in_place": {"ms_per_call": round(float(b) * 1e3, 4), "Msamples_per_s": round(int(n) / float(b) / 1e6, 1)}}
+                    for n, a, b in rows}
+                out["plain_c_process"]["note"] = "examples/c_block_path.c: the same work() loop in a process on the system HIP runtime (no Python, no torch)"
+        except (OSError, subprocess.SubprocessError, ValueError):
+            pass
     if cpu:
         out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
         if "all_cores" in cpu:

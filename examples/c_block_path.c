@@ -57,8 +57,13 @@ static double run(size_t n, int nshards, int circular)
     return best;
 }
 
-int main(void)
+int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "brief")) {      /* machine-readable, for bench.py: samples per call, seconds per call on pinned slabs / on the circular input */
+        const size_t ns[] = {(size_t)1 << 20, (size_t)1 << 24};
+        for (int i = 0; i < 2; i++) printf("%zu %.9f %.9f\n", ns[i], run(ns[i], 1, 0), run(ns[i], 1, 1));
+        return 0;
+    }
     double up, down, both;
     CK(pcx_pcie_probe((size_t)128 << 20, 3, &up, &down, &both));
     printf("plain C process, system HIP runtime.  PCIe: H2D alone %.1f GB/s, D2H alone %.1f, both at once %.1f per direction\n", up, down, both);

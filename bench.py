@@ -979,7 +979,9 @@ def measure_host_path(args, cpu):
     # it: in a process on torch's bundled HIP runtime that is half of the sum (28 GB/s: the two transfers run one after the other),
     # in a plain C process on the system runtime 48 (examples/c_pcie_probe.c, profiles/r05/pcie_lab.txt) -- the in-place kernel,
     # which drives both directions at once itself, is above the first and below the second.
-    roof = min(up.value, down.value)
+    # (the FASTER of the two: the link is symmetric, and a copy engine that lags in one direction -- 30 GB/s D2H was seen on one box in one
+    # run, 57 in the next -- says nothing about what the link carries)
+    roof = max(up.value, down.value)
     K = 255
     calls = {}
     for n in (1 << 20, 1 << 24):
@@ -1025,7 +1027,7 @@ def measure_host_path(args, cpu):
                                           "how": "pcx_pcie_probe in this run: copy engines, 128 MiB of page-locked memory each way, two streams, "
                                                  "3 transfers back to back behind a warm-up one"},
                         "bytes_counted": "8 B per sample in and 8 B out over the wall time of a call; achieved = GB/s in EACH direction (both are busy "
-                                         "at once); peak = the slower direction of the link measured ALONE (full duplex: each direction's ceiling)",
+                                         "at once); peak = the link's per-direction rate measured ALONE, the faster of the two directions (symmetric link, full duplex: each direction's ceiling)",
                         "note": "the kernel reads and writes the host buffers in place over PCIe (zero-copy both ways); a copy-engine pipeline was measured "
                                 "and is slower below ~100 MiB per call (profiles/r05/pcie_lab.txt, drain_ab.txt)"},
            "calls": calls}

@@ -49,7 +49,7 @@ def pcie_roof(nbytes=128 << 20):
 
 if __name__ == "__main__":
     up, down, both = pcie_roof()
-    roof = min(up, down)          # each direction's ceiling: the link is full duplex (bench.py measure_host_path)
+    roof = max(up, down)          # each direction's ceiling: the link is symmetric and full duplex (bench.py measure_host_path)
     print("PCIe roof of this box (copy engines, 128 MiB): H2D alone %.1f GB/s, D2H alone %.1f, H2D || D2H on two streams %.1f per direction; roof = %.1f" % (up, down, both, roof))
     rng = np.random.default_rng(0)
     print("-- 1. C ABI, pcx_fir_process")

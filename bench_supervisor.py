@@ -181,9 +181,9 @@ class _Child:
             t.join(timeout=2)
 
 
-def _run_attempt(a, att, rank, world, sdir, argv, reasons, script):
-    """-> (ok, status text of this rank, result line or None)"""
-    tag = os.path.join(sdir, "a%d" % a)
+def _run_attempt(a, att, rank, world, sdir, argv, reasons, script, run_no=None):
+    """-> (ok, status text of this rank, result line or None).  a: the attempt (which mode), run_no: the run (names the files)"""
+    tag = os.path.join(sdir, "a%d" % (a if run_no is None else run_no))
     if rank == 0:
         _write_atomic(tag + ".port", str(_free_port()))
     got = _wait_for([tag + ".port"], 120.0)
@@ -295,8 +295,17 @@ def supervise(argv, script):
         attempts = [x for x in attempts if "PCX_BENCH_BACKEND" not in x["env"]]      # already host-staged: nothing further to fall back to
     reasons = []
     code = 1
+    run_no = 0
     for a, att in enumerate(attempts):
-        ok, status, line = _run_attempt(a, att, rank, world, sdir, argv, reasons, script)
+        # (the rendezvous port is free when rank 0's supervisor picks it and may be taken when the child binds it: that failure -- every
+        # supervisor reads the same verdict files, so they agree on it -- repeats the SAME attempt on another port, twice at most)
+        for again in range(3):
+            ok, status, line = _run_attempt(a, att, rank, world, sdir, argv, reasons, script, run_no)
+            run_no += 1
+            if ok or not any(m in status for m in ("EADDRINUSE", "Address already in use", "errno: 98", "address already in use")):
+                break
+            if rank == 0:
+                print("bench.py: the rendezvous port was taken before the ranks could bind it, the same attempt again", file=sys.stderr, flush=True)
         if ok:
             if rank == 0:
                 got = json.loads(line)

@@ -215,3 +215,29 @@ def test_the_runners_circular_buffer_is_one_object_mapped_twice():
     assert not [ln for ln in open("/proc/self/maps") if "pcx-circular" in ln]
     with pytest.raises(Exception):
         B.CircularBuffer(0)
+
+
+def test_host_register_mapping_looks_before_it_locks():
+    """pcx_host_register_mapping without a GPU: the /proc/self/maps logic runs on any box -- a window in private memory is left alone
+    (PCX_OK, nothing locked), a range beyond max_bytes likewise; only a shared double mapping reaches hipHostRegister, which on a box
+    without a device fails with a status, not a crash (with a device it locks: tests/test_blocks_gpu.py)"""
+    import ctypes as C
+
+    import torch
+
+    from pothoscomms_amd import _lib
+    L = _lib.load()
+    a = np.zeros(1 << 20, np.uint8)
+    base, n = C.c_void_p(), C.c_size_t()
+    assert L.pcx_host_register_mapping(C.c_void_p(a.ctypes.data), a.nbytes, 0, C.byref(base), C.byref(n)) == 0
+    assert not base.value and n.value == 0
+    circ = B.CircularBuffer(1 << 20)
+    assert L.pcx_host_register_mapping(C.c_void_p(circ.base), 4096, 1 << 20, C.byref(base), C.byref(n)) == 0 and not base.value    # 2 MiB > max_bytes
+    rc = L.pcx_host_register_mapping(C.c_void_p(circ.base + circ.size - 4096), 8192, 0, C.byref(base), C.byref(n))                  # a window across the wrap
+    if torch.cuda.is_available():
+        assert rc == 0 and base.value == circ.base and n.value == 2 * circ.size
+        assert L.pcx_host_unregister(C.c_void_p(circ.base)) == 0
+    else:
+        assert rc != 0 and not base.value and _lib.last_error()
+    assert L.pcx_host_unregister(C.c_void_p(circ.base + 4096)) != 0              # never the base of a range this library locked
+    circ.close()

@@ -21,9 +21,13 @@
  *     `out`.  Page-locked host memory (pcx_host_alloc, hipHostMalloc,
  *     hipHostRegister -- what the module's BufferManagers hand out) is
  *     processed IN PLACE: the kernels read and write it over PCIe, both
- *     directions at once.  Pageable memory is staged through a page-locked
- *     bounce buffer and a device workspace owned by the handle (CPU copy,
- *     pinned H2D, kernel, pinned D2H, CPU copy).
+ *     directions at once, on a launch shape of their own (a link-bound call
+ *     runs on a few dozen workgroups that walk many pieces each, so that one
+ *     piece's loads travel beside the previous piece's stores).  Memory the
+ *     FRAMEWORK owns can be page-locked where it lies (pcx_host_register,
+ *     pcx_host_register_mapping).  Pageable memory is staged through a
+ *     page-locked bounce buffer and a device workspace owned by the handle
+ *     (CPU copy, pinned H2D, kernel, pinned D2H, CPU copy).
  *   - *_create and the setters return with everything they zero or upload
  *     COMPLETE on the device: a handle can be used at once on any stream.
  *   - every handle owns a non-blocking stream for its host-pointer calls, so

@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true",
                     help="ranks over RCCL: do not time the pipelined against the unpipelined pass during setup, take the pipelined one")
     ap.add_argument("--native-submit-threads", action="store_true",
-                    help="--driver native: one thread per shard queues that shard's share of a pass (pcx_shard_set_submit_threads)")
+                    help="--driver native: one thread per device queues that device's share of a pass (pcx_shard_set_submit_threads)")
     ap.add_argument("--native-pingpong", action="store_true",
                     help="--driver native: two handles driven double-buffered (pcx_shard_post_exchange / pcx_shard_compute)")
     ap.add_argument("--no-pingpong", dest="pingpong", action="store_false",
@@ -459,7 +459,7 @@ def run_native(args):
                                      else "peer copies (hipMemcpyPeerAsync between the devices, one process)",
                    "parallelism": "overlap-save shards x%d, one gated launch per shard and pass" % G
                                   + ("; double-buffered over two handles: the halos of batch k+1 exchanged while batch k is filtered" if args.native_pingpong else "")
-                                  + ("; a submit thread per shard" if args.native_submit_threads else "")},
+                                  + ("; a submit thread per device" if args.native_submit_threads else "")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "fmchain_cf32_ols4096_kernel" if chain else "fir_cf32_ols4096_kernel", "avg_launch_ms": round(per * 1e3, 4),

@@ -427,9 +427,10 @@ PCX_API int pcx_shard_step(pcx_shard *s);
  * on a handle whose exchange is posted are PCX_ERR_STATE (the setters would change, or free, what the posted pass is about to use). */
 PCX_API int pcx_shard_post_exchange(pcx_shard *s);
 PCX_API int pcx_shard_compute(pcx_shard *s);
-/* enable != 0: one SUBMIT THREAD per shard.  Queueing a pass costs the host 16-20 us per shard from one thread (the cross-stream waits,
+/* enable != 0: one SUBMIT THREAD per DEVICE.  Queueing a pass costs the host 16-20 us per shard from one thread (the cross-stream waits,
  * the records, the gate signal, the launch): 135-165 us for eight shards against a pass of 195 us at 64 Mi samples per shard.  With
- * submit threads every shard's share of a pass is queued by a thread of its own, bound to its shard's device; pcx_shard_step /
+ * submit threads every device's share of a pass is queued by a thread of its own, bound to that device (several shards on one device:
+ * one thread, in shard order -- threads that call into ONE device's runtime only queue behind its locks); pcx_shard_step /
  * post_exchange / compute still return when everything is queued, and everything the header says about ordering holds unchanged.  The
  * threads spin for ~0.4 ms behind a pass (a stream of passes finds them awake) and sleep after that; they are joined by
  * pcx_shard_destroy or by enable = 0.  Off by default.  PCX_ERR_STATE while an exchange is posted. */

@@ -140,9 +140,8 @@ PhaseClock g_phase;
 // ---- submit threads ---------------------------------------------------------------------------------------------------------------
 // Queueing a pass costs the host 16-20 us PER SHARD from one thread (3-4 us per cross-stream wait, 7 per gated launch, the records, the
 // signal kernel: PCX_SHARD_TIMING in the diagnostic library itemises it) -- 135-165 us for eight shards against a pass of 195 us.
-// With submit threads every shard's share of a pass is queued by a thread of its own (each bound to its shard's device once), the
-// caller's thread posts the parts of the pass in turn and waits for each to be queued: what the host pays is the longest shard plus a
-// hand-over per part.  The threads spin for a while behind a part (a stream of passes finds them awake) and sleep after that.
+// With submit threads every DEVICE's share of a pass is queued by a thread of its own (bound to that device once), the caller's thread
+// posts the parts of the pass in turn and waits for each to be queued: what the host pays is the longest device plus a hand-over per part.  The threads spin for a while behind a part (a stream of passes finds them awake) and sleep after that.
 struct pcx_shard;
 static int shard_part(pcx_shard *s, int g, int part);
 struct ShardWorkers {
@@ -157,13 +156,24 @@ struct ShardWorkers {
     std::vector<std::string> err;
     static constexpr int kSpinUs = 400;      // how long a thread stays awake behind its last part (two passes of a 64 Mi-sample stream)
 
+    // ONE THREAD PER DEVICE: the shards of a device are queued by that device's thread, in shard order, part by part -- several threads
+    // calling into ONE device's runtime convoy on its locks (eight threads on one device: 146 -> 102 us to queue a pass on one box,
+    // 137 -> 403 on another, profiles/r05/README.md), threads on different devices do not share them
     void start(pcx_shard *s, int G, const std::vector<int> &dev)
     {
-        rc.assign(G, 0);
-        err.assign(G, std::string());
-        for (int g = 0; g < G; g++) th.emplace_back([this, s, g, d = dev[g]] { run(s, g, d); });
+        std::vector<int> devices;
+        for (int g = 0; g < G; g++)
+            if (std::find(devices.begin(), devices.end(), dev[g]) == devices.end()) devices.push_back(dev[g]);
+        rc.assign(devices.size(), 0);
+        err.assign(devices.size(), std::string());
+        for (size_t w = 0; w < devices.size(); w++) {
+            std::vector<int> mine;
+            for (int g = 0; g < G; g++)
+                if (dev[g] == devices[w]) mine.push_back(g);
+            th.emplace_back([this, s, w, mine, d = devices[w]] { run(s, (int)w, mine, d); });
+        }
     }
-    void run(pcx_shard *s, int g, int device)
+    void run(pcx_shard *s, int g, const std::vector<int> &shards, int device)
     {
         (void)hipSetDevice(device);
         unsigned seen = 0;
@@ -184,7 +194,8 @@ struct ShardWorkers {
             if (stop.load(std::memory_order_acquire)) return;
             seen = gen.load(std::memory_order_acquire);
             rc[g] = PCX_OK;
-            for (int q = part & 0xff; q <= (part >> 8) && rc[g] == PCX_OK; q++) rc[g] = shard_part(s, g, q);    // parts [first, last] of this shard
+            for (int q = part & 0xff; q <= (part >> 8) && rc[g] == PCX_OK; q++)      // parts [first, last], part by part, of this device's shards
+                for (size_t k = 0; k < shards.size() && rc[g] == PCX_OK; k++) rc[g] = shard_part(s, shards[k], q);
             if (rc[g] != PCX_OK) err[g] = pcx_last_error();
             pending.fetch_sub(1, std::memory_order_acq_rel);
         }
@@ -210,7 +221,7 @@ struct ShardWorkers {
 };
 
 struct pcx_shard {
-    std::unique_ptr<ShardWorkers> workers;        // pcx_shard_set_submit_threads: one thread per shard queues that shard's share of a pass
+    std::unique_ptr<ShardWorkers> workers;        // pcx_shard_set_submit_threads: one thread per device queues that device's share of a pass
     bool tables_ready = false;                    // every shard's tables are on its device (reset by whatever changes them)
     unsigned cur_pass = 0;                        // the pass number the parts of the pass in flight use
     int G = 0;

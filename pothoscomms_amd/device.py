@@ -482,7 +482,7 @@ class NodeStream(_Handle):
         _lib.check(_lib.load().pcx_shard_set_gated(self._h, int(bool(enable))))
 
     def set_submit_threads(self, enable):
-        """pcx_shard_set_submit_threads: one thread per shard queues that shard's share of a pass"""
+        """pcx_shard_set_submit_threads: one thread per device queues that device's share of a pass"""
         _lib.check(_lib.load().pcx_shard_set_submit_threads(self._h, int(bool(enable))))
 
     def set_chain(self, enable, phase=0.0):

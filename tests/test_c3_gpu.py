@@ -73,7 +73,7 @@ def _oracle_fir(o, taps, x, n, complex_taps=True):
 
 @pytest.mark.parametrize("submit_threads", [False, True], ids=["one_thread", "submit_threads"])
 def test_c3_fir_eight_shards_of_64Mi_on_one_device(oracle, submit_threads):
-    """submit_threads: every shard's share of a pass queued by a thread of its own (pcx_shard_set_submit_threads) -- same seams, same bits"""
+    """submit_threads: every device's share of a pass queued by a thread of its own (pcx_shard_set_submit_threads) -- same seams, same bits"""
     import torch
 
     from pothoscomms_amd import _lib, device, taps as tp

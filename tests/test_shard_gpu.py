@@ -643,7 +643,7 @@ def test_two_handles_double_buffered_the_next_batchs_halos_travel_beside_this_ba
 @pytest.mark.parametrize("chain", [False, True], ids=["fir", "chain"])
 @pytest.mark.parametrize("G,Cs", [(4, 9000), (3, 2080 * 3840), (8, 300000)])
 def test_submit_threads_queue_the_same_pass(oracle, G, Cs, chain):
-    """pcx_shard_set_submit_threads: a thread per shard queues that shard's share of every pass.  Several passes with the stream
+    """pcx_shard_set_submit_threads: a thread per device queues that device's share of every pass.  Several passes with the stream
     scattered again in between (the threads' waits and records against the caller's own transfers), halos poisoned: the outputs are
     bit for bit those of a handle driven from one thread, and shard 0's front matches the oracle."""
     from pothoscomms_amd import _lib, device, taps as tp

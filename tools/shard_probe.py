@@ -19,7 +19,7 @@ total = int(os.environ.get("PCX_PROBE_TOTAL", 64 * 1024 * 1024))     # PCX_PROBE
 h = tp.c1_taps()
 for G in [int(a) for a in sys.argv[1:]]:
     ns = device.NodeStream([0] * G, device.NodeStream.PEER_COPY if G > 1 else device.NodeStream.RCCL)
-    threads = bool(os.environ.get("PCX_PROBE_THREADS"))     # pcx_shard_set_submit_threads: a thread per shard queues its share of a pass
+    threads = bool(os.environ.get("PCX_PROBE_THREADS"))     # pcx_shard_set_submit_threads: a thread per device queues its share of a pass
     ns.set_submit_threads(threads)
     ns.set_taps(h)
     ns.configure(total // G)

@@ -1,17 +1,20 @@
-// fir_ols_f64.hip -- overlap-save /comms/fir_filter for complex_float64 streams (M = L = 1): the
-// y = IFFT(FFT(block) .* H) evaluation of the FIRFilter.cpp:294-300 convolution, as fir_ols_r16.hip does
-// it for complex_float32, on the double-precision radix-16 passes of fft_f64.hpp.
+// fir_ols_f64.hip -- overlap-save /comms/fir_filter for complex_float64 streams (M = L = 1), and on the same pipeline the
+// complex_int16 / complex_int8 streams (bit-exact) and the real float64 / int16 / int8 ones: the y = IFFT(FFT(block) .* H)
+// evaluation of the FIRFilter.cpp:294-300 convolution in double precision.
 //
-// Block geometry is the float kernels': Kov >= K-1 (a multiple of 16) outputs dropped per N-sample block,
-// block b's window starts pad = Kov-(K-1) samples before sample b*S, S = N - Kov.  Lane l holds
-// x[l + s*LPF]; a forward transform leaves X[l + k*LPF] in the lane, which is the next transform's
-// first-pass layout, so the spectrum is multiplied by the lane's 16 bins of H and inverse-transformed
-// (conj . FFT . conj) without leaving registers.  H (64 VGPRs) and the Ns = 256 pass's lane constants
-// (60 VGPRs) live in registers across the persistent block loop, the Ns = 16 table in LDS.
+// Block geometry is the float kernels': Kov >= K-1 (a multiple of 16) outputs dropped per N-sample block, block b's window
+// starts pad = Kov-(K-1) samples before sample b*S, S = N - Kov.
 //
-// Rounding: everything is double; the result differs from the reference's direct sum by a few 1e-16 of
-// the output scale (parity bar 1e-13).  Against the sliding-window kernel (K multiply-adds per output on
-// the 78 TFLOP/s f64 pipe) this is the faster form from a few tens of taps up (tools/sweep_fir_f64.py).
+// K <= 2049 (N = 4096): the IN-PLACE transform pair of fft_f64.hpp (ip4096): 4 barriers per block, a conflict-free image, H
+// (64 VGPRs) and six powers of the lane's pass-1 factor (24 VGPRs) in registers across the persistent block loop, the next
+// block's samples fetched ahead for the integer streams (16 VGPRs; a complex_float64 block would need 64), no scratch.
+// 2049 < K <= 4097 (N = 8192): the Stockham radix-16 passes of xform<13> as before (lane l holds x[l + s*LPF]; a forward
+// transform leaves X[l + k*LPF] in the lane, which is the next transform's first-pass layout).
+//
+// Rounding: everything is double; the result differs from the reference's direct sum by a few 1e-16 of the output scale
+// (parity bar 1e-13).  Against the sliding-window kernel (K multiply-adds per output on the 78 TFLOP/s f64 pipe) this is
+// the faster form from a few tens of taps up (tools/sweep_fir_f64.py).  Its roof is the FP64 vector pipe, not HBM: about
+// 1,500 double-precision instructions per 64-lane wave and 3,840-sample block against 4 (int16) to 32 (float64) bytes per sample.
 #include "fft_f64.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -469,27 +472,330 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
     return PCX_OK;
 }
 
+
+// --------------------------------------------------------------------------------- //
+// N = 4096 on the in-place transform pair (fft_f64.hpp, ip4096)
+// --------------------------------------------------------------------------------- //
+// Element types as the transform pair's kernels see them: a RAW register image of one sample (what a fetch-ahead keeps: one
+// dword for the integer streams), its conversion, and the store.  The integer stores: the double holds the exact integer
+// sum (StreamIo above); adding 1.5 * 2^52 leaves round-to-nearest-even(d) modulo 2^32 in the low dword of the sum -- one
+// v_add_f64 instead of the software double -> int64 conversion (|d| < 2^51: sums stay below 2^45 under the caller's bound).
+__device__ __forceinline__ int wrap_i32(double d) { return __double2loint(d + 6755399441055744.0); }
+template <int IO>
+struct IpIo;
+template <>
+struct IpIo<0> {
+    static constexpr int EB = 16;
+    static constexpr bool kAhead = false;
+    typedef u32x4 Raw;
+    template <int AUX> static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX); }
+    static __device__ __forceinline__ cd cvt(Raw t) { return as_cd(t); }
+    template <bool FLOORQ> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, cd y, QShift)
+    {
+        __builtin_amdgcn_raw_buffer_store_b128(as_u4(y), ws, voff, soff, kAuxStream);
+    }
+};
+template <>
+struct IpIo<1> {
+    static constexpr int EB = 4;
+    static constexpr bool kAhead = true;
+    typedef unsigned Raw;
+    template <int AUX> static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX); }
+    static __device__ __forceinline__ cd cvt(Raw t) { return cd{(double)(short)(t & 0xffffu), (double)(short)(t >> 16)}; }
+    template <bool FLOORQ> static __device__ __forceinline__ unsigned q(double d, QShift qs)
+    {
+        const int w = wrap_i32(d);
+        return (unsigned)(FLOORQ ? (w >> qs.shift) : from_q_bits<int>(w, qs)) & 0xffffu;
+    }
+    template <bool FLOORQ> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, cd y, QShift qs)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(q<FLOORQ>(y.x, qs) | (q<FLOORQ>(y.y, qs) << 16), ws, voff, soff, kAuxStream);
+    }
+};
+template <>
+struct IpIo<2> {
+    static constexpr int EB = 2;
+    static constexpr bool kAhead = true;
+    typedef unsigned short Raw;
+    template <int AUX> static __device__ __forceinline__ Raw load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, AUX); }
+    static __device__ __forceinline__ cd cvt(Raw t) { return cd{(double)(signed char)(t & 0xffu), (double)(signed char)((t >> 8) & 0xffu)}; }
+    template <bool FLOORQ> static __device__ __forceinline__ unsigned q(double d, QShift qs)
+    {
+        const short w = (short)wrap_i32(d);
+        return (unsigned)(FLOORQ ? (short)(w >> qs.shift) : from_q_bits<short>(w, qs)) & 0xffu;
+    }
+    template <bool FLOORQ> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, cd y, QShift qs)
+    {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(q<FLOORQ>(y.x, qs) | (q<FLOORQ>(y.y, qs) << 8)), ws, voff, soff, kAuxStream);
+    }
+};
+
+// the window of block b through ONE range-checked descriptor: it starts at the first sample inside the buffer and ends with the
+// window or the buffer, whichever comes first; lanes in front of it (block 0 when pad > 0: samples that only feed dropped outputs)
+// wrap their offset out of range and read 0, as does everything behind the stream's end.  Rows 0 and 15 of the window are shared
+// with the neighbouring blocks and keep the default cache policy, the rest is touched once.
+template <int IO>
+__device__ __forceinline__ void ip_fetch(typename IpIo<IO>::Raw (&raw)[16], const unsigned char *in, size_t in_elems, size_t b, size_t S, int pad, int idx2)
+{
+    typedef IpIo<IO> SIO;
+    constexpr int EB = SIO::EB;
+    const size_t shift = b * S >= (size_t)pad ? 0 : (size_t)pad - b * S;
+    const size_t first = b * S + shift - pad;
+    const size_t left = in_elems > first ? in_elems - first : 0;
+    const size_t want = (size_t)4096 - shift;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first * EB, (unsigned)((left < want ? left : want) * EB));
+    if (shift == 0) {
+        // the lane's offset once, the row in the instruction's scalar offset
+        const int voff = idx2 * EB;
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            raw[s] = (s == 0 || s == 15) ? SIO::template load<0>(rs, voff, s * 256 * EB) : SIO::template load<kAuxStream>(rs, voff, s * 256 * EB);
+    } else {
+        // block 0 of a filter with pad > 0: a lane in front of the buffer in row 0 is inside it from row 1 on, so the whole offset
+        // goes through the range check as one number (a wrapped lane offset stays out of range whatever scalar offset is added)
+#pragma unroll
+        for (int s = 0; s < 16; s++) raw[s] = SIO::template load<0>(rs, (idx2 + 256 * s - (int)shift) * EB, 0);
+    }
+}
+
+// the outputs of block b: u[q] = conj(y[256 bin_of(q) + idx2]); the first Kov of the block are dropped.  DECIM as in the N = 8192
+// kernel below: full-rate index n with (n + 1) % M == 0 is stored at (n + 1) / M - 1.
+template <int IO, bool DECIM, bool FLOORQ>
+__device__ __forceinline__ void ip_store(const cd (&u)[16], unsigned char *out, size_t n_out, size_t n_dec, unsigned M, unsigned magic, size_t b, size_t S,
+                                         int Kov, int idx2, QShift qs)
+{
+    typedef IpIo<IO> SIO;
+    constexpr int EB = SIO::EB;
+    if (DECIM) {
+        const size_t B0 = (b * S) / M;
+        const unsigned base = (unsigned)((b * S) - B0 * M);
+        const size_t room = n_dec > B0 ? n_dec - B0 : 0;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + B0 * EB, (unsigned)((room < (size_t)(4096 / 2 + 2) ? room : (size_t)(4096 / 2 + 2)) * EB));
+        const size_t full_left = n_out - b * S;           // full-rate outputs this block may produce
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = 256 * bin_of(q);
+            if (row + 255 < Kov) continue;
+            const int i = idx2 + row;
+            const unsigned t = base + (unsigned)(i - Kov) + 1u;
+            const unsigned qt = __umulhi(t, magic);
+            if (i >= Kov && (size_t)(i - Kov) < full_left && qt * M == t)
+                SIO::template store<FLOORQ>(ws, (int)((qt - 1u) * (unsigned)EB), 0, cd{u[q].x, -u[q].y}, qs);
+        }
+    } else {
+        const size_t room = n_out - b * S;
+        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * S * EB, (unsigned)((room < S ? room : S) * EB));
+        // outputs in front of Kov: the offset wraps, out of range, dropped.  (The row cannot ride in the scalar offset here: a lane
+        // offset that wrapped stays out of range whatever is added to it, tools/soffset_lab.hip, and the lanes in front of Kov in
+        // one row are valid in the next.)
+        const unsigned vbase = (unsigned)(idx2 - Kov) * (unsigned)EB;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = 256 * bin_of(q);
+            if (row + 255 < Kov) continue;                // whole row dropped: uniform skip
+            SIO::template store<FLOORQ>(ws, (int)(vbase + (unsigned)row * (unsigned)EB), 0, cd{u[q].x, -u[q].y}, qs);
+        }
+    }
+}
+
+template <int IO, bool DECIM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_cf64_ip_kernel(
+    const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, size_t n_dec, unsigned M, unsigned magic,
+    const double2 *__restrict__ Hspec, int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks, QShift qs)
+{
+    typedef IpIo<IO> SIO;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd *lds = reinterpret_cast<cd *>(smem_raw);
+    const int l = threadIdx.x;
+    const size_t S = (size_t)(4096 - Kov);
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const ip4096::Lane L = ip4096::make_lane(l);
+    typename SIO::Raw raw[16];
+    ip_fetch<IO>(raw, in, in_elems, b, S, pad, L.idx2);       // the first block's samples ahead of the tables
+    const cd *tab = reinterpret_cast<const cd *>(twtab);
+    if (l < 240) lds[ip4096::kT2 + l] = tab[l];               // first read behind the first exchange's barrier
+    ip4096::Pow pw;
+    pw.load(tab, L.idx2);
+    cd H[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) H[q] = reinterpret_cast<const cd *>(Hspec)[L.k0 + 256 * bin_of(q)];
+
+    for (;;) {
+        cd v[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) v[s] = SIO::cvt(raw[s]);
+        const size_t nb = b + gridDim.x;
+        if (SIO::kAhead && nb < nblocks) ip_fetch<IO>(raw, in, in_elems, nb, S, pad, L.idx2);   // lands during this block's transforms
+        ip4096::forward(v, lds, L, pw);
+        // u = conj(X .* H), in the natural register order the backward passes start from
+        cd u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const cd p = cmul(v[q], H[q]);
+            u[bin_of(q)] = cd{p.x, -p.y};
+        }
+        ip4096::backward(u, lds, L, pw);
+        if (IO != 0 && qs.mode == PCX_Q_FLOOR) ip_store<IO, DECIM, true>(u, out, n_out, n_dec, M, magic, b, S, Kov, L.idx2, qs);
+        else ip_store<IO, DECIM, false>(u, out, n_out, n_dec, M, magic, b, S, Kov, L.idx2, qs);
+        if (nb >= nblocks) break;
+        b = nb;
+        if (!SIO::kAhead) ip_fetch<IO>(raw, in, in_elems, b, S, pad, L.idx2);
+    }
+}
+
+template <int IO>
+int launch_ip(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, hipStream_t st)
+{
+    const size_t Km1 = K - 1;
+    const size_t Kov = (Km1 + 15) / 16 * 16;
+    if (Kov > 2048) { set_error("fir ols f64: K=%zu too long for 4096-sample blocks", K); return PCX_ERR_UNSUPPORTED; }
+    const size_t pad = Kov - Km1;
+    const size_t S = 4096 - Kov;
+    const size_t nblocks = (n_out + S - 1) / S;
+    const size_t lds = (size_t)ip4096::kLdsSlots * sizeof(cd);
+    auto k = M > 1 ? fir_cf64_ip_kernel<IO, true> : fir_cf64_ip_kernel<IO, false>;
+    const unsigned magic = M > 1 ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
+    PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // two workgroups per CU (73 KB of LDS each); about four blocks per workgroup whatever the call (pcx_internal.hpp rounds_grid:
+    // +5 % over one round at 64 Mi samples, tools/ab_oversub.sh)
+    const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * 2, 1) : rounds_grid(nblocks, 256 * 2, 4);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out, n_out / M, (unsigned)M, magic,
+                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks, qs);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
+// REAL streams on the in-place pair: two consecutive real blocks as the real and imaginary part of one complex block, as
+// fir_real_ols_kernel below.  H is re-read from L2 at the multiply (two windows' descriptors and offsets are live across the block).
+template <int IO, bool DECIM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_real_ip_kernel(
+    const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, const double2 *__restrict__ Hspec,
+    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real, size_t n_dec, unsigned M, unsigned magic, QShift qs)
+{
+    typedef RealIo<IO> RIO;
+    constexpr int EB = RIO::EB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd *lds = reinterpret_cast<cd *>(smem_raw);
+    const int l = threadIdx.x;
+    const size_t S = (size_t)(4096 - Kov);
+    const size_t nblocks = (nblocks_real + 1) / 2;
+    size_t b = blockIdx.x;
+    if (b >= nblocks) return;
+    const ip4096::Lane L = ip4096::make_lane(l);
+    const cd *tab = reinterpret_cast<const cd *>(twtab);
+    if (l < 240) lds[ip4096::kT2 + l] = tab[l];
+    ip4096::Pow pw;
+    pw.load(tab, L.idx2);
+    const cd *Hg = reinterpret_cast<const cd *>(Hspec) + L.k0;
+
+    for (; b < nblocks; b += gridDim.x) {
+        __amdgpu_buffer_rsrc_t rs[2];
+        int shift[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const size_t rb = 2 * b + h;
+            const size_t sh = rb * S >= (size_t)pad ? 0 : (size_t)pad - rb * S;
+            const size_t first = rb * S + sh - pad;
+            const size_t left = (rb < nblocks_real && in_elems > first) ? in_elems - first : 0;
+            const size_t want = (size_t)4096 - sh;
+            rs[h] = make_rsrc(in + first * EB, (unsigned)((left < want ? left : want) * EB));
+            shift[h] = (int)sh;
+        }
+        cd v[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            v[s] = cd{RIO::load(rs[0], (L.idx2 + 256 * s - shift[0]) * EB), RIO::load(rs[1], (L.idx2 + 256 * s - shift[1]) * EB)};
+        ip4096::forward(v, lds, L, pw);
+        const cd *Hb = Hg;
+        asm volatile("" : "+v"(Hb));   // keeps the loads inside the loop (they are loop-invariant and would be hoisted back into registers)
+        cd u[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const cd p = cmul(v[q], Hb[256 * bin_of(q)]);
+            u[bin_of(q)] = cd{p.x, -p.y};
+        }
+        ip4096::backward(u, lds, L, pw);
+        if (DECIM) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const size_t rb = 2 * b + h;
+                if (rb * S >= n_out) continue;                // uniform
+                const size_t B0 = (rb * S) / M;
+                const unsigned base = (unsigned)((rb * S) - B0 * M);
+                const size_t room = n_dec > B0 ? n_dec - B0 : 0;
+                const __amdgpu_buffer_rsrc_t wd = make_rsrc(out + B0 * EB, (unsigned)((room < (size_t)(4096 / 2 + 2) ? room : (size_t)(4096 / 2 + 2)) * EB));
+                const size_t full_left = n_out - rb * S;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int row = 256 * bin_of(q);
+                    if (row + 255 < Kov) continue;
+                    const int i = L.idx2 + row;
+                    const unsigned t = base + (unsigned)(i - Kov) + 1u;
+                    const unsigned qt = __umulhi(t, magic);
+                    if (i >= Kov && (size_t)(i - Kov) < full_left && qt * M == t)
+                        RIO::store(wd, (int)((qt - 1u) * (unsigned)EB), h == 0 ? u[q].x : -u[q].y, qs);
+                }
+            }
+        } else {
+            __amdgpu_buffer_rsrc_t ws[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const size_t rb = 2 * b + h;
+                const size_t room = rb * S < n_out ? n_out - rb * S : 0;
+                ws[h] = make_rsrc(out + (room ? rb * S : 0) * EB, (unsigned)((room < S ? room : S) * EB));
+            }
+            const unsigned vbase = (unsigned)(L.idx2 - Kov) * (unsigned)EB;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int row = 256 * bin_of(q);
+                if (row + 255 < Kov) continue;                // whole row dropped: uniform skip
+                // y = conj(u): block 2b is its real part, block 2b+1 its imaginary part
+                RIO::store(ws[0], (int)(vbase + (unsigned)row * (unsigned)EB), u[q].x, qs);
+                RIO::store(ws[1], (int)(vbase + (unsigned)row * (unsigned)EB), -u[q].y, qs);
+            }
+        }
+    }
+}
+
+template <int IO>
+int launch_real_ip(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, hipStream_t st)
+{
+    const size_t Km1 = K - 1;
+    const size_t Kov = (Km1 + 15) / 16 * 16;
+    if (Kov > 2048) { set_error("fir ols (real): K=%zu too long for 4096-sample blocks", K); return PCX_ERR_UNSUPPORTED; }
+    const size_t pad = Kov - Km1;
+    const size_t S = 4096 - Kov;
+    const size_t nblocks_real = (n_out + S - 1) / S;
+    const size_t nblocks = (nblocks_real + 1) / 2;
+    const size_t lds = (size_t)ip4096::kLdsSlots * sizeof(cd);
+    auto k = M > 1 ? fir_real_ip_kernel<IO, true> : fir_real_ip_kernel<IO, false>;
+    const unsigned magic = M > 1 ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
+    PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * 2, 1) : rounds_grid(nblocks, 256 * 2, 4);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out, (const double2 *)Hspec, (int)Kov,
+                       (int)pad, (const double2 *)tw, nblocks_real, n_out / M, (unsigned)M, magic, qs);
+    PCX_LAUNCH_CHECK();
+    return PCX_OK;
+}
+
 }  // namespace
 
-// log2n in {10 .. 13}; Hspec = FFT_N(h)/N in double, tw = make_tw_r16<double>(log2n) (pcx_api.hip).  io: 0 complex_float64,
+// log2n 12 (K <= 2049: the in-place kernels) or 13; Hspec = FFT_N(h)/N in double, natural bin order; tw = make_tw_ols64(log2n) (pcx_api.hip).  io: 0 complex_float64,
 // 1 complex_int16, 2 complex_int8 (h = the Q-format integer taps; see StreamIo).  n_out = full-rate outputs; M > 1 keeps one in M
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
                         const void *tw, int io, size_t M, QShift qs, hipStream_t st)
 {
     if (n_out == 0) return PCX_OK;
     if (M < 1 || M > 65535) { set_error("fir ols f64: decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
-#define PCX_OLS64_CASE(L2)                                                                                    \
-    case L2:                                                                                                  \
-        return io == 0   ? launch_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)                  \
-               : io == 1 ? launch_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)                  \
-                         : launch_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
-    switch (log2n) {
-        PCX_OLS64_CASE(10)
-        PCX_OLS64_CASE(11)
-        PCX_OLS64_CASE(12)
-        PCX_OLS64_CASE(13)
-    }
-#undef PCX_OLS64_CASE
+    if (log2n == 12)
+        return io == 0   ? launch_ip<0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+               : io == 1 ? launch_ip<1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+                         : launch_ip<2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
+    if (log2n == 13)
+        return io == 0   ? launch_ols<13, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+               : io == 1 ? launch_ols<13, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+                         : launch_ols<13, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
     set_error("fir ols f64: no plan for log2(N) = %d", log2n);
     return PCX_ERR_UNSUPPORTED;
 }
@@ -504,15 +810,16 @@ int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out
 {
     if (n_out == 0) return PCX_OK;
     if (M < 1 || M > 65535) { set_error("fir ols (real): decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
-#define PCX_REAL_CASE(L2)                                                                                   \
-    if (log2n == L2)                                                                                        \
-        return io == 0   ? launch_real_ols<L2, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)            \
-               : io == 1 ? launch_real_ols<L2, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)            \
-               : io == 2 ? launch_real_ols<L2, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)            \
-                         : launch_real_ols<L2, 3>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
-    PCX_REAL_CASE(12)
-    PCX_REAL_CASE(13)
-#undef PCX_REAL_CASE
+    if (log2n == 12)
+        return io == 0   ? launch_real_ip<0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+               : io == 1 ? launch_real_ip<1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+               : io == 2 ? launch_real_ip<2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+                         : launch_real_ip<3>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
+    if (log2n == 13)
+        return io == 0   ? launch_real_ols<13, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+               : io == 1 ? launch_real_ols<13, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+               : io == 2 ? launch_real_ols<13, 2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
+                         : launch_real_ols<13, 3>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
     set_error("fir ols (real): no plan for log2(N) = %d", log2n);
     return PCX_ERR_UNSUPPORTED;
 }

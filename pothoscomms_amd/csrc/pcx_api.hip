@@ -208,6 +208,25 @@ static std::vector<T> make_tw_r16(int log2n)
     return t;
 }
 
+// tables of the double-precision overlap-save kernels (fir_ols_f64.hip).  log2n == 12: the in-place transform pair of
+// fft_f64.hpp (ip4096) -- [15][16] W256^((p + 1) c), then [15][256] W4096^((p + 1) idx); otherwise the radix-16 family's.
+static std::vector<double> make_tw_ols64(int log2n)
+{
+    if (log2n != 12) return make_tw_r16<double>(log2n);
+    std::vector<double> t(2 * (15 * 16 + 15 * 256));
+    const double two_pi = 6.283185307179586476925286766559;
+    auto put = [&](size_t idx, long long num, long long den) {
+        const double turns = (double)(num % den) / (double)den;
+        t[2 * idx] = std::cos(-two_pi * turns);
+        t[2 * idx + 1] = std::sin(-two_pi * turns);
+    };
+    for (int p = 0; p < 15; p++)
+        for (int c = 0; c < 16; c++) put((size_t)p * 16 + c, (long long)(p + 1) * c, 256);
+    for (int p = 0; p < 15; p++)
+        for (int i = 0; i < 256; i++) put((size_t)240 + (size_t)p * 256 + i, (long long)(p + 1) * i, 4096);
+    return t;
+}
+
 // H[b] = sum_k h[k] exp(-j 2 pi b k / 4096) / 4096 (the 1/N of the inverse transform folded
 // in), accumulated in double, rounded once to float; natural bin order
 // `advance`: circular advance of the filter output by that many samples (H[b] *= exp(+j 2 pi b advance / N)) -- the
@@ -848,12 +867,7 @@ static int fir_ols64_block_log2(size_t K)
 {
     const int forced = (int)PCX_ENV_INT("PCX_OLS64_N", 0);
     int l2 = K <= 2049 ? 12 : 13;
-    switch (forced) {
-    case 1024: if (K <= 513) l2 = 10; break;
-    case 2048: if (K <= 1025) l2 = 11; break;
-    case 4096: if (K <= 2049) l2 = 12; break;
-    case 8192: l2 = 13; break;
-    }
+    if (forced == 8192) l2 = 13;
     return l2;
 }
 
@@ -961,7 +975,7 @@ static int fir_sync_tables(pcx_fir *h)
         for (size_t k = 0; k < h->K; k++) hq[k] = std::complex<double>(h->ctaps ? h->taps[2 * k] : h->taps[k], h->ctaps ? h->taps[2 * k + 1] : 0.0);
         h->ols_log2n = fir_ols64_block_log2(h->K);
         PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
-        PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
+        PCX_TRY(upload(h->tw4096, make_tw_ols64(h->ols_log2n)));
         h->have_ols64 = true;
     }
     h->have_ols_int = false;
@@ -978,7 +992,7 @@ static int fir_sync_tables(pcx_fir *h)
         if (norm2 < 17592186044416.0) {   // 2^44
             h->ols_log2n = fir_ols64_block_log2(h->K);
             PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
-            PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
+            PCX_TRY(upload(h->tw4096, make_tw_ols64(h->ols_log2n)));
             h->have_ols_int = true;
         }
     }
@@ -1008,7 +1022,7 @@ static int fir_sync_tables(pcx_fir *h)
         }
         if (ok) {
             PCX_TRY(upload(h->HrowsD, rows));
-            PCX_TRY(upload(h->tw4096, make_tw_r16<double>(12)));
+            PCX_TRY(upload(h->tw4096, make_tw_ols64(12)));
             h->ols_log2n = 12;
             h->have_interp64 = true;
         }
@@ -1039,7 +1053,7 @@ static int fir_sync_tables(pcx_fir *h)
         }
         if (ok) {
             PCX_TRY(upload(h->HrowsD, rows));
-            PCX_TRY(upload(h->tw4096, make_tw_r16<double>(12)));
+            PCX_TRY(upload(h->tw4096, make_tw_ols64(12)));
             h->ols_log2n = 12;
             h->have_interp_real = true;
         }
@@ -1059,7 +1073,7 @@ static int fir_sync_tables(pcx_fir *h)
         if (h->scalar == PCX_F64 || h->scalar == PCX_F32 || norm2 < 17592186044416.0) {   // integers: ||h_q||_2 < 2^22 keeps the rounded sums exact
             h->ols_log2n = h->K <= 2049 ? 12 : 13;
             PCX_TRY(upload(h->Hspec, make_hspec<double>(hq, (size_t)1 << h->ols_log2n)));
-            PCX_TRY(upload(h->tw4096, make_tw_r16<double>(h->ols_log2n)));
+            PCX_TRY(upload(h->tw4096, make_tw_ols64(h->ols_log2n)));
             h->have_ols_real64 = true;
         }
     }

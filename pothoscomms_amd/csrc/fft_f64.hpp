@@ -142,7 +142,7 @@ constexpr int kRow = 272;                // slots between consecutive a
 constexpr int kImg = 16 * kRow;          // the image: 4352 slots
 constexpr int kT2 = kImg;                // [15][16] W256^((p + 1) c)
 constexpr int kLdsSlots = kImg + 240;
-constexpr int kTabT1 = 240;              // global table: [240) the T2 image, then [15][256] W4096^((p + 1) idx)
+constexpr int kTabT1 = 240;              // global table: [15][16] W256^((p + 1) c), then [15][256] W4096^((p + 1) idx)
 
 __device__ __forceinline__ void lds_barrier()
 {
@@ -153,7 +153,7 @@ __device__ __forceinline__ void lds_barrier()
 
 struct Lane {
     int b2, b1, b0;   // slot of the lane's element r = 0 in the patterns over a (stride 272), over b (17), over c (1)
-    int c1;           // the lane's c in the pattern over b: its column of the T2 table
+    int c1;           // the lane's c in the pattern over b
     int idx2;         // the lane's sample inside a 256-sample row in the pattern over a: 16 u + ((w - u) & 15)
     int k0;           // the lane's ka + 16 kb in the pattern over c: bin k0 + 256 kc
 };
@@ -163,64 +163,108 @@ __device__ __forceinline__ Lane make_lane(int l)
     return Lane{17 * u + c, kRow * u + w, kRow * u + 17 * w, w, 16 * u + c, u + 16 * w};
 }
 
-// the lane's w^1, w^2, w^3, w^4, w^8, w^12; the other nine powers are one product away
-struct Pow {
-    cd w1, w2, w3, w4, w8, w12;
-    __device__ __forceinline__ void load(const cd *tab, int idx2)
+// The per-lane factor sets.  Pass "over a": w^1 .. w^15, w = W4096^idx2 -- fifteen registers pairs (60 VGPRs) held across the
+// block loop.  Pass "over b": W256^(c kb), sixteen distinct columns for the whole workgroup: a [15][16] table in LDS, read in
+// front of the multiplies, five at a time.  What was tried instead (tools/f64_lab.hip has the reason it matters: at two waves
+// per SIMD the FP64 pipe issues one instruction per ~3.9 clocks and this kernel runs at 95 % of that, so only the instruction
+// COUNT moves it): both sets as six powers each (w^1, w^2, w^3, w^4, w^8, w^12) with the other nine one product away --
+// 144 more instructions per block on 1,420, 7 % slower; the LDS table read one entry at a time in front of each multiply,
+// as the compiler orders it by itself -- thirty exposed LDS latencies per block.
+struct LaneTw {
+    cd a[15];
+    int t2;        // slot of the lane's column of the table
+    __device__ __forceinline__ void load(const cd *tab, const Lane &L)
     {
-        const cd *t = tab + kTabT1 + idx2;
-        w1 = t[0 * 256]; w2 = t[1 * 256]; w3 = t[2 * 256]; w4 = t[3 * 256]; w8 = t[7 * 256]; w12 = t[11 * 256];
+#pragma unroll
+        for (int p = 0; p < 15; p++) a[p] = tab[kTabT1 + p * 256 + L.idx2];
+        t2 = kT2 + L.c1;
     }
-    __device__ __forceinline__ cd lo(int j) const { return j == 1 ? w1 : j == 2 ? w2 : w3; }
-    __device__ __forceinline__ cd hi(int i) const { return i == 1 ? w4 : i == 2 ? w8 : w12; }
-    __device__ __forceinline__ cd get(int k) const   // k = 1 .. 15, a constant after unrolling
+    // in front of the block loop: the waits for the table loads belong there (fir_cf64_ip_kernel)
+    __device__ __forceinline__ void opaque()
     {
-        if ((k & 3) == 0) return hi(k >> 2);
-        if (k < 4) return lo(k);
-        return cmul(hi(k >> 2), lo(k & 3));
+#pragma unroll
+        for (int p = 0; p < 15; p += 3)
+            asm volatile("" : "+v"(a[p].x), "+v"(a[p].y), "+v"(a[p + 1].x), "+v"(a[p + 1].y), "+v"(a[p + 2].x), "+v"(a[p + 2].y));
     }
 };
+// v[idx(i)] *= T2[i] for i = 1 .. 15, the table entries fetched five at a time (the scheduler may not pull the reads apart)
+template <typename IDX>
+__device__ __forceinline__ void mul_t2(cd (&v)[16], const cd *lds, int t2, IDX idx)
+{
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        cd t[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) t[j] = lds[t2 + (5 * g + j) * 16];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 5; j++) v[idx(5 * g + j + 1)] = cmul(v[idx(5 * g + j + 1)], t[j]);
+    }
+}
+constexpr int unbin(int k) { return 4 * (k & 3) + (k >> 2); }   // the register that holds bin k: bin_of(unbin(k)) == k
 
+// PART (timing-only instantiations of the diagnostic library, WRONG outputs): 0 = the pair as it is; 1 = without the four
+// s_barrier (every LDS access kept); 2 = butterflies and factor multiplies only (no exchange, no barrier, no table read).
+// tools/ip64_parts.sh, 255 taps, 64 Mi complex_int16 samples: 0.301 / 0.293 / 0.238 ms -- the arithmetic alone is four fifths of the
+// launch.  (Also built and measured equal within 1 %: every pass written out in issue order behind scheduling fences -- reads in
+// the order the first-stage butterflies consume them, each second-stage group's factor multiplies and four stores ahead of the
+// next group's arithmetic.  A ds_write_b128 takes its 13 clocks of the SIMD's register ports wherever it sits.)
+template <int PART>
+__device__ __forceinline__ void xbarrier() { if (PART == 0) lds_barrier(); }
 // forward: v[s] = x[256 s + idx2] on entry; X[k0 + 256 bin_of(q)] in v[q] on exit
-__device__ __forceinline__ void forward(cd (&v)[16], cd *lds, const Lane &L, const Pow &pw)
+template <int PART = 0>
+__device__ __forceinline__ void forward(cd (&v)[16], cd *lds, const Lane &L, const LaneTw &tw)
 {
     fft16_plain(v);
 #pragma unroll
-    for (int q = 1; q < 16; q++) v[q] = cmul(v[q], pw.get(bin_of(q)));
+    for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw.a[bin_of(q) - 1]);
+    if (PART != 2) {
 #pragma unroll
-    for (int q = 0; q < 16; q++) lds[L.b2 + kRow * bin_of(q)] = v[q];
-    lds_barrier();
+        for (int q = 0; q < 16; q++) lds[L.b2 + kRow * bin_of(q)] = v[q];
+        xbarrier<PART>();
 #pragma unroll
-    for (int s = 0; s < 16; s++) v[s] = lds[L.b1 + 17 * s];
+        for (int s = 0; s < 16; s++) v[s] = lds[L.b1 + 17 * s];
+    }
     fft16_plain(v);
+    if (PART != 2) {
+        mul_t2(v, lds, tw.t2, [](int k) { return unbin(k); });
 #pragma unroll
-    for (int q = 1; q < 16; q++) v[q] = cmul(v[q], lds[kT2 + (bin_of(q) - 1) * 16 + L.c1]);
+        for (int q = 0; q < 16; q++) lds[L.b1 + 17 * bin_of(q)] = v[q];
+        xbarrier<PART>();
 #pragma unroll
-    for (int q = 0; q < 16; q++) lds[L.b1 + 17 * bin_of(q)] = v[q];
-    lds_barrier();
+        for (int s = 0; s < 16; s++) v[s] = lds[L.b0 + s];
+    } else {
 #pragma unroll
-    for (int s = 0; s < 16; s++) v[s] = lds[L.b0 + s];
+        for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw.a[15 - q]);
+    }
     fft16_plain(v);
 }
 // the same passes backwards: u[kc] = Z[k0 + 256 kc] on entry (natural register order); DFT(Z)[256 bin_of(q) + idx2] in u[q] on exit
-__device__ __forceinline__ void backward(cd (&u)[16], cd *lds, const Lane &L, const Pow &pw)
+template <int PART = 0>
+__device__ __forceinline__ void backward(cd (&u)[16], cd *lds, const Lane &L, const LaneTw &tw)
 {
     fft16_plain(u);
+    if (PART != 2) {
 #pragma unroll
-    for (int q = 0; q < 16; q++) lds[L.b0 + bin_of(q)] = u[q];
-    lds_barrier();
+        for (int q = 0; q < 16; q++) lds[L.b0 + bin_of(q)] = u[q];
+        xbarrier<PART>();
 #pragma unroll
-    for (int s = 0; s < 16; s++) u[s] = lds[L.b1 + 17 * s];
+        for (int s = 0; s < 16; s++) u[s] = lds[L.b1 + 17 * s];
+        mul_t2(u, lds, tw.t2, [](int k) { return k; });
+    } else {
 #pragma unroll
-    for (int s = 1; s < 16; s++) u[s] = cmul(u[s], lds[kT2 + (s - 1) * 16 + L.c1]);
+        for (int s = 1; s < 16; s++) u[s] = cmul(u[s], tw.a[15 - s]);
+    }
     fft16_plain(u);
+    if (PART != 2) {
 #pragma unroll
-    for (int q = 0; q < 16; q++) lds[L.b1 + 17 * bin_of(q)] = u[q];
-    lds_barrier();
+        for (int q = 0; q < 16; q++) lds[L.b1 + 17 * bin_of(q)] = u[q];
+        xbarrier<PART>();
 #pragma unroll
-    for (int s = 0; s < 16; s++) u[s] = lds[L.b2 + kRow * s];
+        for (int s = 0; s < 16; s++) u[s] = lds[L.b2 + kRow * s];
+    }
 #pragma unroll
-    for (int s = 1; s < 16; s++) u[s] = cmul(u[s], pw.get(s));
+    for (int s = 1; s < 16; s++) u[s] = cmul(u[s], tw.a[s - 1]);
     fft16_plain(u);
 }
 }  // namespace ip4096

@@ -481,6 +481,20 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
 // sum (StreamIo above); adding 1.5 * 2^52 leaves round-to-nearest-even(d) modulo 2^32 in the low dword of the sum -- one
 // v_add_f64 instead of the software double -> int64 conversion (|d| < 2^51: sums stay below 2^45 under the caller's bound).
 __device__ __forceinline__ int wrap_i32(double d) { return __double2loint(d + 6755399441055744.0); }
+// fromQ under any of the three roundings (pcx_qformat.hpp from_q_bits) without a branch: floor + ((rem + add) >> n) with
+// add = 0 (FLOOR), 2^(n-1) (ROUND), the remainder mask for negative values (TOWARD_ZERO: + 1 iff q < 0 and rem != 0)
+struct QRound {
+    int shift;
+    unsigned mask, add_round, tz_mask;
+    __device__ __forceinline__ explicit QRound(QShift s)
+        : shift(s.shift), mask((1u << s.shift) - 1u), add_round(s.mode == PCX_Q_ROUND ? 1u << (s.shift - 1) : 0u),
+          tz_mask(s.mode == PCX_Q_TOWARD_ZERO ? (1u << s.shift) - 1u : 0u) {}
+    __device__ __forceinline__ int apply(int q) const
+    {
+        const unsigned rem = (unsigned)q & mask;
+        return (q >> shift) + (int)((rem + add_round + ((unsigned)(q >> 31) & tz_mask)) >> shift);
+    }
+};
 template <int IO>
 struct IpIo;
 template <>
@@ -505,7 +519,7 @@ struct IpIo<1> {
     template <bool FLOORQ> static __device__ __forceinline__ unsigned q(double d, QShift qs)
     {
         const int w = wrap_i32(d);
-        return (unsigned)(FLOORQ ? (w >> qs.shift) : from_q_bits<int>(w, qs)) & 0xffffu;
+        return (unsigned)(FLOORQ ? (w >> qs.shift) : QRound(qs).apply(w)) & 0xffffu;
     }
     template <bool FLOORQ> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, cd y, QShift qs)
     {
@@ -521,8 +535,8 @@ struct IpIo<2> {
     static __device__ __forceinline__ cd cvt(Raw t) { return cd{(double)(signed char)(t & 0xffu), (double)(signed char)((t >> 8) & 0xffu)}; }
     template <bool FLOORQ> static __device__ __forceinline__ unsigned q(double d, QShift qs)
     {
-        const short w = (short)wrap_i32(d);
-        return (unsigned)(FLOORQ ? (short)(w >> qs.shift) : from_q_bits<short>(w, qs)) & 0xffu;
+        const int w = (int)(short)wrap_i32(d);     // the 16-bit Q accumulator, sign-extended: QRound works on it as on a 32-bit one
+        return (unsigned)(FLOORQ ? (w >> qs.shift) : QRound(qs).apply(w)) & 0xffu;
     }
     template <bool FLOORQ> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, cd y, QShift qs)
     {
@@ -534,18 +548,20 @@ struct IpIo<2> {
 // window or the buffer, whichever comes first; lanes in front of it (block 0 when pad > 0: samples that only feed dropped outputs)
 // wrap their offset out of range and read 0, as does everything behind the stream's end.  Rows 0 and 15 of the window are shared
 // with the neighbouring blocks and keep the default cache policy, the rest is touched once.
-template <int IO>
-__device__ __forceinline__ void ip_fetch(typename IpIo<IO>::Raw (&raw)[16], const unsigned char *in, size_t in_elems, size_t b, size_t S, int pad, int idx2)
+template <int IO, bool ANY>
+__device__ __forceinline__ void ip_fetch(typename IpIo<IO>::Raw (&raw)[16], const unsigned char *in, size_t in_elems, size_t b, size_t nblocks, size_t S, int pad,
+                                         int idx2)
 {
     typedef IpIo<IO> SIO;
     constexpr int EB = SIO::EB;
     const size_t shift = b * S >= (size_t)pad ? 0 : (size_t)pad - b * S;
     const size_t first = b * S + shift - pad;
-    const size_t left = in_elems > first ? in_elems - first : 0;
+    const size_t left = (b < nblocks && in_elems > first) ? in_elems - first : 0;     // a block behind the last: an empty descriptor
     const size_t want = (size_t)4096 - shift;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + first * EB, (unsigned)((left < want ? left : want) * EB));
-    if (shift == 0) {
-        // the lane's offset once, the row in the instruction's scalar offset
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + (left ? first : 0) * EB, (unsigned)((left < want ? left : want) * EB));
+    if (!ANY || shift == 0) {
+        // the lane's offset once, the row in the instruction's scalar offset.  !ANY: the caller knows b >= 1 (shift == 0) and wants
+        // exactly sixteen loads, no branch: the fetch-ahead inside the block loop (fir_cf64_ip_kernel says why)
         const int voff = idx2 * EB;
 #pragma unroll
         for (int s = 0; s < 16; s++)
@@ -564,6 +580,9 @@ template <int IO, bool DECIM, bool FLOORQ>
 __device__ __forceinline__ void ip_store(const cd (&u)[16], unsigned char *out, size_t n_out, size_t n_dec, unsigned M, unsigned magic, size_t b, size_t S,
                                          int Kov, int idx2, QShift qs)
 {
+    // EVERY row is stored, by every lane, unconditionally: what must not land gets an offset outside the descriptor.  A store
+    // behind a branch (a dropped row skipped, a lane masked) makes the number of stores in flight unknown to the compiler, and
+    // the wait for the fetched-ahead samples at the foot of the block loop then has to drain them all.
     typedef IpIo<IO> SIO;
     constexpr int EB = SIO::EB;
     if (DECIM) {
@@ -572,15 +591,14 @@ __device__ __forceinline__ void ip_store(const cd (&u)[16], unsigned char *out, 
         const size_t room = n_dec > B0 ? n_dec - B0 : 0;
         const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + B0 * EB, (unsigned)((room < (size_t)(4096 / 2 + 2) ? room : (size_t)(4096 / 2 + 2)) * EB));
         const size_t full_left = n_out - b * S;           // full-rate outputs this block may produce
+        const unsigned left = full_left < 4096 ? (unsigned)full_left : 4096u;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int row = 256 * bin_of(q);
-            if (row + 255 < Kov) continue;
-            const int i = idx2 + row;
+            const int i = idx2 + 256 * bin_of(q);
             const unsigned t = base + (unsigned)(i - Kov) + 1u;
             const unsigned qt = __umulhi(t, magic);
-            if (i >= Kov && (size_t)(i - Kov) < full_left && qt * M == t)
-                SIO::template store<FLOORQ>(ws, (int)((qt - 1u) * (unsigned)EB), 0, cd{u[q].x, -u[q].y}, qs);
+            const bool keep = (unsigned)(i - Kov) < left && qt * M == t;       // (i < Kov wraps: not kept)
+            SIO::template store<FLOORQ>(ws, keep ? (int)((qt - 1u) * (unsigned)EB) : -1, 0, cd{u[q].x, -u[q].y}, qs);
         }
     } else {
         const size_t room = n_out - b * S;
@@ -590,15 +608,15 @@ __device__ __forceinline__ void ip_store(const cd (&u)[16], unsigned char *out, 
         // one row are valid in the next.)
         const unsigned vbase = (unsigned)(idx2 - Kov) * (unsigned)EB;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int row = 256 * bin_of(q);
-            if (row + 255 < Kov) continue;                // whole row dropped: uniform skip
-            SIO::template store<FLOORQ>(ws, (int)(vbase + (unsigned)row * (unsigned)EB), 0, cd{u[q].x, -u[q].y}, qs);
-        }
+        for (int q = 0; q < 16; q++)
+            SIO::template store<FLOORQ>(ws, (int)(vbase + (unsigned)(256 * bin_of(q)) * (unsigned)EB), 0, cd{u[q].x, -u[q].y}, qs);
     }
 }
 
-template <int IO, bool DECIM>
+// FLOORQ: the integer streams' fromQ is the plain arithmetic shift (PCX_Q_FLOOR, the default reading) -- a kernel of its own, not
+// a branch in front of the stores: two alternative store sequences that join make the compiler's count of the stores in flight
+// inexact, and its wait for the fetched-ahead loads at the foot of the loop then drains them.
+template <int IO, bool DECIM, bool FLOORQ, int PART = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_cf64_ip_kernel(
     const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, size_t n_dec, unsigned M, unsigned magic,
     const double2 *__restrict__ Hspec, int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks, QShift qs)
@@ -612,22 +630,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (b >= nblocks) return;
     const ip4096::Lane L = ip4096::make_lane(l);
     typename SIO::Raw raw[16];
-    ip_fetch<IO>(raw, in, in_elems, b, S, pad, L.idx2);       // the first block's samples ahead of the tables
+    ip_fetch<IO, true>(raw, in, in_elems, b, nblocks, S, pad, L.idx2);       // the first block's samples ahead of the tables
     const cd *tab = reinterpret_cast<const cd *>(twtab);
     if (l < 240) lds[ip4096::kT2 + l] = tab[l];               // first read behind the first exchange's barrier
-    ip4096::Pow pw;
-    pw.load(tab, L.idx2);
+    ip4096::LaneTw pw;
+    pw.load(tab, L);
     cd H[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) H[q] = reinterpret_cast<const cd *>(Hspec)[L.k0 + 256 * bin_of(q)];
-
-    for (;;) {
-        cd v[16];
+    // every table register is "used" once HERE: the waits for the table loads then sit in front of the loop.  Left to the first
+    // use inside it, they are vmcnt waits in the loop body, and from the second block on what such a wait drains is the previous
+    // block's stores (vmcnt counts loads and stores in one queue, oldest first).
+    pw.opaque();
 #pragma unroll
-        for (int s = 0; s < 16; s++) v[s] = SIO::cvt(raw[s]);
+    for (int q = 0; q < 16; q += 4)
+        asm volatile("" : "+v"(H[q].x), "+v"(H[q].y), "+v"(H[q + 1].x), "+v"(H[q + 1].y), "+v"(H[q + 2].x), "+v"(H[q + 2].y), "+v"(H[q + 3].x), "+v"(H[q + 3].y));
+
+    // the block's samples are converted at the FOOT of the loop, behind the stores: the fetch-ahead is older than the stores in
+    // the vmcnt queue, so the conversion waits for the loads alone.  (Converted at the head, the compiler carried the fetched
+    // registers over the back edge through copies behind s_waitcnt vmcnt(0): every block waited for its own stores.)
+    cd v[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) v[s] = SIO::cvt(raw[s]);
+    for (;;) {
+        // the next block's samples (nb >= gridDim.x >= 1: never block 0); behind the last block an empty descriptor, no branch: the
+        // compiler must be able to COUNT the loads and stores in flight, or its wait for these loads at the foot drains the stores too
         const size_t nb = b + gridDim.x;
-        if (SIO::kAhead && nb < nblocks) ip_fetch<IO>(raw, in, in_elems, nb, S, pad, L.idx2);   // lands during this block's transforms
-        ip4096::forward(v, lds, L, pw);
+        if (SIO::kAhead) ip_fetch<IO, false>(raw, in, in_elems, nb, nblocks, S, pad, L.idx2);
+        ip4096::forward<PART>(v, lds, L, pw);
         // u = conj(X .* H), in the natural register order the backward passes start from
         cd u[16];
 #pragma unroll
@@ -635,12 +665,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const cd p = cmul(v[q], H[q]);
             u[bin_of(q)] = cd{p.x, -p.y};
         }
-        ip4096::backward(u, lds, L, pw);
-        if (IO != 0 && qs.mode == PCX_Q_FLOOR) ip_store<IO, DECIM, true>(u, out, n_out, n_dec, M, magic, b, S, Kov, L.idx2, qs);
-        else ip_store<IO, DECIM, false>(u, out, n_out, n_dec, M, magic, b, S, Kov, L.idx2, qs);
+        ip4096::backward<PART>(u, lds, L, pw);
+        ip_store<IO, DECIM, FLOORQ>(u, out, n_out, n_dec, M, magic, b, S, Kov, L.idx2, qs);
         if (nb >= nblocks) break;
         b = nb;
-        if (!SIO::kAhead) ip_fetch<IO>(raw, in, in_elems, b, S, pad, L.idx2);
+        if (!SIO::kAhead) ip_fetch<IO, false>(raw, in, in_elems, b, nblocks, S, pad, L.idx2);
+#pragma unroll
+        for (int s = 0; s < 16; s++) v[s] = SIO::cvt(raw[s]);
     }
 }
 
@@ -654,7 +685,14 @@ int launch_ip(const void *in, size_t in_elems, void *out, size_t n_out, const vo
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
     const size_t lds = (size_t)ip4096::kLdsSlots * sizeof(cd);
-    auto k = M > 1 ? fir_cf64_ip_kernel<IO, true> : fir_cf64_ip_kernel<IO, false>;
+    const bool floorq = IO == 0 || qs.mode == PCX_Q_FLOOR;
+    auto k = M > 1 ? (floorq ? fir_cf64_ip_kernel<IO, true, true> : fir_cf64_ip_kernel<IO, true, IO == 0>)
+                   : (floorq ? fir_cf64_ip_kernel<IO, false, true> : fir_cf64_ip_kernel<IO, false, IO == 0>);
+#ifdef PCX_DIAG
+    // timing-only parts of the transform pair (fft_f64.hpp PART; wrong outputs): PCX_IP64_PART=1 no barriers, 2 arithmetic only
+    if (IO == 1 && M == 1 && floorq && PCX_ENV_INT("PCX_IP64_PART", 0) == 1) k = fir_cf64_ip_kernel<1, false, true, 1>;
+    if (IO == 1 && M == 1 && floorq && PCX_ENV_INT("PCX_IP64_PART", 0) == 2) k = fir_cf64_ip_kernel<1, false, true, 2>;
+#endif
     const unsigned magic = M > 1 ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
     PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // two workgroups per CU (73 KB of LDS each); about four blocks per workgroup whatever the call (pcx_internal.hpp rounds_grid:
@@ -685,9 +723,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const ip4096::Lane L = ip4096::make_lane(l);
     const cd *tab = reinterpret_cast<const cd *>(twtab);
     if (l < 240) lds[ip4096::kT2 + l] = tab[l];
-    ip4096::Pow pw;
-    pw.load(tab, L.idx2);
+    ip4096::LaneTw pw;
+    pw.load(tab, L);
     const cd *Hg = reinterpret_cast<const cd *>(Hspec) + L.k0;
+    pw.opaque();     // the waits for the table loads in front of the loop (fir_cf64_ip_kernel)
 
     for (; b < nblocks; b += gridDim.x) {
         __amdgpu_buffer_rsrc_t rs[2];

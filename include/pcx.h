@@ -124,6 +124,7 @@ PCX_API int pcx_get_qformat(pcx_qformat *q);
 /* ---- device plumbing (for hosts without their own HIP runtime binding) ---- */
 PCX_API int pcx_device_count(int *count);
 PCX_API int pcx_set_device(int ordinal);
+PCX_API int pcx_get_device(int *ordinal);   /* the calling thread's current device */
 PCX_API int pcx_dev_alloc(void **dptr, size_t bytes);
 PCX_API int pcx_dev_free(void *dptr);
 PCX_API int pcx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
@@ -160,19 +161,33 @@ PCX_API int pcx_host_free(void *hptr);
  *                                    circular buffer are one object mapped twice -- and page-locks all of it; *base / *len say what
  *                                    was locked (pass *base to pcx_host_unregister).  A range beyond max_bytes (0: 1 GiB), memory that
  *                                    is not a shared mapping (a heap arena, a stack: locking one would pin whatever else lives
- *                                    there) and memory already page-locked leave *base NULL and return PCX_OK: nothing to undo.
+ *                                    there) and memory somebody else page-locked leave *base NULL and return PCX_OK: nothing to undo.
+ * Registrations are COUNTED: a range this library holds already (two blocks on one buffer, one block under a second window)
+ * gets one more holder and the same *base / *len, and pcx_host_unregister only unlocks when the last holder has let go.
+ *   pcx_host_mapping_alive(base, &alive)
+ *                                    is what was mapped at base when it was locked (device and inode of the shared object, the whole
+ *                                    range, read-write) still mapped there?  The lock belongs to the MAPPING: after the framework has
+ *                                    unmapped a buffer, a new one at the same address is not page-locked, whatever the old entry says.
+ *                                    A holder asks when its block is activated, and lets go of what is no longer alive.
+ *   pcx_host_release_range(p, bytes) for the OWNER of the memory, in front of munmap: every registration of this library that overlaps
+ *                                    [p, p + bytes) is dropped, whoever holds it, and unlocked.
  * The /comms/fir_filter block calls pcx_host_register_mapping the first time it sees a pageable port buffer and whenever the
- * buffer's address leaves what it has locked, and unregisters in its destructor. */
+ * buffer's address leaves what it has locked; it lets go in deactivate() (a topology that is re-committed re-allocates its buffers
+ * between deactivate and activate) and in its destructor, and checks what it still holds in activate(). */
 PCX_API int pcx_host_register(void *ptr, size_t bytes);
 PCX_API int pcx_host_unregister(void *ptr);
 PCX_API int pcx_host_register_mapping(const void *p, size_t bytes, size_t max_bytes, void **base, size_t *len);
+PCX_API int pcx_host_mapping_alive(const void *base, int *alive);
+PCX_API int pcx_host_release_range(const void *p, size_t bytes);
 /* synthetic stream generator on the device: the same splitmix64 counter hash as
  * the oracle's orc_fill_uniform_f32 (uniform [-1,1), bit-identical values) */
 PCX_API int pcx_fill_uniform_f32_dev(float *dst_dev, size_t n_scalars, uint64_t seed, uint64_t offset, void *stream);
 /* measurement aid (no reference counterpart): the PCIe roof of this box as the copy engines see it.  `bytes` of page-locked host
  * memory each way, `reps` transfers queued back to back behind a warm-up one: host -> device alone, device -> host alone, and BOTH at
- * once on two streams of the probe's own -- GB/s per direction.  bench.py prices the host-pointer path (secondary.host_path, bound "pcie") on *both_gbs,
- * measured in the same run.  Allocates and frees 2 x bytes of host and of device memory; blocks until done. */
+ * once on two streams of the probe's own -- GB/s per direction.  bench.py prices the host-pointer path (secondary.host_path, bound "pcie") on the
+ * FASTER of the two directions alone (the link is full duplex: what one direction carries alone is the ceiling of each; *both_gbs is
+ * reported beside it, it depends on which HIP runtime the process loaded), measured in the same run.  Allocates and frees 2 x bytes
+ * of host and of device memory; blocks until done. */
 PCX_API int pcx_pcie_probe(size_t bytes, int reps, double *h2d_gbs, double *d2h_gbs, double *both_gbs);
 /* measurement aid (no reference counterpart): ONE wave on `stream` spins for spin_us microseconds and writes the shader clock it
  * ran at, in MHz, to *mhz_dev (shader cycles from s_memtime over the 100 MHz s_memrealtime).  Queued on a stream of its own beside

@@ -39,6 +39,8 @@ PCXB_API const char *pcxb_last_error(void);
 PCXB_API int pcxb_registry_has(const char *path);
 PCXB_API size_t pcxb_registry_count(void);
 PCXB_API const char *pcxb_registry_path(size_t i);
+/* how many arguments the factory registered at `path` takes; -1: no such path */
+PCXB_API long pcxb_registry_arity(const char *path);
 
 /* BlockRegistry::make(path, dtype, ...).  dtype is a Pothos DType name ("complex_float32"),
  * dimension its vector dimension.  The remaining factory arguments by block:
@@ -62,6 +64,10 @@ PCXB_API int pcxb_get_bool(pcxb_block *b, const char *name, int *out);
 PCXB_API int pcxb_get_string(pcxb_block *b, const char *name, char *out, size_t cap);
 PCXB_API int pcxb_get_taps(pcxb_block *b, const char *name, double *out, size_t cap_doubles, size_t *n, int is_complex);
 
+/* the calls the block registered (registerCall): their number, the i-th name, and how many arguments the named one takes (-1: none) */
+PCXB_API int pcxb_call_count(pcxb_block *b, size_t *count);
+PCXB_API int pcxb_call_name(pcxb_block *b, size_t i, char *out, size_t cap);
+PCXB_API long pcxb_call_arity(pcxb_block *b, const char *name);
 PCXB_API int pcxb_activate(pcxb_block *b);
 PCXB_API int pcxb_deactivate(pcxb_block *b);
 /* Topology::connect(src, "signal", dst, "slot") for signal -> setter wiring (the designer's "tapsChanged" ->

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pcx_version": (C.c_char_p, []),
     "pcx_device_count": (_i, [C.POINTER(_i)]),
     "pcx_set_device": (_i, [_i]),
+    "pcx_get_device": (_i, [C.POINTER(_i)]),
     "pcx_dev_alloc": (_i, [C.POINTER(_vp), _sz]),
     "pcx_dev_free": (_i, [_vp]),
     "pcx_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
@@ -77,6 +78,8 @@ SIGNATURES = {
     "pcx_host_register": (_i, [_vp, _sz]),
     "pcx_host_unregister": (_i, [_vp]),
     "pcx_host_register_mapping": (_i, [_vp, _sz, _sz, C.POINTER(_vp), _psz]),
+    "pcx_host_mapping_alive": (_i, [_vp, C.POINTER(_i)]),
+    "pcx_host_release_range": (_i, [_vp, _sz]),
     "pcx_fill_uniform_f32_dev": (_i, [_vp, _sz, C.c_uint64, C.c_uint64, _vp]),
     "pcx_clock_probe_dev": (_i, [_vp, C.c_uint, _vp]),
     "pcx_fir_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),

@@ -44,6 +44,12 @@ def load():
     L.pcxb_registry_count.restype = sz
     L.pcxb_registry_path.restype = cp
     L.pcxb_registry_path.argtypes = [sz]
+    L.pcxb_registry_arity.restype = C.c_long
+    L.pcxb_registry_arity.argtypes = [cp]
+    L.pcxb_call_count.argtypes = [vp, C.POINTER(sz)]
+    L.pcxb_call_name.argtypes = [vp, sz, cp, sz]
+    L.pcxb_call_arity.restype = C.c_long
+    L.pcxb_call_arity.argtypes = [vp, cp]
     L.pcxb_make.argtypes = [cp, cp, sz, cp, sz, i, C.POINTER(vp)]
     L.pcxb_destroy.argtypes = [vp]
     L.pcxb_call_double.argtypes = [vp, cp, C.c_double]
@@ -92,6 +98,11 @@ def _check(rc):
 def registry_paths():
     L = load()
     return sorted(L.pcxb_registry_path(i).decode() for i in range(L.pcxb_registry_count()))
+
+
+def registry_arity(path):
+    """how many arguments the factory registered at `path` takes (-1: no such path)"""
+    return int(load().pcxb_registry_arity(path.encode()))
 
 
 class Label:
@@ -196,7 +207,7 @@ class Block:
             _check(L.pcxb_get_sizes(self._h, n, v, 64, C.byref(cnt)))
             return [int(v[k]) for k in range(cnt.value)]
         if not args:   # getter
-            if name in ("getDecimation", "getInterpolation", "getNumInlineBuffers", "numTaps", "getShardPasses"):
+            if name in ("getDecimation", "getInterpolation", "getNumInlineBuffers", "numTaps", "getShardPasses", "getDevice", "getPortSlabBytes"):
                 v = C.c_size_t()
                 _check(L.pcxb_get_size(self._h, n, C.byref(v)))
                 return v.value
@@ -220,6 +231,18 @@ class Block:
         if isinstance(a, float):
             return _check(L.pcxb_call_double(self._h, n, a))
         return _check(L.pcxb_call_string(self._h, n, str(a).encode()))
+
+    def calls(self):
+        """{name: number of arguments} of the calls the block registered"""
+        L = load()
+        n = C.c_size_t()
+        _check(L.pcxb_call_count(self._h, C.byref(n)))
+        out = {}
+        buf = C.create_string_buffer(128)
+        for i in range(n.value):
+            _check(L.pcxb_call_name(self._h, i, buf, len(buf)))
+            out[buf.value.decode()] = int(L.pcxb_call_arity(self._h, buf.value))
+        return out
 
     def activate(self):
         _check(load().pcxb_activate(self._h))

@@ -132,9 +132,18 @@ struct BlockQFormat {
  * circular input buffer, FFT.cpp:54-59 for frame-sized output slabs).  Every block of this module asks for PINNED slabs
  * on both sides: the C ABI then runs its kernels directly on the port buffers over PCIe instead of staging them
  * (include/pcx.h; 43 GB/s each way against 28 staged, tools/pcie_lab.hip) -- a plain work() loop gets that without
- * the topology doing anything.  8 MiB x 4 per port: one call covers ~1 Mi complex_float32 samples.
+ * the topology doing anything.
+ *
+ * How large: every work() call costs about 60 us of launch, synchronisation and link ramp-up whatever it carries, so the
+ * slab size decides what share of the link a block reaches (complex_float32 FIR, 255 taps, examples/c_block_path.c and
+ * bench.py secondary.host_path): 8 MiB slabs (1 Mi samples per call) 4.1 Gsamples/s = 0.57 of the PCIe roof at 0.26 ms per
+ * call; 32 MiB (4 Mi samples) 5.1 = 0.70 at 0.82 ms; 128 MiB (16 Mi) 5.5 = 0.76 at 3.1 ms.  The default is 32 MiB: where the
+ * curve flattens.  It is a SETTING of every block (setPortSlabBytes, an initializer: the framework asks for the managers when
+ * the topology is committed) -- a latency-bound topology takes 1-8 MiB, a throughput-bound one 128.  Page-locked memory per
+ * block: slab size x the framework's buffers per port (4 by default) x the ports that bring their own manager.
  **********************************************************************/
-constexpr size_t kPortSlabBytes = 8u << 20;
+constexpr size_t kPortSlabBytes = 32u << 20;
+constexpr size_t kPortSlabMin = 64u << 10, kPortSlabMax = 1u << 30;
 #ifdef PCX_WITH_POTHOS
 // Pothos build: a pool of page-locked slabs behind Pothos::BufferManager's PUBLIC interface (init / empty / pop / push over
 // setFrontBuffer) -- the pool logic of the framework's own "generic" manager, which lives in PothosCore's library
@@ -178,16 +187,16 @@ private:
     std::deque<Pothos::ManagedBuffer> _ready;
 };
 // "circular": the FIR's sliding window needs its K-1 history contiguous in front of new samples, which the framework's own
-// circular manager provides by mapping its memory twice (FIRFilter.cpp:196-199 asks for exactly this).  That memory is pageable:
-// the C ABI stages it through its bounce buffer.  (Page-locking it afterwards with hipHostRegister is the upgrade path,
-// INTEGRATION.md 3.)  Anything else: page-locked slabs.
-static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
+// circular manager provides by mapping its memory twice (FIRFilter.cpp:196-199 asks for exactly this).  That memory is pageable
+// when the framework hands it over; the FIR block page-locks it where it lies the first time work() sees it (FIRFilter::pageLock
+// below, pcx_host_register_mapping), after which the kernel reads it in place like any pinned slab.  Anything else: page-locked slabs.
+static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes)
 {
     if (name == "circular") return Pothos::BufferManager::make("circular");
     return pcxfw::BufferManager::Sptr(new PinnedBufferManager(slabBytes));   // the scheduler calls init() with its own args
 }
 #else
-static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
+static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t slabBytes)
 {
     pcxfw::BufferManagerArgs args;
     args.bufferSize = slabBytes;
@@ -196,7 +205,7 @@ static pcxfw::BufferManager::Sptr pinnedManager(const std::string &name, size_t 
     return pcxfw::BufferManager::make(name, args);
 }
 // slabs in device memory, for an edge whose other end is a block of this module too
-static pcxfw::BufferManager::Sptr deviceManager(const std::string &name, size_t slabBytes = kPortSlabBytes)
+static pcxfw::BufferManager::Sptr deviceManager(const std::string &name, size_t slabBytes)
 {
     pcxfw::BufferManagerArgs args;
     args.bufferSize = slabBytes;
@@ -220,8 +229,82 @@ static pcxfw::BufferManager::Sptr deviceManager(const std::string &name, size_t 
 // fused /comms/fm_demod_chain block, tools/chain_path.py): the fused block is the remedy, not device pointers in
 // the framework's hands.
 static const char *const kDomain = "pcx-hip";
+
+// the calling thread's current device for the length of a scope (the C ABI binds a handle to the device current when it is
+// CREATED and runs the stateless maps on the device current when they are CALLED, include/pcx.h)
+class OnDevice {
+public:
+    explicit OnDevice(int device, const char *where = "DeviceBlock") : _prev(-1)
+    {
+        int cur = -1;
+        if (device < 0 || pcx_get_device(&cur) != PCX_OK || cur == device) return;
+        check(pcx_set_device(device), where);
+        _prev = cur;
+    }
+    ~OnDevice() { if (_prev >= 0) (void)pcx_set_device(_prev); }
+    OnDevice(const OnDevice &) = delete;
+    OnDevice &operator=(const OnDevice &) = delete;
+
+private:
+    int _prev;
+};
+
+/***********************************************************************
+ * What every block of this module has on top of its reference counterpart: the GPU it lives on and the size of its port slabs.
+ *
+ *   setDevice(device) / getDevice()   EXTENSION.  The ordinal of the GPU that carries the block (the reference has no devices;
+ *       SURVEY.md 5 plans the knob).  A block is born on the device current on the thread that runs its factory -- inside a Pothos
+ *       process that is device 0 -- and setDevice moves it: device handles are created again on the named device (also when that is
+ *       where the block is) and taps, phase, decimation ... pushed again; CARRIED state starts over as after activate() (FreqDemod's
+ *       previous sample, a FIR's position inside a burst is kept by the block itself).  The stateless
+ *       maps simply make the device current around their call.  work() never changes the calling thread's current device for longer
+ *       than the call.  Eight independent chains of one Pothos process on the eight GPUs of a node: setDevice(0 .. 7), nothing else
+ *       (the streams are independent: "split on frame / element boundaries, no halo").
+ *   setPortSlabBytes(bytes) / getPortSlabBytes()   EXTENSION.  The size of the page-locked slabs the block's buffer managers hand
+ *       out (kPortSlabBytes above); takes effect when the topology asks for the managers, i.e. it is an initializer.
+ **********************************************************************/
 class DeviceBlock : public Block {
 public:
+    DeviceBlock() : _device(-1), _slabBytes(kPortSlabBytes)
+    {
+        int cur = -1;
+        if (pcx_get_device(&cur) == PCX_OK) _device = cur;     // (no device in the process: the first handle's create says so)
+        this->registerCall(this, "setDevice", &DeviceBlock::setDevice);
+        this->registerCall(this, "getDevice", &DeviceBlock::getDevice);
+        this->registerCall(this, "setPortSlabBytes", &DeviceBlock::setPortSlabBytes);
+        this->registerCall(this, "getPortSlabBytes", &DeviceBlock::getPortSlabBytes);
+    }
+    virtual ~DeviceBlock() {}
+
+    void setDevice(const size_t device)
+    {
+        int n = 0;
+        check(pcx_device_count(&n), "DeviceBlock::setDevice()");
+        if (device >= (size_t)n)
+            throw InvalidArgumentException("DeviceBlock::setDevice(" + std::to_string(device) + ")", "the process sees " + std::to_string(n) + " device(s)");
+        // (also for the device the block is on already: "create the handles again here" is what the call means, whatever here is --
+        // which is how one GPU exercises the path)
+        const int from = _device;
+        _device = (int)device;
+        try {
+            OnDevice on(_device, "DeviceBlock::setDevice()");
+            this->rebind();
+        } catch (...) {
+            // getDevice() reports where the block IS: back to where it was (its handles there are still alive when rebind threw early)
+            _device = from;
+            try { OnDevice on(_device, "DeviceBlock::setDevice()"); this->rebind(); } catch (...) {}
+            throw;
+        }
+    }
+    size_t getDevice() const { return _device < 0 ? 0 : (size_t)_device; }
+    void setPortSlabBytes(const size_t bytes)
+    {
+        if (bytes < kPortSlabMin || bytes > kPortSlabMax)
+            throw InvalidArgumentException("DeviceBlock::setPortSlabBytes(" + std::to_string(bytes) + ")", "64 KiB ... 1 GiB");
+        _slabBytes = bytes;
+    }
+    size_t getPortSlabBytes() const { return _slabBytes; }
+
     // every port of a device block carries the module's domain
     pcxfw::InputPort *setupInput(size_t i, const DType &dt = DType()) { return Block::setupInput(i, dt, kDomain); }
     pcxfw::OutputPort *setupOutput(size_t i, const DType &dt = DType()) { return Block::setupOutput(i, dt, kDomain); }
@@ -233,11 +316,12 @@ public:
     pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
     {
         if (domain == kDomain) return pcxfw::BufferManager::Sptr();     // the upstream block of this module provides device slabs
-        return pinnedManager("generic");
+        return pinnedManager("generic", _slabBytes);
     }
     pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &domain)
     {
-        return domain == kDomain ? deviceManager("generic") : pinnedManager("generic");
+        OnDevice on(_device);       // (device slabs are allocated on the block's device)
+        return domain == kDomain ? deviceManager("generic", _slabBytes) : pinnedManager("generic", _slabBytes);
     }
 #else
     // Inside Pothos every edge is page-locked HOST memory.  An input port whose upstream block is one of this module's (its port domain
@@ -245,19 +329,136 @@ public:
     // one edge make the topology insert a copier block, a CPU memcpy per buffer [ext: Topology commit, domain / manager rectification].
     pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
     {
-        return domain == kDomain ? pcxfw::BufferManager::Sptr() : pinnedManager("generic");
+        return domain == kDomain ? pcxfw::BufferManager::Sptr() : pinnedManager("generic", _slabBytes);
     }
-    pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic"); }
+    pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &) { return pinnedManager("generic", _slabBytes); }
 #endif
+
+protected:
+    // create the block's device handles again on the (now current) device and push its settings; the stateless maps have none
+    virtual void rebind() {}
+    int _device;            // the ordinal the block lives on
+    size_t _slabBytes;
 };
 
 /***********************************************************************
- * /comms/fir_filter
+ * |PothosDoc FIR Filter
+ *
+ * A finite-impulse-response filter on the GPU: the element stream on input port 0 is convolved with the taps
+ * and leaves on output port 0, optionally resampled by interpolation / decimation (a polyphase filter: only the
+ * outputs that survive the decimator are computed).  Same results as the CPU block of PothosComms: floating-point
+ * streams within 1e-5 of the output scale, integer streams bit for bit.
+ *
+ * <h2>Bursts</h2>
+ * A burst that is marked inside the stream is filtered as a unit: its tail is flushed with zeros and no sample of the
+ * following burst enters the sums.  Mark a burst either with a label on its first element whose data is the burst's
+ * length in elements, or with a label on its last element.
+ *
+ * <h2>Device</h2>
+ * The filter runs as a frequency-domain overlap-save kernel from a few dozen taps up and as a time-domain kernel below;
+ * "Kernel" overrides the choice.  The block page-locks its input buffer where the framework allocated it and the kernels
+ * read and write the port buffers over PCIe in place.
+ *
+ * |category /Filter
+ * |keywords fir filter taps highpass lowpass bandpass gpu hip
+ * |alias /blocks/fir_filter
+ *
+ * |param dtype[Data Type] Element type of the input and of the output stream.
+ * |widget DTypeChooser(float=1,cfloat=1,int=1,cint=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param tapsType[Taps Type] Real taps, or complex taps (complex streams only).
+ * |option [Real] "REAL"
+ * |option [Complex] "COMPLEX"
+ *
+ * |param decim[Decimation] Keep one output in this many.
+ * |default 1
+ * |widget SpinBox(minimum=1)
+ *
+ * |param interp[Interpolation] Outputs per input element.
+ * |default 1
+ * |widget SpinBox(minimum=1)
+ *
+ * |param taps The filter taps.
+ * Type or paste them here, or leave the default and connect a FIR Designer's "tapsChanged" signal to the setTaps slot.
+ * |default [1.0]
+ *
+ * |param waitTaps[Wait Taps] Hold the stream back until taps have arrived through setTaps().
+ * For filters whose taps only ever come from a designer block at run time.
+ * |default false
+ * |preview valid
+ * |option [Enabled] true
+ * |option [Disabled] false
+ *
+ * |param frameStartId[Frame Start ID] ID of the label that marks the first element of a burst and carries its length.
+ * Empty: no burst handling by start label.
+ * |default ""
+ * |widget StringEntry()
+ * |preview valid
+ * |tab Labels
+ *
+ * |param frameEndId[Frame End ID] ID of the label that marks the last element of a burst.
+ * Empty: no burst handling by end label.
+ * |default ""
+ * |widget StringEntry()
+ * |preview valid
+ * |tab Labels
+ *
+ * |param kernel[Kernel] Which device kernel family serves the filter.
+ * AUTO picks by tap count and type; EXACT is the time-domain sum in the CPU block's operation order (bit-identical floats).
+ * |default "AUTO"
+ * |option [Auto] "AUTO"
+ * |option [Overlap-save FFT] "OLS_FFT"
+ * |option [Time domain] "DIRECT"
+ * |option [Time domain, CPU order] "EXACT"
+ * |preview disable
+ * |tab Device
+ *
+ * |param qformat[Q Format] Fixed-point reading of an integer filter: fractional bits, tap rounding, output rounding.
+ * "DEFAULT", or three words such as "HALF_Q,TRUNCATE,FLOOR".
+ * |default "DEFAULT"
+ * |widget StringEntry()
+ * |preview disable
+ * |tab Device
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param devices[Shard Devices] GPUs that share ONE stream, in stream order: each call is cut into as many contiguous shards,
+ * the tap-length halo travels between neighbours.  Empty: a single device (the one above); one ordinal: that device.
+ * complex_float32 without resampling.
+ * |default []
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/fir_filter(dtype, tapsType)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ * |setter setTaps(taps)
+ * |setter setDecimation(decim)
+ * |setter setInterpolation(interp)
+ * |setter setWaitTaps(waitTaps)
+ * |setter setFrameStartId(frameStartId)
+ * |setter setFrameEndId(frameEndId)
+ * |setter setKernel(kernel)
+ * |setter setQFormat(qformat)
+ * |setter setDevices(devices)
  **********************************************************************/
 class FIRFilter : public DeviceBlock {
 public:
     FIRFilter(const DType &dtype, int scalar, bool cplx, bool complexTaps)
-        : _complexTaps(complexTaps), _elemBytes(dtype.size()), M(1), L(1), K(1), _inputRequire(1),
+        : _scalar(scalar), _cplx(cplx), _complexTaps(complexTaps), _elemBytes(dtype.size()), M(1), L(1), K(1), _inputRequire(1),
           _waitTapsMode(false), _waitTapsArmed(false), _eobSampsLeft(0), _dtype(dtype), _h(nullptr)
     {
         check(pcx_fir_create(scalar, cplx ? 1 : 0, complexTaps ? 1 : 0, &_h), "FIRFilterFactory(" + dtype.toString() + ")");
@@ -297,7 +498,7 @@ public:
     {
         if (_sh) pcx_shard_destroy(_sh);
         pcx_fir_destroy(_h);
-        for (const auto &r : _locked) (void)pcx_host_unregister(r.first);
+        this->unlockAll();
     }
 
     void setTapsReal(const std::vector<double> &taps)
@@ -342,10 +543,7 @@ public:
     // reference's operation order: bit-identical floats, and the reference's locality for Inf/NaN samples)
     void setKernel(const std::string &name)
     {
-        const int algo = name == "AUTO" ? PCX_FIR_AUTO : name == "DIRECT" ? PCX_FIR_DIRECT : name == "OLS_FFT" ? PCX_FIR_OLS_FFT
-                       : name == "EXACT" ? PCX_FIR_EXACT : -1;
-        if (algo < 0) throw InvalidArgumentException("FIRFilter::setKernel(" + name + ")", "unknown kernel");
-        check(pcx_fir_set_algo(_h, algo), "FIRFilter::setKernel(" + name + ")");
+        check(pcx_fir_set_algo(_h, kernelCode(name)), "FIRFilter::setKernel(" + name + ")");
         _kernel = name;
     }
     std::string getKernel() const { return _kernel; }
@@ -364,16 +562,18 @@ public:
     std::string getFrameEndId() const { return _frameEndId; }
 
     // EXTENSION (not in the reference): one stream over several GPUs from this one block.  devices = the ordinals that carry a
-    // shard each, in stream order; an empty list (the default) is the single-device filter.  Each work() call then splits what
-    // the port holds into devices.size() contiguous shards, moves the K-1-sample halo between neighbouring devices (RCCL send/recv;
-    // peer copies when an ordinal repeats, i.e. several shards on one device -- a rehearsal) and filters every shard in ONE gated
-    // launch (pcx_shard_step).  complex_float32 with M = L = 1 outside burst mode; anything else, and calls that bring less
-    // than a shard's worth per device, run on the single-device handle: the totals of consume / produce are the reference's either way.
+    // shard each, in stream order.  An EMPTY list (the default) is the single-device filter on the block's device (setDevice); ONE
+    // ordinal is setDevice(that ordinal) -- the block moves there; two or more: each work() call splits what the port holds into
+    // devices.size() contiguous shards, moves the K-1-sample halo between neighbouring devices (RCCL send/recv; peer copies when an
+    // ordinal repeats, i.e. several shards on one device -- a rehearsal) and filters every shard in ONE gated launch (pcx_shard_step,
+    // DESIGN.md 6).  complex_float32 with M = L = 1 outside burst mode; anything else, and calls that bring less than a shard's worth
+    // per device, run on the single-device handle: the totals of consume / produce are the reference's either way.
     void setDevices(const std::vector<size_t> &devices)
     {
         // validate first: getDevices() reports the layout that is IN EFFECT, also after a call that threw
         if (devices.size() >= 2 && !(_dtype == DType("complex_float32")))
             throw InvalidArgumentException("FIRFilter::setDevices()", "a sharded stream is complex_float32");
+        if (devices.size() == 1) this->setDevice(devices[0]);      // (throws for an ordinal the process does not have)
         pcx_shard *sh = nullptr;
         if (devices.size() >= 2) {
             std::vector<int> d(devices.begin(), devices.end());
@@ -389,7 +589,8 @@ public:
         _shardShort = 0;
         if (_sh) this->pushTaps();
     }
-    std::vector<size_t> getDevices() const { return _devices; }
+    // the layout in effect: the shard devices, or the one device of a filter that was placed with setDevices({d})
+    std::vector<size_t> getDevices() const { return _devices.size() == 1 ? std::vector<size_t>(1, this->getDevice()) : _devices; }
     size_t getShardPasses() const { return _shardPasses; }
 
     // the sliding window needs its K-1 history contiguous in front of new samples -- in HBM when the upstream block is one of
@@ -397,18 +598,30 @@ public:
     pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
     {
 #ifndef PCX_WITH_POTHOS
-        if (domain == kDomain) return deviceManager("circular");
+        if (domain == kDomain) { OnDevice on(_device); return deviceManager("circular", _slabBytes); }
 #else
         (void)domain;
 #endif
-        return pinnedManager("circular");
+        return pinnedManager("circular", _slabBytes);
     }
 
     void activate()
     {
         _waitTapsArmed = _waitTapsMode;
         _eobSampsLeft = 0;
+        // what this block page-locked belongs to MAPPINGS, and a topology that was re-committed has re-allocated its buffers since: a
+        // range whose mapping is gone is let go of (a new buffer at the same address is pageable memory, whatever the old entry said)
+        for (size_t i = 0; i < _locked.size();) {
+            int alive = 0;
+            if (pcx_host_mapping_alive(_locked[i].first, &alive) == PCX_OK && alive) { i++; continue; }
+            (void)pcx_host_release_range(_locked[i].first, _locked[i].second);
+            _locked.erase(_locked.begin() + i);
+        }
+        _unlockable.clear();
     }
+    // the framework may unmap the port buffers once the block is inactive: nothing stays page-locked behind its back.  (Counted:
+    // another block of the module that runs on the same buffer keeps it locked, pcx_host_unregister.)
+    void deactivate() { this->unlockAll(); }
 
     void work()
     {
@@ -480,7 +693,7 @@ public:
             }
         }
         check(pcx_fir_process(_h, src, srcElems, outPort->buffer().template as<void *>(), outPort->elements(), &consumed, &produced),
-              "FIRFilter::work()");
+              "FIRFilter::work()");      // (the handle carries its device: no switch needed around the call)
 
         // K-1 elements stay in the input buffer as filter history
         if (_eobSampsLeft != 0) _eobSampsLeft -= consumed;
@@ -506,25 +719,33 @@ private:
     // the C ABI's bounce buffer by the CPU (0.9-1.2 Gsamples/s); page-locked where it lies, the kernel reads it in place over PCIe.
     // So: the first time a pageable buffer shows up -- and again whenever the port's address leaves what has been locked (the
     // framework re-allocated) -- the mapping that holds it is page-locked, both halves of the double mapping (pcx.h
-    // pcx_host_register_mapping: shared file mappings only, never a heap arena).  The destructor unlocks.  Memory that cannot be
-    // locked (not a shared mapping; the runtime refuses) is remembered and staged as before.
+    // pcx_host_register_mapping: shared file mappings only, never a heap arena; counted, so two blocks on one buffer share one
+    // lock).  deactivate() and the destructor let go; activate() checks that what is still held is still mapped.  Memory that
+    // cannot be locked (not a shared mapping; the runtime refuses) is remembered and staged as before.
     void pageLock(const void *p, size_t bytes)
     {
         if (bytes < kLockFrom) return;
         const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
         for (const auto &r : _locked) if ((uintptr_t)r.first <= lo && hi <= (uintptr_t)r.first + r.second) return;
         for (const auto &r : _unlockable) if (r.first <= lo && hi <= r.first + r.second) return;
-        int kind = PCX_PTR_PAGEABLE;
-        if (pcx_pointer_kind(p, &kind) != PCX_OK || kind != PCX_PTR_PAGEABLE) return;     // a pinned slab, a device slab
-        if (_locked.size() >= 4) {                      // the framework keeps re-allocating: drop the oldest range
-            // (the host-pointer entry points return with their result in place: no call of this block is reading the range)
-            (void)pcx_host_unregister(_locked.front().first);
-            _locked.erase(_locked.begin());
-        }
+        // (a range ANOTHER block of the module locked reads as page-locked here: pcx_host_register_mapping makes this block a holder
+        // of it too, so that the other block's destructor cannot unlock it under this one; a pinned or device slab of somebody else's
+        // comes back with *base NULL, nothing to hold)
         void *base = nullptr;
         size_t len = 0;
-        if (pcx_host_register_mapping(p, bytes, 0, &base, &len) == PCX_OK && base) _locked.emplace_back(base, len);
-        else {
+        if (pcx_host_register_mapping(p, bytes, 0, &base, &len) == PCX_OK && base) {
+            _locked.emplace_back(base, len);
+            if (_locked.size() > 4) {                   // the framework keeps re-allocating: let go of the oldest range
+                // (the host-pointer entry points return with their result in place: no call of THIS block is reading the range, and
+                // the count inside the library keeps it locked for any other block that holds it)
+                (void)pcx_host_unregister(_locked.front().first);
+                _locked.erase(_locked.begin());
+            }
+            return;
+        }
+        int kind = PCX_PTR_PAGEABLE;
+        if (pcx_pointer_kind(p, &kind) != PCX_OK || kind != PCX_PTR_PAGEABLE) return;     // a pinned slab, a device slab: in place as it is
+        {
             // a window that slides through one unlockable buffer must not cost a look at /proc/self/maps per call: a window that overlaps
             // or touches a range already known to be unlockable grows that range
             for (auto &r : _unlockable)
@@ -537,10 +758,44 @@ private:
             _unlockable.emplace_back(lo, bytes);
         }
     }
-    std::vector<std::pair<void *, size_t>> _locked;          // ranges this block page-locked (base, bytes)
+    void unlockAll()
+    {
+        for (const auto &r : _locked) (void)pcx_host_unregister(r.first);
+        _locked.clear();
+        _unlockable.clear();
+    }
+    std::vector<std::pair<void *, size_t>> _locked;          // ranges this block holds page-locked (base, bytes)
     std::vector<std::pair<uintptr_t, size_t>> _unlockable;   // windows that could not be locked: not asked about again
     static constexpr size_t kLockFrom = 65536;               // bytes per call below which staging is as good
 
+    static int kernelCode(const std::string &name)
+    {
+        const int algo = name == "AUTO" ? PCX_FIR_AUTO : name == "DIRECT" ? PCX_FIR_DIRECT : name == "OLS_FFT" ? PCX_FIR_OLS_FFT
+                       : name == "EXACT" ? PCX_FIR_EXACT : -1;
+        if (algo < 0) throw InvalidArgumentException("FIRFilter::setKernel(" + name + ")", "unknown kernel");
+        return algo;
+    }
+    // setDevice: the single-device filter again on the device that is current now, with everything the setters have told it (the
+    // shard set keeps its own devices)
+    void rebind() override
+    {
+        pcx_fir *fresh = nullptr;
+        check(pcx_fir_create(_scalar, _cplx ? 1 : 0, _complexTaps ? 1 : 0, &fresh), "FIRFilter::setDevice()");
+        pcx_fir *old = _h;
+        _h = fresh;
+        try {
+            check(pcx_fir_set_qformat(_h, _qformat.ptr()), "FIRFilter::setDevice()");
+            check(pcx_fir_set_decimation(_h, M), "FIRFilter::setDevice()");
+            check(pcx_fir_set_interpolation(_h, L), "FIRFilter::setDevice()");
+            this->pushTaps();
+            check(pcx_fir_set_algo(_h, kernelCode(_kernel)), "FIRFilter::setDevice()");
+        } catch (...) {
+            _h = old;
+            pcx_fir_destroy(fresh);
+            throw;
+        }
+        pcx_fir_destroy(old);
+    }
     void pushTaps()
     {
         std::vector<double> flat;
@@ -558,7 +813,8 @@ private:
     void refreshGeometry() { check(pcx_fir_get_geometry(_h, &K, &_inputRequire), "FIRFilter::updateInternals()"); }
 
     std::vector<std::complex<double>> _taps;
-    bool _complexTaps;
+    int _scalar;
+    bool _cplx, _complexTaps;
     size_t _elemBytes;
     size_t M, L, K, _inputRequire;
     bool _waitTapsMode, _waitTapsArmed;
@@ -588,17 +844,54 @@ pcxfw::BlockRegistry registerFIRFilter("/comms/fir_filter", &FIRFilterFactory);
 pcxfw::BlockRegistry registerFIRFilterOldPath("/blocks/fir_filter", &FIRFilterFactory);
 
 /***********************************************************************
- * /comms/fft
+ * |PothosDoc FFT
+ *
+ * Discrete Fourier transforms on the GPU: every numBins consecutive elements of input port 0 are one frame, its
+ * transform leaves on output port 0.  All whole frames a call finds are transformed in one launch.  Unscaled in both
+ * directions for the floating-point types; the fixed-point type divides by the radix at every stage, as the CPU block does.
+ *
+ * |category /FFT
+ * |keywords dft fft fast fourier transform gpu hip
+ *
+ * |param dtype[Data Type] Element type of the input and of the output stream.
+ * |widget DTypeChooser(cfloat=1, cint=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param numBins[Num FFT Bins] Frame length: the number of bins of one transform (any length, powers of two are fastest).
+ * |default 1024
+ * |option 512
+ * |option 1024
+ * |option 2048
+ * |option 4096
+ * |widget ComboBox(editable=true)
+ *
+ * |param inverse[Inverse FFT] Direction of the transform.
+ * |option [Forward] false
+ * |option [Inverse] true
+ * |default false
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/fft(dtype, numBins, inverse)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
  **********************************************************************/
 class FFT : public DeviceBlock {
 public:
-    // a device launch per 4096-sample frame would be launch-bound: the block asks for output
-    // slabs of several frames and transforms every whole frame present in one call.  Totals
-    // (consume == produce == frames * numBins) are those of the reference's one-frame calls.
-    static constexpr size_t kFramesPerSlab = 64;
-
     FFT(const DType &dtype, int scalar, const size_t numBins, const bool inverse)
-        : _numBins(numBins), _inverse(inverse), _elemBytes(dtype.size()), _h(nullptr)
+        : _scalar(scalar), _numBins(numBins), _inverse(inverse), _elemBytes(dtype.size()), _h(nullptr)
     {
         check(pcx_fft_create(scalar, numBins, inverse ? 1 : 0, &_h), "FFTFactory(" + dtype.toString() + ")");
         this->setupInput(0, dtype);
@@ -609,13 +902,14 @@ public:
 
     pcxfw::BufferManager::Sptr getOutputBufferManager(const std::string &, const std::string &domain)
     {
-        // several frames per slab so one call amortises the PCIe round trip, but never less than one
-        // frame (the reference's own request, FFT.cpp:54-59) nor slabs beyond 16 MiB for long transforms
+        // a device launch per frame would be launch-bound: the block asks for output slabs of many frames and transforms every whole
+        // frame present in one call -- as many as the slab setting holds, never less than one frame (the reference's own request,
+        // FFT.cpp:54-59) and always a whole number of them.  Totals (consume == produce == frames * numBins) are those of the
+        // reference's one-frame calls.
         const size_t frame = _numBins * _elemBytes;
-        size_t frames = kFramesPerSlab;
-        while (frames > 1 && frame * frames > (16u << 20)) frames /= 2;
+        const size_t frames = std::max<size_t>(1, _slabBytes / frame);
 #ifndef PCX_WITH_POTHOS
-        if (domain == kDomain) return deviceManager("generic", frame * frames);
+        if (domain == kDomain) { OnDevice on(_device); return deviceManager("generic", frame * frames); }
 #else
         (void)domain;
 #endif
@@ -635,6 +929,14 @@ public:
     }
 
 private:
+    void rebind() override
+    {
+        pcx_fft *fresh = nullptr;
+        check(pcx_fft_create(_scalar, _numBins, _inverse ? 1 : 0, &fresh), "FFT::setDevice()");
+        pcx_fft_destroy(_h);
+        _h = fresh;
+    }
+    const int _scalar;
     const size_t _numBins;
     const bool _inverse;
     const size_t _elemBytes;
@@ -653,11 +955,41 @@ Block *FFTFactory(const DType &dtype, const size_t numBins, const bool inverse)
 pcxfw::BlockRegistry registerFFT("/comms/fft", &FFTFactory);
 
 /***********************************************************************
- * /comms/freq_demod
+ * |PothosDoc Freq Demod
+ *
+ * FM demodulation on the GPU: output element n is the angle of in[n] times the conjugate of in[n-1] -- the phase
+ * step from one complex sample to the next.  The last sample of a call is kept for the first of the following one;
+ * activation starts from zero.
+ *
+ * |category /Demod
+ * |keywords frequency modulation fm atan differential gpu hip
+ *
+ * |param dtype[Data Type] Element type of the complex input stream; the output stream is its real type.
+ * Floating-point outputs are radians in [-pi, +pi]; fixed-point outputs map -pi ... +pi (exclusive) to the signed 16-bit range.
+ * |widget DTypeChooser(cfloat=1,cint=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/freq_demod(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
  **********************************************************************/
 class FreqDemod : public DeviceBlock {
 public:
-    FreqDemod(const DType &dtype, int scalar) : _h(nullptr)
+    FreqDemod(const DType &dtype, int scalar) : _scalar(scalar), _h(nullptr)
     {
         check(pcx_freqdemod_create(scalar, &_h), "FreqDemodFactory(" + dtype.toString() + ")");
         this->setupInput(0, dtype);
@@ -678,6 +1010,14 @@ public:
     }
 
 private:
+    void rebind() override      // (the carried sample starts over, as after activate())
+    {
+        pcx_freqdemod *fresh = nullptr;
+        check(pcx_freqdemod_create(_scalar, &fresh), "FreqDemod::setDevice()");
+        pcx_freqdemod_destroy(_h);
+        _h = fresh;
+    }
+    const int _scalar;
     pcx_freqdemod *_h;
 };
 Block *FreqDemodFactory(const DType &dtype)
@@ -698,9 +1038,55 @@ pcxfw::BlockRegistry registerFreqDemod("/comms/freq_demod", &FreqDemodFactory);
  * Like the FIR it keeps K-1 samples of history at the front of its (circular) input buffer and produces one output per input.
  * Rotate's quirk is kept: until setPhase is called the phasor is zero and so is the output (Rotate.cpp:60-62).
  **********************************************************************/
+/***********************************************************************
+ * |PothosDoc FM Demod Chain
+ *
+ * Rotate, FIR filter and frequency demodulator as one GPU block: out[n] = angle(y[n] * conj(y[n-1])) with
+ * y = taps convolved with in * exp(j*phase).  The same stream as the three separate blocks wired in a row, at one
+ * trip through the device instead of three.
+ *
+ * |category /Demod
+ * |category /Filter
+ * |keywords fm demod rotate fir fused chain gpu hip
+ *
+ * |param dtype[Data Type] Element type of the input stream (the output is float32).
+ * |widget DTypeChooser(cfloat=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param tapsType[Taps Type] Real or complex filter taps.
+ * |option [Real] "REAL"
+ * |option [Complex] "COMPLEX"
+ *
+ * |param phase[Phase] Rotation applied in front of the filter, in radians.
+ * |units radians
+ * |default 0.0
+ *
+ * |param taps The filter taps.
+ * |default [1.0]
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/fm_demod_chain(dtype, tapsType)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ * |setter setPhase(phase)
+ * |setter setTaps(taps)
+ **********************************************************************/
 class FmDemodChain : public DeviceBlock {
 public:
-    FmDemodChain(const DType &dtype, bool complexTaps) : _complexTaps(complexTaps), _phase(0.0), K(1), _h(nullptr)
+    FmDemodChain(const DType &dtype, bool complexTaps) : _complexTaps(complexTaps), _phase(0.0), _phaseSet(false), K(1), _h(nullptr)
     {
         check(pcx_fmchain_create(&_h), "fmDemodChainFactory(" + dtype.toString() + ")");
         this->setupInput(0, dtype);
@@ -722,6 +1108,7 @@ public:
     void setPhase(const double phase)
     {
         _phase = phase;
+        _phaseSet = true;
         check(pcx_fmchain_set_phase(_h, phase), "FmDemodChain::setPhase()");
     }
     double getPhase() const { return _phase; }
@@ -748,11 +1135,11 @@ public:
     pcxfw::BufferManager::Sptr getInputBufferManager(const std::string &, const std::string &domain)
     {
 #ifndef PCX_WITH_POTHOS
-        if (domain == kDomain) return deviceManager("circular");
+        if (domain == kDomain) { OnDevice on(_device); return deviceManager("circular", _slabBytes); }
 #else
         (void)domain;
 #endif
-        return pinnedManager("circular");
+        return pinnedManager("circular", _slabBytes);
     }
     void activate() { check(pcx_fmchain_reset(_h), "FmDemodChain::activate()"); }
 
@@ -773,6 +1160,22 @@ public:
     }
 
 private:
+    void rebind() override      // (the demodulator's carried sample starts over, as after activate(); the phasor stays unset if it was)
+    {
+        pcx_fmchain *fresh = nullptr;
+        check(pcx_fmchain_create(&fresh), "FmDemodChain::setDevice()");
+        pcx_fmchain *old = _h;
+        _h = fresh;
+        try {
+            if (_phaseSet) check(pcx_fmchain_set_phase(_h, _phase), "FmDemodChain::setDevice()");
+            this->pushTaps();
+        } catch (...) {
+            _h = old;
+            pcx_fmchain_destroy(fresh);
+            throw;
+        }
+        pcx_fmchain_destroy(old);
+    }
     void pushTaps()
     {
         std::vector<double> flat;
@@ -789,6 +1192,7 @@ private:
     std::vector<std::complex<double>> _taps;
     bool _complexTaps;
     double _phase;
+    bool _phaseSet;
     size_t K;
     pcx_fmchain *_h;
 };
@@ -827,7 +1231,57 @@ protected:
 };
 
 /***********************************************************************
- * /comms/rotate
+ * |PothosDoc Rotate
+ *
+ * Turns every complex input element by a fixed phase on the GPU:
+ *
+ * out[n] = in[n] * exp(j*phase)
+ *
+ * |category /Math
+ * |keywords math phase multiply rotate gpu hip
+ *
+ * |param dtype[Data Type] Element type of the stream (complex types; vectors allowed).
+ * |widget DTypeChooser(cint=1, cfloat=1,dim=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param phase[Phase] The rotation, in radians.
+ * |units radians
+ * |default 0.0
+ *
+ * |param labelId[Label ID] ID of a label whose data replaces the phase from that element on.
+ * An upstream block can steer the rotation along with the samples; empty: labels are ignored.
+ * |preview valid
+ * |default ""
+ * |widget StringEntry()
+ * |tab Labels
+ *
+ * |param qformat[Q Format] Fixed-point reading of the integer types: fractional bits, coefficient rounding, output rounding.
+ * "DEFAULT", or three words such as "HALF_Q,TRUNCATE,FLOOR".
+ * |default "DEFAULT"
+ * |widget StringEntry()
+ * |preview disable
+ * |tab Device
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/rotate(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ * |setter setPhase(phase)
+ * |setter setLabelId(labelId)
+ * |setter setQFormat(qformat)
  **********************************************************************/
 class Rotate : public LabelDrivenMap<Rotate> {
 public:
@@ -864,6 +1318,7 @@ public:
         auto outPort = this->output(0);
         elems = this->scanLabels(elems);
         const size_t N = elems * inPort->dtype().dimension();
+        OnDevice on(_device);
         check(pcx_rotate_q(_scalar, _pr, _pi, _qformat.ptr(), inPort->buffer().template as<const void *>(),
                            outPort->buffer().template as<void *>(), N),
               "Rotate::work()");
@@ -886,7 +1341,56 @@ Block *rotateFactory(const DType &dtype)
 pcxfw::BlockRegistry registerRotate("/comms/rotate", &rotateFactory);
 
 /***********************************************************************
- * /comms/scale
+ * |PothosDoc Scale
+ *
+ * Multiplies every input element by a real factor on the GPU:
+ *
+ * out[n] = in[n] * factor
+ *
+ * |category /Math
+ * |keywords math scale multiply factor gain gpu hip
+ *
+ * |param dtype[Data Type] Element type of the stream (real or complex; vectors allowed).
+ * |widget DTypeChooser(float=1,cfloat=1,int=1,cint=1,dim=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param factor[Factor] The gain.
+ * |default 0.0
+ *
+ * |param labelId[Label ID] ID of a label whose data replaces the factor from that element on.
+ * An upstream block can steer the gain along with the samples; empty: labels are ignored.
+ * |preview valid
+ * |default ""
+ * |widget StringEntry()
+ * |tab Labels
+ *
+ * |param qformat[Q Format] Fixed-point reading of the integer types: fractional bits, coefficient rounding, output rounding.
+ * "DEFAULT", or three words such as "HALF_Q,TRUNCATE,FLOOR".
+ * |default "DEFAULT"
+ * |widget StringEntry()
+ * |preview disable
+ * |tab Device
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/scale(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ * |setter setFactor(factor)
+ * |setter setLabelId(labelId)
+ * |setter setQFormat(qformat)
  **********************************************************************/
 class Scale : public LabelDrivenMap<Scale> {
 public:
@@ -916,6 +1420,7 @@ public:
         auto outPort = this->output(0);
         elems = this->scanLabels(elems);
         const size_t N = elems * inPort->dtype().dimension();
+        OnDevice on(_device);
         check(pcx_scale_q(_scalar, _cplx ? 1 : 0, _factor, _qformat.ptr(), inPort->buffer().template as<const void *>(),
                           outPort->buffer().template as<void *>(), N),
               "Scale::work()");
@@ -939,7 +1444,36 @@ Block *scaleFactory(const DType &dtype)
 pcxfw::BlockRegistry registerScale("/comms/scale", &scaleFactory);
 
 /***********************************************************************
- * /comms/abs, /comms/conjugate
+ * |PothosDoc Abs
+ *
+ * Absolute value of every input element on the GPU: |x| for real streams, the magnitude for complex ones.
+ *
+ * out[n] = abs(in[n])
+ *
+ * |category /Math
+ * |keywords math abs magnitude absolute gpu hip
+ *
+ * |param dtype[Data Type] Element type of the input stream; the output stream is its real type.
+ * |widget DTypeChooser(float=1,cfloat=1,int=1,cint=1,dim=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/abs(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
  **********************************************************************/
 class Abs : public DeviceBlock {
 public:
@@ -955,6 +1489,7 @@ public:
         auto inPort = this->input(0);
         auto outPort = this->output(0);
         const size_t N = elems * inPort->dtype().dimension();
+        OnDevice on(_device);
         check(pcx_abs(_scalar, _cplx ? 1 : 0, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
               "Abs::work()");
         inPort->consume(elems);
@@ -974,7 +1509,42 @@ Block *absFactory(const DType &dtype)
 }
 pcxfw::BlockRegistry registerAbs("/comms/abs", &absFactory);
 
-// /comms/angle (math/Angle.cpp:50-110): the first "next" sibling, shares getAngle with FreqDemod
+/***********************************************************************
+ * /comms/angle (math/Angle.cpp:50-110): the first "next" sibling, shares getAngle with FreqDemod
+ **********************************************************************/
+/***********************************************************************
+ * |PothosDoc Angle
+ *
+ * The argument of every complex input element on the GPU:
+ *
+ * out[n] = atan2(Im{in[n]}, Re{in[n]})
+ *
+ * |category /Math
+ * |keywords math angle complex arg atan gpu hip
+ *
+ * |param dtype[Data Type] Element type of the complex input stream; the output stream is its real type.
+ * Floating-point outputs are radians in [-pi, +pi]; fixed-point outputs map -pi ... +pi (exclusive) to the signed 16-bit range.
+ * |widget DTypeChooser(cfloat=1,cint=1,dim=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/angle(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ **********************************************************************/
 class Angle : public DeviceBlock {
 public:
     Angle(const DType &dtype, int scalar) : _scalar(scalar)
@@ -989,6 +1559,7 @@ public:
         auto inPort = this->input(0);
         auto outPort = this->output(0);
         const size_t N = elems * inPort->dtype().dimension();
+        OnDevice on(_device);
         check(pcx_angle(_scalar, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
               "Angle::work()");
         inPort->consume(elems);
@@ -1007,6 +1578,38 @@ Block *angleFactory(const DType &dtype)
 }
 pcxfw::BlockRegistry registerAngle("/comms/angle", &angleFactory);
 
+/***********************************************************************
+ * |PothosDoc Conjugate
+ *
+ * The complex conjugate of every input element on the GPU:
+ *
+ * out[n] = conj(in[n])
+ *
+ * |category /Math
+ * |keywords math conjugate complex conj gpu hip
+ *
+ * |param dtype[Data Type] Element type of the stream (complex types; vectors allowed).
+ * |widget DTypeChooser(cfloat=1,cint=1,dim=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/conjugate(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ **********************************************************************/
 class Conjugate : public DeviceBlock {
 public:
     Conjugate(const DType &dtype, int scalar) : _scalar(scalar)
@@ -1021,6 +1624,7 @@ public:
         auto inPort = this->input(0);
         auto outPort = this->output(0);
         const size_t N = elems * inPort->dtype().dimension();
+        OnDevice on(_device);
         check(pcx_conj(_scalar, inPort->buffer().template as<const void *>(), outPort->buffer().template as<void *>(), N),
               "Conjugate::work()");
         inPort->consume(elems);
@@ -1041,6 +1645,60 @@ pcxfw::BlockRegistry registerConjugate("/comms/conjugate", &conjugateFactory);
 
 /***********************************************************************
  * /comms/arithmetic (+ /blocks/arithmetic)   math/Arithmetic.cpp:150-305   
+ **********************************************************************/
+/***********************************************************************
+ * |PothosDoc Arithmetic
+ *
+ * Element-wise arithmetic across the input ports on the GPU, folded from port 0 to the last:
+ *
+ * out[n] = in0[n] $op in1[n] $op ... $op in_last[n]
+ *
+ * |category /Math
+ * |keywords math arithmetic add subtract multiply divide gpu hip
+ * |alias /blocks/arithmetic
+ *
+ * |param dtype[Data Type] Element type of every port.
+ * |widget DTypeChooser(float=1,cfloat=1,int=1,cint=1,uint=1,cuint=1,dim=1)
+ * |default "complex_float32"
+ * |preview disable
+ *
+ * |param operation The operation between the ports.
+ * |default "ADD"
+ * |option [Add] "ADD"
+ * |option [Subtract] "SUB"
+ * |option [Multiply] "MUL"
+ * |option [Divide] "DIV"
+ *
+ * |param numInputs[Num Inputs] How many input ports the block has.
+ * |default 2
+ * |widget SpinBox(minimum=2)
+ * |preview disable
+ *
+ * |param preload Elements of zeros queued on each input at activation (a list, one count per port):
+ * what a feedback loop needs to start.
+ * |default []
+ * |widget ComboBox(editable=true)
+ * |option [Ignored] \[\]
+ * |preview disable
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/arithmetic(dtype, operation)
+ * |initializer setNumInputs(numInputs)
+ * |initializer setPreload(preload)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
  **********************************************************************/
 class Arithmetic : public DeviceBlock {
 public:
@@ -1087,6 +1745,7 @@ public:
         const void *in0 = inputs[0]->buffer().template as<const void *>();
         if (out == in0) _numInlineBuffers++;   // track buffer inlining
         const size_t N = elems * output->dtype().dimension();
+        OnDevice on(_device);
         // left fold over the ports, the running result living in `out` (Arithmetic.cpp:217-224)
         for (size_t i = 1; i < inputs.size(); i++) {
             check(pcx_arith(_scalar, _cplx ? 1 : 0, _op, in0, inputs[i]->buffer().template as<const void *>(), out, N), "Arithmetic::work()");
@@ -1126,6 +1785,36 @@ pcxfw::BlockRegistry registerArithmeticOldPath("/blocks/arithmetic", &arithmetic
 /***********************************************************************
  * /comms/split_complex, /comms/combine_complex   utility/SplitComplex.cpp:39-77, utility/CombineComplex.cpp:38-76
  **********************************************************************/
+/***********************************************************************
+ * |PothosDoc Split Complex
+ *
+ * A complex stream taken apart on the GPU: real parts on output port "re", imaginary parts on "im".
+ *
+ * |category /Utility
+ * |category /Convert
+ *
+ * |param dtype[Data Type] Element type of the two real output streams (the input is its complex type).
+ * |widget DTypeChooser(float=1,int=1,dim=1)
+ * |default "float32"
+ * |preview disable
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/split_complex(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ **********************************************************************/
 class SplitComplex : public DeviceBlock {
 public:
     SplitComplex(const DType &dtype, int scalar) : _scalar(scalar)
@@ -1140,6 +1829,7 @@ public:
         if (elems == 0) return;
         auto inPort = this->input(0);
         const size_t N = elems * inPort->dtype().dimension();
+        OnDevice on(_device);
         check(pcx_split_complex(_scalar, inPort->buffer().template as<const void *>(), _rePort->buffer().template as<void *>(),
                                 _imPort->buffer().template as<void *>(), N),
               "SplitComplex::work()");
@@ -1153,6 +1843,36 @@ private:
     pcxfw::OutputPort *_rePort;
     pcxfw::OutputPort *_imPort;
 };
+/***********************************************************************
+ * |PothosDoc Combine Complex
+ *
+ * A complex stream put together on the GPU from the real stream on input port "re" and the one on "im".
+ *
+ * |category /Utility
+ * |category /Convert
+ *
+ * |param dtype[Data Type] Element type of the two real input streams (the output is its complex type).
+ * |widget DTypeChooser(float=1,int=1,dim=1)
+ * |default "float32"
+ * |preview disable
+ *
+ * |param device[Device] Ordinal of the GPU that carries the block.
+ * |default 0
+ * |widget SpinBox(minimum=0)
+ * |preview disable
+ * |tab Device
+ *
+ * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
+ * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
+ * |default 33554432
+ * |units bytes
+ * |preview disable
+ * |tab Device
+ *
+ * |factory /comms/combine_complex(dtype)
+ * |initializer setPortSlabBytes(portSlabBytes)
+ * |initializer setDevice(device)
+ **********************************************************************/
 class CombineComplex : public DeviceBlock {
 public:
     CombineComplex(const DType &dtype, int scalar) : _scalar(scalar)
@@ -1167,6 +1887,7 @@ public:
         if (elems == 0) return;
         auto outPort = this->output(0);
         const size_t N = elems * outPort->dtype().dimension();
+        OnDevice on(_device);
         check(pcx_combine_complex(_scalar, _rePort->buffer().template as<const void *>(), _imPort->buffer().template as<const void *>(),
                                   outPort->buffer().template as<void *>(), N),
               "CombineComplex::work()");

@@ -322,6 +322,118 @@ std::vector<double> prototypeLowPass(const std::string &type, size_t n, double f
     return rootRaisedCosineLowPass(n, fc, alpha);
 }
 
+/***********************************************************************
+ * |PothosDoc FIR Designer
+ *
+ * Computes FIR filter taps on the host and publishes them: the block has no stream ports, it emits the signal
+ * "tapsChanged" -- an array of taps -- when it is activated and whenever one of its settings changes.  Connect the
+ * signal to the setTaps slot of a FIR filter (set that filter's Wait Taps to hold its stream until the first taps arrive).
+ *
+ * |category /Filter
+ * |keywords fir filter taps highpass lowpass bandpass remez designer
+ * |alias /blocks/fir_designer
+ *
+ * |param type[Filter Type] The prototype the taps are derived from.
+ * <ul>
+ * <li>SINC (box-car): a truncated sin(x)/x, shaped by the window.</li>
+ * <li>RAISED_COSINE, ROOT_RAISED_COSINE: pulse-shaping responses with roll-off factor alpha; Lower Freq is the symbol rate.</li>
+ * <li>MAXFLAT: maximally flat, non-linear phase; only discrete cut-off frequencies are reachable.</li>
+ * <li>GAUSSIAN: Lower Freq sets the time-bandwidth product.</li>
+ * <li>REMEZ: equiripple (Parks-McClellan) from the transition width, ripple and attenuation on the Remez tab.</li>
+ * </ul>
+ * |option [Root Raised Cosine] "ROOT_RAISED_COSINE"
+ * |option [Raised Cosine] "RAISED_COSINE"
+ * |option [Box-Car] "SINC"
+ * |option [Maxflat] "MAXFLAT"
+ * |option [Gaussian] "GAUSSIAN"
+ * |option [Remez] "REMEZ"
+ * |default "SINC"
+ *
+ * |param band[Band Type] Which band passes.  The complex variants give one-sided (complex) taps.
+ * |option [Low Pass] "LOW_PASS"
+ * |option [High Pass] "HIGH_PASS"
+ * |option [Band Pass] "BAND_PASS"
+ * |option [Band Stop] "BAND_STOP"
+ * |option [Complex Band Pass] "COMPLEX_BAND_PASS"
+ * |option [Complex Band Stop] "COMPLEX_BAND_STOP"
+ *
+ * |param window[Window Type] The window laid over the prototype; it trades transition width against ripple.
+ * |default "hann"
+ * |option [Rectangular] "rectangular"
+ * |option [Hann] "hann"
+ * |option [Hamming] "hamming"
+ * |option [Blackman] "blackman"
+ * |option [Bartlett] "bartlett"
+ * |option [Flat-top] "flattop"
+ * |option [Kaiser] "kaiser"
+ * |option [Chebyshev] "chebyshev"
+ * |tab Window
+ *
+ * |param windowArgs[Window Args] Arguments of the parameterised windows, as a list:
+ * [beta] for Kaiser, [attenuation in dB] for Chebyshev; ignored by the others.
+ * |default []
+ * |preview valid
+ * |tab Window
+ *
+ * |param gain[Gain] Factor applied to every tap.
+ * |default 1.0
+ *
+ * |param sampRate[Sample Rate] Sample rate of the stream the taps are for; every frequency below must lie under half of it.
+ * |default 1e6
+ * |units Sps
+ *
+ * |param freqLower[Lower Freq] The transition frequency of low- and high-pass filters, the lower edge of the band types,
+ * the symbol rate of the cosine filters, the time-bandwidth product of the Gaussian.
+ * |default 1000
+ * |units Hz
+ *
+ * |param freqUpper[Upper Freq] The upper edge of band-pass and band-stop filters.
+ * |default 2000
+ * |units Hz
+ * |preview when(enum=band, "BAND_PASS", "BAND_STOP", "COMPLEX_BAND_PASS", "COMPLEX_BAND_STOP")
+ *
+ * |param transBw[Transition Width] Width of the transition band of a Remez design.
+ * |default 1000
+ * |units Hz
+ * |preview when(enum=type, "REMEZ")
+ * |tab Remez
+ *
+ * |param numTaps[Num Taps] How many taps to produce: the filter's length, and its cost per sample.
+ * |default 51
+ * |widget SpinBox(minimum=1)
+ *
+ * |param alpha[Alpha] Roll-off (excess bandwidth) of the cosine filters, 0.0 ... 1.0.
+ * |default 0.5
+ * |preview when(enum=type, "RAISED_COSINE", "ROOT_RAISED_COSINE")
+ * |tab Cosine
+ *
+ * |param stopDB[Attenuation] Stop-band attenuation a Remez design aims for.
+ * |default 60.0
+ * |units dB
+ * |preview when(enum=type, "REMEZ")
+ * |tab Remez
+ *
+ * |param passDB[Passband Ripple] Pass-band ripple a Remez design may leave.
+ * |default 0.1
+ * |units dB
+ * |preview when(enum=type, "REMEZ")
+ * |tab Remez
+ *
+ * |factory /comms/fir_designer()
+ * |setter setFilterType(type)
+ * |setter setBandType(band)
+ * |setter setWindowType(window)
+ * |setter setWindowArgs(windowArgs)
+ * |setter setSampleRate(sampRate)
+ * |setter setFrequencyLower(freqLower)
+ * |setter setFrequencyUpper(freqUpper)
+ * |setter setBandwidthTrans(transBw)
+ * |setter setNumTaps(numTaps)
+ * |setter setAlpha(alpha)
+ * |setter setStopDB(stopDB)
+ * |setter setPassDB(passDB)
+ * |setter setGain(gain)
+ **********************************************************************/
 class FIRDesigner : public Block {
 public:
     static Block *make() { return new FIRDesigner(); }

@@ -481,6 +481,7 @@ public:
             if (args.size() != sizeof...(A)) throw Exception("Block::call(" + name + ")", "wrong number of arguments");
             return detail::invoke(self, f, args, std::index_sequence_for<A...>(), std::is_void<R>());
         };
+        _callArity[name] = sizeof...(A);
     }
     template <typename C, typename R, typename... A>
     void registerCall(C *self, const std::string &name, R (C::*f)(A...) const)
@@ -494,6 +495,8 @@ public:
         return it->second(args);
     }
     bool hasCall(const std::string &name) const { return _calls.count(name) != 0; }
+    // the registered calls and how many arguments each takes (what a block description's |setter / |initializer lines are checked against)
+    const std::map<std::string, size_t> &callArities() const { return _callArity; }
 
     // ---- signals (Pothos::Block::registerSignal / emitSignal; Topology::connect(src, "sig", dst, "slot")) ----
     void registerSignal(const std::string &name) { _signals[name]; }
@@ -524,6 +527,7 @@ private:
     std::vector<OutputPort *> _outputPtrs;
     WorkInfo _workInfo;
     std::map<std::string, std::function<Object(const std::vector<Object> &)>> _calls;
+    std::map<std::string, size_t> _callArity;
     std::map<std::string, std::vector<std::pair<Block *, std::string>>> _signals;
     bool _active = false;
 };
@@ -541,6 +545,13 @@ public:
             if (args.size() != sizeof...(A)) throw InvalidArgumentException("BlockRegistry::make(" + path + ")", "wrong number of arguments");
             return call(f, args, std::index_sequence_for<A...>());
         };
+        arities()[path] = sizeof...(A);
+    }
+    // how many arguments the factory behind `path` takes (-1: no such path)
+    static long arity(const std::string &path)
+    {
+        auto it = arities().find(path);
+        return it == arities().end() ? -1L : (long)it->second;
     }
     static Block *make(const std::string &path, const std::vector<Object> &args)
     {
@@ -565,6 +576,11 @@ private:
     static std::map<std::string, Factory> &table()
     {
         static std::map<std::string, Factory> t;
+        return t;
+    }
+    static std::map<std::string, size_t> &arities()
+    {
+        static std::map<std::string, size_t> t;
         return t;
     }
 };

@@ -108,6 +108,25 @@ int pcxb_make(const char *path, const char *dtype, size_t dimension, const char 
     });
 }
 int pcxb_destroy(pcxb_block *b) { delete b; return PCX_OK; }
+long pcxb_registry_arity(const char *path) { return path ? BlockRegistry::arity(path) : -1L; }
+int pcxb_call_count(pcxb_block *b, size_t *count) { return guarded([&] { *count = b->blk->callArities().size(); }); }
+int pcxb_call_name(pcxb_block *b, size_t i, char *out, size_t cap)
+{
+    return guarded([&] {
+        const auto &m = b->blk->callArities();
+        if (i >= m.size()) throw pcxfw::Exception("pcxb_call_name()", "index out of range");
+        auto it = m.begin();
+        std::advance(it, (long)i);
+        std::snprintf(out, cap, "%s", it->first.c_str());
+    });
+}
+long pcxb_call_arity(pcxb_block *b, const char *name)
+{
+    if (!b || !name) return -1L;
+    const auto &m = b->blk->callArities();
+    auto it = m.find(name);
+    return it == m.end() ? -1L : (long)it->second;
+}
 
 int pcxb_call_double(pcxb_block *b, const char *name, double v) { return guarded([&] { b->blk->call(name, {Object(v)}); }); }
 int pcxb_call_size(pcxb_block *b, const char *name, size_t v) { return guarded([&] { b->blk->call(name, {Object((unsigned long)v)}); }); }
@@ -239,6 +258,9 @@ int pcxb_circular_destroy(void *base)
         std::lock_guard<std::mutex> lk(g_circ_mutex);
         auto it = g_circ.find(base);
         if (it == g_circ.end()) throw pcxfw::Exception("pcxb_circular_destroy()", "not a circular buffer of this runner");
+        // the owner of the memory in front of munmap: whatever a block page-locked of it is let go of first (a registration
+        // outliving its mapping would describe whatever is mapped there next)
+        (void)pcx_host_release_range(base, 2 * it->second);
         munmap(base, 2 * it->second);
         g_circ.erase(it);
     });

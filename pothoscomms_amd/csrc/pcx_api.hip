@@ -318,6 +318,12 @@ int pcx_device_count(int *count)
     return PCX_OK;
 }
 int pcx_set_device(int ordinal) { PCX_HIP(hipSetDevice(ordinal)); return PCX_OK; }
+int pcx_get_device(int *ordinal)
+{
+    PCX_CHECK_ARG(ordinal, "null ordinal");
+    PCX_HIP(hipGetDevice(ordinal));
+    return PCX_OK;
+}
 int pcx_dev_alloc(void **dptr, size_t bytes)
 {
     PCX_CHECK_ARG(dptr, "null dptr");
@@ -339,7 +345,11 @@ int pcx_host_free(void *hptr) { PCX_HIP(hipHostFree(hptr)); return PCX_OK; }
 // ---- page-locking memory the framework owns (include/pcx.h) ----
 namespace {
 std::mutex g_reg_mutex;
-std::map<uintptr_t, size_t> g_registered;      // base -> bytes of the ranges THIS library page-locked
+// the ranges THIS library page-locked: base -> bytes, how many callers hold it, and -- for a range found through
+// pcx_host_register_mapping -- which object was mapped there (device + inode of the shared file), so that a caller can ask later
+// whether the registration still describes what is mapped at that address
+struct Registration { size_t bytes; unsigned holders; unsigned long long inode; std::string dev; };
+std::map<uintptr_t, Registration> g_registered;
 struct Vma { uintptr_t lo, hi; bool rw, shared; unsigned long long inode; std::string dev; };
 // the mappings of this process, ascending (/proc/self/maps: "lo-hi perms offset dev inode path")
 std::vector<Vma> read_maps()
@@ -357,10 +367,28 @@ std::vector<Vma> read_maps()
     std::fclose(f);
     return v;
 }
+// is [lo, hi) still covered, without a gap, by shared read-write mappings of the object (dev, inode)?
+bool still_mapped(const std::vector<Vma> &maps, uintptr_t lo, uintptr_t hi, unsigned long long inode, const std::string &dev)
+{
+    uintptr_t at = lo;
+    for (const Vma &m : maps) {
+        if (m.hi <= at) continue;
+        if (m.lo > at) return false;
+        if (!(m.shared && m.rw && m.inode == inode && m.dev == dev)) return false;
+        at = m.hi;
+        if (at >= hi) return true;
+    }
+    return false;
+}
 }  // namespace
 int pcx_host_register(void *ptr, size_t bytes)
 {
     PCX_CHECK_ARG(ptr && bytes, "pcx_host_register: empty range");
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        auto it = g_registered.find((uintptr_t)ptr);
+        if (it != g_registered.end() && it->second.bytes == bytes) { it->second.holders++; return PCX_OK; }
+    }
     int kind = PCX_PTR_PAGEABLE;
     PCX_TRY(pcx_pointer_kind(ptr, &kind));
     if (kind == PCX_PTR_PAGE_LOCKED) return PCX_OK;
@@ -369,7 +397,7 @@ int pcx_host_register(void *ptr, size_t bytes)
     if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return PCX_OK; }
     PCX_HIP(e);
     std::lock_guard<std::mutex> lk(g_reg_mutex);
-    g_registered[(uintptr_t)ptr] = bytes;
+    g_registered[(uintptr_t)ptr] = Registration{bytes, 1u, 0ull, std::string()};
     return PCX_OK;
 }
 int pcx_host_unregister(void *ptr)
@@ -378,6 +406,7 @@ int pcx_host_unregister(void *ptr)
         std::lock_guard<std::mutex> lk(g_reg_mutex);
         auto it = g_registered.find((uintptr_t)ptr);
         PCX_CHECK_ARG(it != g_registered.end(), "pcx_host_unregister: %p is not the base of a range this library page-locked", ptr);
+        if (--it->second.holders > 0) return PCX_OK;         // another block still runs in place on it
         g_registered.erase(it);
     }
     PCX_HIP(hipHostUnregister(ptr));
@@ -387,16 +416,29 @@ int pcx_host_register_mapping(const void *p, size_t bytes, size_t max_bytes, voi
 {
     PCX_CHECK_ARG(p && bytes && base && len, "pcx_host_register_mapping: null argument");
     *base = nullptr; *len = 0;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    {
+        // a range this library locked already (for another block, or for this one under another window): one more holder
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        auto it = g_registered.upper_bound(lo);
+        if (it != g_registered.begin()) {
+            --it;
+            if (it->first <= lo && hi <= it->first + it->second.bytes) {
+                it->second.holders++;
+                *base = (void *)it->first; *len = it->second.bytes;
+                return PCX_OK;
+            }
+        }
+    }
     int kind = PCX_PTR_PAGEABLE;
     PCX_TRY(pcx_pointer_kind(p, &kind));
-    if (kind != PCX_PTR_PAGEABLE) return PCX_OK;            // page-locked already (or device memory): nothing to do
+    if (kind != PCX_PTR_PAGEABLE) return PCX_OK;            // page-locked by somebody else (or device memory): nothing to do
     const std::vector<Vma> maps = read_maps();
-    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
     size_t first = maps.size();
     for (size_t i = 0; i < maps.size(); i++)
         if (maps[i].lo <= lo && lo < maps[i].hi) { first = i; break; }
     if (first == maps.size() || !maps[first].shared || !maps[first].rw || maps[first].inode == 0) return PCX_OK;   // not a shared file object
-    const Vma &m = maps[first];
+    const Vma m = maps[first];
     auto same = [&](const Vma &o) { return o.shared && o.rw && o.inode == m.inode && o.dev == m.dev; };
     // [p, p + bytes) must lie in consecutive mappings of that one object ...
     size_t last = first;
@@ -414,9 +456,39 @@ int pcx_host_register_mapping(const void *p, size_t bytes, size_t max_bytes, voi
     PCX_HIP(e);
     {
         std::lock_guard<std::mutex> lk(g_reg_mutex);
-        g_registered[rlo] = rhi - rlo;
+        g_registered[rlo] = Registration{rhi - rlo, 1u, m.inode, m.dev};
     }
     *base = (void *)rlo; *len = rhi - rlo;
+    return PCX_OK;
+}
+int pcx_host_mapping_alive(const void *base, int *alive)
+{
+    PCX_CHECK_ARG(base && alive, "pcx_host_mapping_alive: null argument");
+    Registration r;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        auto it = g_registered.find((uintptr_t)base);
+        PCX_CHECK_ARG(it != g_registered.end(), "pcx_host_mapping_alive: %p is not the base of a range this library page-locked", base);
+        r = it->second;
+    }
+    // a range registered by address alone (pcx_host_register) has no identity to compare: the caller vouches for it
+    *alive = r.inode == 0 ? 1 : (still_mapped(read_maps(), (uintptr_t)base, (uintptr_t)base + r.bytes, r.inode, r.dev) ? 1 : 0);
+    return PCX_OK;
+}
+int pcx_host_release_range(const void *p, size_t bytes)
+{
+    PCX_CHECK_ARG(p && bytes, "pcx_host_release_range: empty range");
+    std::vector<uintptr_t> gone;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mutex);
+        const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+        for (auto it = g_registered.begin(); it != g_registered.end();) {
+            if (it->first < hi && lo < it->first + it->second.bytes) { gone.push_back(it->first); it = g_registered.erase(it); }
+            else ++it;
+        }
+    }
+    // (the mapping may be gone already, or partly: the runtime's complaint about that is not the caller's problem)
+    for (uintptr_t b : gone) if (hipHostUnregister((void *)b) != hipSuccess) (void)hipGetLastError();
     return PCX_OK;
 }
 int pcx_pointer_kind(const void *p, int *kind)

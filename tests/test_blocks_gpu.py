@@ -713,10 +713,18 @@ def test_host_register_mapping_leaves_private_memory_alone():
     _lib.check(L.pcx_host_register_mapping(C.c_void_p(circ.base + circ.size + 8192), 4096, 0, C.byref(base), C.byref(n)))
     assert base.value == circ.base and n.value == 2 * circ.size       # asked about the SECOND half: both come along
     _lib.check(L.pcx_host_register_mapping(C.c_void_p(circ.base), 4096, 0, C.byref(base), C.byref(n)))
-    assert not base.value                                  # page-locked already: nothing to do, nothing to undo
+    assert base.value == circ.base and n.value == 2 * circ.size       # held already: the same range, one more holder
     with pytest.raises(_lib.PcxError):
         _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base + 4096)))      # not the base of a range this library locked
+    kind = C.c_int()
     _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base)))
+    _lib.check(L.pcx_pointer_kind(C.c_void_p(circ.base), C.byref(kind)))
+    assert kind.value == 1                                 # the first holder has let go, the second keeps it locked
+    _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base)))
+    _lib.check(L.pcx_pointer_kind(C.c_void_p(circ.base), C.byref(kind)))
+    assert kind.value == 0
+    with pytest.raises(_lib.PcxError):
+        _lib.check(L.pcx_host_unregister(C.c_void_p(circ.base)))             # nobody holds it any more
     circ.close()
 
 

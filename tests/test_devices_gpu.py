@@ -115,7 +115,7 @@ def test_the_maps_leave_the_callers_current_device_alone():
     blk.close()
 
 
-@pytest.mark.skipif(_ngpus() < 2, reason="needs two GPUs")
+@pytest.mark.skipif("_ngpus() < 2", reason="needs two GPUs")      # (the string form: evaluated when the test is set up, not when the file is imported)
 def test_two_chains_on_two_devices(oracle):
     """eight independent chains on eight GPUs from one process is this, four times over: every block of a chain is placed with
     setDevice, streams match the oracle, and the calling thread's current device is what it was"""

@@ -25,7 +25,7 @@ cpu_baseline: the oracle (-O3 restatement, kind "port") or oracle/_ref (the refe
           "reference") timed on this host on a bounded sample of the same workload, median of 3
           (rank 0, N=1 only); the FIR line also carries the C0 case (63 taps, 1 Mi samples).
 
-Other workloads (--workload fft4096 | fmchain | rotate | direct255 | decim8 | interp4 | fir255_i16) print the same kind of line
+Other workloads (--workload fft4096 | fmchain | rotate | abs | freq_demod | direct255 | decim8 | interp4 | fir255_i16) print the same kind of line
 for the secondary configs; the driver uses the default.
 """
 import argparse
@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # datasheet FP64 vector: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 SHARD = 64 * 1024 * 1024       # samples per GPU (configs[1])
 PREWARM = 400                  # untimed setup passes before the W warm-up steps (clock settling: tools/transient_probe.py)
 
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "decim8", "interp4", "fir255_i16"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "abs", "freq_demod", "decim8", "interp4", "fir255_i16"])
     ap.add_argument("--shard", type=int, default=SHARD, help="samples per GPU (default 64 Mi)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--driver", default="ranks", choices=["ranks", "native"],
@@ -64,7 +65,8 @@ def parse():
     ap.add_argument("--sustain", type=float, default=1.0,
                     help="seconds of extra launches behind the timed region whose last half is reported as roofline.sustained (0: off)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="default workload only: skip the `secondary` object (configs[2] 4096-pt FFT and configs[4] fused chain, ~1 s of GPU each)")
+                    help="default workload only: skip the `secondary` object (configs[2] 4096-pt FFT, configs[4] fused chain, the element-wise blocks, "
+                         "the integer FIR, the resamplers, configs[3] on one device, the host path: ~1 s of GPU each)")
     ap.add_argument("--rehearse-rccl-rank", action="store_true",
                     help="N = 1 only, fir255 / fmchain: time the pass a MIDDLE rank of an RCCL world runs -- side stream, one grouped RCCL send + receive "
                          "of the halo (to the rank itself: one GPU is enough), gate signal, ONE gated launch on the slots such a rank takes -- instead "
@@ -214,6 +216,22 @@ def cpu_baseline_rotate(n):
     dt = _median_time(lambda: o.rotate(x, 0.7))
     return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": "%d samples, oracle arrayRotate loop (-O3), single thread, median of 3" % n}
+
+
+def cpu_baseline_map(wl, n):
+    """the oracle's loop of one element-wise block (rotate / abs / freq_demod) on n complex_float32 samples"""
+    from oracle import oracle as o
+    x = o.fill_uniform_f32(2 * n, 8, 0).reshape(-1, 2)
+    if wl == "rotate":
+        fn, what = (lambda: o.rotate(x, 0.7)), "arrayRotate loop"
+    elif wl == "abs":
+        fn, what = (lambda: o.abs_(x, True)), "getAbs (std::abs of std::complex<float>) loop"
+    else:
+        fd = o.FreqDemod(o.F32)
+        fn, what = (lambda: fd.work(x)), "FreqDemod::work loop (complex multiply + std::arg)"
+    dt = _median_time(fn)
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d samples, oracle %s (-O3), single thread, median of 3" % (n, what)}
 
 
 def cpu_baseline_resampler(h, M, L, n):
@@ -480,6 +498,23 @@ N_SIMDS = 1024                 # 256 CUs x 4
 VALU_CYCLES_PER_INST = 4
 
 
+def measured_f64_issue_rate():
+    """G wave-instructions/s of the FP64 pipe at two waves per SIMD on an FFT's instruction mix (tools/f64_lab.hip, the committed
+    profiles/*/f64_lab.txt), or None"""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "f64_lab.txt"))):
+        for m in re.finditer(r"fft mix\s+2 wave\(s\)/SIMD:[^\n]*?([0-9.]+) G wave-inst/s", open(f).read()):
+            best = (float(m.group(1)), os.path.relpath(f, ROOT))
+    return best
+
+
+def ctr_insts(entry):
+    ctr = (entry or {}).get("counters") or {}
+    return float(ctr["SQ_INSTS_VALU"]) if ctr.get("SQ_INSTS_VALU") else None
+
+
 def measured_fma_rate():
     """the packed-FMA rate the committed microbenchmark reached on this part (profiles/*/ubench_roofs.txt, TFLOP/s), or None"""
     import glob
@@ -650,13 +685,42 @@ def build_workload(wl, C, dev, rank, world, args):
         W.units = n
         W.roof_bytes = 8.0 * n
         W.read_bytes = 4.0 * n
-        W.kernel_name = "fir_cf64_ols_kernel"
+        W.kernel_name = "fir_cf64_ip_kernel"
         W.step = lambda: f.process_dev(x, y)
         W.inputs = (x,)
         W.desc = {"workload": "255-tap complex_int16 FIR (bit-exact, double-precision overlap-save), %d samples per GPU" % n, "taps": 255}
         W.metric = "Msamples/s complex_int16 255-tap FIR"
         W.dtype = "f64"
-        W.limiter = "f64 issue (the double-precision pipeline that keeps the integer convolution exact)"
+        # NOT an HBM-bound kernel: 8 B per sample against ~100 double-precision flop per sample.  Per 4096-sample block and lane (256
+        # lanes): six plain 16-point transforms at 128 additions + 8 constant complex multiplies, 60 per-lane factor multiplies, 16 for
+        # H -- a complex multiply counted as 6 real flop -- = 1,512 flop; S = 4096 - 256 outputs per block at 255 taps
+        W.bound = "fp64"
+        S = 4096 - (K - 1 + 15) // 16 * 16
+        W.blocks = -(-n // S)
+        W.flops_per_unit = 256 * 1512.0 / S
+        W.limiter = ("FP64 issue at two waves per SIMD (the 64 KB image of a block caps the occupancy): the arithmetic alone is 0.79 of the launch "
+                     "(tools/ip64_parts.sh), and at that occupancy the pipe issues ~380 G wave-instructions/s chip-wide on an add / multiply / "
+                     "FMA mix like an FFT's (tools/f64_lab.hip), not the 614 G/s the datasheet's 78.6 TFLOP/s stand for")
+    elif wl in ("abs", "freq_demod"):
+        # complex_float32 in, float32 out: 8 B read + 4 B written per sample, one launch per step
+        n = C
+        x = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        y = torch.empty((n,), dtype=torch.float32, device=dev)
+        device.fill_uniform_f32_dev(x, seed=8, offset=0)
+        W.units = n
+        W.roof_bytes = 12.0 * n
+        W.read_bytes = 8.0 * n
+        if wl == "abs":
+            W.kernel_name = "map_kernel<abs>"
+            W.step = lambda: device.abs_(x, True, scalar=device.F32, out=y, n=n)
+        else:
+            fd = device.FreqDemod("complex_float32")
+            W.kernel_name = "freqdemod_kernel"
+            W.step = lambda: fd.process_dev(x, y, n)
+            W.owner_keepalive = fd
+        W.inputs = (x,)
+        W.desc = {"workload": "/comms/%s complex_float32 -> float32, %d samples" % (wl, n)}
+        W.metric = "Msamples/s complex_float32 %s" % wl
     else:
         n = C
         x = torch.empty((n, 2), dtype=torch.float32, device=dev)
@@ -777,6 +841,27 @@ def roofline_of(W, avg_ms, sustained=None, cold=None, sustain_s=1.0, clk=None):
         if m:
             r["frac_of_measured_fma_rate"] = round(tf / m[0], 4)
             r["measured_fma_rate"] = {"TFLOP/s": m[0], "source": m[1]}
+    elif W.bound == "fp64":
+        tf = W.flops_per_unit * W.units / sec / 1e12
+        r = {"bound": "fp64", "achieved": round(tf, 2), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": W.kernel_name, "avg_launch_ms": round(avg_ms, 4),
+             "algorithmic_flops_per_launch": W.flops_per_unit * W.units,
+             "flops_counted": "per 4096-sample block 256 lanes x 1,512 flop (six 16-point transforms at 128 additions + 8 constant complex "
+                              "multiplies, 60 per-lane factor multiplies, 16 for H; a complex multiply = 6 flop) = %.1f flop per output sample x "
+                              "%d samples; peak = the datasheet FP64 VECTOR rate, which counts every instruction as an FMA (2 flop): an "
+                              "FFT's instructions are 61 %% additions, so 0.6 is the most this fraction can reach" % (W.flops_per_unit, W.units),
+             "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_launch": W.roof_bytes,
+                     "note": "the other ceiling, kept beside: 8 B per sample -- this kernel is nowhere near it and never will be"}}
+        m = measured_f64_issue_rate()
+        if m and W.blocks:
+            insts = (ctr_insts(entry) or 1420.0 * 4 * W.blocks)
+            r["issue"] = {"wave_insts_per_launch": insts, "G_wave_insts_per_s": round(insts / sec / 1e9, 1),
+                          "measured_roof_G_wave_insts_per_s": m[0], "frac_of_measured_issue_roof": round(insts / sec / 1e9 / m[0], 4),
+                          "source": m[1],
+                          "note": "what the FP64 pipe issues at this kernel's occupancy (two waves per SIMD) on independent add / multiply / FMA "
+                                  "instructions in an FFT's proportions, measured on this part; wave_insts_per_launch from the PMC pass when one "
+                                  "is committed for this kernel, else 1,420 per wave and block from the ISA"}
     else:
         r = {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
              "read_only_frac": round(W.read_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -829,6 +914,8 @@ def cpu_baseline_of(wl, C):
         return cpu_baseline_fmchain(cpu_n)
     if wl == "rotate":
         return cpu_baseline_rotate(cpu_n)
+    if wl in ("abs", "freq_demod"):
+        return cpu_baseline_map(wl, cpu_n)
     if wl == "decim8":
         return cpu_baseline_resampler(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8), 8, 1, cpu_n)
     if wl == "interp4":
@@ -836,9 +923,36 @@ def cpu_baseline_of(wl, C):
     return cpu_baseline_fir_i16(tp.c1_taps() * 0.9, cpu_n // 2)
 
 
+def cpu_baseline_secondary(wl):
+    """the CPU leg of a secondary workload: SHORT slices (about a second each: the driver's whole run stays well under a minute)"""
+    from pothoscomms_amd import taps as tp
+    if wl == "fft4096":
+        return cpu_baseline_fft(2048)
+    if wl == "fmchain":
+        return cpu_baseline_fmchain(4 * 1024 * 1024)
+    if wl in ("rotate", "abs", "freq_demod"):
+        return cpu_baseline_map(wl, 4 * 1024 * 1024)
+    if wl == "decim8":
+        return cpu_baseline_resampler(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8), 8, 1, 2 * 1024 * 1024)
+    if wl == "interp4":
+        return cpu_baseline_resampler(tp.complex_bandpass(255 * 4, 0.05 / 4, 0.05 / 4) * 4, 1, 4, 256 * 1024)
+    return cpu_baseline_fir_i16(tp.c1_taps() * 0.9, 512 * 1024)
+
+
+def guarded(name, fn, *a):
+    """a secondary measurement must not cost the primary line: whatever it raises -- SystemExit included -- becomes {"error": ...}"""
+    try:
+        return fn(*a)
+    except BaseException as e:      # noqa: BLE001 (KeyboardInterrupt is passed on)
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        sys.stderr.write("bench.py: secondary %s failed: %s: %s\n" % (name, type(e).__name__, e))
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def measure_secondary(wl, dev, args):
-    """BASELINE configs[2] / configs[4] behind the headline's timed region, in the same process and under the same event protocol
-    (settling passes, one event pair around the timed launches); outside `value`."""
+    """BASELINE configs[2] / configs[4] and the remaining rows of SURVEY 8 behind the headline's timed region, in the same process and
+    under the same event protocol (settling passes, one event pair around the timed launches); outside `value`."""
     import gc
 
     import torch
@@ -857,7 +971,7 @@ def measure_secondary(wl, dev, args):
            "ms_per_step": round(avg_ms, 4), "wall_ms_per_step": round(wall / n * 1e3, 4), "dtype": W.dtype, "config": W.desc,
            "roofline": roofline_of(W, avg_ms, cold=cold, clk=clk)}
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_fft(2048) if wl == "fft4096" else cpu_baseline_fmchain(4 * 1024 * 1024)
+        out["cpu_baseline"] = cpu_baseline_secondary(wl)
     del W
     gc.collect()
     torch.cuda.empty_cache()
@@ -956,6 +1070,11 @@ def measure_c3_one_device(args, plain_ms):
                         "frac": round(16.0 * G * C / (per_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                         "kernel": "fir_cf32_ols4096_kernel (gated), 8 launches per pass",
                         "clock": "wall clock around %d passes, every stream synchronised on both sides" % n}}
+    if wrong:
+        # not a measurement (the multi-rank path refuses its line in the same situation): the figures go, the reason stays
+        out["value"] = None
+        out["ratio_to_8_plain_launches"] = None
+        out["roofline"] = None
     return out
 
 
@@ -982,9 +1101,15 @@ def measure_host_path(args, cpu):
     # (the FASTER of the two: the link is symmetric, and a copy engine that lags in one direction -- 30 GB/s D2H was seen on one box in one
     # run, 57 in the next -- says nothing about what the link carries)
     roof = max(up.value, down.value)
+    if not roof > 0:
+        raise RuntimeError("pcx_pcie_probe measured no transfer rate (h2d %r, d2h %r GB/s)" % (up.value, down.value))
     K = 255
     calls = {}
-    for n in (1 << 20, 1 << 24):
+    probe = blocks.make("/comms/fir_filter", "complex_float32", "COMPLEX")
+    slab = probe.call("getPortSlabBytes")                # the block's DEFAULT port slab: what a topology gets without setting anything
+    probe.close()
+    n_default = slab // 8
+    for n in sorted({1 << 20, n_default, 1 << 24}):
         for mode in ("pinned_port_buffers", "circular_input_page_locked_in_place"):
             blk = blocks.make("/comms/fir_filter", "complex_float32", "COMPLEX")
             blk.call("setTaps", tp.c1_taps())
@@ -1014,12 +1139,13 @@ def measure_host_path(args, cpu):
             blk.close()
             if circ is not None:
                 circ.close()
-    head = calls["%d_samples_per_call" % (1 << 20)]["pinned_port_buffers"]
+    head = calls["%d_samples_per_call" % n_default]["pinned_port_buffers"]
     out = {"metric": "Msamples/s complex_float32 255-tap FIR, host buffers in and out (PCIe inside the timed region)",
            "value": head["Msamples_per_s"], "unit": "Msamples/s", "ms_per_step": head["ms_per_call"],
            "config": {"workload": "/comms/fir_filter work() on host port buffers, 255 complex taps, complex_float32, %d samples per call "
-                                  "(what the block's 8 MiB port slabs carry); every call returns with its result in the output buffer" % (1 << 20),
-                      "samples_per_call": 1 << 20, "call_loop": "native (pcxb_work_loop)"},
+                                  "(what the block's DEFAULT %d MiB port slabs carry; setPortSlabBytes moves it: `calls` has 1 Mi and 16 Mi samples "
+                                  "per call beside it); every call returns with its result in the output buffer" % (n_default, slab >> 20),
+                      "samples_per_call": n_default, "port_slab_bytes": slab, "call_loop": "native (pcxb_work_loop)"},
            "roofline": {"bound": "pcie", "achieved": head["GB_per_s_each_way"], "peak": round(roof, 2), "unit": "GB/s", "frac": head["frac_of_pcie_roof"],
                         "traffic": None,
                         "peak_measured": {"h2d_alone": round(up.value, 2), "d2h_alone": round(down.value, 2),
@@ -1333,17 +1459,28 @@ def main():
     if W.owner is not None and (world > 1 or rehearsal) and hasattr(W.owner, "ring"):
         _BREAK_EXCHANGE[0] = os.environ.get("PCX_BENCH_TEST_BREAK_SEAM", "")
 
+        pretend = [os.environ.get("PCX_BENCH_TEST_GATE_TIMEOUT") == "%d:timed" % rank]    # tests only: ONE pretended timeout behind the timed region
+
         def gate_timed_out():
             """a pass whose gated launch ran without its halo (the bounded wait of pcx_fir_process_dev_gated) is not a measurement"""
             try:
                 W.owner.check_gate()
             except RuntimeError as e:
                 return str(e)
+            if pretend[0]:
+                pretend[0] = False
+                return "a gate timed out (pretended: PCX_BENCH_TEST_GATE_TIMEOUT)"
             return ""
 
         def seams_wrong():
             """the gate check and the seam check on every rank -> "" or what is wrong on SOME rank (this rank's own finding first)"""
-            wrong = gate_timed_out() or seam_check(W.owner, W.owner.ring.rank > 0) or gate_timed_out()
+            # all three on EVERY rank, whatever the first finds: seam_check is a step of the ring (owner.step() posts the send / recv with the
+            # neighbours), and a rank that skipped it because its own gate had timed out left its neighbours waiting in it while it
+            # waited for them in the all_reduce below (ADVICE r05: `a or b or c` short-circuits)
+            g1 = gate_timed_out()
+            sc = seam_check(W.owner, W.owner.ring.rank > 0)
+            g2 = gate_timed_out()
+            wrong = g1 or sc or g2
             bad = torch.tensor([1 if wrong else 0], dtype=torch.int32, device=ctl if world > 1 else "cpu")
             if world > 1:
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
@@ -1440,10 +1577,19 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             _hb("secondary workloads")
-            out["secondary"] = {"fft4096": measure_secondary("fft4096", dev, args), "fmchain": measure_secondary("fmchain", dev, args)}
+            t_sec = time.perf_counter()
+            sec = {"fft4096": guarded("fft4096", measure_secondary, "fft4096", dev, args),
+                   "fmchain": guarded("fmchain", measure_secondary, "fmchain", dev, args)}
+            # ... the other rows of SURVEY 8: the element-wise blocks (one launch each), the bit-exact integer FIR on the double-precision
+            # pipeline (its roof is FP64 issue, not HBM), the resampling FIRs
+            sec["elementwise"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("rotate", "abs", "freq_demod")}
+            sec["fir255_i16"] = guarded("fir255_i16", measure_secondary, "fir255_i16", dev, args)
+            sec["resamplers"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("decim8", "interp4")}
             # ... configs[3] rehearsed on this one device through the native driver, and the end-to-end number of SURVEY 8d (PCIe inside)
-            out["secondary"]["c3_one_device"] = measure_c3_one_device(args, avg_ms)
-            out["secondary"]["host_path"] = measure_host_path(args, out.get("cpu_baseline"))
+            sec["c3_one_device"] = guarded("c3_one_device", measure_c3_one_device, args, avg_ms)
+            sec["host_path"] = guarded("host_path", measure_host_path, args, out.get("cpu_baseline"))
+            sec["seconds"] = round(time.perf_counter() - t_sec, 1)
+            out["secondary"] = sec
         result_line = json.dumps(out)
         if world > 1:
             # a supervised rank: the line goes out BEFORE the process group is torn down -- the measurement is complete (timed region,

@@ -284,6 +284,15 @@ def supervise(argv, script):
     """The body of a rank process started by torch.distributed.run.  argv: bench.py's own arguments (sys.argv[1:])."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ["WORLD_SIZE"])
+    # ONE node: the verdict and port files live under this node's /tmp, the rendezvous is 127.0.0.1, LOCAL_RANK defaults to RANK.  Under a
+    # multi-node launch every supervisor off node 0 would wait two minutes per run for files that never appear: refused up front, by every rank
+    nodes = int(os.environ.get("GROUP_WORLD_SIZE", "1") or "1")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)) or world)
+    if nodes > 1 or local_world != world:
+        if int(os.environ.get("LOCAL_RANK", str(rank)) or rank) == 0:
+            print("bench.py: the supervised bench runs the ranks of ONE node (--nnodes=1): this launch has %d node group(s), %d of %d ranks "
+                  "on this node" % (nodes, local_world, world), file=sys.stderr, flush=True)
+        return 2
     sdir = session_dir()
     os.makedirs(sdir, exist_ok=True)
     signal.signal(signal.SIGTERM, _on_signal)
@@ -308,13 +317,20 @@ def supervise(argv, script):
             if rank == 0:
                 print("bench.py: the rendezvous port was taken before the ranks could bind it, the same attempt again", file=sys.stderr, flush=True)
         if ok:
+            # rank 0 holds the line: it decides whether the job produced one, and every rank leaves with ITS verdict
+            final = os.path.join(sdir, "final.run%d" % run_no)
             if rank == 0:
                 got = json.loads(line)
                 if got.get("n_gpus") != world:
-                    print("bench.py: asked for %d GPUs, the ranks report n_gpus=%r" % (world, got.get("n_gpus")), file=sys.stderr, flush=True)
+                    print("bench.py: asked for %d GPUs, the ranks report n_gpus=%r: no result line" % (world, got.get("n_gpus")), file=sys.stderr, flush=True)
+                    _write_atomic(final, "mismatch")
                     break
                 print(line, flush=True)
-            code = 0
+                _write_atomic(final, "ok")
+                code = 0
+                break
+            _wait_for([final], 30.0)
+            code = 0 if (_read(final) or "ok").strip() == "ok" else 1
             break
         reasons.append("attempt %d (%s): %s" % (a + 1, att["mode"].split(":")[0], status))
         if rank == 0:

@@ -814,16 +814,23 @@ static unsigned host_grid() { return (unsigned)PCX_ENV_INT("PCX_HOST_GRID", 48);
 // the grid-stride map kernels (pcx_internal.hpp LINK-BOUND LAUNCHES): 32 blocks for the one-to-one maps, 64 for /comms/freq_demod (two reads per sample)
 static unsigned host_map_grid(unsigned dflt = 32) { const unsigned e = (unsigned)PCX_ENV_INT("PCX_HOST_MAP_GRID", -1); return e == (unsigned)-1 ? dflt : e; }
 namespace pcx { thread_local unsigned g_link_grid = 0, g_link_map_grid = 0; }
+// page-locked HOST memory, reached over the link: what the link-bound launch shape is for.  Managed memory is addressed in place as
+// well (pcx_pointer_kind files it under page-locked), but it may be resident in HBM: it keeps the device-resident grid.
 static bool host_page_locked(const void *p)
 {
-    int kind = PCX_PTR_PAGEABLE;
-    return pcx_pointer_kind(p, &kind) == PCX_OK && kind == PCX_PTR_PAGE_LOCKED;
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }
 // (grid, map grid) for a launch whose input or output is page-locked host memory the kernel addresses in place, else (0, 0)
 struct LinkBound : LinkBoundScope {
     static bool any(const void *a, const void *b, const void *c) { return host_page_locked(a) || host_page_locked(b) || (c && host_page_locked(c)); }
-    LinkBound(const void *a, const void *b, const void *c = nullptr, unsigned map_blocks = 32)
-        : LinkBoundScope(any(a, b, c) ? host_grid() : 0, any(a, b, c) ? host_map_grid(map_blocks) : 0) {}
+    LinkBound(const void *a, const void *b, const void *c = nullptr, unsigned map_blocks = 32) : LinkBound(any(a, b, c), map_blocks) {}
+
+private:
+    // (the pointers are looked up ONCE per call: each lookup is a hipPointerGetAttributes)
+    LinkBound(bool link, unsigned map_blocks) : LinkBoundScope(link ? host_grid() : 0, link ? host_map_grid(map_blocks) : 0) {}
 };
 // how many chunks a drained output of `bytes` goes in (2 .. kDrainChunks)
 static int drain_chunks(size_t bytes)

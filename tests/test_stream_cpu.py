@@ -388,3 +388,17 @@ def test_supervised_bench_a_gate_timeout_in_setup_switches_every_rank_to_two_lau
     c = out["config"]
     assert c["attempt"] == 1 and "FALLBACK" in c["halo_scheme"] and "timed out" in c["halo_scheme"]
     assert any("a gated launch timed out" in w for w in c["fallback_reason"]) and "retimed" not in c
+
+
+def test_supervised_bench_a_gate_timeout_behind_the_timed_region_is_retimed_not_deadlocked():
+    """ONE rank > 0 finds a gate timeout behind the timed region.  It still takes part in the seam check (a collective step of
+    the ring), every rank learns of the finding, all switch to the two-launch form, the K steps are timed again and the line says so --
+    inside the first attempt, without the watchdog"""
+    r, lines = _bench_standin({"PCX_BENCH_TEST_GATE_TIMEOUT": "1:timed"}, gpus=3, launcher="torchrun")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = lines[0]
+    _is_flagged_standin_line(out, 3)
+    c = out["config"]
+    assert c["attempt"] == 1 and "FALLBACK" in c["halo_scheme"]
+    assert c["retimed"] and "pretended" in c["retimed"]["first_form_seam_check"] and "rank 1" in c["retimed"]["first_form_seam_check"]
+    assert "watchdog" not in r.stderr

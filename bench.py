@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "abs", "freq_demod", "decim8", "interp4", "fir255_i16"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "abs", "freq_demod", "decim8", "interp4", "fir255_i16", "fir4097", "fir8193"])
     ap.add_argument("--shard", type=int, default=SHARD, help="samples per GPU (default 64 Mi)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--driver", default="ranks", choices=["ranks", "native"],
@@ -701,6 +701,33 @@ def build_workload(wl, C, dev, rank, world, args):
         W.limiter = ("FP64 issue at two waves per SIMD (the 64 KB image of a block caps the occupancy): the arithmetic alone is 0.79 of the launch "
                      "(tools/ip64_parts.sh), and at that occupancy the pipe issues ~380 G wave-instructions/s chip-wide on an add / multiply / "
                      "FMA mix like an FFT's (tools/f64_lab.hip), not the 614 G/s the datasheet's 78.6 TFLOP/s stand for")
+    elif wl in ("fir4097", "fir8193"):
+        # the long-tap plans of the complex_float32 FIR (2049 < K <= 8193): 8192- / 16384-sample blocks, HALF of every block overlap at
+        # these tap counts -- every input sample is fetched twice (the second time from L2 / the Infinity Cache when the neighbour ran
+        # recently) and every output costs twice the transform work of the headline's
+        n = C
+        K = 4097 if wl == "fir4097" else 8193
+        h = tp.complex_bandpass(K, 0.05, 0.05)
+        f = device.FirFilter("complex_float32", "COMPLEX")
+        f.set_taps(h)
+        lead = (-(K - 1)) % 16
+        xa = torch.empty((lead + n + K - 1, 2), dtype=torch.float32, device=dev)
+        x = xa[lead:]
+        y = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        device.fill_uniform_f32_dev(x, seed=9, offset=0)
+        W.units = n
+        W.roof_bytes = 16.0 * n
+        W.read_bytes = 8.0 * n
+        W.kernel_name = "fir_cf32_ols_r16_kernel"
+        W.step = lambda: f.process_dev(x, y)
+        W.inputs = (x,)
+        W.desc = {"workload": "%d-tap complex_float32 FIR, %d-sample overlap-save blocks, %d samples per GPU" % (K, 8192 if K <= 4097 else 16384, n),
+                  "taps": K}
+        W.metric = "Msamples/s complex_float32 %d-tap FIR" % K
+        N = 8192 if K <= 4097 else 16384
+        W.blocks = -(-n // (N - (K - 1 + 15) // 16 * 16))
+        W.limiter = ("half of every block is overlap at this tap count: two transforms of N samples per N/2 outputs (twice the headline's "
+                     "arithmetic per output) and 24 B of memory traffic per output where the window's second fetch misses the caches")
     elif wl in ("abs", "freq_demod"):
         # complex_float32 in, float32 out: 8 B read + 4 B written per sample, one launch per step
         n = C
@@ -920,6 +947,9 @@ def cpu_baseline_of(wl, C):
         return cpu_baseline_resampler(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8), 8, 1, cpu_n)
     if wl == "interp4":
         return cpu_baseline_resampler(tp.complex_bandpass(255 * 4, 0.05 / 4, 0.05 / 4) * 4, 1, 4, cpu_n // 4)
+    if wl in ("fir4097", "fir8193"):
+        K = 4097 if wl == "fir4097" else 8193
+        return cpu_baseline_fir(tp.complex_bandpass(K, 0.05, 0.05), 9, 1024 * 1024)
     return cpu_baseline_fir_i16(tp.c1_taps() * 0.9, cpu_n // 2)
 
 

@@ -12,6 +12,13 @@
 // re-read overlap, 8 spilled VGPRs at 2048), so K <= 2049 stays on fir_ols.hip and this file serves
 // the taps too long for it: N = 8192 for K-1 <= 4096, N = 16384 for K-1 <= 8192 (pcx_api.hip).
 //
+// Round 6, the long-tap plans under the counters (K = 4097 on 8192-sample blocks, 64 Mi samples, profiles/r06/fir4097_*): 0.48 ms;
+// HBM traffic 1.08 GB read + 0.54 GB written = 3.4 TB/s (every window is fetched in full: at this tap count half of it is overlap,
+// and the second fetch misses the caches); VALU 39 % of SIMD time, 21 % of the LDS cycles bank conflicts, waves waiting on LDS 18 %
+// of their time.  No single roof: half-overlap blocks cost twice the headline's arithmetic and 24 B of traffic per output.
+// Tried and dropped: the next window fetched ahead under a 128-VGPR budget (H and the pass-256 factors then have to be re-read
+// from L2 per block to make room): 140 -> 121 Gsamples/s at 4097 taps, 90 -> 81 at 8193.
+//
 // Lane l of a block holds x[l + s*LPF], s = 0..15, LPF = N/16.  A forward transform leaves
 // X[l + k*LPF] in the lane (k = register index for a final radix-R pass, bin_of(q) after a
 // final radix-16 pass): exactly the layout the next transform's first pass wants, so the

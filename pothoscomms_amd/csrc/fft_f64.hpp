@@ -171,20 +171,28 @@ __device__ __forceinline__ Lane make_lane(int l)
 // 144 more instructions per block on 1,420, 7 % slower; the LDS table read one entry at a time in front of each multiply,
 // as the compiler orders it by itself -- thirty exposed LDS latencies per block.
 struct LaneTw {
-    cd a[15];
+    cd a[13];      // w^1 .. w^13; w^14 = w^12 . w^2 and w^15 = w^12 . w^3 at their two uses each (the eight registers they would hold
+                   // are the dealer's and the fetch-ahead's: at 256 the allocator spills whatever lives longest, and reloads it behind vmcnt(0))
     int t2;        // slot of the lane's column of the table
     __device__ __forceinline__ void load(const cd *tab, const Lane &L)
     {
 #pragma unroll
-        for (int p = 0; p < 15; p++) a[p] = tab[kTabT1 + p * 256 + L.idx2];
+        for (int p = 0; p < 13; p++) a[p] = tab[kTabT1 + p * 256 + L.idx2];
         t2 = kT2 + L.c1;
+    }
+    __device__ __forceinline__ cd pow(int k) const      // k = 1 .. 15, a constant after unrolling
+    {
+        if (k < 14) return a[k - 1];
+        cd t = a[11];
+        asm volatile("" : "+v"(t.x), "+v"(t.y));        // (or the product is computed once ahead of the block loop and kept: the registers again)
+        return cmul(t, a[k - 13]);
     }
     // in front of the block loop: the waits for the table loads belong there (fir_cf64_ip_kernel)
     __device__ __forceinline__ void opaque()
     {
 #pragma unroll
-        for (int p = 0; p < 15; p += 3)
-            asm volatile("" : "+v"(a[p].x), "+v"(a[p].y), "+v"(a[p + 1].x), "+v"(a[p + 1].y), "+v"(a[p + 2].x), "+v"(a[p + 2].y));
+        for (int p = 0; p < 12; p += 2) asm volatile("" : "+v"(a[p].x), "+v"(a[p].y), "+v"(a[p + 1].x), "+v"(a[p + 1].y));
+        asm volatile("" : "+v"(a[12].x), "+v"(a[12].y));
     }
 };
 // v[idx(i)] *= T2[i] for i = 1 .. 15, the table entries fetched five at a time (the scheduler may not pull the reads apart)
@@ -217,7 +225,7 @@ __device__ __forceinline__ void forward(cd (&v)[16], cd *lds, const Lane &L, con
 {
     fft16_plain(v);
 #pragma unroll
-    for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw.a[bin_of(q) - 1]);
+    for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw.pow(bin_of(q)));
     if (PART != 2) {
 #pragma unroll
         for (int q = 0; q < 16; q++) lds[L.b2 + kRow * bin_of(q)] = v[q];
@@ -235,7 +243,7 @@ __device__ __forceinline__ void forward(cd (&v)[16], cd *lds, const Lane &L, con
         for (int s = 0; s < 16; s++) v[s] = lds[L.b0 + s];
     } else {
 #pragma unroll
-        for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw.a[15 - q]);
+        for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw.pow(16 - q));
     }
     fft16_plain(v);
 }
@@ -253,7 +261,7 @@ __device__ __forceinline__ void backward(cd (&u)[16], cd *lds, const Lane &L, co
         mul_t2(u, lds, tw.t2, [](int k) { return k; });
     } else {
 #pragma unroll
-        for (int s = 1; s < 16; s++) u[s] = cmul(u[s], tw.a[15 - s]);
+        for (int s = 1; s < 16; s++) u[s] = cmul(u[s], tw.pow(16 - s));
     }
     fft16_plain(u);
     if (PART != 2) {
@@ -264,7 +272,7 @@ __device__ __forceinline__ void backward(cd (&u)[16], cd *lds, const Lane &L, co
         for (int s = 0; s < 16; s++) u[s] = lds[L.b2 + kRow * s];
     }
 #pragma unroll
-    for (int s = 1; s < 16; s++) u[s] = cmul(u[s], tw.a[s - 1]);
+    for (int s = 1; s < 16; s++) u[s] = cmul(u[s], tw.pow(s));
     fft16_plain(u);
 }
 }  // namespace ip4096

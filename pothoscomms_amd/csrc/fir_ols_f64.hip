@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "pcx_internal.hpp"
+#include "pcx_sched.hpp"
 
 namespace pcx {
 
@@ -616,18 +617,28 @@ __device__ __forceinline__ void ip_store(const cd (&u)[16], unsigned char *out, 
 // FLOORQ: the integer streams' fromQ is the plain arithmetic shift (PCX_Q_FLOOR, the default reading) -- a kernel of its own, not
 // a branch in front of the stores: two alternative store sequences that join make the compiler's count of the stores in flight
 // inexact, and its wait for the fetched-ahead loads at the foot of the loop then drains them.
-template <int IO, bool DECIM, bool FLOORQ, int PART = 0>
+// DYN: 512 persistent workgroups (two per CU) that DRAW their blocks (pcx_sched.hpp AheadDealer: the next block must be known at
+// the head of a block, for the fetch-ahead, so blocks are dealt in strided pairs with the draw one block ahead) instead of ~4,400
+// workgroups of four blocks each: the tables (H, the pass factors: 124 registers from L2) are loaded once per 34 blocks instead of
+// once per 4, and the launch no longer ends on a half-empty ninth round of workgroups.
+template <int IO, bool DECIM, bool FLOORQ, int PART = 0, bool DYN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_cf64_ip_kernel(
     const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, size_t n_dec, unsigned M, unsigned magic,
-    const double2 *__restrict__ Hspec, int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks, QShift qs)
+    const double2 *__restrict__ Hspec, int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks, QShift qs, SchedState *__restrict__ sched)
 {
     typedef IpIo<IO> SIO;
+    constexpr bool PRIO = true;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd *lds = reinterpret_cast<cd *>(smem_raw);
+    __shared__ unsigned sched_slot;
     const int l = threadIdx.x;
     const size_t S = (size_t)(4096 - Kov);
     size_t b = blockIdx.x;
-    if (b >= nblocks) return;
+    AheadDealer deal;
+    if (DYN) {
+        if (!deal.begin(sched, &sched_slot, nblocks, l)) { deal.finish(l); return; }
+        b = deal.block();
+    } else if (b >= nblocks) return;
     const ip4096::Lane L = ip4096::make_lane(l);
     typename SIO::Raw raw[16];
     ip_fetch<IO, true>(raw, in, in_elems, b, nblocks, S, pad, L.idx2);       // the first block's samples ahead of the tables
@@ -655,8 +666,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (;;) {
         // the next block's samples (nb >= gridDim.x >= 1: never block 0); behind the last block an empty descriptor, no branch: the
         // compiler must be able to COUNT the loads and stores in flight, or its wait for these loads at the foot drains the stores too
-        const size_t nb = b + gridDim.x;
+        size_t nb = b + gridDim.x;
+        const bool more = DYN ? deal.next(&nb) : nb < nblocks;
+        if (!more) nb = nblocks;
+        // (the dealer's "lane 0" is asked for through L.idx2, which is 0 for lane 0 alone and lives in a register across the loop anyway:
+        // threadIdx.x itself did not, and came back from scratch behind an s_waitcnt vmcnt(0) at the head of every block)
+        if (DYN) deal.draw(L.idx2);    // (ahead of the fetch in the in-order vmcnt queue.  One conditional operation there, younger than
+                                       //  nothing the foot waits for: it makes that wait a notch stronger, it cannot make it drain the stores)
         if (SIO::kAhead) ip_fetch<IO, false>(raw, in, in_elems, nb, nblocks, S, pad, L.idx2);
+        // Wave priority rises with the progress through a block: 1 for the forward transform, 2 from the backward one to the last
+        // store, 0 again for the foot (the fetched-ahead samples' conversion).  A SIMD holds one wave of each of the CU's two
+        // workgroups; without it the two drift into the same phase and wait on LDS together.  Interleaved on two boxes
+        // (profiles/r06/ab_ip64_prio.txt): none 0.2873, second half at 1: 0.2818, at 3: 0.2775, 1 then 2: 0.2773 ms.
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
         ip4096::forward<PART>(v, lds, L, pw);
         // u = conj(X .* H), in the natural register order the backward passes start from
         cd u[16];
@@ -665,18 +687,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const cd p = cmul(v[q], H[q]);
             u[bin_of(q)] = cd{p.x, -p.y};
         }
+        if (DYN) deal.publish(L.idx2); // the backward passes' barriers come behind it
+        if (PRIO) __builtin_amdgcn_s_setprio(2);
         ip4096::backward<PART>(u, lds, L, pw);
         ip_store<IO, DECIM, FLOORQ>(u, out, n_out, n_dec, M, magic, b, S, Kov, L.idx2, qs);
-        if (nb >= nblocks) break;
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (!more) break;
+        if (DYN) (void)deal.advance();
         b = nb;
         if (!SIO::kAhead) ip_fetch<IO, false>(raw, in, in_elems, b, nblocks, S, pad, L.idx2);
 #pragma unroll
         for (int s = 0; s < 16; s++) v[s] = SIO::cvt(raw[s]);
     }
+    if (DYN) deal.finish(L.idx2);
 }
 
 template <int IO>
-int launch_ip(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, hipStream_t st)
+int launch_ip(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, void *sched,
+              hipStream_t st)
 {
     const size_t Km1 = K - 1;
     const size_t Kov = (Km1 + 15) / 16 * 16;
@@ -686,20 +714,25 @@ int launch_ip(const void *in, size_t in_elems, void *out, size_t n_out, const vo
     const size_t nblocks = (n_out + S - 1) / S;
     const size_t lds = (size_t)ip4096::kLdsSlots * sizeof(cd);
     const bool floorq = IO == 0 || qs.mode == PCX_Q_FLOOR;
+    // dealt from 512 persistent workgroups when the call is long enough for it to matter and nothing asks for a small grid (a
+    // link-bound host call, pcx_internal.hpp); PCX_SCHED_STATIC (diagnostic library) keeps the grid-stride walk for A/B
+    // (M == 1: with the decimating store's index arithmetic on top the dealt form spills a register, and reloads it behind vmcnt(0))
+    const bool dyn = sched && M == 1 && nblocks > 4 * 512 && nblocks < ((size_t)1 << 31) && !g_link_grid && !PCX_ENV_SET("PCX_SCHED_STATIC");
     auto k = M > 1 ? (floorq ? fir_cf64_ip_kernel<IO, true, true> : fir_cf64_ip_kernel<IO, true, IO == 0>)
                    : (floorq ? fir_cf64_ip_kernel<IO, false, true> : fir_cf64_ip_kernel<IO, false, IO == 0>);
+    if (dyn) k = floorq ? fir_cf64_ip_kernel<IO, false, true, 0, true> : fir_cf64_ip_kernel<IO, false, IO == 0, 0, true>;
 #ifdef PCX_DIAG
     // timing-only parts of the transform pair (fft_f64.hpp PART; wrong outputs): PCX_IP64_PART=1 no barriers, 2 arithmetic only
-    if (IO == 1 && M == 1 && floorq && PCX_ENV_INT("PCX_IP64_PART", 0) == 1) k = fir_cf64_ip_kernel<1, false, true, 1>;
-    if (IO == 1 && M == 1 && floorq && PCX_ENV_INT("PCX_IP64_PART", 0) == 2) k = fir_cf64_ip_kernel<1, false, true, 2>;
+    if (IO == 1 && M == 1 && floorq && PCX_ENV_INT("PCX_IP64_PART", 0) == 1) k = dyn ? fir_cf64_ip_kernel<1, false, true, 1, true> : fir_cf64_ip_kernel<1, false, true, 1>;
+    if (IO == 1 && M == 1 && floorq && PCX_ENV_INT("PCX_IP64_PART", 0) == 2) k = dyn ? fir_cf64_ip_kernel<1, false, true, 2, true> : fir_cf64_ip_kernel<1, false, true, 2>;
 #endif
     const unsigned magic = M > 1 ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
     PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // two workgroups per CU (73 KB of LDS each); about four blocks per workgroup whatever the call (pcx_internal.hpp rounds_grid:
     // +5 % over one round at 64 Mi samples, tools/ab_oversub.sh)
-    const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * 2, 1) : rounds_grid(nblocks, 256 * 2, 4);
+    const unsigned grid = dyn ? 512u : PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * 2, 1) : rounds_grid(nblocks, 256 * 2, 4);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out, n_out / M, (unsigned)M, magic,
-                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks, qs);
+                       (const double2 *)Hspec, (int)Kov, (int)pad, (const double2 *)tw, nblocks, qs, (SchedState *)sched);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -745,6 +778,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int s = 0; s < 16; s++)
             v[s] = cd{RIO::load(rs[0], (L.idx2 + 256 * s - shift[0]) * EB), RIO::load(rs[1], (L.idx2 + 256 * s - shift[1]) * EB)};
+        __builtin_amdgcn_s_setprio(1);      // (priority rising with the progress through a block: fir_cf64_ip_kernel says why)
         ip4096::forward(v, lds, L, pw);
         const cd *Hb = Hg;
         asm volatile("" : "+v"(Hb));   // keeps the loads inside the loop (they are loop-invariant and would be hoisted back into registers)
@@ -754,6 +788,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const cd p = cmul(v[q], Hb[256 * bin_of(q)]);
             u[bin_of(q)] = cd{p.x, -p.y};
         }
+        __builtin_amdgcn_s_setprio(2);
         ip4096::backward(u, lds, L, pw);
         if (DECIM) {
 #pragma unroll
@@ -794,6 +829,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 RIO::store(ws[1], (int)(vbase + (unsigned)row * (unsigned)EB), -u[q].y, qs);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -823,14 +859,14 @@ int launch_real_ip(const void *in, size_t in_elems, void *out, size_t n_out, con
 // log2n 12 (K <= 2049: the in-place kernels) or 13; Hspec = FFT_N(h)/N in double, natural bin order; tw = make_tw_ols64(log2n) (pcx_api.hip).  io: 0 complex_float64,
 // 1 complex_int16, 2 complex_int8 (h = the Q-format integer taps; see StreamIo).  n_out = full-rate outputs; M > 1 keeps one in M
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
-                        const void *tw, int io, size_t M, QShift qs, hipStream_t st)
+                        const void *tw, int io, size_t M, QShift qs, hipStream_t st, void *sched)
 {
     if (n_out == 0) return PCX_OK;
     if (M < 1 || M > 65535) { set_error("fir ols f64: decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
     if (log2n == 12)
-        return io == 0   ? launch_ip<0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
-               : io == 1 ? launch_ip<1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
-                         : launch_ip<2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
+        return io == 0   ? launch_ip<0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, sched, st)
+               : io == 1 ? launch_ip<1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, sched, st)
+                         : launch_ip<2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, sched, st);
     if (log2n == 13)
         return io == 0   ? launch_ols<13, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
                : io == 1 ? launch_ols<13, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)

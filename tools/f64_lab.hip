@@ -40,6 +40,48 @@ __global__ __launch_bounds__(256) void k(double *out, unsigned long long *cyc, d
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// dependency distance: the same number of v_add_f64 / v_fma_f64, but only NACC independent chains (an instruction depends on the one
+// NACC instructions before it): how much instruction-level parallelism does the FP64 pipe need from ONE wave?
+template <int NACC, int FMA>
+__global__ __launch_bounds__(256) void kdep(double *out, unsigned long long *cyc, double a, double b)
+{
+    double r[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) r[i] = a * (threadIdx.x + i);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int j = 0; j < 16 / NACC; j++)
+#pragma unroll
+            for (int i = 0; i < NACC; i++) {
+                if (FMA) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(b), "v"(a));
+                else asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+            }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) s += r[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int NACC, int FMA>
+void rundep(int wgs_per_cu, double *out, unsigned long long *cyc)
+{
+    const int grid = 256 * wgs_per_cu;
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL((kdep<NACC, FMA>), dim3(grid), dim3(256), 0, 0, out, cyc, 1.0000001, 0.9999999);
+        CHECK(hipDeviceSynchronize());
+    }
+    std::vector<unsigned long long> h(grid);
+    CHECK(hipMemcpy(h.data(), cyc, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double mean = 0;
+    for (auto c : h) mean += (double)c;
+    mean /= grid;
+    printf("%s, %2d independent chain(s) per wave, %d wave(s)/SIMD: %.2f clk per wave-instruction (one wave's view), %.2f per instruction per SIMD\n",
+           FMA ? "fma_f64" : "add_f64", NACC, wgs_per_cu, mean / (ITER * 16.0), mean / (ITER * 16.0) / wgs_per_cu);
+}
+
 template <int KIND>
 void run(const char *name, int wgs_per_cu, double *out, unsigned long long *cyc)
 {
@@ -77,6 +119,10 @@ int main()
         run<5>("fft mix", w, out, cyc);
         run<3>("add_f32", w, out, cyc);
         run<4>("xor_b32", w, out, cyc);
+    }
+    for (int w = 1; w <= 2; w++) {
+        rundep<1, 0>(w, out, cyc); rundep<2, 0>(w, out, cyc); rundep<4, 0>(w, out, cyc); rundep<8, 0>(w, out, cyc); rundep<16, 0>(w, out, cyc);
+        rundep<1, 1>(w, out, cyc); rundep<2, 1>(w, out, cyc); rundep<4, 1>(w, out, cyc); rundep<8, 1>(w, out, cyc); rundep<16, 1>(w, out, cyc);
     }
     return 0;
 }

@@ -104,6 +104,9 @@ __device__ __forceinline__ void xform(cd (&v)[16], cd *lds, int l, T3 t3, const 
 // transform carries that convolution exactly: with |x| <= 2^15, ||h_q||_2 < 2^22 (checked by the caller) and 4096-
 // or 8192-sample blocks its error stays below 0.05 (eps * c log2 N * ||x||_2 ||h||_2), so rounding to the nearest
 // integer recovers every sum bit for bit before the same wrap, shift and truncation are applied.
+// the exact integer sum held in a double -> its value modulo 2^32: adding 1.5 * 2^52 leaves round-to-nearest-even(d) in the low dword of
+// the sum -- one v_add_f64 instead of the software double -> int64 conversion (|d| < 2^51: sums stay below 2^45 under the caller's bound)
+__device__ __forceinline__ int wrap_i32(double d) { return __double2loint(d + 6755399441055744.0); }
 template <int IO>
 struct StreamIo;
 template <>
@@ -128,7 +131,7 @@ struct StreamIo<1> {
     }
     static __device__ __forceinline__ unsigned q(double d, QShift qs)   // wrap to the 32-bit Q accumulator, fromQ (pcx_qformat.hpp), truncate to int16
     {
-        const int w = (int)(unsigned)(unsigned long long)__double2ll_rn(d);
+        const int w = wrap_i32(d);
         return (unsigned)from_q_bits<int>(w, qs) & 0xffffu;
     }
     static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y, QShift qs)
@@ -146,7 +149,7 @@ struct StreamIo<2> {
     }
     static __device__ __forceinline__ unsigned q(double d, QShift qs)   // 16-bit Q accumulator, fromQ, truncate to int8
     {
-        const short w = (short)(unsigned short)(unsigned long long)__double2ll_rn(d);
+        const short w = (short)wrap_i32(d);
         return (unsigned)from_q_bits<short>(w, qs) & 0xffu;
     }
     static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, cd y, QShift qs)
@@ -478,10 +481,7 @@ int launch_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, co
 // N = 4096 on the in-place transform pair (fft_f64.hpp, ip4096)
 // --------------------------------------------------------------------------------- //
 // Element types as the transform pair's kernels see them: a RAW register image of one sample (what a fetch-ahead keeps: one
-// dword for the integer streams), its conversion, and the store.  The integer stores: the double holds the exact integer
-// sum (StreamIo above); adding 1.5 * 2^52 leaves round-to-nearest-even(d) modulo 2^32 in the low dword of the sum -- one
-// v_add_f64 instead of the software double -> int64 conversion (|d| < 2^51: sums stay below 2^45 under the caller's bound).
-__device__ __forceinline__ int wrap_i32(double d) { return __double2loint(d + 6755399441055744.0); }
+// dword for the integer streams), its conversion, and the store (the integer stores: wrap_i32 above).
 // fromQ under any of the three roundings (pcx_qformat.hpp from_q_bits) without a branch: floor + ((rem + add) >> n) with
 // add = 0 (FLOOR), 2^(n-1) (ROUND), the remainder mask for negative values (TOWARD_ZERO: + 1 iff q < 0 and rem != 0)
 struct QRound {
@@ -524,7 +524,10 @@ struct IpIo<1> {
     }
     template <bool FLOORQ> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, cd y, QShift qs)
     {
-        __builtin_amdgcn_raw_buffer_store_b32(q<FLOORQ>(y.x, qs) | (q<FLOORQ>(y.y, qs) << 16), ws, voff, soff, kAuxStream);
+        // FLOORQ: q >> 16 on both parts and the two halves packed = the HIGH halves of the two wrapped sums side by side: one v_perm_b32
+        const unsigned packed = FLOORQ ? __builtin_amdgcn_perm((unsigned)wrap_i32(y.y), (unsigned)wrap_i32(y.x), 0x07060302u)
+                                       : (q<false>(y.x, qs) | (q<false>(y.y, qs) << 16));
+        __builtin_amdgcn_raw_buffer_store_b32(packed, ws, voff, soff, kAuxStream);
     }
 };
 template <>
@@ -541,7 +544,10 @@ struct IpIo<2> {
     }
     template <bool FLOORQ> static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t ws, int voff, int soff, cd y, QShift qs)
     {
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(q<FLOORQ>(y.x, qs) | (q<FLOORQ>(y.y, qs) << 8)), ws, voff, soff, kAuxStream);
+        // FLOORQ: (q >> 8) & 0xff of the two 16-bit sums = byte 1 of each wrapped sum
+        const unsigned packed = FLOORQ ? __builtin_amdgcn_perm((unsigned)wrap_i32(y.y), (unsigned)wrap_i32(y.x), 0x0c0c0501u)
+                                       : (q<false>(y.x, qs) | (q<false>(y.y, qs) << 8));
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)packed, ws, voff, soff, kAuxStream);
     }
 };
 
@@ -614,7 +620,8 @@ __device__ __forceinline__ void ip_store(const cd (&u)[16], unsigned char *out, 
     }
 }
 
-// FLOORQ: the integer streams' fromQ is the plain arithmetic shift (PCX_Q_FLOOR, the default reading) -- a kernel of its own, not
+// FLOORQ: the integer streams' fromQ is the plain arithmetic shift by HALF the accumulator (PCX_Q_FLOOR + PCX_Q_FRAC_HALF_Q, the default
+// reading: 16 of 32 bits for int16, 8 of 16 for int8; every other reading takes the branch-free general form) -- a kernel of its own, not
 // a branch in front of the stores: two alternative store sequences that join make the compiler's count of the stores in flight
 // inexact, and its wait for the fetched-ahead loads at the foot of the loop then drains them.
 // DYN: 512 persistent workgroups (two per CU) that DRAW their blocks (pcx_sched.hpp AheadDealer: the next block must be known at
@@ -713,7 +720,7 @@ int launch_ip(const void *in, size_t in_elems, void *out, size_t n_out, const vo
     const size_t S = 4096 - Kov;
     const size_t nblocks = (n_out + S - 1) / S;
     const size_t lds = (size_t)ip4096::kLdsSlots * sizeof(cd);
-    const bool floorq = IO == 0 || qs.mode == PCX_Q_FLOOR;
+    const bool floorq = IO == 0 || (qs.mode == PCX_Q_FLOOR && qs.shift == (IO == 1 ? 16 : 8));
     // dealt from 512 persistent workgroups when the call is long enough for it to matter and nothing asks for a small grid (a
     // link-bound host call, pcx_internal.hpp); PCX_SCHED_STATIC (diagnostic library) keeps the grid-stride walk for A/B
     // (M == 1: with the decimating store's index arithmetic on top the dealt form spills a register, and reloads it behind vmcnt(0))

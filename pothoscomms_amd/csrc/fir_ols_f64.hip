@@ -746,10 +746,13 @@ int launch_ip(const void *in, size_t in_elems, void *out, size_t n_out, const vo
 
 // REAL streams on the in-place pair: two consecutive real blocks as the real and imaginary part of one complex block, as
 // fir_real_ols_kernel below.  H is re-read from L2 at the multiply (two windows' descriptors and offsets are live across the block).
-template <int IO, bool DECIM>
+// DYN: blocks drawn one at a time from 512 persistent workgroups (pcx_sched.hpp BlockDealer; no fetch-ahead here, so the next block need
+// only be known at the end of the current one) instead of the grid-stride walk over ~4 blocks per workgroup
+template <int IO, bool DECIM, bool DYN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_real_ip_kernel(
     const unsigned char *__restrict__ in, size_t in_elems, unsigned char *__restrict__ out, size_t n_out, const double2 *__restrict__ Hspec,
-    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real, size_t n_dec, unsigned M, unsigned magic, QShift qs)
+    int Kov, int pad, const double2 *__restrict__ twtab, size_t nblocks_real, size_t n_dec, unsigned M, unsigned magic, QShift qs,
+    SchedState *__restrict__ sched)
 {
     typedef RealIo<IO> RIO;
     constexpr int EB = RIO::EB;
@@ -758,9 +761,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int l = threadIdx.x;
     const size_t S = (size_t)(4096 - Kov);
     const size_t nblocks = (nblocks_real + 1) / 2;
-    size_t b = blockIdx.x;
-    if (b >= nblocks) return;
+    __shared__ unsigned sched_slot;
     const ip4096::Lane L = ip4096::make_lane(l);
+    BlockWalk<DYN> walk;
+    if (!walk.begin(sched, &sched_slot, nblocks, L.idx2)) { walk.finish(L.idx2); return; }     // (L.idx2 == 0 for lane 0 alone: the dealer's "lane")
     const cd *tab = reinterpret_cast<const cd *>(twtab);
     if (l < 240) lds[ip4096::kT2 + l] = tab[l];
     ip4096::LaneTw pw;
@@ -768,7 +772,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const cd *Hg = reinterpret_cast<const cd *>(Hspec) + L.k0;
     pw.opaque();     // the waits for the table loads in front of the loop (fir_cf64_ip_kernel)
 
-    for (; b < nblocks; b += gridDim.x) {
+    for (;;) {
+        const size_t b = walk.block();
         __amdgpu_buffer_rsrc_t rs[2];
         int shift[2];
 #pragma unroll
@@ -785,6 +790,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int s = 0; s < 16; s++)
             v[s] = cd{RIO::load(rs[0], (L.idx2 + 256 * s - shift[0]) * EB), RIO::load(rs[1], (L.idx2 + 256 * s - shift[1]) * EB)};
+        walk.draw(L.idx2);                  // (every load of the block has been issued; its value is parked in front of the backward passes' barriers)
         __builtin_amdgcn_s_setprio(1);      // (priority rising with the progress through a block: fir_cf64_ip_kernel says why)
         ip4096::forward(v, lds, L, pw);
         const cd *Hb = Hg;
@@ -795,6 +801,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const cd p = cmul(v[q], Hb[256 * bin_of(q)]);
             u[bin_of(q)] = cd{p.x, -p.y};
         }
+        walk.publish(L.idx2);
         __builtin_amdgcn_s_setprio(2);
         ip4096::backward(u, lds, L, pw);
         if (DECIM) {
@@ -837,11 +844,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if (!walk.advance()) break;
     }
+    walk.finish(L.idx2);
 }
 
 template <int IO>
-int launch_real_ip(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, hipStream_t st)
+int launch_real_ip(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, const void *tw, size_t M, QShift qs, void *sched,
+                   hipStream_t st)
 {
     const size_t Km1 = K - 1;
     const size_t Kov = (Km1 + 15) / 16 * 16;
@@ -851,12 +861,13 @@ int launch_real_ip(const void *in, size_t in_elems, void *out, size_t n_out, con
     const size_t nblocks_real = (n_out + S - 1) / S;
     const size_t nblocks = (nblocks_real + 1) / 2;
     const size_t lds = (size_t)ip4096::kLdsSlots * sizeof(cd);
-    auto k = M > 1 ? fir_real_ip_kernel<IO, true> : fir_real_ip_kernel<IO, false>;
+    const bool dyn = sched && M == 1 && nblocks > 4 * 512 && nblocks < ((size_t)1 << 31) && !g_link_grid && !PCX_ENV_SET("PCX_SCHED_STATIC");
+    auto k = M > 1 ? fir_real_ip_kernel<IO, true> : dyn ? fir_real_ip_kernel<IO, false, true> : fir_real_ip_kernel<IO, false>;
     const unsigned magic = M > 1 ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
     PCX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * 2, 1) : rounds_grid(nblocks, 256 * 2, 4);
+    const unsigned grid = dyn ? 512u : PCX_ENV_INT("PCX_OVERSUB", 0) > 0 ? persistent_grid(nblocks, 256 * 2, 1) : rounds_grid(nblocks, 256 * 2, 4);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, (const unsigned char *)in, in_elems, (unsigned char *)out, n_out, (const double2 *)Hspec, (int)Kov,
-                       (int)pad, (const double2 *)tw, nblocks_real, n_out / M, (unsigned)M, magic, qs);
+                       (int)pad, (const double2 *)tw, nblocks_real, n_out / M, (unsigned)M, magic, qs, (SchedState *)sched);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -888,15 +899,15 @@ namespace pcx {
 // REAL streams on the same pipeline (real taps): io 0 float64, 1 int16, 2 int8, 3 float32; log2n 12 (K <= 2049) or 13 (K <= 4097);
 // n_out = full-rate outputs, M > 1 keeps one in M
 int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n, const void *tw,
-                        int io, size_t M, QShift qs, hipStream_t st)
+                        int io, size_t M, QShift qs, hipStream_t st, void *sched)
 {
     if (n_out == 0) return PCX_OK;
     if (M < 1 || M > 65535) { set_error("fir ols (real): decimation %zu outside 1..65535", M); return PCX_ERR_UNSUPPORTED; }
     if (log2n == 12)
-        return io == 0   ? launch_real_ip<0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
-               : io == 1 ? launch_real_ip<1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
-               : io == 2 ? launch_real_ip<2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
-                         : launch_real_ip<3>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st);
+        return io == 0   ? launch_real_ip<0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, sched, st)
+               : io == 1 ? launch_real_ip<1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, sched, st)
+               : io == 2 ? launch_real_ip<2>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, sched, st)
+                         : launch_real_ip<3>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, sched, st);
     if (log2n == 13)
         return io == 0   ? launch_real_ols<13, 0>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)
                : io == 1 ? launch_real_ols<13, 1>(in, in_elems, out, n_out, Hspec, K, tw, M, qs, st)

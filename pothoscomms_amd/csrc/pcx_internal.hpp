@@ -257,7 +257,7 @@ int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
                         const void *tw, int io, size_t M, QShift qs, hipStream_t st, void *sched = nullptr);
 int launch_fir_real_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n, const void *tw,
-                        int io, size_t M, QShift qs, hipStream_t st);
+                        int io, size_t M, QShift qs, hipStream_t st, void *sched = nullptr);
 
 // real float32 stream, real taps, M=L=1: two real blocks per complex transform
 int launch_fir_f32_ols4096(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K,

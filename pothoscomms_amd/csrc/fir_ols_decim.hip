@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
             for (int k1 = 0; k1 < P; k1++) zz[g * P + k1] = z[k1];
         }
         // ---- one inverse stage for the whole group: T sub-transforms of 256 points, 16 lanes each ----
+        __builtin_amdgcn_s_setprio(1);                    // (the second half of a group ahead of another workgroup's first: fir_ols_f64.hip, round 6)
         __syncthreads();                                  // the last block's pass-3 reads of the image are done
 #pragma unroll
         for (int t = 0; t < T; t++) lds[t * FRAME + js + (js >> 4)] = zz[t];
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(256, OCC) void fir_cf32_ols4096_decim_batched_kerne
                 store_cf<2>(ws, vbase + (unsigned)(256 * i) * 8u, y);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -784,6 +786,7 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(1);                    // (the group's inverse transforms and stores ahead of another workgroup's forward stage)
         // park the lane's values of every block: the inverse passes below reuse the image
         cf gg[T];
 #pragma unroll
@@ -829,6 +832,7 @@ __global__ __launch_bounds__(256, 3) void fir_cf32_ols4096_interp_batched_kernel
                 store_cf<2>(ws, vbase + (unsigned)row * 8u, u[q]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 

@@ -17,7 +17,8 @@
 // and the second fetch misses the caches); VALU 39 % of SIMD time, 21 % of the LDS cycles bank conflicts, waves waiting on LDS 18 %
 // of their time.  No single roof: half-overlap blocks cost twice the headline's arithmetic and 24 B of traffic per output.
 // Tried and dropped: the next window fetched ahead under a 128-VGPR budget (H and the pass-256 factors then have to be re-read
-// from L2 per block to make room): 140 -> 121 Gsamples/s at 4097 taps, 90 -> 81 at 8193.
+// from L2 per block to make room): 140 -> 121 Gsamples/s at 4097 taps, 90 -> 81 at 8193; the second half of a block at wave
+// priority 1 (what gave the 4096-sample resamplers 3-6 %): -1.5 % / +-0 here (four waves per SIMD of two workgroups).
 //
 // Lane l of a block holds x[l + s*LPF], s = 0..15, LPF = N/16.  A forward transform leaves
 // X[l + k*LPF] in the lane (k = register index for a final radix-R pass, bin_of(q) after a

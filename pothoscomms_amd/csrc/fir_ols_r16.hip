@@ -209,7 +209,6 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF, 4) void fir_cf32_ols_r16_kerne
             else cmul2_conj(u[k0], u[k1], H[k0], H[k1]);
         }
         if (TFG) asm volatile("" : "+v"(tfp));
-        __builtin_amdgcn_s_setprio(1);      // the second half of a block ahead of the other workgroup's first (as fir_ols.hip; A/B in the header)
         if (DIAG != 2) xform<LOG2N, TFS>(u, lds, l, t3, tfp);
         // time sample i = l + k*LPF of the block is output b*S + i - Kov; i < Kov wraps past
         // num_records and is dropped by the range check, as are outputs past n_out
@@ -223,7 +222,6 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF, 4) void fir_cf32_ols_r16_kerne
             if (row + LPF - 1 < Kov) continue;                // whole row dropped: uniform skip
             store_cf<0>(ws, vbase + (unsigned)row * 8u, cf{u[q].x, -u[q].y});
         }
-        __builtin_amdgcn_s_setprio(0);
     }
 }
 

@@ -344,9 +344,14 @@ def test_supervised_bench_a_broken_exchange_in_the_one_launch_form_is_retimed_in
 def test_supervised_bench_no_line_when_every_form_fails():
     """PCX_BENCH_TEST_BREAK_SEAM=2: the exchange delivers nothing in any form -- every attempt ends in a failed seam check, the run
     exits non-zero and prints NO line (a number with wrong seams is not a measurement)"""
-    r, lines = _bench_standin({"PCX_BENCH_TEST_BREAK_SEAM": "2"})
-    assert r.returncode != 0 and not lines
-    assert "attempt 2" in r.stderr and "every attempt failed" in r.stderr
+    # (up to two goes: on a loaded box a rendezvous of one of the six child groups this run starts has been seen to fail for reasons of
+    # its own -- once in a dozen full suites --, which ends the run just as non-zero and line-less but by another road)
+    for go in range(2):
+        r, lines = _bench_standin({"PCX_BENCH_TEST_BREAK_SEAM": "2"})
+        assert r.returncode != 0 and not lines
+        if "attempt 2" in r.stderr and "every attempt failed" in r.stderr:
+            break
+    assert "attempt 2" in r.stderr and "every attempt failed" in r.stderr, r.stderr[-3000:]
 
 
 def test_supervised_bench_a_teardown_that_hangs_behind_the_line_does_not_cost_it():

@@ -238,3 +238,53 @@ def test_dynamic_dealing_is_deterministic_and_complete(dev, torch_dev):
         ch.process_dev(xc, z, n + Kc - 1, n)
         if i % 10 == 9:
             assert torch.equal(z, z0), i
+
+
+@pytest.mark.parametrize("dtype,cplx,n", [("complex_int16", True, 24 << 20), ("complex_int8", True, 24 << 20), ("int16", False, 40 << 20),
+                                          ("complex_float64", True, 12 << 20), ("float64", False, 24 << 20)])
+def test_double_pipeline_fir_at_a_size_that_is_dealt(oracle, dev, torch_dev, dtype, cplx, n):
+    """round 6: the double-precision overlap-save kernels draw their blocks from 512 persistent workgroups once a call is long enough
+    (more than 2,048 blocks: fir_ols_f64.hip launch_ip / launch_real_ip).  Every block exactly once: the WHOLE stream equals the
+    time-domain kernel's (EXACT: the reference's own operation order on the device) -- bit for bit for the integer types, to 1e-12
+    for double --, and the oracle on windows at both ends and across block seams; the element count behind the last whole block
+    is odd on purpose (a ragged last block, an empty fetch-ahead behind it)."""
+    torch, d = torch_dev
+    from pothoscomms_amd import _lib
+    rng = np.random.default_rng(6)
+    K = 255
+    n = n + 12345
+    scalar, _ = dev.parse_dtype(dtype)
+    h = (rng.normal(size=K) + (1j * rng.normal(size=K) if cplx else 0)) / np.sqrt(K) * (0.5 if "int" in dtype else 1.0)
+    shape = (n + K - 1, 2) if cplx else (n + K - 1,)
+    tdt = {"complex_int16": torch.int16, "int16": torch.int16, "complex_int8": torch.int8, "complex_float64": torch.float64, "float64": torch.float64}[dtype]
+    if "int" in dtype:
+        amp = 100 if "int8" in dtype else 20000
+        x = torch.randint(-amp, amp, shape, device=d).to(tdt)
+    else:
+        x = torch.rand(shape, dtype=tdt, device=d) - 0.5
+    oshape = (n, 2) if cplx else (n,)
+    y_ols = torch.empty(oshape, dtype=tdt, device=d)
+    y_td = torch.empty(oshape, dtype=tdt, device=d)
+    for algo, y in ((_lib.FIR_OLS_FFT, y_ols), (_lib.FIR_EXACT, y_td)):
+        f = dev.FirFilter(dtype, "COMPLEX" if cplx else "REAL"); f.set_taps(h); f.set_algo(algo)
+        c, p = f.process_dev(x, y)
+        assert (c, p) == (n, n)
+        assert f.last_algo == algo
+    torch.cuda.synchronize()
+    S = 4096 - (K - 1 + 15) // 16 * 16
+    assert -(-n // S) // (1 if cplx else 2) > 2048              # the call IS long enough to be dealt
+    if "int" in dtype:
+        assert torch.equal(y_ols, y_td)
+    else:
+        assert float((y_ols - y_td).abs().max()) / float(y_td.abs().max()) <= 1e-12
+    ref = oracle.Fir(scalar, cplx, cplx); ref.set_taps(h); ref.activate()
+    for start in (0, S - 300, 2500 * S - 300, n - 20000):
+        m = 20000 if start in (0, n - 20000) else 600
+        ref.activate()
+        want, _, p, _ = ref.work(x[start:start + m + K - 1].cpu().numpy(), m)
+        got = y_ols[start:start + m].cpu().numpy()
+        assert p == m
+        if "int" in dtype:
+            assert np.array_equal(got, want), start
+        else:
+            assert nerr(got, want) <= 1e-12, start

@@ -42,7 +42,8 @@ struct OlsPlan {
 };
 
 // forward DFT_N of the block held as v[s] = x[l + s*LPF]; on exit v[q] = X[l + LPF*(NATURAL ? q : bin_of(q))]
-template <int LOG2N, typename T3>
+// TFS: stride of the final-pass factors behind `tf` (1: the lane's register copy; LPF: the device table itself, re-read at each use)
+template <int LOG2N, typename T3, int TFS = 1>
 __device__ __forceinline__ void xform(cd (&v)[16], cd *lds, int l, T3 t3, const cd *tf)
 {
     typedef OlsPlan<LOG2N> P;
@@ -84,7 +85,7 @@ __device__ __forceinline__ void xform(cd (&v)[16], cd *lds, int l, T3 t3, const 
 #pragma unroll
         for (int t = 0; t < G; t++) {
 #pragma unroll
-            for (int r = 1; r < R; r++) v[t + r * G] = cmul(v[t + r * G], tf[t * (R - 1) + (r - 1)]);
+            for (int r = 1; r < R; r++) v[t + r * G] = cmul(v[t + r * G], tf[(t * (R - 1) + (r - 1)) * TFS]);
             if (R == 2) {
                 const cd a = v[t], b = v[t + G];
                 v[t] = a + b;
@@ -187,9 +188,10 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
 #pragma unroll
     for (int p = 0; p < P::NTWF; p++) tf[p] = tab[P::TF_OFF + p * LPF + l];
     for (int i = l; i < P::LDS_T2; i += LPF) lds[P::LDS_IMG + i] = tab[i];
-    cd H[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) H[k] = reinterpret_cast<const cd *>(Hspec)[l + LPF * k];
+    // the lane's 16 bins of H (64 VGPRs as doubles) are re-read from L2 at the multiply, as fir_real_ols_kernel does: with the pass-256
+    // factors (60) and the final-pass factors (32) resident they do not fit beside the block (this kernel serves N = 8192 only since
+    // round 6; held in registers it spilled 30-61 VGPRs)
+    const cd *Hg = reinterpret_cast<const cd *>(Hspec) + l;
     auto tw3 = [&](int p) { return t3[p]; };
     const int nov = (Kov + LPF - 1) / LPF;   // window rows shared with a neighbouring block
 
@@ -214,11 +216,13 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
         }
         xform<LOG2N>(v, lds, l, tw3, tf);
         // u = conj(X .* H) in the first-pass layout of the next transform (register k <- bin k*LPF + l)
+        const cd *Hb = Hg;
+        asm volatile("" : "+v"(Hb));   // keeps the loads inside the loop (they are loop-invariant and would be hoisted back into registers)
         cd u[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int k = P::NATURAL ? q : bin_of(q);
-            const cd p = cmul(v[q], H[k]);
+            const cd p = cmul(v[q], Hb[LPF * k]);
             u[k] = cd{p.x, -p.y};
         }
         xform<LOG2N>(u, lds, l, tw3, tf);
@@ -369,9 +373,9 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
 #pragma unroll
         for (int p = 0; p < 15; p++) t3[p] = tab[P::T3_OFF + p * 256 + (l & 255)];
     }
-    cd tf[P::NTWF > 0 ? P::NTWF : 1];
-#pragma unroll
-    for (int p = 0; p < P::NTWF; p++) tf[p] = tab[P::TF_OFF + p * LPF + l];
+    // (the final-pass factors, 32 VGPRs at N = 8192, are re-read from the device table at their use: the decimating instantiations
+    // spilled four registers with them resident)
+    const cd *tfg = tab + P::TF_OFF + l;
     for (int i = l; i < P::LDS_T2; i += LPF) lds[P::LDS_IMG + i] = tab[i];
     // the lane's 16 bins of H (64 VGPRs as doubles) are re-read from L2 at the multiply: with two windows' descriptors
     // live the block loop has no room to keep them
@@ -397,7 +401,9 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
 #pragma unroll
         for (int s = 0; s < 16; s++)
             v[s] = cd{RIO::load(rs[0], (l + LPF * s - shift[0]) * EB), RIO::load(rs[1], (l + LPF * s - shift[1]) * EB)};
-        xform<LOG2N>(v, lds, l, tw3, tf);
+        const cd *tf = tfg;
+        asm volatile("" : "+v"(tf));
+        xform<LOG2N, decltype(tw3), LPF>(v, lds, l, tw3, tf);
         const cd *Hb = Hg;
         asm volatile("" : "+v"(Hb));   // keeps the loads inside the loop (they are loop-invariant and would be hoisted back into registers)
         cd u[16];
@@ -407,7 +413,8 @@ __global__ __launch_bounds__(OlsPlan<LOG2N>::LPF) __attribute__((amdgpu_waves_pe
             const cd p = cmul(v[q], Hb[LPF * k]);
             u[k] = cd{p.x, -p.y};
         }
-        xform<LOG2N>(u, lds, l, tw3, tf);
+        asm volatile("" : "+v"(tf));
+        xform<LOG2N, decltype(tw3), LPF>(u, lds, l, tw3, tf);
         if (DECIM) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {

@@ -60,7 +60,7 @@ static double run(size_t n, int nshards, int circular)
 int main(int argc, char **argv)
 {
     if (argc > 1 && !strcmp(argv[1], "brief")) {      /* machine-readable, for bench.py: samples per call, seconds per call on pinned slabs / on the circular input */
-        const size_t ns[] = {(size_t)1 << 20, (size_t)1 << 22, (size_t)1 << 24};     /* 4 Mi samples = the default 32 MiB port slab */
+        const size_t ns[] = {(size_t)1 << 20, (size_t)1 << 22, (size_t)1 << 23, (size_t)1 << 24};     /* 8 Mi samples = the default 64 MiB port slab */
         for (int i = 0; i < 2; i++) printf("%zu %.9f %.9f\n", ns[i], run(ns[i], 1, 0), run(ns[i], 1, 1));
         return 0;
     }

@@ -137,12 +137,12 @@ struct BlockQFormat {
  * How large: every work() call costs about 60 us of launch, synchronisation and link ramp-up whatever it carries, so the
  * slab size decides what share of the link a block reaches (complex_float32 FIR, 255 taps, examples/c_block_path.c and
  * bench.py secondary.host_path): 8 MiB slabs (1 Mi samples per call) 4.1 Gsamples/s = 0.57 of the PCIe roof at 0.26 ms per
- * call; 32 MiB (4 Mi samples) 5.1 = 0.70 at 0.82 ms; 128 MiB (16 Mi) 5.5 = 0.76 at 3.1 ms.  The default is 32 MiB: where the
- * curve flattens.  It is a SETTING of every block (setPortSlabBytes, an initializer: the framework asks for the managers when
+ * call; 32 MiB (4 Mi samples) 5.0 = 0.70 at 0.84 ms; 64 MiB (8 Mi) 5.3 = 0.74 at 1.6 ms; 128 MiB (16 Mi) 5.5 = 0.76 at 3.1 ms.  The
+ * default is 64 MiB: the fixed cost is 6 % of such a call, and the curve is flat from there.  It is a SETTING of every block (setPortSlabBytes, an initializer: the framework asks for the managers when
  * the topology is committed) -- a latency-bound topology takes 1-8 MiB, a throughput-bound one 128.  Page-locked memory per
  * block: slab size x the framework's buffers per port (4 by default) x the ports that bring their own manager.
  **********************************************************************/
-constexpr size_t kPortSlabBytes = 32u << 20;
+constexpr size_t kPortSlabBytes = 64u << 20;
 constexpr size_t kPortSlabMin = 64u << 10, kPortSlabMax = 1u << 30;
 #ifdef PCX_WITH_POTHOS
 // Pothos build: a pool of page-locked slabs behind Pothos::BufferManager's PUBLIC interface (init / empty / pop / push over
@@ -437,7 +437,7 @@ protected:
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -879,7 +879,7 @@ pcxfw::BlockRegistry registerFIRFilterOldPath("/blocks/fir_filter", &FIRFilterFa
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -978,7 +978,7 @@ pcxfw::BlockRegistry registerFFT("/comms/fft", &FFTFactory);
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1073,7 +1073,7 @@ pcxfw::BlockRegistry registerFreqDemod("/comms/freq_demod", &FreqDemodFactory);
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1271,7 +1271,7 @@ protected:
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1380,7 +1380,7 @@ pcxfw::BlockRegistry registerRotate("/comms/rotate", &rotateFactory);
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1466,7 +1466,7 @@ pcxfw::BlockRegistry registerScale("/comms/scale", &scaleFactory);
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1536,7 +1536,7 @@ pcxfw::BlockRegistry registerAbs("/comms/abs", &absFactory);
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1601,7 +1601,7 @@ pcxfw::BlockRegistry registerAngle("/comms/angle", &angleFactory);
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1689,7 +1689,7 @@ pcxfw::BlockRegistry registerConjugate("/comms/conjugate", &conjugateFactory);
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1806,7 +1806,7 @@ pcxfw::BlockRegistry registerArithmeticOldPath("/blocks/arithmetic", &arithmetic
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device
@@ -1864,7 +1864,7 @@ private:
  *
  * |param portSlabBytes[Port Slab Bytes] Size of the page-locked port buffers the block asks the framework for.
  * Larger slabs carry more samples per call (throughput), smaller ones return sooner (latency).
- * |default 33554432
+ * |default 67108864
  * |units bytes
  * |preview disable
  * |tab Device

@@ -132,8 +132,8 @@ def test_the_committed_default_line_carries_every_single_gpu_config_and_the_host
     assert rr["peak"] == pytest.approx(max(alone), abs=0.02)             # the faster direction alone
     assert rr["frac"] == pytest.approx(rr["achieved"] / rr["peak"], abs=2e-3) and 0.3 < rr["frac"] < 1.0
     assert hp["value"] == pytest.approx(hp["config"]["samples_per_call"] / (hp["ms_per_step"] * 1e-3) / 1e6, rel=2e-3)
-    assert hp["config"]["port_slab_bytes"] == 32 << 20 and hp["config"]["samples_per_call"] == 4 << 20 and hp["value"] >= 5000.0     # the DEFAULT slab's figure (VERDICT r05 task 4)
-    for size in ("1048576_samples_per_call", "4194304_samples_per_call", "16777216_samples_per_call"):
+    assert hp["config"]["port_slab_bytes"] == 64 << 20 and hp["config"]["samples_per_call"] == 8 << 20 and hp["value"] >= 5000.0     # the DEFAULT slab's figure (VERDICT r05 task 4)
+    for size in ("1048576_samples_per_call", "8388608_samples_per_call", "16777216_samples_per_call"):
         a, b = hp["calls"][size]["pinned_port_buffers"], hp["calls"][size]["circular_input_page_locked_in_place"]
         assert b["Msamples_per_s"] > 0.9 * a["Msamples_per_s"]             # the framework's circular buffer, locked where it lies, is as fast as the module's own slabs
     assert hp["cpu_baseline"]["kind"] == "port"

@@ -46,7 +46,7 @@ def test_every_description_instantiates_and_applies_its_defaults():
                     v = float(v)
                 blk.call(fn, v)
             if "getDevice" in calls:
-                assert blk.call("getDevice") == 0 and blk.call("getPortSlabBytes") == 32 << 20
+                assert blk.call("getDevice") == 0 and blk.call("getPortSlabBytes") == 64 << 20
             blk.close()
 
 

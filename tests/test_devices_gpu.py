@@ -154,8 +154,8 @@ def test_two_chains_on_two_devices(oracle):
 
 def test_port_slab_bytes_is_a_setting():
     fir = B.make("/comms/fir_filter", "complex_float32", "COMPLEX")
-    assert fir.call("getPortSlabBytes") == 32 << 20
-    assert fir.buffer_manager(False) == ("circular", 32 << 20) and fir.buffer_manager(True) == ("generic", 32 << 20)
+    assert fir.call("getPortSlabBytes") == 64 << 20
+    assert fir.buffer_manager(False) == ("circular", 64 << 20) and fir.buffer_manager(True) == ("generic", 64 << 20)
     fir.call("setPortSlabBytes", 8 << 20)
     assert fir.buffer_manager(False) == ("circular", 8 << 20) and fir.buffer_manager(True) == ("generic", 8 << 20)
     for bad in (0, 1000, (1 << 30) + 1):

@@ -387,7 +387,7 @@ int pcx_host_register(void *ptr, size_t bytes)
     {
         std::lock_guard<std::mutex> lk(g_reg_mutex);
         auto it = g_registered.find((uintptr_t)ptr);
-        if (it != g_registered.end() && it->second.bytes == bytes) { it->second.holders++; return PCX_OK; }
+        if (it != g_registered.end() && it->second.bytes >= bytes) { it->second.holders++; return PCX_OK; }      // held already: one more holder
     }
     int kind = PCX_PTR_PAGEABLE;
     PCX_TRY(pcx_pointer_kind(ptr, &kind));

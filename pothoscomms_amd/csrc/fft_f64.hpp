@@ -163,13 +163,13 @@ __device__ __forceinline__ Lane make_lane(int l)
     return Lane{17 * u + c, kRow * u + w, kRow * u + 17 * w, w, 16 * u + c, u + 16 * w};
 }
 
-// The per-lane factor sets.  Pass "over a": w^1 .. w^15, w = W4096^idx2 -- fifteen registers pairs (60 VGPRs) held across the
-// block loop.  Pass "over b": W256^(c kb), sixteen distinct columns for the whole workgroup: a [15][16] table in LDS, read in
-// front of the multiplies, five at a time.  What was tried instead (tools/f64_lab.hip has the reason it matters: at two waves
-// per SIMD the FP64 pipe issues one instruction per ~3.9 clocks and this kernel runs at 95 % of that, so only the instruction
-// COUNT moves it): both sets as six powers each (w^1, w^2, w^3, w^4, w^8, w^12) with the other nine one product away --
-// 144 more instructions per block on 1,420, 7 % slower; the LDS table read one entry at a time in front of each multiply,
-// as the compiler orders it by itself -- thirty exposed LDS latencies per block.
+// The per-lane factor sets.  Pass "over a": w^1 .. w^15, w = W4096^idx2 -- thirteen of them in register pairs (52 VGPRs) across
+// the block loop, the last two a product away.  Pass "over b": W256^(c kb), sixteen distinct columns for the whole workgroup: a
+// [15][16] table in LDS, read in front of the multiplies, five at a time.  What was tried instead (tools/f64_lab.hip has the
+// reason it matters: at two waves per SIMD the FP64 pipe issues one instruction per ~3.9 clocks and this kernel runs at 95 %
+// of that, so the instruction COUNT moves it): both sets as six powers each (w^1, w^2, w^3, w^4, w^8, w^12) with the other nine
+// one product away -- 144 more instructions per block on 1,420; the LDS table read one entry at a time in front of each
+// multiply, as the compiler orders it by itself -- thirty exposed LDS latencies per block.
 struct LaneTw {
     cd a[13];      // w^1 .. w^13; w^14 = w^12 . w^2 and w^15 = w^12 . w^3 at their two uses each (the eight registers they would hold
                    // are the dealer's and the fetch-ahead's: at 256 the allocator spills whatever lives longest, and reloads it behind vmcnt(0))
@@ -213,8 +213,8 @@ constexpr int unbin(int k) { return 4 * (k & 3) + (k >> 2); }   // the register 
 
 // PART (timing-only instantiations of the diagnostic library, WRONG outputs): 0 = the pair as it is; 1 = without the four
 // s_barrier (every LDS access kept); 2 = butterflies and factor multiplies only (no exchange, no barrier, no table read).
-// tools/ip64_parts.sh, 255 taps, 64 Mi complex_int16 samples: 0.301 / 0.293 / 0.238 ms -- the arithmetic alone is four fifths of the
-// launch.  (Also built and measured equal within 1 %: every pass written out in issue order behind scheduling fences -- reads in
+// tools/ip64_parts.sh, 255 taps, 64 Mi complex_int16 samples: 0.274 / 0.273 / 0.224 ms (profiles/r06/ip64_parts.txt) -- the
+// arithmetic alone is four fifths of the launch, the barriers cost nothing.  (Also built and measured equal within 1 %: every pass written out in issue order behind scheduling fences -- reads in
 // the order the first-stage butterflies consume them, each second-stage group's factor multiplies and four stores ahead of the
 // next group's arithmetic.  A ds_write_b128 takes its 13 clocks of the SIMD's register ports wherever it sits.)
 template <int PART>

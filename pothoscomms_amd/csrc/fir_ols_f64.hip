@@ -6,15 +6,18 @@
 // starts pad = Kov-(K-1) samples before sample b*S, S = N - Kov.
 //
 // K <= 2049 (N = 4096): the IN-PLACE transform pair of fft_f64.hpp (ip4096): 4 barriers per block, a conflict-free image, H
-// (64 VGPRs) and six powers of the lane's pass-1 factor (24 VGPRs) in registers across the persistent block loop, the next
-// block's samples fetched ahead for the integer streams (16 VGPRs; a complex_float64 block would need 64), no scratch.
+// (64 VGPRs) and thirteen powers of the lane's pass-1 factor (52 VGPRs) in registers across the block loop, blocks DEALT to 512
+// persistent workgroups (pcx_sched.hpp), wave priority rising through a block, the next block's samples fetched ahead for the
+// integer streams (16 VGPRs; a complex_float64 block would need 64), no scratch in any instantiation.
 // 2049 < K <= 4097 (N = 8192): the Stockham radix-16 passes of xform<13> as before (lane l holds x[l + s*LPF]; a forward
 // transform leaves X[l + k*LPF] in the lane, which is the next transform's first-pass layout).
 //
 // Rounding: everything is double; the result differs from the reference's direct sum by a few 1e-16 of the output scale
 // (parity bar 1e-13).  Against the sliding-window kernel (K multiply-adds per output on the 78 TFLOP/s f64 pipe) this is
 // the faster form from a few tens of taps up (tools/sweep_fir_f64.py).  Its roof is the FP64 vector pipe, not HBM: about
-// 1,500 double-precision instructions per 64-lane wave and 3,840-sample block against 4 (int16) to 32 (float64) bytes per sample.
+// 1,430 instructions per 64-lane wave and 3,840-sample block against 4 (int16) to 32 (float64) bytes per sample -- and that pipe
+// issues one instruction per ~3.9 clocks and SIMD at the two waves per SIMD the 64 KB image allows (tools/f64_lab.hip): the
+// complex_int16 kernel runs at 0.95 of that rate (244 Gsamples/s at 255 taps).
 #include "fft_f64.hpp"
 #include <cstdio>
 #include <cstdlib>

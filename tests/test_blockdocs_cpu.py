@@ -210,3 +210,20 @@ def test_the_cmake_recipe_enables_the_docs():
     assert m and "ENABLE_DOCS" in m.group(1), "the module recipe in INTEGRATION.md must carry ENABLE_DOCS"
     for f in ("comms_blocks.cpp", "fir_designer.cpp"):
         assert f in m.group(1), "the doc parser reads the SOURCES of the recipe: %s must be among them" % f
+
+
+def test_the_json_view_of_the_descriptions():
+    """tools/blockdocs.py: the descriptions as the JSON a maintainer can diff against PothosUtil --doc-parse"""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "blockdocs.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    docs = {d["path"]: d for d in json.loads(r.stdout)}
+    assert set(docs) == set(our_docs())
+    fir = docs["/comms/fir_filter"]
+    assert fir["args"] == ["dtype", "tapsType"] and fir["aliases"] == ["/blocks/fir_filter"] and fir["categories"] == ["/Filter"]
+    decim = [p for p in fir["params"] if p["key"] == "decim"][0]
+    assert decim["widgetType"] == "SpinBox" and decim["widgetKwargs"] == {"minimum": "1"} and decim["default"] == "1"
+    assert {"type": "initializer", "name": "setDevice", "args": ["device"]} in fir["calls"]
+    assert {"type": "setter", "name": "setTaps", "args": ["taps"]} in fir["calls"]

@@ -240,9 +240,10 @@ def test_dynamic_dealing_is_deterministic_and_complete(dev, torch_dev):
             assert torch.equal(z, z0), i
 
 
-@pytest.mark.parametrize("dtype,cplx,n", [("complex_int16", True, 24 << 20), ("complex_int8", True, 24 << 20), ("int16", False, 40 << 20),
-                                          ("complex_float64", True, 12 << 20), ("float64", False, 24 << 20)])
-def test_double_pipeline_fir_at_a_size_that_is_dealt(oracle, dev, torch_dev, dtype, cplx, n):
+@pytest.mark.parametrize("dtype,cplx,n,K", [("complex_int16", True, 24 << 20, 255), ("complex_int8", True, 24 << 20, 255), ("int16", False, 40 << 20, 255),
+                                            ("complex_float64", True, 12 << 20, 255), ("float64", False, 24 << 20, 255),
+                                            ("complex_int16", True, 6 << 20, 2049), ("complex_int16", True, 12 << 20, 17), ("int16", False, 12 << 20, 2049)])
+def test_double_pipeline_fir_at_a_size_that_is_dealt(oracle, dev, torch_dev, dtype, cplx, n, K):
     """round 6: the double-precision overlap-save kernels draw their blocks from 512 persistent workgroups once a call is long enough
     (more than 2,048 blocks: fir_ols_f64.hip launch_ip / launch_real_ip).  Every block exactly once: the WHOLE stream equals the
     time-domain kernel's (EXACT: the reference's own operation order on the device) -- bit for bit for the integer types, to 1e-12
@@ -251,7 +252,6 @@ def test_double_pipeline_fir_at_a_size_that_is_dealt(oracle, dev, torch_dev, dty
     torch, d = torch_dev
     from pothoscomms_amd import _lib
     rng = np.random.default_rng(6)
-    K = 255
     n = n + 12345
     scalar, _ = dev.parse_dtype(dtype)
     h = (rng.normal(size=K) + (1j * rng.normal(size=K) if cplx else 0)) / np.sqrt(K) * (0.5 if "int" in dtype else 1.0)
@@ -279,7 +279,7 @@ def test_double_pipeline_fir_at_a_size_that_is_dealt(oracle, dev, torch_dev, dty
         assert float((y_ols - y_td).abs().max()) / float(y_td.abs().max()) <= 1e-12
     ref = oracle.Fir(scalar, cplx, cplx); ref.set_taps(h); ref.activate()
     for start in (0, S - 300, 2500 * S - 300, n - 20000):
-        m = 20000 if start in (0, n - 20000) else 600
+        m = (20000 if K <= 255 else 3000) if start in (0, n - 20000) else 600
         ref.activate()
         want, _, p, _ = ref.work(x[start:start + m + K - 1].cpu().numpy(), m)
         got = y_ols[start:start + m].cpu().numpy()

@@ -702,9 +702,9 @@ def build_workload(wl, C, dev, rank, world, args):
                      "(tools/ip64_parts.sh), and at that occupancy the pipe issues ~380 G wave-instructions/s chip-wide on an add / multiply / "
                      "FMA mix like an FFT's (tools/f64_lab.hip), not the 614 G/s the datasheet's 78.6 TFLOP/s stand for")
     elif wl in ("fir4097", "fir8193"):
-        # the long-tap plans of the complex_float32 FIR (2049 < K <= 8193): 8192- / 16384-sample blocks, HALF of every block overlap at
-        # these tap counts -- every input sample is fetched twice (the second time from L2 / the Infinity Cache when the neighbour ran
-        # recently) and every output costs twice the transform work of the headline's
+        # the long-tap plans of the complex_float32 FIR (2049 < K <= 8193): 4096-sample blocks advancing by 2048, the taps in
+        # 2 / 4 partitions of 2048 against the spectra of the previous windows (fir_ols_part.hip) -- one transform pair per 2048
+        # outputs whatever K, every input sample fetched once
         n = C
         K = 4097 if wl == "fir4097" else 8193
         h = tp.complex_bandpass(K, 0.05, 0.05)
@@ -718,16 +718,16 @@ def build_workload(wl, C, dev, rank, world, args):
         W.units = n
         W.roof_bytes = 16.0 * n
         W.read_bytes = 8.0 * n
-        W.kernel_name = "fir_cf32_ols_r16_kernel"
+        W.kernel_name = "fir_cf32_upols_kernel"
         W.step = lambda: f.process_dev(x, y)
         W.inputs = (x,)
-        W.desc = {"workload": "%d-tap complex_float32 FIR, %d-sample overlap-save blocks, %d samples per GPU" % (K, 8192 if K <= 4097 else 16384, n),
-                  "taps": K}
+        W.desc = {"workload": "%d-tap complex_float32 FIR, 4096-sample overlap-save blocks with the taps in %d partitions, %d samples per GPU"
+                              % (K, (K - 1 + 2047) // 2048, n), "taps": K}
         W.metric = "Msamples/s complex_float32 %d-tap FIR" % K
-        N = 8192 if K <= 4097 else 16384
-        W.blocks = -(-n // (N - (K - 1 + 15) // 16 * 16))
-        W.limiter = ("half of every block is overlap at this tap count: two transforms of N samples per N/2 outputs (twice the headline's "
-                     "arithmetic per output) and 24 B of memory traffic per output where the window's second fetch misses the caches")
+        W.blocks = -(-n // 2048)
+        W.limiter = ("a transform pair per 2048 outputs: 1.9 x the headline's arithmetic per output, plus one multiply-add per bin and "
+                     "partition against spectra held in registers (which is what sets the occupancy: 3 workgroups per CU at 2 "
+                     "partitions, 2 at 3 and 4) and the partitions' spectra re-read from L2 in every block")
     elif wl in ("abs", "freq_demod"):
         # complex_float32 in, float32 out: 8 B read + 4 B written per sample, one launch per step
         n = C

@@ -518,8 +518,11 @@ __device__ __forceinline__ void load_pass2_twiddles(LaneTw &tw, const cf *lds, i
 }
 // forward, part 1: v[r] = x[j + 256 r] -> butterflies of A (a dealt kernel issues its draw behind this)
 __device__ __forceinline__ void dif_a_math(cf (&v)[16], const LaneTw &tw3) { fft16_post(v, tw3); }
-// forward, the rest: on exit v[q] = X[spec_lane(j) + 256 bin_of(q)]
-__device__ __forceinline__ void dif_rest(cf (&v)[16], cf *lds, int j)
+// forward, the rest: on exit v[q] = X[spec_lane(j) + 256 bin_of(q)].  `before_last` runs in front of the last sixteen-point
+// transform, the registers of the pass-2 factors free again (fir_ols_part.hip issues its first table loads there)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <typename HOOK = NoHook>
+__device__ __forceinline__ void dif_rest(cf (&v)[16], cf *lds, int j, HOOK before_last = HOOK())
 {
     const int row = 272 * (j >> 4), l = j & 15;
     lds_barrier();                                   // the readers of the previous exchange 1^T are done
@@ -537,6 +540,7 @@ __device__ __forceinline__ void dif_rest(cf (&v)[16], cf *lds, int j)
     wave_lds_order();
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = lds[row + 17 * l + r];
+    before_last();
     fft16_plain(v);
 }
 // inverse on conjugated input: u[r] = conj(Y)[spec_lane(j) + 256 r] on entry, u[q] = IFFT(Y)[j + 256 bin_of(q)] on exit

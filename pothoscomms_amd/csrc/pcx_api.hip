@@ -269,6 +269,34 @@ static std::vector<float> turn_spectrum_lanes(const std::vector<float> &H)
         }
     return T;
 }
+// Table of the partitioned overlap-save kernel (fir_ols_part.hip): the taps cut into partitions of 2048 (the last one takes
+// what is left, up to 2049), each partition's 4096-bin spectrum in the lanes' order, two partitions to a 16-byte entry
+// (plane g: [16][256] entries {H_2g, H_2g+1}; the last plane of an odd count holds one partition in 8-byte entries).
+static std::vector<float> make_hparts(const std::vector<std::complex<double>> &h, int parts)
+{
+    const size_t B = 2048;
+    std::vector<std::vector<float>> T((size_t)parts);
+    for (int p = 0; p < parts; p++) {
+        const size_t lo = (size_t)p * B, hi = p + 1 == parts ? h.size() : std::min(h.size(), lo + B);
+        std::vector<std::complex<double>> hp(h.begin() + (std::ptrdiff_t)std::min(lo, h.size()), h.begin() + (std::ptrdiff_t)hi);
+        if (hp.empty()) hp.push_back(0.0);
+        T[(size_t)p] = turn_spectrum_lanes(make_hspec(hp, 4096));
+    }
+    std::vector<float> out(fir_upols_table_bytes(parts) / sizeof(float));
+    size_t o = 0;
+    for (int g = 0; 2 * g < parts; g++) {
+        const bool pair = 2 * g + 1 < parts;
+        for (size_t e = 0; e < 4096; e++) {
+            out[o++] = T[(size_t)(2 * g)][2 * e];
+            out[o++] = T[(size_t)(2 * g)][2 * e + 1];
+            if (pair) {
+                out[o++] = T[(size_t)(2 * g + 1)][2 * e];
+                out[o++] = T[(size_t)(2 * g + 1)][2 * e + 1];
+            }
+        }
+    }
+    return out;
+}
 
 }  // namespace pcx
 
@@ -897,15 +925,15 @@ struct pcx_fir {
     bool have_interp_real = false; // REAL float64 / float32 / int16 / int8, L > 1: the same with the two-real-blocks kernel
     DevBuf HrowsD;
     DevBuf HspecRows;
-    int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; 10..13: fir_ols_r16.hip plan
+    int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; -2 .. -4: that many tap partitions (fir_ols_part.hip); 10..14: fir_ols_r16.hip plan
     bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
     bool taps16 = false;      // complex_int16 / complex_int8 stream, complex taps within +-32767 after floatToQ (v_dot2_i32_i16 path)
     DevBuf tapsP;             // packed (a, -b), (b, a) pairs for that path
 };
 
-// Overlap-save block size for K taps (complex_float32, M = L = 1): 0 = the dedicated 4096-sample
-// kernel (K <= 2049), else the log2 of a radix-16 family plan (fir_ols_r16.hip) for longer taps.
-// PCX_OLS_N=1024/2048/4096/8192/16384 forces a plan (A/B runs, tools/ab_ols.py).
+// Overlap-save plan for K taps (complex_float32, M = L = 1): 0 = the dedicated 4096-sample kernel (K <= 2049); -P = the same
+// blocks with the taps in P = 2 .. 4 partitions (fir_ols_part.hip, 2049 < K <= 8193); 10 .. 14 = the log2 of a radix-16 family
+// plan (fir_ols_r16.hip) -- only when forced: PCX_OLS_N=1024/2048/4096/8192/16384 (diagnostic library, A/B runs, tools/ab_ols.py).
 static int fir_ols_block_log2(size_t K)
 {
     const int forced = (int)PCX_ENV_INT("PCX_OLS_N", 0);
@@ -917,7 +945,7 @@ static int fir_ols_block_log2(size_t K)
     case 16384: return 14;
     }
     if (K <= 2049) return 0;
-    return K <= 4097 ? 13 : 14;
+    return -(int)((K - 1 + 2047) / 2048);
 }
 constexpr size_t kOlsMaxTaps = 8193;
 constexpr size_t kRowsWorkspaceCap = (size_t)1 << 30;   // polyphase-row workspace of the interpolating paths (pcx_fir_process_dev)
@@ -1039,6 +1067,9 @@ static int fir_sync_tables(pcx_fir *h)
             h->ols_log2n = fir_ols_block_log2(K);
             if (h->ols_log2n == 0) {   // the dedicated 4096-sample kernel (fir_ols.hip)
                 PCX_TRY(upload(h->Hspec, make_hspec4096(hq)));
+                PCX_TRY(upload(h->tw4096, make_tw4096()));
+            } else if (h->ols_log2n < 0) {   // the same blocks, the taps in partitions (fir_ols_part.hip)
+                PCX_TRY(upload(h->Hspec, make_hparts(hq, -h->ols_log2n)));
                 PCX_TRY(upload(h->tw4096, make_tw4096()));
             } else {                   // radix-16 family plan (fir_ols_r16.hip)
                 PCX_TRY(upload(h->Hspec, make_hspec(hq, (size_t)1 << h->ols_log2n)));
@@ -1455,6 +1486,8 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n < 0) {
+        rc = launch_fir_cf32_upols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, -h->ols_log2n, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {
         rc = launch_fir_cf32_ols_r16(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {

@@ -154,13 +154,13 @@ def test_fir_anchors(oracle, dev):
 
 
 @pytest.mark.parametrize("algo", ["DIRECT", "OLS_FFT", "AUTO"])
-@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 9, 63, 64, 127, 255, 256, 257, 1000, 2049, 2050, 4097, 4098, 8193])
+@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 9, 63, 64, 127, 255, 256, 257, 1000, 2049, 2050, 3000, 4097, 4098, 6145, 6146, 8192, 8193])
 def test_fir_cf32_fast_paths(oracle, dev, algo, ntaps):
     """LDS-tiled direct kernel and frequency-domain overlap-save kernel vs the oracle."""
     if algo == "DIRECT" and ntaps > 2049:
         pytest.skip("direct tile plan")
     rng = np.random.default_rng(ntaps)
-    n = 3 * 4096 + 777 + ntaps + (40000 if ntaps > 2049 else 0)   # several 8192/16384-sample blocks
+    n = 3 * 4096 + 777 + ntaps + (40000 if ntaps > 2049 else 0)   # beyond 2049 taps: 2 ... 4 partitions, runs of several blocks
     x = rand_stream(rng, oracle.F32, n, True)
     taps = _taps(rng, ntaps, True)
     ref_blk = oracle.Fir(oracle.F32, True, True); ref_blk.set_taps(taps); ref_blk.activate()
@@ -171,7 +171,7 @@ def test_fir_cf32_fast_paths(oracle, dev, algo, ntaps):
     assert (gc, gp) == (rc, rp) == (n - ntaps + 1, n - ntaps + 1)
     assert nerr(got, ref) <= TOL, f.last_algo
     if algo == "AUTO" and ntaps > 1:
-        assert f.last_algo == dev._lib.FIR_OLS_FFT   # 4096-sample blocks to 2049 taps, 8192 / 16384 beyond
+        assert f.last_algo == dev._lib.FIR_OLS_FFT   # 4096-sample blocks; beyond 2049 taps the taps in partitions (fir_ols_part.hip)
 
 
 def test_fir_cf32_real_taps_fast(oracle, dev):

@@ -327,7 +327,7 @@ __device__ __forceinline__ cf fast_atan2f_x2(cf y, cf x)
     return cf{__builtin_copysignf(r.x, y.x), __builtin_copysignf(r.y, y.y)};
 }
 
-// ---- helpers of the radix-16 family plans (fft_r16.hip, fir_ols_r16.hip) ----
+// ---- helpers of the radix-16 family plans (fft_r16.hip) ----
 __device__ __forceinline__ int padi(int i) { return i + (i >> 4); }
 __device__ __forceinline__ cf cmul1(cf a, cf w)
 {

@@ -925,28 +925,19 @@ struct pcx_fir {
     bool have_interp_real = false; // REAL float64 / float32 / int16 / int8, L > 1: the same with the two-real-blocks kernel
     DevBuf HrowsD;
     DevBuf HspecRows;
-    int ols_log2n = 0;        // 0: fir_ols.hip's 4096 kernel; -2 .. -4: that many tap partitions (fir_ols_part.hip); 10..14: fir_ols_r16.hip plan
+    int ols_parts = 0;        // complex_float32 M = L = 1: 0 = fir_ols.hip's 4096 kernel alone, 2 .. 4 = that many tap partitions (fir_ols_part.hip)
+    int ols_log2n = 0;        // the double-precision plans: log2 of the block (12, 13)
     bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
     bool taps16 = false;      // complex_int16 / complex_int8 stream, complex taps within +-32767 after floatToQ (v_dot2_i32_i16 path)
     DevBuf tapsP;             // packed (a, -b), (b, a) pairs for that path
 };
 
-// Overlap-save plan for K taps (complex_float32, M = L = 1): 0 = the dedicated 4096-sample kernel (K <= 2049); -P = the same
-// blocks with the taps in P = 2 .. 4 partitions (fir_ols_part.hip, 2049 < K <= 8193); 10 .. 14 = the log2 of a radix-16 family
-// plan (fir_ols_r16.hip) -- only when forced: PCX_OLS_N=1024/2048/4096/8192/16384 (diagnostic library, A/B runs, tools/ab_ols.py).
-static int fir_ols_block_log2(size_t K)
-{
-    const int forced = (int)PCX_ENV_INT("PCX_OLS_N", 0);
-    switch (forced) {
-    case 1024: return 10;
-    case 2048: return 11;
-    case 4096: return 12;
-    case 8192: return 13;
-    case 16384: return 14;
-    }
-    if (K <= 2049) return 0;
-    return -(int)((K - 1 + 2047) / 2048);
-}
+// Tap partitions of the overlap-save plan for K taps (complex_float32, M = L = 1): 0 = the dedicated 4096-sample kernel alone
+// (fir_ols.hip, K <= 2049); P = 2 .. 4 = the same blocks with the taps in P partitions of 2048 (fir_ols_part.hip, 2049 < K <= 8193).
+// (Until round 6 longer filters took 8192- / 16384-sample blocks on radix-16 family passes -- 143 / 88 Gsamples/s at 4097 / 8193
+// taps against 206 / 167 now, profiles/r06/ab_upols.txt; blocks SHORTER than 4096 never paid either: 0.2413 ms at 2048, 0.2723 at
+// 1024 against 0.2246 at 255 taps, round 2.)
+static int fir_ols_partitions(size_t K) { return K <= 2049 ? 0 : (int)((K - 1 + 2047) / 2048); }
 constexpr size_t kOlsMaxTaps = 8193;
 constexpr size_t kRowsWorkspaceCap = (size_t)1 << 30;   // polyphase-row workspace of the interpolating paths (pcx_fir_process_dev)
 // complex_float64 (fir_ols_f64.hip): 4096-sample blocks to K = 2049, 8192 to K = 4097; PCX_OLS64_N forces a plan (A/B)
@@ -1064,17 +1055,13 @@ static int fir_sync_tables(pcx_fir *h)
             for (size_t k = 0; k < K; k++)   // floatToQ<QTapsType>: narrowed to float first (FIRFilter.cpp:348)
                 hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]),
                                              h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
-            h->ols_log2n = fir_ols_block_log2(K);
-            if (h->ols_log2n == 0) {   // the dedicated 4096-sample kernel (fir_ols.hip)
+            h->ols_parts = fir_ols_partitions(K);
+            if (h->ols_parts == 0) {   // the dedicated 4096-sample kernel (fir_ols.hip)
                 PCX_TRY(upload(h->Hspec, make_hspec4096(hq)));
-                PCX_TRY(upload(h->tw4096, make_tw4096()));
-            } else if (h->ols_log2n < 0) {   // the same blocks, the taps in partitions (fir_ols_part.hip)
-                PCX_TRY(upload(h->Hspec, make_hparts(hq, -h->ols_log2n)));
-                PCX_TRY(upload(h->tw4096, make_tw4096()));
-            } else {                   // radix-16 family plan (fir_ols_r16.hip)
-                PCX_TRY(upload(h->Hspec, make_hspec(hq, (size_t)1 << h->ols_log2n)));
-                PCX_TRY(upload(h->tw4096, make_tw_r16(h->ols_log2n)));
+            } else {                   // the same blocks, the taps in partitions (fir_ols_part.hip)
+                PCX_TRY(upload(h->Hspec, make_hparts(hq, h->ols_parts)));
             }
+            PCX_TRY(upload(h->tw4096, make_tw4096()));
             h->have_ols = true;
         }
     }
@@ -1351,7 +1338,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
 // their outputs stay within the 1e-5 of the oracle either way, but are not bit-identical to an uncut call's.
 static size_t fir_chunk_quantum(const pcx_fir *h)
 {
-    const bool plain = h->scalar == PCX_F32 && h->cplx && h->M == 1 && h->L == 1 && h->have_ols && h->ols_log2n == 0 && h->K > 1;
+    const bool plain = h->scalar == PCX_F32 && h->cplx && h->M == 1 && h->L == 1 && h->have_ols && h->ols_parts == 0 && h->K > 1;
     if (plain) return 4096 - (h->K - 1 + 15) / 16 * 16;
     return h->M * 4096;
 }
@@ -1431,7 +1418,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         // a gated call: only the plain complex_float32 M = L = 1 plan on 4096-sample blocks has the gate (and only its dealt launch,
         // launch_fir_cf32_ols4096 decides).  Anything else: *gated stays 0, nothing has been queued, the caller orders the halo itself.
         const bool plain = algo == PCX_FIR_OLS_FFT && !h->have_interp_real && !h->have_interp64 && !h->have_ols_real64 && !h->have_ols64 &&
-                           !h->have_ols_int && !h->have_real_ols && !h->have_interp && !h->have_decim && !h->have_poly && h->ols_log2n == 0;
+                           !h->have_ols_int && !h->have_real_ols && !h->have_interp && !h->have_decim && !h->have_poly && h->ols_parts == 0;
         if (!plain) return PCX_OK;
         rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, gate_word, gate_value, gated, h->slots);
         if (rc != PCX_OK || !*gated) return rc;
@@ -1486,10 +1473,8 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_poly) {
         rc = launch_fir_cf32_ols4096_poly(in_dev, used_in, out_dev, N, h->HspecRows.p, h->K, h->L, h->M, h->tw4096.p, st);
-    } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n < 0) {
-        rc = launch_fir_cf32_upols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, -h->ols_log2n, h->tw4096.p, st);
-    } else if (algo == PCX_FIR_OLS_FFT && h->ols_log2n != 0) {
-        rc = launch_fir_cf32_ols_r16(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p, st);
+    } else if (algo == PCX_FIR_OLS_FFT && h->ols_parts != 0) {
+        rc = launch_fir_cf32_upols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_parts, h->tw4096.p, st);
     } else if (algo == PCX_FIR_OLS_FFT) {
         rc = launch_fir_cf32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st, nullptr, 0, nullptr, h->slots, h->lead_valid);
     } else if (algo == PCX_FIR_DIRECT && fast && (2048 + h->Kp + 8) * 9 / 8 * 8 + 64 <= 64 * 1024) {

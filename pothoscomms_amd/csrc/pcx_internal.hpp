@@ -252,8 +252,6 @@ int launch_fir_cf32_ols4096_interp(const void *in, size_t in_elems, void *out, s
 size_t fir_decim_fold_factor(size_t M);
 int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
                                   const void *tw4096, void *sched, hipStream_t st);
-int launch_fir_cf32_ols_r16(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
-                            const void *tw, hipStream_t st);
 // (fir_ols_part.hip) 2049 < K <= 8193: 4096-sample blocks, the taps in `parts` = ceil((K - 1) / 2048) partitions
 int launch_fir_cf32_upols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, int parts, const void *tw,
                           hipStream_t st);

@@ -1,6 +1,8 @@
-"""A/B of the overlap-save block size (PCX_OLS_N, read once per process): parity against the oracle on a
-short stream and the per-pass time at 64 Mi samples, for a few tap counts.  Run once per block size:
-    PCX_OLS_N=2048 python tools/ab_ols.py
+"""A/B of a build variant of the overlap-save FIR (diagnostic library: PCX_OLS_VARIANT, PCX_OLS_SLOTS, PCX_UPOLS_VARIANT ..., read once
+per process): parity against the oracle on a short stream and the per-pass time at 64 Mi samples, for a few tap counts (AB_KS).  Run
+once per setting:
+    PCX_HIP_LIBRARY=pothoscomms_amd/libpcx_hip_diag.so PCX_OLS_VARIANT=9 python tools/ab_ols.py
+(Rounds 2-5 compared block SIZES with it -- PCX_OLS_N, the radix-16 family plans: removed in round 6, see pcx_api.hip fir_ols_partitions.)
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +11,7 @@ from pothoscomms_amd import _lib, device, taps as tp
 from oracle import oracle
 
 d = torch.device("cuda", 0)
-N = os.environ.get("PCX_OLS_N", "dedicated-4096")
+N = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("PCX_") and k != "PCX_HIP_LIBRARY") or "product"
 Ks = [int(k) for k in os.environ.get("AB_KS", "16,64,127,255,511").split(",")]
 n = 64 * 1024 * 1024
 REAL = os.environ.get("AB_TYPE", "complex_float32") == "float32"     # real stream, real taps

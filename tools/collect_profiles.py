@@ -16,8 +16,8 @@ KERNELS = {
     "decim8": ("fir_cf32_ols4096_decim_batched_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
     "interp4": ("fir_cf32_ols4096_interp_batched_kernel", [C + "fir_ols_decim.hip", C + "fft4096.hpp", C + "pcx_sched.hpp"]),
     "fir255_i16": ("fir_cf64_ip_kernel", [C + "fir_ols_f64.hip", C + "fft_f64.hpp", C + "pcx_sched.hpp"]),
-    "fir4097": ("fir_cf32_ols_r16_kernel", [C + "fir_ols_r16.hip", C + "fft4096.hpp"]),
-    "fir8193": ("fir_cf32_ols_r16_kernel", [C + "fir_ols_r16.hip", C + "fft4096.hpp"]),
+    "fir4097": ("fir_cf32_upols_kernel", [C + "fir_ols_part.hip", C + "fft4096.hpp"]),
+    "fir8193": ("fir_cf32_upols_kernel", [C + "fir_ols_part.hip", C + "fft4096.hpp"]),
     "rotate": ("map_kernel", [C + "elementwise.hip", C + "vec_io.hpp"]),
 }
 def hashes(files):
@@ -29,7 +29,7 @@ def newest(pattern):
     return fs[-1] if fs else None
 
 for name in ("bench_default.json", "bench_other_workloads.jsonl", "bench_driver_flags.json", "bench_two_ranks_one_gpu_gloo.json",
-             "f64_lab.txt", "ip64_parts.txt", "ab_ip64_sched.txt", "rccl_group_lab.txt", "pytest_gpu.txt", "soak.txt",
+             "f64_lab.txt", "ip64_parts.txt", "ab_ip64_sched.txt", "ab_upols.txt", "rccl_group_lab.txt", "pytest_gpu.txt", "soak.txt",
              "ab_sched.txt", "ab_oversub.txt", "ab_fft4096_family.txt", "ab_fft_family_rounds.txt", "shard_probe.txt", "host_path.txt", "two_blocks.txt", "chain_path.txt", "pcie_lab.txt", "ubench_roofs.txt",
              "ols_lab_summary.txt", "sweep_fir_taps.txt", "sweep_elementwise.txt", "sweep_fft_sizes.txt", "sweep_fft_f64.txt",
              "sweep_fft_mixed.txt", "sweep_fir_f64.txt", "real_f32_fir.txt", "ols_lab3_summary.txt", "transient_probe.txt", "shard4_trace.txt",

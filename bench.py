@@ -66,7 +66,7 @@ def parse():
                     help="seconds of extra launches behind the timed region whose last half is reported as roofline.sustained (0: off)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default workload only: skip the `secondary` object (configs[2] 4096-pt FFT, configs[4] fused chain, the element-wise blocks, "
-                         "the integer FIR, the resamplers, configs[3] on one device, the host path: ~1 s of GPU each)")
+                         "the integer FIR, the resamplers, the long-tap FIRs, configs[3] on one device, the host path: ~1 s of GPU each)")
     ap.add_argument("--rehearse-rccl-rank", action="store_true",
                     help="N = 1 only, fir255 / fmchain: time the pass a MIDDLE rank of an RCCL world runs -- side stream, one grouped RCCL send + receive "
                          "of the halo (to the rank itself: one GPU is enough), gate signal, ONE gated launch on the slots such a rank takes -- instead "
@@ -966,6 +966,9 @@ def cpu_baseline_secondary(wl):
         return cpu_baseline_resampler(tp.complex_bandpass(255, 0.05 / 8, 0.05 / 8), 8, 1, 2 * 1024 * 1024)
     if wl == "interp4":
         return cpu_baseline_resampler(tp.complex_bandpass(255 * 4, 0.05 / 4, 0.05 / 4) * 4, 1, 4, 256 * 1024)
+    if wl in ("fir4097", "fir8193"):
+        K = 4097 if wl == "fir4097" else 8193
+        return cpu_baseline_fir(tp.complex_bandpass(K, 0.05, 0.05), 9, (64 if K == 4097 else 32) * 1024)
     return cpu_baseline_fir_i16(tp.c1_taps() * 0.9, 512 * 1024)
 
 
@@ -1615,6 +1618,7 @@ def main():
             sec["elementwise"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("rotate", "abs", "freq_demod")}
             sec["fir255_i16"] = guarded("fir255_i16", measure_secondary, "fir255_i16", dev, args)
             sec["resamplers"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("decim8", "interp4")}
+            sec["long_taps"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("fir4097", "fir8193")}   # taps in partitions
             # ... configs[3] rehearsed on this one device through the native driver, and the end-to-end number of SURVEY 8d (PCIe inside)
             sec["c3_one_device"] = guarded("c3_one_device", measure_c3_one_device, args, avg_ms)
             sec["host_path"] = guarded("host_path", measure_host_path, args, out.get("cpu_baseline"))

@@ -6,7 +6,7 @@
 // transposed back with the twiddle W_N^(n2 k1) applied on the way, transformed along N2, and
 // transposed once more into natural order.  Same unnormalised DFT as kissfft<T>::transform
 // (fft/kissfft.hh:81-161), which accepts any size; parity bar 1e-5 of max|X|.  This file holds the
-// batched tiled transpose (+ twiddle); pcx_api.hip strings the five launches together.
+// batched tiled transpose (+ twiddle); pcx_fft_api.hip strings the five launches together.
 #include "fft4096.hpp"
 #include "pcx_internal.hpp"
 

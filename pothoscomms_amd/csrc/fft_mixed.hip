@@ -689,7 +689,7 @@ int launch_fft_mixed(int scalar, const void *in, void *out, size_t nbins, size_t
 }  // namespace pcx
 
 namespace pcx {
-// complex_float32 / complex_float64, numBins = 2^a 3^b 5^c: radices (16 / 8 / 4 / 2 / 6 / 15 / 9 / 5 / 3) chosen by pcx_api.hip,
+// complex_float32 / complex_float64, numBins = 2^a 3^b 5^c: radices (16 / 8 / 4 / 2 / 6 / 15 / 9 / 5 / 3) chosen by pcx_fft_api.hip,
 // forward twiddle table of the element type
 int launch_fft_smooth(int scalar, const void *in, void *out, size_t nbins, size_t nframes, bool inverse, const void *tw, const void *iperm,
                       const int *radix_host, int nstages, hipStream_t st)

@@ -21,7 +21,7 @@
 // Registers: P spectra of 16 bins (32 VGPRs each) + the product + the pass-3 factors (30) + the kept half window (16): every P
 // runs two workgroups per CU on up to 256 VGPRs.  P = 2 holds its bins of H_0 and H_1 in registers as well (64); P = 3 and 4 read
 // the H_p from L2 in every block (96 / 128 KB a table, the same for every workgroup), stored the way the lanes hold the spectrum
-// (pcx_api.hip turn_spectrum_lanes), two partitions to a 16-byte entry.
+// (pcx_tables.hpp turn_spectrum_lanes), two partitions to a 16-byte entry.
 #include "fft4096.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -301,7 +301,7 @@ size_t fir_upols_table_bytes(int parts)
     return parts == 2 ? HTable<2>::kBytes : parts == 3 ? HTable<3>::kBytes : parts == 4 ? HTable<4>::kBytes : 0;
 }
 
-// parts = ceil((K - 1) / 2048) in 2 .. 4; Hparts = the partitions' spectra (pcx_api.hip make_hparts), tw = make_tw4096()
+// parts = ceil((K - 1) / 2048) in 2 .. 4; Hparts = the partitions' spectra (pcx_tables.hpp make_hparts), tw = make_tw4096()
 int launch_fir_cf32_upols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, int parts, const void *tw,
                           hipStream_t st)
 {

@@ -106,7 +106,7 @@ struct TraceRange {
 };
 #define PCX_TRACE() ::pcx::TraceRange pcx_trace_range_(__func__)
 
-// (pcx_api.hip, for pcx_shard.hip) upload a FIR handle's tables now instead of at its next call
+// (pcx_fir_api.hip, for pcx_shard.hip) upload a FIR handle's tables now instead of at its next call
 int fir_prepare(struct ::pcx_fir *h);
 int fmchain_prepare(struct ::pcx_fmchain *h);
 // (pcx_shard.hip) resident workgroups a handle's persistent launches may take: 1024 / the number of shards that share the device

@@ -100,14 +100,21 @@ def test_the_committed_default_line_carries_every_single_gpu_config_and_the_host
     assert r["traffic"] and 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.15       # PMC bytes of THIS kernel (stamped sources)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     s = d["secondary"]
-    assert set(s) == {"fft4096", "fmchain", "elementwise", "fir255_i16", "resamplers", "c3_one_device", "host_path", "seconds"}
-    assert s["seconds"] < 40 and not any("error" in (v if isinstance(v, dict) else {}) for v in s.values())
+    assert set(s) == {"fft4096", "fmchain", "elementwise", "fir255_i16", "resamplers", "long_taps", "c3_one_device", "host_path", "seconds"}
+    assert s["seconds"] < 45 and not any("error" in (v if isinstance(v, dict) else {}) for v in s.values())
     for k in ("fft4096", "fmchain"):
         assert s[k]["roofline"]["bound"] == "hbm" and s[k]["roofline"]["frac"] > 0.4 and "cpu_baseline" in s[k]
     # round 6: the remaining rows of SURVEY 8 in the driver's own line
     assert set(s["elementwise"]) == {"rotate", "abs", "freq_demod"} and set(s["resamplers"]) == {"decim8", "interp4"}
     for w in list(s["elementwise"].values()) + list(s["resamplers"].values()):
         assert w["roofline"]["bound"] == "hbm" and w["roofline"]["frac"] > 0.4 and w["cpu_baseline"]["kind"] == "port"
+    # the long filters on the headline's blocks, the taps in partitions: every input sample fetched once
+    assert set(s["long_taps"]) == {"fir4097", "fir8193"}
+    for w, floor in (("fir4097", 0.36), ("fir8193", 0.29)):
+        lt = s["long_taps"][w]
+        assert lt["roofline"]["kernel"] == "fir_cf32_upols_kernel" and lt["roofline"]["bound"] == "hbm" and lt["roofline"]["frac"] > floor
+        assert lt["cpu_baseline"]["kind"] == "port" and lt["config"]["taps"] == int(w[3:])
+        assert 0.97 < lt["roofline"]["traffic"] / lt["roofline"]["algorithmic_bytes_per_launch"] < 1.08
     i16 = s["fir255_i16"]
     ri = i16["roofline"]
     assert ri["bound"] == "fp64" and ri["peak"] == 78.6 and ri["unit"] == "TFLOP/s" and i16["dtype"] == "f64" and i16["cpu_baseline"]["kind"] == "port"

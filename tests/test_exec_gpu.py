@@ -1,4 +1,4 @@
-"""GPU suite: the execution model of the C ABI (pcx_api.hip ExecCtx, include/pcx.h "Conventions") -- what round 1's review
+"""GPU suite: the execution model of the C ABI (pcx_host.hpp ExecCtx, include/pcx.h "Conventions") -- what round 1's review
 found missing: page-locked host buffers processed in place, calls of one handle on DIFFERENT streams ordered behind each
 other (carried state, tables), setters between asynchronous calls, reset enqueued, two handles on two threads."""
 import ctypes as C

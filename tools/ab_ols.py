@@ -2,7 +2,7 @@
 per process): parity against the oracle on a short stream and the per-pass time at 64 Mi samples, for a few tap counts (AB_KS).  Run
 once per setting:
     PCX_HIP_LIBRARY=pothoscomms_amd/libpcx_hip_diag.so PCX_OLS_VARIANT=9 python tools/ab_ols.py
-(Rounds 2-5 compared block SIZES with it -- PCX_OLS_N, the radix-16 family plans: removed in round 6, see pcx_api.hip fir_ols_partitions.)
+(Rounds 2-5 compared block SIZES with it -- PCX_OLS_N, the radix-16 family plans: removed in round 6, see pcx_fir_api.hip fir_ols_partitions.)
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

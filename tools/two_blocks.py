@@ -1,5 +1,5 @@
 """Two /comms/fir_filter blocks on two scheduler threads, each calling work() on its own pinned port buffers (what two
-Pothos actors do).  Every handle owns a stream (pcx_api.hip ExecCtx), so their kernels overlap instead of serialising
+Pothos actors do).  Every handle owns a stream (pcx_host.hpp ExecCtx), so their kernels overlap instead of serialising
 on the legacy default stream.
 
     python tools/two_blocks.py                       aggregate rate, one thread vs two

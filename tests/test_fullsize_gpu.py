@@ -48,6 +48,41 @@ def test_fir255_64Mi_windows_and_cross_check(oracle, dev, torch_dev):
     assert np.array_equal(x[:1000].cpu().numpy().ravel(), oracle.fill_uniform_f32(2000, 2, 0))
 
 
+@pytest.mark.parametrize("K", [4097, 6145, 8193])
+def test_long_tap_fir_64Mi_windows_at_run_and_block_seams(oracle, dev, torch_dev, K):
+    """The taps in partitions (fir_ols_part.hip): 64 Mi samples, 32768 blocks of 2048 outputs in 512 runs of 64.  The oracle on windows:
+    the start of the stream (the windows in front of the buffer), the first run seam (where a workgroup computes its own history
+    spectra), seams deep in the stream and the ragged end; an impulse in front of a run seam returns the taps across it."""
+    torch, d = torch_dev
+    from pothoscomms_amd import _lib, taps as tp
+    h = tp.complex_bandpass(K, 0.05, 0.05)
+    n = C1 + 1234                                         # a ragged last block
+    x = torch.empty((n + K - 1, 2), dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(x, seed=5, offset=0)
+    y = torch.empty((n, 2), dtype=torch.float32, device=d)
+    f = dev.FirFilter("complex_float32", "COMPLEX"); f.set_taps(h)
+    assert f.process_dev(x, y) == (n, n) and f.last_algo == _lib.FIR_OLS_FFT
+    torch.cuda.synchronize()
+    ref = oracle.Fir(oracle.F32, True, True); ref.set_taps(h); ref.activate()
+    nblocks = -(-n // 2048)
+    run = nblocks // 512 + 1                               # the longer runs come first (a balanced partition)
+    for start in (0, 2048 - 200, run * 2048 - 300, 7 * run * 2048 - 300, 300 * 2048 * 64 + 1800, n - 3000):
+        m = 3000 if start in (0, n - 3000) else 600
+        win = x[start:start + m + K - 1].cpu().numpy()
+        want, _, p, _ = ref.work(win, m)
+        assert p == m and nerr(y[start:start + m].cpu().numpy(), want) <= TOL, (K, start)
+    # an impulse: the taps come back, across block and run seams
+    x.zero_()
+    at = run * 2048 - 1000 + K - 1
+    x[at, 0] = 1.0
+    assert f.process_dev(x, y) == (n, n)
+    torch.cuda.synchronize()
+    got = y[at - (K - 1):at + 1].cpu().numpy()
+    hh = np.stack([h.real, h.imag], axis=1).astype(np.float32)
+    assert np.abs(got - hh).max() <= 1e-5 * np.abs(hh).max() + 1e-7
+    assert float(y[:at - (K - 1)].abs().max()) <= 1e-6 and float(y[at + 1:].abs().max()) <= 1e-6
+
+
 def test_fir_linearity_and_impulse_full_size(dev, torch_dev):
     """FIR(a x1 + x2) = a FIR(x1) + FIR(x2); an impulse returns the taps."""
     torch, d = torch_dev

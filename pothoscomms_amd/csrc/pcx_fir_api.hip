@@ -447,7 +447,10 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
 // M = L = 1, 4096-sample blocks: block b of a call computes outputs [b S, (b + 1) S), S = 4096 - (K - 1 rounded up to 16)) where that
 // plan serves the handle; the time-domain kernels and the exact integer pipelines compute every output by itself, any multiple of
 // M will do (a generous one: chunks stay whole tiles).  Other float plans (long taps, resamplers) are cut at multiples of M * 4096:
-// their outputs stay within the 1e-5 of the oracle either way, but are not bit-identical to an uncut call's.
+// their outputs stay within the 1e-5 of the oracle either way, but are not bit-identical to an uncut call's.  (The partitioned
+// long-tap plan computes block b from windows b, b - 1, ... alone -- whichever workgroup's run it falls into, so a call returns the
+// same bits on any grid -- but the first blocks of a CUT call see zeros where the uncut call's windows hold samples that meet no
+// tap: equal in exact arithmetic, not in the transform's rounding.)
 static size_t fir_chunk_quantum(const pcx_fir *h)
 {
     const bool plain = h->scalar == PCX_F32 && h->cplx && h->M == 1 && h->L == 1 && h->have_ols && h->ols_parts == 0 && h->K > 1;

@@ -2,8 +2,8 @@
 //
 // The same y[n] = sum_k h[k] x[n-k] as FIRFilter.cpp:294-300.  fir_ols.hip evaluates it per 4096-sample block as
 // IFFT(FFT(block) .* H) and stops at K - 1 = 2048: a block cannot be shorter than the filter.  Until round 6 longer filters
-// went to 8192- / 16384-sample blocks (fir_ols_r16.hip: 512 / 1024 lanes per block, six / eight LDS exchanges per transform
-// pair, half of every window overlap) at 0.29 / 0.18 of the HBM rate.  Here the BLOCK stays 4096 samples and the filter is cut
+// went to 8192- / 16384-sample blocks (fir_ols_r16.hip, removed: 512 / 1024 lanes per block, six / eight LDS exchanges per
+// transform pair, half of every window overlap) at 0.29 / 0.18 of the HBM rate.  Here the BLOCK stays 4096 samples and the filter is cut
 // instead: h = h_0 + z^-B h_1 + ... + z^-(P-1)B h_(P-1), B = 2048 taps each (the last one up to B + 1), and
 //     y_b = IFFT( X_b . H_0 + X_(b-1) . H_1 + ... + X_(b-P+1) . H_(P-1) ) [B .. 2B)        X_m = FFT( x[mB + off .. mB + off + 4096) )
 // -- ONE forward and ONE inverse 4096-point transform per B outputs whatever K, plus P multiply-adds per bin against spectra the
@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const float2 *__
     load_pass3_twiddles(tw3, make_rsrc(twtab, TW_TABLE_ELEMS * 8), j);
     stage_pass2_twiddles(lds, twtab, j);          // (in front of the first dif_rest's barriers)
 
-    // rows [r0, r1) of window m into dst[r - d0].  Whole windows inside the buffer take one descriptor and scalar row offsets; a
-    // window that starts in front of the buffer or ends behind it goes through the range check lane by lane (reads 0 outside).
+    // Window m, whole (the prologue of a run).  Windows inside the buffer take one descriptor and scalar row offsets; a window that
+    // starts in front of the buffer or ends behind it goes through the range check lane by lane (reads 0 outside).
     // Non-temporal, except the upper half of a window that the next block fetches again as its lower half (no KEEP).
-    auto fetch = [&](auto &dst, long long m, auto r0c, auto d0c) {
-        constexpr int r0 = decltype(r0c)::value, d0 = decltype(d0c)::value;
+    auto fetch = [&](cf (&dst)[16], long long m) {
+        constexpr int r0 = 0, d0 = 0;
         const long long s = m * kHop + off;
         if (s >= 0 && (size_t)s + 4096 <= in_elems) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + s, 4096 * 8);
@@ -190,11 +190,11 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const float2 *__
     // the spectra in front of the run: windows b0 - P + 1 .. b0 - 1 into slots P - 1 .. 1
 #pragma unroll
     for (int p = P - 1; p >= 1; p--) {
-        fetch(X[p], (long long)b0 - p, I0(), I0());
+        fetch(X[p], (long long)b0 - p);
         first_pass(X[p]);
         dif_rest(X[p], lds, j);
     }
-    fetch(X[0], (long long)b0, I0(), I0());
+    fetch(X[0], (long long)b0);
 
     size_t b = b0;
     auto step = [&](auto rc) {

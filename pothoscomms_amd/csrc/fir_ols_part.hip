@@ -18,11 +18,17 @@
 // and sample B + t is exactly sum_k h_p[k] in[bB + t + K-1 - pB - k].  Windows in front of the buffer (m < 0 at the start of
 // the stream) read as zero through the descriptor's range check; they only meet taps that do not exist.
 //
+// REAL float32 streams (real taps) ride the same kernel two at a time: a real filter does not mix the parts of a complex stream, so
+// z[t] = x[t] + i x[t + D] -- the call's first half beside its second, D = half the outputs -- is filtered as ONE complex stream of
+// half the length and y[t] = Re, y[t + D] = Im.  Only the fetches and the stores differ (two 4-byte accesses per element instead
+// of one of 8); the second half's history is the end of the first half, real samples in the same buffer.
+//
 // Registers: P spectra of 16 bins (32 VGPRs each) + the product + the pass-3 factors (30) + the kept half window (16): every P
 // runs two workgroups per CU on up to 256 VGPRs.  P = 2 holds its bins of H_0 and H_1 in registers as well (64); P = 3 and 4 read
 // the H_p from L2 in every block (96 / 128 KB a table, the same for every workgroup), stored the way the lanes hold the spectrum
 // (pcx_tables.hpp turn_spectrum_lanes), two partitions to a 16-byte entry.
 #include "fft4096.hpp"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -91,13 +97,19 @@ struct HTable {
 // two with H in registers 0.327; the pass-3 factors in LDS instead of registers (to make room for the next window's upper half a
 // whole block early) 0.345 either way: thirty more LDS reads per transform are not hidden at two waves per SIMD, and the earlier
 // fetch bought nothing -- memory latency is not what a block waits for.  K = 8193 -- 0.403 ms.
-template <int P, bool KEEP, bool HREG, int BP>
-__global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const float2 *__restrict__ in, size_t in_elems, float2 *__restrict__ out,
+// REAL: `in` / `out` are float streams, `half` = D (outputs [0, half) are the real part's, [half, n_out) the imaginary part's);
+// n_out, in_elems in real samples, nblocks = blocks of the first half.
+template <int P, bool KEEP, bool HREG, int BP, bool REAL>
+__global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const void *__restrict__ in_, size_t in_elems, void *__restrict__ out_,
                                                                   size_t n_out, const unsigned char *__restrict__ Hparts, long long off,
-                                                                  const float2 *__restrict__ twtab, size_t nblocks)
+                                                                  const float2 *__restrict__ twtab, size_t nblocks, size_t half)
 {
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
+    const float2 *in = static_cast<const float2 *>(in_);
+    float2 *out = static_cast<float2 *>(out_);
+    const float *inr = static_cast<const float *>(in_);
+    float *outr = static_cast<float *>(out_);
     // this workgroup's run of blocks: a balanced partition of 0 .. nblocks - 1
     const size_t q = nblocks / gridDim.x, rem = nblocks % gridDim.x, w = blockIdx.x;
     const size_t b0 = w * q + (w < rem ? w : rem), b1 = b0 + q + (w < rem ? 1 : 0);
@@ -110,10 +122,31 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const float2 *__
     // Window m, whole (the prologue of a run).  Windows inside the buffer take one descriptor and scalar row offsets; a window that
     // starts in front of the buffer or ends behind it goes through the range check lane by lane (reads 0 outside).
     // Non-temporal, except the upper half of a window that the next block fetches again as its lower half (no KEEP).
+    // one part of a real pair: 4-byte samples from inr + s_h, the range check lane by lane.  A lane in front of the buffer gets a fixed
+    // out-of-range offset, not its (negative, wrapped) own: written as (j + 256 r - shift) * 4 the compiler keeps (j - shift) * 4 in
+    // the register and 1024 r in the instruction's offset field, and a buffer_load_dword whose register part is wrapped DROPS the
+    // valid lanes that share a four-lane group with lanes still out of range after the addition (tools/bufload_quad_lab.hip,
+    // profiles/r06/bufload_quad_lab.txt: dword loads with a non-zero instruction offset only; dwordx2 loads are not affected)
+    auto fetch_part = [&](float (&dst)[16], long long s_h) {
+        const long long shift = s_h < 0 ? -s_h : 0, first = s_h + shift;
+        const long long left = (long long)in_elems > first ? (long long)in_elems - first : 0, want = 4096 - shift;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(inr + first, (unsigned)((left < want ? left : want) * 4));
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int e = j + 256 * r - (int)shift;
+            dst[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, e < 0 ? 0x7ffffff0 : e * 4, 0, kAuxStream));
+        }
+    };
     auto fetch = [&](cf (&dst)[16], long long m) {
         constexpr int r0 = 0, d0 = 0;
         const long long s = m * kHop + off;
-        if (s >= 0 && (size_t)s + 4096 <= in_elems) {
+        if (REAL) {
+            float re[16], im[16];
+            fetch_part(re, s);
+            fetch_part(im, s + (long long)half);
+#pragma unroll
+            for (int r = 0; r < 16; r++) dst[r] = cf{re[r], im[r]};
+        } else if (s >= 0 && (size_t)s + 4096 <= in_elems) {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + s, 4096 * 8);
 #pragma unroll
             for (int r = r0; r < 16; r++) {
@@ -138,6 +171,19 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const float2 *__
     auto fetch_next = [&](auto &dst, size_t m, auto r0c, auto d0c) {
         constexpr int r0 = decltype(r0c)::value, d0 = decltype(d0c)::value;
         const size_t s = m * kHop + (size_t)off;
+        if (REAL) {
+            const size_t sb = s + half;
+            const size_t la = in_elems > s ? in_elems - s : 0, lb = in_elems > sb ? in_elems - sb : 0;
+            const __amdgpu_buffer_rsrc_t ra = make_rsrc(inr + (la ? s : 0), (unsigned)((la < 4096 ? la : 4096) * 4));
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(inr + (lb ? sb : 0), (unsigned)((lb < 4096 ? lb : 4096) * 4));
+#pragma unroll
+            for (int r = r0; r < 16; r++) {
+                const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(ra, (j + 256 * r) * 4, 0, kAuxStream);
+                const unsigned c = __builtin_amdgcn_raw_buffer_load_b32(rb, (j + 256 * r) * 4, 0, kAuxStream);
+                dst[r - d0] = cf{__uint_as_float(a), __uint_as_float(c)};
+            }
+            return;
+        }
         const size_t left = in_elems > s ? in_elems - s : 0;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + (left ? s : 0), (unsigned)((left < 4096 ? left : 4096) * 8));
 #pragma unroll
@@ -256,13 +302,26 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const float2 *__
         __builtin_amdgcn_s_setprio(1);
         dit_back(u, lds, j, tw3);
         // time sample i = j + 256 bin_of(q) >= B of the block is output bB + i - B; outputs past n_out fall to the range check
-        const size_t room = n_out - b * kHop;
-        const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * kHop, (unsigned)((room < (size_t)kHop ? room : (size_t)kHop) * 8));
+        if (REAL) {
+            const size_t o = b * kHop, na = half - o, nb = n_out - half > o ? n_out - half - o : 0;       // (o < half: nblocks covers the first half)
+            const __amdgpu_buffer_rsrc_t wa = make_rsrc(outr + o, (unsigned)((na < (size_t)kHop ? na : (size_t)kHop) * 4));
+            const __amdgpu_buffer_rsrc_t wb = make_rsrc(outr + (nb ? half + o : 0), (unsigned)((nb < (size_t)kHop ? nb : (size_t)kHop) * 4));
 #pragma unroll
-        for (int qq = 0; qq < 16; qq++) {
-            const int row = bin_of(qq);
-            if (row < 8) continue;
-            store_cf<kAuxStream>(ws, (unsigned)j * 8u + (unsigned)(row - 8) * 2048u, u[qq]);
+            for (int qq = 0; qq < 16; qq++) {
+                const int row = bin_of(qq);
+                if (row < 8) continue;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[qq].x), wa, (j + 256 * (row - 8)) * 4, 0, kAuxStream);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[qq].y), wb, (j + 256 * (row - 8)) * 4, 0, kAuxStream);
+            }
+        } else {
+            const size_t room = n_out - b * kHop;
+            const __amdgpu_buffer_rsrc_t ws = make_rsrc(out + b * kHop, (unsigned)((room < (size_t)kHop ? room : (size_t)kHop) * 8));
+#pragma unroll
+            for (int qq = 0; qq < 16; qq++) {
+                const int row = bin_of(qq);
+                if (row < 8) continue;
+                store_cf<kAuxStream>(ws, (unsigned)j * 8u + (unsigned)(row - 8) * 2048u, u[qq]);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         b++;
@@ -276,10 +335,12 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const float2 *__
     }
 }
 
-template <int P, bool KEEP, bool HREG, int BP>
+template <int P, bool KEEP, bool HREG, int BP, bool REAL>
 int launch_parts(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, const void *tw, hipStream_t st)
 {
-    const size_t nblocks = (n_out + kHop - 1) / kHop;
+    // REAL: the first `half` outputs (a multiple of 32: whole 128-byte lines for the second half's rows) beside the rest
+    const size_t half = REAL ? std::min(n_out, ((n_out + 1) / 2 + 31) / 32 * 32) : 0;
+    const size_t nblocks = ((REAL ? half : n_out) + kHop - 1) / kHop;
     // a run pays P - 1 forward transforms before its first output: runs of at least 4 (P - 1) blocks while the call has them
     const long oversub = PCX_ENV_INT("PCX_UPOLS_OVERSUB", 1);      // (diagnostic library: workgroups queued per slot, A/B)
     const unsigned slots = 256u * 2u * (unsigned)(oversub > 0 ? oversub : 1);      // two workgroups per CU
@@ -288,8 +349,8 @@ int launch_parts(const void *in, size_t in_elems, void *out, size_t n_out, const
     size_t grid = (nblocks + min_run - 1) / min_run;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((fir_cf32_upols_kernel<P, KEEP, HREG, BP>), dim3((unsigned)grid), dim3(256), 0, st, (const float2 *)in, in_elems,
-                       (float2 *)out, n_out, (const unsigned char *)Hparts, (long long)(K - 1) - kHop, (const float2 *)tw, nblocks);
+    hipLaunchKernelGGL((fir_cf32_upols_kernel<P, KEEP, HREG, BP, REAL>), dim3((unsigned)grid), dim3(256), 0, st, in, in_elems, out, n_out,
+                       (const unsigned char *)Hparts, (long long)(K - 1) - kHop, (const float2 *)tw, nblocks, half);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -301,29 +362,34 @@ size_t fir_upols_table_bytes(int parts)
     return parts == 2 ? HTable<2>::kBytes : parts == 3 ? HTable<3>::kBytes : parts == 4 ? HTable<4>::kBytes : 0;
 }
 
-// parts = ceil((K - 1) / 2048) in 2 .. 4; Hparts = the partitions' spectra (pcx_tables.hpp make_hparts), tw = make_tw4096()
+// parts = ceil((K - 1) / 2048) in 2 .. 4; Hparts = the partitions' spectra (pcx_tables.hpp make_hparts), tw = make_tw4096();
+// real_stream: float32 samples and outputs (real taps), else complex_float32
 int launch_fir_cf32_upols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, int parts, const void *tw,
-                          hipStream_t st)
+                          hipStream_t st, bool real_stream)
 {
     if (n_out == 0) return PCX_OK;
     if (K < 2050 || (K - 1 + kHop - 1) / kHop != (size_t)parts) { set_error("fir partitioned ols: K=%zu does not make %d partitions", K, parts); return PCX_ERR_UNSUPPORTED; }
     const int variant = (int)PCX_ENV_INT("PCX_UPOLS_VARIANT", 0);   // (diagnostic library: A/B)
-#define PCX_UPOLS(P, KEEP, HREG, BP) return launch_parts<P, KEEP, HREG, BP>(in, in_elems, out, n_out, Hparts, K, tw, st)
+#define PCX_UPOLS(P, KEEP, HREG, BP)                                                                                            \
+    do {                                                                                                                        \
+        if (real_stream) return launch_parts<P, KEEP, HREG, BP, true>(in, in_elems, out, n_out, Hparts, K, tw, st);             \
+        return launch_parts<P, KEEP, HREG, BP, false>(in, in_elems, out, n_out, Hparts, K, tw, st);                             \
+    } while (0)
     switch (parts) {
     case 2:
 #ifdef PCX_DIAG
-        if (variant == 1) PCX_UPOLS(2, true, false, 4);
-        if (variant == 2) PCX_UPOLS(2, false, true, 8);
+        if (variant == 1 && !real_stream) return launch_parts<2, true, false, 4, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
+        if (variant == 2 && !real_stream) return launch_parts<2, false, true, 8, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
 #endif
         PCX_UPOLS(2, true, true, 8);
     case 3:
 #ifdef PCX_DIAG
-        if (variant == 1) PCX_UPOLS(3, true, false, 1);
+        if (variant == 1 && !real_stream) return launch_parts<3, true, false, 1, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
 #endif
         PCX_UPOLS(3, true, false, 2);
     case 4:
 #ifdef PCX_DIAG
-        if (variant == 1) PCX_UPOLS(4, false, false, 2);
+        if (variant == 1 && !real_stream) return launch_parts<4, false, false, 2, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
 #endif
         PCX_UPOLS(4, true, false, 1);
     }

@@ -37,7 +37,7 @@ struct pcx_fir {
     bool have_interp_real = false; // REAL float64 / float32 / int16 / int8, L > 1: the same with the two-real-blocks kernel
     DevBuf HrowsD;
     DevBuf HspecRows;
-    int ols_parts = 0;        // complex_float32 M = L = 1: 0 = fir_ols.hip's 4096 kernel alone, 2 .. 4 = that many tap partitions (fir_ols_part.hip)
+    int ols_parts = 0;        // complex_float32 / float32, M = L = 1: 0 = fir_ols.hip's 4096 kernels alone, 2 .. 4 = that many tap partitions (fir_ols_part.hip)
     int ols_log2n = 0;        // the double-precision plans: log2 of the block (12, 13)
     bool taps24 = false;      // integer Q taps all fit 24 signed bits (v_mul_i32_i24 path)
     bool taps16 = false;      // complex_int16 / complex_int8 stream, complex taps within +-32767 after floatToQ (v_dot2_i32_i16 path)
@@ -287,10 +287,14 @@ static int fir_sync_tables(pcx_fir *h)
         }
     }
     h->have_real_ols = false;
-    if (h->scalar == PCX_F32 && !h->cplx && h->M == 1 && h->L == 1 && h->K <= 2049) {
+    if (h->scalar == PCX_F32 && !h->cplx && h->M == 1 && h->L == 1 && h->K <= kOlsMaxTaps) {
+        // two real blocks per complex transform (fir_ols.hip); beyond 2049 taps the two halves of the call side by side through the
+        // partitioned kernel (fir_ols_part.hip)
         std::vector<std::complex<double>> hq(h->K);
         for (size_t k = 0; k < h->K; k++) hq[k] = std::complex<double>((double)(float)h->taps[k], 0.0);
-        PCX_TRY(upload(h->Hspec, make_hspec4096(hq)));
+        h->ols_parts = fir_ols_partitions(h->K);
+        if (h->ols_parts == 0) PCX_TRY(upload(h->Hspec, make_hspec4096(hq)));
+        else PCX_TRY(upload(h->Hspec, make_hparts(hq, h->ols_parts)));
         PCX_TRY(upload(h->tw4096, make_tw4096()));
         h->have_real_ols = true;
     }
@@ -522,7 +526,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     }
     if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64 || h->have_ols_int || h->have_ols_real64 ||
                                      h->have_interp64 || h->have_interp_real)) {
-        set_error("fir: OLS_FFT needs complex_float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
+        set_error("fir: OLS_FFT needs complex_float32 or float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
@@ -573,6 +577,8 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     } else if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
         rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, h->M, qs, st, h->sched.p);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols && h->ols_parts != 0) {
+        rc = launch_fir_cf32_upols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_parts, h->tw4096.p, st, true);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {
         rc = launch_fir_f32_ols4096(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->tw4096.p, h->sched.p, st);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_interp) {

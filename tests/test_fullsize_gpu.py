@@ -83,6 +83,32 @@ def test_long_tap_fir_64Mi_windows_at_run_and_block_seams(oracle, dev, torch_dev
     assert float(y[:at - (K - 1)].abs().max()) <= 1e-6 and float(y[at + 1:].abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("K", [4097, 8193])
+def test_long_tap_real_fir_64Mi_windows(oracle, dev, torch_dev, K):
+    """real float32, long taps: the call's two halves ride the partitioned kernel side by side as one complex stream.  The oracle on
+    windows at the start, around the seam between the halves (the second half's history is the end of the first), at run seams of
+    both halves and at the ragged end."""
+    torch, d = torch_dev
+    from pothoscomms_amd import _lib, taps as tp
+    h = tp.lowpass(K, 0.07)
+    n = C1 + 4321
+    x = torch.empty((n + K - 1 + 1) // 2 * 2, dtype=torch.float32, device=d)
+    dev.fill_uniform_f32_dev(x.view(-1, 2), seed=6, offset=0)
+    x = x[:n + K - 1]
+    y = torch.empty(n, dtype=torch.float32, device=d)
+    f = dev.FirFilter("float32", "REAL"); f.set_taps(h)
+    assert f.process_dev(x, y) == (n, n) and f.last_algo == _lib.FIR_OLS_FFT
+    torch.cuda.synchronize()
+    ref = oracle.Fir(oracle.F32, False, False); ref.set_taps(h); ref.activate()
+    half = ((n + 1) // 2 + 31) // 32 * 32
+    run = -(-half // 2048) // 512 + 1
+    for start in (0, 2048 - 200, run * 2048 - 300, half - 1500, half + run * 2048 - 300, n - 3000):
+        m = 3000
+        win = x[start:start + m + K - 1].cpu().numpy()
+        want, _, p, _ = ref.work(win, m)
+        assert p == m and nerr(y[start:start + m].cpu().numpy(), want) <= TOL, (K, start)
+
+
 def test_fir_linearity_and_impulse_full_size(dev, torch_dev):
     """FIR(a x1 + x2) = a FIR(x1) + FIR(x2); an impulse returns the taps."""
     torch, d = torch_dev

@@ -775,11 +775,12 @@ def test_fir_cf32_frequency_domain_resampling(oracle, dev, L, M, ntaps, ctaps):
             assert nerr(got, ref) <= TOL
 
 
-@pytest.mark.parametrize("ntaps", [2, 31, 255, 1024, 2049])
+@pytest.mark.parametrize("ntaps", [2, 31, 255, 1024, 2049, 2050, 3000, 4097, 4098, 6145, 8193])
 def test_fir_real_f32_frequency_domain(oracle, dev, ntaps):
-    """real float32 stream with REAL taps: two real blocks per complex transform"""
+    """real float32 stream with REAL taps: two real blocks per complex transform; beyond 2049 taps the call's two halves side by side
+    as one complex stream through the partitioned kernel (odd and even lengths, a second half shorter than the first, one block)"""
     rng = np.random.default_rng(ntaps + 77)
-    for n in (ntaps + 5, 3842 * 2 + 100 + ntaps, 3842 * 5 + 7 + ntaps):
+    for n in (ntaps + 5, 3842 * 2 + 100 + ntaps, 3842 * 5 + 7 + ntaps) + ((ntaps + 2048 * 9 + 31, ntaps + 70001) if ntaps > 2049 else ()):
         x = rand_stream(rng, oracle.F32, n, False)
         taps = _taps(rng, ntaps, False)
         ref_blk = oracle.Fir(oracle.F32, False, False); ref_blk.set_taps(taps); ref_blk.activate()

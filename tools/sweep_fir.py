@@ -5,7 +5,7 @@ import numpy as np, torch
 from pothoscomms_amd import _lib, device, taps as tp
 d = torch.device("cuda", 0)
 n = 64 * 1024 * 1024
-for K in (1, 2, 4, 8, 16, 32, 63, 127, 255, 511, 1023, 2049, 4097, 8193):
+for K in (1, 2, 4, 8, 16, 32, 63, 127, 255, 511, 1023, 1537, 2049, 2050, 3073, 4097, 4098, 6145, 6146, 8193):
     h = tp.complex_bandpass(K, 0.05, 0.05) if K > 1 else np.array([1.0 + 0j])
     lead = (-(K - 1)) % 16
     xa = torch.empty((lead + n + K - 1, 2), dtype=torch.float32, device=d); device.fill_uniform_f32_dev(xa, seed=1)

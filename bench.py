@@ -882,13 +882,13 @@ def roofline_of(W, avg_ms, sustained=None, cold=None, sustain_s=1.0, clk=None):
                      "note": "the other ceiling, kept beside: 8 B per sample -- this kernel is nowhere near it and never will be"}}
         m = measured_f64_issue_rate()
         if m and W.blocks:
-            insts = (ctr_insts(entry) or 1420.0 * 4 * W.blocks)
+            insts = (ctr_insts(entry) or 1350.0 * 4 * W.blocks)
             r["issue"] = {"wave_insts_per_launch": insts, "G_wave_insts_per_s": round(insts / sec / 1e9, 1),
                           "measured_roof_G_wave_insts_per_s": m[0], "frac_of_measured_issue_roof": round(insts / sec / 1e9 / m[0], 4),
                           "source": m[1],
                           "note": "what the FP64 pipe issues at this kernel's occupancy (two waves per SIMD) on independent add / multiply / FMA "
                                   "instructions in an FFT's proportions, measured on this part; wave_insts_per_launch from the PMC pass when one "
-                                  "is committed for this kernel, else 1,420 per wave and block from the ISA"}
+                                  "is committed for this kernel, else 1,350 per wave and block from the ISA"}
     else:
         r = {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
              "read_only_frac": round(W.read_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -45,25 +45,51 @@ DI void fft16_outer(cd (&v)[16])
 #pragma unroll
     for (int k1 = 0; k1 < 4; k1++) fft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
-// 16-point forward DFT, x[n] at v[n]; X[k] lands at v[4*(k&3) + (k>>2)]
+// 16-point forward DFT, x[n] at v[n]; X[k] lands at v[4*(k&3) + (k>>2)].
+// The eight constant factors W16^e between the two layers are not multiplied out: a * (c - i s) = c * (a.x + a.y t, a.y - a.x t),
+// t = s / c, costs two FMAs (two additions where t = +-1), and the scale c rides on the additions of the second layer, which become
+// FMAs -- 16 instructions fewer per transform than eight 4-instruction multiplies (96 per block of the overlap-save kernels, which
+// run at the FP64 issue rate; round 6).  Within a DFT4 the two odd inputs share one scale: C1 r1 + S1 r3 = C1 (r1 + T1 r3).
+DI cd tw_t(cd a, double t) { return cd{__builtin_fma(a.y, t, a.x), __builtin_fma(-a.x, t, a.y)}; }   // (a.x + a.y t, a.y - a.x t)
+DI cd fma_s(double c, cd r, cd a) { return cd{__builtin_fma(c, r.x, a.x), __builtin_fma(c, r.y, a.y)}; }   // a + c r
+// a + c * (-i) z  and  a - c * (-i) z,  (-i) z = (z.y, -z.x)
+DI cd fma_mi(double c, cd z, cd a) { return cd{__builtin_fma(c, z.y, a.x), __builtin_fma(-c, z.x, a.y)}; }
 DI void fft16_plain(cd (&v)[16])
 {
     constexpr double C1 = 0.92387953251128673848313610506;   // cos(pi/8)
     constexpr double S1 = 0.38268343236508977172845998403;   // sin(pi/8)
     constexpr double R2 = 0.70710678118654752440084436210;   // cos(pi/4)
+    constexpr double T1 = 0.41421356237309504880168872421;   // tan(pi/8)
+    constexpr double T3 = 2.41421356237309504880168872421;   // cot(pi/8)
     fft16_inner(v);
-    v[4 * 1 + 1] = cmul_cs(v[4 * 1 + 1], C1, S1);
-    v[4 * 1 + 2] = cmul_cs(v[4 * 1 + 2], R2, R2);
-    v[4 * 1 + 3] = cmul_cs(v[4 * 1 + 3], S1, C1);
-    v[4 * 2 + 1] = cmul_cs(v[4 * 2 + 1], R2, R2);
-    v[4 * 2 + 3] = cmul_cs(v[4 * 2 + 3], -R2, R2);
-    v[4 * 3 + 1] = cmul_cs(v[4 * 3 + 1], S1, C1);
-    v[4 * 3 + 2] = cmul_cs(v[4 * 3 + 2], -R2, R2);
-    v[4 * 3 + 3] = cmul_cs(v[4 * 3 + 3], -C1, -S1);
     fft4(v[0], v[1], v[2], v[3]);
-    fft4(v[4], v[5], v[6], v[7]);
-    fft4_mi2(v[8], v[9], v[10], v[11]);
-    fft4(v[12], v[13], v[14], v[15]);
+    {   // k1 = 1: v[5] W16^1, v[6] W16^2, v[7] W16^3 = C1 r1, R2 r2, S1 r3
+        const cd a0 = v[4], r1 = tw_t(v[5], T1), r2 = cd{v[6].x + v[6].y, v[6].y - v[6].x}, r3 = tw_t(v[7], T3);
+        const cd t0 = fma_s(R2, r2, a0), t1 = fma_s(-R2, r2, a0);
+        const cd t2 = fma_s(T1, r3, r1), dd = fma_s(-T1, r3, r1);          // (a1 + a3) / C1, (a1 - a3) / C1
+        v[4] = fma_s(C1, t2, t0);
+        v[6] = fma_s(-C1, t2, t0);
+        v[5] = fma_mi(C1, dd, t1);
+        v[7] = fma_mi(-C1, dd, t1);
+    }
+    {   // k1 = 2: v[9] W16^2, v[10] W16^4 = -i, v[11] W16^6 = R2 r1, (-i) a2, -R2 r3
+        const cd a0 = v[8], r1 = cd{v[9].x + v[9].y, v[9].y - v[9].x}, r = mul_mi(v[10]), r3 = cd{v[11].x - v[11].y, v[11].y + v[11].x};
+        const cd t0 = a0 + r, t1 = a0 - r;
+        const cd t2 = r1 - r3, dd = r1 + r3;                                // (a1 + a3) / R2, (a1 - a3) / R2
+        v[8] = fma_s(R2, t2, t0);
+        v[10] = fma_s(-R2, t2, t0);
+        v[9] = fma_mi(R2, dd, t1);
+        v[11] = fma_mi(-R2, dd, t1);
+    }
+    {   // k1 = 3: v[13] W16^3, v[14] W16^6, v[15] W16^9 = S1 r1, -R2 r2, -C1 r3
+        const cd a0 = v[12], r1 = tw_t(v[13], T3), r2 = cd{v[14].x - v[14].y, v[14].y + v[14].x}, r3 = tw_t(v[15], T1);
+        const cd t0 = fma_s(-R2, r2, a0), t1 = fma_s(R2, r2, a0);
+        const cd t2 = fma_s(-T3, r3, r1), dd = fma_s(T3, r3, r1);          // (a1 + a3) / S1, (a1 - a3) / S1
+        v[12] = fma_s(S1, t2, t0);
+        v[14] = fma_s(-S1, t2, t0);
+        v[13] = fma_mi(S1, dd, t1);
+        v[15] = fma_mi(-S1, dd, t1);
+    }
 }
 // 16-point forward DFT of x[n] * w^n; the lane's 15 factors (layout of make_tw_r16: 3 x (w^4)^n1, then
 // c[(n2-1)*4 + k1] = w^n2 W16^(n2 k1)) are fetched through `tw(p)`, p = 0..14, at their use
@@ -168,7 +194,7 @@ __device__ __forceinline__ Lane make_lane(int l)
 // [15][16] table in LDS, read in front of the multiplies, five at a time.  What was tried instead (tools/f64_lab.hip has the
 // reason it matters: at two waves per SIMD the FP64 pipe issues one instruction per ~3.9 clocks and this kernel runs at 95 %
 // of that, so the instruction COUNT moves it): both sets as six powers each (w^1, w^2, w^3, w^4, w^8, w^12) with the other nine
-// one product away -- 144 more instructions per block on 1,420; the LDS table read one entry at a time in front of each
+// one product away -- 144 more instructions per block on (then) 1,420; the LDS table read one entry at a time in front of each
 // multiply, as the compiler orders it by itself -- thirty exposed LDS latencies per block.
 struct LaneTw {
     cd a[13];      // w^1 .. w^13; w^14 = w^12 . w^2 and w^15 = w^12 . w^3 at their two uses each (the eight registers they would hold

@@ -15,9 +15,9 @@
 // Rounding: everything is double; the result differs from the reference's direct sum by a few 1e-16 of the output scale
 // (parity bar 1e-13).  Against the sliding-window kernel (K multiply-adds per output on the 78 TFLOP/s f64 pipe) this is
 // the faster form from a few tens of taps up (tools/sweep_fir_f64.py).  Its roof is the FP64 vector pipe, not HBM: about
-// 1,430 instructions per 64-lane wave and 3,840-sample block against 4 (int16) to 32 (float64) bytes per sample -- and that pipe
+// 1,330 instructions per 64-lane wave and 3,840-sample block against 4 (int16) to 32 (float64) bytes per sample -- and that pipe
 // issues one instruction per ~3.9 clocks and SIMD at the two waves per SIMD the 64 KB image allows (tools/f64_lab.hip): the
-// complex_int16 kernel runs at 0.95 of that rate (244 Gsamples/s at 255 taps).
+// complex_int16 kernel runs at 0.9 of that rate (250 Gsamples/s at 255 taps).
 #include "fft_f64.hpp"
 #include <cstdio>
 #include <cstdlib>

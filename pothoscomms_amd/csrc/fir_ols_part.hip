@@ -23,6 +23,11 @@
 // half the length and y[t] = Re, y[t + D] = Im.  Only the fetches and the stores differ (two 4-byte accesses per element instead
 // of one of 8); the second half's history is the end of the first half, real samples in the same buffer.
 //
+// DECIMATING filters (L = 1, M > 1, FIRFilter.cpp:286-302: the output with (n + 1) % M == 0 is kept) run the same blocks at the full
+// rate and keep one output in M at the store -- 200 x the time-domain tile they fell to beyond 2049 taps.  (Up to 2049 taps the
+// folded-spectrum kernel of fir_ols_decim.hip also shortens the inverse transform; here the spectra of P windows would have to be
+// folded each.)  A real pair's halves then split at a multiple of M, so that both halves keep the same phase.
+//
 // Registers: P spectra of 16 bins (32 VGPRs each) + the product + the pass-3 factors (30) + the kept half window (16): every P
 // runs two workgroups per CU on up to 256 VGPRs.  P = 2 holds its bins of H_0 and H_1 in registers as well (64); P = 3 and 4 read
 // the H_p from L2 in every block (96 / 128 KB a table, the same for every workgroup), stored the way the lanes hold the spectrum
@@ -99,10 +104,12 @@ struct HTable {
 // fetch bought nothing -- memory latency is not what a block waits for.  K = 8193 -- 0.403 ms.
 // REAL: `in` / `out` are float streams, `half` = D (outputs [0, half) are the real part's, [half, n_out) the imaginary part's);
 // n_out, in_elems in real samples, nblocks = blocks of the first half.
-template <int P, bool KEEP, bool HREG, int BP, bool REAL>
+// DECIM: n_out counts full-rate outputs, n_dec the stored ones; magic = ceil(2^32 / M) (exact quotient for t * M < 2^32).
+template <int P, bool KEEP, bool HREG, int BP, bool REAL, bool DECIM>
 __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const void *__restrict__ in_, size_t in_elems, void *__restrict__ out_,
                                                                   size_t n_out, const unsigned char *__restrict__ Hparts, long long off,
-                                                                  const float2 *__restrict__ twtab, size_t nblocks, size_t half)
+                                                                  const float2 *__restrict__ twtab, size_t nblocks, size_t half,
+                                                                  size_t n_dec, unsigned M, unsigned magic)
 {
     __shared__ cf lds[LDS_ELEMS];
     const int j = threadIdx.x;
@@ -254,6 +261,12 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const void *__re
         cf u[16];
         auto mac_pair = [&](int qq, const cf (&h0)[P], const cf (&h1)[P]) {
             const int k0 = bin_of(qq), k1 = bin_of(qq + 1);
+            if (P == 1) {            // one partition: the plain product, conjugated
+                u[k0] = v[qq];
+                u[k1] = v[qq + 1];
+                cmul2_conj(u[k0], u[k1], h0[0], h1[0]);
+                return;
+            }
             mac_first(u[k0], u[k1], v[qq], v[qq + 1], h0[0], h1[0]);
 #pragma unroll
             for (int p = 1; p < P; p++) {
@@ -302,7 +315,33 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const void *__re
         __builtin_amdgcn_s_setprio(1);
         dit_back(u, lds, j, tw3);
         // time sample i = j + 256 bin_of(q) >= B of the block is output bB + i - B; outputs past n_out fall to the range check
-        if (REAL) {
+        if (DECIM) {
+            // full-rate output n = o + t of the block (of either half of a real pair: `half` is a multiple of M) is kept when
+            // (n + 1) % M == 0, at (n + 1) / M - 1; everything else gets an offset outside the descriptor, no branch
+            const size_t o = b * kHop, B0 = o / M;
+            const unsigned base = (unsigned)(o - B0 * M);
+            constexpr size_t kMost = kHop / 2 + 2;             // outputs a block can keep (M >= 2)
+            constexpr int EB = REAL ? 4 : 8;
+            const size_t lim_a = REAL ? half : n_out, dec_a = REAL ? half / M : n_dec;
+            const size_t left_a = lim_a > o ? lim_a - o : 0, room_a = dec_a > B0 ? dec_a - B0 : 0;
+            const __amdgpu_buffer_rsrc_t wa = make_rsrc(static_cast<unsigned char *>(out_) + B0 * EB, (unsigned)((room_a < kMost ? room_a : kMost) * EB));
+            const size_t left_b = REAL && n_out > half + o ? n_out - half - o : 0, B0b = half / M + B0, room_b = REAL && n_dec > B0b ? n_dec - B0b : 0;
+            const __amdgpu_buffer_rsrc_t wb = make_rsrc(static_cast<unsigned char *>(out_) + (room_b ? B0b * EB : 0), (unsigned)((room_b < kMost ? room_b : kMost) * EB));
+#pragma unroll
+            for (int qq = 0; qq < 16; qq++) {
+                const int row = bin_of(qq);
+                if (row < 8) continue;
+                const unsigned t = (unsigned)(j + 256 * (row - 8)), tt = base + t + 1u, qt = __umulhi(tt, magic);
+                const bool hit = qt * M == tt;
+                const int at = (int)((qt - 1u) * (unsigned)EB);
+                if (REAL) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[qq].x), wa, hit && t < left_a ? at : 0x7ffffff0, 0, kAuxStream);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u[qq].y), wb, hit && t < left_b ? at : 0x7ffffff0, 0, kAuxStream);
+                } else {
+                    store_cf<kAuxStream>(wa, (unsigned)(hit && t < left_a ? at : 0x7ffffff0), u[qq]);
+                }
+            }
+        } else if (REAL) {
             const size_t o = b * kHop, na = half - o, nb = n_out - half > o ? n_out - half - o : 0;       // (o < half: nblocks covers the first half)
             const __amdgpu_buffer_rsrc_t wa = make_rsrc(outr + o, (unsigned)((na < (size_t)kHop ? na : (size_t)kHop) * 4));
             const __amdgpu_buffer_rsrc_t wb = make_rsrc(outr + (nb ? half + o : 0), (unsigned)((nb < (size_t)kHop ? nb : (size_t)kHop) * 4));
@@ -335,22 +374,30 @@ __global__ __launch_bounds__(256, 2) void fir_cf32_upols_kernel(const void *__re
     }
 }
 
-template <int P, bool KEEP, bool HREG, int BP, bool REAL>
-int launch_parts(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, const void *tw, hipStream_t st)
+template <int P, bool KEEP, bool HREG, int BP, bool REAL, bool DECIM>
+int launch_parts(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, const void *tw, size_t M, hipStream_t st)
 {
-    // REAL: the first `half` outputs (a multiple of 32: whole 128-byte lines for the second half's rows) beside the rest
-    const size_t half = REAL ? std::min(n_out, ((n_out + 1) / 2 + 31) / 32 * 32) : 0;
+    // REAL: the first `half` outputs beside the rest -- a multiple of 32 (whole 128-byte lines for the second half's rows) and of M
+    // (both halves keep the same phase of the decimator)
+    size_t half = 0;
+    if (REAL) {
+        size_t q = 32;
+        if (DECIM) { size_t a = M, b = 32; while (b) { const size_t t = a % b; a = b; b = t; } q = M / a * 32; }
+        half = std::min(n_out, ((n_out + 1) / 2 + q - 1) / q * q);
+    }
     const size_t nblocks = ((REAL ? half : n_out) + kHop - 1) / kHop;
     // a run pays P - 1 forward transforms before its first output: runs of at least 4 (P - 1) blocks while the call has them
     const long oversub = PCX_ENV_INT("PCX_UPOLS_OVERSUB", 1);      // (diagnostic library: workgroups queued per slot, A/B)
     const unsigned slots = 256u * 2u * (unsigned)(oversub > 0 ? oversub : 1);      // two workgroups per CU
     const size_t cap = g_link_grid ? (size_t)g_link_grid : (size_t)slots;
-    const size_t min_run = 4 * (size_t)(P - 1);
+    const size_t min_run = P > 1 ? 4 * (size_t)(P - 1) : 1;
     size_t grid = (nblocks + min_run - 1) / min_run;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((fir_cf32_upols_kernel<P, KEEP, HREG, BP, REAL>), dim3((unsigned)grid), dim3(256), 0, st, in, in_elems, out, n_out,
-                       (const unsigned char *)Hparts, (long long)(K - 1) - kHop, (const float2 *)tw, nblocks, half);
+    const unsigned magic = DECIM ? (unsigned)(((1ull << 32) + M - 1) / M) : 0u;
+    hipLaunchKernelGGL((fir_cf32_upols_kernel<P, KEEP, HREG, BP, REAL, DECIM>), dim3((unsigned)grid), dim3(256), 0, st, in, in_elems, out, n_out,
+                       (const unsigned char *)Hparts, (long long)(K - 1) - kHop, (const float2 *)tw, nblocks, half, n_out / (DECIM ? M : 1),
+                       (unsigned)M, magic);
     PCX_LAUNCH_CHECK();
     return PCX_OK;
 }
@@ -359,42 +406,57 @@ int launch_parts(const void *in, size_t in_elems, void *out, size_t n_out, const
 
 size_t fir_upols_table_bytes(int parts)
 {
-    return parts == 2 ? HTable<2>::kBytes : parts == 3 ? HTable<3>::kBytes : parts == 4 ? HTable<4>::kBytes : 0;
+    return parts == 1 ? HTable<1>::kBytes : parts == 2 ? HTable<2>::kBytes : parts == 3 ? HTable<3>::kBytes : parts == 4 ? HTable<4>::kBytes : 0;
 }
 
-// parts = ceil((K - 1) / 2048) in 2 .. 4; Hparts = the partitions' spectra (pcx_tables.hpp make_hparts), tw = make_tw4096();
-// real_stream: float32 samples and outputs (real taps), else complex_float32
+// parts = ceil((K - 1) / 2048) in 2 .. 4 (1, K <= 2049: real decimating filters only); Hparts = the partitions' spectra
+// (pcx_tables.hpp make_hparts), tw = make_tw4096();
+// real_stream: float32 samples and outputs (real taps), else complex_float32; M > 1: n_out full-rate outputs (a multiple of M), one in
+// M stored
 int launch_fir_cf32_upols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, int parts, const void *tw,
-                          hipStream_t st, bool real_stream)
+                          hipStream_t st, bool real_stream, size_t M)
 {
     if (n_out == 0) return PCX_OK;
-    if (K < 2050 || (K - 1 + kHop - 1) / kHop != (size_t)parts) { set_error("fir partitioned ols: K=%zu does not make %d partitions", K, parts); return PCX_ERR_UNSUPPORTED; }
+    if (K < 1 || std::max<size_t>(1, (K - 1 + kHop - 1) / kHop) != (size_t)parts) { set_error("fir partitioned ols: K=%zu does not make %d partitions", K, parts); return PCX_ERR_UNSUPPORTED; }
+    if (M < 1 || M > 65535) { set_error("fir partitioned ols: decimation %zu outside 1 .. 65535", M); return PCX_ERR_UNSUPPORTED; }
     const int variant = (int)PCX_ENV_INT("PCX_UPOLS_VARIANT", 0);   // (diagnostic library: A/B)
-#define PCX_UPOLS(P, KEEP, HREG, BP)                                                                                            \
-    do {                                                                                                                        \
-        if (real_stream) return launch_parts<P, KEEP, HREG, BP, true>(in, in_elems, out, n_out, Hparts, K, tw, st);             \
-        return launch_parts<P, KEEP, HREG, BP, false>(in, in_elems, out, n_out, Hparts, K, tw, st);                             \
+#define PCX_UPOLS(P, KEEP, HREG, BP)                                                                                                  \
+    do {                                                                                                                              \
+        if (real_stream && M > 1) return launch_parts<P, KEEP, HREG, BP, true, true>(in, in_elems, out, n_out, Hparts, K, tw, M, st);   \
+        if (real_stream) return launch_parts<P, KEEP, HREG, BP, true, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);           \
+        if (M > 1) return launch_parts<P, KEEP, HREG, BP, false, true>(in, in_elems, out, n_out, Hparts, K, tw, M, st);                 \
+        return launch_parts<P, KEEP, HREG, BP, false, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);                           \
     } while (0)
+    const bool plain = !real_stream && M == 1;
     switch (parts) {
+    case 1:
+        // one partition = plain overlap-save advancing by 2048 whatever K <= 2049: kept for what has no better kernel -- REAL
+        // decimating filters (two halves per transform, one output in M stored: twice the double-precision pipeline they ran on)
+        if (real_stream && M > 1) return launch_parts<1, true, true, 8, true, true>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
+        break;
     case 2:
 #ifdef PCX_DIAG
-        if (variant == 1 && !real_stream) return launch_parts<2, true, false, 4, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
-        if (variant == 2 && !real_stream) return launch_parts<2, false, true, 8, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
+        if (variant == 1 && plain) return launch_parts<2, true, false, 4, false, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
+        if (variant == 2 && plain) return launch_parts<2, false, true, 8, false, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
 #endif
         PCX_UPOLS(2, true, true, 8);
     case 3:
 #ifdef PCX_DIAG
-        if (variant == 1 && !real_stream) return launch_parts<3, true, false, 1, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
+        if (variant == 1 && plain) return launch_parts<3, true, false, 1, false, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
 #endif
         PCX_UPOLS(3, true, false, 2);
     case 4:
 #ifdef PCX_DIAG
-        if (variant == 1 && !real_stream) return launch_parts<4, false, false, 2, false>(in, in_elems, out, n_out, Hparts, K, tw, st);
+        if (variant == 1 && plain) return launch_parts<4, false, false, 2, false, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
 #endif
-        PCX_UPOLS(4, true, false, 1);
+        // (decimating: the store's index arithmetic does not fit beside the kept half window in 256 registers; whole windows fetched)
+        if (real_stream && M > 1) return launch_parts<4, false, false, 1, true, true>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
+        if (M > 1) return launch_parts<4, false, false, 1, false, true>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
+        if (real_stream) return launch_parts<4, true, false, 1, true, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
+        return launch_parts<4, true, false, 1, false, false>(in, in_elems, out, n_out, Hparts, K, tw, M, st);
     }
 #undef PCX_UPOLS
-    (void)variant;
+    (void)variant; (void)plain;
     set_error("fir partitioned ols: no kernel for %d partitions", parts);
     return PCX_ERR_UNSUPPORTED;
 }

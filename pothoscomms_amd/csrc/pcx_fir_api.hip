@@ -30,6 +30,7 @@ struct pcx_fir {
     bool have_interp = false; // M = 1, L in {2,4,8,16}: replicated spectrum of the short forward transform (Hdecim holds H of all taps)
     DevBuf Hdecim;
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
+    bool have_upols_decim = false; // complex_float32 / float32, L = 1, M > 1, 2049 < K <= 8193: the partitioned kernel with a decimating store
     bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
     bool have_ols_int = false;    // complex_int16 / complex_int8 stream, M=L=1: exact integer convolution on the double transform
     bool have_ols_real64 = false; // REAL float64 / int16 / int8 stream (real taps), M=L=1: two real blocks per double transform
@@ -269,7 +270,8 @@ static int fir_sync_tables(pcx_fir *h)
     }
     h->have_ols_real64 = false;
     // (real float32 joins for decimating filters only: its undecimated stream has the float kernel below)
-    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8 || (h->scalar == PCX_F32 && h->M > 1)) && !h->cplx && h->M <= 65535 &&
+    // (decimating real float32 filters take the partitioned float kernel, have_upols_decim below)
+    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M <= 65535 &&
         h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
             std::vector<std::complex<double>> hq(h->K);
         double norm2 = 0;
@@ -297,6 +299,20 @@ static int fir_sync_tables(pcx_fir *h)
         else PCX_TRY(upload(h->Hspec, make_hparts(hq, h->ols_parts)));
         PCX_TRY(upload(h->tw4096, make_tw4096()));
         h->have_real_ols = true;
+    }
+    h->have_upols_decim = false;
+    if (h->scalar == PCX_F32 && h->L == 1 && h->M > 1 && h->M <= 65535 && h->K <= kOlsMaxTaps && (h->K > 2049 || (!h->cplx && h->K >= 2))) {
+        // long DECIMATING filters, complex_float32 or float32: the partitioned kernel at the full rate, one output in M stored
+        // (fir_ols_part.hip) -- the time-domain tile they fell to runs at 1-2 Gsamples/s of input at these tap counts.  REAL float32
+        // decimators of any length take it as well (one partition up to 2049 taps): 300 against the 155 Gsamples/s of the
+        // double-precision pipeline they shared with the integer types
+        std::vector<std::complex<double>> hq(h->K);
+        for (size_t k = 0; k < h->K; k++)
+            hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * k] : h->taps[k]), h->ctaps ? (double)(float)h->taps[2 * k + 1] : 0.0);
+        h->ols_parts = std::max(1, fir_ols_partitions(h->K));
+        PCX_TRY(upload(h->Hspec, make_hparts(hq, h->ols_parts)));
+        PCX_TRY(upload(h->tw4096, make_tw4096()));
+        h->have_upols_decim = true;
     }
     h->have_poly = false;
     if (h->scalar == PCX_F32 && h->cplx && (h->L > 1 || h->M > 1) && h->K <= 2049 && h->L <= 64 && h->M < (1u << 17)) {
@@ -514,7 +530,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         // decimating complex_float64 / complex_int16 / complex_int8 filters: the full-rate double pipeline with one output in M
         // stored runs at 130-170 Gsamples/s of input whatever K; the one-output-per-lane kernel it replaces measured 45-129
         // (int16) / 27-31 (float64) at 63 taps and 12-33 / 6-8 at 255 (tools/decim_int_probe.py)
-        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) ||
+        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_upols_decim && h->K >= 16) ||
                  (h->have_ols64 && h->K >= (h->M > 1 ? 16 : kOls64MinTaps)) ||
                  (h->have_ols_int && h->K >= (h->M > 1 ? 32 : ols_int_min_taps(h->scalar))) ||
                  (h->have_ols_real64 && h->K >= (h->M > 1 ? 16 : ols_real64_min_taps(h->scalar))) ||
@@ -524,9 +540,9 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
-    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_ols64 || h->have_ols_int || h->have_ols_real64 ||
+    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_upols_decim || h->have_ols64 || h->have_ols_int || h->have_ols_real64 ||
                                      h->have_interp64 || h->have_interp_real)) {
-        set_error("fir: OLS_FFT needs complex_float32 or float32 and K<=8193 (resampling: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
+        set_error("fir: OLS_FFT needs complex_float32 or float32 and K<=8193 (interpolating: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
@@ -577,6 +593,8 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     } else if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
         rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, h->M, qs, st, h->sched.p);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_upols_decim) {
+        rc = launch_fir_cf32_upols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_parts, h->tw4096.p, st, !h->cplx, h->M);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols && h->ols_parts != 0) {
         rc = launch_fir_cf32_upols(in_dev, used_in, out_dev, n_out, h->Hspec.p, h->K, h->ols_parts, h->tw4096.p, st, true);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols) {

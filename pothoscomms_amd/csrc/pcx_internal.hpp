@@ -253,9 +253,9 @@ size_t fir_decim_fold_factor(size_t M);
 int launch_fir_cf32_ols4096_decim(const void *in, size_t in_elems, void *out, size_t n_iter, const void *Hspec, size_t K, size_t M,
                                   const void *tw4096, void *sched, hipStream_t st);
 // (fir_ols_part.hip) 2049 < K <= 8193: 4096-sample blocks, the taps in `parts` = ceil((K - 1) / 2048) partitions; complex_float32, or
-// (real_stream) float32 with real taps
+// (real_stream) float32 with real taps; M > 1: a decimating filter (n_out full-rate outputs, one in M stored)
 int launch_fir_cf32_upols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hparts, size_t K, int parts, const void *tw,
-                          hipStream_t st, bool real_stream = false);
+                          hipStream_t st, bool real_stream = false, size_t M = 1);
 size_t fir_upols_table_bytes(int parts);
 int launch_fir_cf64_ols(const void *in, size_t in_elems, void *out, size_t n_out, const void *Hspec, size_t K, int log2n,
                         const void *tw, int io, size_t M, QShift qs, hipStream_t st, void *sched = nullptr);

@@ -383,7 +383,7 @@ def test_fir_writes_only_its_outputs_and_reads_only_its_inputs(oracle, dev, seed
     nan = float("nan")
     geoms = [(1, 1), (1, 1), (1, 2), (1, 8), (2, 1), (4, 1), (3, 1), (3, 2), (1, 1), (1, 5)]
     L, M = geoms[seed % len(geoms)]
-    ntaps = int(rng.choice([2, 17, 63, 255, 1000, 3000, 5000, 8193])) if (L, M) == (1, 1) else int(rng.choice([8, 63, 255])) * L
+    ntaps = int(rng.choice([2, 17, 63, 255, 1000, 3000, 5000, 8193])) if L == 1 else int(rng.choice([8, 63, 255])) * L   # (L = 1, M > 1 beyond 2049 taps: the partitioned kernel's decimating store)
     algo = [_lib.FIR_AUTO, _lib.FIR_OLS_FFT, _lib.FIR_DIRECT, _lib.FIR_EXACT][seed % 4] if (L, M) == (1, 1) else _lib.FIR_AUTO
     h = (rng.normal(size=ntaps) + 1j * rng.normal(size=ntaps)) / ntaps
     f = dev.FirFilter("complex_float32", "COMPLEX")
@@ -410,8 +410,8 @@ def test_fir_writes_only_its_outputs_and_reads_only_its_inputs(oracle, dev, seed
 
 @pytest.mark.parametrize("seed", GSEEDS)
 def test_real_fir_writes_only_its_outputs_and_reads_only_its_inputs(oracle, dev, seed):
-    """real float32 streams: the two-blocks-per-transform kernel and, beyond 2049 taps, the call's two halves side by side through the
-    partitioned kernel (the second half reads at an offset of half the outputs: whatever lies behind the input must stay unread).
+    """real float32 streams: the two-blocks-per-transform kernel and, beyond 2049 taps or decimating, the call's two halves side by side
+    through the partitioned kernel (the second half reads at an offset of half the outputs: whatever lies behind the input must stay unread).
     NaN guard bands around input and output; tiny, odd and large calls."""
     import torch
     from pothoscomms_amd import _lib
@@ -419,28 +419,29 @@ def test_real_fir_writes_only_its_outputs_and_reads_only_its_inputs(oracle, dev,
     rng = np.random.default_rng(9700 + seed)
     nan = float("nan")
     ntaps = int(rng.choice([2, 63, 255, 2049, 2050, 3000, 4097, 5000, 8193]))
+    M = int(rng.choice([1, 1, 2, 7, 64, 1000]))
     h = rng.normal(size=ntaps) / np.sqrt(ntaps)
     f = dev.FirFilter("float32", "REAL")
-    f.set_taps(h)
-    n_out = int(rng.choice([1, 2, 31, 33, 2047, 2049, int(rng.integers(1, 60000))]))
-    n_in = n_out + ntaps - 1
+    f.set_taps(h); f.set_decimation(M)
+    n_out = int(rng.choice([1, 2, 31, 33, 2047, 2049, int(rng.integers(1, 60000 // M + 2))]))
+    n_in = n_out * M + ntaps - 1
     xw, x = _guarded(torch, d, n_in, 1, torch.float32, nan)
     yw, y = _guarded(torch, d, n_out, 1, torch.float32, nan)
     xh = rng.uniform(-1, 1, n_in).astype(np.float32)
     x.copy_(torch.from_numpy(xh).to(d))
     c, p = f.process_dev(x, y, n_in, n_out)
     torch.cuda.synchronize()
-    assert (c, p) == (n_out, n_out)
-    assert f.last_algo == _lib.FIR_OLS_FFT
-    assert _bands_intact(yw, n_out, 1, nan), (ntaps, n_out)
+    assert (c, p) == (n_out * M, n_out)
+    assert f.last_algo == _lib.FIR_OLS_FFT or (M > 1 and ntaps < 16)
+    assert _bands_intact(yw, n_out, 1, nan), (ntaps, n_out, M)
     got = y.cpu().numpy()
     assert np.isfinite(got).all(), (ntaps, n_out)             # no NaN from beyond the input window
     blk = oracle.Fir(oracle.F32, False, False)
-    blk.set_taps(h); blk.activate()
+    blk.set_taps(h); blk.set_decimation(M); blk.activate()
     ref, rc, rp, _ = blk.work(xh, n_out)
     assert (rc, rp) == (c, p)
     typical = float(np.sqrt(np.sum(h ** 2)) * np.sqrt(np.mean(xh.astype(np.float64) ** 2)))
-    assert float(np.abs(got - ref).max()) <= TOL * max(float(np.abs(ref).max()), 0.1 * typical) * (3.0 if ntaps > 2049 else 1.0), (ntaps, n_out)
+    assert float(np.abs(got - ref).max()) <= TOL * max(float(np.abs(ref).max()), 0.1 * typical) * (3.0 if ntaps > 2049 else 1.0), (ntaps, n_out, M)
 
 
 @pytest.mark.parametrize("seed", GSEEDS)

@@ -547,6 +547,39 @@ def test_fir_cf32_interpolating_replicated_spectrum(oracle, dev, ntaps, L, ctaps
             assert (gc2, gp2) == (rc2, rp2) and nerr(got2, ref2) <= TOL, (ntaps, L, n, cap)
 
 
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("M", [2, 3, 8, 64, 1000])
+@pytest.mark.parametrize("ntaps", [2050, 3000, 4097, 4098, 6145, 8193])
+def test_fir_f32_long_decimating_filters(oracle, dev, ntaps, M, cplx):
+    """complex_float32 / float32, decimation M, more than 2049 taps: the partitioned kernel at the full rate with a decimating store
+    (fir_ols_part.hip; a real pair's halves split at a multiple of M).  Same kept outputs and consume / produce counts as the
+    reference's loop (FIRFilter.cpp:286-302: the output with (n + 1) % M == 0); a short output buffer limits the iterations."""
+    rng = np.random.default_rng(23 * ntaps + M + cplx)
+    ctaps = cplx and bool(M % 2)
+    taps = _taps(rng, ntaps, ctaps)
+    for n in (ntaps + M - 1, ntaps + 5 * M + 3, ntaps + 2048 * 3 + 77, ntaps + 2048 * 11 + 5 * M + 1):
+        x = rand_stream(rng, oracle.F32, n, cplx)
+        ref_blk = oracle.Fir(oracle.F32, cplx, ctaps)
+        ref_blk.set_taps(taps); ref_blk.set_decimation(M); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n)
+        f = dev.FirFilter((oracle.F32, cplx), "COMPLEX" if ctaps else "REAL")
+        f.set_taps(taps); f.set_decimation(M)
+        got, gc, gp = f.process(x, n)
+        assert (gc, gp) == (rc, rp), (ntaps, M, n)
+        if rp:
+            assert f.last_algo == dev._lib.FIR_OLS_FFT
+            typical = float(np.sqrt(np.sum(np.abs(taps) ** 2)) * np.sqrt(np.mean(x.astype(np.float64) ** 2) * (2 if cplx else 1)))
+            assert float(np.abs(got - ref).max()) <= 2 * TOL * max(float(np.abs(ref).max()), 0.1 * typical), (ntaps, M, n)
+        cap = rp // 2
+        if cap:
+            ref_blk2 = oracle.Fir(oracle.F32, cplx, ctaps)
+            ref_blk2.set_taps(taps); ref_blk2.set_decimation(M); ref_blk2.activate()
+            ref2, rc2, rp2, _ = ref_blk2.work(x, cap)
+            got2, gc2, gp2 = f.process(x, cap)
+            assert (gc2, gp2) == (rc2, rp2), (ntaps, M, n, cap)
+            assert float(np.abs(got2 - ref2).max()) <= 2 * TOL * max(float(np.abs(ref2).max()), 0.1 * typical), (ntaps, M, n, cap)
+
+
 @pytest.mark.parametrize("scalar_name", ["float64", "int16", "int8"])
 @pytest.mark.parametrize("M", [2, 3, 5, 8, 16, 100])
 @pytest.mark.parametrize("ntaps", [2, 31, 32, 255, 2049, 4097])
@@ -581,7 +614,7 @@ def test_fir_complex_decimating_on_the_double_pipeline(oracle, dev, ntaps, M, sc
 @pytest.mark.parametrize("scalar_name", ["float64", "float32", "int16", "int8"])
 @pytest.mark.parametrize("M", [2, 3, 7, 16, 100])
 @pytest.mark.parametrize("ntaps", [2, 15, 16, 255, 2049, 4097])
-def test_fir_real_decimating_on_the_double_pipeline(oracle, dev, ntaps, M, scalar_name):
+def test_fir_real_decimating_on_the_double_pipeline(oracle, dev, ntaps, M, scalar_name):   # (float32: the partitioned float kernel since late round 6)
     """REAL float64 / float32 / int16 / int8 streams with decimation M: two real blocks per double-precision transform at
     full rate, one output in M stored.  Integers bit-exact, float64 1e-13, float32 1e-5; counts as the reference."""
     scalar = {"float64": oracle.F64, "float32": oracle.F32, "int16": oracle.I16, "int8": oracle.I8}[scalar_name]

@@ -144,3 +144,15 @@ def test_the_committed_default_line_carries_every_single_gpu_config_and_the_host
         a, b = hp["calls"][size]["pinned_port_buffers"], hp["calls"][size]["circular_input_page_locked_in_place"]
         assert b["Msamples_per_s"] > 0.9 * a["Msamples_per_s"]             # the framework's circular buffer, locked where it lies, is as fast as the module's own slabs
     assert hp["cpu_baseline"]["kind"] == "port"
+
+
+def test_the_pmc_stamps_are_of_this_tree():
+    """profiles/traffic.json names, per workload, the source files its PMC pass measured (tools/collect_profiles.py); bench.py reports
+    `roofline.traffic` only while they still hash to that.  A kernel edited without its profile re-taken would ship a line without it."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    stale = [(wl, f) for wl, e in t.items() for f, h in e["sources"].items()
+             if hashlib.sha256(open(os.path.join(root, f), "rb").read()).hexdigest()[:16] != h]
+    assert not stale, "re-take: bash tools/prof.sh <workload> gpurun_out/x/<workload> <kernel>; python tools/collect_profiles.py gpurun_out/x profiles/r06 -- %s" % stale
+

@@ -205,7 +205,7 @@ typedef enum pcx_fir_algo {
     PCX_FIR_DIRECT = 1,  /* time-domain LDS-tiled dot product (FMA) */
     PCX_FIR_OLS_FFT = 2, /* frequency-domain overlap-save on 4096-sample blocks: complex_float32 (K <= 8193 -- beyond
                             2049 taps the taps in partitions of 2048 against the previous windows' spectra, decimating
-                            filters as well; interpolating K <= 2049 per row), real float32 (K <= 8193, likewise; L = 1),
+                            and interpolating filters as well, K per polyphase row), real float32 (K <= 8193, likewise),
                             complex_float64 and M = L = 1 (K <= 4097), complex_int16 / complex_int8 and real float64 / int16 / int8 with
                             M = L = 1 (K <= 4097; integers bit-exact: the rounded double-precision sums are the integer
                             convolution); anything else -> PCX_ERR_UNSUPPORTED */

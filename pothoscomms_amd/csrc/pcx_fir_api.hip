@@ -30,6 +30,7 @@ struct pcx_fir {
     bool have_interp = false; // M = 1, L in {2,4,8,16}: replicated spectrum of the short forward transform (Hdecim holds H of all taps)
     DevBuf Hdecim;
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
+    bool have_upols_rows = false;  // complex_float32 / float32, L > 1, polyphase rows of 2050 .. 8193 taps: the partitioned kernel row by row + interleave
     bool have_upols_decim = false; // complex_float32 / float32, L = 1, M > 1, 2049 < K <= 8193: the partitioned kernel with a decimating store
     bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
     bool have_ols_int = false;    // complex_int16 / complex_int8 stream, M=L=1: exact integer convolution on the double transform
@@ -314,6 +315,29 @@ static int fir_sync_tables(pcx_fir *h)
         PCX_TRY(upload(h->tw4096, make_tw4096()));
         h->have_upols_decim = true;
     }
+    h->have_upols_rows = false;
+    if (h->scalar == PCX_F32 && h->L > 1 && h->L <= 64 && h->M <= 65535 && h->K > 2049 && h->K <= kOlsMaxTaps) {
+        // INTERPOLATING filters whose polyphase rows h_j[k] = taps[j + k L] (FIRFilter.cpp:341-350) are longer than 2049 taps: every row
+        // through the partitioned kernel at the input rate into a workspace row, then the interleaving pass (which also keeps one
+        // position in M) -- as the shorter rows go through fir_ols.hip.  A row the tap vector leaves short ends in zeros.
+        const int parts = fir_ols_partitions(h->K);
+        const size_t tb = fir_upols_table_bytes(parts) / sizeof(float);
+        std::vector<float> rows(h->L * tb);
+        for (size_t jr = 0; jr < h->L; jr++) {
+            std::vector<std::complex<double>> hq(h->K, 0.0);
+            for (size_t k = 0; k < h->K; k++) {
+                const size_t i = jr + k * h->L;
+                if (i >= h->ntaps) break;
+                hq[k] = std::complex<double>((double)(float)(h->ctaps ? h->taps[2 * i] : h->taps[i]), h->ctaps ? (double)(float)h->taps[2 * i + 1] : 0.0);
+            }
+            const std::vector<float> T = make_hparts(hq, parts);
+            std::copy(T.begin(), T.end(), rows.begin() + jr * tb);
+        }
+        h->ols_parts = parts;
+        PCX_TRY(upload(h->HspecRows, rows));
+        PCX_TRY(upload(h->tw4096, make_tw4096()));
+        h->have_upols_rows = true;
+    }
     h->have_poly = false;
     if (h->scalar == PCX_F32 && h->cplx && (h->L > 1 || h->M > 1) && h->K <= 2049 && h->L <= 64 && h->M < (1u << 17)) {
         // one spectrum per polyphase row: h_j[k] = taps[j + k*L] (FIRFilter.cpp:341-350)
@@ -530,7 +554,7 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         // decimating complex_float64 / complex_int16 / complex_int8 filters: the full-rate double pipeline with one output in M
         // stored runs at 130-170 Gsamples/s of input whatever K; the one-output-per-lane kernel it replaces measured 45-129
         // (int16) / 27-31 (float64) at 63 taps and 12-33 / 6-8 at 255 (tools/decim_int_probe.py)
-        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_upols_decim && h->K >= 16) ||
+        else if ((fast && h->have_ols) || h->have_poly || (h->have_real_ols && h->K > 1) || (h->have_upols_decim && h->K >= 16) || h->have_upols_rows ||
                  (h->have_ols64 && h->K >= (h->M > 1 ? 16 : kOls64MinTaps)) ||
                  (h->have_ols_int && h->K >= (h->M > 1 ? 32 : ols_int_min_taps(h->scalar))) ||
                  (h->have_ols_real64 && h->K >= (h->M > 1 ? 16 : ols_real64_min_taps(h->scalar))) ||
@@ -540,9 +564,9 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
-    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_upols_decim || h->have_ols64 || h->have_ols_int || h->have_ols_real64 ||
+    if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_upols_decim || h->have_upols_rows || h->have_ols64 || h->have_ols_int || h->have_ols_real64 ||
                                      h->have_interp64 || h->have_interp_real)) {
-        set_error("fir: OLS_FFT needs complex_float32 or float32 and K<=8193 (interpolating: K<=2049, L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
+        set_error("fir: OLS_FFT needs complex_float32 or float32 and K<=8193 (interpolating: L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
     int rc;
@@ -593,6 +617,12 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
     } else if (algo == PCX_FIR_OLS_FFT && (h->have_ols64 || h->have_ols_int)) {
         rc = launch_fir_cf64_ols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_log2n, h->tw4096.p,
                                  h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : 2, h->M, qs, st, h->sched.p);
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_upols_rows) {
+        const size_t tb = fir_upols_table_bytes(h->ols_parts);
+        rc = rows_path(fir_elem_bytes(h), h->M, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
+            return launch_fir_cf32_upols(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HspecRows.p) + jr * tb, h->K, h->ols_parts, h->tw4096.p, st,
+                                         !h->cplx, 1);
+        });
     } else if (algo == PCX_FIR_OLS_FFT && h->have_upols_decim) {
         rc = launch_fir_cf32_upols(in_dev, used_in, out_dev, N, h->Hspec.p, h->K, h->ols_parts, h->tw4096.p, st, !h->cplx, h->M);
     } else if (algo == PCX_FIR_OLS_FFT && h->have_real_ols && h->ols_parts != 0) {

@@ -548,6 +548,32 @@ def test_fir_cf32_interpolating_replicated_spectrum(oracle, dev, ntaps, L, ctaps
 
 
 @pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("L,M", [(2, 1), (3, 1), (5, 3), (2, 3), (16, 1)])
+@pytest.mark.parametrize("rowK", [2050, 4097, 5000, 8193])
+def test_fir_f32_interpolating_with_long_rows(oracle, dev, rowK, L, M, cplx):
+    """complex_float32 / float32, interpolation L (and decimation M) with polyphase rows of more than 2049 taps: every row through the
+    partitioned kernel, then the interleaving pass.  Tap counts that leave the last rows one tap short; the reference's counts."""
+    rng = np.random.default_rng(31 * rowK + 7 * L + M + cplx)
+    ntaps = rowK * L - (L // 2)                                  # rows 0 .. L - L//2 - 1 have rowK taps, the others one fewer
+    ctaps = cplx and bool(L % 2)
+    taps = _taps(rng, ntaps, ctaps)
+    for n in (rowK + M - 1, rowK + 4 * M + 2, rowK + 2048 * 2 + 77 * M):
+        x = rand_stream(rng, oracle.F32, n, cplx)
+        ref_blk = oracle.Fir(oracle.F32, cplx, ctaps)
+        ref_blk.set_taps(taps); ref_blk.set_interpolation(L); ref_blk.set_decimation(M); ref_blk.activate()
+        ref, rc, rp, _ = ref_blk.work(x, n * L)
+        f = dev.FirFilter((oracle.F32, cplx), "COMPLEX" if ctaps else "REAL")
+        f.set_taps(taps); f.set_interpolation(L); f.set_decimation(M)
+        assert f.K == rowK
+        got, gc, gp = f.process(x, n * L)
+        assert (gc, gp) == (rc, rp), (rowK, L, M, n)
+        if rp:
+            assert f.last_algo == dev._lib.FIR_OLS_FFT
+            typical = float(np.sqrt(np.sum(np.abs(taps) ** 2) / L) * np.sqrt(np.mean(x.astype(np.float64) ** 2) * (2 if cplx else 1)))
+            assert float(np.abs(got - ref).max()) <= 2 * TOL * max(float(np.abs(ref).max()), 0.1 * typical), (rowK, L, M, n)
+
+
+@pytest.mark.parametrize("cplx", [True, False])
 @pytest.mark.parametrize("M", [2, 3, 8, 64, 1000])
 @pytest.mark.parametrize("ntaps", [2050, 3000, 4097, 4098, 6145, 8193])
 def test_fir_f32_long_decimating_filters(oracle, dev, ntaps, M, cplx):

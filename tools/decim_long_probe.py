@@ -6,11 +6,11 @@ from pothoscomms_amd import _lib, device, taps as tp
 d = torch.device("cuda", 0)
 n = 16 << 20
 for dtype, cplx in (("complex_float32", True), ("float32", False)):
-    for K, M, L in ((4097, 8, 1), (4097, 64, 1), (8193, 16, 1), (2049, 8, 1), (4097, 1, 4), (8193, 1, 8)):
+    for K, M, L in ((4097, 8, 1), (4097, 64, 1), (8193, 16, 1), (2049, 8, 1), (4097, 1, 4), (8193, 1, 8), (8193, 1, 2), (16385, 1, 4), (8193, 3, 2)):
         h = tp.complex_bandpass(K, 0.4 / max(M, L), 0.02) if cplx else tp.lowpass(K, 0.4 / max(M, L))
         f = device.FirFilter(dtype, "COMPLEX" if cplx else "REAL"); f.set_taps(h); f.set_decimation(M); f.set_interpolation(L)
         Kr = f.K
-        nin = n // L
+        nin = n // L // M * M
         shape = (nin + Kr - 1, 2) if cplx else (nin + Kr - 1,)
         x = torch.randn(shape, device=d)
         no = nin // M * L

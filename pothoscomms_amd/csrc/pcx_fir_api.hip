@@ -30,6 +30,7 @@ struct pcx_fir {
     bool have_interp = false; // M = 1, L in {2,4,8,16}: replicated spectrum of the short forward transform (Hdecim holds H of all taps)
     DevBuf Hdecim;
     bool have_real_ols = false;   // real float32 stream, real taps, M=L=1
+    bool have_interp_f32 = false;  // REAL float32, L > 1, rows of up to 2049 taps: the real float kernel row by row + interleave
     bool have_upols_rows = false;  // complex_float32 / float32, L > 1, polyphase rows of 2050 .. 8193 taps: the partitioned kernel row by row + interleave
     bool have_upols_decim = false; // complex_float32 / float32, L = 1, M > 1, 2049 < K <= 8193: the partitioned kernel with a decimating store
     bool have_ols64 = false;      // complex_float64 stream, M=L=1 (Hspec / tw4096 then hold doubles)
@@ -239,7 +240,8 @@ static int fir_sync_tables(pcx_fir *h)
         }
     }
     h->have_interp_real = false;
-    if ((h->scalar == PCX_F64 || h->scalar == PCX_F32 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M <= 65535 && h->L > 1 &&
+    // (real float32 has the float kernel for its rows: have_interp_f32 below)
+    if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M <= 65535 && h->L > 1 &&
         h->L <= 64 && h->K >= 2 && h->K <= 2049) {
             auto tq = [&](double t) {
             return h->scalar == PCX_F64 ? t : h->scalar == PCX_F32 ? (double)(float)t
@@ -269,9 +271,29 @@ static int fir_sync_tables(pcx_fir *h)
             h->have_interp_real = true;
         }
     }
+    h->have_interp_f32 = false;
+    if (h->scalar == PCX_F32 && !h->cplx && h->M <= 65535 && h->L > 1 && h->L <= 64 && h->K >= 2 && h->K <= 2049) {
+        // interpolating REAL float32 filters: every polyphase row through the real float kernel (two real blocks per complex transform,
+        // fir_ols.hip) into a workspace row, then the interleaving pass -- instead of the double-precision rows they had shared with
+        // the integer types
+        std::vector<float> rows(h->L * 2 * 4096);
+        for (size_t jr = 0; jr < h->L; jr++) {
+            std::vector<std::complex<double>> hq;
+            for (size_t k = 0; k < h->K; k++) {
+                const size_t i = jr + k * h->L;
+                if (i >= h->ntaps) continue;
+                hq.push_back(std::complex<double>((double)(float)h->taps[i], 0.0));
+            }
+            if (hq.empty()) hq.push_back(0.0);
+            const std::vector<float> H = make_hspec4096(hq);
+            std::copy(H.begin(), H.end(), rows.begin() + jr * 2 * 4096);
+        }
+        PCX_TRY(upload(h->HspecRows, rows));
+        PCX_TRY(upload(h->tw4096, make_tw4096()));
+        h->have_interp_f32 = true;
+    }
     h->have_ols_real64 = false;
-    // (real float32 joins for decimating filters only: its undecimated stream has the float kernel below)
-    // (decimating real float32 filters take the partitioned float kernel, have_upols_decim below)
+    // (real float32 streams have the float kernels: undecimated fir_ols.hip, decimating the partitioned kernel, have_upols_decim below)
     if ((h->scalar == PCX_F64 || h->scalar == PCX_I16 || h->scalar == PCX_I8) && !h->cplx && h->M <= 65535 &&
         h->L == 1 && h->K >= 2 && h->K <= kOls64MaxTaps) {
             std::vector<std::complex<double>> hq(h->K);
@@ -558,14 +580,14 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
                  (h->have_ols64 && h->K >= (h->M > 1 ? 16 : kOls64MinTaps)) ||
                  (h->have_ols_int && h->K >= (h->M > 1 ? 32 : ols_int_min_taps(h->scalar))) ||
                  (h->have_ols_real64 && h->K >= (h->M > 1 ? 16 : ols_real64_min_taps(h->scalar))) ||
-                 ((h->have_interp64 || h->have_interp_real) && h->K >= 16)) algo = PCX_FIR_OLS_FFT;
+                 ((h->have_interp64 || h->have_interp_real || h->have_interp_f32) && h->K >= 16)) algo = PCX_FIR_OLS_FFT;
         // longer than every frequency-domain plan (K > 8193): the sliding-window kernel in the reference's own
         // operation order -- 8k-term float sums accumulate enough rounding that a reordered sum would sit on the 1e-5 bar
         else if (fast) algo = h->K > kOlsMaxTaps ? PCX_FIR_EXACT : PCX_FIR_DIRECT;
         else algo = is_float_scalar(h->scalar) ? PCX_FIR_DIRECT : PCX_FIR_EXACT;
     }
     if (algo == PCX_FIR_OLS_FFT && !((fast && h->have_ols) || h->have_poly || h->have_real_ols || h->have_upols_decim || h->have_upols_rows || h->have_ols64 || h->have_ols_int || h->have_ols_real64 ||
-                                     h->have_interp64 || h->have_interp_real)) {
+                                     h->have_interp64 || h->have_interp_real || h->have_interp_f32)) {
         set_error("fir: OLS_FFT needs complex_float32 or float32 and K<=8193 (interpolating: L<=64 rows) or complex_float64 / complex_int16 / complex_int8 with M=L=1, 2<=K<=4097");
         return PCX_ERR_UNSUPPORTED;
     }
@@ -601,7 +623,12 @@ static int fir_process_dev_impl(pcx_fir *h, const void *in_dev, size_t in_elems,
         }
         return PCX_OK;
     };
-    if (algo == PCX_FIR_OLS_FFT && h->have_interp_real) {
+    if (algo == PCX_FIR_OLS_FFT && h->have_interp_f32) {
+        rc = rows_path(4, h->M, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
+            return launch_fir_f32_ols4096(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HspecRows.p) + jr * 2 * 4096 * sizeof(float), h->K,
+                                          h->tw4096.p, h->sched.p, st);
+        });
+    } else if (algo == PCX_FIR_OLS_FFT && h->have_interp_real) {
         rc = rows_path(fir_elem_bytes(h), h->M, [&](const void *in_b, size_t nb, void *dst, size_t jr) {
             return launch_fir_real_ols(in_b, nb + h->K - 1, dst, nb, static_cast<const char *>(h->HrowsD.p) + jr * 2 * 4096 * sizeof(double), h->K, 12,
                                        h->tw4096.p, h->scalar == PCX_F64 ? 0 : h->scalar == PCX_I16 ? 1 : h->scalar == PCX_I8 ? 2 : 3, 1, qs, st);

@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "abs", "freq_demod", "decim8", "interp4", "fir255_i16", "fir4097", "fir8193"])
+    ap.add_argument("--workload", default="fir255", choices=["fir255", "direct255", "fft4096", "fmchain", "rotate", "abs", "freq_demod", "decim8", "interp4", "fir255_i16", "fir4097", "fir8193", "fir4097_real"])
     ap.add_argument("--shard", type=int, default=SHARD, help="samples per GPU (default 64 Mi)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--driver", default="ranks", choices=["ranks", "native"],
@@ -118,17 +118,17 @@ def _host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline_fir(taps, seed, nsamples, real_taps=False):
+def cpu_baseline_fir(taps, seed, nsamples, real_taps=False, real_stream=False):
     """Single-thread oracle FIR (reference accumulation order) on `nsamples` of the stream, median of 3;
-    beside it the same loop on all host cores, the stream statically chunked with K-1 overlap."""
+    beside it the same loop on all host cores, the stream statically chunked with K-1 overlap (complex streams)."""
     import threading
 
     import numpy as np
 
     from oracle import oracle as o      # CPU baseline leg: the checker, timed as the baseline
     K = len(taps)
-    x = o.fill_uniform_f32(2 * (nsamples + K - 1), seed, 0).reshape(-1, 2)
-    blk = o.Fir(o.F32, True, not real_taps)
+    x = o.fill_uniform_f32(nsamples + K - 1, seed, 0) if real_stream else o.fill_uniform_f32(2 * (nsamples + K - 1), seed, 0).reshape(-1, 2)
+    blk = o.Fir(o.F32, not real_stream, not (real_taps or real_stream))
     blk.set_taps(taps)
     blk.activate()
 
@@ -136,6 +136,10 @@ def cpu_baseline_fir(taps, seed, nsamples, real_taps=False):
         _, c, p, _ = blk.work(x, nsamples)
         assert p == nsamples
     dt = _median_time(one)
+    if real_stream:
+        return {"value": round(nsamples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": "%d-sample slice of the same REAL stream, %d real taps, oracle/pcx_oracle.c fir_loop_f32 (reference accumulation "
+                          "order, -O3, no FMA), single thread, median of 3" % (nsamples, K)}
     # all host cores: thread i filters samples [i*per, (i+1)*per) of the SAME slice (its K-1 history is the
     # tail of chunk i-1: static chunking with overlap) -- a parallelised restatement, not reference behaviour
     ncores = _host_cores()
@@ -701,6 +705,30 @@ def build_workload(wl, C, dev, rank, world, args):
         W.limiter = ("FP64 issue at two waves per SIMD (the 64 KB image of a block caps the occupancy): the arithmetic alone is 0.79 of the launch "
                      "(tools/ip64_parts.sh), and at that occupancy the pipe issues ~380 G wave-instructions/s chip-wide on an add / multiply / "
                      "FMA mix like an FFT's (tools/f64_lab.hip), not the 614 G/s the datasheet's 78.6 TFLOP/s stand for")
+    elif wl == "fir4097_real":
+        # a REAL float32 stream through a 4097-tap real filter: the call's two halves side by side as one complex stream through the
+        # partitioned kernel (fir_ols_part.hip); 4 B read + 4 B written per sample
+        n = C
+        K = 4097
+        h = tp.lowpass(K, 0.1)
+        f = device.FirFilter("float32", "REAL")
+        f.set_taps(h)
+        xa = torch.empty(((n + K - 1 + 1) // 2, 2), dtype=torch.float32, device=dev)
+        device.fill_uniform_f32_dev(xa, seed=9, offset=0)
+        x = xa.view(-1)[:n + K - 1]
+        y = torch.empty((n,), dtype=torch.float32, device=dev)
+        W.units = n
+        W.roof_bytes = 8.0 * n
+        W.read_bytes = 4.0 * n
+        W.kernel_name = "fir_cf32_upols_kernel"
+        W.step = lambda: f.process_dev(x, y)
+        W.inputs = (x,)
+        W.desc = {"workload": "%d-tap float32 FIR (real stream, real taps), two halves of the call as one complex stream through the "
+                              "partitioned kernel, %d samples per GPU" % (K, n), "taps": K}
+        W.metric = "Msamples/s float32 %d-tap FIR" % K
+        W.blocks = -(-n // 4096)
+        W.limiter = ("the complex kernel's transform pair per 4096 real outputs at two waves per SIMD (DESIGN.md 4.8); until the end of round "
+                     "6 this filter ran on the time-domain tile at 5 Gsamples/s")
     elif wl in ("fir4097", "fir8193"):
         # the long-tap plans of the complex_float32 FIR (2049 < K <= 8193): 4096-sample blocks advancing by 2048, the taps in
         # 2 / 4 partitions of 2048 against the spectra of the previous windows (fir_ols_part.hip) -- one transform pair per 2048
@@ -950,6 +978,8 @@ def cpu_baseline_of(wl, C):
     if wl in ("fir4097", "fir8193"):
         K = 4097 if wl == "fir4097" else 8193
         return cpu_baseline_fir(tp.complex_bandpass(K, 0.05, 0.05), 9, 1024 * 1024)
+    if wl == "fir4097_real":
+        return cpu_baseline_fir(tp.lowpass(4097, 0.1), 9, 1024 * 1024, real_stream=True)
     return cpu_baseline_fir_i16(tp.c1_taps() * 0.9, cpu_n // 2)
 
 
@@ -969,6 +999,8 @@ def cpu_baseline_secondary(wl):
     if wl in ("fir4097", "fir8193"):
         K = 4097 if wl == "fir4097" else 8193
         return cpu_baseline_fir(tp.complex_bandpass(K, 0.05, 0.05), 9, (64 if K == 4097 else 32) * 1024)
+    if wl == "fir4097_real":
+        return cpu_baseline_fir(tp.lowpass(4097, 0.1), 9, 128 * 1024, real_stream=True)
     return cpu_baseline_fir_i16(tp.c1_taps() * 0.9, 512 * 1024)
 
 
@@ -1618,7 +1650,7 @@ def main():
             sec["elementwise"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("rotate", "abs", "freq_demod")}
             sec["fir255_i16"] = guarded("fir255_i16", measure_secondary, "fir255_i16", dev, args)
             sec["resamplers"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("decim8", "interp4")}
-            sec["long_taps"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("fir4097", "fir8193")}   # taps in partitions
+            sec["long_taps"] = {w: guarded(w, measure_secondary, w, dev, args) for w in ("fir4097", "fir8193", "fir4097_real")}   # taps in partitions
             # ... configs[3] rehearsed on this one device through the native driver, and the end-to-end number of SURVEY 8d (PCIe inside)
             sec["c3_one_device"] = guarded("c3_one_device", measure_c3_one_device, args, avg_ms)
             sec["host_path"] = guarded("host_path", measure_host_path, args, out.get("cpu_baseline"))

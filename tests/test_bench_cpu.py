@@ -109,7 +109,9 @@ def test_the_committed_default_line_carries_every_single_gpu_config_and_the_host
     for w in list(s["elementwise"].values()) + list(s["resamplers"].values()):
         assert w["roofline"]["bound"] == "hbm" and w["roofline"]["frac"] > 0.4 and w["cpu_baseline"]["kind"] == "port"
     # the long filters on the headline's blocks, the taps in partitions: every input sample fetched once
-    assert set(s["long_taps"]) == {"fir4097", "fir8193"}
+    assert set(s["long_taps"]) == {"fir4097", "fir8193", "fir4097_real"}
+    lr = s["long_taps"]["fir4097_real"]
+    assert lr["roofline"]["kernel"] == "fir_cf32_upols_kernel" and lr["value"] > 300e3 and lr["cpu_baseline"]["kind"] == "port"
     for w, floor in (("fir4097", 0.36), ("fir8193", 0.29)):
         lt = s["long_taps"][w]
         assert lt["roofline"]["kernel"] == "fir_cf32_upols_kernel" and lt["roofline"]["bound"] == "hbm" and lt["roofline"]["frac"] > floor

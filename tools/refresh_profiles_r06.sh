@@ -6,7 +6,7 @@ O=${1:-gpurun_out/r06z}; rm -rf $O; mkdir -p $O
 ulimit -c 0
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> /dev/null
-for w in fft4096 fmchain rotate abs freq_demod direct255 decim8 interp4 fir255_i16 fir4097 fir8193; do python bench.py --workload $w 2>/dev/null | tail -1 >> $O/bench_other_workloads.jsonl; done
+for w in fft4096 fmchain rotate abs freq_demod direct255 decim8 interp4 fir255_i16 fir4097 fir8193 fir4097_real; do python bench.py --workload $w 2>/dev/null | tail -1 >> $O/bench_other_workloads.jsonl; done
 PCX_BENCH_BACKEND=gloo python bench.py --gpus 2 --shard 33554432 --steps 50 --warmup 10 --no-cpu > $O/bench_two_ranks_one_gpu_gloo.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -- python3 bench.py --steps 2000 --warmup 50 --no-cpu --no-secondary > $O/bench_kt.log 2>&1
 bash tools/prof.sh fir255 $O/fir255 ols4096 > /dev/null 2>&1
